@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure; see oracle/laser_oracle.c)."""
+    from oracle import oracle as o
+    o.build()
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def kats():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "laser_kats.json")) as f:
+        return json.load(f)
