@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric: fp32 sgemm GFLOP/s and fraction of the MI355X fp32
+MFMA roofline at M=N=K=8192 (configs[1]), on 1/2/4/8 GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path: C <- A.B through laser_hip's device-resident entry point
+(operands already resident in HBM; the PCIe-inclusive host-pointer rate is reported in DESIGN.md,
+never here).  N = 1: the 8192^3 problem.  N > 1: weak scaling -- every rank owns 8192 rows of an
+(8192 N) x 8192 x 8192 problem (configs[4] at N = 8), row panels dealt block-cyclically, C
+all-gathered over RCCL/xGMI inside the timed region (laser_amd/distributed.py).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the GEMM kernel alone against the dense fp32
+MFMA peak (157.3 TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); `cpu_baseline` is the CPU
+oracle's OpenMP restatement of Laser's algorithm timed on this host's cores on a bounded sample of
+the same workload -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+SIZE = 8192
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def host_info():
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
+
+
+def cpu_baseline(budget_s=15.0):
+    """Laser-style OpenMP CPU path (oracle, kind "port") on a bounded sample of the 8192^3 job:
+    the first `rows` rows of C (full N and K, so packing of B and the kc=512 slicing are the real
+    ones).  Calibrates on 192 rows, then sizes the sample for ~budget_s of CPU work."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    rng = np.random.default_rng(42)
+    n = SIZE
+    B = rng.uniform(-0.1, 0.1, (n, n)).astype(np.float32)
+    A = rng.uniform(-0.1, 0.1, (n, n)).astype(np.float32)
+    threads = oracle.num_threads()
+    isa = oracle.detect_isa(np.float32)
+
+    def run(rows):
+        C = np.zeros((rows, n), dtype=np.float32)
+        t0 = time.perf_counter()
+        oracle.gemm_strided(rows, n, n, 1.0, A, n, 1, B, n, 1, 0.0, C, n, 1, isa=isa)
+        return time.perf_counter() - t0
+
+    run(192)                      # warm-up (page faults, thread pool)
+    t_cal = run(384)
+    rate = 2.0 * 384 * n * n / t_cal
+    rows = int(min(n, max(384, rate * budget_s / (2.0 * n * n))))
+    rows = max(192, rows // 192 * 192) if rows < n else n
+    t = run(rows)
+    gflops = 2.0 * rows * n * n / t / 1e9
+    names = {0: "generic", 1: "sse", 2: "sse2", 3: "sse4.1", 4: "avx", 5: "avx+fma", 6: "avx2", 7: "avx512"}
+    ncpu, model = host_info()
+    log(f"[cpu_baseline] host: {ncpu} logical CPUs, {model}; omp threads {threads}; isa {names.get(isa)}; "
+        f"sample rows={rows} of {n} ({t:.2f} s) -> {gflops:.1f} GFLOP/s")
+    return {"value": round(gflops, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"first {rows} rows of the {n}^3 sgemm (M={rows}, N=K={n}), Laser algorithm restated in C "
+                      f"(oracle/), OpenMP {threads} threads, ukernel {names.get(isa)}, {t:.2f} s; host {model}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["laser_order", "fast"], default=None, help="fp32 accumulation mode (default: library default)")
+    ap.add_argument("--cfg", type=int, default=-1, help="force an f32 tile configuration (-1 = heuristic)")
+    ap.add_argument("--size", type=int, default=SIZE)
+    ap.add_argument("--panels-per-rank", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import laser_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; laser_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    L = laser_amd.lib()
+    laser_amd._lib.check(L.laser_hip_init(local_rank))
+    if args.mode is not None:
+        laser_amd.set_float_mode(0 if args.mode == "laser_order" else 1)
+    laser_amd.set_f32_config(args.cfg)
+    mode = "laser_order" if laser_amd.get_float_mode() == 0 else "fast"
+
+    n = args.size
+    M_total, N, K = n * world, n, n
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    # uniform [-0.1, 0.1) like the reference's bench inputs (gemm_bench_float32.nim:343-344);
+    # random data is mandatory: zero-filled operands run at a higher clock (DVFS) and inflate TF/s
+    B = (torch.rand((K, N), generator=torch.Generator(device=dev).manual_seed(7), device=dev) - 0.5) * 0.2
+    from laser_amd.distributed import ShardedGemm
+    sg = ShardedGemm(M_total, N, K, torch.float32, dev, None, args.panels_per_rank if world > 1 else 1)
+    A_local = (torch.rand((sg.plan.panels_per_rank * sg.plan.rows, K), generator=g, device=dev) - 0.5) * 0.2
+    C = sg.alloc_C()
+
+    def step():
+        sg.run(A_local, B, C)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+
+    # cheap self-check inside the bench: a few rows against an fp64 product on the GPU
+    rows = sg.local_rows()[:8]
+    ref = (A_local[:8].double() @ B.double())
+    err = (C[rows].double() - ref).abs().max().item()
+    assert err < 1e-4, f"bench self-check failed: max abs err {err}"
+
+    if rank == 0:
+        flops_step = 2.0 * M_total * N * K
+        ms_per_step = wall / args.steps * 1e3
+        value = flops_step / (wall / args.steps) / 1e9
+        out = {
+            "metric": "sgemm GFLOP/s (M=N=K=8192 per GPU, fp32, device-resident)",
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": (f"fp32 sgemm M=N=K={n} contiguous row-major, alpha=1 beta=0, 1xMI355X (BASELINE configs[1])"
+                             if world == 1 else
+                             f"fp32 sgemm M={M_total} N={N} K={K} row-panel sharded over {world}xMI355X, "
+                             f"RCCL all-gather of C inside the timed region (BASELINE configs[4] shape at 8 GPUs)"),
+                "M": M_total, "N": N, "K": K, "accumulation": mode,
+                "tile_config": "heuristic" if args.cfg < 0 else laser_amd.f32_configs()[args.cfg],
+                "parallelism": f"row-panels x{world}" + (f", {sg.plan.panels_per_rank} block-cyclic panels/rank" if world > 1 else ""),
+                "pct_of_fp32_mfma_peak": round(100.0 * value / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 2),
+            },
+        }
+        if world == 1:
+            # one step == one launch of the GEMM kernel on torch's current stream, bracketed by HIP
+            # events on that same stream: average launch duration = ev_ms / steps
+            k_ms = ev_ms / args.steps
+            ach = 2.0 * n * n * n / (k_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "kernel": "gemm_f32_mfma_kernel", "kernel_ms": round(k_ms, 4),
+                               "algorithmic_flops_per_launch": 2.0 * n * n * n}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,207 @@
+/* include/laser_hip.h -- C-ABI of liblaser_hip.so, the MI355X (gfx950) implementation of Laser's
+ * packed-panel GEMM hot path, its physical transposes and the im2col->GEMM convolution.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and element strides; no C++/torch types.
+ * Every entry point names the reference proc it replaces (file:line relative to the mratsim/laser
+ * tree).  The Nim side keeps its own signatures and forwards here with
+ *   {.dynlib: "liblaser_hip.so", importc: "laser_hip_...", cdecl.}
+ * (see INTEGRATION.md and nim/laser_hip.nim).  Nim `int` == int64_t on amd64, `float32` == float.
+ *
+ * Conventions
+ *   - Return value: 0 on success, non-zero on failure (LASER_HIP_E_*); the message is available
+ *     from laser_hip_last_error() (thread-local).  The reference procs return void and abort via
+ *     doAssert on precondition violations; the Nim shim turns a non-zero return into doAssert.
+ *   - Strides are in ELEMENTS, element X[r,c] lives at ptr[r*rowStride + c*colStride]
+ *     (gemm_utils.nim:36-60).  Any strides are accepted, including transposed and negative.
+ *   - Host-pointer entry points (no suffix) are synchronous: they stage operands to the GPU, run,
+ *     and copy C back before returning -- exactly Laser's blocking call semantics.  Caller keeps
+ *     ownership of every pointer; the library owns only cached device scratch (freed by
+ *     laser_hip_finalize).
+ *   - `_dev` entry points take DEVICE pointers and a hipStream_t (as void*; NULL = default stream)
+ *     and are asynchronous on that stream: this is the path measured against the roofline.
+ *   - Semantics preserved from the reference: beta == 0 never reads C (NaN / uninitialised safe,
+ *     gemm_ukernel_generic.nim:53-76); K == 0 leaves C untouched even if beta != 1 (gemm.nim:150);
+ *     alpha, beta have the element type (integers too); overlapping A/B/C is undefined.
+ *   - fp32 arithmetic order (LASER_HIP_F32_LASER_ORDER, the default): for every C[i,j] an
+ *     ascending-k fused-multiply-add chain restarted from +0 every kc = 512 values of k, the slice
+ *     sums added into beta*C in ascending order -- bit-identical to Laser on an FMA host
+ *     (gemm_ukernel_generator.nim:245-248, gemm.nim:150-158, gemm_tiling.nim:309-310).
+ *     LASER_HIP_F32_FAST keeps one chain across all of K (within 1e-5 relative, not bit-equal
+ *     for K > 512).  f64 follows the same rule with kc = 256.
+ */
+#ifndef LASER_HIP_H
+#define LASER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LASER_HIP_OK 0
+#define LASER_HIP_E_INVALID 1   /* bad argument (negative size, null pointer, misaligned pre-pack buffer ...) */
+#define LASER_HIP_E_HIP 2       /* a HIP runtime call failed; see laser_hip_last_error() */
+#define LASER_HIP_E_NODEVICE 3  /* no gfx950 device / library built without device code for this GPU */
+#define LASER_HIP_E_HANDLE 4    /* pre-packed buffer handle is stale or corrupt */
+
+/* ---- lifecycle ----------------------------------------------------------------------------- */
+/* Lazy-initialised on first use; explicit init selects the device (-1 = current device). */
+int laser_hip_init(int device);
+int laser_hip_finalize(void);
+const char *laser_hip_last_error(void);
+const char *laser_hip_version(void);
+int laser_hip_device_count(void);
+/* Name of the GPU architecture in use, e.g. "gfx950" (replaces the reference's cpuinfo ISA
+ * dispatch, gemm.nim:228-247). */
+const char *laser_hip_arch(void);
+
+#define LASER_HIP_F32_LASER_ORDER 0
+#define LASER_HIP_F32_FAST 1
+int laser_hip_set_float_mode(int mode);
+int laser_hip_get_float_mode(void);
+/* Force one tile configuration of the f32 MFMA kernel (-1 = heuristic).  For tuning/benchmarks. */
+int laser_hip_set_f32_config(int cfg);
+int laser_hip_f32_config_count(void);
+const char *laser_hip_f32_config_name(int cfg);
+
+/* ---- gemm_strided -- laser/primitives/matrix_multiplication/gemm.nim:184-193 ------------------
+ * proc gemm_strided*[T: SomeNumber](M, N, K: int, alpha: T, A: ptr T, rowStrideA, colStrideA: int,
+ *        B: ptr T, rowStrideB, colStrideB: int, beta: T, C: ptr T, rowStrideC, colStrideC: int) */
+#define LASER_HIP_DECL_GEMM(SFX, T)                                                               \
+  int laser_hip_gemm_strided_##SFX(int64_t M, int64_t N, int64_t K, T alpha, const T *A,          \
+                                   int64_t rowStrideA, int64_t colStrideA, const T *B,            \
+                                   int64_t rowStrideB, int64_t colStrideB, T beta, T *C,          \
+                                   int64_t rowStrideC, int64_t colStrideC);                       \
+  int laser_hip_gemm_strided_##SFX##_dev(int64_t M, int64_t N, int64_t K, T alpha, const T *dA,   \
+                                         int64_t rowStrideA, int64_t colStrideA, const T *dB,     \
+                                         int64_t rowStrideB, int64_t colStrideB, T beta, T *dC,   \
+                                         int64_t rowStrideC, int64_t colStrideC, void *stream);   \
+  /* `batch` independent problems; operand b starts at ptr + b*batchStrideX (elements; 0 shares). \
+   * Used by the convolution (one GEMM per image, conv2d_im2col.nim:126-166). */                  \
+  int laser_hip_gemm_strided_batched_##SFX##_dev(                                                 \
+      int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, const T *dA, int64_t rowStrideA,   \
+      int64_t colStrideA, int64_t batchStrideA, const T *dB, int64_t rowStrideB,                  \
+      int64_t colStrideB, int64_t batchStrideB, T beta, T *dC, int64_t rowStrideC,                \
+      int64_t colStrideC, int64_t batchStrideC, void *stream);
+LASER_HIP_DECL_GEMM(f32, float)
+LASER_HIP_DECL_GEMM(f64, double)
+LASER_HIP_DECL_GEMM(i32, int32_t)
+LASER_HIP_DECL_GEMM(i64, int64_t)
+#undef LASER_HIP_DECL_GEMM
+
+/* ---- pre-packed GEMM -- gemm_prepacked.nim:63-292 ----------------------------------------------
+ * gemm_prepackB_mem_required*(T, M, N, K): int            :76-85
+ * gemm_prepackB*[T](dst_packedB, M, N, K, src_B, rowStrideB, colStrideB)   :111-135
+ * gemm_prepackA_mem_required*, gemm_prepackA*             :157-218
+ * gemm_packed*[T](M, N, K, alpha, packedA, packedB, beta, C, rowStrideC, colStrideC)  :275-292
+ *
+ * As in the reference the packed buffers are opaque, machine dependent and "unsafe to store or
+ * serialize" (:120-123).  Host variant: the caller allocates `mem_required` bytes, 64-B aligned
+ * (same doAssert as :125/:208 -> LASER_HIP_E_INVALID); the library uploads the operand ONCE into
+ * a tile-padded device-resident panel image and writes a handle into the first 64 bytes of dst.
+ * Device memory is released by laser_hip_gemm_prepack_release(dst) or laser_hip_finalize().
+ * `_dev` variant: dst is a DEVICE buffer of `mem_required` bytes that receives the padded panel
+ * image itself (no handle, nothing to release).  Unlike the reference (whose prepackA indexing is
+ * only right for K <= kc, :186/:265) these are valid for every K. */
+#define LASER_HIP_DECL_PACK(SFX, T)                                                               \
+  int64_t laser_hip_gemm_prepackA_mem_required_##SFX(int64_t M, int64_t N, int64_t K);            \
+  int64_t laser_hip_gemm_prepackB_mem_required_##SFX(int64_t M, int64_t N, int64_t K);            \
+  int laser_hip_gemm_prepackA_##SFX(void *dst_packedA, int64_t M, int64_t N, int64_t K,           \
+                                    const T *src_A, int64_t rowStrideA, int64_t colStrideA);      \
+  int laser_hip_gemm_prepackB_##SFX(void *dst_packedB, int64_t M, int64_t N, int64_t K,           \
+                                    const T *src_B, int64_t rowStrideB, int64_t colStrideB);      \
+  int laser_hip_gemm_packed_##SFX(int64_t M, int64_t N, int64_t K, T alpha, const void *packedA,  \
+                                  const void *packedB, T beta, T *C, int64_t rowStrideC,          \
+                                  int64_t colStrideC);                                            \
+  int laser_hip_gemm_prepackA_##SFX##_dev(void *d_dst, int64_t M, int64_t N, int64_t K,           \
+                                          const T *dA, int64_t rowStrideA, int64_t colStrideA,    \
+                                          void *stream);                                          \
+  int laser_hip_gemm_prepackB_##SFX##_dev(void *d_dst, int64_t M, int64_t N, int64_t K,           \
+                                          const T *dB, int64_t rowStrideB, int64_t colStrideB,    \
+                                          void *stream);                                          \
+  int laser_hip_gemm_packed_##SFX##_dev(int64_t M, int64_t N, int64_t K, T alpha,                 \
+                                        const void *d_packedA, const void *d_packedB, T beta,     \
+                                        T *dC, int64_t rowStrideC, int64_t colStrideC,            \
+                                        void *stream);
+LASER_HIP_DECL_PACK(f32, float)
+LASER_HIP_DECL_PACK(f64, double)
+LASER_HIP_DECL_PACK(i32, int32_t)
+LASER_HIP_DECL_PACK(i64, int64_t)
+#undef LASER_HIP_DECL_PACK
+int laser_hip_gemm_prepack_release(void *packed);
+
+/* ---- physical transposes -- laser/primitives/swapaxes.nim:16-112 --------------------------------
+ * transpose2D_copy*[T](dst, src, NR, NC)        :16-54   dst[j][i] = src[i][j]
+ * transpose2D_batched*[T](dst, src, N, NR, NC)  :56-84
+ * nchw2nhwc*[T](dst, src, N, C, H, W)           :86-98   = transpose2D_batched(N, C, H*W)
+ * nhwc2nchw*[T](dst, src, N, C, H, W)           :100-112 = transpose2D_batched(N, H*W, C)
+ * Pure data movement: one entry point per element size (b32: float32/int32, b64: float64/int64). */
+#define LASER_HIP_DECL_TR(SFX)                                                                    \
+  int laser_hip_transpose2d_copy_##SFX(void *dst, const void *src, int64_t NR, int64_t NC);       \
+  int laser_hip_transpose2d_batched_##SFX(void *dst, const void *src, int64_t N, int64_t NR,      \
+                                          int64_t NC);                                            \
+  int laser_hip_nchw2nhwc_##SFX(void *dst, const void *src, int64_t N, int64_t C, int64_t H,      \
+                                int64_t W);                                                       \
+  int laser_hip_nhwc2nchw_##SFX(void *dst, const void *src, int64_t N, int64_t C, int64_t H,      \
+                                int64_t W);                                                       \
+  int laser_hip_transpose2d_batched_##SFX##_dev(void *d_dst, const void *d_src, int64_t N,        \
+                                                int64_t NR, int64_t NC, void *stream);
+LASER_HIP_DECL_TR(b32)
+LASER_HIP_DECL_TR(b64)
+#undef LASER_HIP_DECL_TR
+
+/* ---- im2col + GEMM convolution -- benchmarks/convolution/conv2d_im2col.nim -----------------------
+ * TensorShape = (n, c, h, w), KernelShape = (c_out, c_in, kH, kW), Padding = (h, w),
+ * Strides = (h, w) (conv2d_common.nim:6-13) are passed as separate scalars.
+ * conv2d_out_shape                           conv2d_common.nim:15-45
+ * im2col_workspace_size*(ishape, kshape, padding, strides): int      conv2d_im2col.nim:10-20
+ * im2col*[T](pworkspace, oshape, pinput, ishape, kshape, padding, strides)     :42-88
+ * conv2d_im2col*(output, oshape, input, ishape, kernel, kshape, padding, strides, pworkspace) :90-166 */
+int laser_hip_conv2d_out_shape(int64_t iN, int64_t iC, int64_t iH, int64_t iW, int64_t c_out,
+                               int64_t c_in, int64_t kH, int64_t kW, int64_t padH, int64_t padW,
+                               int64_t strideH, int64_t strideW, int64_t *oN, int64_t *oC,
+                               int64_t *oH, int64_t *oW);
+/* number of ELEMENTS, like the reference */
+int64_t laser_hip_im2col_workspace_size(int64_t iN, int64_t iC, int64_t iH, int64_t iW,
+                                        int64_t c_out, int64_t c_in, int64_t kH, int64_t kW,
+                                        int64_t padH, int64_t padW, int64_t strideH,
+                                        int64_t strideW);
+/* One image [iC, iH, iW] -> workspace [iC*kH*kW, oH*oW]. */
+int laser_hip_im2col_f32(float *pworkspace, int64_t oH, int64_t oW, const float *pinput, int64_t iC,
+                         int64_t iH, int64_t iW, int64_t kH, int64_t kW, int64_t padH, int64_t padW,
+                         int64_t strideH, int64_t strideW);
+int laser_hip_im2col_f32_dev(float *d_workspace, int64_t oH, int64_t oW, const float *d_input,
+                             int64_t batch, int64_t iC, int64_t iH, int64_t iW, int64_t kH,
+                             int64_t kW, int64_t padH, int64_t padW, int64_t strideH,
+                             int64_t strideW, void *stream);
+/* output [iN, c_out, oH, oW] = conv(input [iN, iC, iH, iW], kernel [c_out, c_in, kH, kW]).
+ * `pworkspace` (host variant) may be NULL: the scratch lives on the device; if non-NULL it must
+ * hold im2col_workspace_size elements and receives the last image's im2col matrix, as in the
+ * reference.  LASER_HIP_E_INVALID if c_in != iC (the reference asserts oshape.c == kshape.c_out,
+ * :109, and conv2d_required_ops doAsserts C_in == kernel.c_in, conv2d_common.nim:66). */
+int laser_hip_conv2d_im2col_f32(float *output, const float *input, int64_t iN, int64_t iC,
+                                int64_t iH, int64_t iW, const float *kernel, int64_t c_out,
+                                int64_t c_in, int64_t kH, int64_t kW, int64_t padH, int64_t padW,
+                                int64_t strideH, int64_t strideW, float *pworkspace);
+/* Device variant: d_workspace must hold iN * im2col_workspace_size elements (all images are
+ * expanded at once and multiplied by one batched GEMM), or may be NULL to use library scratch. */
+int laser_hip_conv2d_im2col_f32_dev(float *d_output, const float *d_input, int64_t iN, int64_t iC,
+                                    int64_t iH, int64_t iW, const float *d_kernel, int64_t c_out,
+                                    int64_t c_in, int64_t kH, int64_t kW, int64_t padH,
+                                    int64_t padW, int64_t strideH, int64_t strideW,
+                                    float *d_workspace, void *stream);
+
+/* ---- cblas-shaped GEMM -- benchmarks/third_party/blas.nim:12-23 ---------------------------------
+ * The call conv2d_im2col makes (conv2d_im2col.nim:161-166); ORDER 101 rowMajor / 102 colMajor,
+ * TRANS 111 noTranspose / 112 transpose / 113 conjTranspose.  Mapped onto gemm_strided strides. */
+int laser_hip_cblas_sgemm(int order, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                          float alpha, const float *A, int64_t lda, const float *B, int64_t ldb,
+                          float beta, float *C, int64_t ldc);
+int laser_hip_cblas_dgemm(int order, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                          double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
+                          double beta, double *C, int64_t ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASER_HIP_H */

@@ -1,0 +1,10 @@
+"""laser_amd -- MI355X (gfx950) implementation of mratsim/laser's packed-panel GEMM hot path.
+
+The product is liblaser_hip.so (hand-written HIP behind the C-ABI of include/laser_hip.h); this
+package is the thin host-side mirror of the reference's Nim procs over that ABI.  No CPU fallback.
+"""
+from ._lib import LaserHipError, LIB_PATH, lib  # noqa: F401
+from .primitives import *  # noqa: F401,F403
+from . import primitives  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,671 @@
+// laser_amd/csrc/capi.cpp -- the extern "C" boundary of liblaser_hip.so (include/laser_hip.h).
+//
+// Host-pointer entry points reproduce Laser's blocking call semantics (caller owns every pointer,
+// the call returns when C is final); `_dev` entry points are the device-resident, stream-ordered
+// path that benchmarks and multi-GPU code use.  No CPU compute fallback exists anywhere in this
+// library: without a usable gfx950 device every compute entry point returns LASER_HIP_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/laser_hip.h"
+#include "common.h"
+
+using namespace laser_hip;
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;  // serialises the host-pointer paths (shared scratch) and the handle registry
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(LASER_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  std::string arch;
+  int float_mode = LASER_HIP_F32_LASER_ORDER;
+  int f32_cfg = -1;
+  // cached device scratch for the host-pointer paths, one growing buffer per role
+  void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[6] = {0, 0, 0, 0, 0, 0};
+};
+Context g_ctx;
+
+int ensure_init_locked(int device) {
+  if (g_ctx.ready && (device < 0 || device == g_ctx.device)) return LASER_HIP_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(LASER_HIP_E_NODEVICE, "no HIP device available (%s)",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0) {
+    HIP_TRY(hipGetDevice(&device));
+  } else {
+    if (device >= n) return fail(LASER_HIP_E_INVALID, "device %d out of range (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+  }
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  std::string arch = prop.gcnArchName;
+  // gcnArchName looks like "gfx950:sramecc+:xnack-"; this library carries gfx950 code objects only
+  if (arch.rfind("gfx950", 0) != 0)
+    return fail(LASER_HIP_E_NODEVICE, "device %d is %s; liblaser_hip is built for gfx950 (MI355X) only",
+                device, arch.c_str());
+  g_ctx.arch = arch.substr(0, arch.find(':'));
+  g_ctx.device = device;
+  g_ctx.ready = true;
+  return LASER_HIP_OK;
+}
+
+int ensure_init() {
+  if (g_ctx.ready) return LASER_HIP_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return ensure_init_locked(-1);
+}
+
+int scratch_get(int slot, size_t bytes, void **out) {
+  if (bytes == 0) bytes = 16;
+  if (g_ctx.scratch_sz[slot] < bytes) {
+    if (g_ctx.scratch[slot]) HIP_TRY(hipFree(g_ctx.scratch[slot]));
+    g_ctx.scratch[slot] = nullptr;
+    g_ctx.scratch_sz[slot] = 0;
+    size_t want = bytes + bytes / 8;  // a little headroom so slowly growing sizes do not thrash
+    HIP_TRY(hipMalloc(&g_ctx.scratch[slot], want));
+    g_ctx.scratch_sz[slot] = want;
+  }
+  *out = g_ctx.scratch[slot];
+  return LASER_HIP_OK;
+}
+
+// Lowest / highest element offset touched by an R x C strided view (strides may be negative).
+void view_span(int64_t R, int64_t C, int64_t rs, int64_t cs, int64_t *lo, int64_t *hi) {
+  const int64_t r = (R - 1) * rs, c = (C - 1) * cs;
+  *lo = std::min<int64_t>(0, r) + std::min<int64_t>(0, c);
+  *hi = std::max<int64_t>(0, r) + std::max<int64_t>(0, c);
+}
+
+template <typename T>
+hipError_t run_gemm(const GemmArgs<T> &a, hipStream_t s);
+template <>
+hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
+  return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+}
+template <>
+hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
+  return launch_gemm_valu<double>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+}
+template <>
+hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
+  return launch_gemm_valu<int32_t>(a, false, s);
+}
+template <>
+hipError_t run_gemm<int64_t>(const GemmArgs<int64_t> &a, hipStream_t s) {
+  return launch_gemm_valu<int64_t>(a, false, s);
+}
+
+template <typename T>
+GemmArgs<T> make_args(int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
+                      int64_t csA, int64_t bsA, const T *B, int64_t rsB, int64_t csB, int64_t bsB, T beta,
+                      T *C, int64_t rsC, int64_t csC, int64_t bsC) {
+  GemmArgs<T> a;
+  memset(&a, 0, sizeof a);
+  a.M = M; a.N = N; a.K = K;
+  a.alpha = alpha; a.beta = beta;
+  a.A = A; a.rsA = rsA; a.csA = csA; a.bsA = bsA;
+  a.B = B; a.rsB = rsB; a.csB = csB; a.bsB = bsB;
+  a.C = C; a.rsC = rsC; a.csC = csC; a.bsC = bsC;
+  a.Mext = M; a.Next = N; a.Kext = K;
+  a.batch = (int32_t)batch;
+  return a;
+}
+
+template <typename T>
+int gemm_dev(int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA,
+             int64_t bsA, const T *B, int64_t rsB, int64_t csB, int64_t bsB, T beta, T *C, int64_t rsC,
+             int64_t csC, int64_t bsC, void *stream) {
+  if (M < 0 || N < 0 || K < 0 || batch < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = ensure_init()) return rc;
+  // K == 0: the reference's pc loop never runs, C is left untouched even if beta != 1 (gemm.nim:150)
+  if (M == 0 || N == 0 || K == 0 || batch == 0) return LASER_HIP_OK;
+  if (!A || !B || !C) return fail(LASER_HIP_E_INVALID, "null operand pointer");
+  if (batch > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
+  GemmArgs<T> a = make_args<T>(batch, M, N, K, alpha, A, rsA, csA, bsA, B, rsB, csB, bsB, beta, C, rsC, csC, bsC);
+  HIP_TRY(run_gemm<T>(a, (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
+
+// Host-pointer gemm_strided: stage the touched span of each operand, run, copy the C span back.
+template <typename T>
+int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *B,
+              int64_t rsB, int64_t csB, T beta, T *C, int64_t rsC, int64_t csC) {
+  if (M < 0 || N < 0 || K < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = ensure_init()) return rc;
+  if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
+  if (!A || !B || !C) return fail(LASER_HIP_E_INVALID, "null operand pointer");
+  std::lock_guard<std::mutex> lk(g_mu);
+  int64_t alo, ahi, blo, bhi, clo, chi;
+  view_span(M, K, rsA, csA, &alo, &ahi);
+  view_span(K, N, rsB, csB, &blo, &bhi);
+  view_span(M, N, rsC, csC, &clo, &chi);
+  const size_t an = (size_t)(ahi - alo + 1), bn = (size_t)(bhi - blo + 1), cn = (size_t)(chi - clo + 1);
+  void *dA, *dB, *dC;
+  if (int rc = scratch_get(0, an * sizeof(T), &dA)) return rc;
+  if (int rc = scratch_get(1, bn * sizeof(T), &dB)) return rc;
+  if (int rc = scratch_get(2, cn * sizeof(T), &dC)) return rc;
+  HIP_TRY(hipMemcpy(dA, A + alo, an * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dB, B + blo, bn * sizeof(T), hipMemcpyHostToDevice));
+  // C must be uploaded when it is read (beta != 0) or when its span has gaps that belong to the
+  // caller (so the copy-back restores them unchanged).  A dense C with beta == 0 is write-only.
+  const bool c_dense = (cn == (size_t)M * (size_t)N);
+  if (beta != (T)0 || !c_dense) HIP_TRY(hipMemcpy(dC, C + clo, cn * sizeof(T), hipMemcpyHostToDevice));
+  GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, (const T *)dA - alo, rsA, csA, 0, (const T *)dB - blo, rsB,
+                               csB, 0, beta, (T *)dC - clo, rsC, csC, 0);
+  HIP_TRY(run_gemm<T>(a, nullptr));
+  HIP_TRY(hipMemcpy(C + clo, dC, cn * sizeof(T), hipMemcpyDeviceToHost));  // synchronises
+  return LASER_HIP_OK;
+}
+
+// ---- pre-pack ------------------------------------------------------------------------------------
+// Panel image = dense row-major copy, zero-padded so every tile configuration is "full":
+// rows of A / cols of B to a multiple of 256, k to a multiple of 32.
+constexpr int64_t kPadMN = 256, kPadK = 32;
+inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+constexpr uint64_t kMagic = 0x4c41534552484950ull;  // "LASERHIP"
+struct PackHandle {  // lives in the first 64 bytes of the caller's (64-B aligned) host buffer
+  uint64_t magic, self, id;
+  int64_t M, N, K;
+  int32_t is_a, elem;
+};
+static_assert(sizeof(PackHandle) <= 64, "handle must fit the alignment unit");
+struct DevPanel {
+  void *ptr;
+  size_t bytes;
+};
+std::unordered_map<uint64_t, DevPanel> g_panels;
+uint64_t g_next_id = 1;
+
+template <typename T>
+int64_t prepack_bytes(bool is_a, int64_t M, int64_t N, int64_t K) {
+  if (M < 0 || N < 0 || K < 0) return 0;
+  const int64_t x = is_a ? rup(M, kPadMN) : rup(N, kPadMN);
+  const int64_t b = (int64_t)sizeof(T) * x * rup(K, kPadK);
+  return std::max<int64_t>(b, 64);
+}
+
+template <typename T>
+int prepack_dev(bool is_a, void *d_dst, int64_t M, int64_t N, int64_t K, const T *src, int64_t rs, int64_t cs,
+                void *stream) {
+  if (int rc = ensure_init()) return rc;
+  if (!d_dst || !src) return fail(LASER_HIP_E_INVALID, "null pointer");
+  if (is_a)  // A image: [Mpad][Kpad], k contiguous
+    HIP_TRY(launch_pack_pad<T>((T *)d_dst, rup(M, kPadMN), rup(K, kPadK), src, M, K, rs, cs, (hipStream_t)stream));
+  else       // B image: [Kpad][Npad], n contiguous
+    HIP_TRY(launch_pack_pad<T>((T *)d_dst, rup(K, kPadK), rup(N, kPadMN), src, K, N, rs, cs, (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
+
+template <typename T>
+int prepack_host(bool is_a, void *dst, int64_t M, int64_t N, int64_t K, const T *src, int64_t rs, int64_t cs) {
+  if (!dst || !src) return fail(LASER_HIP_E_INVALID, "null pointer");
+  // same precondition as the reference's doAssert (gemm_prepacked.nim:125, :208)
+  if ((reinterpret_cast<uintptr_t>(dst) & 63) != 0)
+    return fail(LASER_HIP_E_INVALID, "The destination pointer must be 64-byte aligned");
+  if (M < 0 || N < 0 || K < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = ensure_init()) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int64_t R = is_a ? M : K, Cc = is_a ? K : N;
+  int64_t lo, hi;
+  view_span(std::max<int64_t>(R, 1), std::max<int64_t>(Cc, 1), rs, cs, &lo, &hi);
+  const size_t n = (size_t)(hi - lo + 1);
+  void *dsrc;
+  if (int rc = scratch_get(3, n * sizeof(T), &dsrc)) return rc;
+  if (R > 0 && Cc > 0) HIP_TRY(hipMemcpy(dsrc, src + lo, n * sizeof(T), hipMemcpyHostToDevice));
+  DevPanel p;
+  p.bytes = (size_t)prepack_bytes<T>(is_a, M, N, K);
+  HIP_TRY(hipMalloc(&p.ptr, p.bytes));
+  if (is_a)
+    HIP_TRY(launch_pack_pad<T>((T *)p.ptr, rup(M, kPadMN), rup(K, kPadK), (const T *)dsrc - lo, M, K, rs, cs, nullptr));
+  else
+    HIP_TRY(launch_pack_pad<T>((T *)p.ptr, rup(K, kPadK), rup(N, kPadMN), (const T *)dsrc - lo, K, N, rs, cs, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  PackHandle h;
+  memset(&h, 0, sizeof h);
+  h.magic = kMagic;
+  h.self = reinterpret_cast<uint64_t>(dst);
+  h.id = g_next_id++;
+  h.M = M; h.N = N; h.K = K;
+  h.is_a = is_a ? 1 : 0;
+  h.elem = (int32_t)sizeof(T);
+  // re-packing into a buffer that still holds a live handle releases the old panel first
+  PackHandle old;
+  memcpy(&old, dst, sizeof old);
+  if (old.magic == kMagic && old.self == h.self) {
+    auto it = g_panels.find(old.id);
+    if (it != g_panels.end()) {
+      (void)hipFree(it->second.ptr);
+      g_panels.erase(it);
+    }
+  }
+  memcpy(dst, &h, sizeof h);
+  g_panels[h.id] = p;
+  return LASER_HIP_OK;
+}
+
+int resolve_handle(const void *packed, bool want_a, int elem, int64_t M, int64_t N, int64_t K, void **dptr) {
+  if (!packed) return fail(LASER_HIP_E_INVALID, "null packed buffer");
+  PackHandle h;
+  memcpy(&h, packed, sizeof h);
+  if (h.magic != kMagic || h.self != reinterpret_cast<uint64_t>(packed))
+    return fail(LASER_HIP_E_HANDLE, "buffer does not hold a live pre-pack handle (copied or never packed)");
+  if ((h.is_a != 0) != want_a || h.elem != elem)
+    return fail(LASER_HIP_E_HANDLE, "pre-pack handle is for another operand / element type");
+  if (want_a ? (h.M != M || h.K != K) : (h.N != N || h.K != K))
+    return fail(LASER_HIP_E_HANDLE, "pre-pack handle was made for a different shape");
+  auto it = g_panels.find(h.id);
+  if (it == g_panels.end()) return fail(LASER_HIP_E_HANDLE, "pre-pack handle was released");
+  *dptr = it->second.ptr;
+  return LASER_HIP_OK;
+}
+
+template <typename T>
+GemmArgs<T> packed_args(int64_t M, int64_t N, int64_t K, T alpha, const void *dA, const void *dB, T beta, T *dC,
+                        int64_t rsC, int64_t csC) {
+  GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, (const T *)dA, rup(K, kPadK), 1, 0, (const T *)dB,
+                               rup(N, kPadMN), 1, 0, beta, dC, rsC, csC, 0);
+  a.Mext = rup(M, kPadMN);
+  a.Next = rup(N, kPadMN);
+  a.Kext = rup(K, kPadK);
+  return a;
+}
+
+template <typename T>
+int packed_dev(int64_t M, int64_t N, int64_t K, T alpha, const void *dA, const void *dB, T beta, T *dC,
+               int64_t rsC, int64_t csC, void *stream) {
+  if (M < 0 || N < 0 || K < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = ensure_init()) return rc;
+  if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
+  if (!dA || !dB || !dC) return fail(LASER_HIP_E_INVALID, "null pointer");
+  HIP_TRY(run_gemm<T>(packed_args<T>(M, N, K, alpha, dA, dB, beta, dC, rsC, csC), (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
+
+template <typename T>
+int packed_host(int64_t M, int64_t N, int64_t K, T alpha, const void *pA, const void *pB, T beta, T *C,
+                int64_t rsC, int64_t csC) {
+  if (M < 0 || N < 0 || K < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = ensure_init()) return rc;
+  if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
+  if (!C) return fail(LASER_HIP_E_INVALID, "null pointer");
+  std::lock_guard<std::mutex> lk(g_mu);
+  void *dA, *dB, *dC;
+  if (int rc = resolve_handle(pA, true, (int)sizeof(T), M, N, K, &dA)) return rc;
+  if (int rc = resolve_handle(pB, false, (int)sizeof(T), M, N, K, &dB)) return rc;
+  int64_t clo, chi;
+  view_span(M, N, rsC, csC, &clo, &chi);
+  const size_t cn = (size_t)(chi - clo + 1);
+  if (int rc = scratch_get(2, cn * sizeof(T), &dC)) return rc;
+  if (beta != (T)0 || cn != (size_t)M * (size_t)N)
+    HIP_TRY(hipMemcpy(dC, C + clo, cn * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(run_gemm<T>(packed_args<T>(M, N, K, alpha, dA, dB, beta, (T *)dC - clo, rsC, csC), nullptr));
+  HIP_TRY(hipMemcpy(C + clo, dC, cn * sizeof(T), hipMemcpyDeviceToHost));
+  return LASER_HIP_OK;
+}
+
+// ---- transposes ------------------------------------------------------------------------------------
+int transpose_host(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, int elem) {
+  if (N < 0 || NR < 0 || NC < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = ensure_init()) return rc;
+  const size_t bytes = (size_t)N * NR * NC * elem;
+  if (bytes == 0) return LASER_HIP_OK;
+  if (!dst || !src) return fail(LASER_HIP_E_INVALID, "null pointer");
+  std::lock_guard<std::mutex> lk(g_mu);
+  void *ds, *dd;
+  if (int rc = scratch_get(0, bytes, &ds)) return rc;
+  if (int rc = scratch_get(2, bytes, &dd)) return rc;
+  HIP_TRY(hipMemcpy(ds, src, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(launch_transpose_batched(dd, ds, N, NR, NC, elem, nullptr));
+  HIP_TRY(hipMemcpy(dst, dd, bytes, hipMemcpyDeviceToHost));
+  return LASER_HIP_OK;
+}
+
+// ---- convolution -------------------------------------------------------------------------------------
+void out_hw(int64_t iH, int64_t iW, int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW,
+            int64_t *oH, int64_t *oW) {
+  // conv2d_common.nim:43-44 with dilation 1
+  *oH = 1 + (iH + 2 * pH - kH) / sH;
+  *oW = 1 + (iW + 2 * pW - kW) / sW;
+}
+
+int conv_check(int64_t iN, int64_t iC, int64_t iH, int64_t iW, int64_t c_out, int64_t c_in, int64_t kH, int64_t kW,
+               int64_t pH, int64_t pW, int64_t sH, int64_t sW) {
+  if (iN < 0 || iC <= 0 || iH <= 0 || iW <= 0 || c_out <= 0 || kH <= 0 || kW <= 0 || pH < 0 || pW < 0)
+    return fail(LASER_HIP_E_INVALID, "bad convolution shape");
+  if (c_in != iC) return fail(LASER_HIP_E_INVALID, "kernel c_in (%lld) != input channels (%lld)", (long long)c_in, (long long)iC);
+  // conv2d_common.nim:33-34: doAssert 0 < sH and sH < iH (same for W)
+  if (!(0 < sH && sH < iH && 0 < sW && sW < iW)) return fail(LASER_HIP_E_INVALID, "strides must satisfy 0 < s < input size");
+  if (iH + 2 * pH < kH || iW + 2 * pW < kW) return fail(LASER_HIP_E_INVALID, "kernel larger than padded input");
+  return LASER_HIP_OK;
+}
+
+int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, int64_t iW, const float *dker,
+             int64_t c_out, int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
+             hipStream_t s) {
+  int64_t oH, oW;
+  out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
+  const int64_t M = c_out, K = iC * kH * kW, N = oH * oW;
+  // 1x1 shortcut (conv2d_im2col.nim:121,128,151-153): the input already is the [K, N] matrix --
+  // taken only for stride 1 / no padding, where that is actually true.
+  const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
+  const float *Bm = din;
+  int64_t bsB = iC * iH * iW;
+  if (!direct) {
+    HIP_TRY(launch_im2col_f32(dws, oH, oW, din, iN, iC, iH, iW, kH, kW, pH, pW, sH, sW, s));
+    Bm = dws;
+    bsB = K * N;
+  }
+  // O[n] (M x N) = F (M x K) . W[n] (K x N), alpha = 1, beta = 0 (conv2d_im2col.nim:104-105,161-166);
+  // all images in ONE batched launch: A = filter shared by every image (batch stride 0)
+  GemmArgs<float> a = make_args<float>(iN, M, N, K, 1.0f, dker, K, 1, 0, Bm, N, 1, bsB, 0.0f, dout, N, 1, M * N);
+  HIP_TRY(run_gemm<float>(a, s));
+  return LASER_HIP_OK;
+}
+
+// cblas enums: benchmarks/third_party/blas.nim:12-16
+template <typename T>
+int cblas_gemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t lda,
+                      const T *B, int64_t ldb, T beta, T *C, int64_t ldc) {
+  if ((order != 101 && order != 102) || tA < 111 || tA > 113 || tB < 111 || tB > 113)
+    return fail(LASER_HIP_E_INVALID, "bad cblas order/transpose enum");
+  const bool rowm = order == 101;
+  // op(X)[r,c]: row-major no-trans -> (ld,1); row-major trans -> (1,ld); col-major swaps them
+  auto strides = [&](bool trans, int64_t ld, int64_t *rs, int64_t *cs) {
+    const bool r_contig_c = rowm != trans;  // element [r, c+1] adjacent
+    *rs = r_contig_c ? ld : 1;
+    *cs = r_contig_c ? 1 : ld;
+  };
+  int64_t rsA, csA, rsB, csB;
+  strides(tA != 111, lda, &rsA, &csA);
+  strides(tB != 111, ldb, &rsB, &csB);
+  const int64_t rsC = rowm ? ldc : 1, csC = rowm ? 1 : ldc;
+  return gemm_host<T>(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, C, rsC, csC);
+}
+
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int laser_hip_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return ensure_init_locked(device);
+}
+
+int laser_hip_finalize(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < 6; i++) {
+    if (g_ctx.scratch[i]) (void)hipFree(g_ctx.scratch[i]);
+    g_ctx.scratch[i] = nullptr;
+    g_ctx.scratch_sz[i] = 0;
+  }
+  for (auto &kv : g_panels) (void)hipFree(kv.second.ptr);
+  g_panels.clear();
+  g_ctx.ready = false;
+  return LASER_HIP_OK;
+}
+
+const char *laser_hip_last_error(void) { return g_err.c_str(); }
+const char *laser_hip_version(void) { return "laser_hip 0.1.0 (gfx950)"; }
+int laser_hip_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+const char *laser_hip_arch(void) {
+  if (ensure_init()) return "";
+  return g_ctx.arch.c_str();
+}
+
+int laser_hip_set_float_mode(int mode) {
+  if (mode != LASER_HIP_F32_LASER_ORDER && mode != LASER_HIP_F32_FAST) return fail(LASER_HIP_E_INVALID, "bad float mode");
+  g_ctx.float_mode = mode;
+  return LASER_HIP_OK;
+}
+int laser_hip_get_float_mode(void) { return g_ctx.float_mode; }
+int laser_hip_set_f32_config(int cfg) {
+  if (cfg >= gemm_f32_config_count()) return fail(LASER_HIP_E_INVALID, "bad f32 config index");
+  g_ctx.f32_cfg = cfg < 0 ? -1 : cfg;
+  return LASER_HIP_OK;
+}
+int laser_hip_f32_config_count(void) { return gemm_f32_config_count(); }
+const char *laser_hip_f32_config_name(int cfg) { return gemm_f32_config_name(cfg); }
+
+#define LH_DEF_GEMM(SFX, T)                                                                                   \
+  int laser_hip_gemm_strided_##SFX(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,         \
+                                   int64_t csA, const T *B, int64_t rsB, int64_t csB, T beta, T *C,           \
+                                   int64_t rsC, int64_t csC) {                                                \
+    return gemm_host<T>(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, C, rsC, csC);                         \
+  }                                                                                                           \
+  int laser_hip_gemm_strided_##SFX##_dev(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,   \
+                                         int64_t csA, const T *B, int64_t rsB, int64_t csB, T beta, T *C,     \
+                                         int64_t rsC, int64_t csC, void *stream) {                            \
+    return gemm_dev<T>(1, M, N, K, alpha, A, rsA, csA, 0, B, rsB, csB, 0, beta, C, rsC, csC, 0, stream);      \
+  }                                                                                                           \
+  int laser_hip_gemm_strided_batched_##SFX##_dev(                                                             \
+      int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA,          \
+      int64_t bsA, const T *B, int64_t rsB, int64_t csB, int64_t bsB, T beta, T *C, int64_t rsC, int64_t csC, \
+      int64_t bsC, void *stream) {                                                                            \
+    return gemm_dev<T>(batch, M, N, K, alpha, A, rsA, csA, bsA, B, rsB, csB, bsB, beta, C, rsC, csC, bsC,     \
+                       stream);                                                                               \
+  }                                                                                                           \
+  int64_t laser_hip_gemm_prepackA_mem_required_##SFX(int64_t M, int64_t N, int64_t K) {                       \
+    return prepack_bytes<T>(true, M, N, K);                                                                   \
+  }                                                                                                           \
+  int64_t laser_hip_gemm_prepackB_mem_required_##SFX(int64_t M, int64_t N, int64_t K) {                       \
+    return prepack_bytes<T>(false, M, N, K);                                                                  \
+  }                                                                                                           \
+  int laser_hip_gemm_prepackA_##SFX(void *dst, int64_t M, int64_t N, int64_t K, const T *A, int64_t rs,       \
+                                    int64_t cs) {                                                             \
+    return prepack_host<T>(true, dst, M, N, K, A, rs, cs);                                                    \
+  }                                                                                                           \
+  int laser_hip_gemm_prepackB_##SFX(void *dst, int64_t M, int64_t N, int64_t K, const T *B, int64_t rs,       \
+                                    int64_t cs) {                                                             \
+    return prepack_host<T>(false, dst, M, N, K, B, rs, cs);                                                   \
+  }                                                                                                           \
+  int laser_hip_gemm_packed_##SFX(int64_t M, int64_t N, int64_t K, T alpha, const void *pA, const void *pB,   \
+                                  T beta, T *C, int64_t rsC, int64_t csC) {                                   \
+    return packed_host<T>(M, N, K, alpha, pA, pB, beta, C, rsC, csC);                                         \
+  }                                                                                                           \
+  int laser_hip_gemm_prepackA_##SFX##_dev(void *d, int64_t M, int64_t N, int64_t K, const T *A, int64_t rs,   \
+                                          int64_t cs, void *stream) {                                         \
+    return prepack_dev<T>(true, d, M, N, K, A, rs, cs, stream);                                               \
+  }                                                                                                           \
+  int laser_hip_gemm_prepackB_##SFX##_dev(void *d, int64_t M, int64_t N, int64_t K, const T *B, int64_t rs,   \
+                                          int64_t cs, void *stream) {                                         \
+    return prepack_dev<T>(false, d, M, N, K, B, rs, cs, stream);                                              \
+  }                                                                                                           \
+  int laser_hip_gemm_packed_##SFX##_dev(int64_t M, int64_t N, int64_t K, T alpha, const void *dA,             \
+                                        const void *dB, T beta, T *dC, int64_t rsC, int64_t csC,              \
+                                        void *stream) {                                                       \
+    return packed_dev<T>(M, N, K, alpha, dA, dB, beta, dC, rsC, csC, stream);                                 \
+  }
+LH_DEF_GEMM(f32, float)
+LH_DEF_GEMM(f64, double)
+LH_DEF_GEMM(i32, int32_t)
+LH_DEF_GEMM(i64, int64_t)
+#undef LH_DEF_GEMM
+
+int laser_hip_gemm_prepack_release(void *packed) {
+  if (!packed) return fail(LASER_HIP_E_INVALID, "null packed buffer");
+  std::lock_guard<std::mutex> lk(g_mu);
+  PackHandle h;
+  memcpy(&h, packed, sizeof h);
+  if (h.magic != kMagic || h.self != reinterpret_cast<uint64_t>(packed))
+    return fail(LASER_HIP_E_HANDLE, "buffer does not hold a live pre-pack handle");
+  auto it = g_panels.find(h.id);
+  if (it == g_panels.end()) return fail(LASER_HIP_E_HANDLE, "pre-pack handle already released");
+  (void)hipFree(it->second.ptr);
+  g_panels.erase(it);
+  memset(packed, 0, sizeof h);
+  return LASER_HIP_OK;
+}
+
+#define LH_DEF_TR(SFX, ELEM)                                                                                  \
+  int laser_hip_transpose2d_copy_##SFX(void *dst, const void *src, int64_t NR, int64_t NC) {                  \
+    return transpose_host(dst, src, 1, NR, NC, ELEM);                                                         \
+  }                                                                                                           \
+  int laser_hip_transpose2d_batched_##SFX(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC) {    \
+    return transpose_host(dst, src, N, NR, NC, ELEM);                                                         \
+  }                                                                                                           \
+  int laser_hip_nchw2nhwc_##SFX(void *dst, const void *src, int64_t N, int64_t C, int64_t H, int64_t W) {     \
+    return transpose_host(dst, src, N, C, H * W, ELEM); /* swapaxes.nim:98 */                                 \
+  }                                                                                                           \
+  int laser_hip_nhwc2nchw_##SFX(void *dst, const void *src, int64_t N, int64_t C, int64_t H, int64_t W) {     \
+    return transpose_host(dst, src, N, H * W, C, ELEM); /* swapaxes.nim:112 */                                \
+  }                                                                                                           \
+  int laser_hip_transpose2d_batched_##SFX##_dev(void *dst, const void *src, int64_t N, int64_t NR,            \
+                                                int64_t NC, void *stream) {                                   \
+    if (N < 0 || NR < 0 || NC < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");                    \
+    if (int rc = ensure_init()) return rc;                                                                    \
+    if (N == 0 || NR == 0 || NC == 0) return LASER_HIP_OK;                                                    \
+    if (!dst || !src) return fail(LASER_HIP_E_INVALID, "null pointer");                                       \
+    HIP_TRY(launch_transpose_batched(dst, src, N, NR, NC, ELEM, (hipStream_t)stream));                        \
+    return LASER_HIP_OK;                                                                                      \
+  }
+LH_DEF_TR(b32, 4)
+LH_DEF_TR(b64, 8)
+#undef LH_DEF_TR
+
+int laser_hip_conv2d_out_shape(int64_t iN, int64_t iC, int64_t iH, int64_t iW, int64_t c_out, int64_t c_in,
+                               int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW,
+                               int64_t *oN, int64_t *oC, int64_t *oH, int64_t *oW) {
+  if (int rc = conv_check(iN, iC, iH, iW, c_out, c_in, kH, kW, pH, pW, sH, sW)) return rc;
+  *oN = iN;
+  *oC = c_out;
+  out_hw(iH, iW, kH, kW, pH, pW, sH, sW, oH, oW);
+  return LASER_HIP_OK;
+}
+
+int64_t laser_hip_im2col_workspace_size(int64_t iN, int64_t iC, int64_t iH, int64_t iW, int64_t c_out,
+                                        int64_t c_in, int64_t kH, int64_t kW, int64_t pH, int64_t pW,
+                                        int64_t sH, int64_t sW) {
+  (void)iN; (void)c_out; (void)c_in;
+  if (sH <= 0 || sW <= 0) return 0;
+  int64_t oH, oW;
+  out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
+  return iC * kH * kW * oH * oW;  // conv2d_im2col.nim:19-20
+}
+
+int laser_hip_im2col_f32_dev(float *dws, int64_t oH, int64_t oW, const float *din, int64_t batch, int64_t iC,
+                             int64_t iH, int64_t iW, int64_t kH, int64_t kW, int64_t pH, int64_t pW,
+                             int64_t sH, int64_t sW, void *stream) {
+  if (int rc = ensure_init()) return rc;
+  if (!dws || !din) return fail(LASER_HIP_E_INVALID, "null pointer");
+  if (oH < 0 || oW < 0 || batch < 0 || iC <= 0 || sH <= 0 || sW <= 0) return fail(LASER_HIP_E_INVALID, "bad shape");
+  HIP_TRY(launch_im2col_f32(dws, oH, oW, din, batch, iC, iH, iW, kH, kW, pH, pW, sH, sW, (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
+
+int laser_hip_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t iC, int64_t iH,
+                         int64_t iW, int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW) {
+  if (int rc = ensure_init()) return rc;
+  if (!ws || !in) return fail(LASER_HIP_E_INVALID, "null pointer");
+  if (oH < 0 || oW < 0 || iC <= 0 || sH <= 0 || sW <= 0) return fail(LASER_HIP_E_INVALID, "bad shape");
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t ib = (size_t)iC * iH * iW * 4, wb = (size_t)iC * kH * kW * oH * oW * 4;
+  if (wb == 0) return LASER_HIP_OK;
+  void *di, *dw;
+  if (int rc = scratch_get(0, ib, &di)) return rc;
+  if (int rc = scratch_get(4, wb, &dw)) return rc;
+  HIP_TRY(hipMemcpy(di, in, ib, hipMemcpyHostToDevice));
+  HIP_TRY(launch_im2col_f32((float *)dw, oH, oW, (const float *)di, 1, iC, iH, iW, kH, kW, pH, pW, sH, sW, nullptr));
+  HIP_TRY(hipMemcpy(ws, dw, wb, hipMemcpyDeviceToHost));
+  return LASER_HIP_OK;
+}
+
+int laser_hip_conv2d_im2col_f32_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
+                                    int64_t iW, const float *dker, int64_t c_out, int64_t c_in, int64_t kH,
+                                    int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
+                                    void *stream) {
+  if (int rc = conv_check(iN, iC, iH, iW, c_out, c_in, kH, kW, pH, pW, sH, sW)) return rc;
+  if (int rc = ensure_init()) return rc;
+  if (iN == 0) return LASER_HIP_OK;
+  if (!dout || !din || !dker) return fail(LASER_HIP_E_INVALID, "null pointer");
+  if (iN > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
+  if (!dws) {
+    int64_t oH, oW;
+    out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
+    std::lock_guard<std::mutex> lk(g_mu);
+    void *p;
+    if (int rc = scratch_get(4, (size_t)iN * iC * kH * kW * oH * oW * 4, &p)) return rc;
+    dws = (float *)p;
+  }
+  return conv_dev(dout, din, iN, iC, iH, iW, dker, c_out, kH, kW, pH, pW, sH, sW, dws, (hipStream_t)stream);
+}
+
+int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t iC, int64_t iH, int64_t iW,
+                                const float *ker, int64_t c_out, int64_t c_in, int64_t kH, int64_t kW,
+                                int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *pworkspace) {
+  if (int rc = conv_check(iN, iC, iH, iW, c_out, c_in, kH, kW, pH, pW, sH, sW)) return rc;
+  if (int rc = ensure_init()) return rc;
+  if (iN == 0) return LASER_HIP_OK;
+  if (!out || !in || !ker) return fail(LASER_HIP_E_INVALID, "null pointer");
+  if (iN > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
+  std::lock_guard<std::mutex> lk(g_mu);
+  int64_t oH, oW;
+  out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
+  const size_t ib = (size_t)iN * iC * iH * iW * 4, kb = (size_t)c_out * iC * kH * kW * 4;
+  const size_t ob = (size_t)iN * c_out * oH * oW * 4, w1 = (size_t)iC * kH * kW * oH * oW * 4;
+  void *di, *dk, *dout, *dws;
+  if (int rc = scratch_get(0, ib, &di)) return rc;
+  if (int rc = scratch_get(1, kb, &dk)) return rc;
+  if (int rc = scratch_get(2, ob, &dout)) return rc;
+  if (int rc = scratch_get(4, w1 * iN, &dws)) return rc;
+  HIP_TRY(hipMemcpy(di, in, ib, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dk, ker, kb, hipMemcpyHostToDevice));
+  if (int rc = conv_dev((float *)dout, (const float *)di, iN, iC, iH, iW, (const float *)dk, c_out, kH, kW, pH,
+                        pW, sH, sW, (float *)dws, nullptr))
+    return rc;
+  HIP_TRY(hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost));
+  // like the reference, the caller's workspace ends up holding the LAST image's im2col matrix
+  const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
+  if (pworkspace && !direct && w1 > 0)
+    HIP_TRY(hipMemcpy(pworkspace, (const char *)dws + (size_t)(iN - 1) * w1, w1, hipMemcpyDeviceToHost));
+  return LASER_HIP_OK;
+}
+
+int laser_hip_cblas_sgemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, float alpha, const float *A,
+                          int64_t lda, const float *B, int64_t ldb, float beta, float *C, int64_t ldc) {
+  return cblas_gemm<float>(order, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+int laser_hip_cblas_dgemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, double alpha,
+                          const double *A, int64_t lda, const double *B, int64_t ldb, double beta, double *C,
+                          int64_t ldc) {
+  return cblas_gemm<double>(order, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+}  // extern "C"

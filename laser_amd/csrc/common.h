@@ -1,0 +1,55 @@
+// laser_amd/csrc/common.h -- shared host/device declarations of liblaser_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace laser_hip {
+
+// One (possibly batched) strided GEMM problem: C <- alpha*A*B + beta*C, element X[r,c] at
+// X[r*rs + c*cs] (strides in elements) -- the MatrixView triple of gemm_utils.nim:36-60.
+template <typename T>
+struct GemmArgs {
+  int64_t M, N, K;
+  T alpha, beta;
+  const T *A;
+  int64_t rsA, csA, bsA;
+  const T *B;
+  int64_t rsB, csB, bsB;
+  T *C;
+  int64_t rsC, csC, bsC;
+  // Readable extents of the operand allocations: rows of A / cols of B / k of both may be read up to
+  // these bounds (values beyond M/N/K are zero).  Equal to M, N, K for plain operands; larger for the
+  // tile-padded panel images made by the pre-pack API, which lets ragged shapes use the vector loaders.
+  int64_t Mext, Next, Kext;
+  int32_t tiles_m, tiles_n;  // grid decomposition (filled by the launcher)
+  int32_t kc;                // accumulation slice in k (Laser's kc; 0 = one chain over all K)
+  int32_t batch;
+};
+
+// How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of
+// pack_A_mc_kc / pack_B_kc_nc, gemm_packing.nim:24-94 -- strides are resolved HERE).
+enum LoadMode : int {
+  LOAD_VEC_X = 0,  // unit stride along the tile's M/N dimension, 16-B vector loads, full tiles
+  LOAD_VEC_K = 1,  // unit stride along k, 16-B vector loads + transposing LDS write, full tiles
+  LOAD_GEN_X = 2,  // any strides / ragged edges, scalar predicated loads, lanes run along M/N
+  LOAD_GEN_K = 3,  // any strides / ragged edges, scalar predicated loads, lanes run along k
+};
+
+hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
+int gemm_f32_config_count();
+const char *gemm_f32_config_name(int cfg);
+
+template <typename T>
+hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream_t s);
+
+hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,
+                                    int elem_size, hipStream_t s);
+hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,
+                             int64_t C, int64_t H, int64_t W, int64_t kH, int64_t kW, int64_t pH,
+                             int64_t pW, int64_t sH, int64_t sW, hipStream_t s);
+// dst[r*ld + c] = (r < R && c < Ccols) ? src[r*rs + c*cs] : 0 for r < Rpad, c < Cpad
+template <typename T>
+hipError_t launch_pack_pad(T *dst, int64_t Rpad, int64_t Cpad, const T *src, int64_t R,
+                           int64_t Ccols, int64_t rs, int64_t cs, hipStream_t s);
+
+}  // namespace laser_hip

@@ -1,0 +1,275 @@
+"""Host-side mirror of Laser's primitives for the GEMM hot path, over the C-ABI of liblaser_hip.so.
+
+Names, argument order and meaning follow the reference's Nim procs so that tests read like the
+reference's own:
+
+  gemm_strided            laser/primitives/matrix_multiplication/gemm.nim:184-193
+  gemm_prepack{A,B}[_mem_required], gemm_packed     gemm_prepacked.nim:76-292
+  transpose2D_copy, transpose2D_batched, nchw2nhwc, nhwc2nchw    laser/primitives/swapaxes.nim:16-112
+  conv2d_out_shape, im2col_workspace_size, im2col, conv2d_im2col
+                          benchmarks/convolution/conv2d_common.nim:15-45, conv2d_im2col.nim:10-166
+  gemm (cblas-shaped)     benchmarks/third_party/blas.nim:12-23
+
+A "raw buffer" argument is what the Nim side would pass as `ptr T` (the result of
+`unsafe_raw_data`): either a numpy array (host memory -> blocking host-pointer entry point) or a
+torch CUDA tensor (device memory -> `_dev` entry point on torch's current stream).  The pointer
+passed down is the address of the array's first element; strides are in elements.  Nothing here
+computes: every function forwards to the HIP library and raises LaserHipError on failure.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+try:  # torch is plumbing for device memory / streams only
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+_SFX = {"float32": "f32", "float64": "f64", "int32": "i32", "int64": "i64"}
+
+
+def _is_dev(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _sfx(x):
+    name = str(x.dtype).replace("torch.", "")
+    if name not in _SFX:
+        raise TypeError(f"unsupported element type {x.dtype} (Laser GEMM: float32/float64/int32/int64)")
+    return _SFX[name]
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_dev(x):
+        if not x.is_cuda:
+            raise TypeError("torch tensors must live on the GPU (pass numpy arrays for host memory)")
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x.ctypes.data)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _same_side(*xs):
+    dev = [_is_dev(x) for x in xs if x is not None]
+    if any(dev) and not all(dev):
+        raise TypeError("operands must be all host (numpy) or all device (torch.cuda) buffers")
+    return bool(dev) and dev[0]
+
+
+def set_float_mode(mode):
+    """0 = LASER_ORDER (bit-identical to Laser on an FMA host, default), 1 = FAST."""
+    _lib.check(_lib.lib().laser_hip_set_float_mode(int(mode)))
+
+
+def get_float_mode():
+    return _lib.lib().laser_hip_get_float_mode()
+
+
+def set_f32_config(cfg):
+    _lib.check(_lib.lib().laser_hip_set_f32_config(int(cfg)))
+
+
+def f32_configs():
+    L = _lib.lib()
+    return [L.laser_hip_f32_config_name(i).decode() for i in range(L.laser_hip_f32_config_count())]
+
+
+# ---- GEMM ----------------------------------------------------------------------------------------
+def gemm_strided(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C_,
+                 rowStrideC, colStrideC):
+    """C <- alpha*A*B + beta*C, element X[r,c] at X_ptr[r*rowStride + c*colStride]."""
+    L = _lib.lib()
+    s = _sfx(C_)
+    if _sfx(A) != s or _sfx(B) != s:
+        raise TypeError("A, B, C must share one element type")
+    ct = _lib.ctype_of(s)
+    args = [M, N, K, ct(alpha), _ptr(A), rowStrideA, colStrideA, _ptr(B), rowStrideB, colStrideB,
+            ct(beta), _ptr(C_), rowStrideC, colStrideC]
+    if _same_side(A, B, C_):
+        _lib.check(getattr(L, f"laser_hip_gemm_strided_{s}_dev")(*args, _stream()))
+    else:
+        _lib.check(getattr(L, f"laser_hip_gemm_strided_{s}")(*args))
+    return C_
+
+
+def gemm_strided_batched(batch, M, N, K, alpha, A, rsA, csA, bsA, B, rsB, csB, bsB, beta, C_, rsC, csC, bsC):
+    """Device-only: `batch` independent problems, operand b at ptr + b*batchStride (0 = shared)."""
+    L = _lib.lib()
+    s = _sfx(C_)
+    if not _same_side(A, B, C_):
+        raise TypeError("batched GEMM is a device-resident entry point")
+    ct = _lib.ctype_of(s)
+    _lib.check(getattr(L, f"laser_hip_gemm_strided_batched_{s}_dev")(
+        batch, M, N, K, ct(alpha), _ptr(A), rsA, csA, bsA, _ptr(B), rsB, csB, bsB, ct(beta), _ptr(C_),
+        rsC, csC, bsC, _stream()))
+    return C_
+
+
+def _estrides(x):
+    if _is_dev(x):
+        return tuple(x.stride())
+    return tuple(st // x.dtype.itemsize for st in x.strides)
+
+
+def matmul(A, B, alpha=1, beta=0, out=None):
+    """Convenience over gemm_strided for 2-D views of any strides (numpy or torch.cuda)."""
+    M, K = A.shape
+    K2, N = B.shape
+    if K != K2:
+        raise ValueError("inner dimensions differ")
+    if out is None:
+        out = torch.zeros((M, N), dtype=A.dtype, device=A.device) if _is_dev(A) else np.zeros((M, N), dtype=A.dtype)
+    (rsA, csA), (rsB, csB), (rsC, csC) = _estrides(A), _estrides(B), _estrides(out)
+    gemm_strided(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, out, rsC, csC)
+    return out
+
+
+def _np_dtype(T):
+    return np.dtype(T) if not (torch is not None and isinstance(T, torch.dtype)) else np.dtype(str(T).replace("torch.", ""))
+
+
+def gemm_prepackA_mem_required(T, M, N, K):
+    return getattr(_lib.lib(), f"laser_hip_gemm_prepackA_mem_required_{_SFX[_np_dtype(T).name]}")(M, N, K)
+
+
+def gemm_prepackB_mem_required(T, M, N, K):
+    return getattr(_lib.lib(), f"laser_hip_gemm_prepackB_mem_required_{_SFX[_np_dtype(T).name]}")(M, N, K)
+
+
+def _prepack(which, dst, M, N, K, src, rs, cs):
+    L = _lib.lib()
+    s = _sfx(src)
+    if _same_side(dst, src):
+        _lib.check(getattr(L, f"laser_hip_gemm_prepack{which}_{s}_dev")(_ptr(dst), M, N, K, _ptr(src), rs, cs, _stream()))
+    else:
+        _lib.check(getattr(L, f"laser_hip_gemm_prepack{which}_{s}")(_ptr(dst), M, N, K, _ptr(src), rs, cs))
+    return dst
+
+
+def gemm_prepackA(dst_packedA, M, N, K, src_A, rowStrideA, colStrideA):
+    return _prepack("A", dst_packedA, M, N, K, src_A, rowStrideA, colStrideA)
+
+
+def gemm_prepackB(dst_packedB, M, N, K, src_B, rowStrideB, colStrideB):
+    return _prepack("B", dst_packedB, M, N, K, src_B, rowStrideB, colStrideB)
+
+
+def gemm_packed(M, N, K, alpha, packedA, packedB, beta, C_, rowStrideC, colStrideC):
+    L = _lib.lib()
+    s = _sfx(C_)
+    ct = _lib.ctype_of(s)
+    if _same_side(packedA, packedB, C_):
+        _lib.check(getattr(L, f"laser_hip_gemm_packed_{s}_dev")(M, N, K, ct(alpha), _ptr(packedA), _ptr(packedB),
+                                                                ct(beta), _ptr(C_), rowStrideC, colStrideC, _stream()))
+    else:
+        _lib.check(getattr(L, f"laser_hip_gemm_packed_{s}")(M, N, K, ct(alpha), _ptr(packedA), _ptr(packedB),
+                                                            ct(beta), _ptr(C_), rowStrideC, colStrideC))
+    return C_
+
+
+def gemm_prepack_release(packed):
+    _lib.check(_lib.lib().laser_hip_gemm_prepack_release(_ptr(packed)))
+
+
+def aligned_host_buffer(nbytes, dtype=np.uint8, align=64):
+    """A 64-byte aligned numpy buffer (what `newTensor` / Laser's allocator gives the Nim caller)."""
+    raw = np.zeros(nbytes + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + nbytes].view(dtype)
+
+
+# ---- transposes ------------------------------------------------------------------------------------
+def _bsfx(x):
+    size = x.element_size() if _is_dev(x) else x.dtype.itemsize
+    if size not in (4, 8):
+        raise TypeError("transposes support 4- and 8-byte elements")
+    return "b32" if size == 4 else "b64"
+
+
+def transpose2D_batched(dst, src, N, NR, NC):
+    L = _lib.lib()
+    b = _bsfx(src)
+    if _same_side(dst, src):
+        _lib.check(getattr(L, f"laser_hip_transpose2d_batched_{b}_dev")(_ptr(dst), _ptr(src), N, NR, NC, _stream()))
+    else:
+        _lib.check(getattr(L, f"laser_hip_transpose2d_batched_{b}")(_ptr(dst), _ptr(src), N, NR, NC))
+    return dst
+
+
+def transpose2D_copy(dst, src, NR, NC):
+    if _same_side(dst, src):
+        return transpose2D_batched(dst, src, 1, NR, NC)
+    _lib.check(getattr(_lib.lib(), f"laser_hip_transpose2d_copy_{_bsfx(src)}")(_ptr(dst), _ptr(src), NR, NC))
+    return dst
+
+
+def nchw2nhwc(dst_nhwc, src_nchw, N, C_, H, W):
+    if _same_side(dst_nhwc, src_nchw):
+        return transpose2D_batched(dst_nhwc, src_nchw, N, C_, H * W)
+    _lib.check(getattr(_lib.lib(), f"laser_hip_nchw2nhwc_{_bsfx(src_nchw)}")(_ptr(dst_nhwc), _ptr(src_nchw), N, C_, H, W))
+    return dst_nhwc
+
+
+def nhwc2nchw(dst_nchw, src_nhwc, N, C_, H, W):
+    if _same_side(dst_nchw, src_nhwc):
+        return transpose2D_batched(dst_nchw, src_nhwc, N, H * W, C_)
+    _lib.check(getattr(_lib.lib(), f"laser_hip_nhwc2nchw_{_bsfx(src_nhwc)}")(_ptr(dst_nchw), _ptr(src_nhwc), N, C_, H, W))
+    return dst_nchw
+
+
+# ---- convolution -------------------------------------------------------------------------------------
+# TensorShape = (n, c, h, w); KernelShape = (c_out, c_in, kH, kW); Padding = (h, w); Strides = (h, w)
+def conv2d_out_shape(ishape, kshape, padding, strides):
+    o = [C.c_int64() for _ in range(4)]
+    _lib.check(_lib.lib().laser_hip_conv2d_out_shape(*ishape, *kshape, *padding, *strides, *[C.byref(v) for v in o]))
+    return tuple(v.value for v in o)
+
+
+def im2col_workspace_size(ishape, kshape, padding, strides):
+    return _lib.lib().laser_hip_im2col_workspace_size(*ishape, *kshape, *padding, *strides)
+
+
+def im2col(pworkspace, oshape, pinput, ishape, kshape, padding, strides):
+    """One image [c,h,w] -> pworkspace [c*kH*kW, oH*oW]."""
+    L = _lib.lib()
+    if _same_side(pworkspace, pinput):
+        _lib.check(L.laser_hip_im2col_f32_dev(_ptr(pworkspace), oshape[2], oshape[3], _ptr(pinput), 1, ishape[1],
+                                              ishape[2], ishape[3], kshape[2], kshape[3], *padding, *strides, _stream()))
+    else:
+        _lib.check(L.laser_hip_im2col_f32(_ptr(pworkspace), oshape[2], oshape[3], _ptr(pinput), ishape[1], ishape[2],
+                                          ishape[3], kshape[2], kshape[3], *padding, *strides))
+    return pworkspace
+
+
+def conv2d_im2col(output, oshape, input_, ishape, kernel, kshape, padding, strides, pworkspace=None):
+    L = _lib.lib()
+    if tuple(oshape) != conv2d_out_shape(ishape, kshape, padding, strides):
+        raise ValueError("oshape does not match conv2d_out_shape(ishape, kshape, padding, strides)")
+    if oshape[1] != kshape[0]:
+        raise ValueError("oshape.c != kshape.c_out")  # conv2d_im2col.nim:109
+    args = [_ptr(output), _ptr(input_), *ishape, _ptr(kernel), *kshape, *padding, *strides, _ptr(pworkspace)]
+    if _same_side(output, input_, kernel, pworkspace):
+        _lib.check(L.laser_hip_conv2d_im2col_f32_dev(*args, _stream()))
+    else:
+        _lib.check(L.laser_hip_conv2d_im2col_f32(*args))
+    return output
+
+
+# cblas enums (benchmarks/third_party/blas.nim:12-16)
+noTranspose, transpose, conjTranspose = 111, 112, 113
+rowMajor, colMajor = 101, 102
+
+
+def gemm(ORDER, TRANSA, TRANSB, M, N, K, ALPHA, A, LDA, B, LDB, BETA, C_, LDC):
+    """cblas-shaped gemm, the call conv2d_im2col makes in the reference (conv2d_im2col.nim:161-166)."""
+    L = _lib.lib()
+    s = _sfx(C_)
+    fn = {"f32": L.laser_hip_cblas_sgemm, "f64": L.laser_hip_cblas_dgemm}[s]
+    _lib.check(fn(ORDER, TRANSA, TRANSB, M, N, K, ALPHA, _ptr(A), LDA, _ptr(B), LDB, BETA, _ptr(C_), LDC))
+    return C_

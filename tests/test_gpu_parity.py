@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the host mirror laser_amd.primitives)
+against the CPU oracle on the same seeded inputs, the reference's KATs, and -- at BASELINE.json's
+full sizes -- size-independent properties.
+
+Bars: bit-exact (np.array_equal) for int32/int64, for float64, and for float32 in the default
+LASER_ORDER mode (an f32 MFMA is a k-ordered fmaf chain; the kernel restarts it every kc=512 like
+Laser's pc loop).  FAST mode: mean relative error <= 1e-5 (gemm_bench_float32.nim:365-367).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64, np.int32, np.int64]
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import laser_amd
+    laser_amd.lib()
+    assert laser_amd.lib().laser_hip_arch().decode().startswith("gfx950")
+    laser_amd.set_float_mode(0)
+    laser_amd.set_f32_config(-1)
+    return laser_amd
+
+
+def rand(rng, shape, dtype, full_range=False):
+    if np.dtype(dtype).kind == "f":
+        return rng.uniform(-0.1, 0.1, shape).astype(dtype)  # gemm_bench_float32.nim:343-344
+    if full_range:
+        info = np.iinfo(dtype)
+        return rng.integers(info.min, info.max, shape, dtype=dtype)
+    return rng.integers(0, 101, shape).astype(dtype)  # gemm_bench_int32.nim:190-191
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_reference_kats(la, kats, dtype):
+    for k in kats["gemm"]:
+        A = np.array(k["A"], dtype=dtype)
+        B = np.array(k["B"], dtype=dtype)
+        C = np.full((k["M"], k["N"]), 77, dtype=dtype)
+        la.gemm_strided(k["M"], k["N"], k["K"], 1, A, k["K"], 1, B, k["N"], 1, 0, C, k["N"], 1)
+        assert np.array_equal(C, np.array(k["C"], dtype=dtype)), k["source"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_reference_prepacked_kats(la, kats, dtype):
+    # the reference's pack_and_test (gemm_prepacked.nim:314-351)
+    for k in kats["gemm_prepacked"]:
+        M, N, K = k["M"], k["N"], k["K"]
+        A = np.array(k["A"], dtype=dtype)
+        B = np.array(k["B"], dtype=dtype)
+        pa = la.aligned_host_buffer(la.gemm_prepackA_mem_required(dtype, M, N, K))
+        pb = la.aligned_host_buffer(la.gemm_prepackB_mem_required(dtype, M, N, K))
+        la.gemm_prepackA(pa, M, N, K, A, K, 1)
+        la.gemm_prepackB(pb, M, N, K, B, N, 1)
+        C = np.zeros((M, N), dtype=dtype)
+        la.gemm_packed(M, N, K, 1, pa, pb, 0, C, N, 1)
+        assert np.array_equal(C, np.array(k["C"], dtype=dtype)), k["source"]
+        la.gemm_prepack_release(pa)
+        la.gemm_prepack_release(pb)
+
+
+def test_reference_conv_kats(la, kats):
+    for c in kats["conv"]:
+        x = np.array(c["input"], dtype=np.float32)
+        w = np.array(c["kernel"], dtype=np.float32)
+        ishape, kshape, pad, st = tuple(c["ishape"]), tuple(c["kshape"]), tuple(c["padding"]), tuple(c["strides"])
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+        out = np.zeros(int(np.prod(oshape)), dtype=np.float32)
+        ws = np.zeros(la.im2col_workspace_size(ishape, kshape, pad, st), dtype=np.float32)
+        la.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, ws)
+        assert out.tolist() == c["target"], c["source"]
+
+
+SHAPES = [(128, 128, 128),      # BASELINE configs[0]
+          (1, 1, 1), (3, 5, 7), (129, 131, 515), (257, 255, 1030), (64, 300, 33), (512, 384, 1024),
+          (31, 1000, 2), (700, 17, 520)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_bit_exact_vs_oracle(la, oracle, dtype, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(hash((M, N, K)) % 2**32)
+    A = rand(rng, (M, K), dtype, full_range=True)
+    B = rand(rng, (K, N), dtype, full_range=True)
+    C0 = rand(rng, (M, N), dtype)
+    for alpha, beta in [(1, 0), (1, 1), (2, 3) if np.dtype(dtype).kind == "i" else (0.5, 0.25)]:
+        want = oracle.matmul(A, B, alpha, beta, C0.copy())
+        got = la.matmul(A, B, alpha, beta, C0.copy())
+        assert np.array_equal(got, want), (shape, alpha, beta, float(np.max(np.abs(got.astype(np.float64) - want))))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+def test_strided_and_transposed_operands(la, oracle, dtype):
+    """BASELINE configs[2] at reduced size: B stored transposed (rowStride 1), A an every-2nd-row
+    view, C with colStride 2; plus column-major A and negative strides."""
+    rng = np.random.default_rng(11)
+    M, N, K = 384, 256, 640
+    Abig = rand(rng, (2 * M, K), dtype)
+    Bt = rand(rng, (N, K), dtype)
+    Acm = np.asfortranarray(rand(rng, (M, K), dtype))
+    cases = [
+        (Abig[::2], Bt.T),            # strided rows, transposed B
+        (Acm, Bt.T),                  # column-major A, transposed B
+        (Acm, np.ascontiguousarray(Bt.T)),
+        (Abig[::2][:, ::-1], Bt.T[::-1, :]),   # negative strides along k on both
+        (Abig[1::2][:, ::3], np.ascontiguousarray(Bt.T)[::3, :]),  # generic strides, ragged K
+    ]
+    for A, B in cases:
+        Mv, Kv = A.shape
+        Nv = B.shape[1]
+        Cbuf = np.full((Mv, 2 * Nv), np.nan if np.dtype(dtype).kind == "f" else 7, dtype=dtype)
+        want = oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B))
+        la.matmul(A, B, 1, 0, Cbuf[:, ::2])
+        assert np.array_equal(Cbuf[:, ::2], want)
+        gaps = Cbuf[:, 1::2]
+        assert np.isnan(gaps).all() if np.dtype(dtype).kind == "f" else (gaps == 7).all()
+
+
+def test_semantics_beta0_nan_and_k0(la):
+    rng = np.random.default_rng(12)
+    A = rand(rng, (65, 40), np.float32)
+    B = rand(rng, (40, 70), np.float32)
+    C = np.full((65, 70), np.nan, dtype=np.float32)
+    la.matmul(A, B, 1, 0, C)   # beta == 0 never reads C
+    assert not np.isnan(C).any()
+    C = np.full((4, 4), 3.0, dtype=np.float32)
+    la.gemm_strided(4, 4, 0, 1.0, np.zeros(1, np.float32), 0, 1, np.zeros(1, np.float32), 4, 1, 0.5, C, 4, 1)
+    assert (C == 3.0).all()    # K == 0: C untouched even though beta != 1
+    with pytest.raises(la.LaserHipError):
+        la.gemm_strided(-1, 4, 4, 1.0, A, 4, 1, B, 4, 1, 0.0, C, 4, 1)
+
+
+def test_every_f32_tile_config_bit_exact(la, oracle):
+    rng = np.random.default_rng(13)
+    M, N, K = 512, 768, 1056      # multiples of every tile; 3 kc slices (2 full + ragged)
+    A = rand(rng, (M, K), np.float32)
+    B = rand(rng, (K, N), np.float32)
+    Bt = np.ascontiguousarray(B.T)
+    Acm = np.asfortranarray(A)
+    want = oracle.matmul(A, B)
+    try:
+        for cfg, name in enumerate(la.f32_configs()):
+            la.set_f32_config(cfg)
+            for Av, Bv in [(A, B), (A, Bt.T), (Acm, B), (Acm, Bt.T)]:
+                got = la.matmul(Av, Bv)
+                assert np.array_equal(got, want), (name, Av.strides, Bv.strides)
+    finally:
+        la.set_f32_config(-1)
+
+
+def test_f32_fast_mode_within_tolerance(la, oracle):
+    rng = np.random.default_rng(14)
+    M, N, K = 384, 384, 2048
+    A = rand(rng, (M, K), np.float32)
+    B = rand(rng, (K, N), np.float32)
+    want = oracle.matmul(A, B)
+    try:
+        la.set_float_mode(1)
+        for cfg in range(len(la.f32_configs())):
+            la.set_f32_config(cfg)
+            got = la.matmul(A, B)
+            assert oracle.mean_relative_error(got, want) <= 1e-5   # the reference's bar
+            f64 = oracle.naive_gemm_f64(A, B)
+            assert np.max(np.abs(got - f64)) <= 1e-5 * np.max(np.abs(f64)) + 1e-6
+    finally:
+        la.set_float_mode(0)
+        la.set_f32_config(-1)
+
+
+def test_device_resident_path_matches_host_path(la, oracle):
+    import torch
+    rng = np.random.default_rng(15)
+    M, N, K = 300, 260, 700
+    for dtype in DTYPES:
+        A = rand(rng, (M, K), dtype, True)
+        B = rand(rng, (K, N), dtype, True)
+        want = oracle.matmul(A, B)
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        dC = torch.full((M, N), 5, dtype=dA.dtype, device="cuda")
+        la.matmul(dA, dB, 1, 0, dC)
+        assert np.array_equal(dC.cpu().numpy(), want)
+        # transposed-B device view (strides (1, K))
+        dBt = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t()
+        assert np.array_equal(la.matmul(dA, dBt).cpu().numpy(), want)
+
+
+def test_batched_device_gemm(la, oracle):
+    import torch
+    rng = np.random.default_rng(16)
+    b, M, N, K = 3, 96, 200, 130
+    A = rand(rng, (M, K), np.float32)
+    B = rand(rng, (b, K, N), np.float32)
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    dC = torch.empty((b, M, N), dtype=torch.float32, device="cuda")
+    la.gemm_strided_batched(b, M, N, K, 1.0, dA, K, 1, 0, dB, N, 1, K * N, 0.0, dC, N, 1, M * N)
+    for i in range(b):
+        assert np.array_equal(dC[i].cpu().numpy(), oracle.matmul(A, B[i]))
+
+
+def test_prepacked_ragged_shapes(la, oracle):
+    rng = np.random.default_rng(17)
+    for dtype in DTYPES:
+        M, N, K = 130, 77, 600
+        A = rand(rng, (M, K), dtype, True)
+        B = rand(rng, (K, N), dtype, True)
+        pa = la.aligned_host_buffer(la.gemm_prepackA_mem_required(dtype, M, N, K))
+        pb = la.aligned_host_buffer(la.gemm_prepackB_mem_required(dtype, M, N, K))
+        la.gemm_prepackA(pa, M, N, K, np.asfortranarray(A), 1, M)   # column-major source
+        la.gemm_prepackB(pb, M, N, K, B, N, 1)
+        C = np.zeros((M, N), dtype=dtype)
+        la.gemm_packed(M, N, K, 1, pa, pb, 0, C, N, 1)
+        assert np.array_equal(C, oracle.matmul(A, B))
+        with pytest.raises(la.LaserHipError):   # 64-B alignment precondition (gemm_prepacked.nim:125)
+            la.gemm_prepackB(pb[4:], M, N, K, B, N, 1)
+        la.gemm_prepack_release(pa)
+        with pytest.raises(la.LaserHipError):   # released handle
+            la.gemm_packed(M, N, K, 1, pa, pb, 0, C, N, 1)
+        la.gemm_prepack_release(pb)
+
+
+def test_transposes(la, oracle):
+    import torch
+    rng = np.random.default_rng(18)
+    for shape in [(1, 1), (33, 65), (100, 7), (500, 250), (64, 64)]:
+        for dtype in (np.float32, np.float64, np.int32, np.int64):
+            x = rng.integers(-1000, 1000, shape).astype(dtype)
+            dst = np.empty(shape[::-1], dtype=dtype)
+            la.transpose2D_copy(dst, x, *shape)
+            assert np.array_equal(dst, oracle.transpose2D_copy(x))
+    x = rng.standard_normal((3, 45, 70)).astype(np.float32)
+    dst = np.empty((3, 70, 45), dtype=np.float32)
+    la.transpose2D_batched(dst, x, 3, 45, 70)
+    assert np.array_equal(dst, oracle.transpose2D_batched(x))
+    x = rng.standard_normal((2, 5, 6, 7)).astype(np.float32)
+    nhwc = np.empty((2, 6, 7, 5), dtype=np.float32)
+    la.nchw2nhwc(nhwc, x, 2, 5, 6, 7)
+    assert np.array_equal(nhwc, oracle.nchw2nhwc(x))
+    back = np.empty_like(x)
+    la.nhwc2nchw(back, nhwc, 2, 5, 6, 7)
+    assert np.array_equal(back, x)
+    # device-resident, BASELINE transpose shape 4000 x 2000 (transpose_bench.nim)
+    d = torch.randn(4000, 2000, device="cuda")
+    o = torch.empty(2000, 4000, device="cuda")
+    la.transpose2D_copy(o, d, 4000, 2000)
+    assert torch.equal(o, d.t())
+
+
+def test_im2col_and_conv_vs_oracle(la, oracle):
+    rng = np.random.default_rng(19)
+    for (ishape, kshape, pad, st) in [((2, 5, 13, 11), (4, 5, 3, 3), (1, 1), (1, 1)),
+                                      ((1, 3, 9, 14), (2, 3, 3, 2), (0, 1), (2, 1)),
+                                      ((2, 8, 6, 6), (5, 8, 1, 1), (0, 0), (1, 1)),
+                                      ((3, 16, 20, 20), (24, 16, 3, 3), (0, 0), (1, 1)),
+                                      ((2, 4, 10, 10), (3, 4, 1, 1), (0, 0), (2, 2))]:
+        x = rng.uniform(0, 1, ishape).astype(np.float32)   # conv2d_bench.nim:124-125
+        w = rng.uniform(0, 1, kshape).astype(np.float32)
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+        assert oshape == oracle.conv2d_out_shape(ishape, kshape, pad, st)
+        assert la.im2col_workspace_size(ishape, kshape, pad, st) == oracle.im2col_workspace_size(ishape, kshape, pad, st)
+        ws = np.empty((ishape[1] * kshape[2] * kshape[3], oshape[2] * oshape[3]), dtype=np.float32)
+        la.im2col(ws, oshape, x[0], ishape, kshape, pad, st)
+        assert np.array_equal(ws, oracle.im2col(x[0], kshape, pad, st))
+        out = np.zeros(oshape, dtype=np.float32)
+        la.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None)
+        if kshape[2] * kshape[3] == 1 and st != (1, 1):
+            want = oracle.conv2d_direct(x, w, pad, st)   # reference's 1x1 shortcut is only right for stride 1
+            assert oracle.mean_relative_error(out, want) <= 1e-5
+        else:
+            want = oracle.conv2d_im2col(x, w, pad, st)
+            assert np.array_equal(out, want)   # same GEMM order on both sides
+        assert oracle.mean_relative_error(out, oracle.conv2d_direct(x, w, pad, st)) <= 1e-5
+
+
+def test_cblas_shaped_gemm(la, oracle):
+    rng = np.random.default_rng(20)
+    M, N, K = 50, 60, 70
+    A = rand(rng, (M, K), np.float32)
+    B = rand(rng, (K, N), np.float32)
+    want = oracle.matmul(A, B)
+    C = np.zeros((M, N), np.float32)
+    la.gemm(la.rowMajor, la.noTranspose, la.noTranspose, M, N, K, 1.0, A, K, B, N, 0.0, C, N)
+    assert np.array_equal(C, want)
+    At, Bt = np.ascontiguousarray(A.T), np.ascontiguousarray(B.T)
+    C[:] = 0
+    la.gemm(la.rowMajor, la.transpose, la.transpose, M, N, K, 1.0, At, M, Bt, K, 0.0, C, N)
+    assert np.array_equal(C, want)
+    Cc = np.zeros((N, M), np.float32)  # column-major C (M x N, ldc = M)
+    la.gemm(la.colMajor, la.noTranspose, la.noTranspose, M, N, K, 1.0, At, M, Bt, K, 0.0, Cc, M)
+    assert np.array_equal(Cc.T, want)
+
+
+# ---- BASELINE.json full sizes: properties that do not need the oracle to redo the whole job ----------
+def test_full_size_8192_rows_bit_exact_and_checksum(la, oracle):
+    """configs[1]: fp32 sgemm M=N=K=8192 on the device-resident path.
+    (1) LASER_ORDER results do not depend on tiling, so any subset of rows must equal the oracle's
+        result for just those rows, bit for bit;  (2) checksum of checksums: C.1 == A.(B.1) in fp64."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(42)
+    n = 8192
+    A = (torch.rand((n, n), generator=g, device="cuda") - 0.5) * 0.2
+    B = (torch.rand((n, n), generator=g, device="cuda") - 0.5) * 0.2
+    Cd = torch.full((n, n), float("nan"), device="cuda")
+    la.matmul(A, B, 1, 0, Cd)
+    torch.cuda.synchronize()
+    assert not torch.isnan(Cd).any()
+    rows = [0, 1, 127, 128, 4095, 4096, 8000, 8191] + list(range(2048, 2048 + 24))
+    Asub = A[rows].cpu().numpy()
+    want = oracle.matmul(Asub, B.cpu().numpy())
+    assert np.array_equal(Cd[rows].cpu().numpy(), want)
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    lhs = Cd.double() @ ones
+    rhs = A.double() @ (B.double() @ ones)
+    assert torch.allclose(lhs, rhs, rtol=0, atol=2e-3), float((lhs - rhs).abs().max())
+    # FAST mode within the stated tolerance of LASER_ORDER at full size
+    try:
+        la.set_float_mode(1)
+        Cf = torch.empty_like(Cd)
+        la.matmul(A, B, 1, 0, Cf)
+        denom = torch.maximum(Cf.abs(), Cd.abs())
+        rel = torch.where(denom > 0, (Cf - Cd).abs() / denom, torch.zeros_like(denom)).mean().item()
+        assert rel <= 1e-5, rel
+    finally:
+        la.set_float_mode(0)
+
+
+def test_full_size_transposed_b_4096(la, oracle):
+    """configs[2]: strided / transposed-B gemm M=N=K=4096 (device-resident), sampled rows bit-exact."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(43)
+    n = 4096
+    Abig = (torch.rand((2 * n, n), generator=g, device="cuda") - 0.5) * 0.2
+    Bt = (torch.rand((n, n), generator=g, device="cuda") - 0.5) * 0.2     # stored N x K
+    A = Abig[::2]            # rowStride 2K
+    B = Bt.t()               # (rowStride 1, colStride K)
+    Cbuf = torch.zeros((n, 2 * n), device="cuda")
+    C = Cbuf[:, ::2]         # colStride 2
+    la.matmul(A, B, 1, 0, C)
+    rows = [0, 5, 2047, 2048, 4095]
+    want = oracle.matmul(A[rows].cpu().numpy(), np.ascontiguousarray(B.cpu().numpy()))
+    assert np.array_equal(C[rows].cpu().numpy(), want)
+    assert (Cbuf[:, 1::2] == 0).all()
+
+
+def test_full_size_conv_c4(la, oracle):
+    """configs[3]: im2col + gemm conv N=32 C=128 H=W=56 K=256 R=S=3, pad 1 stride 1, device-resident.
+    Image 0 and 31 against the oracle (<= 1e-5, and in fact bit-exact), everything against
+    torch's conv2d on the same GPU within tolerance."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(44)
+    ishape, kshape, pad, st = (32, 128, 56, 56), (256, 128, 3, 3), (1, 1), (1, 1)
+    x = torch.rand(ishape, generator=g, device="cuda")
+    w = torch.rand(kshape, generator=g, device="cuda")
+    oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+    assert oshape == (32, 256, 56, 56)
+    out = torch.zeros(oshape, device="cuda")
+    la.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=pad, stride=st)
+    rel = ((out.double() - ref).abs() / ref.abs().clamp_min(1e-30)).mean().item()
+    assert rel <= 1e-5, rel
+    for n in (0, 31):
+        want = oracle.conv2d_im2col(x[n:n + 1].cpu().numpy(), w.cpu().numpy(), pad, st)
+        assert np.array_equal(out[n:n + 1].cpu().numpy(), want)
