@@ -462,6 +462,13 @@ int laser_hip_set_f32_config(int cfg) {
   return LASER_HIP_OK;
 }
 int laser_hip_f32_config_count(void) { return gemm_f32_config_count(); }
+// tuning probe (not declared in laser_hip.h): contiguous row-major device operands, multiples of 256
+int laser_hip_probe_f32_dev(int64_t n, const float *A, const float *B, float *C, int dbg, void *stream) {
+  if (int rc = ensure_init()) return rc;
+  GemmArgs<float> a = make_args<float>(1, n, n, n, 1.0f, A, n, 1, 0, B, n, 1, 0, 0.0f, C, n, 1, 0);
+  HIP_TRY(launch_gemm_f32_probe(a, dbg, (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
 const char *laser_hip_f32_config_name(int cfg) { return gemm_f32_config_name(cfg); }
 
 #define LH_DEF_GEMM(SFX, T)                                                                                   \

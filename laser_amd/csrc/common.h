@@ -24,6 +24,7 @@ struct GemmArgs {
   int32_t tiles_m, tiles_n;  // grid decomposition (filled by the launcher)
   int32_t kc;                // accumulation slice in k (Laser's kc; 0 = one chain over all K)
   int32_t batch;
+  int32_t dbg;  // ablation switches for the tuning probe build only (0 in production)
 };
 
 // How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of
@@ -33,9 +34,15 @@ enum LoadMode : int {
   LOAD_VEC_K = 1,  // unit stride along k, 16-B vector loads + transposing LDS write, full tiles
   LOAD_GEN_X = 2,  // any strides / ragged edges, scalar predicated loads, lanes run along M/N
   LOAD_GEN_K = 3,  // any strides / ragged edges, scalar predicated loads, lanes run along k
+  // 16-B vector loads on ragged problems (extents multiples of 4, not of the tile): addresses are
+  // clamped into the operand, quads beyond K are replaced by zeros (Laser zero-pads its panels the
+  // same way, gemm_packing.nim:46-55,85-94; rows/cols beyond M/N only feed outputs never stored)
+  LOAD_VEC_X_EDGE = 4,
+  LOAD_VEC_K_EDGE = 5,
 };
 
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
+hipError_t launch_gemm_f32_probe(const GemmArgs<float> &args, int dbg, hipStream_t s);
 int gemm_f32_config_count();
 const char *gemm_f32_config_name(int cfg);
 

@@ -3,62 +3,24 @@
 #include "gemm_f32_cfgs.h"
 #include "gemm_f32_mfma_kernel.h"
 
+#ifndef LH_CFG
+#error "compile with -DLH_CFG=<configuration index>"
+#endif
+
 namespace laser_hip {
 
-template <int BM, int BN, int BK, int WM, int WN, bool WV, bool WG, bool WE>
-static hipError_t run_cfg(const GemmArgs<float> &a, int amode, int bmode, bool exact, hipStream_t s) {
-  if (exact && !WE) return hipErrorNotSupported;
-  if constexpr (WE) {
-    if (exact) return launch_cfg_mode<BM, BN, BK, WM, WN, WV, WG, true>(a, amode, bmode, s);
+template <>
+hipError_t launch_gemm_f32_cfg<LH_CFG>(const GemmArgs<float> &a, int amode, int bmode, bool exact,
+                                       hipStream_t s) {
+  using C = F32Cfg<LH_CFG>;
+  if (exact && !C::EXACT) return hipErrorNotSupported;
+  if constexpr (C::EXACT) {
+    if (exact)
+      return launch_cfg_mode<C::BM, C::BN, C::BK, C::WM, C::WN, C::STAGES, C::OCCE, C::VEC, C::GEN, true>(
+          a, amode, bmode, s);
   }
-  return launch_cfg_mode<BM, BN, BK, WM, WN, WV, WG, false>(a, amode, bmode, s);
+  return launch_cfg_mode<C::BM, C::BN, C::BK, C::WM, C::WN, C::STAGES, C::OCCF, C::VEC, C::GEN, false>(
+      a, amode, bmode, s);
 }
-
-#define LH_CAT2(a, b) a##b
-#define LH_CAT(a, b) LH_CAT2(a, b)
-#define X(IDX, BM, BN, BK, WM, WN, WV, WG, WE)                                                      \
-  LH_IF_##IDX(hipError_t LH_CAT(launch_gemm_f32_cfg, IDX)(const GemmArgs<float> &a, int amode,      \
-                                                         int bmode, bool exact, hipStream_t s) {    \
-    return run_cfg<BM, BN, BK, WM, WN, WV, WG, WE>(a, amode, bmode, exact, s);                      \
-  })
-#define LH_EMPTY(...)
-#define LH_KEEP(...) __VA_ARGS__
-#if LH_CFG == 0
-#define LH_IF_0 LH_KEEP
-#else
-#define LH_IF_0 LH_EMPTY
-#endif
-#if LH_CFG == 1
-#define LH_IF_1 LH_KEEP
-#else
-#define LH_IF_1 LH_EMPTY
-#endif
-#if LH_CFG == 2
-#define LH_IF_2 LH_KEEP
-#else
-#define LH_IF_2 LH_EMPTY
-#endif
-#if LH_CFG == 3
-#define LH_IF_3 LH_KEEP
-#else
-#define LH_IF_3 LH_EMPTY
-#endif
-#if LH_CFG == 4
-#define LH_IF_4 LH_KEEP
-#else
-#define LH_IF_4 LH_EMPTY
-#endif
-#if LH_CFG == 5
-#define LH_IF_5 LH_KEEP
-#else
-#define LH_IF_5 LH_EMPTY
-#endif
-#if LH_CFG == 6
-#define LH_IF_6 LH_KEEP
-#else
-#define LH_IF_6 LH_EMPTY
-#endif
-LH_F32_CONFIGS(X)
-#undef X
 
 }  // namespace laser_hip

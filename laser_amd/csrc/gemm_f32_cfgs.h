@@ -1,13 +1,43 @@
 // laser_amd/csrc/gemm_f32_cfgs.h -- the tile configurations of the f32 MFMA kernel.
-// X(index, BM, BN, BK, WM, WN, WITH_VEC, WITH_GEN, WITH_EXACT)
+// X(index, BM, BN, BK, WM, WN, STAGES, OCC_FAST, OCC_EXACT, WITH_VEC, WITH_GEN, WITH_EXACT)
+//   BM x BN x BK   workgroup tile;  WM x WN  waves (wave tile = BM/WM x BN/WN, built of 32x32 MFMAs)
+//   STAGES         LDS stages (2: barrier per tile end; 3: ring with mid-tile barrier)
+//   OCC_*          waves per SIMD requested from the register allocator (fast / laser-order kernels)
+//   WITH_GEN       also build the predicated scalar loaders (arbitrary strides, ragged edges)
+//   WITH_EXACT     also build the laser-order kernel (needs a second accumulator set in registers)
 // Each line is compiled in its own translation unit (gemm_f32_cfg.hip with -DLH_CFG=index).
 #pragma once
-#define LH_F32_CONFIGS(X)                         \
-  X(0, 128, 128, 32, 2, 2, true, true, true)     \
-  X(1, 256, 128, 32, 4, 2, true, false, true)    \
-  X(2, 128, 128, 16, 2, 2, true, false, true)    \
-  X(3, 128, 256, 32, 2, 4, true, false, true)    \
-  X(4, 64, 64, 32, 2, 2, true, true, true)       \
-  X(5, 256, 256, 16, 2, 4, true, false, false)   \
-  X(6, 256, 128, 16, 4, 2, true, false, true)
-#define LH_F32_NUM_CONFIGS 7
+#include "common.h"
+#define LH_F32_CONFIGS(X)                                        \
+  X(0, 256, 256, 16, 2, 4, 3, 2, 2, true, false, false)          \
+  X(1, 256, 128, 16, 4, 2, 3, 2, 2, true, false, true)           \
+  X(2, 128, 128, 16, 2, 2, 3, 3, 2, true, false, true)           \
+  X(3, 64, 64, 32, 2, 2, 2, 3, 2, true, true, true)
+#define LH_F32_NUM_CONFIGS 4
+// Measured on MI355X at 8192^3 (profiles/r01/sweep_f32_v4.json): cfg 0 fast 138-139 TFLOP/s,
+// cfg 1 laser-order 130-131, cfg 1 fast 135, cfg 2 fast 133 / laser-order 128, cfg 3 117-120.
+// Rejected in the sweep (kept out of the build): 2-stage forms of the same tiles (-3..-8 %), BK=32
+// rings (LDS 144 KiB, -6 %), 4-wave 256x128 / 128x256 tiles at 1 wave/SIMD for laser-order (-8 %).
+
+namespace laser_hip {
+template <int IDX>
+struct F32Cfg;
+#define X(IDX, BM_, BN_, BK_, WM_, WN_, ST_, OF_, OE_, WV_, WG_, WE_)                                  \
+  template <>                                                                                          \
+  struct F32Cfg<IDX> {                                                                                 \
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, STAGES = ST_, OCCF = OF_,   \
+                         OCCE = OE_;                                                                   \
+    static constexpr bool VEC = WV_, GEN = WG_, EXACT = WE_;                                           \
+  };
+LH_F32_CONFIGS(X)
+#undef X
+
+// defined in gemm_f32_cfg.hip (one explicit specialisation per translation unit)
+template <int IDX>
+hipError_t launch_gemm_f32_cfg(const GemmArgs<float> &a, int amode, int bmode, bool exact, hipStream_t s);
+#define X(IDX, ...) \
+  template <>       \
+  hipError_t launch_gemm_f32_cfg<IDX>(const GemmArgs<float> &, int, int, bool, hipStream_t);
+LH_F32_CONFIGS(X)
+#undef X
+}  // namespace laser_hip

@@ -7,20 +7,15 @@
 
 namespace laser_hip {
 
-#define X(IDX, BM, BN, BK, WM, WN, WV, WG, WE) \
-  hipError_t launch_gemm_f32_cfg##IDX(const GemmArgs<float> &, int, int, bool, hipStream_t);
-LH_F32_CONFIGS(X)
-#undef X
-
 struct CfgInfo {
-  int bm, bn, bk, wm, wn;
+  int bm, bn, bk, wm, wn, stages;
   bool vec, gen, exact;
   const char *name;
   hipError_t (*fn)(const GemmArgs<float> &, int, int, bool, hipStream_t);
 };
 
-#define X(IDX, BM, BN, BK, WM, WN, WV, WG, WE) \
-  {BM, BN, BK, WM, WN, WV, WG, WE, #BM "x" #BN "x" #BK "_w" #WM "x" #WN, launch_gemm_f32_cfg##IDX},
+#define X(IDX, BM, BN, BK, WM, WN, ST, OF, OE, WV, WG, WE) \
+  {BM, BN, BK, WM, WN, ST, WV, WG, WE, #BM "x" #BN "x" #BK "_w" #WM "x" #WN "_s" #ST, &launch_gemm_f32_cfg<IDX>},
 static const CfgInfo kCfgs[LH_F32_NUM_CONFIGS] = {LH_F32_CONFIGS(X)};
 #undef X
 
@@ -31,33 +26,44 @@ const char *gemm_f32_config_name(int cfg) {
 
 static inline int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
 
-// Can operand X (panel along `x` with stride sx, k with stride sk) use 16-B vector loads for this
-// tile shape?  Needs: unit stride along one axis, the other stride and the batch stride multiples of
-// 4 elements, 16-B aligned base, and no ragged tile in x or k.
+// Which loader can bring operand X (x = its M/N axis with stride sx, k with stride sk) into LDS?
+//   *vec  : plain 16-B vector loads  -- unit stride on one axis, other stride and batch stride
+//           multiples of 4 elements, 16-B aligned base, no ragged tile in x or k;
+//   *edge : the clamped / zero-selecting 16-B form -- same alignment, extents multiples of 4 only;
+//   otherwise the predicated scalar loaders (GEN) handle anything.
 static int pick_mode(const float *p, int64_t sx, int64_t sk, int64_t bs, int64_t X, int64_t K, int bx,
-                     int bk, bool *vec_ok) {
+                     int bk, bool *vec, bool *edge) {
   const bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (bs % 4 == 0);
   const bool full = (X % bx == 0) && (K % bk == 0);
+  *vec = *edge = false;
   if (sk == 1) {
-    *vec_ok = aligned && full && (sx % 4 == 0);
+    const bool ok = aligned && (sx % 4 == 0);
+    *vec = ok && full;
+    *edge = ok && (K % 4 == 0) && K >= 4 && X >= 1;
     return LOAD_VEC_K;
   }
   if (sx == 1) {
-    *vec_ok = aligned && full && (sk % 4 == 0);
+    const bool ok = aligned && (sk % 4 == 0);
+    *vec = ok && full;
+    *edge = ok && (X % 4 == 0) && X >= 4;
     return LOAD_VEC_X;
   }
-  *vec_ok = false;
   return iabs64(sk) <= iabs64(sx) ? LOAD_VEC_K : LOAD_VEC_X;
 }
 
 static int to_gen(int mode) { return mode == LOAD_VEC_K ? LOAD_GEN_K : LOAD_GEN_X; }
+static int to_edge(int mode) { return mode == LOAD_VEC_K ? LOAD_VEC_K_EDGE : LOAD_VEC_X_EDGE; }
 
+constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3;
+
+// Largest tile that still gives every CU work: >= ~0.8 x 256 workgroups, else the next size down.
 static int heuristic_cfg(const GemmArgs<float> &a, bool exact) {
-  (void)exact;
-  // Small problems: more, smaller tiles so the 256 CUs have something to do.
-  const int64_t tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
-  if (tiles128 < 128) return 4;
-  return 0;
+  auto tiles = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (int64_t)a.batch; };
+  if (!exact && tiles(256, 256) >= 200) return kCfgBig;
+  if (tiles(256, 128) >= 200) return kCfgWide;
+  if (tiles(128, 128) >= 200) return kCfgMid;
+  if (tiles(128, 128) >= 2 * tiles(64, 64) / 5 && tiles(128, 128) >= 96) return kCfgMid;
+  return kCfgSmall;
 }
 
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
@@ -66,17 +72,22 @@ hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_orde
   if (a.Mext < a.M) a.Mext = a.M;
   if (a.Next < a.N) a.Next = a.N;
   if (a.Kext < a.K) a.Kext = a.K;
-  a.kc = laser_order ? 512 : 0;  // gemm_tiling.nim:310: kc = 2048 / sizeof(float32)
-  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, laser_order);
-  if (laser_order && !kCfgs[cfg].exact) cfg = 1;
+  a.dbg = 0;
+  // K <= kc is ONE accumulation slice: the single-chain kernel already is Laser's arithmetic, so the
+  // second accumulator set of the laser-order kernels is only paid for when K > 512.
+  const bool exact = laser_order && a.K > 512;
+  a.kc = exact ? 512 : 0;  // gemm_tiling.nim:310: kc = 2048 / sizeof(float32)
+  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact);
+  if (exact && !kCfgs[cfg].exact) cfg = kCfgWide;
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo &c = kCfgs[cfg];
-    bool va, vb;
-    int am = pick_mode(a.A, a.rsA, a.csA, a.bsA, a.Mext, a.Kext, c.bm, c.bk, &va);
-    int bm = pick_mode(a.B, a.csB, a.rsB, a.bsB, a.Next, a.Kext, c.bn, c.bk, &vb);
-    if (va && vb && c.vec) return c.fn(a, am, bm, laser_order, s);
-    if (c.gen) return c.fn(a, to_gen(am), to_gen(bm), laser_order, s);
-    cfg = (((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch < 128) ? 4 : 0;  // has GEN loaders
+    bool va, vb, ea, eb;
+    const int am = pick_mode(a.A, a.rsA, a.csA, a.bsA, a.Mext, a.Kext, c.bm, c.bk, &va, &ea);
+    const int bm = pick_mode(a.B, a.csB, a.rsB, a.bsB, a.Next, a.Kext, c.bn, c.bk, &vb, &eb);
+    if (c.vec && va && vb) return c.fn(a, am, bm, exact, s);
+    if (c.vec && (va || ea) && (vb || eb)) return c.fn(a, to_edge(am), to_edge(bm), exact, s);
+    if (c.gen) return c.fn(a, to_gen(am), to_gen(bm), exact, s);
+    cfg = kCfgSmall;  // the configuration that carries the scalar (any-stride) loaders
   }
   return hipErrorInvalidValue;
 }

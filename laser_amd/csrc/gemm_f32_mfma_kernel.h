@@ -27,6 +27,8 @@
 //   (c) transposing scalar writes (4 consecutive k of one x per lane, ds_write_b32) are conflict-free
 // with no padding (see DESIGN.md section 3 for the bank arithmetic).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace laser_hip {
@@ -50,8 +52,9 @@ template <int BX, int BK, int NT, int MODE>
 struct TileLoader {
   static constexpr int NV = (BX * BK / 4) / NT;  // 16-B pieces per thread per tile
   static_assert(NV >= 1 && (BX * BK / 4) % NT == 0, "tile must split evenly over the workgroup");
-  static constexpr bool ALONG_K = (MODE == LOAD_VEC_K || MODE == LOAD_GEN_K);
-  static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K);
+  static constexpr bool ALONG_K = (MODE == LOAD_VEC_K || MODE == LOAD_GEN_K || MODE == LOAD_VEC_K_EDGE);
+  static constexpr bool EDGE = (MODE == LOAD_VEC_X_EDGE || MODE == LOAD_VEC_K_EDGE);
+  static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || EDGE);
   f32x4 v[NV];
 
   // base: element (x=0,k=0) of this workgroup's operand panel; sx/sk element strides along x / k;
@@ -59,62 +62,104 @@ struct TileLoader {
   __device__ __forceinline__ void load(const float *__restrict__ base, int64_t sx, int64_t sk,
                                        int64_t k0, int64_t xlim, int64_t klim, int t) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const int idx = t + i * NT;
-      if constexpr (!ALONG_K) {
-        const int xq = idx % (BX / 4), k = idx / (BX / 4);
-        if constexpr (VEC) {
-          v[i] = *reinterpret_cast<const f32x4 *>(base + (k0 + k) * sk + 4 * xq);
-        } else {
-          const int64_t kk = k0 + k;
-          const float *p = base + kk * sk + (int64_t)(4 * xq) * sx;
-          const bool kin = kk < klim;
-#pragma unroll
-          for (int c = 0; c < 4; c++) v[i][c] = (kin && (4 * xq + c) < xlim) ? p[c * sx] : 0.0f;
-        }
-      } else {
-        const int kq = idx % (BK / 4), x = idx / (BK / 4);
-        if constexpr (VEC) {
-          v[i] = *reinterpret_cast<const f32x4 *>(base + (int64_t)x * sx + k0 + 4 * kq);
-        } else {
-          const int64_t kk = k0 + 4 * kq;
-          const float *p = base + (int64_t)x * sx + kk * sk;
-          const bool xin = x < xlim;
-#pragma unroll
-          for (int c = 0; c < 4; c++) v[i][c] = (xin && (kk + c) < klim) ? p[c * sk] : 0.0f;
-        }
-      }
-    }
+    for (int i = 0; i < NV; i++) load_op(base, sx, sk, k0, xlim, klim, t, i);
   }
 
   __device__ __forceinline__ void store(float *__restrict__ lds, int t) const {
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const int idx = t + i * NT;
-      if constexpr (!ALONG_K) {
-        const int xq = idx % (BX / 4), k = idx / (BX / 4);
-        *reinterpret_cast<f32x4 *>(lds + k * BX + ((4 * xq) ^ swz<BK>(k))) = v[i];
-      } else {
-        const int kq = idx % (BK / 4), x = idx / (BK / 4);
-        const int xs = x ^ swz<BK>(4 * kq);
+    for (int i = 0; i < NV; i++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) lds[(4 * kq + c) * BX + xs] = v[i][c];
+      for (int c = 0; c < WOPS; c++) store_op(lds, t, i, c);
+  }
+
+  // The same work cut into single-instruction "ops" so the main loop can slot one op between two
+  // MFMAs instead of issuing the whole staging block at once (which idles the matrix pipe):
+  //   piece i (one 16-B register quad):  WOPS LDS-write ops (4 x ds_write_b32 when transposing,
+  //   1 x ds_write_b128 otherwise), then 1 load op that refills the quad for the tile after next.
+  static constexpr int WOPS = ALONG_K ? 4 : 1;
+  static constexpr int OPS_PER_PIECE = WOPS + 1;
+  static constexpr int NOPS = NV * OPS_PER_PIECE;
+
+  __device__ __forceinline__ void store_op(float *__restrict__ lds, int t, int i, int c) const {
+    const int idx = t + i * NT;
+    if constexpr (!ALONG_K) {
+      const int xq = idx % (BX / 4), k = idx / (BX / 4);
+      *reinterpret_cast<f32x4 *>(lds + k * BX + ((4 * xq) ^ swz<BK>(k))) = v[i];
+    } else {
+      const int kq = idx % (BK / 4), x = idx / (BK / 4);
+      const int xs = x ^ swz<BK>(4 * kq);
+      lds[(4 * kq + c) * BX + xs] = v[i][c];
+    }
+  }
+
+  __device__ __forceinline__ void load_op(const float *__restrict__ base, int64_t sx, int64_t sk, int64_t k0,
+                                          int64_t xlim, int64_t klim, int t, int i) {
+    const int idx = t + i * NT;
+    if constexpr (!ALONG_K) {
+      const int xq = idx % (BX / 4), k = idx / (BX / 4);
+      if constexpr (VEC && !EDGE) {
+        v[i] = *reinterpret_cast<const f32x4 *>(base + (k0 + k) * sk + 4 * xq);
+      } else if constexpr (EDGE) {
+        // xlim % 4 == 0 (checked by the dispatcher): a quad is entirely inside or outside in x
+        const int64_t kk = k0 + k;
+        const bool kin = kk < klim;
+        const int64_t xc = (4 * xq < xlim) ? 4 * xq : xlim - 4;
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(base + (kin ? kk : 0) * sk + xc);
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v[i] = kin ? q : z;
+      } else {
+        const int64_t kk = k0 + k;
+        const float *p = base + kk * sk + (int64_t)(4 * xq) * sx;
+        const bool kin = kk < klim;
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[i][c] = (kin && (4 * xq + c) < xlim) ? p[c * sx] : 0.0f;
+      }
+    } else {
+      const int kq = idx % (BK / 4), x = idx / (BK / 4);
+      if constexpr (VEC && !EDGE) {
+        v[i] = *reinterpret_cast<const f32x4 *>(base + (int64_t)x * sx + k0 + 4 * kq);
+      } else if constexpr (EDGE) {
+        // klim % 4 == 0 (checked by the dispatcher): a quad is entirely inside or outside in k
+        const int64_t kk = k0 + 4 * kq;
+        const bool kin = kk < klim;
+        const int64_t xc = (x < xlim) ? x : xlim - 1;
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(base + xc * sx + (kin ? kk : 0));
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v[i] = kin ? q : z;
+      } else {
+        const int64_t kk = k0 + 4 * kq;
+        const float *p = base + (int64_t)x * sx + kk * sk;
+        const bool xin = x < xlim;
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[i][c] = (xin && (kk + c) < klim) ? p[c * sk] : 0.0f;
       }
     }
   }
 };
 
 // ---- the kernel -----------------------------------------------------------------------------------
-// __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for:
-// 256-thread workgroups ask for 2-3 (several workgroups per CU share each SIMD, so one workgroup's
-// MFMAs cover another's barrier / LDS-fill bubbles); 512-thread workgroups already put 2 on a SIMD.
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT>
-__global__ void __launch_bounds__(WM *WN * 64, (WM * WN * 64 >= 512) ? 2 : (EXACT ? 2 : 3))
+// STAGES = 2: double-buffered LDS, one barrier at the end of every K-tile (fill next stage, barrier).
+// STAGES = 3: LDS ring with the barrier in the MIDDLE of the K-tile's MFMA stream:
+//     iteration t:  R (tile t+1, loaded during t-1) -> LDS[(t+1)%3] ; issue HBM loads of tile t+2 -> R ;
+//                   first half of tile t's MFMAs ; barrier ; second half ; prefetch tile t+1's first
+//                   fragments.  The stage written in iteration t was last read in iteration t-2, and
+//                   every wave has passed barrier t-1 => finished t-2: no WAR race; reads of tile t+1
+//                   start only after barrier t => after every wave's stores: no RAW race.  The
+//                   vmcnt -> ds_write -> lgkmcnt -> barrier -> ds_read chain that idles the matrix
+//                   pipe at every tile boundary of the 2-stage form disappears.
+// Fragments are register double-buffered (k-step j+1 is read from LDS while step j's MFMAs issue).
+//
+// __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for.
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
+          bool DBG = false>
+__global__ void __launch_bounds__(WM *WN * 64, OCC)
     gemm_f32_mfma_kernel(const GemmArgs<float> g) {
   constexpr int NT = WM * WN * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int NJ = BK / 2;  // MFMA k-steps (k-pairs) per K-tile
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be built from 32x32 MFMA blocks");
+  static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
   constexpr int STAGE = BK * (BM + BN);  // floats per LDS stage: A panel then B panel
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -161,7 +206,7 @@ __global__ void __launch_bounds__(WM *WN * 64, (WM * WN * 64 >= 512) ? 2 : (EXAC
   const float alpha = g.alpha, beta = g.beta;
 
   // C element owned by (i, n, r): row = wm0 + 32 i + (r&3) + 8 (r>>2) + 4 hi, col = wn0 + 32 n + lo
-  auto c_ptr = [&](int i, int n, int r, bool &ok) -> float * {
+  auto c_ptr = [&](int i, int n, int r, bool &ok) __attribute__((always_inline)) -> float * {
     const int64_t row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
     const int64_t col = n0 + wn0 + 32 * n + lo;
     ok = (row < g.M) && (col < g.N);
@@ -169,7 +214,7 @@ __global__ void __launch_bounds__(WM *WN * 64, (WM * WN * 64 >= 512) ? 2 : (EXAC
   };
   // beta*C0 exactly as the reference's epilogues do it: beta == 0 -> 0 without reading C,
   // beta == 1 -> C, else C*beta (one rounding)  [gemm_ukernel_generic.nim:59-66, 107-115]
-  auto scaled_c0 = [&](int i, int n, int r) -> float {
+  auto scaled_c0 = [&](int i, int n, int r) __attribute__((always_inline)) -> float {
     if (beta == 0.0f) return 0.0f;
     bool ok;
     const float *p = c_ptr(i, n, r, ok);
@@ -177,7 +222,7 @@ __global__ void __launch_bounds__(WM *WN * 64, (WM * WN * 64 >= 512) ? 2 : (EXAC
     return beta == 1.0f ? c0 : __fmul_rn(c0, beta);
   };
   // C += AB or C += alpha*AB, unfused  [gemm_ukernel_generic.nim:68-76]
-  auto axpy = [&](float run, float ab) -> float {
+  auto axpy = [&](float run, float ab) __attribute__((always_inline)) -> float {
     return __fadd_rn(run, alpha == 1.0f ? ab : __fmul_rn(alpha, ab));
   };
 
@@ -194,62 +239,173 @@ __global__ void __launch_bounds__(WM *WN * 64, (WM * WN * 64 >= 512) ? 2 : (EXAC
   const int nkt = (int)((K + BK - 1) / BK);
   const int kc_tiles = EXACT ? (g.kc / BK) : 0;
 
-  // -- prologue: tile 0 -> LDS stage 0 --
-  la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
-  lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t);
-  la.store(smem, t);
-  lb.store(smem + BK * BM, t);
-  __syncthreads();
-
-  int until_fold = kc_tiles;
-  for (int kt = 0; kt < nkt; kt++) {
-    const float *sA = smem + (kt & 1) * STAGE;
-    const float *sB = sA + BK * BM;
-    const bool more = (kt + 1) < nkt;
-    if (more) {  // issue the next tile's HBM loads before the MFMA block (latency hides under it)
-      la.load(Ab, g.rsA, g.csA, (int64_t)(kt + 1) * BK, mlim, K, t);
-      lb.load(Bb, g.csB, g.rsB, (int64_t)(kt + 1) * BK, nlim, K, t);
-    }
-
+  // fragment of k-step j: lanes 0-31 feed k = 2j, lanes 32-63 feed k = 2j+1 -> ascending-k chain
+  float fa[2][TM], fb[2][TN];
+  auto ldfrag = [&](const float *sA, const float *sB, int j, int slot) __attribute__((always_inline)) {
+    const int k = 2 * j + hi;
+    const int s = swz<BK>(2 * j);
 #pragma unroll
-    for (int j = 0; j < BK / 2; j++) {
-      const int k = 2 * j + hi;  // lanes 0-31 feed k=2j, lanes 32-63 feed k=2j+1: ascending-k chain
-      const int s = swz<BK>(2 * j);
-      float a[TM], b[TN];
+    for (int i = 0; i < TM; i++) fa[slot][i] = sA[k * BM + wm0 + 32 * i + (lo ^ s)];
 #pragma unroll
-      for (int i = 0; i < TM; i++) a[i] = sA[k * BM + wm0 + 32 * i + (lo ^ s)];
+    for (int n = 0; n < TN; n++) fb[slot][n] = sB[k * BN + wn0 + 32 * n + (lo ^ s)];
+  };
+  auto mfma_step = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
-      for (int n = 0; n < TN; n++) b[n] = sB[k * BN + wn0 + 32 * n + (lo ^ s)];
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int n = 0; n < TN; n++)
+        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i], fb[slot][n], acc[i][n], 0, 0, 0);
+  };
+  // Laser's pc loop: the micro-kernel accumulator restarts at +0 for every kc slice and the slice sum
+  // is added into C (gemm.nim:150-158; ukernel zero-init gemm_ukernel_generator.nim:189)
+  auto fold = [&]() __attribute__((always_inline)) {
+    if constexpr (EXACT) {
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int n = 0; n < TN; n++)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[n], acc[i][n], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            run[i][n][r] = axpy(run[i][n][r], acc[i][n][r]);
+            acc[i][n][r] = 0.0f;
+          }
     }
+  };
 
-    if constexpr (EXACT) {
-      // Laser's pc loop: the micro-kernel accumulator restarts at +0 for every kc slice and the
-      // slice sum is added into C (gemm.nim:150-158; ukernel zero-init gemm_ukernel_generator.nim:189)
-      if (--until_fold == 0 && more) {
-        until_fold = kc_tiles;
+  int until_fold = kc_tiles;
+
+  if constexpr (STAGES == 2) {
+    // -- prologue: tile 0 -> LDS stage 0 --
+    la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
+    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t);
+    la.store(smem, t);
+    lb.store(smem + BK * BM, t);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+      const float *sA = smem + (kt & 1) * STAGE;
+      const float *sB = sA + BK * BM;
+      const bool more = (kt + 1) < nkt;
+      if (more) {  // issue the next tile's HBM loads before the MFMA block (latency hides under it)
+        la.load(Ab, g.rsA, g.csA, (int64_t)(kt + 1) * BK, mlim, K, t);
+        lb.load(Bb, g.csB, g.rsB, (int64_t)(kt + 1) * BK, nlim, K, t);
+      }
+      ldfrag(sA, sB, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        if (j + 1 < NJ) ldfrag(sA, sB, j + 1, (j + 1) & 1);
+        // pin the order "LDS reads of step j+1, then MFMAs of step j": without it hipcc sinks each
+        // ds_read down to its first use and every MFMA group eats the full LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(j & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (EXACT) {
+        if (--until_fold == 0 && more) {
+          until_fold = kc_tiles;
+          fold();
+        }
+      }
+      if (more) {
+        float *dA = smem + ((kt + 1) & 1) * STAGE;
+        la.store(dA, t);
+        lb.store(dA + BK * BM, t);
+      }
+      __syncthreads();
+    }
+  } else {
+    // -- prologue: tile 0 -> LDS stage 0; tile 1 -> registers --
+    la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
+    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t);
+    la.store(smem, t);
+    lb.store(smem + BK * BM, t);
+    if (nkt > 1) {
+      la.load(Ab, g.rsA, g.csA, BK, mlim, K, t);
+      lb.load(Bb, g.csB, g.rsB, BK, nlim, K, t);
+    }
+    __syncthreads();
+    ldfrag(smem, smem + BK * BM, 0, 0);
+    int st = 0;  // stage holding tile kt
+    // One K-tile.  MORE / MORE2 (tile kt+1 / kt+2 exist) are compile-time so that the steady-state
+    // body is ONE basic block: hipcc then derives exact counted `s_waitcnt vmcnt(N)` for the
+    // interleaved loads; with run-time guards every staging op became its own block behind a
+    // conservative vmcnt(0), i.e. a full HBM round trip per op.
+    auto k_tile = [&](auto MORE_, auto MORE2_, int kt) __attribute__((always_inline)) {
+      constexpr bool more = decltype(MORE_)::value, more2 = decltype(MORE2_)::value;
+      const float *sA = smem + st * STAGE;
+      const float *sB = sA + BK * BM;
+      const int st1 = (st == 2) ? 0 : st + 1;
+      const float *nA = smem + st1 * STAGE;
+      const float *nB = nA + BK * BM;
+      float *wA = smem + st1 * STAGE;
+      float *wB = wA + BK * BM;
+      const int64_t k2 = (int64_t)(kt + 2) * BK;
+      // staging op `o` of this iteration: A pieces first, then B pieces; per piece its LDS writes
+      // (tile kt+1, from registers) followed by the HBM load that refills the registers (tile kt+2)
+      auto staging_op = [&](int o) __attribute__((always_inline)) {
+        constexpr int NA = decltype(la)::NOPS, NB = decltype(lb)::NOPS;
+        if (o < NA) {
+          constexpr int P = decltype(la)::OPS_PER_PIECE;
+          const int i = o / P, c = o % P;
+          if (c < P - 1) {
+            if (!DBG || !(g.dbg & 2)) la.store_op(wA, t, i, c);
+          } else if (more2 && (!DBG || !(g.dbg & 1))) {
+            la.load_op(Ab, g.rsA, g.csA, k2, mlim, K, t, i);
+          }
+        } else if (o < NA + NB) {
+          constexpr int P = decltype(lb)::OPS_PER_PIECE;
+          const int i = (o - NA) / P, c = (o - NA) % P;
+          if (c < P - 1) {
+            if (!DBG || !(g.dbg & 2)) lb.store_op(wB, t, i, c);
+          } else if (more2 && (!DBG || !(g.dbg & 1))) {
+            lb.load_op(Bb, g.csB, g.rsB, k2, nlim, K, t, i);
+          }
+        }
+      };
+      constexpr int NOPS = decltype(la)::NOPS + decltype(lb)::NOPS;
+      constexpr int NMF = TM * TN;                     // MFMA slots per k-step
+      constexpr int SLOTS = (NJ / 2) * NMF;            // slots before the mid-tile barrier
+      constexpr int PER = (NOPS + SLOTS - 1) / SLOTS;  // staging ops per slot (1 unless the tile is tiny)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        // everyone's stores of tile kt+1 are done past this point
+        if (j == NJ / 2 && (!DBG || !(g.dbg & 4))) __syncthreads();
+        if (j + 1 < NJ)
+          ldfrag(sA, sB, j + 1, (j + 1) & 1);
+        else if (more)
+          ldfrag(nA, nB, 0, (j + 1) & 1);  // NJ even => slot 0: first fragments of the next tile
+        // pin the order "LDS reads of step j+1, then MFMAs of step j": without it hipcc sinks each
+        // ds_read down to its first use and every MFMA group eats the full LDS latency
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int n = 0; n < TN; n++)
+          for (int n = 0; n < TN; n++) {
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][i], fb[j & 1][n], acc[i][n], 0, 0, 0);
+            if (more && j < NJ / 2) {
+              const int slot = j * NMF + i * TN + n;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-              run[i][n][r] = axpy(run[i][n][r], acc[i][n][r]);
-              acc[i][n][r] = 0.0f;
+              for (int q = 0; q < PER; q++) staging_op(slot * PER + q);
             }
+            __builtin_amdgcn_sched_barrier(0);  // one staging op rides behind each MFMA
+          }
       }
+      if constexpr (EXACT) {
+        if (--until_fold == 0 && more) {
+          until_fold = kc_tiles;
+          fold();
+        }
+      }
+      st = st1;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < nkt; kt++) k_tile(T_{}, T_{}, kt);
+    if (kt + 1 < nkt) {
+      k_tile(T_{}, F_{}, kt);
+      kt++;
     }
-
-    if (more) {
-      float *dA = smem + ((kt + 1) & 1) * STAGE;
-      la.store(dA, t);
-      lb.store(dA + BK * BM, t);
-    }
-    __syncthreads();
+    if (kt < nkt) k_tile(F_{}, F_{}, kt);
   }
 
   // -- epilogue: last (or only) slice, then store with the caller's strides --
@@ -272,10 +428,12 @@ __global__ void __launch_bounds__(WM *WN * 64, (WM * WN * 64 >= 512) ? 2 : (EXAC
 }
 
 // ---- per-configuration launcher ---------------------------------------------------------------------
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT>
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
+          bool DBG = false>
 hipError_t launch_one(const GemmArgs<float> &a, hipStream_t s) {
-  auto kern = gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, AMODE, BMODE, EXACT>;
-  constexpr size_t lds = 2 * BK * (BM + BN) * sizeof(float);
+  auto kern = gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, AMODE, BMODE, EXACT, STAGES, OCC, DBG>;
+  constexpr size_t lds = (size_t)STAGES * BK * (BM + BN) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget is 160 KiB per CU");
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -292,15 +450,19 @@ hipError_t launch_one(const GemmArgs<float> &a, hipStream_t s) {
 }
 
 // dispatch over the loader modes for one tile configuration
-template <int BM, int BN, int BK, int WM, int WN, bool WITH_VEC, bool WITH_GEN, bool EXACT>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int OCC, bool WITH_VEC, bool WITH_GEN, bool EXACT>
 hipError_t launch_cfg_mode(const GemmArgs<float> &a, int amode, int bmode, hipStream_t s) {
 #define LH_CASE(AM, BMD) \
-  if (amode == AM && bmode == BMD) return launch_one<BM, BN, BK, WM, WN, AM, BMD, EXACT>(a, s);
+  if (amode == AM && bmode == BMD) return launch_one<BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC>(a, s);
   if constexpr (WITH_VEC) {
     LH_CASE(LOAD_VEC_K, LOAD_VEC_X)
     LH_CASE(LOAD_VEC_K, LOAD_VEC_K)
     LH_CASE(LOAD_VEC_X, LOAD_VEC_X)
     LH_CASE(LOAD_VEC_X, LOAD_VEC_K)
+    LH_CASE(LOAD_VEC_K_EDGE, LOAD_VEC_X_EDGE)
+    LH_CASE(LOAD_VEC_K_EDGE, LOAD_VEC_K_EDGE)
+    LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_X_EDGE)
+    LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_K_EDGE)
   }
   if constexpr (WITH_GEN) {
     LH_CASE(LOAD_GEN_K, LOAD_GEN_X)

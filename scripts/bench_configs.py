@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Time every BASELINE.json config (plus the data-movement primitives and the integer path) on one
+MI355X, device-resident unless stated.  One JSON line per measurement -> gpurun_out/configs.jsonl."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import laser_amd
+
+PEAK_TF, PEAK_HBM = 157.3, 8000.0
+OUT = []
+
+
+def ev_time(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(iters):
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def emit(**kw):
+    OUT.append(kw)
+    print(json.dumps(kw), flush=True)
+
+
+def rnd(shape, seed, lo=-0.1, hi=0.1):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.rand(shape, generator=g, device="cuda") * (hi - lo) + lo
+
+
+def gemm_case(name, M, N, K, Aview, Bview, Cview, modes=(0, 1)):
+    for mode in modes:
+        laser_amd.set_float_mode(mode)
+        med, mn = ev_time(lambda: laser_amd.matmul(Aview, Bview, 1, 0, Cview))
+        tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
+        emit(config=name, mode="laser_order" if mode == 0 else "fast", M=M, N=N, K=K, ms_med=round(med, 4),
+             ms_min=round(mn, 4), tflops=round(tf, 2), frac_mfma_peak=round(tf / PEAK_TF, 4))
+    laser_amd.set_float_mode(0)
+
+
+def main():
+    # C1: 128^3 (launch-latency bound: report time)
+    A, B, C = rnd((128, 128), 1), rnd((128, 128), 2), torch.zeros((128, 128), device="cuda")
+    gemm_case("C1 fp32 128^3 device-resident", 128, 128, 128, A, B, C, modes=(0,))
+    Ah, Bh, Ch = A.cpu().numpy(), B.cpu().numpy(), np.zeros((128, 128), np.float32)
+    laser_amd.matmul(Ah, Bh, 1, 0, Ch)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        laser_amd.matmul(Ah, Bh, 1, 0, Ch)
+    emit(config="C1 fp32 128^3 host-pointer end-to-end", ms_med=round((time.perf_counter() - t0) / 20 * 1e3, 4))
+    # C2: 8192^3
+    n = 8192
+    A, B, C = rnd((n, n), 3), rnd((n, n), 4), torch.zeros((n, n), device="cuda")
+    gemm_case("C2 fp32 8192^3 contiguous", n, n, n, A, B, C)
+    # C2 host-pointer end-to-end (PCIe inclusive, pageable host memory)
+    Ah, Bh, Ch = A.cpu().numpy(), B.cpu().numpy(), np.zeros((n, n), np.float32)
+    laser_amd.matmul(Ah, Bh, 1, 0, Ch)
+    t0 = time.perf_counter(); laser_amd.matmul(Ah, Bh, 1, 0, Ch); dt = time.perf_counter() - t0
+    emit(config="C2 fp32 8192^3 host-pointer end-to-end (H2D A,B + kernel + D2H C, pageable)", ms_med=round(dt * 1e3, 2),
+         tflops=round(2.0 * n ** 3 / dt / 1e12, 2))
+    del Ah, Bh, Ch
+    # C3: strided / transposed-B 4096^3
+    n = 4096
+    Abig, Bt, Cbuf = rnd((2 * n, n), 5), rnd((n, n), 6), torch.zeros((n, 2 * n), device="cuda")
+    gemm_case("C3 fp32 4096^3 B transposed (rsB=1,csB=K), A contiguous", n, n, n, Abig[:n], Bt.t(), Cbuf[:, :n].contiguous())
+    gemm_case("C3 fp32 4096^3 A every-2nd-row view, B transposed, C colStride 2", n, n, n, Abig[::2], Bt.t(), Cbuf[:, ::2])
+    gemm_case("C3 fp32 4096^3 A column-major, B row-major", n, n, n, Bt.t(), Abig[:n], Cbuf[:, :n].contiguous())
+    # C4: conv
+    ishape, kshape, pad, st = (32, 128, 56, 56), (256, 128, 3, 3), (1, 1), (1, 1)
+    x, w = rnd(ishape, 7, 0, 1), rnd(kshape, 8, 0, 1)
+    oshape = laser_amd.conv2d_out_shape(ishape, kshape, pad, st)
+    out = torch.zeros(oshape, device="cuda")
+    ws = torch.empty(ishape[0] * laser_amd.im2col_workspace_size(ishape, kshape, pad, st), device="cuda")
+    flops = 2.0 * oshape[0] * oshape[1] * oshape[2] * oshape[3] * kshape[1] * 9
+    for mode in (0, 1):
+        laser_amd.set_float_mode(mode)
+        med, mn = ev_time(lambda: laser_amd.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, ws))
+        emit(config="C4 conv 32x128x56x56 * 256x128x3x3 pad1 stride1 (im2col kernel + batched GEMM)",
+             mode="laser_order" if mode == 0 else "fast", ms_med=round(med, 4), ms_min=round(mn, 4),
+             tflops=round(flops / (med * 1e-3) / 1e12, 2), frac_mfma_peak=round(flops / (med * 1e-3) / 1e12 / PEAK_TF, 4))
+    laser_amd.set_float_mode(0)
+    L = laser_amd.lib()
+    med, mn = ev_time(lambda: L.laser_hip_im2col_f32_dev(ws.data_ptr(), 56, 56, x.data_ptr(), 32, 128, 56, 56, 3, 3, 1, 1, 1, 1,
+                                                         torch.cuda.current_stream().cuda_stream))
+    byts = (x.numel() + ws.numel()) * 4.0
+    emit(config="C4 im2col alone (HBM-bound)", ms_med=round(med, 4), gbps=round(byts / (med * 1e-3) / 1e9, 1),
+         frac_hbm_peak=round(byts / (med * 1e-3) / 1e9 / PEAK_HBM, 4))
+    # transposes (reference bench shape 4000x2000, plus the C3 helper 4096^2)
+    for (r, c) in [(4000, 2000), (4096, 4096), (16384, 8192)]:
+        s = rnd((r, c), 9)
+        d = torch.empty((c, r), device="cuda")
+        med, mn = ev_time(lambda: laser_amd.transpose2D_copy(d, s, r, c), iters=9)
+        byts = 2.0 * r * c * 4
+        emit(config=f"transpose2D_copy {r}x{c} f32", ms_med=round(med, 4), gbps=round(byts / (med * 1e-3) / 1e9, 1),
+             frac_hbm_peak=round(byts / (med * 1e-3) / 1e9 / PEAK_HBM, 4))
+    # integer / f64 GEMM (VALU kernels), reference bench shapes
+    for dt, n in [(torch.int32, 1920), (torch.int32, 4096), (torch.int64, 960), (torch.float64, 960), (torch.float64, 4096)]:
+        if dt.is_floating_point:
+            A = (torch.rand((n, n), device="cuda", dtype=dt) - 0.5) * 0.2
+            B = (torch.rand((n, n), device="cuda", dtype=dt) - 0.5) * 0.2
+        else:
+            A = torch.randint(0, 101, (n, n), device="cuda", dtype=dt)
+            B = torch.randint(0, 101, (n, n), device="cuda", dtype=dt)
+        C = torch.zeros((n, n), device="cuda", dtype=dt)
+        med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C))
+        emit(config=f"gemm {str(dt).replace('torch.', '')} {n}^3", ms_med=round(med, 4), tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/configs.jsonl", "w") as f:
+        for r in OUT:
+            f.write(json.dumps(r) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,7 @@ def main():
     sizes = [int(s) for s in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["8192", "4096"])]
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     cfgs = laser_amd.f32_configs()
+    only = set(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
     results = []
     for n in sizes:
         g = torch.Generator(device="cuda").manual_seed(1)
@@ -35,6 +36,8 @@ def main():
         C = torch.zeros((n, n), device="cuda")
         variants = []
         for ci, name in enumerate(cfgs):
+            if only is not None and ci not in only:
+                continue
             for mode in (0, 1):
                 for lay, (Av, Bv) in (("nn", (A, B)), ("nt", (A, Bt))):
                     variants.append((ci, name, mode, lay, Av, Bv))

@@ -77,7 +77,8 @@ def test_reference_conv_kats(la, kats):
 
 SHAPES = [(128, 128, 128),      # BASELINE configs[0]
           (1, 1, 1), (3, 5, 7), (129, 131, 515), (257, 255, 1030), (64, 300, 33), (512, 384, 1024),
-          (31, 1000, 2), (700, 17, 520)]
+          (31, 1000, 2), (700, 17, 520),
+          (260, 136, 516), (4, 4, 4), (1028, 516, 1540), (256, 3136, 1152)]   # ragged but 4-aligned: EDGE vector loaders
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -137,20 +138,23 @@ def test_semantics_beta0_nan_and_k0(la):
 
 def test_every_f32_tile_config_bit_exact(la, oracle):
     rng = np.random.default_rng(13)
-    M, N, K = 512, 768, 1056      # multiples of every tile; 3 kc slices (2 full + ragged)
-    A = rand(rng, (M, K), np.float32)
-    B = rand(rng, (K, N), np.float32)
-    Bt = np.ascontiguousarray(B.T)
-    Acm = np.asfortranarray(A)
-    want = oracle.matmul(A, B)
-    try:
-        for cfg, name in enumerate(la.f32_configs()):
-            la.set_f32_config(cfg)
-            for Av, Bv in [(A, B), (A, Bt.T), (Acm, B), (Acm, Bt.T)]:
-                got = la.matmul(Av, Bv)
-                assert np.array_equal(got, want), (name, Av.strides, Bv.strides)
-    finally:
-        la.set_f32_config(-1)
+    # (512, 768, 1056): multiples of every tile, 3 kc slices (2 full + ragged) -> plain vector loaders;
+    # (516, 772, 1060): 4-aligned but ragged against every tile -> EDGE vector loaders;
+    # (515, 770, 1057): nothing aligned -> scalar loaders (forces the fallback configuration)
+    for (M, N, K) in [(512, 768, 1056), (516, 772, 1060), (515, 770, 1057)]:
+        A = rand(rng, (M, K), np.float32)
+        B = rand(rng, (K, N), np.float32)
+        Bt = np.ascontiguousarray(B.T)
+        Acm = np.asfortranarray(A)
+        want = oracle.matmul(A, B)
+        try:
+            for cfg, name in enumerate(la.f32_configs()):
+                la.set_f32_config(cfg)
+                for Av, Bv in [(A, B), (A, Bt.T), (Acm, B), (Acm, Bt.T)]:
+                    got = la.matmul(Av, Bv)
+                    assert np.array_equal(got, want), (name, (M, N, K), Av.strides, Bv.strides)
+        finally:
+            la.set_f32_config(-1)
 
 
 def test_f32_fast_mode_within_tolerance(la, oracle):
