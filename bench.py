@@ -82,6 +82,18 @@ def cpu_baseline(budget_s=15.0):
                       f"(oracle/), OpenMP {threads} threads, ukernel {names.get(isa)}, {t:.2f} s; host {model}"}
 
 
+def pmc_traffic(mode):
+    """HBM-side bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, in bytes).
+    Counters cannot be collected inside this process, so this is the latest committed measurement
+    of the same kernel on the same shape, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(mode)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +205,28 @@ def main():
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                                "kernel": "gemm_f32_mfma_kernel", "kernel_ms": round(k_ms, 4),
                                "algorithmic_flops_per_launch": 2.0 * n * n * n}
+            tr = pmc_traffic(mode)
+            if tr is not None:
+                out["roofline"]["traffic"] = tr["bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr["source"]
+            # the other accumulation mode, same operands, same protocol (reported, not `value`)
+            other = 1 if mode == "laser_order" else 0
+            laser_amd.set_float_mode(other)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+            o_ms = e0.elapsed_time(e1) / args.steps
+            laser_amd.set_float_mode(1 - other)
+            o_tf = 2.0 * n * n * n / (o_ms * 1e-3) / 1e12
+            out["config"]["other_mode"] = {"accumulation": "fast" if other == 1 else "laser_order",
+                                           "ms_per_step": round(o_ms, 4), "gflops": round(o_tf * 1e3, 1),
+                                           "frac_mfma_peak": round(o_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1,0 +1,176 @@
+# nim/laser_hip.nim -- the shim a Laser maintainer adds to route the GEMM hot path to an MI355X.
+#
+# Every exported proc below keeps the SIGNATURE of the reference proc it replaces (file:line given
+# per proc) and forwards to the monomorphic C-ABI symbol of liblaser_hip.so (include/laser_hip.h).
+# FFI idiom is the one the reference already uses for OpenBLAS (benchmarks/third_party/blas.nim:
+# 18-23: `{.dynlib: blas, importc: "cblas_sgemm".}`) and for libjit (gemm_bench_float32.nim:199-202).
+#
+# NOTE: delivered as SOURCE.  The build image has no Nim compiler (probed: nim/nimble absent, no
+# network), so this file has not been compiled; the C-ABI itself is exercised from C++
+# (include/laser.hpp) and Python ctypes (laser_amd/primitives.py, tests/).
+#
+# Usage inside Laser: `import laser_hip` instead of `./gemm` / `./gemm_prepacked` /
+# `../swapaxes` / `./conv2d_im2col`; call sites do not change.
+
+const laserHip* = "liblaser_hip.so"
+
+{.pragma: lh, cdecl, dynlib: laserHip.}
+
+proc laser_hip_last_error(): cstring {.lh, importc.}
+proc laser_hip_init*(device: cint): cint {.lh, importc.}
+proc laser_hip_finalize*(): cint {.lh, importc.}
+proc laser_hip_set_float_mode*(mode: cint): cint {.lh, importc.}   # 0 = Laser order (default), 1 = fast
+
+template check(rc: cint) =
+  # the reference procs return void and doAssert on precondition violations
+  # (gemm_prepacked.nim:125,208; conv2d_im2col.nim:109); keep that contract
+  let code = rc
+  doAssert code == 0, "laser_hip error " & $code & ": " & $laser_hip_last_error()
+
+# ---- C-ABI imports (Nim int == int64 on amd64, float32 == C float) ---------------------------
+template importGemm(sfx: untyped, T: typedesc) =
+  proc `laser_hip_gemm_strided sfx`(M, N, K: int, alpha: T, A: ptr T, rsA, csA: int,
+      B: ptr T, rsB, csB: int, beta: T, C: ptr T, rsC, csC: int): cint {.lh, importc.}
+  proc `laser_hip_gemm_prepackA_mem_required sfx`(M, N, K: int): int {.lh, importc.}
+  proc `laser_hip_gemm_prepackB_mem_required sfx`(M, N, K: int): int {.lh, importc.}
+  proc `laser_hip_gemm_prepackA sfx`(dst: pointer, M, N, K: int, A: ptr T, rs, cs: int): cint {.lh, importc.}
+  proc `laser_hip_gemm_prepackB sfx`(dst: pointer, M, N, K: int, B: ptr T, rs, cs: int): cint {.lh, importc.}
+  proc `laser_hip_gemm_packed sfx`(M, N, K: int, alpha: T, pA, pB: pointer, beta: T,
+      C: ptr T, rsC, csC: int): cint {.lh, importc.}
+
+importGemm(_f32, float32)
+importGemm(_f64, float64)
+importGemm(_i32, int32)
+importGemm(_i64, int64)
+
+proc laser_hip_gemm_prepack_release*(packed: pointer): cint {.lh, importc.}
+
+proc laser_hip_transpose2d_copy_b32(dst, src: pointer, NR, NC: int): cint {.lh, importc.}
+proc laser_hip_transpose2d_copy_b64(dst, src: pointer, NR, NC: int): cint {.lh, importc.}
+proc laser_hip_transpose2d_batched_b32(dst, src: pointer, N, NR, NC: int): cint {.lh, importc.}
+proc laser_hip_transpose2d_batched_b64(dst, src: pointer, N, NR, NC: int): cint {.lh, importc.}
+
+proc laser_hip_im2col_workspace_size(iN, iC, iH, iW, cOut, cIn, kH, kW, pH, pW, sH, sW: int): int {.lh, importc.}
+proc laser_hip_im2col_f32(ws: ptr float32, oH, oW: int, input: ptr float32,
+    iC, iH, iW, kH, kW, pH, pW, sH, sW: int): cint {.lh, importc.}
+proc laser_hip_conv2d_im2col_f32(output, input: ptr float32, iN, iC, iH, iW: int,
+    kernel: ptr float32, cOut, cIn, kH, kW, pH, pW, sH, sW: int, ws: ptr float32): cint {.lh, importc.}
+proc laser_hip_cblas_sgemm(order, tA, tB: cint, M, N, K: int, alpha: float32, A: ptr float32, lda: int,
+    B: ptr float32, ldb: int, beta: float32, C: ptr float32, ldc: int): cint {.lh, importc.}
+
+# ---- gemm_strided -- laser/primitives/matrix_multiplication/gemm.nim:184-193 --------------------
+proc gemm_strided*[T: SomeNumber](
+      M, N, K: int,
+      alpha: T,
+      A: ptr T,
+      rowStrideA, colStrideA: int,
+      B: ptr T,
+      rowStrideB, colStrideB: int,
+      beta: T,
+      C: ptr T,
+      rowStrideC, colStrideC: int) =
+  when T is float32:
+    check laser_hip_gemm_strided_f32(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C, rowStrideC, colStrideC)
+  elif T is float64:
+    check laser_hip_gemm_strided_f64(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C, rowStrideC, colStrideC)
+  elif T is int32:
+    check laser_hip_gemm_strided_i32(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C, rowStrideC, colStrideC)
+  elif T is int64 or T is int:
+    check laser_hip_gemm_strided_i64(M, N, K, cast[int64](alpha), cast[ptr int64](A), rowStrideA, colStrideA,
+                                     cast[ptr int64](B), rowStrideB, colStrideB, cast[int64](beta),
+                                     cast[ptr int64](C), rowStrideC, colStrideC)
+  else:
+    {.error: "laser_hip: unsupported element type " & $T.}
+
+# ---- pre-packed GEMM -- gemm_prepacked.nim:76-292 -----------------------------------------------
+proc gemm_prepackB_mem_required*(T: typedesc, M, N, K: int): int =
+  when T is float32: laser_hip_gemm_prepackB_mem_required_f32(M, N, K)
+  elif T is float64: laser_hip_gemm_prepackB_mem_required_f64(M, N, K)
+  elif T is int32: laser_hip_gemm_prepackB_mem_required_i32(M, N, K)
+  else: laser_hip_gemm_prepackB_mem_required_i64(M, N, K)
+
+proc gemm_prepackA_mem_required*(T: typedesc, M, N, K: int): int =
+  when T is float32: laser_hip_gemm_prepackA_mem_required_f32(M, N, K)
+  elif T is float64: laser_hip_gemm_prepackA_mem_required_f64(M, N, K)
+  elif T is int32: laser_hip_gemm_prepackA_mem_required_i32(M, N, K)
+  else: laser_hip_gemm_prepackA_mem_required_i64(M, N, K)
+
+proc gemm_prepackB*[T](dst_packedB: ptr (T or UncheckedArray[T]), M, N, K: int,
+                       src_B: ptr T, rowStrideB, colStrideB: int) =
+  when T is float32: check laser_hip_gemm_prepackB_f32(dst_packedB, M, N, K, src_B, rowStrideB, colStrideB)
+  elif T is float64: check laser_hip_gemm_prepackB_f64(dst_packedB, M, N, K, src_B, rowStrideB, colStrideB)
+  elif T is int32: check laser_hip_gemm_prepackB_i32(dst_packedB, M, N, K, src_B, rowStrideB, colStrideB)
+  else: check laser_hip_gemm_prepackB_i64(dst_packedB, M, N, K, cast[ptr int64](src_B), rowStrideB, colStrideB)
+
+proc gemm_prepackA*[T](dst_packedA: ptr (T or UncheckedArray[T]), M, N, K: int,
+                       src_A: ptr T, rowStrideA, colStrideA: int) =
+  when T is float32: check laser_hip_gemm_prepackA_f32(dst_packedA, M, N, K, src_A, rowStrideA, colStrideA)
+  elif T is float64: check laser_hip_gemm_prepackA_f64(dst_packedA, M, N, K, src_A, rowStrideA, colStrideA)
+  elif T is int32: check laser_hip_gemm_prepackA_i32(dst_packedA, M, N, K, src_A, rowStrideA, colStrideA)
+  else: check laser_hip_gemm_prepackA_i64(dst_packedA, M, N, K, cast[ptr int64](src_A), rowStrideA, colStrideA)
+
+proc gemm_packed*[T: SomeNumber](M, N, K: int, alpha: T,
+      packedA: ptr (T or UncheckedArray[T]), packedB: ptr (T or UncheckedArray[T]),
+      beta: T, C: ptr (T or UncheckedArray[T]), rowStrideC, colStrideC: int) =
+  when T is float32: check laser_hip_gemm_packed_f32(M, N, K, alpha, packedA, packedB, beta, cast[ptr float32](C), rowStrideC, colStrideC)
+  elif T is float64: check laser_hip_gemm_packed_f64(M, N, K, alpha, packedA, packedB, beta, cast[ptr float64](C), rowStrideC, colStrideC)
+  elif T is int32: check laser_hip_gemm_packed_i32(M, N, K, alpha, packedA, packedB, beta, cast[ptr int32](C), rowStrideC, colStrideC)
+  else: check laser_hip_gemm_packed_i64(M, N, K, cast[int64](alpha), packedA, packedB, cast[int64](beta), cast[ptr int64](C), rowStrideC, colStrideC)
+
+# ---- physical transposes -- laser/primitives/swapaxes.nim:16-112 ---------------------------------
+proc transpose2D_copy*[T](dst, src: ptr (T or UncheckedArray[T]), NR, NC: Natural) =
+  when sizeof(T) == 4: check laser_hip_transpose2d_copy_b32(dst, src, NR, NC)
+  elif sizeof(T) == 8: check laser_hip_transpose2d_copy_b64(dst, src, NR, NC)
+  else: {.error: "laser_hip transposes support 4- and 8-byte elements".}
+
+proc transpose2D_batched*[T](dst, src: ptr (T or UncheckedArray[T]), N, NR, NC: Natural) =
+  when sizeof(T) == 4: check laser_hip_transpose2d_batched_b32(dst, src, N, NR, NC)
+  elif sizeof(T) == 8: check laser_hip_transpose2d_batched_b64(dst, src, N, NR, NC)
+  else: {.error: "laser_hip transposes support 4- and 8-byte elements".}
+
+proc nchw2nhwc*[T](dst_nhwc, src_nchw: ptr (T or UncheckedArray[T]), N, C, H, W: Natural) {.inline.} =
+  transpose2D_batched(dst_nhwc, src_nchw, N, C, H*W)       # swapaxes.nim:98
+
+proc nhwc2nchw*[T](dst_nchw, src_nhwc: ptr (T or UncheckedArray[T]), N, C, H, W: Natural) {.inline.} =
+  transpose2D_batched(dst_nchw, src_nhwc, N, H*W, C)       # swapaxes.nim:112
+
+# ---- im2col + GEMM convolution -- benchmarks/convolution/conv2d_im2col.nim -----------------------
+type
+  TensorShape* = tuple[n, c, h, w: int]            # conv2d_common.nim:6-13
+  KernelShape* = tuple[c_out, c_in, kH, kW: int]
+  Padding* = tuple[h, w: int]
+  Strides* = tuple[h, w: int]
+
+proc im2col_workspace_size*(ishape: TensorShape, kshape: KernelShape, padding: Padding, strides: Strides): int =
+  laser_hip_im2col_workspace_size(ishape.n, ishape.c, ishape.h, ishape.w, kshape.c_out, kshape.c_in,
+                                  kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w)
+
+proc im2col*(pworkspace: ptr float32, oshape: TensorShape, pinput: ptr UncheckedArray[float32],
+             ishape: TensorShape, kshape: KernelShape, padding: Padding, strides: Strides) =
+  check laser_hip_im2col_f32(pworkspace, oshape.h, oshape.w, cast[ptr float32](pinput), ishape.c, ishape.h,
+                             ishape.w, kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w)
+
+proc conv2d_im2col*(output: var seq[float32], oshape: TensorShape, input: seq[float32], ishape: TensorShape,
+                    kernel: seq[float32], kshape: KernelShape, padding: Padding, strides: Strides,
+                    pworkspace: ptr float32) =
+  assert oshape.c == kshape.c_out                        # conv2d_im2col.nim:109
+  check laser_hip_conv2d_im2col_f32(output[0].addr, input[0].unsafeAddr, ishape.n, ishape.c, ishape.h, ishape.w,
+                                    kernel[0].unsafeAddr, kshape.c_out, kshape.c_in, kshape.kH, kshape.kW,
+                                    padding.h, padding.w, strides.h, strides.w, pworkspace)
+
+# ---- cblas-shaped gemm -- benchmarks/third_party/blas.nim:12-23 ----------------------------------
+type
+  TransposeType* {.size: sizeof(cint).} = enum
+    noTranspose = 111, transpose = 112, conjTranspose = 113
+  OrderType* {.size: sizeof(cint).} = enum
+    rowMajor = 101, colMajor = 102
+
+proc gemm*(ORDER: OrderType, TRANSA, TRANSB: TransposeType, M, N, K: int, ALPHA: float32,
+           A: ptr float32, LDA: int, B: ptr float32, LDB: int, BETA: float32, C: ptr float32, LDC: int) =
+  check laser_hip_cblas_sgemm(cint(ORDER), cint(TRANSA), cint(TRANSB), M, N, K, ALPHA, A, LDA, B, LDB, BETA, C, LDC)
+
+# ---- RawTensor / forEach surface ------------------------------------------------------------------
+# Nothing to replace: `Tensor[T]`, `unsafe_raw_data`, `forEach` stay Laser's own
+# (laser/tensor/datatypes.nim:13-30, laser/strided_iteration/foreach.nim:192-264).  A caller does
+#   gemm_strided(M, N, K, 1'f32, a.unsafe_raw_data, a.strides[0], a.strides[1], ...)
+# exactly as before; only raw pointers and element strides cross the ABI.

@@ -1,0 +1,77 @@
+// tests/cpp/kat_host_mirror.cpp -- the reference's self-tests (gemm.nim:255-507) re-typed against the
+// C++ host mirror include/laser.hpp, the way a compiled caller would use the drop-in.  Built and run
+// by tests/test_gpu_cpp_mirror.py on the GPU box (g++, links liblaser_hip.so).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "laser.hpp"
+
+template <typename T>
+static int run() {
+  int fails = 0;
+  {  // gemm.nim:336-360  (M x K) * (K x N) with M < N
+    const T a[2][3] = {{-2, -3, -1}, {3, 0, 4}};
+    const T b[3][4] = {{1, 5, 2, -1}, {-3, 0, 3, 4}, {6, -2, 7, -4}};
+    const T ab[2][4] = {{1, -8, -20, -6}, {27, 7, 34, -19}};
+    T res[2][4];
+    laser::gemm_strided<T>(2, 4, 3, T(1), &a[0][0], 3, 1, &b[0][0], 4, 1, T(0), &res[0][0], 4, 1);
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 4; j++) fails += (res[i][j] != ab[i][j]);
+  }
+  {  // gemm.nim:311-334
+    const T a[2][3] = {{1, 2, 3}, {4, 5, 6}};
+    const T b[3][2] = {{7, 8}, {9, 10}, {11, 12}};
+    const T ab[2][2] = {{58, 64}, {139, 154}};
+    T res[2][2];
+    laser::gemm_strided<T>(2, 2, 3, T(1), &a[0][0], 3, 1, &b[0][0], 2, 1, T(0), &res[0][0], 2, 1);
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) fails += (res[i][j] != ab[i][j]);
+    // pack_and_test (gemm_prepacked.nim:314-351)
+    void *pa = aligned_alloc(64, (size_t)((laser::gemm_prepackA_mem_required<T>(2, 2, 3) + 63) / 64 * 64));
+    void *pb = aligned_alloc(64, (size_t)((laser::gemm_prepackB_mem_required<T>(2, 2, 3) + 63) / 64 * 64));
+    laser::gemm_prepackA<T>(pa, 2, 2, 3, &a[0][0], 3, 1);
+    laser::gemm_prepackB<T>(pb, 2, 2, 3, &b[0][0], 2, 1);
+    T res2[2][2] = {{0, 0}, {0, 0}};
+    laser::gemm_packed<T>(2, 2, 3, T(1), pa, pb, T(0), &res2[0][0], 2, 1);
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) fails += (res2[i][j] != ab[i][j]);
+    laser::gemm_prepack_release(pa);
+    laser::gemm_prepack_release(pb);
+    free(pa);
+    free(pb);
+  }
+  return fails;
+}
+
+int main() {
+  int fails = run<float>() + run<double>() + run<int32_t>() + run<int64_t>();
+  // conv KAT 1 (conv2d_common.nim:147-186)
+  const float in[16] = {1, 2, 0, 0, 5, 3, 0, 4, 0, 0, 0, 7, 9, 3, 0, 0};
+  const float ker[9] = {1, 1, 1, 1, 1, 0, 1, 0, 0};
+  const float target[16] = {1, 8, 5, 0, 8, 11, 5, 4, 8, 17, 10, 11, 9, 12, 10, 7};
+  laser::TensorShape ishape{1, 1, 4, 4};
+  laser::KernelShape kshape{1, 1, 3, 3};
+  auto oshape = laser::conv2d_out_shape(ishape, kshape, {1, 1}, {1, 1});
+  std::vector<float> out(16, 0.f), ws(laser::im2col_workspace_size(ishape, kshape, {1, 1}, {1, 1}));
+  laser::conv2d_im2col(out.data(), oshape, in, ishape, ker, kshape, {1, 1}, {1, 1}, ws.data());
+  for (int i = 0; i < 16; i++) fails += (out[i] != target[i]);
+  // transposes
+  const int32_t m[2][3] = {{1, 2, 3}, {4, 5, 6}};
+  int32_t t[3][2];
+  laser::transpose2D_copy(&t[0][0], &m[0][0], 2, 3);
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 3; j++) fails += (t[j][i] != m[i][j]);
+  // error contract: misaligned pre-pack destination throws (reference: doAssert, gemm_prepacked.nim:125)
+  bool threw = false;
+  alignas(64) char buf[256];
+  const float one = 1.f;
+  try {
+    laser::gemm_prepackB<float>(buf + 4, 1, 1, 1, &one, 1, 1);
+  } catch (const laser::Error &) {
+    threw = true;
+  }
+  fails += !threw;
+  std::printf(fails ? "FAIL (%d)\n" : "SUCCESS\n", fails);
+  return fails ? 1 : 0;
+}
