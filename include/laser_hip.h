@@ -62,6 +62,10 @@ int laser_hip_get_float_mode(void);
 /* Force one tile configuration of the f32 MFMA kernel (-1 = heuristic).  For tuning/benchmarks. */
 int laser_hip_set_f32_config(int cfg);
 int laser_hip_f32_config_count(void);
+/* Convolution strategy: 1 (default) = implicit GEMM, im2col's index arithmetic fused into the GEMM's
+ * B-tile loader (no workspace traffic); 0 = explicit im2col into the workspace + batched GEMM, the
+ * reference's literal structure (conv2d_im2col.nim:126-166).  Results are bit-identical. */
+int laser_hip_set_conv_implicit(int on);
 const char *laser_hip_f32_config_name(int cfg);
 
 /* ---- gemm_strided -- laser/primitives/matrix_multiplication/gemm.nim:184-193 ------------------

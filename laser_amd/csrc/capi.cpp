@@ -49,6 +49,7 @@ struct Context {
   std::string arch;
   int float_mode = LASER_HIP_F32_LASER_ORDER;
   int f32_cfg = -1;
+  bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
   // cached device scratch for the host-pointer paths, one growing buffer per role
   void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[6] = {0, 0, 0, 0, 0, 0};
@@ -381,9 +382,19 @@ int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, 
   // 1x1 shortcut (conv2d_im2col.nim:121,128,151-153): the input already is the [K, N] matrix --
   // taken only for stride 1 / no padding, where that is actually true.
   const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
+  const bool geom_fits = iH < 32000 && iW < 32000 && oH * sH + kH < 32000 && oW * sW + kW < 32000;
+  if (!direct && g_ctx.conv_implicit && geom_fits) {
+    // implicit GEMM: im2col's index arithmetic runs inside the B-tile loader, nothing is materialised
+    GemmArgs<float> a = make_args<float>(iN, M, N, K, 1.0f, dker, K, 1, 0, din, 0, 1, iC * iH * iW, 0.0f, dout, N, 1, M * N);
+    a.cH = (int32_t)iH; a.cW = (int32_t)iW; a.ckH = (int32_t)kH; a.ckW = (int32_t)kW; a.coW = (int32_t)oW;
+    a.cpH = (int32_t)pH; a.cpW = (int32_t)pW; a.csH = (int32_t)sH; a.csW = (int32_t)sW;
+    HIP_TRY(launch_conv_implicit_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s));
+    return LASER_HIP_OK;
+  }
   const float *Bm = din;
   int64_t bsB = iC * iH * iW;
   if (!direct) {
+    if (!dws) return fail(LASER_HIP_E_INVALID, "explicit im2col path needs a workspace");
     HIP_TRY(launch_im2col_f32(dws, oH, oW, din, iN, iC, iH, iW, kH, kW, pH, pW, sH, sW, s));
     Bm = dws;
     bsB = K * N;
@@ -462,6 +473,11 @@ int laser_hip_set_f32_config(int cfg) {
   return LASER_HIP_OK;
 }
 int laser_hip_f32_config_count(void) { return gemm_f32_config_count(); }
+// 1 = implicit GEMM (default), 0 = explicit im2col workspace + batched GEMM (comparison / A-B timing)
+int laser_hip_set_conv_implicit(int on) {
+  g_ctx.conv_implicit = on != 0;
+  return LASER_HIP_OK;
+}
 // tuning probe (not declared in laser_hip.h): contiguous row-major device operands, multiples of 256
 int laser_hip_probe_f32_dev(int64_t n, const float *A, const float *B, float *C, int dbg, void *stream) {
   if (int rc = ensure_init()) return rc;
@@ -623,7 +639,7 @@ int laser_hip_conv2d_im2col_f32_dev(float *dout, const float *din, int64_t iN, i
   if (iN == 0) return LASER_HIP_OK;
   if (!dout || !din || !dker) return fail(LASER_HIP_E_INVALID, "null pointer");
   if (iN > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
-  if (!dws) {
+  if (!dws && !g_ctx.conv_implicit) {
     int64_t oH, oW;
     out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -648,10 +664,12 @@ int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t
   const size_t ib = (size_t)iN * iC * iH * iW * 4, kb = (size_t)c_out * iC * kH * kW * 4;
   const size_t ob = (size_t)iN * c_out * oH * oW * 4, w1 = (size_t)iC * kH * kW * oH * oW * 4;
   void *di, *dk, *dout, *dws;
+  const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
+  const bool implicit = g_ctx.conv_implicit;
   if (int rc = scratch_get(0, ib, &di)) return rc;
   if (int rc = scratch_get(1, kb, &dk)) return rc;
   if (int rc = scratch_get(2, ob, &dout)) return rc;
-  if (int rc = scratch_get(4, w1 * iN, &dws)) return rc;
+  if (int rc = scratch_get(4, implicit ? w1 : w1 * iN, &dws)) return rc;
   HIP_TRY(hipMemcpy(di, in, ib, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dk, ker, kb, hipMemcpyHostToDevice));
   if (int rc = conv_dev((float *)dout, (const float *)di, iN, iC, iH, iW, (const float *)dk, c_out, kH, kW, pH,
@@ -659,9 +677,15 @@ int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t
     return rc;
   HIP_TRY(hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost));
   // like the reference, the caller's workspace ends up holding the LAST image's im2col matrix
-  const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
-  if (pworkspace && !direct && w1 > 0)
-    HIP_TRY(hipMemcpy(pworkspace, (const char *)dws + (size_t)(iN - 1) * w1, w1, hipMemcpyDeviceToHost));
+  if (pworkspace && !direct && w1 > 0) {
+    const char *src = (const char *)dws + (size_t)(iN - 1) * w1;
+    if (implicit) {  // nothing was materialised: expand just the last image for the caller
+      HIP_TRY(launch_im2col_f32((float *)dws, oH, oW, (const float *)di + (size_t)(iN - 1) * iC * iH * iW, 1, iC, iH, iW,
+                                kH, kW, pH, pW, sH, sW, nullptr));
+      src = (const char *)dws;
+    }
+    HIP_TRY(hipMemcpy(pworkspace, src, w1, hipMemcpyDeviceToHost));
+  }
   return LASER_HIP_OK;
 }
 

@@ -25,6 +25,10 @@ struct GemmArgs {
   int32_t kc;                // accumulation slice in k (Laser's kc; 0 = one chain over all K)
   int32_t batch;
   int32_t dbg;  // ablation switches for the tuning probe build only (0 in production)
+  // Implicit-GEMM convolution (B loader LOAD_IM2COL): B is never materialised; element (k, j) of
+  // image b's [C*kH*kW, oH*oW] matrix is gathered from the NCHW input at B + b*bsB with the index
+  // arithmetic of im2col (benchmarks/convolution/conv2d_im2col.nim:62-87).
+  int32_t cH, cW, ckH, ckW, coW, cpH, cpW, csH, csW;
 };
 
 // How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of
@@ -39,9 +43,14 @@ enum LoadMode : int {
   // same way, gemm_packing.nim:46-55,85-94; rows/cols beyond M/N only feed outputs never stored)
   LOAD_VEC_X_EDGE = 4,
   LOAD_VEC_K_EDGE = 5,
+  // B operand only: im2col fused into the loader (implicit-GEMM convolution), lanes run along
+  // the output pixel index j = oh*oW + ow, predicated gathers from the NCHW image, zeros for padding
+  LOAD_IM2COL = 6,
 };
 
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
+// args.B = NCHW input, args.bsB = C*H*W, args.c* = geometry, N = oH*oW, K = C*kH*kW; A = filter
+hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
 hipError_t launch_gemm_f32_probe(const GemmArgs<float> &args, int dbg, hipStream_t s);
 int gemm_f32_config_count();
 const char *gemm_f32_config_name(int cfg);

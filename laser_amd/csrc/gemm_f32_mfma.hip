@@ -92,4 +92,28 @@ hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_orde
   return hipErrorInvalidValue;
 }
 
+
+// Implicit-GEMM convolution: same kernels, B loader = LOAD_IM2COL.  M = C_out, N = oH*oW, K = C_in*kH*kW,
+// batch = images; A (the filter bank) is always k-contiguous.
+hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
+  if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
+  GemmArgs<float> a = args;
+  a.Mext = a.M; a.Next = a.N; a.Kext = a.K;
+  a.dbg = 0;
+  const bool exact = laser_order && a.K > 512;
+  a.kc = exact ? 512 : 0;
+  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact);
+  if (exact && !kCfgs[cfg].exact) cfg = kCfgWide;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const CfgInfo &c = kCfgs[cfg];
+    bool va, ea;
+    pick_mode(a.A, a.rsA, a.csA, a.bsA, a.M, a.K, c.bm, c.bk, &va, &ea);
+    if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, LOAD_IM2COL, exact, s);
+    if (a.csA == 1 && ea) return c.fn(a, LOAD_VEC_K_EDGE, LOAD_IM2COL, exact, s);
+    if (c.gen) return c.fn(a, LOAD_GEN_K, LOAD_IM2COL, exact, s);
+    cfg = kCfgSmall;
+  }
+  return hipErrorInvalidValue;
+}
+
 }  // namespace laser_hip

@@ -55,14 +55,40 @@ struct TileLoader {
   static constexpr bool ALONG_K = (MODE == LOAD_VEC_K || MODE == LOAD_GEN_K || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool EDGE = (MODE == LOAD_VEC_X_EDGE || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || EDGE);
+  static constexpr bool CONV = (MODE == LOAD_IM2COL);
   f32x4 v[NV];
+  // LOAD_IM2COL: per piece and element, (oh*sH - pH) in the high and (ow*sW - pW) in the low 16 bits
+  // of the output pixel this lane gathers for (fixed for the whole K loop); 0x7fff7fff = beyond N.
+  int32_t pix[CONV ? NV : 1][CONV ? 4 : 1];
+
+  __device__ __forceinline__ void init_conv(const GemmArgs<float> &g, int64_t n0, int t) {
+    if constexpr (CONV) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int idx = t + i * NT;
+        const int xq = idx % (BX / 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int64_t j = n0 + 4 * xq + e;
+          if (j < g.N) {
+            const int oh = (int)(j / g.coW), ow = (int)(j - (int64_t)oh * g.coW);
+            const int r0 = oh * g.csH - g.cpH, c0 = ow * g.csW - g.cpW;
+            pix[i][e] = (int32_t)(((uint32_t)(r0 & 0xffff) << 16) | (uint32_t)(c0 & 0xffff));
+          } else {
+            pix[i][e] = 0x7fff7fff;  // row 32767: fails the bounds test for every kr
+          }
+        }
+      }
+    }
+  }
 
   // base: element (x=0,k=0) of this workgroup's operand panel; sx/sk element strides along x / k;
   // xlim/klim: number of valid x / k from `base` on (only used by the GEN modes).
   __device__ __forceinline__ void load(const float *__restrict__ base, int64_t sx, int64_t sk,
-                                       int64_t k0, int64_t xlim, int64_t klim, int t) {
+                                       int64_t k0, int64_t xlim, int64_t klim, int t,
+                                       const GemmArgs<float> *cg = nullptr) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) load_op(base, sx, sk, k0, xlim, klim, t, i);
+    for (int i = 0; i < NV; i++) load_op(base, sx, sk, k0, xlim, klim, t, i, cg);
   }
 
   __device__ __forceinline__ void store(float *__restrict__ lds, int t) const {
@@ -93,9 +119,25 @@ struct TileLoader {
   }
 
   __device__ __forceinline__ void load_op(const float *__restrict__ base, int64_t sx, int64_t sk, int64_t k0,
-                                          int64_t xlim, int64_t klim, int t, int i) {
+                                          int64_t xlim, int64_t klim, int t, int i,
+                                          const GemmArgs<float> *cg = nullptr) {
     const int idx = t + i * NT;
-    if constexpr (!ALONG_K) {
+    if constexpr (CONV) {
+      // k -> (channel, kernel row, kernel col); the pixel part was decoded once in init_conv
+      const int k = idx / (BX / 4);
+      const int kk = (int)k0 + k;
+      const int khw = cg->ckH * cg->ckW;
+      const int c = kk / khw, rem = kk - c * khw;
+      const int kr = rem / cg->ckW, kc = rem - kr * cg->ckW;
+      const bool kin = kk < (int)klim;
+      const float *img = base + (int64_t)c * cg->cH * cg->cW;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int row = (int)(int16_t)(pix[i][e] >> 16) + kr, col = (int)(int16_t)(pix[i][e] & 0xffff) + kc;
+        const bool ok = kin && (unsigned)row < (unsigned)cg->cH && (unsigned)col < (unsigned)cg->cW;
+        v[i][e] = ok ? img[row * cg->cW + col] : 0.0f;
+      }
+    } else if constexpr (!ALONG_K) {
       const int xq = idx % (BX / 4), k = idx / (BX / 4);
       if constexpr (VEC && !EDGE) {
         v[i] = *reinterpret_cast<const f32x4 *>(base + (k0 + k) * sk + 4 * xq);
@@ -187,13 +229,15 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
 
   const float *Ab = g.A + bz * g.bsA + m0 * g.rsA;  // x = row of A, k along csA
-  const float *Bb = g.B + bz * g.bsB + n0 * g.csB;  // x = col of B, k along rsB
+  // x = col of B, k along rsB; for the implicit-GEMM conv the "matrix" is the NCHW image itself
+  const float *Bb = (BMODE == LOAD_IM2COL) ? g.B + bz * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
   float *Cb = g.C + bz * g.bsC;
   const int64_t K = g.K;
   const int64_t mlim = g.M - m0, nlim = g.N - n0;
 
   TileLoader<BM, BK, NT, AMODE> la;
   TileLoader<BN, BK, NT, BMODE> lb;
+  lb.init_conv(g, n0, t);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -277,7 +321,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   if constexpr (STAGES == 2) {
     // -- prologue: tile 0 -> LDS stage 0 --
     la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
-    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t);
+    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t, &g);
     la.store(smem, t);
     lb.store(smem + BK * BM, t);
     __syncthreads();
@@ -287,7 +331,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       const bool more = (kt + 1) < nkt;
       if (more) {  // issue the next tile's HBM loads before the MFMA block (latency hides under it)
         la.load(Ab, g.rsA, g.csA, (int64_t)(kt + 1) * BK, mlim, K, t);
-        lb.load(Bb, g.csB, g.rsB, (int64_t)(kt + 1) * BK, nlim, K, t);
+        lb.load(Bb, g.csB, g.rsB, (int64_t)(kt + 1) * BK, nlim, K, t, &g);
       }
       ldfrag(sA, sB, 0, 0);
 #pragma unroll
@@ -315,12 +359,12 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   } else {
     // -- prologue: tile 0 -> LDS stage 0; tile 1 -> registers --
     la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
-    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t);
+    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t, &g);
     la.store(smem, t);
     lb.store(smem + BK * BM, t);
     if (nkt > 1) {
       la.load(Ab, g.rsA, g.csA, BK, mlim, K, t);
-      lb.load(Bb, g.csB, g.rsB, BK, nlim, K, t);
+      lb.load(Bb, g.csB, g.rsB, BK, nlim, K, t, &g);
     }
     __syncthreads();
     ldfrag(smem, smem + BK * BM, 0, 0);
@@ -357,7 +401,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
           if (c < P - 1) {
             if (!DBG || !(g.dbg & 2)) lb.store_op(wB, t, i, c);
           } else if (more2 && (!DBG || !(g.dbg & 1))) {
-            lb.load_op(Bb, g.csB, g.rsB, k2, nlim, K, t, i);
+            lb.load_op(Bb, g.csB, g.rsB, k2, nlim, K, t, i, &g);
           }
         }
       };
@@ -463,12 +507,15 @@ hipError_t launch_cfg_mode(const GemmArgs<float> &a, int amode, int bmode, hipSt
     LH_CASE(LOAD_VEC_K_EDGE, LOAD_VEC_K_EDGE)
     LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_X_EDGE)
     LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_K_EDGE)
+    LH_CASE(LOAD_VEC_K, LOAD_IM2COL)       // implicit-GEMM conv: filter [C_out][C_in*kH*kW] is k-contiguous
+    LH_CASE(LOAD_VEC_K_EDGE, LOAD_IM2COL)
   }
   if constexpr (WITH_GEN) {
     LH_CASE(LOAD_GEN_K, LOAD_GEN_X)
     LH_CASE(LOAD_GEN_K, LOAD_GEN_K)
     LH_CASE(LOAD_GEN_X, LOAD_GEN_X)
     LH_CASE(LOAD_GEN_X, LOAD_GEN_K)
+    LH_CASE(LOAD_GEN_K, LOAD_IM2COL)
   }
 #undef LH_CASE
   return hipErrorInvalidValue;

@@ -75,6 +75,11 @@ def set_f32_config(cfg):
     _lib.check(_lib.lib().laser_hip_set_f32_config(int(cfg)))
 
 
+def set_conv_implicit(on):
+    """True (default): implicit-GEMM convolution; False: explicit im2col workspace + batched GEMM."""
+    _lib.check(_lib.lib().laser_hip_set_conv_implicit(1 if on else 0))
+
+
 def f32_configs():
     L = _lib.lib()
     return [L.laser_hip_f32_config_name(i).decode() for i in range(L.laser_hip_f32_config_count())]

@@ -81,13 +81,17 @@ def main():
     out = torch.zeros(oshape, device="cuda")
     ws = torch.empty(ishape[0] * laser_amd.im2col_workspace_size(ishape, kshape, pad, st), device="cuda")
     flops = 2.0 * oshape[0] * oshape[1] * oshape[2] * oshape[3] * kshape[1] * 9
-    for mode in (0, 1):
-        laser_amd.set_float_mode(mode)
-        med, mn = ev_time(lambda: laser_amd.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, ws))
-        emit(config="C4 conv 32x128x56x56 * 256x128x3x3 pad1 stride1 (im2col kernel + batched GEMM)",
-             mode="laser_order" if mode == 0 else "fast", ms_med=round(med, 4), ms_min=round(mn, 4),
-             tflops=round(flops / (med * 1e-3) / 1e12, 2), frac_mfma_peak=round(flops / (med * 1e-3) / 1e12 / PEAK_TF, 4))
+    for implicit in (True, False):
+        laser_amd.set_conv_implicit(implicit)
+        for mode in (0, 1):
+            laser_amd.set_float_mode(mode)
+            med, mn = ev_time(lambda: laser_amd.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, ws))
+            emit(config="C4 conv 32x128x56x56 * 256x128x3x3 pad1 stride1 " +
+                 ("(implicit GEMM: im2col fused into the B loader)" if implicit else "(explicit im2col kernel + batched GEMM)"),
+                 mode="laser_order" if mode == 0 else "fast", ms_med=round(med, 4), ms_min=round(mn, 4),
+                 tflops=round(flops / (med * 1e-3) / 1e12, 2), frac_mfma_peak=round(flops / (med * 1e-3) / 1e12 / PEAK_TF, 4))
     laser_amd.set_float_mode(0)
+    laser_amd.set_conv_implicit(True)
     L = laser_amd.lib()
     med, mn = ev_time(lambda: L.laser_hip_im2col_f32_dev(ws.data_ptr(), 56, 56, x.data_ptr(), 32, 128, 56, 56, 3, 3, 1, 1, 1, 1,
                                                          torch.cuda.current_stream().cuda_stream))

@@ -260,6 +260,9 @@ def test_im2col_and_conv_vs_oracle(la, oracle):
                                       ((1, 3, 9, 14), (2, 3, 3, 2), (0, 1), (2, 1)),
                                       ((2, 8, 6, 6), (5, 8, 1, 1), (0, 0), (1, 1)),
                                       ((3, 16, 20, 20), (24, 16, 3, 3), (0, 0), (1, 1)),
+                                      ((2, 24, 30, 31), (40, 24, 5, 3), (2, 1), (2, 3)),     # K = 360: EDGE filter loader
+                                      ((2, 7, 17, 9), (130, 7, 3, 3), (1, 1), (1, 1)),       # K = 63: scalar filter loader
+                                      ((1, 64, 28, 28), (300, 64, 3, 3), (1, 1), (1, 1)),    # K = 576 > kc: two slices
                                       ((2, 4, 10, 10), (3, 4, 1, 1), (0, 0), (2, 2))]:
         x = rng.uniform(0, 1, ishape).astype(np.float32)   # conv2d_bench.nim:124-125
         w = rng.uniform(0, 1, kshape).astype(np.float32)
@@ -271,6 +274,21 @@ def test_im2col_and_conv_vs_oracle(la, oracle):
         assert np.array_equal(ws, oracle.im2col(x[0], kshape, pad, st))
         out = np.zeros(oshape, dtype=np.float32)
         la.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None)
+        # the reference's literal structure (explicit workspace + GEMM) gives the same bits as the
+        # default implicit-GEMM path, and the caller's workspace receives the last image's matrix
+        try:
+            la.set_conv_implicit(False)
+            out2 = np.zeros(oshape, dtype=np.float32)
+            ws2 = np.full(la.im2col_workspace_size(ishape, kshape, pad, st), np.nan, dtype=np.float32)
+            la.conv2d_im2col(out2, oshape, x, ishape, w, kshape, pad, st, ws2)
+        finally:
+            la.set_conv_implicit(True)
+        assert np.array_equal(out, out2)
+        ws3 = np.full(ws2.shape, np.nan, dtype=np.float32)
+        la.conv2d_im2col(np.zeros(oshape, dtype=np.float32), oshape, x, ishape, w, kshape, pad, st, ws3)
+        if not (kshape[2] * kshape[3] == 1 and st == (1, 1) and pad == (0, 0)):
+            want_ws = oracle.im2col(x[-1], kshape, pad, st).ravel()
+            assert np.array_equal(ws2, want_ws) and np.array_equal(ws3, want_ws)
         if kshape[2] * kshape[3] == 1 and st != (1, 1):
             want = oracle.conv2d_direct(x, w, pad, st)   # reference's 1x1 shortcut is only right for stride 1
             assert oracle.mean_relative_error(out, want) <= 1e-5
