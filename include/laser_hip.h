@@ -66,6 +66,9 @@ int laser_hip_f32_config_count(void);
  * B-tile loader (no workspace traffic); 0 = explicit im2col into the workspace + batched GEMM, the
  * reference's literal structure (conv2d_im2col.nim:126-166).  Results are bit-identical. */
 int laser_hip_set_conv_implicit(int on);
+/* int32 GEMM strategy: 1 (default) = signed 8-bit limb decomposition on the int8 matrix cores
+ * (bit-exact mod 2^32); 0 = the VALU kernel.  Results are bit-identical. */
+int laser_hip_set_i32_mfma(int on);
 const char *laser_hip_f32_config_name(int cfg);
 
 /* ---- gemm_strided -- laser/primitives/matrix_multiplication/gemm.nim:184-193 ------------------

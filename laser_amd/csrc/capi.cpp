@@ -49,6 +49,7 @@ struct Context {
   std::string arch;
   int float_mode = LASER_HIP_F32_LASER_ORDER;
   int f32_cfg = -1;
+  bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
   bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
   // cached device scratch for the host-pointer paths, one growing buffer per role
   void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -121,6 +122,17 @@ hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
 }
 template <>
 hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
+  // Large single problems go to the int8 matrix cores (limb decomposition, gemm_i32_mfma.hip); the
+  // limb planes live in stream-ordered scratch so concurrent streams never share a buffer.
+  const double work = (double)a.M * (double)a.N * (double)a.K;
+  if (g_ctx.i32_mfma && a.batch == 1 && work >= 64.0 * 64.0 * 64.0 * 8.0) {
+    void *ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, gemm_i32_mfma_workspace_bytes(a.M, a.N, a.K), s);
+    if (e != hipSuccess) return e;
+    e = launch_gemm_i32_mfma(a, ws, s);
+    hipError_t e2 = hipFreeAsync(ws, s);
+    return e != hipSuccess ? e : e2;
+  }
   return launch_gemm_valu<int32_t>(a, false, s);
 }
 template <>
@@ -473,6 +485,11 @@ int laser_hip_set_f32_config(int cfg) {
   return LASER_HIP_OK;
 }
 int laser_hip_f32_config_count(void) { return gemm_f32_config_count(); }
+// 1 = int32 GEMM via int8-limb MFMA (default), 0 = VALU kernel (comparison / A-B timing)
+int laser_hip_set_i32_mfma(int on) {
+  g_ctx.i32_mfma = on != 0;
+  return LASER_HIP_OK;
+}
 // 1 = implicit GEMM (default), 0 = explicit im2col workspace + batched GEMM (comparison / A-B timing)
 int laser_hip_set_conv_implicit(int on) {
   g_ctx.conv_implicit = on != 0;

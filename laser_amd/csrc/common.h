@@ -58,6 +58,11 @@ const char *gemm_f32_config_name(int cfg);
 template <typename T>
 hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream_t s);
 
+// int32 GEMM on the int8 matrix cores (signed 8-bit limb decomposition, bit-exact mod 2^32);
+// ws = device scratch of gemm_i32_mfma_workspace_bytes(M, N, K) bytes, valid on stream s.
+size_t gemm_i32_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
+hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
+
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,
                                     int elem_size, hipStream_t s);
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,

@@ -75,6 +75,11 @@ def set_f32_config(cfg):
     _lib.check(_lib.lib().laser_hip_set_f32_config(int(cfg)))
 
 
+def set_i32_mfma(on):
+    """True (default): int32 GEMM on the int8 matrix cores (limb decomposition); False: VALU kernel."""
+    _lib.check(_lib.lib().laser_hip_set_i32_mfma(1 if on else 0))
+
+
 def set_conv_implicit(on):
     """True (default): implicit-GEMM convolution; False: explicit im2col workspace + batched GEMM."""
     _lib.check(_lib.lib().laser_hip_set_conv_implicit(1 if on else 0))

@@ -107,7 +107,17 @@ def main():
         emit(config=f"transpose2D_copy {r}x{c} f32", ms_med=round(med, 4), gbps=round(byts / (med * 1e-3) / 1e9, 1),
              frac_hbm_peak=round(byts / (med * 1e-3) / 1e9 / PEAK_HBM, 4))
     # integer / f64 GEMM (VALU kernels), reference bench shapes
-    for dt, n in [(torch.int32, 1920), (torch.int32, 4096), (torch.int64, 960), (torch.float64, 960), (torch.float64, 4096)]:
+    for n in (1920, 4096, 8192):
+        A = torch.randint(0, 101, (n, n), device="cuda", dtype=torch.int32)
+        B = torch.randint(0, 101, (n, n), device="cuda", dtype=torch.int32)
+        C = torch.zeros((n, n), device="cuda", dtype=torch.int32)
+        for on in (True, False):
+            laser_amd.set_i32_mfma(on)
+            med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C))
+            emit(config=f"gemm int32 {n}^3 " + ("(int8-limb MFMA)" if on else "(VALU kernel)"), ms_med=round(med, 4),
+                 tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
+        laser_amd.set_i32_mfma(True)
+    for dt, n in [(torch.int64, 960), (torch.float64, 960), (torch.float64, 4096)]:
         if dt.is_floating_point:
             A = (torch.rand((n, n), device="cuda", dtype=dt) - 0.5) * 0.2
             B = (torch.rand((n, n), device="cuda", dtype=dt) - 0.5) * 0.2

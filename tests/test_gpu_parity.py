@@ -176,6 +176,41 @@ def test_f32_fast_mode_within_tolerance(la, oracle):
         la.set_f32_config(-1)
 
 
+def test_int32_mfma_limb_path_bit_exact(la, oracle):
+    """int32 on the int8 matrix cores (signed 8-bit limb decomposition) == VALU kernel == oracle,
+    full-range operands (wrap-around), every stride flavour, alpha/beta, K past the fold interval."""
+    import torch
+    rng = np.random.default_rng(21)
+    info = np.iinfo(np.int32)
+    for (M, N, K) in [(128, 128, 64), (130, 257, 100), (64, 64, 8192 + 70), (513, 129, 1000), (200, 300, 16500)]:
+        A = rng.integers(info.min, info.max, (M, K), dtype=np.int32)
+        B = rng.integers(info.min, info.max, (K, N), dtype=np.int32)
+        C0 = rng.integers(info.min, info.max, (M, N), dtype=np.int32)
+        for alpha, beta in [(1, 0), (-3, 7), (info.min, 1)]:
+            want = oracle.matmul(A, B, alpha, beta, C0.copy())
+            got = la.matmul(A, B, alpha, beta, C0.copy())
+            assert np.array_equal(got, want), (M, N, K, alpha, beta)
+        # strided / transposed views on the device-resident path
+        dA = torch.from_numpy(np.asfortranarray(A)).cuda()          # column-major A
+        dBt = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t()  # transposed B
+        dC = torch.zeros((M, 2 * N), dtype=torch.int32, device="cuda")
+        la.matmul(dA, dBt, 1, 0, dC[:, ::2])
+        want = oracle.matmul(A, B)
+        assert np.array_equal(dC[:, ::2].cpu().numpy(), want)
+        assert (dC[:, 1::2] == 0).all()
+        try:
+            la.set_i32_mfma(False)
+            assert np.array_equal(la.matmul(A, B), want)
+        finally:
+            la.set_i32_mfma(True)
+    # extreme digits: every limb at its limits
+    for val in (info.min, info.max, -1, 0x7f7f7f7f, -0x7f7f7f80, 0x00808080, 128, 127, -128, -129):
+        A = np.full((64, 96), val, dtype=np.int32)
+        B = rng.integers(info.min, info.max, (96, 64), dtype=np.int32)
+        assert np.array_equal(la.matmul(A, B), oracle.matmul(A, B)), val
+        assert np.array_equal(la.matmul(B.T.copy(), A.T.copy()), oracle.matmul(B.T.copy(), A.T.copy())), val
+
+
 def test_device_resident_path_matches_host_path(la, oracle):
     import torch
     rng = np.random.default_rng(15)
