@@ -49,7 +49,7 @@ def host_info():
 def cpu_baseline(budget_s=15.0):
     """Laser-style OpenMP CPU path (oracle, kind "port") on a bounded sample of the 8192^3 job:
     the first `rows` rows of C (full N and K, so packing of B and the kc=512 slicing are the real
-    ones).  Calibrates on 192 rows, then sizes the sample for ~budget_s of CPU work."""
+    ones).  Calibrates the OpenMP team size, then sizes the sample for ~budget_s of CPU work."""
     import numpy as np
     from oracle import oracle
     oracle.build()
@@ -67,17 +67,34 @@ def cpu_baseline(budget_s=15.0):
         return time.perf_counter() - t0
 
     run(192)                      # warm-up (page faults, thread pool)
-    t_cal = run(384)
-    rate = 2.0 * 384 * n * n / t_cal
-    rows = int(min(n, max(384, rate * budget_s / (2.0 * n * n))))
+    # Laser's loop nest exposes ceil(M/192) ic tasks + jr tasks and a serial pc loop (gemm.nim:150-176);
+    # on a many-core host the best OpenMP team is not always "all logical CPUs": calibrate a few team
+    # sizes on 1920 rows (10 ic tasks) and keep the fastest (reported as `cores`).
+    ncpu_all = oracle.num_threads()
+    best = None
+    for th in sorted({ncpu_all, max(1, ncpu_all // 2), max(1, ncpu_all // 4), min(ncpu_all, 32)}):
+        oracle.set_num_threads(th)
+        t_cal = run(1920)
+        if best is None or t_cal < best[1]:
+            best = (th, t_cal)
+    threads, t_cal = best
+    oracle.set_num_threads(threads)
+    rate = 2.0 * 1920 * n * n / t_cal
+    rows = int(min(n, max(1920, rate * budget_s / (2.0 * n * n))))
     rows = max(192, rows // 192 * 192) if rows < n else n
     t = run(rows)
     gflops = 2.0 * rows * n * n / t / 1e9
     names = {0: "generic", 1: "sse", 2: "sse2", 3: "sse4.1", 4: "avx", 5: "avx+fma", 6: "avx2", 7: "avx512"}
     ncpu, model = host_info()
+    # the reference's own comparator ("vendor BLAS", gemm_bench_float32.nim:191-197): numpy == OpenBLAS
+    t0 = time.perf_counter()
+    _ = A[:rows] @ B
+    t_blas = time.perf_counter() - t0
+    blas_gflops = 2.0 * rows * n * n / t_blas / 1e9
     log(f"[cpu_baseline] host: {ncpu} logical CPUs, {model}; omp threads {threads}; isa {names.get(isa)}; "
-        f"sample rows={rows} of {n} ({t:.2f} s) -> {gflops:.1f} GFLOP/s")
+        f"sample rows={rows} of {n} ({t:.2f} s) -> {gflops:.1f} GFLOP/s; numpy/OpenBLAS same sample {blas_gflops:.1f} GFLOP/s")
     return {"value": round(gflops, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "openblas_same_sample_gflops": round(blas_gflops, 1),
             "sample": f"first {rows} rows of the {n}^3 sgemm (M={rows}, N=K={n}), Laser algorithm restated in C "
                       f"(oracle/), OpenMP {threads} threads, ukernel {names.get(isa)}, {t:.2f} s; host {model}"}
 
@@ -135,13 +152,29 @@ def main():
 
     n = args.size
     M_total, N, K = n * world, n, n
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
-    # uniform [-0.1, 0.1) like the reference's bench inputs (gemm_bench_float32.nim:343-344);
-    # random data is mandatory: zero-filled operands run at a higher clock (DVFS) and inflate TF/s
-    B = (torch.rand((K, N), generator=torch.Generator(device=dev).manual_seed(7), device=dev) - 0.5) * 0.2
     from laser_amd.distributed import ShardedGemm
     sg = ShardedGemm(M_total, N, K, torch.float32, dev, None, args.panels_per_rank if world > 1 else 1)
-    A_local = (torch.rand((sg.plan.panels_per_rank * sg.plan.rows, K), generator=g, device=dev) - 0.5) * 0.2
+
+    # Operands: uniform [-0.1, 0.1) like the reference's bench inputs (gemm_bench_float32.nim:343-344).
+    # Random data is mandatory: zero-filled operands run at a higher DVFS clock and inflate TF/s.
+    # Every element is a pure function of its GLOBAL (row, k) index (a 32-bit integer hash), so any rank
+    # can regenerate any row of the global A to verify rows it received through the all-gather.
+    def hashed(rows, cols, salt):
+        r = torch.as_tensor(rows, dtype=torch.int64, device=dev).view(-1, 1)
+        c = torch.arange(cols, dtype=torch.int64, device=dev).view(1, -1)
+        h = (r * 2654435761 + c * 40503 + salt) & 0xFFFFFFFF
+        h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+        h = (h ^ (h >> 13)) * 3266489917 & 0xFFFFFFFF
+        h = h ^ (h >> 16)
+        return ((h & 0xFFFFFF).to(torch.float32) / 16777216.0 - 0.5) * 0.2
+
+    B = hashed(range(K), N, 7)
+    p = sg.plan
+    A_local = torch.zeros((p.panels_per_rank * p.rows, K), dtype=torch.float32, device=dev)
+    for s_ in range(p.panels_per_rank):
+        start, valid = p.panel(s_, rank)
+        if valid > 0:
+            A_local[s_ * p.rows: s_ * p.rows + valid] = hashed(range(start, start + valid), K, 1)
     C = sg.alloc_C()
 
     def step():
@@ -170,11 +203,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
 
-    # cheap self-check inside the bench: a few rows against an fp64 product on the GPU
-    rows = sg.local_rows()[:8]
-    ref = (A_local[:8].double() @ B.double())
-    err = (C[rows].double() - ref).abs().max().item()
-    assert err < 1e-4, f"bench self-check failed: max abs err {err}"
+    # self-check inside the bench: rows of C against an fp64 product on this GPU -- a few of this rank's own
+    # rows and, through the hashed generator, a few rows owned by EVERY other rank (they can only be right
+    # if the all-gather delivered them)
+    check_rows = []
+    for r_ in range(world):
+        start, valid = p.panel(p.panels_per_rank - 1, r_)
+        check_rows += list(range(start, start + min(valid, 4)))
+        start, valid = p.panel(0, r_)
+        check_rows += list(range(start + max(0, valid - 4), start + valid))
+    ref = hashed(check_rows, K, 1).double() @ B.double()
+    err = (C[check_rows].double() - ref).abs().max().item()
+    assert err < 1e-4, f"bench self-check failed on rank {rank}: max abs err {err}"
 
     if rank == 0:
         flops_step = 2.0 * M_total * N * K

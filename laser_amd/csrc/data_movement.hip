@@ -8,82 +8,136 @@
 namespace laser_hip {
 
 // ---- batched 2-D transpose: dst[n][j][i] = src[n][i][j] -------------------------------------------
-// 64x64 tile through LDS ([64][65]: +1 pad makes the column reads conflict-free for 4-B elements),
-// reads coalesced along NC, writes coalesced along NR (the reference writes contiguously and reads
-// strided, swapaxes.nim:34-39; with LDS in between both sides are contiguous here).
-template <typename T>
+// 64x64 tile through LDS, 16-byte accesses on BOTH HBM sides (the reference writes contiguously and
+// reads strided, swapaxes.nim:34-39; with LDS in between both sides are contiguous here):
+//   read : thread (ty, tx) loads V consecutive elements (16 B) of src row r0+ty+16i -> LDS tile[row][col]
+//   write: thread gathers V consecutive SOURCE ROWS of one source column from LDS (V scalar reads,
+//          row stride 65/66 words => conflict-free), packs them and stores 16 B of dst row c0+col
+// VEC16 needs NR, NC multiples of V and 16-B aligned bases; otherwise the scalar form below runs.
+template <typename T, bool VEC16>
 __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                                                 int64_t NR, int64_t NC, int64_t tiles_c,
                                                                 int64_t tiles_r) {
-  __shared__ T tile[64][65];
+  constexpr int V = 16 / sizeof(T);        // elements per 16-byte access: 4 (b32) or 2 (b64)
+  constexpr int PAD = (sizeof(T) == 4) ? 1 : 1;
+  __shared__ T tile[64][64 + PAD];
   const int64_t bid = blockIdx.x;
   const int64_t tc = bid % tiles_c, tr = (bid / tiles_c) % tiles_r, n = bid / (tiles_c * tiles_r);
-  const int tx = threadIdx.x % 64, ty = threadIdx.x / 64;
   const T *s = src + n * NR * NC;
   T *d = dst + n * NR * NC;
   const int64_t r0 = tr * 64, c0 = tc * 64;
+  const int t = threadIdx.x;
+  if constexpr (VEC16) {
+    using VT = __attribute__((ext_vector_type(V))) T;
+    constexpr int TPR = 64 / V;            // threads per tile row: 16 or 32
+    constexpr int RPI = 256 / TPR;         // rows per iteration: 16 or 8
+    const int tx = t % TPR, ty = t / TPR;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
-    if (r < NR && c < NC) tile[ty + 4 * i][tx] = s[r * NC + c];
-  }
-  __syncthreads();
+    for (int i = 0; i < 64 / RPI; i++) {
+      const int row = ty + RPI * i;
+      const int64_t r = r0 + row, c = c0 + V * tx;
+      if (r < NR && c < NC) {
+        const VT q = *reinterpret_cast<const VT *>(s + r * NC + c);
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
-    if (r < NR && c < NC) d[c * NR + r] = tile[tx][ty + 4 * i];
+        for (int e = 0; e < V; e++) tile[row][V * tx + e] = q[e];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64 / RPI; i++) {
+      const int col = ty + RPI * i;        // source column = destination row
+      const int64_t c = c0 + col, r = r0 + V * tx;
+      if (c < NC && r < NR) {
+        VT q;
+#pragma unroll
+        for (int e = 0; e < V; e++) q[e] = tile[V * tx + e][col];
+        *reinterpret_cast<VT *>(d + c * NR + r) = q;
+      }
+    }
+  } else {
+    const int tx = t % 64, ty = t / 64;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
+      if (r < NR && c < NC) tile[ty + 4 * i][tx] = s[r * NC + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
+      if (r < NR && c < NC) d[c * NR + r] = tile[tx][ty + 4 * i];
+    }
   }
+}
+
+template <typename T>
+static hipError_t launch_transpose_t(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s) {
+  const int64_t tiles_r = (NR + 63) / 64, tiles_c = (NC + 63) / 64;
+  const int64_t blocks = N * tiles_r * tiles_c;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  constexpr int V = 16 / sizeof(T);
+  const bool vec = (NR % V == 0) && (NC % V == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((transpose_batched_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst, (const T *)src,
+                       NR, NC, tiles_c, tiles_r);
+  else
+    hipLaunchKernelGGL((transpose_batched_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst, (const T *)src,
+                       NR, NC, tiles_c, tiles_r);
+  return hipGetLastError();
 }
 
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,
                                     int elem_size, hipStream_t s) {
   if (N <= 0 || NR <= 0 || NC <= 0) return hipSuccess;
-  const int64_t tiles_r = (NR + 63) / 64, tiles_c = (NC + 63) / 64;
-  const int64_t blocks = N * tiles_r * tiles_c;
-  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (elem_size == 4)
-    hipLaunchKernelGGL(transpose_batched_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s,
-                       (uint32_t *)dst, (const uint32_t *)src, NR, NC, tiles_c, tiles_r);
-  else if (elem_size == 8)
-    hipLaunchKernelGGL(transpose_batched_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, s,
-                       (uint64_t *)dst, (const uint64_t *)src, NR, NC, tiles_c, tiles_r);
-  else
-    return hipErrorInvalidValue;
-  return hipGetLastError();
+  if (elem_size == 4) return launch_transpose_t<uint32_t>(dst, src, N, NR, NC, s);
+  if (elem_size == 8) return launch_transpose_t<uint64_t>(dst, src, N, NR, NC, s);
+  return hipErrorInvalidValue;
 }
 
 // ---- im2col: [batch][C][H][W] -> [batch][C*kH*kW][oH*oW] -------------------------------------------
-// One thread per workspace element; consecutive lanes run along ow (unit stride in both the
-// workspace and, for stride 1, the input).  Same index arithmetic as conv2d_im2col.nim:62-87:
-// row = -pH + krow + oh*sH, col = -pW + kcol + ow*sW, zero outside the image.
+// One workgroup = 1024 consecutive output pixels of ONE workspace row (image, channel, kernel row,
+// kernel col); 4 pixels per thread, one 16-byte store when oH*oW % 4 == 0.  Same index arithmetic as
+// conv2d_im2col.nim:62-87: row = -pH + krow + oh*sH, col = -pW + kcol + ow*sW, zero outside the image.
 __global__ void __launch_bounds__(256) im2col_f32_kernel(float *__restrict__ ws, const float *__restrict__ in,
-                                                         int64_t total, int C, int H, int W, int kH, int kW,
-                                                         int oH, int oW, int pH, int pW, int sH, int sW) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = e;
-    const int ow = (int)(r % oW); r /= oW;
-    const int oh = (int)(r % oH); r /= oH;
-    const int kcol = (int)(r % kW); r /= kW;
-    const int krow = (int)(r % kH); r /= kH;
-    const int c = (int)(r % C);
-    const int64_t n = r / C;
+                                                         int chunks, int H, int W, int kH, int kW, int oH, int oW,
+                                                         int pH, int pW, int sH, int sW, int vec_ok) {
+  const int64_t wrow = blockIdx.x / chunks;        // ((n*C + c)*kH + krow)*kW + kcol
+  const int chunk = (int)(blockIdx.x % chunks);
+  const int kcol = (int)(wrow % kW);
+  const int krow = (int)((wrow / kW) % kH);
+  const int64_t nc = wrow / ((int64_t)kW * kH);    // n*C + c
+  const float *img = in + nc * (int64_t)H * W;
+  float *out = ws + wrow * (int64_t)oH * oW;
+  const int npix = oH * oW;
+  const int p0 = (chunk * 256 + (int)threadIdx.x) * 4;
+  if (p0 >= npix) return;
+  float v[4];
+  int oh = p0 / oW, ow = p0 - oh * oW;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
     const int row = -pH + krow + oh * sH, col = -pW + kcol + ow * sW;
-    float v = 0.0f;
-    if (row >= 0 && row < H && col >= 0 && col < W) v = in[((n * C + c) * H + row) * (int64_t)W + col];
-    ws[e] = v;
+    v[e] = (p0 + e < npix && row >= 0 && row < H && col >= 0 && col < W) ? img[row * W + col] : 0.0f;
+    if (++ow == oW) { ow = 0; ++oh; }
+  }
+  if (vec_ok && p0 + 3 < npix) {
+    *reinterpret_cast<float4 *>(out + p0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (p0 + e < npix) out[p0 + e] = v[e];
   }
 }
 
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch, int64_t C,
                              int64_t H, int64_t W, int64_t kH, int64_t kW, int64_t pH, int64_t pW,
                              int64_t sH, int64_t sW, hipStream_t s) {
-  const int64_t total = batch * C * kH * kW * oH * oW;
-  if (total <= 0) return hipSuccess;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
-  hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, in, total, (int)C,
-                     (int)H, (int)W, (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW);
+  const int64_t rows = batch * C * kH * kW, npix = oH * oW;
+  if (rows <= 0 || npix <= 0) return hipSuccess;
+  const int64_t chunks = (npix + 1023) / 1024;
+  if (npix > 0x7fffffffLL / 8 || H * W > 0x7fffffffLL || rows * chunks > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int vec_ok = (npix % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+  hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, s, ws, in, (int)chunks, (int)H,
+                     (int)W, (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW, vec_ok);
   return hipGetLastError();
 }
 

@@ -15,14 +15,18 @@ PEAK_TF, PEAK_HBM = 157.3, 8000.0
 OUT = []
 
 
-def ev_time(fn, iters=5, warm=2):
+def ev_time(fn, iters=5, warm=3, inner=4):
+    """median / min of `iters` timings, each over `inner` back-to-back launches (keeps the clocks up)."""
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(iters):
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / inner)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 
