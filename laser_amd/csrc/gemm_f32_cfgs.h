@@ -12,12 +12,15 @@
   X(0, 256, 256, 16, 2, 4, 3, 2, 2, true, false, false)          \
   X(1, 256, 128, 16, 4, 2, 3, 2, 2, true, false, true)           \
   X(2, 128, 128, 16, 2, 2, 3, 3, 2, true, false, true)           \
-  X(3, 64, 64, 32, 2, 2, 2, 3, 2, true, true, true)
-#define LH_F32_NUM_CONFIGS 4
-// Measured on MI355X at 8192^3 (profiles/r01/sweep_f32_v4.json): cfg 0 fast 138-139 TFLOP/s,
-// cfg 1 laser-order 130-131, cfg 1 fast 135, cfg 2 fast 133 / laser-order 128, cfg 3 117-120.
-// Rejected in the sweep (kept out of the build): 2-stage forms of the same tiles (-3..-8 %), BK=32
-// rings (LDS 144 KiB, -6 %), 4-wave 256x128 / 128x256 tiles at 1 wave/SIMD for laser-order (-8 %).
+  X(3, 64, 64, 32, 2, 2, 2, 3, 2, true, true, true)              \
+  X(4, 256, 128, 32, 4, 2, 3, 2, 2, true, false, true)
+#define LH_F32_NUM_CONFIGS 5
+// Measured on MI355X at 8192^3 (profiles/r01/sweep_f32_v6.json): cfg 0 fast 138-140 TFLOP/s;
+// laser-order (second accumulator set => 1 workgroup/CU on every 64x64-wave tile): cfg 4 129.6-131.3,
+// cfg 2 127.4, cfg 1 126.2; fast cfg 1 (2 workgroups/CU) 134.8, cfg 2 133.3, cfg 3 118-122.
+// Rejected by measurement (kept out of the build): 2-stage forms of the same tiles (-3..-8 %),
+// 128x256x32 (= cfg 4 within noise), 4-wave 256x128 / 128x256 tiles at 1 wave/SIMD for laser-order
+// (-8 %), fragment prefetch distance 2 (no gain at 1 WG/CU, costs the 128-VGPR step of cfg 1 fast).
 
 namespace laser_hip {
 template <int IDX>

@@ -54,13 +54,13 @@ static int pick_mode(const float *p, int64_t sx, int64_t sk, int64_t bs, int64_t
 static int to_gen(int mode) { return mode == LOAD_VEC_K ? LOAD_GEN_K : LOAD_GEN_X; }
 static int to_edge(int mode) { return mode == LOAD_VEC_K ? LOAD_VEC_K_EDGE : LOAD_VEC_X_EDGE; }
 
-constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3;
+constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3, kCfgWideExact = 4;
 
 // Largest tile that still gives every CU work: >= ~0.8 x 256 workgroups, else the next size down.
 static int heuristic_cfg(const GemmArgs<float> &a, bool exact) {
   auto tiles = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (int64_t)a.batch; };
   if (!exact && tiles(256, 256) >= 200) return kCfgBig;
-  if (tiles(256, 128) >= 200) return kCfgWide;
+  if (tiles(256, 128) >= 200) return exact ? kCfgWideExact : kCfgWide;
   if (tiles(128, 128) >= 200) return kCfgMid;
   if (tiles(128, 128) >= 2 * tiles(64, 64) / 5 && tiles(128, 128) >= 96) return kCfgMid;
   return kCfgSmall;
@@ -78,7 +78,7 @@ hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_orde
   const bool exact = laser_order && a.K > 512;
   a.kc = exact ? 512 : 0;  // gemm_tiling.nim:310: kc = 2048 / sizeof(float32)
   if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact);
-  if (exact && !kCfgs[cfg].exact) cfg = kCfgWide;
+  if (exact && !kCfgs[cfg].exact) cfg = kCfgWideExact;
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo &c = kCfgs[cfg];
     bool va, vb, ea, eb;
@@ -103,7 +103,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   const bool exact = laser_order && a.K > 512;
   a.kc = exact ? 512 : 0;
   if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact);
-  if (exact && !kCfgs[cfg].exact) cfg = kCfgWide;
+  if (exact && !kCfgs[cfg].exact) cfg = kCfgWideExact;
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo &c = kCfgs[cfg];
     bool va, ea;

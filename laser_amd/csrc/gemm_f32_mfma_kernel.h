@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   constexpr int NJ = BK / 2;  // MFMA k-steps (k-pairs) per K-tile
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be built from 32x32 MFMA blocks");
   static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+  static_assert(STAGES == 2 || BK >= 16, "ring form prefetches past the mid-tile barrier: needs NJ/2 >= 2");
   constexpr int STAGE = BK * (BM + BN);  // floats per LDS stage: A panel then B panel
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -284,7 +285,11 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   const int kc_tiles = EXACT ? (g.kc / BK) : 0;
 
   // fragment of k-step j: lanes 0-31 feed k = 2j, lanes 32-63 feed k = 2j+1 -> ascending-k chain
-  float fa[2][TM], fb[2][TN];
+  // fragment ring: 4 slots (NJ is a multiple of 4, so slot = j & 3 stays compile-time across tiles);
+  // the 3-stage loop reads PFD steps ahead, the 2-stage loop one step ahead
+  float fa[4][TM], fb[4][TN];
+  constexpr int PFD = 1;  // 2 was measured: no gain at 1 WG/CU and it costs the 128-VGPR occupancy step of the fast 256x128 kernel
+  static_assert(NJ % 4 == 0, "BK must be a multiple of 8");
   auto ldfrag = [&](const float *sA, const float *sB, int j, int slot) __attribute__((always_inline)) {
     const int k = 2 * j + hi;
     const int s = swz<BK>(2 * j);
@@ -304,6 +309,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   // is added into C (gemm.nim:150-158; ukernel zero-init gemm_ukernel_generator.nim:189)
   auto fold = [&]() __attribute__((always_inline)) {
     if constexpr (EXACT) {
+      asm volatile("; laser-order slice fold" ::: "memory");  // keeps this a real (rare) block, never if-converted
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -316,8 +322,6 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     }
   };
 
-  int until_fold = kc_tiles;
-
   if constexpr (STAGES == 2) {
     // -- prologue: tile 0 -> LDS stage 0 --
     la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
@@ -325,10 +329,10 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     la.store(smem, t);
     lb.store(smem + BK * BM, t);
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt++) {
+    auto k_tile2 = [&](auto MORE_, int kt) __attribute__((always_inline)) {
+      constexpr bool more = decltype(MORE_)::value;
       const float *sA = smem + (kt & 1) * STAGE;
       const float *sB = sA + BK * BM;
-      const bool more = (kt + 1) < nkt;
       if (more) {  // issue the next tile's HBM loads before the MFMA block (latency hides under it)
         la.load(Ab, g.rsA, g.csA, (int64_t)(kt + 1) * BK, mlim, K, t);
         lb.load(Bb, g.csB, g.rsB, (int64_t)(kt + 1) * BK, nlim, K, t, &g);
@@ -336,26 +340,41 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       ldfrag(sA, sB, 0, 0);
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        if (j + 1 < NJ) ldfrag(sA, sB, j + 1, (j + 1) & 1);
+        if (j + 1 < NJ) ldfrag(sA, sB, j + 1, (j + 1) & 3);
         // pin the order "LDS reads of step j+1, then MFMAs of step j": without it hipcc sinks each
         // ds_read down to its first use and every MFMA group eats the full LDS latency
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step(j & 1);
+        mfma_step(j & 3);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (EXACT) {
-        if (--until_fold == 0 && more) {
-          until_fold = kc_tiles;
-          fold();
-        }
-      }
-      if (more) {
-        float *dA = smem + ((kt + 1) & 1) * STAGE;
-        la.store(dA, t);
-        lb.store(dA + BK * BM, t);
-      }
+    };
+    auto refill = [&](int kt) __attribute__((always_inline)) {
+      float *dA = smem + ((kt + 1) & 1) * STAGE;
+      la.store(dA, t);
+      lb.store(dA + BK * BM, t);
       __syncthreads();
+    };
+    // slice folds live outside the steady-state loop (a test inside it is if-converted into
+    // predicated VALU work on every tile)
+    int kt = 0;
+    int next_fold = (EXACT && kc_tiles > 0) ? kc_tiles : 0x7fffffff;
+    for (;;) {
+      const int stop = min(next_fold - 1, nkt - 1);  // tiles [kt, stop) are followed by another tile of the same slice
+      for (; kt < stop; kt++) {
+        k_tile2(std::true_type{}, kt);
+        refill(kt);
+      }
+      if (kt == next_fold - 1 && kt + 1 < nkt) {  // last tile of a slice, more slices follow
+        k_tile2(std::true_type{}, kt);
+        fold();
+        refill(kt);
+        kt++;
+        next_fold += kc_tiles;
+        continue;
+      }
+      break;
     }
+    if (kt < nkt) k_tile2(std::false_type{}, kt);
   } else {
     // -- prologue: tile 0 -> LDS stage 0; tile 1 -> registers --
     la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
@@ -367,7 +386,8 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       lb.load(Bb, g.csB, g.rsB, BK, nlim, K, t, &g);
     }
     __syncthreads();
-    ldfrag(smem, smem + BK * BM, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PFD; j++) ldfrag(smem, smem + BK * BM, j, j);
     int st = 0;  // stage holding tile kt
     // One K-tile.  MORE / MORE2 (tile kt+1 / kt+2 exist) are compile-time so that the steady-state
     // body is ONE basic block: hipcc then derives exact counted `s_waitcnt vmcnt(N)` for the
@@ -413,18 +433,18 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       for (int j = 0; j < NJ; j++) {
         // everyone's stores of tile kt+1 are done past this point
         if (j == NJ / 2 && (!DBG || !(g.dbg & 4))) __syncthreads();
-        if (j + 1 < NJ)
-          ldfrag(sA, sB, j + 1, (j + 1) & 1);
+        if (j + PFD < NJ)
+          ldfrag(sA, sB, j + PFD, (j + PFD) & 3);
         else if (more)
-          ldfrag(nA, nB, 0, (j + 1) & 1);  // NJ even => slot 0: first fragments of the next tile
-        // pin the order "LDS reads of step j+1, then MFMAs of step j": without it hipcc sinks each
+          ldfrag(nA, nB, j + PFD - NJ, (j + PFD) & 3);  // first fragments of the next tile (past the barrier)
+        // pin the order "LDS reads of step j+PFD, then MFMAs of step j": without it hipcc sinks each
         // ds_read down to its first use and every MFMA group eats the full LDS latency
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int n = 0; n < TN; n++) {
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][i], fb[j & 1][n], acc[i][n], 0, 0, 0);
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 3][i], fb[j & 3][n], acc[i][n], 0, 0, 0);
             if (more && j < NJ / 2) {
               const int slot = j * NMF + i * TN + n;
 #pragma unroll
@@ -433,21 +453,31 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
             __builtin_amdgcn_sched_barrier(0);  // one staging op rides behind each MFMA
           }
       }
-      if constexpr (EXACT) {
-        if (--until_fold == 0 && more) {
-          until_fold = kc_tiles;
-          fold();
-        }
-      }
       st = st1;
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
+    // Slice boundaries are handled OUTSIDE the steady-state loop: a fold test inside it gets
+    // if-converted by hipcc into 256 predicated VALU ops per K-tile (measured -3 %).
     int kt = 0;
-    for (; kt + 2 < nkt; kt++) k_tile(T_{}, T_{}, kt);
+    int next_fold = (EXACT && kc_tiles > 0) ? kc_tiles : 0x7fffffff;  // fold once tiles [.., next_fold) are done
+    for (;;) {
+      const int stop = min(next_fold, nkt - 2);
+      for (; kt < stop; kt++) k_tile(T_{}, T_{}, kt);
+      if (kt == next_fold && kt < nkt) {
+        fold();
+        next_fold += kc_tiles;
+        continue;
+      }
+      break;
+    }
     if (kt + 1 < nkt) {
       k_tile(T_{}, F_{}, kt);
       kt++;
+      if (kt == next_fold && kt < nkt) {
+        fold();
+        next_fold += kc_tiles;
+      }
     }
     if (kt < nkt) k_tile(F_{}, F_{}, kt);
   }
