@@ -10,7 +10,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -49,6 +52,7 @@ struct Context {
   std::string arch;
   int float_mode = LASER_HIP_F32_LASER_ORDER;
   int f32_cfg = -1;
+  hipStream_t s_up = nullptr, s_comp = nullptr;  // host-pointer pipeline: uploads / kernels
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
   bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
   // cached device scratch for the host-pointer paths, one growing buffer per role
@@ -171,6 +175,110 @@ int gemm_dev(int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, const T *A
   return LASER_HIP_OK;
 }
 
+// Row-panel pipelined host path (see gemm_host).  dA0/dB0/dC0 are the device addresses of element
+// (0,0) of each operand inside the cached scratch; Bspan/bn = host span of B; dBbuf = its device copy.
+template <typename T>
+int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *Bspan,
+                        size_t bn, int64_t rsB, int64_t csB, T beta, T *C, int64_t rsC, int64_t csC, const T *dA0,
+                        const T *dB0, T *dBbuf, T *dC0, bool c_up) {
+  if (!g_ctx.s_up) {
+    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.s_up, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.s_comp, hipStreamNonBlocking));
+  }
+  int64_t R = (M / 8 + 255) / 256 * 256;  // ~8 panels, whole 256-row tiles
+  if (R < 256) R = 256;
+  const int nchunks = (int)((M + R - 1) / R);
+  std::vector<hipEvent_t> ev_up(nchunks), ev_comp(nchunks);
+  for (int i = 0; i < nchunks; i++) {
+    HIP_TRY(hipEventCreateWithFlags(&ev_up[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_comp[i], hipEventDisableTiming));
+  }
+  const int64_t ca = (K - 1) * csA, cc = (N - 1) * csC;
+  auto a_span = [&](int64_t r0, int64_t r1, int64_t *lo, int64_t *hi) {
+    *lo = r0 * rsA + std::min<int64_t>(0, ca);
+    *hi = (r1 - 1) * rsA + std::max<int64_t>(0, ca);
+  };
+  auto c_span = [&](int64_t r0, int64_t r1, int64_t *lo, int64_t *hi) {
+    *lo = r0 * rsC + std::min<int64_t>(0, cc);
+    *hi = (r1 - 1) * rsC + std::max<int64_t>(0, cc);
+  };
+
+  // helper thread: copy finished C panels back while the main thread keeps uploading
+  std::mutex qm;
+  std::condition_variable qcv;
+  std::deque<int> queue;
+  bool closed = false;
+  hipError_t down_err = hipSuccess;
+  const int device = g_ctx.device;
+  std::thread downloader([&]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      int i;
+      {
+        std::unique_lock<std::mutex> lk(qm);
+        qcv.wait(lk, [&] { return !queue.empty() || closed; });
+        if (queue.empty()) return;
+        i = queue.front();
+        queue.pop_front();
+      }
+      const int64_t r0 = i * R, r1 = std::min<int64_t>(M, r0 + R);
+      int64_t lo, hi;
+      c_span(r0, r1, &lo, &hi);
+      hipError_t e = hipEventSynchronize(ev_comp[i]);
+      if (e == hipSuccess) e = hipMemcpy(C + lo, dC0 + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyDeviceToHost);
+      if (e != hipSuccess && down_err == hipSuccess) down_err = e;
+    }
+  });
+  auto finish = [&]() {
+    {
+      std::lock_guard<std::mutex> lk(qm);
+      closed = true;
+    }
+    qcv.notify_all();
+    downloader.join();
+    for (int i = 0; i < nchunks; i++) {
+      (void)hipEventDestroy(ev_up[i]);
+      (void)hipEventDestroy(ev_comp[i]);
+    }
+  };
+#define PIPE_TRY(expr)                                                                                        \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) {                                                                                   \
+      finish();                                                                                               \
+      (void)hipDeviceSynchronize();                                                                           \
+      return fail(LASER_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                                         \
+  } while (0)
+
+  PIPE_TRY(hipMemcpyAsync(dBbuf, Bspan, bn * sizeof(T), hipMemcpyHostToDevice, g_ctx.s_up));
+  for (int i = 0; i < nchunks; i++) {
+    const int64_t r0 = i * R, r1 = std::min<int64_t>(M, r0 + R);
+    int64_t lo, hi;
+    a_span(r0, r1, &lo, &hi);
+    PIPE_TRY(hipMemcpyAsync((T *)dA0 + lo, A + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyHostToDevice, g_ctx.s_up));
+    if (c_up) {
+      c_span(r0, r1, &lo, &hi);
+      PIPE_TRY(hipMemcpyAsync(dC0 + lo, C + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyHostToDevice, g_ctx.s_up));
+    }
+    PIPE_TRY(hipEventRecord(ev_up[i], g_ctx.s_up));
+    PIPE_TRY(hipStreamWaitEvent(g_ctx.s_comp, ev_up[i], 0));
+    GemmArgs<T> a = make_args<T>(1, r1 - r0, N, K, alpha, dA0 + r0 * rsA, rsA, csA, 0, dB0, rsB, csB, 0, beta,
+                                 dC0 + r0 * rsC, rsC, csC, 0);
+    PIPE_TRY(run_gemm<T>(a, g_ctx.s_comp));
+    PIPE_TRY(hipEventRecord(ev_comp[i], g_ctx.s_comp));
+    {
+      std::lock_guard<std::mutex> lk(qm);
+      queue.push_back(i);
+    }
+    qcv.notify_one();
+  }
+#undef PIPE_TRY
+  finish();
+  if (down_err != hipSuccess) return fail(LASER_HIP_E_HIP, "D2H of a C panel failed: %s", hipGetErrorString(down_err));
+  return LASER_HIP_OK;
+}
+
 // Host-pointer gemm_strided: stage the touched span of each operand, run, copy the C span back.
 template <typename T>
 int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *B,
@@ -189,14 +297,27 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   if (int rc = scratch_get(0, an * sizeof(T), &dA)) return rc;
   if (int rc = scratch_get(1, bn * sizeof(T), &dB)) return rc;
   if (int rc = scratch_get(2, cn * sizeof(T), &dC)) return rc;
-  HIP_TRY(hipMemcpy(dA, A + alo, an * sizeof(T), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dB, B + blo, bn * sizeof(T), hipMemcpyHostToDevice));
   // C must be uploaded when it is read (beta != 0) or when its span has gaps that belong to the
   // caller (so the copy-back restores them unchanged).  A dense C with beta == 0 is write-only.
   const bool c_dense = (cn == (size_t)M * (size_t)N);
-  if (beta != (T)0 || !c_dense) HIP_TRY(hipMemcpy(dC, C + clo, cn * sizeof(T), hipMemcpyHostToDevice));
-  GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, (const T *)dA - alo, rsA, csA, 0, (const T *)dB - blo, rsB,
-                               csB, 0, beta, (T *)dC - clo, rsC, csC, 0);
+  const bool c_up = (beta != (T)0 || !c_dense);
+  const T *dA0 = (const T *)dA - alo, *dB0 = (const T *)dB - blo;
+  T *dC0 = (T *)dC - clo;
+
+  // Large row-major-like problems: stream row panels so PCIe and the kernel overlap (rows of C are
+  // independent, so the per-element arithmetic is unchanged):
+  //   main thread : H2D B, then per panel  H2D A_i [+ C_i]  ->  kernel_i on its own stream
+  //   helper thread: D2H C_i as soon as kernel_i is done (PCIe is full duplex)
+  auto iabs = [](int64_t v) { return v < 0 ? -v : v; };
+  const bool panels_disjoint = rsA > 0 && rsC > 0 && rsA >= iabs(csA) * (K - 1) + 1 && rsC >= iabs(csC) * (N - 1) + 1;
+  if (panels_disjoint && M >= 2048 && (an + bn + cn) * sizeof(T) >= ((size_t)64 << 20))
+    return gemm_host_pipelined<T>(M, N, K, alpha, A, rsA, csA, B + blo, bn, rsB, csB, beta, C, rsC, csC, dA0, dB0,
+                                  (T *)dB, dC0, c_up);
+
+  HIP_TRY(hipMemcpy(dA, A + alo, an * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dB, B + blo, bn * sizeof(T), hipMemcpyHostToDevice));
+  if (c_up) HIP_TRY(hipMemcpy(dC, C + clo, cn * sizeof(T), hipMemcpyHostToDevice));
+  GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, dA0, rsA, csA, 0, dB0, rsB, csB, 0, beta, dC0, rsC, csC, 0);
   HIP_TRY(run_gemm<T>(a, nullptr));
   HIP_TRY(hipMemcpy(C + clo, dC, cn * sizeof(T), hipMemcpyDeviceToHost));  // synchronises
   return LASER_HIP_OK;
@@ -458,6 +579,11 @@ int laser_hip_finalize(void) {
   }
   for (auto &kv : g_panels) (void)hipFree(kv.second.ptr);
   g_panels.clear();
+  if (g_ctx.s_up) {
+    (void)hipStreamDestroy(g_ctx.s_up);
+    (void)hipStreamDestroy(g_ctx.s_comp);
+    g_ctx.s_up = g_ctx.s_comp = nullptr;
+  }
   g_ctx.ready = false;
   return LASER_HIP_OK;
 }

@@ -228,6 +228,27 @@ def test_device_resident_path_matches_host_path(la, oracle):
         assert np.array_equal(la.matmul(dA, dBt).cpu().numpy(), want)
 
 
+def test_host_pointer_pipelined_path(la, oracle):
+    """Large host-pointer calls stream row panels (H2D / kernel / D2H overlapped): same bits as the
+    oracle, beta != 0 and a C view with caller-owned gaps included, float32 and int32."""
+    rng = np.random.default_rng(22)
+    M, N, K = 4096, 2048, 2048          # 80 MB of operands: above the pipelining threshold
+    A = rand(rng, (M, K), np.float32)
+    B = rand(rng, (K, N), np.float32)
+    C0 = rand(rng, (M, N), np.float32)
+    want = oracle.matmul(A, B, 1, 0, np.zeros((M, N), np.float32))
+    assert np.array_equal(la.matmul(A, B), want)
+    want2 = oracle.matmul(A, B, 0.5, 0.25, C0.copy())
+    assert np.array_equal(la.matmul(A, B, 0.5, 0.25, C0.copy()), want2)
+    Cbuf = np.full((M, N + 8), np.nan, dtype=np.float32)      # row stride N+8: gaps owned by the caller
+    la.matmul(A[:, ::-1], B[::-1, :], 1, 0, Cbuf[:, :N])       # negative k strides on both operands
+    assert np.array_equal(Cbuf[:, :N], oracle.matmul(np.ascontiguousarray(A[:, ::-1]), np.ascontiguousarray(B[::-1, :])))
+    assert np.isnan(Cbuf[:, N:]).all()
+    Ai = rng.integers(-2**31, 2**31 - 1, (M, K), dtype=np.int32)
+    Bi = rng.integers(-2**31, 2**31 - 1, (K, N), dtype=np.int32)
+    assert np.array_equal(la.matmul(Ai, Bi), oracle.matmul(Ai, Bi))
+
+
 def test_batched_device_gemm(la, oracle):
     import torch
     rng = np.random.default_rng(16)
