@@ -243,7 +243,7 @@ def main():
             ach = 2.0 * n * n * n / (k_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "gemm_f32_mfma_kernel", "kernel_ms": round(k_ms, 4),
+                               "kernel": "gemm_mfma_kernel<float,...>", "kernel_ms": round(k_ms, 4),
                                "algorithmic_flops_per_launch": 2.0 * n * n * n}
             tr = pmc_traffic(mode)
             if tr is not None:

@@ -69,6 +69,9 @@ int laser_hip_set_conv_implicit(int on);
 /* int32 GEMM strategy: 1 (default) = signed 8-bit limb decomposition on the int8 matrix cores
  * (bit-exact mod 2^32); 0 = the VALU kernel.  Results are bit-identical. */
 int laser_hip_set_i32_mfma(int on);
+/* float64 GEMM strategy: 1 (default) = v_mfma_f64_16x16x4_f64 (bitwise a k-ordered fma chain, so the
+ * laser-order result is unchanged); 0 = the VALU kernel.  Results are bit-identical. */
+int laser_hip_set_f64_mfma(int on);
 const char *laser_hip_f32_config_name(int cfg);
 
 /* ---- gemm_strided -- laser/primitives/matrix_multiplication/gemm.nim:184-193 ------------------

@@ -53,6 +53,7 @@ struct Context {
   int float_mode = LASER_HIP_F32_LASER_ORDER;
   int f32_cfg = -1;
   hipStream_t s_up = nullptr, s_comp = nullptr;  // host-pointer pipeline: uploads / kernels
+  bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
   bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
   // cached device scratch for the host-pointer paths, one growing buffer per role
@@ -122,7 +123,9 @@ hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
 }
 template <>
 hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
-  return launch_gemm_valu<double>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+  const bool laser = g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER;
+  if (g_ctx.f64_mfma) return launch_gemm_f64(a, laser, s);  // v_mfma_f64_16x16x4_f64: a k-ordered fma chain
+  return launch_gemm_valu<double>(a, laser, s);
 }
 template <>
 hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
@@ -611,6 +614,11 @@ int laser_hip_set_f32_config(int cfg) {
   return LASER_HIP_OK;
 }
 int laser_hip_f32_config_count(void) { return gemm_f32_config_count(); }
+// 1 = float64 GEMM on the f64 matrix cores (default), 0 = VALU kernel (comparison / A-B timing)
+int laser_hip_set_f64_mfma(int on) {
+  g_ctx.f64_mfma = on != 0;
+  return LASER_HIP_OK;
+}
 // 1 = int32 GEMM via int8-limb MFMA (default), 0 = VALU kernel (comparison / A-B timing)
 int laser_hip_set_i32_mfma(int on) {
   g_ctx.i32_mfma = on != 0;

@@ -49,6 +49,7 @@ enum LoadMode : int {
 };
 
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
+hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
 // args.B = NCHW input, args.bsB = C*H*W, args.c* = geometry, N = oH*oW, K = C*kH*kW; A = filter
 hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
 hipError_t launch_gemm_f32_probe(const GemmArgs<float> &args, int dbg, hipStream_t s);

@@ -2,7 +2,7 @@
 // the 256x256x16 3-stage fast kernel with run-time ablation switches (dbg bit 0: skip HBM loads,
 // bit 1: skip LDS stores, bit 2: skip barriers) to price each part of the main loop.  Results are
 // WRONG by construction when any switch is on; scripts/ablate_f32.py only times it.
-#include "gemm_f32_mfma_kernel.h"
+#include "gemm_mfma_kernel.h"
 
 namespace laser_hip {
 hipError_t launch_gemm_f32_probe(const GemmArgs<float> &a, int dbg, hipStream_t s) {
@@ -10,6 +10,6 @@ hipError_t launch_gemm_f32_probe(const GemmArgs<float> &a, int dbg, hipStream_t 
   g.dbg = dbg;
   g.kc = 0;
   g.Mext = g.M; g.Next = g.N; g.Kext = g.K;
-  return launch_one<256, 256, 16, 2, 4, LOAD_VEC_K, LOAD_VEC_X, false, 3, 2, true>(g, s);
+  return launch_one<float, 256, 256, 16, 2, 4, LOAD_VEC_K, LOAD_VEC_X, false, 3, 2, true>(g, s);
 }
 }  // namespace laser_hip

@@ -1,0 +1,146 @@
+// laser_amd/csrc/gemm_mfma.hip -- host-side dispatch for the f32 / f64 MFMA GEMMs: picks the tile
+// configuration and, per operand, the HBM->LDS "packing" loader that matches its strides.
+// This replaces the reference's run-time ISA dispatch (gemm.nim:228-247) and its Tiles/partitionMNK
+// geometry (gemm_tiling.nim:276-341) -- on the GPU the geometry is the workgroup tile.
+#include "common.h"
+#include "gemm_mfma_cfgs.h"
+
+namespace laser_hip {
+
+template <typename E>
+struct CfgInfo {
+  int bm, bn, bk, wm, wn, stages;
+  bool vec, gen, exact;
+  const char *name;
+  hipError_t (*fn)(const GemmArgs<E> &, int, int, bool, hipStream_t);
+};
+
+#define X(IDX, BM, BN, BK, WM, WN, ST, OF, OE, WV, WG, WE) \
+  {BM, BN, BK, WM, WN, ST, WV, WG, WE, #BM "x" #BN "x" #BK "_w" #WM "x" #WN "_s" #ST, &launch_gemm_f32_cfg<IDX>},
+static const CfgInfo<float> kCfgsF32[LH_F32_NUM_CONFIGS] = {LH_F32_CONFIGS(X)};
+#undef X
+#define X(IDX, BM, BN, BK, WM, WN, ST, OF, OE, WV, WG, WE) \
+  {BM, BN, BK, WM, WN, ST, WV, WG, WE, #BM "x" #BN "x" #BK "_w" #WM "x" #WN "_s" #ST, &launch_gemm_f64_cfg<IDX>},
+static const CfgInfo<double> kCfgsF64[LH_F64_NUM_CONFIGS] = {LH_F64_CONFIGS(X)};
+#undef X
+
+int gemm_f32_config_count() { return LH_F32_NUM_CONFIGS; }
+const char *gemm_f32_config_name(int cfg) {
+  return (cfg >= 0 && cfg < LH_F32_NUM_CONFIGS) ? kCfgsF32[cfg].name : "?";
+}
+
+static inline int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
+
+// Which loader can bring operand X (x = its M/N axis with stride sx, k with stride sk) into LDS?
+// EPV = elements per 16 bytes (4 for f32, 2 for f64).
+//   *vec  : plain 16-B vector loads  -- unit stride on one axis, other stride and batch stride
+//           multiples of EPV elements, 16-B aligned base, no ragged tile in x or k;
+//   *edge : the clamped / zero-selecting 16-B form -- same alignment, extents multiples of EPV only;
+//   otherwise the predicated scalar loaders (GEN) handle anything.
+template <typename E>
+static int pick_mode(const E *p, int64_t sx, int64_t sk, int64_t bs, int64_t X, int64_t K, int bx, int bk,
+                     bool *vec, bool *edge) {
+  constexpr int64_t EPV = 16 / sizeof(E);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (bs % EPV == 0);
+  const bool full = (X % bx == 0) && (K % bk == 0);
+  *vec = *edge = false;
+  if (sk == 1) {
+    const bool ok = aligned && (sx % EPV == 0);
+    *vec = ok && full;
+    *edge = ok && (K % EPV == 0) && K >= EPV && X >= 1;
+    return LOAD_VEC_K;
+  }
+  if (sx == 1) {
+    const bool ok = aligned && (sk % EPV == 0);
+    *vec = ok && full;
+    *edge = ok && (X % EPV == 0) && X >= EPV;
+    return LOAD_VEC_X;
+  }
+  return iabs64(sk) <= iabs64(sx) ? LOAD_VEC_K : LOAD_VEC_X;
+}
+
+static int to_gen(int mode) { return mode == LOAD_VEC_K ? LOAD_GEN_K : LOAD_GEN_X; }
+static int to_edge(int mode) { return mode == LOAD_VEC_K ? LOAD_VEC_K_EDGE : LOAD_VEC_X_EDGE; }
+
+template <typename E>
+static int64_t tiles_of(const GemmArgs<E> &a, int bm, int bn) {
+  return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (int64_t)a.batch;
+}
+
+// fp32: largest tile that still gives every CU work (>= ~0.8 x 256 workgroups), else the next size down.
+constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3, kCfgWideExact = 4;
+static int heuristic_cfg(const GemmArgs<float> &a, bool exact) {
+  if (!exact && tiles_of(a, 256, 256) >= 200) return kCfgBig;
+  if (tiles_of(a, 256, 128) >= 200) return exact ? kCfgWideExact : kCfgWide;
+  if (tiles_of(a, 128, 128) >= 200) return kCfgMid;
+  if (tiles_of(a, 128, 128) >= 2 * tiles_of(a, 64, 64) / 5 && tiles_of(a, 128, 128) >= 96) return kCfgMid;
+  return kCfgSmall;
+}
+static int fallback_exact_cfg(const GemmArgs<float> &) { return kCfgWideExact; }
+static int gen_cfg(const GemmArgs<float> &) { return kCfgSmall; }
+
+// fp64: two configurations.
+static int heuristic_cfg(const GemmArgs<double> &a, bool) { return tiles_of(a, 128, 128) >= 128 ? 0 : 1; }
+static int fallback_exact_cfg(const GemmArgs<double> &) { return 0; }
+static int gen_cfg(const GemmArgs<double> &) { return 1; }
+
+template <typename E>
+static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, int ncfg, int cfg, bool laser_order,
+                              int kc_elems, hipStream_t s) {
+  if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
+  GemmArgs<E> a = args;
+  if (a.Mext < a.M) a.Mext = a.M;
+  if (a.Next < a.N) a.Next = a.N;
+  if (a.Kext < a.K) a.Kext = a.K;
+  a.dbg = 0;
+  // K <= kc is ONE accumulation slice: the single-chain kernel already is Laser's arithmetic, so the
+  // second accumulator set of the laser-order kernels is only paid for when K > kc.
+  const bool exact = laser_order && a.K > kc_elems;
+  a.kc = exact ? kc_elems : 0;  // gemm_tiling.nim:310: kc = 2048 / sizeof(T)
+  if (cfg < 0 || cfg >= ncfg) cfg = heuristic_cfg(a, exact);
+  if (exact && !cfgs[cfg].exact) cfg = fallback_exact_cfg(a);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const CfgInfo<E> &c = cfgs[cfg];
+    bool va, vb, ea, eb;
+    const int am = pick_mode<E>(a.A, a.rsA, a.csA, a.bsA, a.Mext, a.Kext, c.bm, c.bk, &va, &ea);
+    const int bm = pick_mode<E>(a.B, a.csB, a.rsB, a.bsB, a.Next, a.Kext, c.bn, c.bk, &vb, &eb);
+    if (c.vec && va && vb) return c.fn(a, am, bm, exact, s);
+    if (c.vec && (va || ea) && (vb || eb)) return c.fn(a, to_edge(am), to_edge(bm), exact, s);
+    if (c.gen) return c.fn(a, to_gen(am), to_gen(bm), exact, s);
+    cfg = gen_cfg(a);  // the configuration that carries the scalar (any-stride) loaders
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
+  return launch_mfma<float>(args, kCfgsF32, LH_F32_NUM_CONFIGS, cfg, laser_order, 512, s);
+}
+
+hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipStream_t s) {
+  return launch_mfma<double>(args, kCfgsF64, LH_F64_NUM_CONFIGS, -1, laser_order, 256, s);
+}
+
+// Implicit-GEMM convolution: same kernels, B loader = LOAD_IM2COL.  M = C_out, N = oH*oW, K = C_in*kH*kW,
+// batch = images; A (the filter bank) is always k-contiguous.
+hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
+  if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
+  GemmArgs<float> a = args;
+  a.Mext = a.M; a.Next = a.N; a.Kext = a.K;
+  a.dbg = 0;
+  const bool exact = laser_order && a.K > 512;
+  a.kc = exact ? 512 : 0;
+  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact);
+  if (exact && !kCfgsF32[cfg].exact) cfg = kCfgWideExact;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const CfgInfo<float> &c = kCfgsF32[cfg];
+    bool va, ea;
+    pick_mode<float>(a.A, a.rsA, a.csA, a.bsA, a.M, a.K, c.bm, c.bk, &va, &ea);
+    if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, LOAD_IM2COL, exact, s);
+    if (a.csA == 1 && ea) return c.fn(a, LOAD_VEC_K_EDGE, LOAD_IM2COL, exact, s);
+    if (c.gen) return c.fn(a, LOAD_GEN_K, LOAD_IM2COL, exact, s);
+    cfg = kCfgSmall;
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace laser_hip

@@ -1,11 +1,12 @@
-// laser_amd/csrc/gemm_f32_cfgs.h -- the tile configurations of the f32 MFMA kernel.
+// laser_amd/csrc/gemm_mfma_cfgs.h -- the tile configurations of the f32 / f64 MFMA kernels.
 // X(index, BM, BN, BK, WM, WN, STAGES, OCC_FAST, OCC_EXACT, WITH_VEC, WITH_GEN, WITH_EXACT)
 //   BM x BN x BK   workgroup tile;  WM x WN  waves (wave tile = BM/WM x BN/WN, built of 32x32 MFMAs)
 //   STAGES         LDS stages (2: barrier per tile end; 3: ring with mid-tile barrier)
 //   OCC_*          waves per SIMD requested from the register allocator (fast / laser-order kernels)
 //   WITH_GEN       also build the predicated scalar loaders (arbitrary strides, ragged edges)
 //   WITH_EXACT     also build the laser-order kernel (needs a second accumulator set in registers)
-// Each line is compiled in its own translation unit (gemm_f32_cfg.hip with -DLH_CFG=index).
+// Each line is compiled in its own translation unit (gemm_mfma_cfg.hip with -DLH_CFG=index, plus
+// -DLH_F64 for the float64 list).
 #pragma once
 #include "common.h"
 #define LH_F32_CONFIGS(X)                                        \
@@ -22,9 +23,18 @@
 // 128x256x32 (= cfg 4 within noise), 4-wave 256x128 / 128x256 tiles at 1 wave/SIMD for laser-order
 // (-8 %), fragment prefetch distance 2 (no gain at 1 WG/CU, costs the 128-VGPR step of cfg 1 fast).
 
+// float64 (v_mfma_f64_16x16x4_f64, 16x16 blocks, 4 k per instruction): the 8-wave 128x128 tile has the
+// same cadence as f32 cfg 0 (8 MFMAs of 64 cycles per k-step); laser-order needs acc 64 + run 64 regs.
+#define LH_F64_CONFIGS(X)                                        \
+  X(0, 128, 128, 16, 2, 4, 3, 2, 2, true, false, true)           \
+  X(1, 64, 64, 16, 2, 2, 2, 2, 2, true, true, true)
+#define LH_F64_NUM_CONFIGS 2
+
 namespace laser_hip {
 template <int IDX>
 struct F32Cfg;
+template <int IDX>
+struct F64Cfg;
 #define X(IDX, BM_, BN_, BK_, WM_, WN_, ST_, OF_, OE_, WV_, WG_, WE_)                                  \
   template <>                                                                                          \
   struct F32Cfg<IDX> {                                                                                 \
@@ -34,13 +44,29 @@ struct F32Cfg;
   };
 LH_F32_CONFIGS(X)
 #undef X
+#define X(IDX, BM_, BN_, BK_, WM_, WN_, ST_, OF_, OE_, WV_, WG_, WE_)                                  \
+  template <>                                                                                          \
+  struct F64Cfg<IDX> {                                                                                 \
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, STAGES = ST_, OCCF = OF_,   \
+                         OCCE = OE_;                                                                   \
+    static constexpr bool VEC = WV_, GEN = WG_, EXACT = WE_;                                           \
+  };
+LH_F64_CONFIGS(X)
+#undef X
 
-// defined in gemm_f32_cfg.hip (one explicit specialisation per translation unit)
+// defined in gemm_mfma_cfg.hip (one explicit specialisation per translation unit)
 template <int IDX>
 hipError_t launch_gemm_f32_cfg(const GemmArgs<float> &a, int amode, int bmode, bool exact, hipStream_t s);
 #define X(IDX, ...) \
   template <>       \
   hipError_t launch_gemm_f32_cfg<IDX>(const GemmArgs<float> &, int, int, bool, hipStream_t);
 LH_F32_CONFIGS(X)
+#undef X
+template <int IDX>
+hipError_t launch_gemm_f64_cfg(const GemmArgs<double> &a, int amode, int bmode, bool exact, hipStream_t s);
+#define X(IDX, ...) \
+  template <>       \
+  hipError_t launch_gemm_f64_cfg<IDX>(const GemmArgs<double> &, int, int, bool, hipStream_t);
+LH_F64_CONFIGS(X)
 #undef X
 }  // namespace laser_hip

@@ -1,4 +1,5 @@
-// laser_amd/csrc/gemm_f32_mfma_kernel.h -- fp32 GEMM on the gfx950 exact-f32 matrix cores.
+// laser_amd/csrc/gemm_mfma_kernel.h -- fp32 / fp64 GEMM on the gfx950 exact-IEEE matrix cores
+// (v_mfma_f32_32x32x2_f32, v_mfma_f64_16x16x4_f64: both are bitwise k-ordered fma chains).
 //
 // GPU re-mapping of Laser's Goto/BLIS nest (gemm.nim:109-176), not a translation of it:
 //
@@ -35,33 +36,82 @@ namespace laser_hip {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+using f64x2 = __attribute__((ext_vector_type(2))) double;
 
-template <int BK>
-struct SwzShift {
-  static_assert(BK == 8 || BK == 16 || BK == 32, "BK must be 8, 16 or 32");
-  static constexpr int value = (BK == 32) ? 2 : (BK == 16) ? 3 : 4;
+// Per-element-type description of the matrix instruction and of a 16-byte memory piece.
+//   EPV   elements per 16-byte vector           MB   edge of one MFMA output block
+//   KS    k consumed by one MFMA                ACC  accumulator elements per lane per block
+//   lane -> operand element: A[x = lx(lane)][k = lk(lane)], B[k = lk(lane)][x = lx(lane)]
+//   accumulator element r of lane -> C[acc_row(r, lane)][acc_col(lane)]
+template <typename E>
+struct Mma;
+template <>
+struct Mma<float> {
+  using Vec = f32x4;
+  using Acc = f32x16;
+  static constexpr int EPV = 4, MB = 32, KS = 2, ACC = 16, WGRP = 32;  // WGRP: lanes per ds_write bank group
+  static constexpr int KC = 512;                                       // gemm_tiling.nim:310: 2048 / sizeof(float32)
+  static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int lx(int lane) { return lane & 31; }
+  static __device__ __forceinline__ int lk(int lane) { return lane >> 5; }
+  static __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+  static __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
+  static __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+  static __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+};
+template <>
+struct Mma<double> {
+  using Vec = f64x2;
+  using Acc = f64x4;
+  static constexpr int EPV = 2, MB = 16, KS = 4, ACC = 4, WGRP = 16;
+  static constexpr int KC = 256;                                       // 2048 / sizeof(float64)
+  static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int lx(int lane) { return lane & 15; }
+  static __device__ __forceinline__ int lk(int lane) { return lane >> 4; }
+  static __device__ __forceinline__ int acc_row(int r, int lane) { return (lane >> 4) + 4 * r; }
+  static __device__ __forceinline__ int acc_col(int lane) { return lane & 15; }
+  static __device__ __forceinline__ double mul(double a, double b) { return __dmul_rn(a, b); }
+  static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
 };
 
-template <int BK>
+// LDS panel swizzle: element (k, x) lives at T[k][x ^ swz(k)], swz(k) = ((k / EPV) & 7) << SHIFT.
+// A transposing write group (WGRP lanes = BK/EPV k-pieces x WGRP/(BK/EPV) consecutive x) then covers
+// WGRP distinct banks; SHIFT >= log2(EPV) keeps a 16-byte piece along x contiguous; swz < MB keeps a
+// fragment inside its MFMA block.
+template <typename E, int BK>
+struct SwzShift {
+  static constexpr int NKQ = BK / Mma<E>::EPV;
+  static constexpr int value = (Mma<E>::WGRP / NKQ >= 16) ? 4 : (Mma<E>::WGRP / NKQ >= 8) ? 3 : (Mma<E>::WGRP / NKQ >= 4) ? 2
+                               : (Mma<E>::WGRP / NKQ >= 2) ? 1 : 0;
+  static_assert(NKQ >= 1 && NKQ <= 8 && ((NKQ - 1) << value) < Mma<E>::MB, "unsupported BK for this element type");
+};
+
+template <typename E, int BK>
 __device__ __forceinline__ int swz(int k) {
-  return ((k >> 2) & 7) << SwzShift<BK>::value;
+  return ((k / Mma<E>::EPV) & 7) << SwzShift<E, BK>::value;
 }
 
 // ---- operand tile loader: HBM -> registers -> LDS panel (the "packing" stage) -------------------
-template <int BX, int BK, int NT, int MODE>
+template <typename E, int BX, int BK, int NT, int MODE>
 struct TileLoader {
-  static constexpr int NV = (BX * BK / 4) / NT;  // 16-B pieces per thread per tile
-  static_assert(NV >= 1 && (BX * BK / 4) % NT == 0, "tile must split evenly over the workgroup");
+  using M_ = Mma<E>;
+  using Vec = typename M_::Vec;
+  static constexpr int EPV = M_::EPV;
+  static constexpr int NV = (BX * BK / EPV) / NT;  // 16-B pieces per thread per tile
+  static_assert(NV >= 1 && (BX * BK / EPV) % NT == 0, "tile must split evenly over the workgroup");
   static constexpr bool ALONG_K = (MODE == LOAD_VEC_K || MODE == LOAD_GEN_K || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool EDGE = (MODE == LOAD_VEC_X_EDGE || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || EDGE);
   static constexpr bool CONV = (MODE == LOAD_IM2COL);
-  f32x4 v[NV];
+  static_assert(!CONV || std::is_same<E, float>::value, "the implicit-GEMM loader is fp32 only");
+  static_assert(ALONG_K || SwzShift<E, BK>::value >= (EPV == 4 ? 2 : 1), "16-byte pieces along x must stay contiguous");
+  Vec v[NV];
   // LOAD_IM2COL: per piece and element, (oh*sH - pH) in the high and (ow*sW - pW) in the low 16 bits
   // of the output pixel this lane gathers for (fixed for the whole K loop); 0x7fff7fff = beyond N.
   int32_t pix[CONV ? NV : 1][CONV ? 4 : 1];
 
-  __device__ __forceinline__ void init_conv(const GemmArgs<float> &g, int64_t n0, int t) {
+  __device__ __forceinline__ void init_conv(const GemmArgs<E> &g, int64_t n0, int t) {
     if constexpr (CONV) {
 #pragma unroll
       for (int i = 0; i < NV; i++) {
@@ -84,14 +134,14 @@ struct TileLoader {
 
   // base: element (x=0,k=0) of this workgroup's operand panel; sx/sk element strides along x / k;
   // xlim/klim: number of valid x / k from `base` on (only used by the GEN modes).
-  __device__ __forceinline__ void load(const float *__restrict__ base, int64_t sx, int64_t sk,
+  __device__ __forceinline__ void load(const E *__restrict__ base, int64_t sx, int64_t sk,
                                        int64_t k0, int64_t xlim, int64_t klim, int t,
-                                       const GemmArgs<float> *cg = nullptr) {
+                                       const GemmArgs<E> *cg = nullptr) {
 #pragma unroll
     for (int i = 0; i < NV; i++) load_op(base, sx, sk, k0, xlim, klim, t, i, cg);
   }
 
-  __device__ __forceinline__ void store(float *__restrict__ lds, int t) const {
+  __device__ __forceinline__ void store(E *__restrict__ lds, int t) const {
 #pragma unroll
     for (int i = 0; i < NV; i++)
 #pragma unroll
@@ -100,27 +150,27 @@ struct TileLoader {
 
   // The same work cut into single-instruction "ops" so the main loop can slot one op between two
   // MFMAs instead of issuing the whole staging block at once (which idles the matrix pipe):
-  //   piece i (one 16-B register quad):  WOPS LDS-write ops (4 x ds_write_b32 when transposing,
-  //   1 x ds_write_b128 otherwise), then 1 load op that refills the quad for the tile after next.
-  static constexpr int WOPS = ALONG_K ? 4 : 1;
+  //   piece i (one 16-B register vector):  WOPS LDS-write ops (EPV scalar writes when transposing,
+  //   1 x ds_write_b128 otherwise), then 1 load op that refills the vector for the tile after next.
+  static constexpr int WOPS = ALONG_K ? EPV : 1;
   static constexpr int OPS_PER_PIECE = WOPS + 1;
   static constexpr int NOPS = NV * OPS_PER_PIECE;
 
-  __device__ __forceinline__ void store_op(float *__restrict__ lds, int t, int i, int c) const {
+  __device__ __forceinline__ void store_op(E *__restrict__ lds, int t, int i, int c) const {
     const int idx = t + i * NT;
     if constexpr (!ALONG_K) {
-      const int xq = idx % (BX / 4), k = idx / (BX / 4);
-      *reinterpret_cast<f32x4 *>(lds + k * BX + ((4 * xq) ^ swz<BK>(k))) = v[i];
+      const int xq = idx % (BX / EPV), k = idx / (BX / EPV);
+      *reinterpret_cast<Vec *>(lds + k * BX + ((EPV * xq) ^ swz<E, BK>(k))) = v[i];
     } else {
-      const int kq = idx % (BK / 4), x = idx / (BK / 4);
-      const int xs = x ^ swz<BK>(4 * kq);
-      lds[(4 * kq + c) * BX + xs] = v[i][c];
+      const int kq = idx % (BK / EPV), x = idx / (BK / EPV);
+      const int xs = x ^ swz<E, BK>(EPV * kq);
+      lds[(EPV * kq + c) * BX + xs] = v[i][c];
     }
   }
 
-  __device__ __forceinline__ void load_op(const float *__restrict__ base, int64_t sx, int64_t sk, int64_t k0,
+  __device__ __forceinline__ void load_op(const E *__restrict__ base, int64_t sx, int64_t sk, int64_t k0,
                                           int64_t xlim, int64_t klim, int t, int i,
-                                          const GemmArgs<float> *cg = nullptr) {
+                                          const GemmArgs<E> *cg = nullptr) {
     const int idx = t + i * NT;
     if constexpr (CONV) {
       // k -> (channel, kernel row, kernel col); the pixel part was decoded once in init_conv
@@ -130,50 +180,50 @@ struct TileLoader {
       const int c = kk / khw, rem = kk - c * khw;
       const int kr = rem / cg->ckW, kc = rem - kr * cg->ckW;
       const bool kin = kk < (int)klim;
-      const float *img = base + (int64_t)c * cg->cH * cg->cW;
+      const E *img = base + (int64_t)c * cg->cH * cg->cW;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int row = (int)(int16_t)(pix[i][e] >> 16) + kr, col = (int)(int16_t)(pix[i][e] & 0xffff) + kc;
         const bool ok = kin && (unsigned)row < (unsigned)cg->cH && (unsigned)col < (unsigned)cg->cW;
-        v[i][e] = ok ? img[row * cg->cW + col] : 0.0f;
+        v[i][e] = ok ? img[row * cg->cW + col] : (E)0;
       }
     } else if constexpr (!ALONG_K) {
-      const int xq = idx % (BX / 4), k = idx / (BX / 4);
+      const int xq = idx % (BX / EPV), k = idx / (BX / EPV);
       if constexpr (VEC && !EDGE) {
-        v[i] = *reinterpret_cast<const f32x4 *>(base + (k0 + k) * sk + 4 * xq);
+        v[i] = *reinterpret_cast<const Vec *>(base + (k0 + k) * sk + EPV * xq);
       } else if constexpr (EDGE) {
-        // xlim % 4 == 0 (checked by the dispatcher): a quad is entirely inside or outside in x
+        // xlim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in x
         const int64_t kk = k0 + k;
         const bool kin = kk < klim;
-        const int64_t xc = (4 * xq < xlim) ? 4 * xq : xlim - 4;
-        const f32x4 q = *reinterpret_cast<const f32x4 *>(base + (kin ? kk : 0) * sk + xc);
-        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int64_t xc = (EPV * xq < xlim) ? EPV * xq : xlim - EPV;
+        const Vec q = *reinterpret_cast<const Vec *>(base + (kin ? kk : 0) * sk + xc);
+        const Vec z = {};
         v[i] = kin ? q : z;
       } else {
         const int64_t kk = k0 + k;
-        const float *p = base + kk * sk + (int64_t)(4 * xq) * sx;
+        const E *p = base + kk * sk + (int64_t)(EPV * xq) * sx;
         const bool kin = kk < klim;
 #pragma unroll
-        for (int c = 0; c < 4; c++) v[i][c] = (kin && (4 * xq + c) < xlim) ? p[c * sx] : 0.0f;
+        for (int c = 0; c < EPV; c++) v[i][c] = (kin && (EPV * xq + c) < xlim) ? p[c * sx] : (E)0;
       }
     } else {
-      const int kq = idx % (BK / 4), x = idx / (BK / 4);
+      const int kq = idx % (BK / EPV), x = idx / (BK / EPV);
       if constexpr (VEC && !EDGE) {
-        v[i] = *reinterpret_cast<const f32x4 *>(base + (int64_t)x * sx + k0 + 4 * kq);
+        v[i] = *reinterpret_cast<const Vec *>(base + (int64_t)x * sx + k0 + EPV * kq);
       } else if constexpr (EDGE) {
-        // klim % 4 == 0 (checked by the dispatcher): a quad is entirely inside or outside in k
-        const int64_t kk = k0 + 4 * kq;
+        // klim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in k
+        const int64_t kk = k0 + EPV * kq;
         const bool kin = kk < klim;
         const int64_t xc = (x < xlim) ? x : xlim - 1;
-        const f32x4 q = *reinterpret_cast<const f32x4 *>(base + xc * sx + (kin ? kk : 0));
-        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        const Vec q = *reinterpret_cast<const Vec *>(base + xc * sx + (kin ? kk : 0));
+        const Vec z = {};
         v[i] = kin ? q : z;
       } else {
-        const int64_t kk = k0 + 4 * kq;
-        const float *p = base + (int64_t)x * sx + kk * sk;
+        const int64_t kk = k0 + EPV * kq;
+        const E *p = base + (int64_t)x * sx + kk * sk;
         const bool xin = x < xlim;
 #pragma unroll
-        for (int c = 0; c < 4; c++) v[i][c] = (xin && (kk + c) < klim) ? p[c * sk] : 0.0f;
+        for (int c = 0; c < EPV; c++) v[i][c] = (xin && (kk + c) < klim) ? p[c * sk] : (E)0;
       }
     }
   }
@@ -192,20 +242,24 @@ struct TileLoader {
 // Fragments are register double-buffered (k-step j+1 is read from LDS while step j's MFMAs issue).
 //
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for.
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
+template <typename E, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
           bool DBG = false>
 __global__ void __launch_bounds__(WM *WN * 64, OCC)
-    gemm_f32_mfma_kernel(const GemmArgs<float> g) {
+    gemm_mfma_kernel(const GemmArgs<E> g) {
+  using M_ = Mma<E>;
+  using Acc = typename M_::Acc;
+  constexpr int MB = M_::MB, KS = M_::KS, ACC = M_::ACC;
   constexpr int NT = WM * WN * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int NJ = BK / 2;  // MFMA k-steps (k-pairs) per K-tile
-  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be built from 32x32 MFMA blocks");
+  constexpr int TM = WTM / MB, TN = WTN / MB;
+  constexpr int NJ = BK / KS;  // MFMA k-steps per K-tile
+  static_assert(WTM % MB == 0 && WTN % MB == 0, "wave tile must be built from whole MFMA blocks");
   static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
-  static_assert(STAGES == 2 || BK >= 16, "ring form prefetches past the mid-tile barrier: needs NJ/2 >= 2");
-  constexpr int STAGE = BK * (BM + BN);  // floats per LDS stage: A panel then B panel
+  static_assert(STAGES == 2 || NJ >= 4, "ring form prefetches past the mid-tile barrier: needs NJ/2 >= 2");
+  constexpr int STAGE = BK * (BM + BN);  // elements per LDS stage: A panel then B panel
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  E *const smem = reinterpret_cast<E *>(smem_raw);
 
   // -- which C tile: XCD-aware (bijective) remap, then a grouped raster (8 tile-rows per group) --
   const int nwg = gridDim.x;
@@ -226,84 +280,85 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lane = t & 63, lo = lane & 31, hi = lane >> 5;
+  const int lane = t & 63, lo = M_::lx(lane), hi = M_::lk(lane);
   const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
 
-  const float *Ab = g.A + bz * g.bsA + m0 * g.rsA;  // x = row of A, k along csA
+  const E *Ab = g.A + bz * g.bsA + m0 * g.rsA;  // x = row of A, k along csA
   // x = col of B, k along rsB; for the implicit-GEMM conv the "matrix" is the NCHW image itself
-  const float *Bb = (BMODE == LOAD_IM2COL) ? g.B + bz * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
-  float *Cb = g.C + bz * g.bsC;
+  const E *Bb = (BMODE == LOAD_IM2COL) ? g.B + bz * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
+  E *Cb = g.C + bz * g.bsC;
   const int64_t K = g.K;
   const int64_t mlim = g.M - m0, nlim = g.N - n0;
 
-  TileLoader<BM, BK, NT, AMODE> la;
-  TileLoader<BN, BK, NT, BMODE> lb;
+  TileLoader<E, BM, BK, NT, AMODE> la;
+  TileLoader<E, BN, BK, NT, BMODE> lb;
   lb.init_conv(g, n0, t);
 
-  f32x16 acc[TM][TN];
+  Acc acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int n = 0; n < TN; n++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][n][r] = 0.0f;
+      for (int r = 0; r < ACC; r++) acc[i][n][r] = (E)0;
 
-  const float alpha = g.alpha, beta = g.beta;
+  const E alpha = g.alpha, beta = g.beta;
 
-  // C element owned by (i, n, r): row = wm0 + 32 i + (r&3) + 8 (r>>2) + 4 hi, col = wn0 + 32 n + lo
-  auto c_ptr = [&](int i, int n, int r, bool &ok) __attribute__((always_inline)) -> float * {
-    const int64_t row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    const int64_t col = n0 + wn0 + 32 * n + lo;
+  // C element owned by (block i, block n, accumulator element r) of this lane
+  auto c_ptr = [&](int i, int n, int r, bool &ok) __attribute__((always_inline)) -> E * {
+    const int64_t row = m0 + wm0 + MB * i + M_::acc_row(r, lane);
+    const int64_t col = n0 + wn0 + MB * n + M_::acc_col(lane);
     ok = (row < g.M) && (col < g.N);
     return Cb + row * g.rsC + col * g.csC;
   };
   // beta*C0 exactly as the reference's epilogues do it: beta == 0 -> 0 without reading C,
   // beta == 1 -> C, else C*beta (one rounding)  [gemm_ukernel_generic.nim:59-66, 107-115]
-  auto scaled_c0 = [&](int i, int n, int r) __attribute__((always_inline)) -> float {
-    if (beta == 0.0f) return 0.0f;
+  auto scaled_c0 = [&](int i, int n, int r) __attribute__((always_inline)) -> E {
+    if (beta == (E)0) return (E)0;
     bool ok;
-    const float *p = c_ptr(i, n, r, ok);
-    const float c0 = ok ? *p : 0.0f;
-    return beta == 1.0f ? c0 : __fmul_rn(c0, beta);
+    const E *p = c_ptr(i, n, r, ok);
+    const E c0 = ok ? *p : (E)0;
+    return beta == (E)1 ? c0 : M_::mul(c0, beta);
   };
   // C += AB or C += alpha*AB, unfused  [gemm_ukernel_generic.nim:68-76]
-  auto axpy = [&](float run, float ab) __attribute__((always_inline)) -> float {
-    return __fadd_rn(run, alpha == 1.0f ? ab : __fmul_rn(alpha, ab));
+  auto axpy = [&](E run, E ab) __attribute__((always_inline)) -> E {
+    return M_::add(run, alpha == (E)1 ? ab : M_::mul(alpha, ab));
   };
 
-  f32x16 run[EXACT ? TM : 1][EXACT ? TN : 1];
+  Acc run[EXACT ? TM : 1][EXACT ? TN : 1];
   if constexpr (EXACT) {
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int n = 0; n < TN; n++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) run[i][n][r] = scaled_c0(i, n, r);
+        for (int r = 0; r < ACC; r++) run[i][n][r] = scaled_c0(i, n, r);
   }
 
   const int nkt = (int)((K + BK - 1) / BK);
   const int kc_tiles = EXACT ? (g.kc / BK) : 0;
 
-  // fragment of k-step j: lanes 0-31 feed k = 2j, lanes 32-63 feed k = 2j+1 -> ascending-k chain
+  // fragment of k-step j: lane feeds k = KS*j + lk(lane) (the MFMA consumes them in ascending order,
+  // continuing the ascending-k chain), x = block base + lx(lane)
   // fragment ring: 4 slots (NJ is a multiple of 4, so slot = j & 3 stays compile-time across tiles);
   // the 3-stage loop reads PFD steps ahead, the 2-stage loop one step ahead
-  float fa[4][TM], fb[4][TN];
+  E fa[4][TM], fb[4][TN];
   constexpr int PFD = 1;  // 2 was measured: no gain at 1 WG/CU and it costs the 128-VGPR occupancy step of the fast 256x128 kernel
-  static_assert(NJ % 4 == 0, "BK must be a multiple of 8");
-  auto ldfrag = [&](const float *sA, const float *sB, int j, int slot) __attribute__((always_inline)) {
-    const int k = 2 * j + hi;
-    const int s = swz<BK>(2 * j);
+  static_assert(NJ % 4 == 0, "BK must give a multiple of 4 MFMA k-steps");
+  auto ldfrag = [&](const E *sA, const E *sB, int j, int slot) __attribute__((always_inline)) {
+    const int k = KS * j + hi;
+    // all k of one step share a swizzle when the step fits one 16-byte piece (fp32); otherwise it is per lane
+    const int s = (KS <= M_::EPV) ? swz<E, BK>(KS * j) : swz<E, BK>(k);
 #pragma unroll
-    for (int i = 0; i < TM; i++) fa[slot][i] = sA[k * BM + wm0 + 32 * i + (lo ^ s)];
+    for (int i = 0; i < TM; i++) fa[slot][i] = sA[k * BM + wm0 + MB * i + (lo ^ s)];
 #pragma unroll
-    for (int n = 0; n < TN; n++) fb[slot][n] = sB[k * BN + wn0 + 32 * n + (lo ^ s)];
+    for (int n = 0; n < TN; n++) fb[slot][n] = sB[k * BN + wn0 + MB * n + (lo ^ s)];
   };
   auto mfma_step = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-      for (int n = 0; n < TN; n++)
-        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i], fb[slot][n], acc[i][n], 0, 0, 0);
+      for (int n = 0; n < TN; n++) acc[i][n] = M_::mma(fa[slot][i], fb[slot][n], acc[i][n]);
   };
   // Laser's pc loop: the micro-kernel accumulator restarts at +0 for every kc slice and the slice sum
   // is added into C (gemm.nim:150-158; ukernel zero-init gemm_ukernel_generator.nim:189)
@@ -315,9 +370,9 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 #pragma unroll
         for (int n = 0; n < TN; n++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
+          for (int r = 0; r < ACC; r++) {
             run[i][n][r] = axpy(run[i][n][r], acc[i][n][r]);
-            acc[i][n][r] = 0.0f;
+            acc[i][n][r] = (E)0;
           }
     }
   };
@@ -331,8 +386,8 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     __syncthreads();
     auto k_tile2 = [&](auto MORE_, int kt) __attribute__((always_inline)) {
       constexpr bool more = decltype(MORE_)::value;
-      const float *sA = smem + (kt & 1) * STAGE;
-      const float *sB = sA + BK * BM;
+      const E *sA = smem + (kt & 1) * STAGE;
+      const E *sB = sA + BK * BM;
       if (more) {  // issue the next tile's HBM loads before the MFMA block (latency hides under it)
         la.load(Ab, g.rsA, g.csA, (int64_t)(kt + 1) * BK, mlim, K, t);
         lb.load(Bb, g.csB, g.rsB, (int64_t)(kt + 1) * BK, nlim, K, t, &g);
@@ -349,7 +404,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       }
     };
     auto refill = [&](int kt) __attribute__((always_inline)) {
-      float *dA = smem + ((kt + 1) & 1) * STAGE;
+      E *dA = smem + ((kt + 1) & 1) * STAGE;
       la.store(dA, t);
       lb.store(dA + BK * BM, t);
       __syncthreads();
@@ -395,13 +450,13 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     // conservative vmcnt(0), i.e. a full HBM round trip per op.
     auto k_tile = [&](auto MORE_, auto MORE2_, int kt) __attribute__((always_inline)) {
       constexpr bool more = decltype(MORE_)::value, more2 = decltype(MORE2_)::value;
-      const float *sA = smem + st * STAGE;
-      const float *sB = sA + BK * BM;
+      const E *sA = smem + st * STAGE;
+      const E *sB = sA + BK * BM;
       const int st1 = (st == 2) ? 0 : st + 1;
-      const float *nA = smem + st1 * STAGE;
-      const float *nB = nA + BK * BM;
-      float *wA = smem + st1 * STAGE;
-      float *wB = wA + BK * BM;
+      const E *nA = smem + st1 * STAGE;
+      const E *nB = nA + BK * BM;
+      E *wA = smem + st1 * STAGE;
+      E *wB = wA + BK * BM;
       const int64_t k2 = (int64_t)(kt + 2) * BK;
       // staging op `o` of this iteration: A pieces first, then B pieces; per piece its LDS writes
       // (tile kt+1, from registers) followed by the HBM load that refills the registers (tile kt+2)
@@ -444,7 +499,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int n = 0; n < TN; n++) {
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 3][i], fb[j & 3][n], acc[i][n], 0, 0, 0);
+            acc[i][n] = M_::mma(fa[j & 3][i], fb[j & 3][n], acc[i][n]);
             if (more && j < NJ / 2) {
               const int slot = j * NMF + i * TN + n;
 #pragma unroll
@@ -488,25 +543,25 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 #pragma unroll
     for (int n = 0; n < TN; n++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
+      for (int r = 0; r < ACC; r++) {
         bool ok;
-        float *p = c_ptr(i, n, r, ok);
-        float base;
+        E *p = c_ptr(i, n, r, ok);
+        E base;
         if constexpr (EXACT)
           base = run[i][n][r];
         else
           base = scaled_c0(i, n, r);
-        const float out = axpy(base, acc[i][n][r]);
+        const E out = axpy(base, acc[i][n][r]);
         if (ok) *p = out;
       }
 }
 
 // ---- per-configuration launcher ---------------------------------------------------------------------
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
+template <typename E, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
           bool DBG = false>
-hipError_t launch_one(const GemmArgs<float> &a, hipStream_t s) {
-  auto kern = gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, AMODE, BMODE, EXACT, STAGES, OCC, DBG>;
-  constexpr size_t lds = (size_t)STAGES * BK * (BM + BN) * sizeof(float);
+hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
+  auto kern = gemm_mfma_kernel<E, BM, BN, BK, WM, WN, AMODE, BMODE, EXACT, STAGES, OCC, DBG>;
+  constexpr size_t lds = (size_t)STAGES * BK * (BM + BN) * sizeof(E);
   static_assert(lds <= 160 * 1024, "LDS budget is 160 KiB per CU");
   static bool attr_done = false;
   if (!attr_done) {
@@ -515,7 +570,7 @@ hipError_t launch_one(const GemmArgs<float> &a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  GemmArgs<float> g = a;
+  GemmArgs<E> g = a;
   g.tiles_m = (int)((a.M + BM - 1) / BM);
   g.tiles_n = (int)((a.N + BN - 1) / BN);
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)a.batch, 1), block(WM * WN * 64, 1, 1);
@@ -524,10 +579,10 @@ hipError_t launch_one(const GemmArgs<float> &a, hipStream_t s) {
 }
 
 // dispatch over the loader modes for one tile configuration
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int OCC, bool WITH_VEC, bool WITH_GEN, bool EXACT>
-hipError_t launch_cfg_mode(const GemmArgs<float> &a, int amode, int bmode, hipStream_t s) {
+template <typename E, int BM, int BN, int BK, int WM, int WN, int STAGES, int OCC, bool WITH_VEC, bool WITH_GEN, bool EXACT>
+hipError_t launch_cfg_mode(const GemmArgs<E> &a, int amode, int bmode, hipStream_t s) {
 #define LH_CASE(AM, BMD) \
-  if (amode == AM && bmode == BMD) return launch_one<BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC>(a, s);
+  if (amode == AM && bmode == BMD) return launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC>(a, s);
   if constexpr (WITH_VEC) {
     LH_CASE(LOAD_VEC_K, LOAD_VEC_X)
     LH_CASE(LOAD_VEC_K, LOAD_VEC_K)
@@ -537,15 +592,19 @@ hipError_t launch_cfg_mode(const GemmArgs<float> &a, int amode, int bmode, hipSt
     LH_CASE(LOAD_VEC_K_EDGE, LOAD_VEC_K_EDGE)
     LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_X_EDGE)
     LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_K_EDGE)
-    LH_CASE(LOAD_VEC_K, LOAD_IM2COL)       // implicit-GEMM conv: filter [C_out][C_in*kH*kW] is k-contiguous
-    LH_CASE(LOAD_VEC_K_EDGE, LOAD_IM2COL)
+    if constexpr (std::is_same<E, float>::value) {
+      LH_CASE(LOAD_VEC_K, LOAD_IM2COL)  // implicit-GEMM conv: filter [C_out][C_in*kH*kW] is k-contiguous
+      LH_CASE(LOAD_VEC_K_EDGE, LOAD_IM2COL)
+    }
   }
   if constexpr (WITH_GEN) {
     LH_CASE(LOAD_GEN_K, LOAD_GEN_X)
     LH_CASE(LOAD_GEN_K, LOAD_GEN_K)
     LH_CASE(LOAD_GEN_X, LOAD_GEN_X)
     LH_CASE(LOAD_GEN_X, LOAD_GEN_K)
-    LH_CASE(LOAD_GEN_K, LOAD_IM2COL)
+    if constexpr (std::is_same<E, float>::value) {
+      LH_CASE(LOAD_GEN_K, LOAD_IM2COL)
+    }
   }
 #undef LH_CASE
   return hipErrorInvalidValue;

@@ -75,6 +75,11 @@ def set_f32_config(cfg):
     _lib.check(_lib.lib().laser_hip_set_f32_config(int(cfg)))
 
 
+def set_f64_mfma(on):
+    """True (default): float64 GEMM on the f64 matrix cores; False: VALU kernel."""
+    _lib.check(_lib.lib().laser_hip_set_f64_mfma(1 if on else 0))
+
+
 def set_i32_mfma(on):
     """True (default): int32 GEMM on the int8 matrix cores (limb decomposition); False: VALU kernel."""
     _lib.check(_lib.lib().laser_hip_set_i32_mfma(1 if on else 0))

@@ -121,16 +121,28 @@ def main():
             emit(config=f"gemm int32 {n}^3 " + ("(int8-limb MFMA)" if on else "(VALU kernel)"), ms_med=round(med, 4),
                  tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
         laser_amd.set_i32_mfma(True)
-    for dt, n in [(torch.int64, 960), (torch.float64, 960), (torch.float64, 4096)]:
-        if dt.is_floating_point:
-            A = (torch.rand((n, n), device="cuda", dtype=dt) - 0.5) * 0.2
-            B = (torch.rand((n, n), device="cuda", dtype=dt) - 0.5) * 0.2
-        else:
-            A = torch.randint(0, 101, (n, n), device="cuda", dtype=dt)
-            B = torch.randint(0, 101, (n, n), device="cuda", dtype=dt)
-        C = torch.zeros((n, n), device="cuda", dtype=dt)
-        med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C))
-        emit(config=f"gemm {str(dt).replace('torch.', '')} {n}^3", ms_med=round(med, 4), tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
+    for n in (960, 4096, 8192):
+        A = (torch.rand((n, n), device="cuda", dtype=torch.float64) - 0.5) * 0.2
+        B = (torch.rand((n, n), device="cuda", dtype=torch.float64) - 0.5) * 0.2
+        C = torch.zeros((n, n), device="cuda", dtype=torch.float64)
+        for on in (True, False):
+            if not on and n > 4096:
+                continue
+            laser_amd.set_f64_mfma(on)
+            for mode in (0, 1):
+                laser_amd.set_float_mode(mode)
+                med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C))
+                emit(config=f"gemm float64 {n}^3 " + ("(f64 MFMA)" if on else "(VALU kernel)"), mode="laser_order" if mode == 0 else "fast",
+                     ms_med=round(med, 4), tflops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3),
+                     frac_f64_peak=round(2.0 * n ** 3 / (med * 1e-3) / 1e12 / 78.6, 4))
+        laser_amd.set_float_mode(0)
+        laser_amd.set_f64_mfma(True)
+    n = 960
+    A = torch.randint(0, 101, (n, n), device="cuda", dtype=torch.int64)
+    B = torch.randint(0, 101, (n, n), device="cuda", dtype=torch.int64)
+    C = torch.zeros((n, n), device="cuda", dtype=torch.int64)
+    med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C))
+    emit(config=f"gemm int64 {n}^3 (VALU kernel)", ms_med=round(med, 4), tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/configs.jsonl", "w") as f:
         for r in OUT:

@@ -176,6 +176,30 @@ def test_f32_fast_mode_within_tolerance(la, oracle):
         la.set_f32_config(-1)
 
 
+def test_float64_mfma_path_bit_exact(la, oracle):
+    """float64 on v_mfma_f64_16x16x4_f64 == VALU kernel == oracle (fma chain restarted every kc=256),
+    every loader flavour: full tiles, 2-aligned ragged (EDGE), odd sizes / generic strides (scalar)."""
+    import torch
+    rng = np.random.default_rng(23)
+    for (M, N, K) in [(128, 128, 256), (256, 384, 1024), (130, 258, 1030), (129, 131, 515), (64, 64, 16), (1, 7, 3), (512, 128, 2050)]:
+        A = rng.uniform(-0.1, 0.1, (M, K))
+        B = rng.uniform(-0.1, 0.1, (K, N))
+        C0 = rng.uniform(-0.1, 0.1, (M, N))
+        for alpha, beta in [(1, 0), (0.5, 0.25)]:
+            want = oracle.matmul(A, B, alpha, beta, C0.copy())
+            assert np.array_equal(la.matmul(A, B, alpha, beta, C0.copy()), want), (M, N, K, alpha, beta)
+        want = oracle.matmul(A, B)
+        dAcm = torch.from_numpy(np.asfortranarray(A)).cuda()
+        dBt = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t()
+        for dA, dB in [(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()), (dAcm, dBt), (torch.from_numpy(A).cuda(), dBt)]:
+            assert np.array_equal(la.matmul(dA, dB).cpu().numpy(), want), (M, N, K)
+        try:
+            la.set_f64_mfma(False)
+            assert np.array_equal(la.matmul(A, B), want)
+        finally:
+            la.set_f64_mfma(True)
+
+
 def test_int32_mfma_limb_path_bit_exact(la, oracle):
     """int32 on the int8 matrix cores (signed 8-bit limb decomposition) == VALU kernel == oracle,
     full-range operands (wrap-around), every stride flavour, alpha/beta, K past the fold interval."""
