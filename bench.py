@@ -190,10 +190,15 @@ def main():
         step()
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if world == 1 else []
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if marks:
+            marks[i].record()     # per-step marks for mean/min/max/stddev like the reference's printStats
         step()
+    if marks:
+        marks[-1].record()
     ev1.record()
     fence()
     wall = time.perf_counter() - t0
@@ -221,7 +226,7 @@ def main():
         ms_per_step = wall / args.steps * 1e3
         value = flops_step / (wall / args.steps) / 1e9
         out = {
-            "metric": "sgemm GFLOP/s (M=N=K=8192 per GPU, fp32, device-resident)",
+            "metric": "sgemm GFLOP/s and %MFMA-peak, M=N=K=8192, 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -241,6 +246,11 @@ def main():
             # events on that same stream: average launch duration = ev_ms / steps
             k_ms = ev_ms / args.steps
             ach = 2.0 * n * n * n / (k_ms * 1e-3) / 1e12
+            per = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+            mean = sum(per) / len(per)
+            out["config"]["step_ms_stats"] = {   # benchmarks/gemm/gemm_bench_float32.nim:20-27 (printStats)
+                "mean": round(mean, 4), "min": round(min(per), 4), "max": round(max(per), 4),
+                "stddev": round((sum((x - mean) ** 2 for x in per) / max(1, len(per) - 1)) ** 0.5, 4)}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                                "kernel": "gemm_mfma_kernel<float,...>", "kernel_ms": round(k_ms, 4),

@@ -396,6 +396,40 @@ def test_cblas_shaped_gemm(la, oracle):
     assert np.array_equal(Cc.T, want)
 
 
+def test_race_screen_repeatability(la):
+    """The ring pipelines (LDS stages, LDS-DMA, mid-tile barrier) must give the same bits on every
+    launch: 12 back-to-back launches per kernel family on a 2048^2 x 4096 problem, compared bitwise to
+    the first; every f32 tile configuration in both accumulation modes, f64, int32."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M = N = 2048
+    K = 4096
+    A = (torch.rand((M, K), generator=g, device="cuda") - 0.5) * 0.2
+    B = (torch.rand((K, N), generator=g, device="cuda") - 0.5) * 0.2
+
+    def screen(a, b, tag):
+        first = la.matmul(a, b).clone()
+        out = torch.empty_like(first)
+        for it in range(12):
+            la.matmul(a, b, 1, 0, out)
+            assert torch.equal(out, first), (tag, it)
+
+    try:
+        for cfg, name in enumerate(la.f32_configs()):
+            for mode in (0, 1):
+                la.set_f32_config(cfg)
+                la.set_float_mode(mode)
+                screen(A, B, (name, mode))
+                screen(A, B.t().contiguous().t(), (name, mode, "nt"))
+    finally:
+        la.set_f32_config(-1)
+        la.set_float_mode(0)
+    screen(A.double(), B.double(), "f64")
+    Ai = torch.randint(-2**31, 2**31 - 1, (M, K), device="cuda", dtype=torch.int32)
+    Bi = torch.randint(-2**31, 2**31 - 1, (K, N), device="cuda", dtype=torch.int32)
+    screen(Ai, Bi, "i32")
+
+
 # ---- BASELINE.json full sizes: properties that do not need the oracle to redo the whole job ----------
 def test_full_size_8192_rows_bit_exact_and_checksum(la, oracle):
     """configs[1]: fp32 sgemm M=N=K=8192 on the device-resident path.
