@@ -93,6 +93,13 @@ __device__ __forceinline__ int swz(int k) {
 }
 
 // ---- operand tile loader: HBM -> registers -> LDS panel (the "packing" stage) -------------------
+// Every HBM load is UNCONDITIONAL and comes from a clamped, always-valid address; what must read as
+// zero (k beyond K -- Laser zero-pads its panels the same way, gemm_packing.nim:46-55,85-94 -- and
+// the convolution's padding) is recorded in a per-piece validity mask and zeroed when the piece is
+// written to LDS one K-tile later.  A select (or a predicated load) at LOAD time would make the wave
+// wait for the HBM round trip in the middle of the MFMA stream (measured: 70 vs 120 TFLOP/s on the
+// ragged conv-shaped GEMM).  Rows/cols beyond M/N need no zeroing: they only feed outputs that are
+// never stored.
 template <typename E, int BX, int BK, int NT, int MODE>
 struct TileLoader {
   using M_ = Mma<E>;
@@ -104,9 +111,11 @@ struct TileLoader {
   static constexpr bool EDGE = (MODE == LOAD_VEC_X_EDGE || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || EDGE);
   static constexpr bool CONV = (MODE == LOAD_IM2COL);
+  static constexpr bool MASKED = !(MODE == LOAD_VEC_X || MODE == LOAD_VEC_K);
   static_assert(!CONV || std::is_same<E, float>::value, "the implicit-GEMM loader is fp32 only");
   static_assert(ALONG_K || SwzShift<E, BK>::value >= (EPV == 4 ? 2 : 1), "16-byte pieces along x must stay contiguous");
   Vec v[NV];
+  uint32_t msk[MASKED ? NV : 1];  // bit c: element c of piece i is real data (else it reads as zero)
   // LOAD_IM2COL: per piece and element, (oh*sH - pH) in the high and (ow*sW - pW) in the low 16 bits
   // of the output pixel this lane gathers for (fixed for the whole K loop); 0x7fff7fff = beyond N.
   int32_t pix[CONV ? NV : 1][CONV ? 4 : 1];
@@ -133,7 +142,7 @@ struct TileLoader {
   }
 
   // base: element (x=0,k=0) of this workgroup's operand panel; sx/sk element strides along x / k;
-  // xlim/klim: number of valid x / k from `base` on (only used by the GEN modes).
+  // xlim/klim: number of valid x / k from `base` on (unused by the plain VEC modes).
   __device__ __forceinline__ void load(const E *__restrict__ base, int64_t sx, int64_t sk,
                                        int64_t k0, int64_t xlim, int64_t klim, int t,
                                        const GemmArgs<E> *cg = nullptr) {
@@ -156,15 +165,27 @@ struct TileLoader {
   static constexpr int OPS_PER_PIECE = WOPS + 1;
   static constexpr int NOPS = NV * OPS_PER_PIECE;
 
+  __device__ __forceinline__ E masked(int i, int c) const {
+    if constexpr (MASKED)
+      return ((msk[i] >> c) & 1u) ? v[i][c] : (E)0;
+    else
+      return v[i][c];
+  }
+
   __device__ __forceinline__ void store_op(E *__restrict__ lds, int t, int i, int c) const {
     const int idx = t + i * NT;
     if constexpr (!ALONG_K) {
       const int xq = idx % (BX / EPV), k = idx / (BX / EPV);
-      *reinterpret_cast<Vec *>(lds + k * BX + ((EPV * xq) ^ swz<E, BK>(k))) = v[i];
+      Vec q = v[i];
+      if constexpr (MASKED) {
+#pragma unroll
+        for (int e = 0; e < EPV; e++) q[e] = masked(i, e);
+      }
+      *reinterpret_cast<Vec *>(lds + k * BX + ((EPV * xq) ^ swz<E, BK>(k))) = q;
     } else {
       const int kq = idx % (BK / EPV), x = idx / (BK / EPV);
       const int xs = x ^ swz<E, BK>(EPV * kq);
-      lds[(EPV * kq + c) * BX + xs] = v[i][c];
+      lds[(EPV * kq + c) * BX + xs] = masked(i, c);
     }
   }
 
@@ -172,58 +193,72 @@ struct TileLoader {
                                           int64_t xlim, int64_t klim, int t, int i,
                                           const GemmArgs<E> *cg = nullptr) {
     const int idx = t + i * NT;
+    constexpr uint32_t ALL = (1u << EPV) - 1u;
     if constexpr (CONV) {
       // k -> (channel, kernel row, kernel col); the pixel part was decoded once in init_conv
       const int k = idx / (BX / 4);
       const int kk = (int)k0 + k;
-      const int khw = cg->ckH * cg->ckW;
-      const int c = kk / khw, rem = kk - c * khw;
-      const int kr = rem / cg->ckW, kc = rem - kr * cg->ckW;
       const bool kin = kk < (int)klim;
+      const int kc_ = kin ? kk : (int)klim - 1;  // clamped: the address stays inside the image
+      const int khw = cg->ckH * cg->ckW;
+      const int c = kc_ / khw, rem = kc_ - c * khw;
+      const int kr = rem / cg->ckW, kcol = rem - kr * cg->ckW;
       const E *img = base + (int64_t)c * cg->cH * cg->cW;
+      uint32_t m = 0;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const int row = (int)(int16_t)(pix[i][e] >> 16) + kr, col = (int)(int16_t)(pix[i][e] & 0xffff) + kc;
+        const int row = (int)(int16_t)(pix[i][e] >> 16) + kr, col = (int)(int16_t)(pix[i][e] & 0xffff) + kcol;
         const bool ok = kin && (unsigned)row < (unsigned)cg->cH && (unsigned)col < (unsigned)cg->cW;
-        v[i][e] = ok ? img[row * cg->cW + col] : (E)0;
+        const int rc = min(max(row, 0), cg->cH - 1), cc = min(max(col, 0), cg->cW - 1);
+        v[i][e] = img[rc * cg->cW + cc];
+        m |= (ok ? 1u : 0u) << e;
       }
+      msk[i] = m;
     } else if constexpr (!ALONG_K) {
       const int xq = idx % (BX / EPV), k = idx / (BX / EPV);
       if constexpr (VEC && !EDGE) {
         v[i] = *reinterpret_cast<const Vec *>(base + (k0 + k) * sk + EPV * xq);
-      } else if constexpr (EDGE) {
-        // xlim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in x
-        const int64_t kk = k0 + k;
-        const bool kin = kk < klim;
-        const int64_t xc = (EPV * xq < xlim) ? EPV * xq : xlim - EPV;
-        const Vec q = *reinterpret_cast<const Vec *>(base + (kin ? kk : 0) * sk + xc);
-        const Vec z = {};
-        v[i] = kin ? q : z;
       } else {
         const int64_t kk = k0 + k;
-        const E *p = base + kk * sk + (int64_t)(EPV * xq) * sx;
         const bool kin = kk < klim;
+        const int64_t kc_ = kin ? kk : klim - 1;
+        if constexpr (EDGE) {
+          // xlim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in x
+          const int64_t xc = (EPV * xq < xlim) ? EPV * xq : xlim - EPV;
+          v[i] = *reinterpret_cast<const Vec *>(base + kc_ * sk + xc);
+        } else {
+          const E *p = base + kc_ * sk;
 #pragma unroll
-        for (int c = 0; c < EPV; c++) v[i][c] = (kin && (EPV * xq + c) < xlim) ? p[c * sx] : (E)0;
+          for (int c = 0; c < EPV; c++) {
+            const int64_t x = EPV * xq + c;
+            v[i][c] = p[(x < xlim ? x : xlim - 1) * sx];
+          }
+        }
+        msk[i] = kin ? ALL : 0u;
       }
     } else {
       const int kq = idx % (BK / EPV), x = idx / (BK / EPV);
       if constexpr (VEC && !EDGE) {
         v[i] = *reinterpret_cast<const Vec *>(base + (int64_t)x * sx + k0 + EPV * kq);
-      } else if constexpr (EDGE) {
-        // klim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in k
-        const int64_t kk = k0 + EPV * kq;
-        const bool kin = kk < klim;
-        const int64_t xc = (x < xlim) ? x : xlim - 1;
-        const Vec q = *reinterpret_cast<const Vec *>(base + xc * sx + (kin ? kk : 0));
-        const Vec z = {};
-        v[i] = kin ? q : z;
       } else {
         const int64_t kk = k0 + EPV * kq;
-        const E *p = base + (int64_t)x * sx + kk * sk;
-        const bool xin = x < xlim;
+        const int64_t xc = (x < xlim) ? x : xlim - 1;
+        if constexpr (EDGE) {
+          // klim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in k
+          const bool kin = kk < klim;
+          v[i] = *reinterpret_cast<const Vec *>(base + xc * sx + (kin ? kk : klim - EPV));
+          msk[i] = kin ? ALL : 0u;
+        } else {
+          const E *p = base + xc * sx;
+          uint32_t m = 0;
 #pragma unroll
-        for (int c = 0; c < EPV; c++) v[i][c] = (xin && (kk + c) < klim) ? p[c * sk] : (E)0;
+          for (int c = 0; c < EPV; c++) {
+            const int64_t kc_ = kk + c;
+            v[i][c] = p[(kc_ < klim ? kc_ : klim - 1) * sk];
+            m |= (kc_ < klim ? 1u : 0u) << c;
+          }
+          msk[i] = m;
+        }
       }
     }
   }
