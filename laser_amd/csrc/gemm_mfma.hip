@@ -67,22 +67,40 @@ static int64_t tiles_of(const GemmArgs<E> &a, int bm, int bn) {
   return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (int64_t)a.batch;
 }
 
-// fp32: largest tile that still gives every CU work (>= ~0.8 x 256 workgroups), else the next size down.
+// fp32: pick the configuration with the smallest predicted time.  Every CU works through
+// ceil(tiles / 256) tiles of bm x bn (how many of them are co-resident only changes the efficiency),
+// so  time ~ ceil(tiles / 256) * bm * bn / speed(cfg),  speed = TFLOP/s measured at 8192^3
+// (profiles/r01/sweep_f32_v6.json).  This is what makes 4100^3 take 128x128 tiles (5 rounds of 16384)
+// instead of 256x256 (2 rounds of 65536, the second 13 % full).
 constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3, kCfgWideExact = 4;
-static int heuristic_cfg(const GemmArgs<float> &a, bool exact) {
-  if (!exact && tiles_of(a, 256, 256) >= 200) return kCfgBig;
-  if (tiles_of(a, 256, 128) >= 200) return exact ? kCfgWideExact : kCfgWide;
-  if (tiles_of(a, 128, 128) >= 200) return kCfgMid;
-  if (tiles_of(a, 128, 128) >= 2 * tiles_of(a, 64, 64) / 5 && tiles_of(a, 128, 128) >= 96) return kCfgMid;
-  return kCfgSmall;
+static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = false) {
+  struct Cand { int cfg, bm, bn; double fast, laser; bool gen; };
+  static const Cand cands[] = {
+      {kCfgBig, 256, 256, 139.0, 0.0, false},   {kCfgWide, 256, 128, 135.0, 126.0, false},
+      {kCfgWideExact, 256, 128, 130.0, 130.0, false}, {kCfgMid, 128, 128, 133.0, 127.5, true},
+      {kCfgSmall, 64, 64, 120.0, 118.0, true},
+  };
+  int best = kCfgSmall;
+  double best_t = 1e300;
+  for (const Cand &c : cands) {
+    const double speed = exact ? c.laser : c.fast;
+    if (speed <= 0.0 || (need_gen && !c.gen)) continue;
+    const double rounds = (double)((tiles_of(a, c.bm, c.bn) + 255) / 256);
+    const double t = rounds * c.bm * c.bn / speed;
+    if (t < best_t * 0.999) {  // ties go to the earlier (larger-tile) candidate: less L2 traffic
+      best_t = t;
+      best = c.cfg;
+    }
+  }
+  return best;
 }
 static int fallback_exact_cfg(const GemmArgs<float> &) { return kCfgWideExact; }
-static int gen_cfg(const GemmArgs<float> &) { return kCfgSmall; }
+static int gen_cfg(const GemmArgs<float> &a, bool exact) { return heuristic_cfg(a, exact, true); }
 
 // fp64: two configurations.
-static int heuristic_cfg(const GemmArgs<double> &a, bool) { return tiles_of(a, 128, 128) >= 128 ? 0 : 1; }
+static int heuristic_cfg(const GemmArgs<double> &a, bool, bool = false) { return tiles_of(a, 128, 128) >= 128 ? 0 : 1; }
 static int fallback_exact_cfg(const GemmArgs<double> &) { return 0; }
-static int gen_cfg(const GemmArgs<double> &) { return 1; }
+static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 
 template <typename E>
 static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, int ncfg, int cfg, bool laser_order,
@@ -107,7 +125,7 @@ static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, i
     if (c.vec && va && vb) return c.fn(a, am, bm, exact, s);
     if (c.vec && (va || ea) && (vb || eb)) return c.fn(a, to_edge(am), to_edge(bm), exact, s);
     if (c.gen) return c.fn(a, to_gen(am), to_gen(bm), exact, s);
-    cfg = gen_cfg(a);  // the configuration that carries the scalar (any-stride) loaders
+    cfg = gen_cfg(a, exact);  // a configuration that carries the scalar (any-stride) loaders
   }
   return hipErrorInvalidValue;
 }
@@ -138,7 +156,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, LOAD_IM2COL, exact, s);
     if (a.csA == 1 && ea) return c.fn(a, LOAD_VEC_K_EDGE, LOAD_IM2COL, exact, s);
     if (c.gen) return c.fn(a, LOAD_GEN_K, LOAD_IM2COL, exact, s);
-    cfg = kCfgSmall;
+    cfg = gen_cfg(a, exact);
   }
   return hipErrorInvalidValue;
 }

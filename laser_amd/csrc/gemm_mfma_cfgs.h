@@ -12,7 +12,7 @@
 #define LH_F32_CONFIGS(X)                                        \
   X(0, 256, 256, 16, 2, 4, 3, 2, 2, true, false, false)          \
   X(1, 256, 128, 16, 4, 2, 3, 2, 2, true, false, true)           \
-  X(2, 128, 128, 16, 2, 2, 3, 3, 2, true, false, true)           \
+  X(2, 128, 128, 16, 2, 2, 3, 3, 2, true, true, true)            \
   X(3, 64, 64, 32, 2, 2, 2, 3, 2, true, true, true)              \
   X(4, 256, 128, 32, 4, 2, 3, 2, 2, true, false, true)
 #define LH_F32_NUM_CONFIGS 5

@@ -78,6 +78,10 @@ def main():
     gemm_case("C3 fp32 4096^3 B transposed (rsB=1,csB=K), A contiguous", n, n, n, Abig[:n], Bt.t(), Cbuf[:, :n].contiguous())
     gemm_case("C3 fp32 4096^3 A every-2nd-row view, B transposed, C colStride 2", n, n, n, Abig[::2], Bt.t(), Cbuf[:, ::2])
     gemm_case("C3 fp32 4096^3 A column-major, B row-major", n, n, n, Bt.t(), Abig[:n], Cbuf[:, :n].contiguous())
+    # ragged / odd shapes: EDGE vector loaders (4-aligned) and scalar loaders (nothing aligned)
+    for (M_, N_, K_) in [(4100, 4100, 4100), (4095, 4097, 4099), (1000, 3000, 2000)]:
+        Ar, Br, Cr = rnd((M_, K_), 11), rnd((K_, N_), 12), torch.zeros((M_, N_), device="cuda")
+        gemm_case(f"ragged fp32 {M_}x{N_}x{K_}", M_, N_, K_, Ar, Br, Cr)
     # C4: conv
     ishape, kshape, pad, st = (32, 128, 56, 56), (256, 128, 3, 3), (1, 1), (1, 1)
     x, w = rnd(ishape, 7, 0, 1), rnd(kshape, 8, 0, 1)
