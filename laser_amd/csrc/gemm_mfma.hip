@@ -70,15 +70,15 @@ static int64_t tiles_of(const GemmArgs<E> &a, int bm, int bn) {
 // fp32: pick the configuration with the smallest predicted time.  Every CU works through
 // ceil(tiles / 256) tiles of bm x bn (how many of them are co-resident only changes the efficiency),
 // so  time ~ ceil(tiles / 256) * bm * bn / speed(cfg),  speed = TFLOP/s measured at 8192^3
-// (profiles/r01/sweep_f32_v6.json).  This is what makes 4100^3 take 128x128 tiles (5 rounds of 16384)
+// (profiles/r01/sweep_f32_v8.json).  This is what makes 4100^3 take 128x128 tiles (5 rounds of 16384)
 // instead of 256x256 (2 rounds of 65536, the second 13 % full).
 constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3, kCfgWideExact = 4;
 static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = false) {
   struct Cand { int cfg, bm, bn; double fast, laser; bool gen; };
   static const Cand cands[] = {
-      {kCfgBig, 256, 256, 139.0, 0.0, false},   {kCfgWide, 256, 128, 135.0, 126.0, false},
-      {kCfgWideExact, 256, 128, 130.0, 130.0, false}, {kCfgMid, 128, 128, 133.0, 127.5, true},
-      {kCfgSmall, 64, 64, 120.0, 118.0, true},
+      {kCfgBig, 256, 256, 138.7, 0.0, false},   {kCfgWideExact, 256, 128, 133.1, 132.2, false},
+      {kCfgWide, 256, 128, 133.0, 130.5, false}, {kCfgMid, 128, 128, 134.1, 130.1, true},
+      {kCfgSmall, 64, 64, 120.8, 118.8, true},
   };
   int best = kCfgSmall;
   double best_t = 1e300;

@@ -57,8 +57,23 @@ struct Mma<float> {
   static __device__ __forceinline__ int lk(int lane) { return lane >> 5; }
   static __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
   static __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
-  static __device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
-  static __device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+  // (hipcc contracts a*b+c across __fmul_rn/__fadd_rn under its default -ffp-contract=fast; the pragma drops
+  // the `contract` flag from these instructions, which survives inlining)
+  static __device__ __forceinline__ float mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+  }
+  static __device__ __forceinline__ float add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+  }
+  // run + alpha*ab on a whole accumulator block, unfused (two roundings, like the scalar epilogue);
+  // vector-typed so that it lowers to v_pk_mul_f32 / v_pk_add_f32 (8 + 8 instructions per block)
+  static __device__ __forceinline__ Acc fold_acc(Acc run, Acc ab, float alpha) {
+#pragma clang fp contract(off)
+    const Acc t = ab * alpha;
+    return run + t;
+  }
 };
 template <>
 struct Mma<double> {
@@ -71,8 +86,19 @@ struct Mma<double> {
   static __device__ __forceinline__ int lk(int lane) { return lane >> 4; }
   static __device__ __forceinline__ int acc_row(int r, int lane) { return (lane >> 4) + 4 * r; }
   static __device__ __forceinline__ int acc_col(int lane) { return lane & 15; }
-  static __device__ __forceinline__ double mul(double a, double b) { return __dmul_rn(a, b); }
-  static __device__ __forceinline__ double add(double a, double b) { return __dadd_rn(a, b); }
+  static __device__ __forceinline__ double mul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+  }
+  static __device__ __forceinline__ double add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+  }
+  static __device__ __forceinline__ Acc fold_acc(Acc run, Acc ab, double alpha) {
+#pragma clang fp contract(off)
+    const Acc t = ab * alpha;
+    return run + t;
+  }
 };
 
 // LDS panel swizzle: element (k, x) lives at T[k][x ^ swz(k)], swz(k) = ((k / EPV) & 7) << SHIFT.
@@ -290,7 +316,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   constexpr int NJ = BK / KS;  // MFMA k-steps per K-tile
   static_assert(WTM % MB == 0 && WTN % MB == 0, "wave tile must be built from whole MFMA blocks");
   static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
-  static_assert(STAGES == 2 || NJ >= 4, "ring form prefetches past the mid-tile barrier: needs NJ/2 >= 2");
+  static_assert(STAGES == 2 || NJ >= 4, "ring form prefetches past the mid-tile barrier");
   constexpr int STAGE = BK * (BM + BN);  // elements per LDS stage: A panel then B panel
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -356,9 +382,8 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     return beta == (E)1 ? c0 : M_::mul(c0, beta);
   };
   // C += AB or C += alpha*AB, unfused  [gemm_ukernel_generic.nim:68-76]
-  auto axpy = [&](E run, E ab) __attribute__((always_inline)) -> E {
-    return M_::add(run, alpha == (E)1 ? ab : M_::mul(alpha, ab));
-  };
+  // (alpha == 1 needs no special case: 1*x is x bit for bit, so the multiply is always issued)
+  auto axpy = [&](E run, E ab) __attribute__((always_inline)) -> E { return M_::add(run, M_::mul(alpha, ab)); };
 
   Acc run[EXACT ? TM : 1][EXACT ? TN : 1];
   if constexpr (EXACT) {
@@ -375,25 +400,38 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 
   // fragment of k-step j: lane feeds k = KS*j + lk(lane) (the MFMA consumes them in ascending order,
   // continuing the ascending-k chain), x = block base + lx(lane)
-  // fragment ring: 4 slots (NJ is a multiple of 4, so slot = j & 3 stays compile-time across tiles);
-  // the 3-stage loop reads PFD steps ahead, the 2-stage loop one step ahead
-  E fa[4][TM], fb[4][TN];
-  constexpr int PFD = 1;  // 2 was measured: no gain at 1 WG/CU and it costs the 128-VGPR occupancy step of the fast 256x128 kernel
-  static_assert(NJ % 4 == 0, "BK must give a multiple of 4 MFMA k-steps");
-  auto ldfrag = [&](const E *sA, const E *sB, int j, int slot) __attribute__((always_inline)) {
-    const int k = KS * j + hi;
-    // all k of one step share a swizzle when the step fits one 16-byte piece (fp32); otherwise it is per lane
-    const int s = (KS <= M_::EPV) ? swz<E, BK>(KS * j) : swz<E, BK>(k);
+  // Fragments are read and consumed in GROUPS of KGRP consecutive k-steps so that every pinned group holds
+  // ~8 MFMAs whatever the wave tile: with 4 MFMAs per group (64x64 wave tile, KGRP = 1) the bare
+  // MFMA + fragment-read stream already ran 5 % slower than with 8 (ablation, scripts/ablate_f32.py).
+  // Ring of 2 group slots (group g+1 is read from LDS while group g's MFMAs issue); NG is even, so
+  // slot = g & 1 stays compile-time across tiles.
+  // (the 2-stage form has no cross-tile fragment prefetch: the first group's LDS latency is exposed once
+  // per tile, so larger groups only lengthen the exposed part -- measured 127 -> 111 TFLOP/s at KGRP = 4)
+  constexpr int KGRP_WANT = 8 / (TM * TN) < 1 ? 1 : 8 / (TM * TN);
+  constexpr int KGRP = STAGES == 2 ? 1 : (KGRP_WANT > NJ / 4 ? (NJ / 4 < 1 ? 1 : NJ / 4) : KGRP_WANT);
+  constexpr int NG = NJ / KGRP;  // groups per K-tile
+  static_assert(NJ % KGRP == 0 && NG % 2 == 0 && NG >= 2, "BK must give an even number of fragment groups");
+  E fa[2][KGRP][TM], fb[2][KGRP][TN];
+  auto ldgroup = [&](const E *sA, const E *sB, int grp, int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TM; i++) fa[slot][i] = sA[k * BM + wm0 + MB * i + (lo ^ s)];
+    for (int u = 0; u < KGRP; u++) {
+      const int j = grp * KGRP + u;
+      const int k = KS * j + hi;
+      // all k of one step share a swizzle when the step fits one 16-byte piece (fp32); otherwise it is per lane
+      const int s = (KS <= M_::EPV) ? swz<E, BK>(KS * j) : swz<E, BK>(k);
 #pragma unroll
-    for (int n = 0; n < TN; n++) fb[slot][n] = sB[k * BN + wn0 + MB * n + (lo ^ s)];
+      for (int i = 0; i < TM; i++) fa[slot][u][i] = sA[k * BM + wm0 + MB * i + (lo ^ s)];
+#pragma unroll
+      for (int n = 0; n < TN; n++) fb[slot][u][n] = sB[k * BN + wn0 + MB * n + (lo ^ s)];
+    }
   };
-  auto mfma_step = [&](int slot) __attribute__((always_inline)) {
+  auto mfma_group = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+    for (int u = 0; u < KGRP; u++)
 #pragma unroll
-      for (int n = 0; n < TN; n++) acc[i][n] = M_::mma(fa[slot][i], fb[slot][n], acc[i][n]);
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int n = 0; n < TN; n++) acc[i][n] = M_::mma(fa[slot][u][i], fb[slot][u][n], acc[i][n]);
   };
   // Laser's pc loop: the micro-kernel accumulator restarts at +0 for every kc slice and the slice sum
   // is added into C (gemm.nim:150-158; ukernel zero-init gemm_ukernel_generator.nim:189)
@@ -427,14 +465,14 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
         la.load(Ab, g.rsA, g.csA, (int64_t)(kt + 1) * BK, mlim, K, t);
         lb.load(Bb, g.csB, g.rsB, (int64_t)(kt + 1) * BK, nlim, K, t, &g);
       }
-      ldfrag(sA, sB, 0, 0);
+      ldgroup(sA, sB, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        if (j + 1 < NJ) ldfrag(sA, sB, j + 1, (j + 1) & 3);
-        // pin the order "LDS reads of step j+1, then MFMAs of step j": without it hipcc sinks each
+      for (int gi = 0; gi < NG; gi++) {
+        if (gi + 1 < NG) ldgroup(sA, sB, gi + 1, (gi + 1) & 1);
+        // pin the order "LDS reads of group g+1, then MFMAs of group g": without it hipcc sinks each
         // ds_read down to its first use and every MFMA group eats the full LDS latency
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step(j & 3);
+        mfma_group(gi & 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -476,15 +514,19 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       lb.load(Bb, g.csB, g.rsB, BK, nlim, K, t, &g);
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PFD; j++) ldfrag(smem, smem + BK * BM, j, j);
+    ldgroup(smem, smem + BK * BM, 0, 0);
     int st = 0;  // stage holding tile kt
     // One K-tile.  MORE / MORE2 (tile kt+1 / kt+2 exist) are compile-time so that the steady-state
     // body is ONE basic block: hipcc then derives exact counted `s_waitcnt vmcnt(N)` for the
     // interleaved loads; with run-time guards every staging op became its own block behind a
     // conservative vmcnt(0), i.e. a full HBM round trip per op.
-    auto k_tile = [&](auto MORE_, auto MORE2_, int kt) __attribute__((always_inline)) {
+    // FOLD_: this tile is the first of a Laser kc slice -- each accumulator block is folded into `run`
+    // right before its first MFMA of the tile, and that MFMA takes a literal-zero C operand.  The fold's
+    // VALU work (16 packed ops per block) then issues in the shadow of the previous block's MFMA instead
+    // of stalling the matrix pipe for the whole fold at a slice boundary.
+    auto k_tile = [&](auto MORE_, auto MORE2_, auto FOLD_, int kt) __attribute__((always_inline)) {
       constexpr bool more = decltype(MORE_)::value, more2 = decltype(MORE2_)::value;
+      constexpr bool fold_here = EXACT && decltype(FOLD_)::value;
       const E *sA = smem + st * STAGE;
       const E *sB = sA + BK * BM;
       const int st1 = (st == 2) ? 0 : st + 1;
@@ -520,28 +562,35 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       constexpr int SLOTS = (NJ / 2) * NMF;            // slots before the mid-tile barrier
       constexpr int PER = (NOPS + SLOTS - 1) / SLOTS;  // staging ops per slot (1 unless the tile is tiny)
 #pragma unroll
-      for (int j = 0; j < NJ; j++) {
+      for (int gi = 0; gi < NG; gi++) {
         // everyone's stores of tile kt+1 are done past this point
-        if (j == NJ / 2 && (!DBG || !(g.dbg & 4))) __syncthreads();
-        if (j + PFD < NJ)
-          ldfrag(sA, sB, j + PFD, (j + PFD) & 3);
+        if (gi == NG / 2 && (!DBG || !(g.dbg & 4))) __syncthreads();
+        if (gi + 1 < NG)
+          ldgroup(sA, sB, gi + 1, (gi + 1) & 1);
         else if (more)
-          ldfrag(nA, nB, j + PFD - NJ, (j + PFD) & 3);  // first fragments of the next tile (past the barrier)
-        // pin the order "LDS reads of step j+PFD, then MFMAs of step j": without it hipcc sinks each
+          ldgroup(nA, nB, 0, 0);  // first fragment group of the next tile (past the barrier)
+        // pin the order "LDS reads of group g+1, then MFMAs of group g": without it hipcc sinks each
         // ds_read down to its first use and every MFMA group eats the full LDS latency
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+        for (int u = 0; u < KGRP; u++)
 #pragma unroll
-          for (int n = 0; n < TN; n++) {
-            acc[i][n] = M_::mma(fa[j & 3][i], fb[j & 3][n], acc[i][n]);
-            if (more && j < NJ / 2) {
-              const int slot = j * NMF + i * TN + n;
+          for (int i = 0; i < TM; i++)
 #pragma unroll
-              for (int q = 0; q < PER; q++) staging_op(slot * PER + q);
+            for (int n = 0; n < TN; n++) {
+              if (fold_here && gi == 0 && u == 0) {
+                run[EXACT ? i : 0][EXACT ? n : 0] = M_::fold_acc(run[EXACT ? i : 0][EXACT ? n : 0], acc[i][n], alpha);
+                acc[i][n] = M_::mma(fa[0][0][i], fb[0][0][n], Acc{});
+              } else {
+                acc[i][n] = M_::mma(fa[gi & 1][u][i], fb[gi & 1][u][n], acc[i][n]);
+              }
+              if (more && gi < NG / 2) {
+                const int slot = (gi * KGRP + u) * NMF + i * TN + n;
+#pragma unroll
+                for (int q = 0; q < PER; q++) staging_op(slot * PER + q);
+              }
+              __builtin_amdgcn_sched_barrier(0);  // one staging op rides behind each MFMA
             }
-            __builtin_amdgcn_sched_barrier(0);  // one staging op rides behind each MFMA
-          }
       }
       st = st1;
     };
@@ -553,23 +602,29 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     int next_fold = (EXACT && kc_tiles > 0) ? kc_tiles : 0x7fffffff;  // fold once tiles [.., next_fold) are done
     for (;;) {
       const int stop = min(next_fold, nkt - 2);
-      for (; kt < stop; kt++) k_tile(T_{}, T_{}, kt);
-      if (kt == next_fold && kt < nkt) {
-        fold();
+      for (; kt < stop; kt++) k_tile(T_{}, T_{}, F_{}, kt);
+      if (kt == next_fold && kt < nkt - 2) {  // slice boundary in the steady state: the fold rides inside the tile
+        k_tile(T_{}, T_{}, T_{}, kt);
+        kt++;
         next_fold += kc_tiles;
         continue;
       }
       break;
     }
+    // the last two tiles (no more HBM loads / no more LDS writes); a slice boundary here folds in the open
+    if (kt == next_fold && kt < nkt) {
+      fold();
+      next_fold += kc_tiles;
+    }
     if (kt + 1 < nkt) {
-      k_tile(T_{}, F_{}, kt);
+      k_tile(T_{}, F_{}, F_{}, kt);
       kt++;
       if (kt == next_fold && kt < nkt) {
         fold();
         next_fold += kc_tiles;
       }
     }
-    if (kt < nkt) k_tile(F_{}, F_{}, kt);
+    if (kt < nkt) k_tile(F_{}, F_{}, F_{}, kt);
   }
 
   // -- epilogue: last (or only) slice, then store with the caller's strides --

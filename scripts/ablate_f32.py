@@ -10,7 +10,9 @@ g = torch.Generator(device="cuda").manual_seed(1)
 A = (torch.rand((n, n), generator=g, device="cuda") - 0.5) * 0.2
 B = (torch.rand((n, n), generator=g, device="cuda") - 0.5) * 0.2
 Cc = torch.zeros((n, n), device="cuda")
-names = {0: "full", 1: "no HBM loads", 2: "no LDS stores", 3: "no loads+stores", 4: "no barrier", 7: "MFMA + LDS reads only"}
+base = {0: "full(probe build)", 3: "no loads+stores", 4: "no barrier", 7: "MFMA + LDS reads only"}
+shapes = {0: "256x256x16 w128x64", 1: "256x128x32 w64x64", 2: "256x128x16 w64x64"}
+names = {(sh << 8) | d: f"{shapes[sh]:20s} {n}" for sh in shapes for d, n in base.items()}
 res = {k: [] for k in names}
 for r in range(4):
     for dbg in names:
@@ -23,4 +25,4 @@ for r in range(4):
         if r: res[dbg].append(e0.elapsed_time(e1) / 3)
 for dbg, v in res.items():
     v.sort(); ms = v[len(v)//2]
-    print(f"dbg={dbg} {names[dbg]:24s} {ms:.4f} ms  {2*n**3/ms/1e9:.1f} TFLOP/s")
+    print(f"{names[dbg]:46s} {ms:.4f} ms  {2*n**3/ms/1e9:.1f} TFLOP/s")
