@@ -509,6 +509,16 @@ int conv_check(int64_t iN, int64_t iC, int64_t iH, int64_t iW, int64_t c_out, in
   return LASER_HIP_OK;
 }
 
+// The implicit-GEMM loader keeps 8-bit row/column validity bitmaps and 32-bit in-image offsets:
+// kernels up to 8x8 and images below 2^30 elements; anything else goes through the explicit workspace.
+bool conv_takes_implicit(int64_t iC, int64_t iH, int64_t iW, int64_t kH, int64_t kW, int64_t pH, int64_t pW,
+                         int64_t sH, int64_t sW) {
+  int64_t oH, oW;
+  out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
+  const int64_t reach = (oH * sH + kH + pH) * iW + oW * sW + kW + pW;  // largest |window origin| offset
+  return g_ctx.conv_implicit && kH <= 8 && kW <= 8 && iC * iH * iW + reach < (1ll << 30) && iC * kH * kW < (1ll << 30);
+}
+
 int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, int64_t iW, const float *dker,
              int64_t c_out, int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
              hipStream_t s) {
@@ -518,8 +528,7 @@ int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, 
   // 1x1 shortcut (conv2d_im2col.nim:121,128,151-153): the input already is the [K, N] matrix --
   // taken only for stride 1 / no padding, where that is actually true.
   const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
-  const bool geom_fits = iH < 32000 && iW < 32000 && oH * sH + kH < 32000 && oW * sW + kW < 32000;
-  if (!direct && g_ctx.conv_implicit && geom_fits) {
+  if (!direct && conv_takes_implicit(iC, iH, iW, kH, kW, pH, pW, sH, sW)) {
     // implicit GEMM: im2col's index arithmetic runs inside the B-tile loader, nothing is materialised
     GemmArgs<float> a = make_args<float>(iN, M, N, K, 1.0f, dker, K, 1, 0, din, 0, 1, iC * iH * iW, 0.0f, dout, N, 1, M * N);
     a.cH = (int32_t)iH; a.cW = (int32_t)iW; a.ckH = (int32_t)kH; a.ckW = (int32_t)kW; a.coW = (int32_t)oW;
@@ -790,7 +799,7 @@ int laser_hip_conv2d_im2col_f32_dev(float *dout, const float *din, int64_t iN, i
   if (iN == 0) return LASER_HIP_OK;
   if (!dout || !din || !dker) return fail(LASER_HIP_E_INVALID, "null pointer");
   if (iN > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
-  if (!dws && !g_ctx.conv_implicit) {
+  if (!dws && !conv_takes_implicit(iC, iH, iW, kH, kW, pH, pW, sH, sW)) {
     int64_t oH, oW;
     out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -816,7 +825,7 @@ int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t
   const size_t ob = (size_t)iN * c_out * oH * oW * 4, w1 = (size_t)iC * kH * kW * oH * oW * 4;
   void *di, *dk, *dout, *dws;
   const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
-  const bool implicit = g_ctx.conv_implicit;
+  const bool implicit = conv_takes_implicit(iC, iH, iW, kH, kW, pH, pW, sH, sW);
   if (int rc = scratch_get(0, ib, &di)) return rc;
   if (int rc = scratch_get(1, kb, &dk)) return rc;
   if (int rc = scratch_get(2, ob, &dout)) return rc;

@@ -29,6 +29,7 @@ struct GemmArgs {
   // image b's [C*kH*kW, oH*oW] matrix is gathered from the NCHW input at B + b*bsB with the index
   // arithmetic of im2col (benchmarks/convolution/conv2d_im2col.nim:62-87).
   int32_t cH, cW, ckH, ckW, coW, cpH, cpW, csH, csW;
+  int32_t cdc, cdr, cdq;  // per-K-tile advance of the implicit-GEMM loader's (channel, kernel row, kernel col): BK = cdc*kH*kW + cdr*kW + cdq
 };
 
 // How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of

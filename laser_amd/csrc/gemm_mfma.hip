@@ -73,17 +73,21 @@ static int64_t tiles_of(const GemmArgs<E> &a, int bm, int bn) {
 // (profiles/r01/sweep_f32_v8.json).  This is what makes 4100^3 take 128x128 tiles (5 rounds of 16384)
 // instead of 256x256 (2 rounds of 65536, the second 13 % full).
 constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3, kCfgWideExact = 4;
-static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = false) {
-  struct Cand { int cfg, bm, bn; double fast, laser; bool gen; };
+static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = false, bool conv = false) {
+  struct Cand { int cfg, bm, bn; double fast, laser, conv_fast, conv_laser; bool gen; };
+  // conv_*: in-round rates with the gathering B loader (C4, scripts/conv_cfg_probe.py): the gather costs the
+  // small tiles more (fewer MFMAs per gathered element)
   static const Cand cands[] = {
-      {kCfgBig, 256, 256, 138.7, 0.0, false},   {kCfgWideExact, 256, 128, 133.1, 132.2, false},
-      {kCfgWide, 256, 128, 133.0, 130.5, false}, {kCfgMid, 128, 128, 134.1, 130.1, true},
-      {kCfgSmall, 64, 64, 120.8, 118.8, true},
+      {kCfgBig, 256, 256, 138.7, 0.0, 124.7, 0.0, false},
+      {kCfgWideExact, 256, 128, 133.1, 132.2, 117.0, 0.0, false},  // (laser-order gather would spill: cfg 1 instead)
+      {kCfgWide, 256, 128, 133.0, 130.5, 116.0, 117.0, false},
+      {kCfgMid, 128, 128, 134.1, 130.1, 116.0, 111.0, true},
+      {kCfgSmall, 64, 64, 120.8, 118.8, 95.0, 90.0, true},
   };
   int best = kCfgSmall;
   double best_t = 1e300;
   for (const Cand &c : cands) {
-    const double speed = exact ? c.laser : c.fast;
+    const double speed = conv ? (exact ? c.conv_laser : c.conv_fast) : (exact ? c.laser : c.fast);
     if (speed <= 0.0 || (need_gen && !c.gen)) continue;
     const double rounds = (double)((tiles_of(a, c.bm, c.bn) + 255) / 256);
     const double t = rounds * c.bm * c.bn / speed;
@@ -147,8 +151,10 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   a.dbg = 0;
   const bool exact = laser_order && a.K > 512;
   a.kc = exact ? 512 : 0;
-  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact);
+  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact, false, true);
   if (exact && !kCfgsF32[cfg].exact) cfg = kCfgWideExact;
+  // the BK=32 laser-order kernel has no registers left for the gather state (it would spill): same tile at BK=16
+  if (exact && cfg == kCfgWideExact) cfg = kCfgWide;
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo<float> &c = kCfgsF32[cfg];
     bool va, ea;
@@ -156,7 +162,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, LOAD_IM2COL, exact, s);
     if (a.csA == 1 && ea) return c.fn(a, LOAD_VEC_K_EDGE, LOAD_IM2COL, exact, s);
     if (c.gen) return c.fn(a, LOAD_GEN_K, LOAD_IM2COL, exact, s);
-    cfg = gen_cfg(a, exact);
+    cfg = heuristic_cfg(a, exact, true, true);
   }
   return hipErrorInvalidValue;
 }

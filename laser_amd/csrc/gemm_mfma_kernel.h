@@ -137,31 +137,62 @@ struct TileLoader {
   static constexpr bool EDGE = (MODE == LOAD_VEC_X_EDGE || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || EDGE);
   static constexpr bool CONV = (MODE == LOAD_IM2COL);
-  static constexpr bool MASKED = !(MODE == LOAD_VEC_X || MODE == LOAD_VEC_K);
+  static constexpr bool MASKED = !(MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || CONV);  // CONV zeroes through the buffer's bounds check
   static_assert(!CONV || std::is_same<E, float>::value, "the implicit-GEMM loader is fp32 only");
   static_assert(ALONG_K || SwzShift<E, BK>::value >= (EPV == 4 ? 2 : 1), "16-byte pieces along x must stay contiguous");
   Vec v[NV];
   uint32_t msk[MASKED ? NV : 1];  // bit c: element c of piece i is real data (else it reads as zero)
-  // LOAD_IM2COL: per piece and element, (oh*sH - pH) in the high and (ow*sW - pW) in the low 16 bits
-  // of the output pixel this lane gathers for (fixed for the whole K loop); 0x7fff7fff = beyond N.
-  int32_t pix[CONV ? NV : 1][CONV ? 4 : 1];
+  // LOAD_IM2COL state.  The output pixel a lane gathers for is fixed for the whole K loop, so everything
+  // that depends on it is decoded ONCE (init_conv): per piece element the linear offset of its window
+  // origin  org = (oh*sH - pH)*W + (ow*sW - pW)  (may be negative) and two bitmaps, bit kr of `rowbad` /
+  // bit kq of `colbad` = "input row oh*sH-pH+kr / column ow*sW-pW+kq does NOT exist" (padding; all ones for
+  // x beyond N) -- packed 4 x (8 + 8) bits per piece; kernels up to 8x8, larger ones take the
+  // explicit-workspace path.
+  // The k side (channel c, kernel row kr, kernel column kq of the k this piece gathers) is a running
+  // state advanced by BK per tile with carries: no division in the K loop.  load_op() must therefore be
+  // called for consecutive tiles k0 = 0, BK, 2*BK, ... exactly once each (it is).
+  // The image is read through a raw buffer descriptor: an element that must read as zero gets the offset
+  // 0xfffffffc (all ones before the *4), which the bounds check answers with 0 -- as it does for k beyond K
+  // (channel >= C lies past num_records).  No clamping, no validity mask, no select at LDS-store time.
+  // (probe: scripts/probes/buffer_oob.hip -- per-dword check at the top end; a negative offset zeroes the
+  // WHOLE multi-dword load, which is why every element carries its own offset.)
+  int32_t org[CONV ? NV : 1][CONV ? 4 : 1];
+  uint32_t bad[CONV ? NV : 1][CONV ? 2 : 1];  // [i][e/2], 16 bits per element: rowbad | colbad << 8
+  int32_t kc_[CONV ? NV : 1], kr_[CONV ? NV : 1], kq_[CONV ? NV : 1];
+  __amdgpu_buffer_rsrc_t rsrc;  // this image as a bounds-checked buffer (wave-uniform, lives in SGPRs)
 
-  __device__ __forceinline__ void init_conv(const GemmArgs<E> &g, int64_t n0, int t) {
+  __device__ __forceinline__ void init_conv(const GemmArgs<E> &g, int64_t n0, int t, const E *image) {
     if constexpr (CONV) {
+      // readfirstlane: tell the compiler the descriptor is uniform (else every load becomes a waterfall loop)
+      const uint64_t b = reinterpret_cast<uint64_t>(image);
+      const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);  // (int results: no sign extension)
+      const int khw = g.ckH * g.ckW;
+      const int bytes = __builtin_amdgcn_readfirstlane((int)(g.K / khw) * g.cH * g.cW * 4);
+      rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bu), 0, bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NV; i++) {
         const int idx = t + i * NT;
-        const int xq = idx % (BX / 4);
+        const int xq = idx % (BX / 4), k = idx / (BX / 4);
+        kc_[i] = k / khw;
+        const int rem = k - kc_[i] * khw;
+        kr_[i] = rem / g.ckW;
+        kq_[i] = rem - kr_[i] * g.ckW;
+        bad[i][0] = bad[i][1] = 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int64_t j = n0 + 4 * xq + e;
+          uint32_t m = 0xffffu;
+          org[i][e] = 0;
           if (j < g.N) {
             const int oh = (int)(j / g.coW), ow = (int)(j - (int64_t)oh * g.coW);
             const int r0 = oh * g.csH - g.cpH, c0 = ow * g.csW - g.cpW;
-            pix[i][e] = (int32_t)(((uint32_t)(r0 & 0xffff) << 16) | (uint32_t)(c0 & 0xffff));
-          } else {
-            pix[i][e] = 0x7fff7fff;  // row 32767: fails the bounds test for every kr
+            org[i][e] = r0 * g.cW + c0;
+            m = 0;
+            for (int q = 0; q < g.ckH; q++) m |= ((unsigned)(r0 + q) < (unsigned)g.cH ? 0u : 1u) << q;
+            for (int q = 0; q < g.ckW; q++) m |= ((unsigned)(c0 + q) < (unsigned)g.cW ? 0u : 1u) << (8 + q);
           }
+          bad[i][e >> 1] |= m << (16 * (e & 1));
         }
       }
     }
@@ -221,25 +252,21 @@ struct TileLoader {
     const int idx = t + i * NT;
     constexpr uint32_t ALL = (1u << EPV) - 1u;
     if constexpr (CONV) {
-      // k -> (channel, kernel row, kernel col); the pixel part was decoded once in init_conv
-      const int k = idx / (BX / 4);
-      const int kk = (int)k0 + k;
-      const bool kin = kk < (int)klim;
-      const int kc_ = kin ? kk : (int)klim - 1;  // clamped: the address stays inside the image
-      const int khw = cg->ckH * cg->ckW;
-      const int c = kc_ / khw, rem = kc_ - c * khw;
-      const int kr = rem / cg->ckW, kcol = rem - kr * cg->ckW;
-      const E *img = base + (int64_t)c * cg->cH * cg->cW;
-      uint32_t m = 0;
+      // gather the 4 pixels of this piece for k = (kc_, kr_, kq_), then advance k by BK
+      const int c = kc_[i], kr = kr_[i], kq = kq_[i];
+      const int koff = c * (cg->cH * cg->cW) + kr * cg->cW + kq;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const int row = (int)(int16_t)(pix[i][e] >> 16) + kr, col = (int)(int16_t)(pix[i][e] & 0xffff) + kcol;
-        const bool ok = kin && (unsigned)row < (unsigned)cg->cH && (unsigned)col < (unsigned)cg->cW;
-        const int rc = min(max(row, 0), cg->cH - 1), cc = min(max(col, 0), cg->cW - 1);
-        v[i][e] = img[rc * cg->cW + cc];
-        m |= (ok ? 1u : 0u) << e;
+        const uint32_t w = bad[i][e >> 1];
+        // v_bfe_i32 of one bit: 0 (exists) or -1 (padding)
+        const int inv = __builtin_amdgcn_sbfe(w, 16 * (e & 1) + kr, 1) | __builtin_amdgcn_sbfe(w, 16 * (e & 1) + 8 + kq, 1);
+        const int voff = ((org[i][e] + koff) | inv) << 2;
+        v[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
       }
-      msk[i] = m;
+      int nq = kq + cg->cdq, nr = kr + cg->cdr, nc = c + cg->cdc;
+      if (nq >= cg->ckW) { nq -= cg->ckW; nr++; }
+      if (nr >= cg->ckH) { nr -= cg->ckH; nc++; }
+      kq_[i] = nq; kr_[i] = nr; kc_[i] = nc;
     } else if constexpr (!ALONG_K) {
       const int xq = idx % (BX / EPV), k = idx / (BX / EPV);
       if constexpr (VEC && !EDGE) {
@@ -346,14 +373,15 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 
   const E *Ab = g.A + bz * g.bsA + m0 * g.rsA;  // x = row of A, k along csA
   // x = col of B, k along rsB; for the implicit-GEMM conv the "matrix" is the NCHW image itself
-  const E *Bb = (BMODE == LOAD_IM2COL) ? g.B + bz * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
+  constexpr bool BCONV = (BMODE == LOAD_IM2COL);
+  const E *Bb = BCONV ? g.B + bz * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
   E *Cb = g.C + bz * g.bsC;
   const int64_t K = g.K;
   const int64_t mlim = g.M - m0, nlim = g.N - n0;
 
   TileLoader<E, BM, BK, NT, AMODE> la;
   TileLoader<E, BN, BK, NT, BMODE> lb;
-  lb.init_conv(g, n0, t);
+  lb.init_conv(g, n0, t, Bb);
 
   Acc acc[TM][TN];
 #pragma unroll
@@ -663,6 +691,12 @@ hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
   GemmArgs<E> g = a;
   g.tiles_m = (int)((a.M + BM - 1) / BM);
   g.tiles_n = (int)((a.N + BN - 1) / BN);
+  if constexpr (BMODE == LOAD_IM2COL) {
+    const int khw = a.ckH * a.ckW;
+    g.cdc = BK / khw;
+    g.cdr = (BK % khw) / a.ckW;
+    g.cdq = (BK % khw) % a.ckW;
+  }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)a.batch, 1), block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, s, g);
   return hipGetLastError();

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu5.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/pytest_gpu5.log
-timeout 900 python scripts/bench_configs.py > gpurun_out/configs.log 2>&1; echo "configs rc=$?"; grep '^{' gpurun_out/configs.log | grep -i "conv\|im2col"
+timeout 900 python -m pytest tests -m gpu -q -x -k "conv or im2col or kat" > gpurun_out/pytest_gpu5.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu5.log
+timeout 600 python scripts/conv_cfg_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/conv_probe.log

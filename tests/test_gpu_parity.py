@@ -343,7 +343,13 @@ def test_im2col_and_conv_vs_oracle(la, oracle):
                                       ((2, 24, 30, 31), (40, 24, 5, 3), (2, 1), (2, 3)),     # K = 360: EDGE filter loader
                                       ((2, 7, 17, 9), (130, 7, 3, 3), (1, 1), (1, 1)),       # K = 63: scalar filter loader
                                       ((1, 64, 28, 28), (300, 64, 3, 3), (1, 1), (1, 1)),    # K = 576 > kc: two slices
-                                      ((2, 4, 10, 10), (3, 4, 1, 1), (0, 0), (2, 2))]:
+                                      ((2, 4, 10, 10), (3, 4, 1, 1), (0, 0), (2, 2)),
+                                      ((2, 3, 33, 35), (16, 3, 7, 7), (3, 3), (2, 2)),       # stem-style 7x7 / 2
+                                      ((1, 6, 19, 23), (9, 6, 8, 8), (4, 2), (1, 3)),        # 8x8: largest gathered kernel
+                                      ((1, 2, 21, 22), (5, 2, 9, 9), (4, 4), (1, 1)),        # 9x9: explicit-workspace fallback
+                                      ((2, 5, 12, 12), (6, 5, 3, 3), (3, 3), (1, 1)),        # padding wider than the kernel reach
+                                      ((1, 40, 15, 15), (33, 40, 5, 5), (2, 2), (1, 1))]:    # "same" 5x5, K = 1000: two slices
+
         x = rng.uniform(0, 1, ishape).astype(np.float32)   # conv2d_bench.nim:124-125
         w = rng.uniform(0, 1, kshape).astype(np.float32)
         oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
