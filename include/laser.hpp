@@ -53,6 +53,23 @@ void gemm_strided_dev(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int6
 #undef LASER_ARGS
 }
 
+// Fused epilogue -- planned by the reference (README.md:238-242; TODO gemm.nim:196), not present in it:
+//   C = act(alpha*A*B + beta*C + bias),  bias a strided M x N view (strides may be 0), float/double only.
+enum class Activation : int { none = LASER_HIP_ACT_NONE, relu = LASER_HIP_ACT_RELU, tanh = LASER_HIP_ACT_TANH, sigmoid = LASER_HIP_ACT_SIGMOID };
+template <typename T>
+void gemm_strided_fused(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rowStrideA, int64_t colStrideA,
+                        const T *B, int64_t rowStrideB, int64_t colStrideB, T beta, T *C, int64_t rowStrideC,
+                        int64_t colStrideC, const T *bias, int64_t rowStrideBias, int64_t colStrideBias,
+                        Activation act = Activation::none) {
+  static_assert(std::is_floating_point_v<T>, "the fused epilogue is float / double only");
+  if constexpr (std::is_same_v<T, float>)
+    check(laser_hip_gemm_strided_ex_f32(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C,
+                                        rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, (int)act));
+  else
+    check(laser_hip_gemm_strided_ex_f64(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C,
+                                        rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, (int)act));
+}
+
 // gemm_prepacked.nim:76-85, :157-167
 template <typename T>
 int64_t gemm_prepackB_mem_required(int64_t M, int64_t N, int64_t K) {

@@ -201,6 +201,51 @@ int laser_hip_conv2d_im2col_f32_dev(float *d_output, const float *d_input, int64
                                     int64_t padW, int64_t strideH, int64_t strideW,
                                     float *d_workspace, void *stream);
 
+/* ---- fused epilogue ------------------------------------------------
+ * The reference plans it but does not have it: "fusing unary operations (like max/relu, tanh or
+ * sigmoid) and binary operations (like adding a bias) at the end of the matrix multiplication
+ * kernels" (README.md:238-242; TODOs gemm.nim:196, gemm_ukernel_generic.nim:78-79,128-129).
+ *   C[i,j] = act( alpha*A*B + beta*C  +  bias[i*rowStrideBias + j*colStrideBias] )
+ * The GEMM part is exactly gemm_strided (same accumulation order, same K == 0 rule: nothing is
+ * touched); the bias is added with one more rounding after the LAST accumulation slice, then the
+ * activation is applied -- once, on the accumulator, before the only store of C.  `bias` is a strided
+ * M x N view whose strides may be 0: (1,0) = one value per row of C (a convolution's per-channel
+ * bias), (0,1) = one per column (a dense layer's), (ldb,1) = a full residual matrix; NULL = none.
+ * float32 / float64 only (the activations are floating-point functions). */
+#define LASER_HIP_ACT_NONE 0
+#define LASER_HIP_ACT_RELU 1     /* x > 0 ? x : 0 */
+#define LASER_HIP_ACT_TANH 2
+#define LASER_HIP_ACT_SIGMOID 3  /* 1 / (1 + exp(-x)) */
+#define LASER_HIP_DECL_GEMM_EX(SFX, T)                                                            \
+  int laser_hip_gemm_strided_ex_##SFX(int64_t M, int64_t N, int64_t K, T alpha, const T *A,       \
+                                      int64_t rowStrideA, int64_t colStrideA, const T *B,         \
+                                      int64_t rowStrideB, int64_t colStrideB, T beta, T *C,       \
+                                      int64_t rowStrideC, int64_t colStrideC, const T *bias,      \
+                                      int64_t rowStrideBias, int64_t colStrideBias,               \
+                                      int activation);                                            \
+  int laser_hip_gemm_strided_ex_##SFX##_dev(int64_t M, int64_t N, int64_t K, T alpha, const T *dA, \
+                                            int64_t rowStrideA, int64_t colStrideA, const T *dB,  \
+                                            int64_t rowStrideB, int64_t colStrideB, T beta, T *dC, \
+                                            int64_t rowStrideC, int64_t colStrideC,               \
+                                            const T *d_bias, int64_t rowStrideBias,               \
+                                            int64_t colStrideBias, int activation, void *stream);
+LASER_HIP_DECL_GEMM_EX(f32, float)
+LASER_HIP_DECL_GEMM_EX(f64, double)
+#undef LASER_HIP_DECL_GEMM_EX
+/* conv2d_im2col with a per-output-channel bias ([c_out] or NULL) and an activation fused into the
+ * implicit GEMM's store (signature = laser_hip_conv2d_im2col_f32[_dev] + bias, activation). */
+int laser_hip_conv2d_im2col_ex_f32(float *output, const float *input, int64_t iN, int64_t iC,
+                                   int64_t iH, int64_t iW, const float *kernel, int64_t c_out,
+                                   int64_t c_in, int64_t kH, int64_t kW, int64_t padH, int64_t padW,
+                                   int64_t strideH, int64_t strideW, float *pworkspace,
+                                   const float *bias, int activation);
+int laser_hip_conv2d_im2col_ex_f32_dev(float *d_output, const float *d_input, int64_t iN, int64_t iC,
+                                       int64_t iH, int64_t iW, const float *d_kernel, int64_t c_out,
+                                       int64_t c_in, int64_t kH, int64_t kW, int64_t padH,
+                                       int64_t padW, int64_t strideH, int64_t strideW,
+                                       float *d_workspace, const float *d_bias, int activation,
+                                       void *stream);
+
 /* ---- cblas-shaped GEMM -- benchmarks/third_party/blas.nim:12-23 ---------------------------------
  * The call conv2d_im2col makes (conv2d_im2col.nim:161-166); ORDER 101 rowMajor / 102 colMajor,
  * TRANS 111 noTranspose / 112 transpose / 113 conjTranspose.  Mapped onto gemm_strided strides. */

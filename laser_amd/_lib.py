@@ -59,6 +59,11 @@ def lib():
             getattr(L, f"laser_hip_gemm_prepack{ab}_{sfx}_dev").argtypes = [vp, i64, i64, i64, vp, i64, i64, vp]
         getattr(L, f"laser_hip_gemm_packed_{sfx}").argtypes = [i64, i64, i64, ct, vp, vp, ct, vp, i64, i64]
         getattr(L, f"laser_hip_gemm_packed_{sfx}_dev").argtypes = [i64, i64, i64, ct, vp, vp, ct, vp, i64, i64, vp]
+    for sfx in ("f32", "f64"):  # fused epilogue: + bias view (ptr, rowStride, colStride) + activation
+        ct = _CT[sfx]
+        g = [i64, i64, i64, ct, vp, i64, i64, vp, i64, i64, ct, vp, i64, i64, vp, i64, i64, ci]
+        getattr(L, f"laser_hip_gemm_strided_ex_{sfx}").argtypes = g
+        getattr(L, f"laser_hip_gemm_strided_ex_{sfx}_dev").argtypes = g + [vp]
     L.laser_hip_gemm_prepack_release.argtypes = [vp]
     for b in ("b32", "b64"):
         getattr(L, f"laser_hip_transpose2d_copy_{b}").argtypes = [vp, vp, i64, i64]
@@ -73,6 +78,8 @@ def lib():
     L.laser_hip_im2col_f32_dev.argtypes = [vp, i64, i64, vp] + [i64] * 10 + [vp]
     L.laser_hip_conv2d_im2col_f32.argtypes = [vp, vp, i64, i64, i64, i64, vp] + [i64] * 8 + [vp]
     L.laser_hip_conv2d_im2col_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp] + [i64] * 8 + [vp, vp]
+    L.laser_hip_conv2d_im2col_ex_f32.argtypes = [vp, vp, i64, i64, i64, i64, vp] + [i64] * 8 + [vp, vp, ci]
+    L.laser_hip_conv2d_im2col_ex_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp] + [i64] * 8 + [vp, vp, ci, vp]
     L.laser_hip_cblas_sgemm.argtypes = [ci, ci, ci, i64, i64, i64, C.c_float, vp, i64, vp, i64, C.c_float, vp, i64]
     L.laser_hip_cblas_dgemm.argtypes = [ci, ci, ci, i64, i64, i64, C.c_double, vp, i64, vp, i64, C.c_double, vp, i64]
     _lib = L
@@ -96,7 +103,10 @@ def declared_symbols():
              "laser_hip_f32_config_name", "laser_hip_set_conv_implicit", "laser_hip_set_i32_mfma", "laser_hip_set_f64_mfma", "laser_hip_gemm_prepack_release",
              "laser_hip_conv2d_out_shape", "laser_hip_im2col_workspace_size", "laser_hip_im2col_f32",
              "laser_hip_im2col_f32_dev", "laser_hip_conv2d_im2col_f32", "laser_hip_conv2d_im2col_f32_dev",
-             "laser_hip_cblas_sgemm", "laser_hip_cblas_dgemm"]
+             "laser_hip_cblas_sgemm", "laser_hip_cblas_dgemm",
+             "laser_hip_gemm_strided_ex_f32", "laser_hip_gemm_strided_ex_f32_dev",
+             "laser_hip_gemm_strided_ex_f64", "laser_hip_gemm_strided_ex_f64_dev",
+             "laser_hip_conv2d_im2col_ex_f32", "laser_hip_conv2d_im2col_ex_f32_dev"]
     for s in _CT:
         names += [f"laser_hip_gemm_strided_{s}", f"laser_hip_gemm_strided_{s}_dev",
                   f"laser_hip_gemm_strided_batched_{s}_dev", f"laser_hip_gemm_packed_{s}",

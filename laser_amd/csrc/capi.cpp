@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <type_traits>
 #include <thread>
 #include <string>
 #include <unordered_map>
@@ -163,17 +164,41 @@ GemmArgs<T> make_args(int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, c
   return a;
 }
 
+// Fused epilogue request (device pointers): bias == nullptr and act == 0 means "plain gemm_strided".
+template <typename T>
+struct Epi {
+  const T *bias = nullptr;
+  int64_t rs = 0, cs = 0, bs = 0;
+  int act = 0;
+};
+template <typename T>
+int epi_check(const Epi<T> *e) {
+  if (!e) return LASER_HIP_OK;
+  if (e->act < LASER_HIP_ACT_NONE || e->act > LASER_HIP_ACT_SIGMOID) return fail(LASER_HIP_E_INVALID, "unknown activation %d", e->act);
+  if (!std::is_floating_point<T>::value) return fail(LASER_HIP_E_INVALID, "fused epilogue is float32/float64 only");
+  if (std::is_same<T, double>::value && !g_ctx.f64_mfma && (e->bias || e->act))
+    return fail(LASER_HIP_E_INVALID, "fused epilogue needs the f64 MFMA kernel (laser_hip_set_f64_mfma(1))");
+  return LASER_HIP_OK;
+}
+template <typename T>
+void epi_apply(GemmArgs<T> &a, const Epi<T> *e) {
+  if (!e) return;
+  a.bias = e->bias; a.rsBias = e->rs; a.csBias = e->cs; a.bsBias = e->bs; a.act = e->act;
+}
+
 template <typename T>
 int gemm_dev(int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA,
              int64_t bsA, const T *B, int64_t rsB, int64_t csB, int64_t bsB, T beta, T *C, int64_t rsC,
-             int64_t csC, int64_t bsC, void *stream) {
+             int64_t csC, int64_t bsC, void *stream, const Epi<T> *epi = nullptr) {
   if (M < 0 || N < 0 || K < 0 || batch < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = epi_check<T>(epi)) return rc;
   if (int rc = ensure_init()) return rc;
   // K == 0: the reference's pc loop never runs, C is left untouched even if beta != 1 (gemm.nim:150)
   if (M == 0 || N == 0 || K == 0 || batch == 0) return LASER_HIP_OK;
   if (!A || !B || !C) return fail(LASER_HIP_E_INVALID, "null operand pointer");
   if (batch > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
   GemmArgs<T> a = make_args<T>(batch, M, N, K, alpha, A, rsA, csA, bsA, B, rsB, csB, bsB, beta, C, rsC, csC, bsC);
+  epi_apply(a, epi);
   HIP_TRY(run_gemm<T>(a, (hipStream_t)stream));
   return LASER_HIP_OK;
 }
@@ -285,8 +310,9 @@ int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, in
 // Host-pointer gemm_strided: stage the touched span of each operand, run, copy the C span back.
 template <typename T>
 int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *B,
-              int64_t rsB, int64_t csB, T beta, T *C, int64_t rsC, int64_t csC) {
+              int64_t rsB, int64_t csB, T beta, T *C, int64_t rsC, int64_t csC, const Epi<T> *hepi = nullptr) {
   if (M < 0 || N < 0 || K < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
+  if (int rc = epi_check<T>(hepi)) return rc;
   if (int rc = ensure_init()) return rc;
   if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
   if (!A || !B || !C) return fail(LASER_HIP_E_INVALID, "null operand pointer");
@@ -313,7 +339,21 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   //   helper thread: D2H C_i as soon as kernel_i is done (PCIe is full duplex)
   auto iabs = [](int64_t v) { return v < 0 ? -v : v; };
   const bool panels_disjoint = rsA > 0 && rsC > 0 && rsA >= iabs(csA) * (K - 1) + 1 && rsC >= iabs(csC) * (N - 1) + 1;
-  if (panels_disjoint && M >= 2048 && (an + bn + cn) * sizeof(T) >= ((size_t)64 << 20))
+  // fused epilogue: hepi->bias is a HOST view here; its span goes to the device next to the operands
+  Epi<T> depi;
+  const bool fused = hepi && (hepi->bias || hepi->act);
+  if (fused) {
+    depi = *hepi;
+    if (hepi->bias) {
+      int64_t lo, hi;
+      view_span(M, N, hepi->rs, hepi->cs, &lo, &hi);
+      void *dbias;
+      if (int rc = scratch_get(5, (size_t)(hi - lo + 1) * sizeof(T), &dbias)) return rc;
+      HIP_TRY(hipMemcpy(dbias, hepi->bias + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyHostToDevice));
+      depi.bias = (const T *)dbias - lo;
+    }
+  }
+  if (!fused && panels_disjoint && M >= 2048 && (an + bn + cn) * sizeof(T) >= ((size_t)64 << 20))
     return gemm_host_pipelined<T>(M, N, K, alpha, A, rsA, csA, B + blo, bn, rsB, csB, beta, C, rsC, csC, dA0, dB0,
                                   (T *)dB, dC0, c_up);
 
@@ -321,6 +361,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   HIP_TRY(hipMemcpy(dB, B + blo, bn * sizeof(T), hipMemcpyHostToDevice));
   if (c_up) HIP_TRY(hipMemcpy(dC, C + clo, cn * sizeof(T), hipMemcpyHostToDevice));
   GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, dA0, rsA, csA, 0, dB0, rsB, csB, 0, beta, dC0, rsC, csC, 0);
+  if (fused) epi_apply(a, &depi);
   HIP_TRY(run_gemm<T>(a, nullptr));
   HIP_TRY(hipMemcpy(C + clo, dC, cn * sizeof(T), hipMemcpyDeviceToHost));  // synchronises
   return LASER_HIP_OK;
@@ -521,7 +562,11 @@ bool conv_takes_implicit(int64_t iC, int64_t iH, int64_t iW, int64_t kH, int64_t
 
 int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, int64_t iW, const float *dker,
              int64_t c_out, int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
-             hipStream_t s) {
+             hipStream_t s, const float *dbias = nullptr, int act = 0) {
+  // per-output-channel bias = one value per row of the [C_out x oH*oW] product, shared by all images
+  Epi<float> epi;
+  epi.bias = dbias; epi.rs = 1; epi.cs = 0; epi.bs = 0; epi.act = act;
+  if (int rc = epi_check<float>(&epi)) return rc;
   int64_t oH, oW;
   out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
   const int64_t M = c_out, K = iC * kH * kW, N = oH * oW;
@@ -533,6 +578,7 @@ int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, 
     GemmArgs<float> a = make_args<float>(iN, M, N, K, 1.0f, dker, K, 1, 0, din, 0, 1, iC * iH * iW, 0.0f, dout, N, 1, M * N);
     a.cH = (int32_t)iH; a.cW = (int32_t)iW; a.ckH = (int32_t)kH; a.ckW = (int32_t)kW; a.coW = (int32_t)oW;
     a.cpH = (int32_t)pH; a.cpW = (int32_t)pW; a.csH = (int32_t)sH; a.csW = (int32_t)sW;
+    epi_apply(a, &epi);
     HIP_TRY(launch_conv_implicit_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s));
     return LASER_HIP_OK;
   }
@@ -547,6 +593,7 @@ int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, 
   // O[n] (M x N) = F (M x K) . W[n] (K x N), alpha = 1, beta = 0 (conv2d_im2col.nim:104-105,161-166);
   // all images in ONE batched launch: A = filter shared by every image (batch stride 0)
   GemmArgs<float> a = make_args<float>(iN, M, N, K, 1.0f, dker, K, 1, 0, Bm, N, 1, bsB, 0.0f, dout, N, 1, M * N);
+  epi_apply(a, &epi);
   HIP_TRY(run_gemm<float>(a, s));
   return LASER_HIP_OK;
 }
@@ -790,10 +837,10 @@ int laser_hip_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int
   return LASER_HIP_OK;
 }
 
-int laser_hip_conv2d_im2col_f32_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
+static int conv2d_api_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
                                     int64_t iW, const float *dker, int64_t c_out, int64_t c_in, int64_t kH,
                                     int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
-                                    void *stream) {
+                                    const float *dbias, int act, void *stream) {
   if (int rc = conv_check(iN, iC, iH, iW, c_out, c_in, kH, kW, pH, pW, sH, sW)) return rc;
   if (int rc = ensure_init()) return rc;
   if (iN == 0) return LASER_HIP_OK;
@@ -807,12 +854,25 @@ int laser_hip_conv2d_im2col_f32_dev(float *dout, const float *din, int64_t iN, i
     if (int rc = scratch_get(4, (size_t)iN * iC * kH * kW * oH * oW * 4, &p)) return rc;
     dws = (float *)p;
   }
-  return conv_dev(dout, din, iN, iC, iH, iW, dker, c_out, kH, kW, pH, pW, sH, sW, dws, (hipStream_t)stream);
+  return conv_dev(dout, din, iN, iC, iH, iW, dker, c_out, kH, kW, pH, pW, sH, sW, dws, (hipStream_t)stream, dbias, act);
+}
+int laser_hip_conv2d_im2col_f32_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
+                                    int64_t iW, const float *dker, int64_t c_out, int64_t c_in, int64_t kH,
+                                    int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
+                                    void *stream) {
+  return conv2d_api_dev(dout, din, iN, iC, iH, iW, dker, c_out, c_in, kH, kW, pH, pW, sH, sW, dws, nullptr, 0, stream);
+}
+int laser_hip_conv2d_im2col_ex_f32_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
+                                       int64_t iW, const float *dker, int64_t c_out, int64_t c_in, int64_t kH,
+                                       int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
+                                       const float *dbias, int act, void *stream) {
+  return conv2d_api_dev(dout, din, iN, iC, iH, iW, dker, c_out, c_in, kH, kW, pH, pW, sH, sW, dws, dbias, act, stream);
 }
 
-int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t iC, int64_t iH, int64_t iW,
+static int conv2d_api_host(float *out, const float *in, int64_t iN, int64_t iC, int64_t iH, int64_t iW,
                                 const float *ker, int64_t c_out, int64_t c_in, int64_t kH, int64_t kW,
-                                int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *pworkspace) {
+                                int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *pworkspace,
+                                const float *bias, int act) {
   if (int rc = conv_check(iN, iC, iH, iW, c_out, c_in, kH, kW, pH, pW, sH, sW)) return rc;
   if (int rc = ensure_init()) return rc;
   if (iN == 0) return LASER_HIP_OK;
@@ -832,8 +892,13 @@ int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t
   if (int rc = scratch_get(4, implicit ? w1 : w1 * iN, &dws)) return rc;
   HIP_TRY(hipMemcpy(di, in, ib, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dk, ker, kb, hipMemcpyHostToDevice));
+  void *dbias = nullptr;
+  if (bias) {
+    if (int rc = scratch_get(5, (size_t)c_out * 4, &dbias)) return rc;
+    HIP_TRY(hipMemcpy(dbias, bias, (size_t)c_out * 4, hipMemcpyHostToDevice));
+  }
   if (int rc = conv_dev((float *)dout, (const float *)di, iN, iC, iH, iW, (const float *)dk, c_out, kH, kW, pH,
-                        pW, sH, sW, (float *)dws, nullptr))
+                        pW, sH, sW, (float *)dws, nullptr, (const float *)dbias, act))
     return rc;
   HIP_TRY(hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost));
   // like the reference, the caller's workspace ends up holding the LAST image's im2col matrix
@@ -848,6 +913,39 @@ int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t
   }
   return LASER_HIP_OK;
 }
+
+int laser_hip_conv2d_im2col_f32(float *out, const float *in, int64_t iN, int64_t iC, int64_t iH, int64_t iW,
+                                const float *ker, int64_t c_out, int64_t c_in, int64_t kH, int64_t kW,
+                                int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *pworkspace) {
+  return conv2d_api_host(out, in, iN, iC, iH, iW, ker, c_out, c_in, kH, kW, pH, pW, sH, sW, pworkspace, nullptr, 0);
+}
+int laser_hip_conv2d_im2col_ex_f32(float *out, const float *in, int64_t iN, int64_t iC, int64_t iH, int64_t iW,
+                                   const float *ker, int64_t c_out, int64_t c_in, int64_t kH, int64_t kW,
+                                   int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *pworkspace,
+                                   const float *bias, int act) {
+  return conv2d_api_host(out, in, iN, iC, iH, iW, ker, c_out, c_in, kH, kW, pH, pW, sH, sW, pworkspace, bias, act);
+}
+
+#define LH_DEF_GEMM_EX(SFX, T)                                                                                \
+  int laser_hip_gemm_strided_ex_##SFX(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,      \
+                                      int64_t csA, const T *B, int64_t rsB, int64_t csB, T beta, T *C,        \
+                                      int64_t rsC, int64_t csC, const T *bias, int64_t rsBias,                \
+                                      int64_t csBias, int act) {                                              \
+    Epi<T> e;                                                                                                 \
+    e.bias = bias; e.rs = rsBias; e.cs = csBias; e.act = act;                                                 \
+    return gemm_host<T>(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, C, rsC, csC, &e);                     \
+  }                                                                                                           \
+  int laser_hip_gemm_strided_ex_##SFX##_dev(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, \
+                                            int64_t csA, const T *B, int64_t rsB, int64_t csB, T beta, T *C,  \
+                                            int64_t rsC, int64_t csC, const T *bias, int64_t rsBias,          \
+                                            int64_t csBias, int act, void *stream) {                          \
+    Epi<T> e;                                                                                                 \
+    e.bias = bias; e.rs = rsBias; e.cs = csBias; e.act = act;                                                 \
+    return gemm_dev<T>(1, M, N, K, alpha, A, rsA, csA, 0, B, rsB, csB, 0, beta, C, rsC, csC, 0, stream, &e);  \
+  }
+LH_DEF_GEMM_EX(f32, float)
+LH_DEF_GEMM_EX(f64, double)
+#undef LH_DEF_GEMM_EX
 
 int laser_hip_cblas_sgemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, float alpha, const float *A,
                           int64_t lda, const float *B, int64_t ldb, float beta, float *C, int64_t ldc) {

@@ -29,6 +29,12 @@ struct GemmArgs {
   // image b's [C*kH*kW, oH*oW] matrix is gathered from the NCHW input at B + b*bsB with the index
   // arithmetic of im2col (benchmarks/convolution/conv2d_im2col.nim:62-87).
   int32_t cH, cW, ckH, ckW, coW, cpH, cpW, csH, csW;
+  // Fused epilogue (the reference plans it: README.md:238-242, TODOs gemm.nim:196,
+  // gemm_ukernel_generic.nim:78-79): C = act(alpha*AB + beta*C + bias), bias a strided (broadcastable:
+  // strides may be 0) M x N view, applied ONCE after the last accumulation slice.  bias == nullptr / act == 0: off.
+  const T *bias;
+  int64_t rsBias, csBias, bsBias;
+  int32_t act;  // laser_hip_activation
   int32_t cdc, cdr, cdq;  // per-K-tile advance of the implicit-GEMM loader's (channel, kernel row, kernel col): BK = cdc*kH*kW + cdr*kW + cdq
 };
 

@@ -69,6 +69,8 @@ struct Mma<float> {
   }
   // run + alpha*ab on a whole accumulator block, unfused (two roundings, like the scalar epilogue);
   // vector-typed so that it lowers to v_pk_mul_f32 / v_pk_add_f32 (8 + 8 instructions per block)
+  static __device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
+  static __device__ __forceinline__ float exp_(float x) { return expf(x); }
   static __device__ __forceinline__ Acc fold_acc(Acc run, Acc ab, float alpha) {
 #pragma clang fp contract(off)
     const Acc t = ab * alpha;
@@ -94,6 +96,8 @@ struct Mma<double> {
 #pragma clang fp contract(off)
     return a + b;
   }
+  static __device__ __forceinline__ double tanh_(double x) { return tanh(x); }
+  static __device__ __forceinline__ double exp_(double x) { return exp(x); }
   static __device__ __forceinline__ Acc fold_acc(Acc run, Acc ab, double alpha) {
 #pragma clang fp contract(off)
     const Acc t = ab * alpha;
@@ -331,7 +335,7 @@ struct TileLoader {
 //
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for.
 template <typename E, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
-          bool DBG = false>
+          bool DBG = false, bool EPI = false>
 __global__ void __launch_bounds__(WM *WN * 64, OCC)
     gemm_mfma_kernel(const GemmArgs<E> g) {
   using M_ = Mma<E>;
@@ -656,6 +660,24 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   }
 
   // -- epilogue: last (or only) slice, then store with the caller's strides --
+  // optional fused tail (uniform switch, outside the hot loop): + bias (one rounding), then the activation
+  // (EPI is a template flag: the plain kernels carry none of this -- the inlined tanh/exp bodies, one per
+  // accumulator element, triple the code size)
+  auto epilogue = [&](E v, int i, int n, int r, bool ok) __attribute__((always_inline)) -> E {
+    if (g.bias != nullptr) {
+      const int64_t row = m0 + wm0 + MB * i + M_::acc_row(r, lane);
+      const int64_t col = n0 + wn0 + MB * n + M_::acc_col(lane);
+      const E b = ok ? g.bias[bz * g.bsBias + row * g.rsBias + col * g.csBias] : (E)0;
+      v = M_::add(v, b);
+    }
+    switch (g.act) {
+      case 1: v = v > (E)0 ? v : (E)0; break;                          // relu (NaN -> 0, like max(x, 0) on the host)
+      case 2: v = M_::tanh_(v); break;
+      case 3: v = (E)1 / ((E)1 + M_::exp_(-v)); break;                 // sigmoid
+      default: break;
+    }
+    return v;
+  };
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -669,16 +691,17 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
           base = run[i][n][r];
         else
           base = scaled_c0(i, n, r);
-        const E out = axpy(base, acc[i][n][r]);
+        E out = axpy(base, acc[i][n][r]);
+        if constexpr (EPI) out = epilogue(out, i, n, r, ok);
         if (ok) *p = out;
       }
 }
 
 // ---- per-configuration launcher ---------------------------------------------------------------------
 template <typename E, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
-          bool DBG = false>
+          bool DBG = false, bool EPI = false>
 hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
-  auto kern = gemm_mfma_kernel<E, BM, BN, BK, WM, WN, AMODE, BMODE, EXACT, STAGES, OCC, DBG>;
+  auto kern = gemm_mfma_kernel<E, BM, BN, BK, WM, WN, AMODE, BMODE, EXACT, STAGES, OCC, DBG, EPI>;
   constexpr size_t lds = (size_t)STAGES * BK * (BM + BN) * sizeof(E);
   static_assert(lds <= 160 * 1024, "LDS budget is 160 KiB per CU");
   static bool attr_done = false;
@@ -705,8 +728,11 @@ hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
 // dispatch over the loader modes for one tile configuration
 template <typename E, int BM, int BN, int BK, int WM, int WN, int STAGES, int OCC, bool WITH_VEC, bool WITH_GEN, bool EXACT>
 hipError_t launch_cfg_mode(const GemmArgs<E> &a, int amode, int bmode, hipStream_t s) {
+  const bool fused = a.bias != nullptr || a.act != 0;  // fused epilogue: separate instantiation
 #define LH_CASE(AM, BMD) \
-  if (amode == AM && bmode == BMD) return launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC>(a, s);
+  if (amode == AM && bmode == BMD)                                                                           \
+    return fused ? launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC, false, true>(a, s)            \
+                 : launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC, false, false>(a, s);
   if constexpr (WITH_VEC) {
     LH_CASE(LOAD_VEC_K, LOAD_VEC_X)
     LH_CASE(LOAD_VEC_K, LOAD_VEC_K)

@@ -96,9 +96,25 @@ def f32_configs():
 
 
 # ---- GEMM ----------------------------------------------------------------------------------------
+ACTIVATIONS = {None: 0, "none": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+
+
+def _activation_code(activation):
+    if isinstance(activation, int):
+        return activation
+    try:
+        return ACTIVATIONS[activation]
+    except KeyError:
+        raise ValueError(f"unknown activation {activation!r} (one of {sorted(k for k in ACTIVATIONS if k)})")
+
+
 def gemm_strided(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C_,
-                 rowStrideC, colStrideC):
-    """C <- alpha*A*B + beta*C, element X[r,c] at X_ptr[r*rowStride + c*colStride]."""
+                 rowStrideC, colStrideC, bias=None, rowStrideBias=0, colStrideBias=0, activation=None):
+    """C <- alpha*A*B + beta*C, element X[r,c] at X_ptr[r*rowStride + c*colStride].
+
+    Fused epilogue (what the reference plans, README.md:238-242): with `bias` (a strided M x N view whose
+    strides may be 0) and/or `activation` ("relu" | "tanh" | "sigmoid"),
+    C <- act(alpha*A*B + beta*C + bias), applied once on the accumulator before the store; float32/float64."""
     L = _lib.lib()
     s = _sfx(C_)
     if _sfx(A) != s or _sfx(B) != s:
@@ -106,6 +122,18 @@ def gemm_strided(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colSt
     ct = _lib.ctype_of(s)
     args = [M, N, K, ct(alpha), _ptr(A), rowStrideA, colStrideA, _ptr(B), rowStrideB, colStrideB,
             ct(beta), _ptr(C_), rowStrideC, colStrideC]
+    act = _activation_code(activation)
+    if bias is not None or act:
+        if s not in ("f32", "f64"):
+            raise TypeError("the fused epilogue is float32/float64 only")
+        if bias is not None and _sfx(bias) != s:
+            raise TypeError("bias must have the element type of C")
+        args += [_ptr(bias), rowStrideBias, colStrideBias, act]
+        if _same_side(A, B, C_, bias):
+            _lib.check(getattr(L, f"laser_hip_gemm_strided_ex_{s}_dev")(*args, _stream()))
+        else:
+            _lib.check(getattr(L, f"laser_hip_gemm_strided_ex_{s}")(*args))
+        return C_
     if _same_side(A, B, C_):
         _lib.check(getattr(L, f"laser_hip_gemm_strided_{s}_dev")(*args, _stream()))
     else:
@@ -132,8 +160,9 @@ def _estrides(x):
     return tuple(st // x.dtype.itemsize for st in x.strides)
 
 
-def matmul(A, B, alpha=1, beta=0, out=None):
-    """Convenience over gemm_strided for 2-D views of any strides (numpy or torch.cuda)."""
+def matmul(A, B, alpha=1, beta=0, out=None, bias=None, activation=None):
+    """Convenience over gemm_strided for 2-D views of any strides (numpy or torch.cuda).
+    `bias`: a vector of N values (one per column, a dense layer's bias) or an (M, N) / broadcastable 2-D view."""
     M, K = A.shape
     K2, N = B.shape
     if K != K2:
@@ -141,7 +170,19 @@ def matmul(A, B, alpha=1, beta=0, out=None):
     if out is None:
         out = torch.zeros((M, N), dtype=A.dtype, device=A.device) if _is_dev(A) else np.zeros((M, N), dtype=A.dtype)
     (rsA, csA), (rsB, csB), (rsC, csC) = _estrides(A), _estrides(B), _estrides(out)
-    gemm_strided(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, out, rsC, csC)
+    rb = cb = 0
+    if bias is not None:
+        if bias.ndim == 1:
+            if bias.shape[0] != N:
+                raise ValueError("a 1-D bias must have N entries")
+            cb = _estrides(bias)[0]
+        else:
+            (r_, c_) = bias.shape
+            if r_ not in (1, M) or c_ not in (1, N):
+                raise ValueError("bias does not broadcast to (M, N)")
+            rb, cb = _estrides(bias)
+            rb, cb = (rb if r_ == M and M > 1 else 0), (cb if c_ == N and N > 1 else 0)
+    gemm_strided(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, out, rsC, csC, bias, rb, cb, activation)
     return out
 
 
@@ -262,13 +303,26 @@ def im2col(pworkspace, oshape, pinput, ishape, kshape, padding, strides):
     return pworkspace
 
 
-def conv2d_im2col(output, oshape, input_, ishape, kernel, kshape, padding, strides, pworkspace=None):
+def conv2d_im2col(output, oshape, input_, ishape, kernel, kshape, padding, strides, pworkspace=None,
+                  bias=None, activation=None):
+    """conv2d_im2col (benchmarks/convolution/conv2d_im2col.nim:90-166); `bias` ([c_out]) and `activation`
+    are the fused epilogue: output <- act(conv + bias[c_out]) in the same kernel."""
     L = _lib.lib()
     if tuple(oshape) != conv2d_out_shape(ishape, kshape, padding, strides):
         raise ValueError("oshape does not match conv2d_out_shape(ishape, kshape, padding, strides)")
     if oshape[1] != kshape[0]:
         raise ValueError("oshape.c != kshape.c_out")  # conv2d_im2col.nim:109
     args = [_ptr(output), _ptr(input_), *ishape, _ptr(kernel), *kshape, *padding, *strides, _ptr(pworkspace)]
+    act = _activation_code(activation)
+    if bias is not None or act:
+        if bias is not None and int(np.prod(tuple(bias.shape))) != kshape[0]:
+            raise ValueError("bias must hold c_out values")
+        args += [_ptr(bias), act]
+        if _same_side(output, input_, kernel, pworkspace, bias):
+            _lib.check(L.laser_hip_conv2d_im2col_ex_f32_dev(*args, _stream()))
+        else:
+            _lib.check(L.laser_hip_conv2d_im2col_ex_f32(*args))
+        return output
     if _same_side(output, input_, kernel, pworkspace):
         _lib.check(L.laser_hip_conv2d_im2col_f32_dev(*args, _stream()))
     else:

@@ -82,6 +82,33 @@ proc gemm_strided*[T: SomeNumber](
   else:
     {.error: "laser_hip: unsupported element type " & $T.}
 
+# ---- fused epilogue -- planned in the reference (README.md:238-242; TODO gemm.nim:196) -------------
+# C = act(alpha*A*B + beta*C + bias); bias is a strided M x N view whose strides may be 0.
+type Activation* = enum
+  actNone = 0, actRelu = 1, actTanh = 2, actSigmoid = 3
+
+proc laser_hip_gemm_strided_ex_f32(M, N, K: int, alpha: float32, A: ptr float32, rsA, csA: int, B: ptr float32,
+    rsB, csB: int, beta: float32, C: ptr float32, rsC, csC: int, bias: ptr float32, rsBias, csBias: int,
+    activation: cint): cint {.lh, importc.}
+proc laser_hip_gemm_strided_ex_f64(M, N, K: int, alpha: float64, A: ptr float64, rsA, csA: int, B: ptr float64,
+    rsB, csB: int, beta: float64, C: ptr float64, rsC, csC: int, bias: ptr float64, rsBias, csBias: int,
+    activation: cint): cint {.lh, importc.}
+
+proc gemm_strided_fused*[T: float32 or float64](
+      M, N, K: int, alpha: T,
+      A: ptr T, rowStrideA, colStrideA: int,
+      B: ptr T, rowStrideB, colStrideB: int,
+      beta: T,
+      C: ptr T, rowStrideC, colStrideC: int,
+      bias: ptr T, rowStrideBias, colStrideBias: int,
+      activation = actNone) =
+  when T is float32:
+    check laser_hip_gemm_strided_ex_f32(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta,
+                                        C, rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, cint(activation))
+  else:
+    check laser_hip_gemm_strided_ex_f64(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta,
+                                        C, rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, cint(activation))
+
 # ---- pre-packed GEMM -- gemm_prepacked.nim:76-292 -----------------------------------------------
 proc gemm_prepackB_mem_required*(T: typedesc, M, N, K: int): int =
   when T is float32: laser_hip_gemm_prepackB_mem_required_f32(M, N, K)

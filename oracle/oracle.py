@@ -251,6 +251,27 @@ def conv2d_direct(input_, kernel, padding, strides):
     return out
 
 
+def apply_epilogue(C_, bias=None, activation=None):
+    """The fused epilogue the reference plans (README.md:238-242; TODO gemm_ukernel_generic.nim:78-79),
+    restated on top of a finished gemm result: one more rounding for `+ bias` (numpy broadcasting),
+    then the activation, all in C's own precision.  relu = max(x, 0) with NaN -> 0 like `x > 0 ? x : 0`."""
+    out = C_.copy()
+    if bias is not None:
+        out = (out + np.asarray(bias, dtype=out.dtype)).astype(out.dtype)
+    one = out.dtype.type(1)
+    if activation in (None, "none", 0):
+        pass
+    elif activation in ("relu", 1):
+        out = np.where(out > 0, out, out.dtype.type(0)).astype(out.dtype)
+    elif activation in ("tanh", 2):
+        out = np.tanh(out).astype(out.dtype)
+    elif activation in ("sigmoid", 3):
+        out = (one / (one + np.exp(-out))).astype(out.dtype)
+    else:
+        raise ValueError(activation)
+    return out
+
+
 def mean_relative_error(y, y_true):
     """laser/private/error_functions.nim:6-26, float32 accumulation like the reference."""
     y = np.ascontiguousarray(y, dtype=np.float32).ravel()

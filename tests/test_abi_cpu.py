@@ -19,22 +19,12 @@ def built():
 
 
 def header_symbols():
-    """Expand the declaration macros of include/laser_hip.h by hand: every laser_hip_* identifier
-    that is followed by '(' after substituting SFX."""
-    src = open(os.path.join(ROOT, "include", "laser_hip.h")).read()
-    names = set(re.findall(r"\b(laser_hip_\w+)\s*\(", src))
-    out = set()
-    for n in names:
-        if "##SFX" in n:
-            continue
-        out.add(n)
-    # macro-generated families
-    for m in re.finditer(r"(laser_hip_\w+?)_##SFX(##_dev)?", src):
-        base, dev = m.group(1), "_dev" if m.group(2) else ""
-        fam = ("b32", "b64") if ("transpose2d" in base or "nchw" in base or "nhwc" in base) else ("f32", "f64", "i32", "i64")
-        for s in fam:
-            out.add(f"{base}_{s}{dev}")
-    return {n for n in out if not n.endswith("_")}
+    """Every function include/laser_hip.h declares: run the real preprocessor (the declaration macros
+    expand per element type) and collect each laser_hip_* identifier followed by '('."""
+    import subprocess
+    src = subprocess.run(["gcc", "-E", "-P", os.path.join(ROOT, "include", "laser_hip.h")], check=True,
+                         capture_output=True, text=True).stdout
+    return set(re.findall(r"\b(laser_hip_\w+)\s*\(", src))
 
 
 def test_library_exports_every_declared_symbol(built):

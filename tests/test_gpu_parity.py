@@ -507,3 +507,80 @@ def test_full_size_conv_c4(la, oracle):
     for n in (0, 31):
         want = oracle.conv2d_im2col(x[n:n + 1].cpu().numpy(), w.cpu().numpy(), pad, st)
         assert np.array_equal(out[n:n + 1].cpu().numpy(), want)
+
+
+# ---- fused epilogue (the reference only plans it) ---------------------------
+EPI_TOL = {np.float32: 4e-7, np.float64: 8e-16}   # tanh / sigmoid: device libm vs numpy, a few ulp of 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(129, 131, 515), (256, 384, 1030), (64, 64, 40)])
+def test_fused_epilogue_gemm_vs_oracle(la, oracle, dtype, shape):
+    """act(alpha*A*B + beta*C + bias): the GEMM part stays bit-identical to the oracle; bias / relu are
+    exact, tanh / sigmoid within a few ulp.  Host and device entry points, every bias broadcast form."""
+    import torch
+    M, N, K = shape
+    rng = np.random.default_rng(sum(shape) + (0 if dtype == np.float32 else 7))
+    A = rng.uniform(-0.5, 0.5, (M, K)).astype(dtype)
+    B = rng.uniform(-0.5, 0.5, (K, N)).astype(dtype)
+    C0 = rng.uniform(-1, 1, (M, N)).astype(dtype)
+    biases = {"col": rng.uniform(-1, 1, (1, N)).astype(dtype), "row": rng.uniform(-1, 1, (M, 1)).astype(dtype),
+              "full": rng.uniform(-1, 1, (M, N)).astype(dtype), "none": None}
+    alpha, beta = dtype(0.75), dtype(-0.5)
+    base = oracle.matmul(A, B, alpha=alpha, beta=beta, C_=C0.copy(), isa=oracle.fused_isa(dtype))
+    for bname, bias in biases.items():
+        for act in (None, "relu", "tanh", "sigmoid"):
+            if bias is None and act is None:
+                continue
+            want = oracle.apply_epilogue(base, bias, act)
+            got = la.matmul(A, B, alpha=alpha, beta=beta, out=C0.copy(), bias=bias, activation=act)
+            dA, dB, dC = (torch.from_numpy(x).cuda() for x in (A, B, C0.copy()))
+            dbias = None if bias is None else torch.from_numpy(bias).cuda()
+            got_dev = la.matmul(dA, dB, alpha=alpha, beta=beta, out=dC, bias=dbias, activation=act).cpu().numpy()
+            assert np.array_equal(got, got_dev), (bname, act)
+            if act in (None, "relu"):
+                assert np.array_equal(got, want), (bname, act)
+            else:
+                assert np.max(np.abs(got - want)) <= EPI_TOL[dtype], (bname, act, np.max(np.abs(got - want)))
+
+
+@pytest.mark.gpu
+def test_fused_epilogue_semantics(la):
+    A = np.ones((8, 0), np.float32); B = np.ones((0, 8), np.float32)
+    C0 = np.full((8, 8), 3.0, np.float32)
+    out = la.matmul(A, B, beta=0.0, out=C0.copy(), bias=np.ones((1, 8), np.float32), activation="relu")
+    assert np.array_equal(out, C0)                      # K == 0: nothing is touched, epilogue included
+    A = np.full((4, 4), np.nan, np.float32); B = np.ones((4, 4), np.float32)
+    out = la.matmul(A, B, activation="relu")
+    assert np.array_equal(out, np.zeros((4, 4), np.float32))   # x > 0 ? x : 0 maps NaN to 0
+    with pytest.raises(TypeError):
+        la.matmul(np.ones((4, 4), np.int32), np.ones((4, 4), np.int32), activation="relu")
+    with pytest.raises(ValueError):
+        la.matmul(np.ones((4, 4), np.float32), np.ones((4, 4), np.float32), activation="gelu")
+    with pytest.raises(la.LaserHipError):
+        la.gemm_strided(4, 4, 4, 1.0, np.ones((4, 4), np.float32), 4, 1, np.ones((4, 4), np.float32), 4, 1, 0.0,
+                        np.zeros((4, 4), np.float32), 4, 1, None, 0, 0, 9)
+
+
+@pytest.mark.gpu
+def test_fused_epilogue_conv_vs_oracle(la, oracle):
+    import torch
+    rng = np.random.default_rng(77)
+    for (ishape, kshape, pad, st) in [((2, 5, 13, 11), (4, 5, 3, 3), (1, 1), (1, 1)),
+                                      ((1, 64, 28, 28), (300, 64, 3, 3), (1, 1), (1, 1)),   # K = 576: two slices
+                                      ((1, 2, 21, 22), (5, 2, 9, 9), (4, 4), (1, 1)),      # explicit-workspace path
+                                      ((2, 8, 6, 6), (5, 8, 1, 1), (0, 0), (1, 1))]:       # 1x1 shortcut
+        x = rng.uniform(-1, 1, ishape).astype(np.float32)
+        w = rng.uniform(-1, 1, kshape).astype(np.float32)
+        b = rng.uniform(-1, 1, kshape[0]).astype(np.float32)
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+        ref = oracle.conv2d_im2col(x, w, pad, st, isa=oracle.fused_isa(np.float32))
+        want = oracle.apply_epilogue(ref, b.reshape(1, -1, 1, 1), "relu")
+        out = np.full(oshape, np.nan, np.float32)
+        la.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None, bias=b, activation="relu")
+        assert np.array_equal(out, want), (ishape, kshape)
+        dout = torch.full(oshape, float("nan"), device="cuda")
+        la.conv2d_im2col(dout, oshape, torch.from_numpy(x).cuda(), ishape, torch.from_numpy(w).cuda(), kshape, pad, st,
+                         None, bias=torch.from_numpy(b).cuda(), activation="relu")
+        assert np.array_equal(dout.cpu().numpy(), want), (ishape, kshape)
