@@ -3,8 +3,12 @@
 // originals (file:line per function); errors become exceptions where the reference doAsserts.
 // Header-only; link with -llaser_hip.  No compute happens on the host.
 #pragma once
+#include <array>
 #include <cstdint>
+#include <initializer_list>
+#include <memory>
 #include <stdexcept>
+#include <vector>
 #include <string>
 #include <type_traits>
 
@@ -148,6 +152,133 @@ inline void conv2d_im2col(float *output, TensorShape oshape, const float *input,
   if (oshape.c != kshape.c_out) throw Error(LASER_HIP_E_INVALID, "oshape.c != kshape.c_out");  // conv2d_im2col.nim:109
   check(laser_hip_conv2d_im2col_f32(output, input, ishape.n, ishape.c, ishape.h, ishape.w, kernel, kshape.c_out, kshape.c_in,
                                     kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w, pworkspace));
+}
+
+// ---- device-resident Tensor[T] -- laser/tensor/datatypes.nim:18-52, initialization.nim:42-202 ------
+// Same fields as the reference's Tensor (shape, strides, offset, storage); the storage's raw_buffer is a
+// DEVICE address, so gemm_strided_dev / transposes / conv chained on Tensors never cross PCIe.
+constexpr int LASER_MAXRANK = 6;  // laser/dynamic_stack_arrays.nim:6
+
+template <typename T>
+struct HipStorage {  // CpuStorage's twin (datatypes.nim:24-30); freed by the destructor = the Nim finalizer
+  T *raw_buffer = nullptr;
+  void *memalloc = nullptr;
+  bool memowner = false;
+  explicit HipStorage(int64_t size) {  // allocCpuStorage (allocator.nim:17-29): aligned, zero-filled
+    check(laser_hip_storage_alloc(&memalloc, size * (int64_t)sizeof(T)));
+    raw_buffer = static_cast<T *>(memalloc);
+    memowner = true;
+  }
+  HipStorage(const HipStorage &) = delete;
+  HipStorage &operator=(const HipStorage &) = delete;
+  ~HipStorage() {
+    if (memowner && memalloc) (void)laser_hip_storage_free(memalloc);
+  }
+};
+
+template <typename T>
+struct Tensor {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "float, double, int32_t or int64_t");
+  std::vector<int64_t> shape, strides;
+  int64_t offset = 0;
+  std::shared_ptr<HipStorage<T>> storage;
+
+  int rank() const { return (int)shape.size(); }
+  int64_t size() const {
+    int64_t n = 1;
+    for (int64_t s : shape) n *= s;
+    return n;
+  }
+  bool is_C_contiguous() const {  // datatypes.nim:38-47
+    int64_t cur = 1;
+    for (int i = rank() - 1; i >= 0; i--) {
+      if (shape[i] != 1 && strides[i] != cur) return false;
+      cur *= shape[i];
+    }
+    return true;
+  }
+  T *unsafe_raw_data() { return storage->raw_buffer + offset; }              // device pointer
+  const T *unsafe_raw_data() const { return storage->raw_buffer + offset; }
+  Tensor transposed() const {  // view: reversed axes
+    Tensor t = *this;
+    t.shape.assign(shape.rbegin(), shape.rend());
+    t.strides.assign(strides.rbegin(), strides.rend());
+    return t;
+  }
+  std::vector<T> to_host() const;
+};
+
+template <typename T>
+Tensor<T> newTensor(std::initializer_list<int64_t> shape) {  // initialization.nim:156-166 (zero-initialised)
+  if ((int)shape.size() > LASER_MAXRANK) throw Error(LASER_HIP_E_INVALID, "rank > LASER_MAXRANK");
+  Tensor<T> t;
+  t.shape.assign(shape.begin(), shape.end());
+  t.strides.resize(t.shape.size());
+  int64_t size = 1;
+  for (int i = t.rank() - 1; i >= 0; i--) {
+    t.strides[i] = size;
+    size *= t.shape[i];
+  }
+  t.storage = std::make_shared<HipStorage<T>>(size);
+  return t;
+}
+template <typename T>
+void copy_strided_dev(Tensor<T> &dst, const Tensor<T> &src) {
+  if (dst.shape != src.shape) throw Error(LASER_HIP_E_INVALID, "shapes differ");
+  if constexpr (sizeof(T) == 4)
+    check(laser_hip_copy_strided_b32_dev(dst.unsafe_raw_data(), dst.strides.data(), src.unsafe_raw_data(), src.strides.data(),
+                                         dst.shape.data(), dst.rank(), nullptr));
+  else
+    check(laser_hip_copy_strided_b64_dev(dst.unsafe_raw_data(), dst.strides.data(), src.unsafe_raw_data(), src.strides.data(),
+                                         dst.shape.data(), dst.rank(), nullptr));
+}
+template <typename T>
+void copyFrom(Tensor<T> &dst, const Tensor<T> &src) { copy_strided_dev(dst, src); }  // initialization.nim:77-110
+template <typename T>
+void deepCopy(Tensor<T> &dst, const Tensor<T> &src) {  // initialization.nim:42-75: fresh row-major storage
+  Tensor<T> fresh;
+  fresh.shape = src.shape;
+  fresh.strides.resize(src.shape.size());
+  int64_t size = 1;
+  for (int i = fresh.rank() - 1; i >= 0; i--) {
+    fresh.strides[i] = size;
+    size *= fresh.shape[i];
+  }
+  fresh.storage = std::make_shared<HipStorage<T>>(size);
+  copy_strided_dev(fresh, src);
+  dst = fresh;
+}
+template <typename T>
+void copyFromRaw(Tensor<T> &dst, const T *buffer, int64_t len) {  // initialization.nim:112-128
+  if (dst.size() != len) throw Error(LASER_HIP_E_INVALID, "Tensor size and buffer length should be the same");
+  if (!dst.is_C_contiguous()) throw Error(LASER_HIP_E_INVALID, "copyFromRaw needs a contiguous destination");
+  check(laser_hip_storage_upload(dst.unsafe_raw_data(), buffer, len * (int64_t)sizeof(T)));
+}
+template <typename T>
+void setZero(Tensor<T> &t) {  // initialization.nim:130-154
+  if (!t.is_C_contiguous()) throw Error(LASER_HIP_E_INVALID, "Input tensor is not contiguous.");
+  check(laser_hip_storage_set_zero(t.unsafe_raw_data(), t.size() * (int64_t)sizeof(T), nullptr));
+}
+template <typename T>
+std::vector<T> Tensor<T>::to_host() const {
+  Tensor<T> c;
+  const Tensor<T> *src = this;
+  if (!is_C_contiguous()) {
+    deepCopy(c, *this);
+    src = &c;
+  }
+  std::vector<T> out((size_t)size());
+  check(laser_hip_storage_download(out.data(), src->unsafe_raw_data(), size() * (int64_t)sizeof(T)));
+  return out;
+}
+// C (M x N) = alpha * A (M x K) * B (K x N) + beta * C on 2-D Tensors of any strides, all device-resident
+template <typename T>
+void gemm(T alpha, const Tensor<T> &A, const Tensor<T> &B, T beta, Tensor<T> &C) {
+  if (A.rank() != 2 || B.rank() != 2 || C.rank() != 2 || A.shape[1] != B.shape[0] || C.shape[0] != A.shape[0] ||
+      C.shape[1] != B.shape[1])
+    throw Error(LASER_HIP_E_INVALID, "gemm: shapes do not agree");
+  gemm_strided_dev<T>(A.shape[0], B.shape[1], A.shape[1], alpha, A.unsafe_raw_data(), A.strides[0], A.strides[1],
+                      B.unsafe_raw_data(), B.strides[0], B.strides[1], beta, C.unsafe_raw_data(), C.strides[0], C.strides[1]);
 }
 
 #undef LASER_DISPATCH

@@ -246,6 +246,33 @@ int laser_hip_conv2d_im2col_ex_f32_dev(float *d_output, const float *d_input, in
                                        float *d_workspace, const float *d_bias, int activation,
                                        void *stream);
 
+/* ---- device tensor storage -----------------------------------------
+ * The device twin of CpuStorage / allocCpuStorage and of the data-moving procs of
+ * laser/tensor/initialization.nim, so that a Tensor[T]-shaped object (shape, strides, offset,
+ * storage -- laser/tensor/datatypes.nim:18-30) can keep its buffer in HBM and chains of
+ * gemm_strided / transposes / conv never cross PCIe.  The Tensor object itself stays on the host
+ * language's side (nim/laser_hip.nim, include/laser.hpp, laser_amd/tensor.py); only raw buffers and
+ * strides cross this ABI, as for every other entry point.
+ *   storage_alloc    allocCpuStorage (allocator.nim:17-29): `bytes` of device memory, aligned to at
+ *                    least LASER_MEM_ALIGN = 64 and zero-filled (allocShared0)
+ *   storage_free     the storage finalizer (allocator.nim:11-15)
+ *   storage_upload   copyFromRaw (initialization.nim:112-128): host buffer -> device storage
+ *   storage_download the reverse (reading results back)
+ *   storage_set_zero setZero (initialization.nim:130-154) on a contiguous extent
+ *   copy_strided     `forEachStrided d in dst, s in src: d = s` (deepCopy / copyFrom of views,
+ *                    initialization.nim:42-110): rank <= 6 (LASER_MAXRANK), element strides, same shape */
+int laser_hip_storage_alloc(void **d_raw_buffer, int64_t bytes);
+int laser_hip_storage_free(void *d_raw_buffer);
+int laser_hip_storage_upload(void *d_dst, const void *host_src, int64_t bytes);
+int laser_hip_storage_download(void *host_dst, const void *d_src, int64_t bytes);
+int laser_hip_storage_set_zero(void *d_buffer, int64_t bytes, void *stream);
+int laser_hip_copy_strided_b32_dev(void *d_dst, const int64_t *dst_strides, const void *d_src,
+                                   const int64_t *src_strides, const int64_t *shape, int rank,
+                                   void *stream);
+int laser_hip_copy_strided_b64_dev(void *d_dst, const int64_t *dst_strides, const void *d_src,
+                                   const int64_t *src_strides, const int64_t *shape, int rank,
+                                   void *stream);
+
 /* ---- cblas-shaped GEMM -- benchmarks/third_party/blas.nim:12-23 ---------------------------------
  * The call conv2d_im2col makes (conv2d_im2col.nim:161-166); ORDER 101 rowMajor / 102 colMajor,
  * TRANS 111 noTranspose / 112 transpose / 113 conjTranspose.  Mapped onto gemm_strided strides. */

@@ -6,5 +6,8 @@ package is the thin host-side mirror of the reference's Nim procs over that ABI.
 from ._lib import LaserHipError, LIB_PATH, lib  # noqa: F401
 from .primitives import *  # noqa: F401,F403
 from . import primitives  # noqa: F401
+from . import tensor  # noqa: F401
+from .tensor import (Tensor, HipStorage, newTensor, toTensor, fromTorch, deepCopy, copyFrom, copyFromRaw,  # noqa: F401
+                     setZero)
 
 __version__ = "0.1.0"

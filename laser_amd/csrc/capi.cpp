@@ -622,6 +622,36 @@ int cblas_gemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, T alp
 }  // namespace
 
 // =====================================================================================================
+namespace {
+template <typename U>
+int copy_strided_api(void *dst, const int64_t *ds, const void *src, const int64_t *ss, const int64_t *shape,
+                            int rank, void *stream) {
+  if (rank < 0 || rank > kMaxRank) return fail(LASER_HIP_E_INVALID, "rank %d outside 0..%d (LASER_MAXRANK)", rank, kMaxRank);
+  if (rank > 0 && (!ds || !ss || !shape)) return fail(LASER_HIP_E_INVALID, "null shape/strides");
+  int64_t total = 1;
+  for (int d = 0; d < rank; d++) {
+    if (shape[d] < 0) return fail(LASER_HIP_E_INVALID, "negative extent");
+    total *= shape[d];
+  }
+  if (int rc = ensure_init()) return rc;
+  if (total == 0) return LASER_HIP_OK;
+  if (!dst || !src) return fail(LASER_HIP_E_INVALID, "null buffer");
+  // both sides C-contiguous: a plain device-to-device copy
+  bool contiguous = true;
+  int64_t run = 1;
+  for (int d = rank - 1; d >= 0; d--) {
+    if (shape[d] != 1 && (ds[d] != run || ss[d] != run)) contiguous = false;
+    run *= shape[d];
+  }
+  if (contiguous) {
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)total * sizeof(U), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return LASER_HIP_OK;
+  }
+  HIP_TRY(launch_copy_strided<U>((U *)dst, ds, (const U *)src, ss, shape, rank, (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int laser_hip_init(int device) {
@@ -946,6 +976,54 @@ int laser_hip_conv2d_im2col_ex_f32(float *out, const float *in, int64_t iN, int6
 LH_DEF_GEMM_EX(f32, float)
 LH_DEF_GEMM_EX(f64, double)
 #undef LH_DEF_GEMM_EX
+
+// ---- device tensor storage -- laser/tensor/allocator.nim, initialization.nim -----------------------
+int laser_hip_storage_alloc(void **d, int64_t bytes) {
+  if (!d || bytes < 0) return fail(LASER_HIP_E_INVALID, "storage_alloc: bad argument");
+  if (int rc = ensure_init()) return rc;
+  *d = nullptr;
+  if (bytes == 0) return LASER_HIP_OK;
+  HIP_TRY(hipMalloc(d, (size_t)bytes));  // hipMalloc is 256-byte aligned >= LASER_MEM_ALIGN
+  hipError_t e = hipMemset(*d, 0, (size_t)bytes);
+  if (e != hipSuccess) {
+    (void)hipFree(*d);
+    *d = nullptr;
+    return fail(LASER_HIP_E_HIP, "hipMemset: %s", hipGetErrorString(e));
+  }
+  return LASER_HIP_OK;
+}
+int laser_hip_storage_free(void *d) {
+  if (!d) return LASER_HIP_OK;
+  if (int rc = ensure_init()) return rc;
+  HIP_TRY(hipFree(d));
+  return LASER_HIP_OK;
+}
+int laser_hip_storage_upload(void *d, const void *h, int64_t bytes) {
+  if (bytes < 0 || (bytes > 0 && (!d || !h))) return fail(LASER_HIP_E_INVALID, "storage_upload: bad argument");
+  if (int rc = ensure_init()) return rc;
+  if (bytes) HIP_TRY(hipMemcpy(d, h, (size_t)bytes, hipMemcpyHostToDevice));
+  return LASER_HIP_OK;
+}
+int laser_hip_storage_download(void *h, const void *d, int64_t bytes) {
+  if (bytes < 0 || (bytes > 0 && (!d || !h))) return fail(LASER_HIP_E_INVALID, "storage_download: bad argument");
+  if (int rc = ensure_init()) return rc;
+  if (bytes) HIP_TRY(hipMemcpy(h, d, (size_t)bytes, hipMemcpyDeviceToHost));
+  return LASER_HIP_OK;
+}
+int laser_hip_storage_set_zero(void *d, int64_t bytes, void *stream) {
+  if (bytes < 0 || (bytes > 0 && !d)) return fail(LASER_HIP_E_INVALID, "storage_set_zero: bad argument");
+  if (int rc = ensure_init()) return rc;
+  if (bytes) HIP_TRY(hipMemsetAsync(d, 0, (size_t)bytes, (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
+int laser_hip_copy_strided_b32_dev(void *dst, const int64_t *ds, const void *src, const int64_t *ss,
+                                   const int64_t *shape, int rank, void *stream) {
+  return copy_strided_api<uint32_t>(dst, ds, src, ss, shape, rank, stream);
+}
+int laser_hip_copy_strided_b64_dev(void *dst, const int64_t *ds, const void *src, const int64_t *ss,
+                                   const int64_t *shape, int rank, void *stream) {
+  return copy_strided_api<uint64_t>(dst, ds, src, ss, shape, rank, stream);
+}
 
 int laser_hip_cblas_sgemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, float alpha, const float *A,
                           int64_t lda, const float *B, int64_t ldb, float beta, float *C, int64_t ldc) {

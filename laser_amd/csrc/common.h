@@ -77,6 +77,11 @@ hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in,
                              int64_t C, int64_t H, int64_t W, int64_t kH, int64_t kW, int64_t pH,
                              int64_t pW, int64_t sH, int64_t sW, hipStream_t s);
 // dst[r*ld + c] = (r < R && c < Ccols) ? src[r*rs + c*cs] : 0 for r < Rpad, c < Cpad
+// rank-N strided element copy (tensor deepCopy / copyFrom); LASER_MAXRANK = 6 (laser/dynamic_stack_arrays.nim:6)
+constexpr int kMaxRank = 6;
+template <typename T>
+hipError_t launch_copy_strided(T *dst, const int64_t *dstrides, const T *src, const int64_t *sstrides,
+                               const int64_t *shape, int rank, hipStream_t s);
 template <typename T>
 hipError_t launch_pack_pad(T *dst, int64_t Rpad, int64_t Cpad, const T *src, int64_t R,
                            int64_t Ccols, int64_t rs, int64_t cs, hipStream_t s);

@@ -170,4 +170,50 @@ template hipError_t launch_pack_pad<double>(double *, int64_t, int64_t, const do
 template hipError_t launch_pack_pad<int32_t>(int32_t *, int64_t, int64_t, const int32_t *, int64_t, int64_t, int64_t, int64_t, hipStream_t);
 template hipError_t launch_pack_pad<int64_t>(int64_t *, int64_t, int64_t, const int64_t *, int64_t, int64_t, int64_t, int64_t, hipStream_t);
 
+// ---- rank-N strided copy: `forEachStrided d in dst, s in src: d = s` -----------------------------
+// (laser/tensor/initialization.nim:42-110: deepCopy / copyFrom of non-contiguous tensors.)  One element
+// per thread, index decoded from the innermost dimension outwards; consecutive threads walk the
+// innermost dimension, so unit-stride inner dimensions coalesce on that side.  HBM-bound.
+struct StridedCopyArgs {
+  int64_t shape[kMaxRank], dstride[kMaxRank], sstride[kMaxRank];
+  int64_t total;
+  int32_t rank;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) copy_strided_kernel(T *__restrict__ dst, const T *__restrict__ src,
+                                                           StridedCopyArgs a) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (int64_t)gridDim.x * 256) {
+    int64_t rem = idx, so = 0, dof = 0;
+#pragma unroll
+    for (int d = kMaxRank - 1; d >= 0; d--) {
+      if (d < a.rank) {
+        const int64_t q = rem / a.shape[d], i = rem - q * a.shape[d];
+        so += i * a.sstride[d];
+        dof += i * a.dstride[d];
+        rem = q;
+      }
+    }
+    dst[dof] = src[so];
+  }
+}
+template <typename T>
+hipError_t launch_copy_strided(T *dst, const int64_t *dstrides, const T *src, const int64_t *sstrides,
+                               const int64_t *shape, int rank, hipStream_t s) {
+  StridedCopyArgs a;
+  a.rank = rank;
+  a.total = 1;
+  for (int d = 0; d < kMaxRank; d++) {
+    a.shape[d] = d < rank ? shape[d] : 1;
+    a.dstride[d] = d < rank ? dstrides[d] : 0;
+    a.sstride[d] = d < rank ? sstrides[d] : 0;
+    a.total *= a.shape[d];
+  }
+  if (a.total == 0) return hipSuccess;
+  const int64_t blocks = std::min<int64_t>((a.total + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(copy_strided_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, a);
+  return hipGetLastError();
+}
+template hipError_t launch_copy_strided<uint32_t>(uint32_t *, const int64_t *, const uint32_t *, const int64_t *, const int64_t *, int, hipStream_t);
+template hipError_t launch_copy_strided<uint64_t>(uint64_t *, const int64_t *, const uint64_t *, const int64_t *, const int64_t *, int, hipStream_t);
+
 }  // namespace laser_hip

@@ -30,8 +30,13 @@ except Exception:  # pragma: no cover
 _SFX = {"float32": "f32", "float64": "f64", "int32": "i32", "int64": "i64"}
 
 
+def _is_lt(x):
+    """A laser_amd.tensor.Tensor: Laser's Tensor[T] with device storage (laser_amd/tensor.py)."""
+    return getattr(x, "_laser_hip_tensor", False)
+
+
 def _is_dev(x):
-    return torch is not None and isinstance(x, torch.Tensor)
+    return _is_lt(x) or (torch is not None and isinstance(x, torch.Tensor))
 
 
 def _sfx(x):
@@ -44,6 +49,8 @@ def _sfx(x):
 def _ptr(x):
     if x is None:
         return None
+    if _is_lt(x):
+        return C.c_void_p(x.unsafe_raw_data())   # what the Nim side passes: unsafe_raw_data(t)
     if _is_dev(x):
         if not x.is_cuda:
             raise TypeError("torch tensors must live on the GPU (pass numpy arrays for host memory)")
@@ -52,6 +59,8 @@ def _ptr(x):
 
 
 def _stream():
+    if torch is None or not torch.cuda.is_available():
+        return None  # the null stream
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -155,6 +164,8 @@ def gemm_strided_batched(batch, M, N, K, alpha, A, rsA, csA, bsA, B, rsB, csB, b
 
 
 def _estrides(x):
+    if _is_lt(x):
+        return tuple(x.strides)
     if _is_dev(x):
         return tuple(x.stride())
     return tuple(st // x.dtype.itemsize for st in x.strides)
@@ -168,11 +179,15 @@ def matmul(A, B, alpha=1, beta=0, out=None, bias=None, activation=None):
     if K != K2:
         raise ValueError("inner dimensions differ")
     if out is None:
-        out = torch.zeros((M, N), dtype=A.dtype, device=A.device) if _is_dev(A) else np.zeros((M, N), dtype=A.dtype)
+        if _is_lt(A):
+            from .tensor import newTensor
+            out = newTensor(A.dtype, M, N)
+        else:
+            out = torch.zeros((M, N), dtype=A.dtype, device=A.device) if _is_dev(A) else np.zeros((M, N), dtype=A.dtype)
     (rsA, csA), (rsB, csB), (rsC, csC) = _estrides(A), _estrides(B), _estrides(out)
     rb = cb = 0
     if bias is not None:
-        if bias.ndim == 1:
+        if len(bias.shape) == 1:
             if bias.shape[0] != N:
                 raise ValueError("a 1-D bias must have N entries")
             cb = _estrides(bias)[0]
@@ -242,7 +257,7 @@ def aligned_host_buffer(nbytes, dtype=np.uint8, align=64):
 
 # ---- transposes ------------------------------------------------------------------------------------
 def _bsfx(x):
-    size = x.element_size() if _is_dev(x) else x.dtype.itemsize
+    size = x.element_size() if (_is_dev(x) and not _is_lt(x)) else x.dtype.itemsize
     if size not in (4, 8):
         raise TypeError("transposes support 4- and 8-byte elements")
     return "b32" if size == 4 else "b64"

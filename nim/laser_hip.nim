@@ -201,3 +201,56 @@ proc gemm*(ORDER: OrderType, TRANSA, TRANSB: TransposeType, M, N, K: int, ALPHA:
 # (laser/tensor/datatypes.nim:13-30, laser/strided_iteration/foreach.nim:192-264).  A caller does
 #   gemm_strided(M, N, K, 1'f32, a.unsafe_raw_data, a.strides[0], a.strides[1], ...)
 # exactly as before; only raw pointers and element strides cross the ABI.
+
+# ---- device-resident storage: HipStorage, the twin of CpuStorage ---------------------------------
+# (SURVEY.md section 8f rank 3.)  `Tensor[T]` keeps its shape / strides / offset; what changes is
+# where `storage.raw_buffer` lives.  With a HipStorage the pointer handed to gemm_strided_dev & co.
+# is a device address, so chained calls never cross PCIe.  Same layout as
+# laser/tensor/datatypes.nim:24-30 and the same finalizer pattern as allocator.nim:11-29.
+proc laser_hip_storage_alloc(d: ptr pointer, bytes: int): cint {.lh, importc.}
+proc laser_hip_storage_free(d: pointer): cint {.lh, importc.}
+proc laser_hip_storage_upload(d, host: pointer, bytes: int): cint {.lh, importc.}
+proc laser_hip_storage_download(host, d: pointer, bytes: int): cint {.lh, importc.}
+proc laser_hip_storage_set_zero(d: pointer, bytes: int, stream: pointer): cint {.lh, importc.}
+proc laser_hip_copy_strided_b32_dev(dst: pointer, dstStrides: ptr int, src: pointer, srcStrides: ptr int,
+                                    shape: ptr int, rank: cint, stream: pointer): cint {.lh, importc.}
+proc laser_hip_copy_strided_b64_dev(dst: pointer, dstStrides: ptr int, src: pointer, srcStrides: ptr int,
+                                    shape: ptr int, rank: cint, stream: pointer): cint {.lh, importc.}
+
+type
+  HipStorage*{.shallow.}[T] = ref object
+    raw_buffer*: ptr UncheckedArray[T]   # DEVICE address
+    memalloc*: pointer
+    memowner*: bool
+
+proc finalizer[T](storage: HipStorage[T]) =
+  if storage.memowner and not storage.memalloc.isNil:
+    discard laser_hip_storage_free(storage.memalloc)
+
+proc allocHipStorage*[T](storage: var HipStorage[T], size: int) =
+  ## allocCpuStorage's twin: `size` elements, aligned >= LASER_MEM_ALIGN, zero-filled.
+  new(storage, finalizer[T])
+  check laser_hip_storage_alloc(storage.memalloc.addr, sizeof(T) * size)
+  storage.memowner = true
+  storage.raw_buffer = cast[ptr UncheckedArray[T]](storage.memalloc)
+
+proc copyFromRaw*[T](dst: HipStorage[T], buffer: ptr T, len: Natural) =
+  ## initialization.nim:112-128 for a device storage (host buffer -> HBM).
+  check laser_hip_storage_upload(dst.raw_buffer, buffer, sizeof(T) * len)
+
+proc copyToRaw*[T](buffer: ptr T, src: HipStorage[T], len: Natural) =
+  check laser_hip_storage_download(buffer, src.raw_buffer, sizeof(T) * len)
+
+proc setZero*[T](s: HipStorage[T], len: Natural) =
+  check laser_hip_storage_set_zero(s.raw_buffer, sizeof(T) * len, nil)
+
+proc copyStrided*[T](dst: ptr T, dstStrides: openarray[int], src: ptr T, srcStrides: openarray[int],
+                     shape: openarray[int]) =
+  ## `forEachStrided d in dst, s in src: d = s` on device buffers (deepCopy / copyFrom of views).
+  assert shape.len == dstStrides.len and shape.len == srcStrides.len and shape.len <= 6   # LASER_MAXRANK
+  when sizeof(T) == 4:
+    check laser_hip_copy_strided_b32_dev(dst, dstStrides[0].unsafeAddr, src, srcStrides[0].unsafeAddr,
+                                         shape[0].unsafeAddr, cint(shape.len), nil)
+  else:
+    check laser_hip_copy_strided_b64_dev(dst, dstStrides[0].unsafeAddr, src, srcStrides[0].unsafeAddr,
+                                         shape[0].unsafeAddr, cint(shape.len), nil)

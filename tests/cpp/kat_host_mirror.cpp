@@ -62,6 +62,24 @@ int main() {
   laser::transpose2D_copy(&t[0][0], &m[0][0], 2, 3);
   for (int i = 0; i < 2; i++)
     for (int j = 0; j < 3; j++) fails += (t[j][i] != m[i][j]);
+  // device-resident Tensor chain (laser/tensor/*.nim twin): D = (A*B)^T * A, never leaving the GPU in between
+  {
+    const float a[2][3] = {{1, 2, 3}, {4, 5, 6}}, b[3][2] = {{7, 8}, {9, 10}, {11, 12}};
+    auto A = laser::newTensor<float>({2, 3}), B = laser::newTensor<float>({3, 2});
+    auto C = laser::newTensor<float>({2, 2}), D = laser::newTensor<float>({2, 3});
+    laser::copyFromRaw(A, &a[0][0], 6);
+    laser::copyFromRaw(B, &b[0][0], 6);
+    laser::gemm(1.0f, A, B, 0.0f, C);                       // [[58, 64], [139, 154]]  (gemm.nim:311-334)
+    laser::gemm(1.0f, C.transposed(), A, 0.0f, D);          // C^T * A through a strided view
+    const float want[6] = {58 * 1 + 139 * 4, 58 * 2 + 139 * 5, 58 * 3 + 139 * 6, 64 * 1 + 154 * 4, 64 * 2 + 154 * 5, 64 * 3 + 154 * 6};
+    auto d = D.to_host();
+    for (int i = 0; i < 6; i++) fails += (d[i] != want[i]);
+    auto ct = C.transposed().to_host();                     // deepCopy of a non-contiguous view
+    fails += (ct[0] != 58) + (ct[1] != 139) + (ct[2] != 64) + (ct[3] != 154);
+    fails += !C.is_C_contiguous() + C.transposed().is_C_contiguous() + (laser::newTensor<double>({4, 0, 2}).size() != 0);
+    laser::setZero(C);
+    for (float v : C.to_host()) fails += (v != 0.f);
+  }
   // error contract: misaligned pre-pack destination throws (reference: doAssert, gemm_prepacked.nim:125)
   bool threw = false;
   alignas(64) char buf[256];
