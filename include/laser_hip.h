@@ -66,6 +66,10 @@ int laser_hip_f32_config_count(void);
  * B-tile loader (no workspace traffic); 0 = explicit im2col into the workspace + batched GEMM, the
  * reference's literal structure (conv2d_im2col.nim:126-166).  Results are bit-identical. */
 int laser_hip_set_conv_implicit(int on);
+/* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet) */
+int laser_hip_last_f32_config(void);
+/* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */
+int laser_hip_set_transpose_variant(int variant);
 /* int32 GEMM strategy: 1 (default) = signed 8-bit limb decomposition on the int8 matrix cores
  * (bit-exact mod 2^32); 0 = the VALU kernel.  Results are bit-identical. */
 int laser_hip_set_i32_mfma(int on);

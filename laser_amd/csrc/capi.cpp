@@ -711,6 +711,11 @@ int laser_hip_set_i32_mfma(int on) {
   return LASER_HIP_OK;
 }
 // 1 = implicit GEMM (default), 0 = explicit im2col workspace + batched GEMM (comparison / A-B timing)
+int laser_hip_last_f32_config(void) { return g_last_f32_cfg; }
+int laser_hip_set_transpose_variant(int v) {  // tuning only (scripts/transpose_probe.py)
+  g_transpose_variant = v;
+  return LASER_HIP_OK;
+}
 int laser_hip_set_conv_implicit(int on) {
   g_ctx.conv_implicit = on != 0;
   return LASER_HIP_OK;

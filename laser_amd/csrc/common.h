@@ -71,6 +71,8 @@ hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream
 size_t gemm_i32_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
 
+extern int g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used
+extern int g_transpose_variant;  // tuning knob, 0 = production form
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,
                                     int elem_size, hipStream_t s);
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,

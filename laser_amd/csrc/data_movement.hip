@@ -14,47 +14,59 @@ namespace laser_hip {
 //   write: thread gathers V consecutive SOURCE ROWS of one source column from LDS (V scalar reads,
 //          row stride 65/66 words => conflict-free), packs them and stores 16 B of dst row c0+col
 // VEC16 needs NR, NC multiples of V and 16-B aligned bases; otherwise the scalar form below runs.
-template <typename T, bool VEC16>
+template <typename T, bool VEC16, int TR = 64, int TC = 64, bool NT = false>
 __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                                                 int64_t NR, int64_t NC, int64_t tiles_c,
                                                                 int64_t tiles_r) {
   constexpr int V = 16 / sizeof(T);        // elements per 16-byte access: 4 (b32) or 2 (b64)
-  constexpr int PAD = (sizeof(T) == 4) ? 1 : 1;
-  __shared__ T tile[64][64 + PAD];
+  __shared__ T tile[TR][TC + 1];           // TR source rows x TC source columns (+1: conflict-free column reads)
   const int64_t bid = blockIdx.x;
   const int64_t tc = bid % tiles_c, tr = (bid / tiles_c) % tiles_r, n = bid / (tiles_c * tiles_r);
   const T *s = src + n * NR * NC;
   T *d = dst + n * NR * NC;
-  const int64_t r0 = tr * 64, c0 = tc * 64;
+  const int64_t r0 = tr * TR, c0 = tc * TC;
   const int t = threadIdx.x;
   if constexpr (VEC16) {
     using VT = __attribute__((ext_vector_type(V))) T;
-    constexpr int TPR = 64 / V;            // threads per tile row: 16 or 32
-    constexpr int RPI = 256 / TPR;         // rows per iteration: 16 or 8
-    const int tx = t % TPR, ty = t / TPR;
+    {
+      constexpr int TPR = TC / V;          // threads per source row
+      constexpr int RPI = 256 / TPR;       // source rows per iteration
+      const int tx = t % TPR, ty = t / TPR;
 #pragma unroll
-    for (int i = 0; i < 64 / RPI; i++) {
-      const int row = ty + RPI * i;
-      const int64_t r = r0 + row, c = c0 + V * tx;
-      if (r < NR && c < NC) {
-        const VT q = *reinterpret_cast<const VT *>(s + r * NC + c);
+      for (int i = 0; i < TR / RPI; i++) {
+        const int row = ty + RPI * i;
+        const int64_t r = r0 + row, c = c0 + V * tx;
+        if (r < NR && c < NC) {
+          const VT *p = reinterpret_cast<const VT *>(s + r * NC + c);
+          const VT q = NT ? __builtin_nontemporal_load(p) : *p;
 #pragma unroll
-        for (int e = 0; e < V; e++) tile[row][V * tx + e] = q[e];
+          for (int e = 0; e < V; e++) tile[row][V * tx + e] = q[e];
+        }
       }
     }
     __syncthreads();
+    {
+      constexpr int TPW = TR / V;          // threads per destination row (= source column)
+      constexpr int CPI = 256 / TPW;       // destination rows per iteration
+      const int tx = t % TPW, ty = t / TPW;
 #pragma unroll
-    for (int i = 0; i < 64 / RPI; i++) {
-      const int col = ty + RPI * i;        // source column = destination row
-      const int64_t c = c0 + col, r = r0 + V * tx;
-      if (c < NC && r < NR) {
-        VT q;
+      for (int i = 0; i < TC / CPI; i++) {
+        const int col = ty + CPI * i;      // source column = destination row
+        const int64_t c = c0 + col, r = r0 + V * tx;
+        if (c < NC && r < NR) {
+          VT q;
 #pragma unroll
-        for (int e = 0; e < V; e++) q[e] = tile[V * tx + e][col];
-        *reinterpret_cast<VT *>(d + c * NR + r) = q;
+          for (int e = 0; e < V; e++) q[e] = tile[V * tx + e][col];
+          VT *p = reinterpret_cast<VT *>(d + c * NR + r);
+          if (NT)
+            __builtin_nontemporal_store(q, p);
+          else
+            *p = q;
+        }
       }
     }
   } else {
+    static_assert(VEC16 || (TR == 64 && TC == 64), "the scalar form is 64x64");
     const int tx = t % 64, ty = t / 64;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -70,19 +82,43 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ 
   }
 }
 
+int g_transpose_variant = 0;  // tuning knob (laser_hip_set_transpose_variant): tile shape / streaming hints
+
+template <typename T, int TR, int TC, bool NT>
+static hipError_t launch_transpose_v(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s) {
+  const int64_t tiles_r = (NR + TR - 1) / TR, tiles_c = (NC + TC - 1) / TC;
+  const int64_t blocks = N * tiles_r * tiles_c;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((transpose_batched_kernel<T, true, TR, TC, NT>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst,
+                     (const T *)src, NR, NC, tiles_c, tiles_r);
+  return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t launch_transpose_t(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s) {
+  constexpr int V = 16 / sizeof(T);
+  const bool vec = (NR % V == 0) && (NC % V == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  if (vec) {
+    // production form: 64 source rows x 128 source columns per workgroup (512-B read segments, 256-B write
+    // segments).  scripts/transpose_probe.py (profiles/r01/transpose_probe.log): vs the 64x64 tile
+    // +5 % at 16384x8192 and +19 % at 8192^2, equal elsewhere; it runs AT the rate of a plain D2D copy of
+    // the same bytes (4.7-5.4 TB/s at these sizes).  Streaming (nontemporal) hints cost 5-20 %; 128x128 loses occupancy.
+    switch (g_transpose_variant) {
+      case 1: return launch_transpose_v<T, 64, 64, false>(dst, src, N, NR, NC, s);
+      case 2: return launch_transpose_v<T, 64, 64, true>(dst, src, N, NR, NC, s);
+      case 3: return launch_transpose_v<T, 64, 128, true>(dst, src, N, NR, NC, s);
+      case 4: return launch_transpose_v<T, 128, 64, false>(dst, src, N, NR, NC, s);
+      case 5: return launch_transpose_v<T, 128, 128, false>(dst, src, N, NR, NC, s);
+      case 6: return launch_transpose_v<T, 32, 64, false>(dst, src, N, NR, NC, s);
+      case 7: return launch_transpose_v<T, 32, 128, false>(dst, src, N, NR, NC, s);
+      default: return launch_transpose_v<T, 64, 128, false>(dst, src, N, NR, NC, s);
+    }
+  }
   const int64_t tiles_r = (NR + 63) / 64, tiles_c = (NC + 63) / 64;
   const int64_t blocks = N * tiles_r * tiles_c;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  constexpr int V = 16 / sizeof(T);
-  const bool vec = (NR % V == 0) && (NC % V == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
-  if (vec)
-    hipLaunchKernelGGL((transpose_batched_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst, (const T *)src,
-                       NR, NC, tiles_c, tiles_r);
-  else
-    hipLaunchKernelGGL((transpose_batched_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst, (const T *)src,
-                       NR, NC, tiles_c, tiles_r);
+  hipLaunchKernelGGL((transpose_batched_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst, (const T *)src,
+                     NR, NC, tiles_c, tiles_r);
   return hipGetLastError();
 }
 

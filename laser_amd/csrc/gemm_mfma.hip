@@ -67,30 +67,42 @@ static int64_t tiles_of(const GemmArgs<E> &a, int bm, int bn) {
   return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (int64_t)a.batch;
 }
 
-// fp32: pick the configuration with the smallest predicted time.  Every CU works through
-// ceil(tiles / 256) tiles of bm x bn (how many of them are co-resident only changes the efficiency),
-// so  time ~ ceil(tiles / 256) * bm * bn / speed(cfg),  speed = TFLOP/s measured at 8192^3
-// (profiles/r01/sweep_f32_v8.json).  This is what makes 4100^3 take 128x128 tiles (5 rounds of 16384)
-// instead of 256x256 (2 rounds of 65536, the second 13 % full).
+// fp32: pick the configuration with the smallest predicted time.  Model (fitted on profiles/r01/
+// sweep_f32_v8.json at 8192^3 and sweep_f32_small_v1.json at 512..3072):
+//   a CU hosts up to R workgroups of a configuration (registers / LDS); with w of them resident it reaches
+//   the fraction occ[w-1]/occ[R-1] of that configuration's full-residency speed (a lone 4-wave workgroup is
+//   1 wave per SIMD and leaves most latency exposed);
+//   tiles = q full rounds of 256*R + a tail that puts w = ceil(rem / 256) workgroups on the busiest CU:
+//       time ~ (q*R + w / eff(w)) * bm*bn / speed(cfg)
+// This is what makes 4100^3 take 128x128 tiles instead of 256x256 (2 rounds, the second 13 % full) and
+// 1024^3..3072^3 take the 64x64 tiles (62 / 74 / 101 / 106 TFLOP/s measured vs 25 / 58 / 101 / 98 on 128x128).
 constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3, kCfgWideExact = 4;
 static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = false, bool conv = false) {
-  struct Cand { int cfg, bm, bn; double fast, laser, conv_fast, conv_laser; bool gen; };
-  // conv_*: in-round rates with the gathering B loader (C4, scripts/conv_cfg_probe.py): the gather costs the
-  // small tiles more (fewer MFMAs per gathered element)
+  struct Cand {
+    int cfg, bm, bn;
+    double fast, laser, conv_fast, conv_laser;  // TFLOP/s at full residency; conv_*: with the gathering B loader (C4)
+    int r_fast, r_laser;                        // co-resident workgroups per CU
+    double occ[4];                              // relative CU throughput with 1..4 workgroups resident
+    bool gen;
+  };
   static const Cand cands[] = {
-      {kCfgBig, 256, 256, 138.7, 0.0, 124.7, 0.0, false},
-      {kCfgWideExact, 256, 128, 133.1, 132.2, 117.0, 0.0, false},  // (laser-order gather would spill: cfg 1 instead)
-      {kCfgWide, 256, 128, 133.0, 130.5, 116.0, 117.0, false},
-      {kCfgMid, 128, 128, 134.1, 130.1, 116.0, 111.0, true},
-      {kCfgSmall, 64, 64, 120.8, 118.8, 95.0, 90.0, true},
+      {kCfgBig, 256, 256, 138.7, 0.0, 124.7, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},
+      {kCfgWideExact, 256, 128, 133.1, 132.2, 117.0, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},  // (laser-order gather would spill: cfg 1)
+      {kCfgWide, 256, 128, 133.0, 130.5, 116.0, 117.0, 2, 1, {0.95, 1.0, 1.0, 1.0}, false},
+      {kCfgMid, 128, 128, 134.1, 130.1, 116.0, 111.0, 3, 2, {0.755, 0.93, 1.0, 1.0}, true},
+      {kCfgSmall, 64, 64, 120.8, 118.8, 95.0, 90.0, 4, 3, {0.45, 0.75, 0.92, 1.0}, true},
   };
   int best = kCfgSmall;
   double best_t = 1e300;
   for (const Cand &c : cands) {
     const double speed = conv ? (exact ? c.conv_laser : c.conv_fast) : (exact ? c.laser : c.fast);
     if (speed <= 0.0 || (need_gen && !c.gen)) continue;
-    const double rounds = (double)((tiles_of(a, c.bm, c.bn) + 255) / 256);
-    const double t = rounds * c.bm * c.bn / speed;
+    const int R = exact ? c.r_laser : c.r_fast;
+    const int64_t tiles = tiles_of(a, c.bm, c.bn), slots = 256 * (int64_t)R;
+    const int64_t q = tiles / slots, rem = tiles % slots;
+    const int w = (int)((rem + 255) / 256);
+    const double tail = w ? (double)w * c.occ[R - 1] / c.occ[w - 1] : 0.0;
+    const double t = ((double)(q * R) + tail) * c.bm * c.bn / speed;
     if (t < best_t * 0.999) {  // ties go to the earlier (larger-tile) candidate: less L2 traffic
       best_t = t;
       best = c.cfg;
@@ -105,6 +117,8 @@ static int gen_cfg(const GemmArgs<float> &a, bool exact) { return heuristic_cfg(
 static int heuristic_cfg(const GemmArgs<double> &a, bool, bool = false) { return tiles_of(a, 128, 128) >= 128 ? 0 : 1; }
 static int fallback_exact_cfg(const GemmArgs<double> &) { return 0; }
 static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
+
+int g_last_f32_cfg = -1;  // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
 template <typename E>
 static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, int ncfg, int cfg, bool laser_order,
@@ -123,6 +137,7 @@ static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, i
   if (exact && !cfgs[cfg].exact) cfg = fallback_exact_cfg(a);
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo<E> &c = cfgs[cfg];
+    if (std::is_same<E, float>::value) g_last_f32_cfg = cfg;
     bool va, vb, ea, eb;
     const int am = pick_mode<E>(a.A, a.rsA, a.csA, a.bsA, a.Mext, a.Kext, c.bm, c.bk, &va, &ea);
     const int bm = pick_mode<E>(a.B, a.csB, a.rsB, a.bsB, a.Next, a.Kext, c.bn, c.bk, &vb, &eb);
@@ -157,6 +172,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   if (exact && cfg == kCfgWideExact) cfg = kCfgWide;
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo<float> &c = kCfgsF32[cfg];
+    g_last_f32_cfg = cfg;
     bool va, ea;
     pick_mode<float>(a.A, a.rsA, a.csA, a.bsA, a.M, a.K, c.bm, c.bk, &va, &ea);
     if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, LOAD_IM2COL, exact, s);

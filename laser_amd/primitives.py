@@ -94,6 +94,11 @@ def set_i32_mfma(on):
     _lib.check(_lib.lib().laser_hip_set_i32_mfma(1 if on else 0))
 
 
+def last_f32_config():
+    """Index into f32_configs() of the tile configuration the last fp32 GEMM / conv launch used."""
+    return _lib.lib().laser_hip_last_f32_config()
+
+
 def set_conv_implicit(on):
     """True (default): implicit-GEMM convolution; False: explicit im2col workspace + batched GEMM."""
     _lib.check(_lib.lib().laser_hip_set_conv_implicit(1 if on else 0))
