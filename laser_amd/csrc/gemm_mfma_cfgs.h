@@ -22,6 +22,9 @@
 // Rejected by measurement (kept out of the build): 2-stage forms of the same tiles (-3..-8 %),
 // 128x256x32 (= cfg 4 within noise), 4-wave 256x128 / 128x256 tiles at 1 wave/SIMD for laser-order
 // (-8 %), fragment prefetch distance 2 (no gain at 1 WG/CU, costs the 128-VGPR step of cfg 1 fast).
+// Mid sizes (1024^3..4100^3, scripts/heuristic_check.py with three extra configurations built in): a
+// 3-stage 64x64x32 (+4 % at 1024^3 only), 128x64x16 (never best) and an 8-wave 128x128x16 (+8 % at 2048^3
+// laser-order only, where the grid is exactly 256 tiles) -- not worth three more translation units.
 
 // float64 (v_mfma_f64_16x16x4_f64, 16x16 blocks, 4 k per instruction): the 8-wave 128x128 tile has the
 // same cadence as f32 cfg 0 (8 MFMAs of 64 cycles per k-step); laser-order needs acc 64 + run 64 regs.

@@ -353,14 +353,16 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   E *const smem = reinterpret_cast<E *>(smem_raw);
 
-  // -- which C tile: XCD-aware (bijective) remap, then a grouped raster (8 tile-rows per group) --
+  // -- which C tile: XCD-aware (bijective) remap, then a grouped raster (GROUP_M tile-rows per group) --
   const int nwg = gridDim.x;
   int wgid;
   {
     const int bid = blockIdx.x, xcd = bid % 8, loc = bid / 8, q = nwg / 8, r = nwg % 8;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  constexpr int GROUP_M = 8;
+  // the 32 workgroups resident on an XCD form a GROUP_M x (32/GROUP_M) patch of tiles; its HBM/MALL traffic per
+  // K-tile is ~ (GROUP_M*BM + 32/GROUP_M*BN), smallest for a square patch: 8x4 of square tiles, 4x8 of 256x128
+  constexpr int GROUP_M = (BM >= 2 * BN) ? 4 : 8;
   const int width = GROUP_M * g.tiles_n;
   const int group = wgid / width;
   const int first_m = group * GROUP_M;
