@@ -28,6 +28,9 @@
 //   (c) transposing scalar writes (4 consecutive k of one x per lane, ds_write_b32) are conflict-free
 // with no padding (see DESIGN.md section 3 for the bank arithmetic).
 #pragma once
+#ifndef LH_KQ
+#define LH_KQ 1  // k-quad LDS image for k-contiguous fp32 operands (0: the k-major image everywhere, for A/B runs)
+#endif
 #include <type_traits>
 
 #include "common.h"
@@ -130,7 +133,19 @@ __device__ __forceinline__ int swz(int k) {
 // wait for the HBM round trip in the middle of the MFMA stream (measured: 70 vs 120 TFLOP/s on the
 // ragged conv-shaped GEMM).  Rows/cols beyond M/N need no zeroing: they only feed outputs that are
 // never stored.
-template <typename E, int BX, int BK, int NT, int MODE>
+// k-quad LDS image (KQ_, fp32 operands with unit stride along k): row-major [x][BK] where every group of 8 k
+// is stored as (k0 k2 k4 k6 | k1 k3 k5 k7), i.e. two 16-byte chunks holding what MFMA half hi = 0 / 1 of a
+// lane consumes over FOUR consecutive k-steps -- one ds_read_b128 per fragment per 4 k-steps instead of four
+// ds_read_b32 (256 vs 128 B/clk and a quarter of the instructions, MI355X_MICROARCH.md LDS table), and the
+// 16-byte global piece (4 consecutive k) lands with two ds_write_b64 instead of four transposing
+// ds_write_b32.  Chunk index is XOR-swizzled with kq_swz(x) so the 16 lanes of every ds_read_b128 lane group
+// ({0-3,12-15,20-27}, ...: all 16 residues of x mod 16) cover the 64 banks exactly once.
+template <int BK>
+__device__ __forceinline__ int kq_swz(int x) {
+  return (x / (64 / BK)) % (BK / 4);
+}
+
+template <typename E, int BX, int BK, int NT, int MODE, bool KQ_ = false>
 struct TileLoader {
   using M_ = Mma<E>;
   using Vec = typename M_::Vec;
@@ -138,6 +153,24 @@ struct TileLoader {
   static constexpr int NV = (BX * BK / EPV) / NT;  // 16-B pieces per thread per tile
   static_assert(NV >= 1 && (BX * BK / EPV) % NT == 0, "tile must split evenly over the workgroup");
   static constexpr bool ALONG_K = (MODE == LOAD_VEC_K || MODE == LOAD_GEN_K || MODE == LOAD_VEC_K_EDGE);
+  static constexpr bool KQ = KQ_;
+  static_assert(!KQ || (std::is_same<E, float>::value && (BK == 16 || BK == 32) && BX % 16 == 0 &&
+                        (ALONG_K || MODE == LOAD_VEC_X || MODE == LOAD_VEC_X_EDGE)),
+                "k-quad image: fp32, 16-byte pieces along k or (transposed on the way into LDS) along x");
+  // piece -> (x quad, k) for pieces along x.  Plain: 32 consecutive lanes walk x (512 B of one k row).  k-quad:
+  // 4 lanes walk x (64 B) x 8 consecutive k, so that the transposing ds_write_b32 of a 32-lane group spreads
+  // over >= 16 banks (8 (chunk bit, word) positions of the 8 k x 4 swizzle classes of the 4 x quads: 2-way at
+  // most, which is free for ds_write_b32); 8 lanes x 4 k measured 4-way (256x256 fast 138.9 -> 133.6 TFLOP/s).
+  static __device__ __forceinline__ void piece_xk(int idx, int &xq, int &k) {
+    if constexpr (KQ) {
+      const int a = idx % 4, b = (idx / 4) % 8, c = idx / 32;
+      xq = (c % (BX / 16)) * 4 + a;
+      k = (c / (BX / 16)) * 8 + b;
+    } else {
+      xq = idx % (BX / EPV);
+      k = idx / (BX / EPV);
+    }
+  }
   static constexpr bool EDGE = (MODE == LOAD_VEC_X_EDGE || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || EDGE);
   static constexpr bool CONV = (MODE == LOAD_IM2COL);
@@ -222,7 +255,7 @@ struct TileLoader {
   // MFMAs instead of issuing the whole staging block at once (which idles the matrix pipe):
   //   piece i (one 16-B register vector):  WOPS LDS-write ops (EPV scalar writes when transposing,
   //   1 x ds_write_b128 otherwise), then 1 load op that refills the vector for the tile after next.
-  static constexpr int WOPS = ALONG_K ? EPV : 1;
+  static constexpr int WOPS = KQ ? (ALONG_K ? 2 : 4) : (ALONG_K ? EPV : 1);
   static constexpr int OPS_PER_PIECE = WOPS + 1;
   static constexpr int NOPS = NV * OPS_PER_PIECE;
 
@@ -235,14 +268,31 @@ struct TileLoader {
 
   __device__ __forceinline__ void store_op(E *__restrict__ lds, int t, int i, int c) const {
     const int idx = t + i * NT;
-    if constexpr (!ALONG_K) {
-      const int xq = idx % (BX / EPV), k = idx / (BX / EPV);
+    if constexpr (!ALONG_K && KQ) {
+      // transposing store of element c of an x-piece: row x = 4xq + c, k -> (chunk 2J + (k & 1), word (k % 8) / 2)
+      int xq, k;
+      piece_xk(idx, xq, k);
+      const int x = 4 * xq + c;
+      const int chunk = (2 * (k / 8) + (k & 1)) ^ kq_swz<BK>(x);
+      lds[x * BK + 4 * chunk + ((k % 8) >> 1)] = masked(i, c);
+    } else if constexpr (!ALONG_K) {
+      int xq, k;
+      piece_xk(idx, xq, k);
       Vec q = v[i];
       if constexpr (MASKED) {
 #pragma unroll
         for (int e = 0; e < EPV; e++) q[e] = masked(i, e);
       }
       *reinterpret_cast<Vec *>(lds + k * BX + ((EPV * xq) ^ swz<E, BK>(k))) = q;
+    } else if constexpr (KQ) {
+      // op c = MFMA half: elements (c, c + 2) of the piece are k = 4kq + c and 4kq + c + 2, adjacent in chunk 2J + c
+      const int kq = idx % (BK / 4), x = idx / (BK / 4);
+      const int chunk = (2 * (kq / 2) + c) ^ kq_swz<BK>(x);
+      typedef E E2 __attribute__((ext_vector_type(2)));
+      E2 w;
+      w[0] = masked(i, c);
+      w[1] = masked(i, c + 2);
+      *reinterpret_cast<E2 *>(lds + x * BK + 4 * chunk + 2 * (kq % 2)) = w;
     } else {
       const int kq = idx % (BK / EPV), x = idx / (BK / EPV);
       const int xs = x ^ swz<E, BK>(EPV * kq);
@@ -272,7 +322,8 @@ struct TileLoader {
       if (nr >= cg->ckH) { nr -= cg->ckH; nc++; }
       kq_[i] = nq; kr_[i] = nr; kc_[i] = nc;
     } else if constexpr (!ALONG_K) {
-      const int xq = idx % (BX / EPV), k = idx / (BX / EPV);
+      int xq, k;
+      piece_xk(idx, xq, k);
       if constexpr (VEC && !EDGE) {
         v[i] = *reinterpret_cast<const Vec *>(base + (k0 + k) * sk + EPV * xq);
       } else {
@@ -385,8 +436,19 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   const int64_t K = g.K;
   const int64_t mlim = g.M - m0, nlim = g.N - n0;
 
-  TileLoader<E, BM, BK, NT, AMODE> la;
-  TileLoader<E, BN, BK, NT, BMODE> lb;
+  // k-quad LDS image policy (sweep_f32_v10.json, 8192^3): both operands k-contiguous -> +1.3..2 % on every
+  // 3-stage configuration (ds_read_b128 fragments, ds_write_b64 staging).  An x-contiguous operand needs a
+  // transposing store (4 x ds_write_b32 per piece, 64-B global segments): it pays on the 128x128 tile
+  // (+2.5 %), is neutral on 256x128 and costs the 256x256 tile 4 % -- so it is taken for tiles up to 128x128
+  // only, and never for one operand alone (k-quad A + k-major B: 256x128 laser-order -1.5 %).
+  constexpr bool A_K = (AMODE == LOAD_VEC_K || AMODE == LOAD_GEN_K || AMODE == LOAD_VEC_K_EDGE);
+  constexpr bool B_K = (BMODE == LOAD_VEC_K || BMODE == LOAD_GEN_K || BMODE == LOAD_VEC_K_EDGE);
+  constexpr bool A_X = (AMODE == LOAD_VEC_X || AMODE == LOAD_VEC_X_EDGE), B_X = (BMODE == LOAD_VEC_X || BMODE == LOAD_VEC_X_EDGE);
+  constexpr bool KQ_ON = LH_KQ && STAGES == 3 && std::is_same<E, float>::value &&
+                         ((A_K && B_K) || (BM * BN <= 128 * 128 && (A_K || A_X) && (B_K || B_X)));
+  constexpr bool KQA = KQ_ON, KQB = KQ_ON;
+  TileLoader<E, BM, BK, NT, AMODE, KQA> la;
+  TileLoader<E, BN, BK, NT, BMODE, KQB> lb;
   lb.init_conv(g, n0, t, Bb);
 
   Acc acc[TM][TN];
@@ -442,21 +504,47 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   // (the 2-stage form has no cross-tile fragment prefetch: the first group's LDS latency is exposed once
   // per tile, so larger groups only lengthen the exposed part -- measured 127 -> 111 TFLOP/s at KGRP = 4)
   constexpr int KGRP_WANT = 8 / (TM * TN) < 1 ? 1 : 8 / (TM * TN);
-  constexpr int KGRP = STAGES == 2 ? 1 : (KGRP_WANT > NJ / 4 ? (NJ / 4 < 1 ? 1 : NJ / 4) : KGRP_WANT);
+  // a k-quad operand hands over 4 k-steps per ds_read_b128: groups of 4 k-steps
+  constexpr int KGRP = (KQA || KQB) ? 4 : STAGES == 2 ? 1 : (KGRP_WANT > NJ / 4 ? (NJ / 4 < 1 ? 1 : NJ / 4) : KGRP_WANT);
   constexpr int NG = NJ / KGRP;  // groups per K-tile
   static_assert(NJ % KGRP == 0 && NG % 2 == 0 && NG >= 2, "BK must give an even number of fragment groups");
   E fa[2][KGRP][TM], fb[2][KGRP][TN];
+  const int kqs = (KQA || KQB) ? kq_swz<(BK == 16 || BK == 32) ? BK : 16>(lo) : 0;  // block bases are multiples of 32: swizzle of x = of lo
   auto ldgroup = [&](const E *sA, const E *sB, int grp, int slot) __attribute__((always_inline)) {
+    if constexpr (KQA || KQB) {
+      typedef E E4 __attribute__((ext_vector_type(4)));
+      const int chunk = 4 * ((2 * grp + hi) ^ kqs);  // the 16 bytes of this lane's MFMA half for k-steps 4grp .. 4grp+3
+      if constexpr (KQA) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const E4 q = *reinterpret_cast<const E4 *>(sA + (wm0 + MB * i + lo) * BK + chunk);
+#pragma unroll
+          for (int u = 0; u < 4; u++) fa[slot][u][i] = q[u];
+        }
+      }
+      if constexpr (KQB) {
+#pragma unroll
+        for (int n = 0; n < TN; n++) {
+          const E4 q = *reinterpret_cast<const E4 *>(sB + (wn0 + MB * n + lo) * BK + chunk);
+#pragma unroll
+          for (int u = 0; u < 4; u++) fb[slot][u][n] = q[u];
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < KGRP; u++) {
       const int j = grp * KGRP + u;
       const int k = KS * j + hi;
       // all k of one step share a swizzle when the step fits one 16-byte piece (fp32); otherwise it is per lane
       const int s = (KS <= M_::EPV) ? swz<E, BK>(KS * j) : swz<E, BK>(k);
+      if constexpr (!KQA) {
 #pragma unroll
-      for (int i = 0; i < TM; i++) fa[slot][u][i] = sA[k * BM + wm0 + MB * i + (lo ^ s)];
+        for (int i = 0; i < TM; i++) fa[slot][u][i] = sA[k * BM + wm0 + MB * i + (lo ^ s)];
+      }
+      if constexpr (!KQB) {
 #pragma unroll
-      for (int n = 0; n < TN; n++) fb[slot][u][n] = sB[k * BN + wn0 + MB * n + (lo ^ s)];
+        for (int n = 0; n < TN; n++) fb[slot][u][n] = sB[k * BN + wn0 + MB * n + (lo ^ s)];
+      }
     }
   };
   auto mfma_group = [&](int slot) __attribute__((always_inline)) {
