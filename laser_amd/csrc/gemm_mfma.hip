@@ -86,10 +86,10 @@ static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = f
     bool gen;
   };
   static const Cand cands[] = {
-      {kCfgBig, 256, 256, 138.7, 0.0, 124.7, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},
-      {kCfgWideExact, 256, 128, 133.1, 132.2, 117.0, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},  // (laser-order gather would spill: cfg 1)
-      {kCfgWide, 256, 128, 133.0, 130.5, 116.0, 117.0, 2, 1, {0.95, 1.0, 1.0, 1.0}, false},
-      {kCfgMid, 128, 128, 136.6, 130.6, 116.0, 111.0, 3, 2, {0.755, 0.93, 1.0, 1.0}, true},
+      {kCfgBig, 256, 256, 141.5, 0.0, 124.7, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},
+      {kCfgWideExact, 256, 128, 136.1, 133.8, 117.0, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},  // (laser-order gather would spill: cfg 1)
+      {kCfgWide, 256, 128, 134.0, 131.1, 116.0, 117.0, 2, 1, {0.95, 1.0, 1.0, 1.0}, false},
+      {kCfgMid, 128, 128, 136.4, 130.0, 116.0, 111.0, 3, 2, {0.755, 0.93, 1.0, 1.0}, true},
       {kCfgSmall, 64, 64, 120.8, 118.8, 95.0, 90.0, 4, 3, {0.45, 0.75, 0.92, 1.0}, true},
   };
   int best = kCfgSmall;

@@ -157,16 +157,23 @@ struct TileLoader {
   static_assert(!KQ || (std::is_same<E, float>::value && (BK == 16 || BK == 32) && BX % 16 == 0 &&
                         (ALONG_K || MODE == LOAD_VEC_X || MODE == LOAD_VEC_X_EDGE)),
                 "k-quad image: fp32, 16-byte pieces along k or (transposed on the way into LDS) along x");
-  // piece -> (x quad, k) for pieces along x.  Plain: 32 consecutive lanes walk x (512 B of one k row).  k-quad:
-  // 4 lanes walk x (64 B) x 8 consecutive k, so that the transposing ds_write_b32 of a 32-lane group spreads
-  // over >= 16 banks (8 (chunk bit, word) positions of the 8 k x 4 swizzle classes of the 4 x quads: 2-way at
-  // most, which is free for ds_write_b32); 8 lanes x 4 k measured 4-way (256x256 fast 138.9 -> 133.6 TFLOP/s).
-  static __device__ __forceinline__ void piece_xk(int idx, int &xq, int &k) {
-    if constexpr (KQ) {
-      const int a = idx % 4, b = (idx / 4) % 8, c = idx / 32;
+  // x-contiguous operand into the k-quad image: pieces are handled in PAIRS (rows k and k + 2 of the same x
+  // quad, held by one thread), because k and k + 2 are neighbours in a chunk -> element e of both pieces is
+  // one ds_write_b64 into row x = 4xq + e (4 writes per pair, where single pieces needed 8 ds_write_b32).
+  static constexpr bool PAIRS = KQ && !ALONG_K;
+  static constexpr int GROUPN = PAIRS ? 2 : 1;  // pieces per op group
+  static_assert(!PAIRS || NV % 2 == 0, "pair mode needs an even number of pieces per thread");
+  // piece i -> (x quad, k) for pieces along x.  Plain: 32 consecutive lanes walk x (512 B of one k row).
+  // Pair mode: lane bits (a:2 = x quad, p:1, h:1, rest) -> k = 8J + 4h + p + 2*(i & 1); the 16 contiguous lanes
+  // of a ds_write_b64 group then hit 4 swizzle classes x 2 chunk parities x 2 word pairs = 16 banks x 2 (free).
+  static __device__ __forceinline__ void piece_xk(int t, int i, int &xq, int &k) {
+    if constexpr (PAIRS) {
+      const int idx = t + (i / 2) * NT;
+      const int a = idx % 4, p = (idx / 4) % 2, h = (idx / 8) % 2, c = idx / 16;
       xq = (c % (BX / 16)) * 4 + a;
-      k = (c / (BX / 16)) * 8 + b;
+      k = 8 * (c / (BX / 16)) + 4 * h + p + 2 * (i & 1);
     } else {
+      const int idx = t + i * NT;
       xq = idx % (BX / EPV);
       k = idx / (BX / EPV);
     }
@@ -246,18 +253,19 @@ struct TileLoader {
 
   __device__ __forceinline__ void store(E *__restrict__ lds, int t) const {
 #pragma unroll
-    for (int i = 0; i < NV; i++)
+    for (int gi = 0; gi < NV / GROUPN; gi++)
 #pragma unroll
-      for (int c = 0; c < WOPS; c++) store_op(lds, t, i, c);
+      for (int c = 0; c < WOPS; c++) store_op(lds, t, gi, c);
   }
 
   // The same work cut into single-instruction "ops" so the main loop can slot one op between two
   // MFMAs instead of issuing the whole staging block at once (which idles the matrix pipe):
   //   piece i (one 16-B register vector):  WOPS LDS-write ops (EPV scalar writes when transposing,
   //   1 x ds_write_b128 otherwise), then 1 load op that refills the vector for the tile after next.
-  static constexpr int WOPS = KQ ? (ALONG_K ? 2 : 4) : (ALONG_K ? EPV : 1);
-  static constexpr int OPS_PER_PIECE = WOPS + 1;
-  static constexpr int NOPS = NV * OPS_PER_PIECE;
+  //   (pair mode: an op group is 2 pieces: 4 x ds_write_b64, then the 2 loads.)
+  static constexpr int WOPS = KQ ? (ALONG_K ? 2 : 4) : (ALONG_K ? EPV : 1);  // LDS-write ops per group
+  static constexpr int OPS_PER_GROUP = WOPS + GROUPN;
+  static constexpr int NOPS = (NV / GROUPN) * OPS_PER_GROUP;
 
   __device__ __forceinline__ E masked(int i, int c) const {
     if constexpr (MASKED)
@@ -266,18 +274,24 @@ struct TileLoader {
       return v[i][c];
   }
 
-  __device__ __forceinline__ void store_op(E *__restrict__ lds, int t, int i, int c) const {
+  // op c of group gi (a group is one piece, or a pair of pieces in pair mode)
+  __device__ __forceinline__ void store_op(E *__restrict__ lds, int t, int gi, int c) const {
+    const int i = gi;  // (single-piece groups)
     const int idx = t + i * NT;
-    if constexpr (!ALONG_K && KQ) {
-      // transposing store of element c of an x-piece: row x = 4xq + c, k -> (chunk 2J + (k & 1), word (k % 8) / 2)
+    if constexpr (PAIRS) {
+      // element c of pieces 2gi (k) and 2gi + 1 (k + 2): adjacent words of chunk 2J + (k & 1) in row x = 4xq + c
       int xq, k;
-      piece_xk(idx, xq, k);
+      piece_xk(t, 2 * gi, xq, k);
       const int x = 4 * xq + c;
       const int chunk = (2 * (k / 8) + (k & 1)) ^ kq_swz<BK>(x);
-      lds[x * BK + 4 * chunk + ((k % 8) >> 1)] = masked(i, c);
+      typedef E E2 __attribute__((ext_vector_type(2)));
+      E2 w;
+      w[0] = masked(2 * gi, c);
+      w[1] = masked(2 * gi + 1, c);
+      *reinterpret_cast<E2 *>(lds + x * BK + 4 * chunk + ((k % 8) >> 1)) = w;
     } else if constexpr (!ALONG_K) {
       int xq, k;
-      piece_xk(idx, xq, k);
+      piece_xk(t, i, xq, k);
       Vec q = v[i];
       if constexpr (MASKED) {
 #pragma unroll
@@ -323,7 +337,7 @@ struct TileLoader {
       kq_[i] = nq; kr_[i] = nr; kc_[i] = nc;
     } else if constexpr (!ALONG_K) {
       int xq, k;
-      piece_xk(idx, xq, k);
+      piece_xk(t, i, xq, k);
       if constexpr (VEC && !EDGE) {
         v[i] = *reinterpret_cast<const Vec *>(base + (k0 + k) * sk + EPV * xq);
       } else {
@@ -436,16 +450,18 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   const int64_t K = g.K;
   const int64_t mlim = g.M - m0, nlim = g.N - n0;
 
-  // k-quad LDS image policy (sweep_f32_v10.json, 8192^3): both operands k-contiguous -> +1.3..2 % on every
-  // 3-stage configuration (ds_read_b128 fragments, ds_write_b64 staging).  An x-contiguous operand needs a
-  // transposing store (4 x ds_write_b32 per piece, 64-B global segments): it pays on the 128x128 tile
-  // (+2.5 %), is neutral on 256x128 and costs the 256x256 tile 4 % -- so it is taken for tiles up to 128x128
-  // only, and never for one operand alone (k-quad A + k-major B: 256x128 laser-order -1.5 %).
+  // k-quad LDS image policy (sweep_f32_v10/v11.json, 8192^3): taken whenever BOTH operands can use it --
+  // k-contiguous pieces (2 x ds_write_b64), or x-contiguous pieces in pair mode (an even number of pieces per
+  // thread: 4 x ds_write_b64 per pair).  B transposed: +1.3..2 %; plain row-major A and B: 256x256 fast
+  // 138.9 -> 141.5, 256x128x32 fast 133.1 -> 136.1 / laser-order 132.8 -> 133.8, 128x128 fast 134 -> 136.4.
+  // Never for one operand alone (k-quad A + k-major B: 256x128 laser-order -1.5 %); single transposed pieces
+  // (8 x ds_write_b32 per 2 pieces) cost the 256x256 tile 4 %, hence pairs.
   constexpr bool A_K = (AMODE == LOAD_VEC_K || AMODE == LOAD_GEN_K || AMODE == LOAD_VEC_K_EDGE);
   constexpr bool B_K = (BMODE == LOAD_VEC_K || BMODE == LOAD_GEN_K || BMODE == LOAD_VEC_K_EDGE);
   constexpr bool A_X = (AMODE == LOAD_VEC_X || AMODE == LOAD_VEC_X_EDGE), B_X = (BMODE == LOAD_VEC_X || BMODE == LOAD_VEC_X_EDGE);
+  constexpr bool A_XP = A_X && ((BM * BK / 4) / NT) % 2 == 0, B_XP = B_X && ((BN * BK / 4) / NT) % 2 == 0;  // pair mode possible
   constexpr bool KQ_ON = LH_KQ && STAGES == 3 && std::is_same<E, float>::value &&
-                         ((A_K && B_K) || (BM * BN <= 128 * 128 && (A_K || A_X) && (B_K || B_X)));
+                         (A_K || A_XP) && (B_K || B_XP);
   constexpr bool KQA = KQ_ON, KQB = KQ_ON;
   TileLoader<E, BM, BK, NT, AMODE, KQA> la;
   TileLoader<E, BN, BK, NT, BMODE, KQB> lb;
@@ -662,20 +678,20 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       auto staging_op = [&](int o) __attribute__((always_inline)) {
         constexpr int NA = decltype(la)::NOPS, NB = decltype(lb)::NOPS;
         if (o < NA) {
-          constexpr int P = decltype(la)::OPS_PER_PIECE;
-          const int i = o / P, c = o % P;
-          if (c < P - 1) {
-            if (!DBG || !(g.dbg & 2)) la.store_op(wA, t, i, c);
+          constexpr int P = decltype(la)::OPS_PER_GROUP, W = decltype(la)::WOPS, GN = decltype(la)::GROUPN;
+          const int gi = o / P, c = o % P;
+          if (c < W) {
+            if (!DBG || !(g.dbg & 2)) la.store_op(wA, t, gi, c);
           } else if (more2 && (!DBG || !(g.dbg & 1))) {
-            la.load_op(Ab, g.rsA, g.csA, k2, mlim, K, t, i);
+            la.load_op(Ab, g.rsA, g.csA, k2, mlim, K, t, gi * GN + (c - W));
           }
         } else if (o < NA + NB) {
-          constexpr int P = decltype(lb)::OPS_PER_PIECE;
-          const int i = (o - NA) / P, c = (o - NA) % P;
-          if (c < P - 1) {
-            if (!DBG || !(g.dbg & 2)) lb.store_op(wB, t, i, c);
+          constexpr int P = decltype(lb)::OPS_PER_GROUP, W = decltype(lb)::WOPS, GN = decltype(lb)::GROUPN;
+          const int gi = (o - NA) / P, c = (o - NA) % P;
+          if (c < W) {
+            if (!DBG || !(g.dbg & 2)) lb.store_op(wB, t, gi, c);
           } else if (more2 && (!DBG || !(g.dbg & 1))) {
-            lb.load_op(Bb, g.csB, g.rsB, k2, nlim, K, t, i, &g);
+            lb.load_op(Bb, g.csB, g.rsB, k2, nlim, K, t, gi * GN + (c - W), &g);
           }
         }
       };
