@@ -43,17 +43,19 @@ static int pick_mode(const E *p, int64_t sx, int64_t sk, int64_t bs, int64_t X, 
   constexpr int64_t EPV = 16 / sizeof(E);
   const bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (bs % EPV == 0);
   const bool full = (X % bx == 0) && (K % bk == 0);
+  // *edge: 16-byte loads through a bounds-checked buffer descriptor -- unit stride along one direction, a
+  // positive leading dimension, element alignment only, and the whole operand under 4 GB (32-bit offsets)
+  const auto small = [&](int64_t ld) { return ld > 0 && ((X - 1) + (K - 1)) >= 0 &&
+                                              (double)ld * (double)((sk == 1 ? X : K)) * sizeof(E) < 4.0e9; };
   *vec = *edge = false;
   if (sk == 1) {
-    const bool ok = aligned && (sx % EPV == 0);
-    *vec = ok && full;
-    *edge = ok && (K % EPV == 0) && K >= EPV && X >= 1;
+    *vec = aligned && (sx % EPV == 0) && full;
+    *edge = small(sx) && sx >= K;
     return LOAD_VEC_K;
   }
   if (sx == 1) {
-    const bool ok = aligned && (sk % EPV == 0);
-    *vec = ok && full;
-    *edge = ok && (X % EPV == 0) && X >= EPV;
+    *vec = aligned && (sk % EPV == 0) && full;
+    *edge = small(sk) && sk >= X;
     return LOAD_VEC_X;
   }
   return iabs64(sk) <= iabs64(sx) ? LOAD_VEC_K : LOAD_VEC_X;

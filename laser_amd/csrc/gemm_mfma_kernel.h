@@ -205,6 +205,26 @@ struct TileLoader {
   int32_t kc_[CONV ? NV : 1], kr_[CONV ? NV : 1], kq_[CONV ? NV : 1];
   __amdgpu_buffer_rsrc_t rsrc;  // this image as a bounds-checked buffer (wave-uniform, lives in SGPRs)
 
+  // EDGE modes read the operand panel through a raw buffer descriptor: 16-byte loads need only element
+  // alignment (the probe scripts/probes/buffer_oob.hip: dword-aligned b128 loads work, each dword is range
+  // checked on its own at the top end), and whatever lies beyond the operand's last element reads as 0
+  // instead of faulting -- so ragged extents, odd leading dimensions and unaligned bases all take the vector
+  // path, with no address clamping.  `span`: elements from `panel` to the operand's last valid element + 1.
+  __device__ __forceinline__ void init_buf(const E *panel, int64_t span) {
+    if constexpr (EDGE) {
+      const uint64_t b = reinterpret_cast<uint64_t>(panel);
+      const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+      const int64_t bytes = span * (int64_t)sizeof(E);
+      const int nrec = __builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0xffffffffll ? 0xffffffffll : (bytes < 0 ? 0 : bytes)));
+      rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bu), 0, nrec, 0x00020000);
+    }
+  }
+  __device__ __forceinline__ Vec buf_load(uint32_t byte_off) const {
+    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(Vec, q);
+  }
+
   __device__ __forceinline__ void init_conv(const GemmArgs<E> &g, int64_t n0, int t, const E *image) {
     if constexpr (CONV) {
       // readfirstlane: tell the compiler the descriptor is uniform (else every load becomes a waterfall loop)
@@ -345,9 +365,9 @@ struct TileLoader {
         const bool kin = kk < klim;
         const int64_t kc_ = kin ? kk : klim - 1;
         if constexpr (EDGE) {
-          // xlim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in x
-          const int64_t xc = (EPV * xq < xlim) ? EPV * xq : xlim - EPV;
-          v[i] = *reinterpret_cast<const Vec *>(base + kc_ * sk + xc);
+          // x beyond xlim only feeds outputs that are never stored; k beyond klim is masked below (and lies
+          // past the operand's end anyway).  32-bit offsets: the dispatcher keeps the panel under 4 GB.
+          v[i] = buf_load((uint32_t)((kk * sk + EPV * xq) * (int64_t)sizeof(E)));
         } else {
           const E *p = base + kc_ * sk;
 #pragma unroll
@@ -366,10 +386,10 @@ struct TileLoader {
         const int64_t kk = k0 + EPV * kq;
         const int64_t xc = (x < xlim) ? x : xlim - 1;
         if constexpr (EDGE) {
-          // klim % EPV == 0 (checked by the dispatcher): a piece is entirely inside or outside in k
-          const bool kin = kk < klim;
-          v[i] = *reinterpret_cast<const Vec *>(base + xc * sx + (kin ? kk : klim - EPV));
-          msk[i] = kin ? ALL : 0u;
+          // the k tail must read as zero (the next elements in memory belong to the next row): per-element mask
+          v[i] = buf_load((uint32_t)(((int64_t)x * sx + kk) * (int64_t)sizeof(E)));
+          const int64_t left = klim - kk;
+          msk[i] = left >= EPV ? ALL : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
         } else {
           const E *p = base + xc * sx;
           uint32_t m = 0;
@@ -465,6 +485,9 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   constexpr bool KQA = KQ_ON, KQB = KQ_ON;
   TileLoader<E, BM, BK, NT, AMODE, KQA> la;
   TileLoader<E, BN, BK, NT, BMODE, KQB> lb;
+  // (EDGE modes) operand panels as bounds-checked buffers: span = offset of the panel's last valid element + 1
+  la.init_buf(Ab, (g.Mext - m0 - 1) * g.rsA + (g.Kext - 1) * g.csA + 1);
+  lb.init_buf(Bb, (g.Next - n0 - 1) * g.csB + (g.Kext - 1) * g.rsB + 1);
   lb.init_conv(g, n0, t, Bb);
 
   Acc acc[TM][TN];
