@@ -155,7 +155,7 @@ struct TileLoader {
   static constexpr bool ALONG_K = (MODE == LOAD_VEC_K || MODE == LOAD_GEN_K || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool KQ = KQ_;
   static_assert(!KQ || (std::is_same<E, float>::value && (BK == 16 || BK == 32) && BX % 16 == 0 &&
-                        (ALONG_K || MODE == LOAD_VEC_X || MODE == LOAD_VEC_X_EDGE)),
+                        (ALONG_K || MODE == LOAD_VEC_X || MODE == LOAD_VEC_X_EDGE || MODE == LOAD_IM2COL)),
                 "k-quad image: fp32, 16-byte pieces along k or (transposed on the way into LDS) along x");
   // x-contiguous operand into the k-quad image: pieces are handled in PAIRS (rows k and k + 2 of the same x
   // quad, held by one thread), because k and k + 2 are neighbours in a chunk -> element e of both pieces is
@@ -236,8 +236,8 @@ struct TileLoader {
       rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bu), 0, bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NV; i++) {
-        const int idx = t + i * NT;
-        const int xq = idx % (BX / 4), k = idx / (BX / 4);
+        int xq, k;
+        piece_xk(t, i, xq, k);
         kc_[i] = k / khw;
         const int rem = k - kc_[i] * khw;
         kr_[i] = rem / g.ckW;
@@ -478,7 +478,9 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   // (8 x ds_write_b32 per 2 pieces) cost the 256x256 tile 4 %, hence pairs.
   constexpr bool A_K = (AMODE == LOAD_VEC_K || AMODE == LOAD_GEN_K || AMODE == LOAD_VEC_K_EDGE);
   constexpr bool B_K = (BMODE == LOAD_VEC_K || BMODE == LOAD_GEN_K || BMODE == LOAD_VEC_K_EDGE);
-  constexpr bool A_X = (AMODE == LOAD_VEC_X || AMODE == LOAD_VEC_X_EDGE), B_X = (BMODE == LOAD_VEC_X || BMODE == LOAD_VEC_X_EDGE);
+  constexpr bool A_X = (AMODE == LOAD_VEC_X || AMODE == LOAD_VEC_X_EDGE);
+  // (the im2col gather could feed the image in pair mode as well: measured neutral on C4, left on the k-major image)
+  constexpr bool B_X = (BMODE == LOAD_VEC_X || BMODE == LOAD_VEC_X_EDGE);
   constexpr bool A_XP = A_X && ((BM * BK / 4) / NT) % 2 == 0, B_XP = B_X && ((BN * BK / 4) / NT) % 2 == 0;  // pair mode possible
   constexpr bool KQ_ON = LH_KQ && STAGES == 3 && std::is_same<E, float>::value &&
                          (A_K || A_XP) && (B_K || B_XP);

@@ -584,3 +584,32 @@ def test_fused_epilogue_conv_vs_oracle(la, oracle):
         la.conv2d_im2col(dout, oshape, torch.from_numpy(x).cuda(), ishape, torch.from_numpy(w).cuda(), kshape, pad, st,
                          None, bias=torch.from_numpy(b).cuda(), activation="relu")
         assert np.array_equal(dout.cpu().numpy(), want), (ishape, kshape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32])
+def test_unaligned_bases_and_odd_leading_dimensions(la, oracle, dtype):
+    """Operands carved out of larger buffers at odd element offsets (4-byte / 8-byte aligned only), odd leading
+    dimensions, ragged extents: the bounds-checked 16-byte loaders must give the oracle's bits, on the device path
+    (pointers are passed through unchanged there)."""
+    import torch
+    rng = np.random.default_rng(21)
+    for (M, N, K, offA, offB, ldA, ldB) in [(130, 70, 517, 1, 3, 517 + 3, 70 + 1), (257, 129, 1031, 3, 1, 1031, 129 + 6),
+                                            (64, 64, 64, 1, 1, 65, 67), (33, 260, 45, 5, 7, 45, 261)]:
+        bufA = rand(rng, (offA + M * ldA + 8,), dtype, full_range=True)
+        bufB = rand(rng, (offB + K * ldB + 8,), dtype, full_range=True)
+        A = np.lib.stride_tricks.as_strided(bufA[offA:], (M, K), (ldA * bufA.itemsize, bufA.itemsize))
+        B = np.lib.stride_tricks.as_strided(bufB[offB:], (K, N), (ldB * bufB.itemsize, bufB.itemsize))
+        want = oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B), isa=oracle.fused_isa(dtype))
+        dA, dB = torch.from_numpy(bufA).cuda(), torch.from_numpy(bufB).cuda()
+        vA = torch.as_strided(dA, (M, K), (ldA, 1), offA)
+        vB = torch.as_strided(dB, (K, N), (ldB, 1), offB)
+        got = la.matmul(vA, vB).cpu().numpy()
+        assert np.array_equal(got, want), (M, N, K, dtype)
+        # B handed over transposed (k-contiguous), same odd offsets
+        bufBt = rand(rng, (offB + N * (K + 1) + 8,), dtype, full_range=True)
+        Bt = np.lib.stride_tricks.as_strided(bufBt[offB:], (N, K), ((K + 1) * bufBt.itemsize, bufBt.itemsize))
+        want_t = oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(Bt.T), isa=oracle.fused_isa(dtype))
+        vBt = torch.as_strided(torch.from_numpy(bufBt).cuda(), (N, K), (K + 1, 1), offB)
+        got_t = la.matmul(vA, vBt.t()).cpu().numpy()
+        assert np.array_equal(got_t, want_t), (M, N, K, dtype, "nt")
