@@ -140,10 +140,20 @@ __device__ __forceinline__ int swz(int k) {
 // 16-byte global piece (4 consecutive k) lands with two ds_write_b64 instead of four transposing
 // ds_write_b32.  Chunk index is XOR-swizzled with kq_swz(x) so the 16 lanes of every ds_read_b128 lane group
 // ({0-3,12-15,20-27}, ...: all 16 residues of x mod 16) cover the 64 banks exactly once.
+// (the XOR with bit log2(R/2) of x, R = 64/BK rows per 64-bank line, keeps the read property -- lanes of equal
+// x mod R still see distinct values -- and sends rows x and x + R/2, which share a 16-lane ds_write_b64 group
+// when k-contiguous pieces are stored, to opposite chunk parities: SQ_LDS_BANK_CONFLICT 256 -> 0 cycles per tile)
 template <int BK>
 __device__ __forceinline__ int kq_swz(int x) {
-  return (x / (64 / BK)) % (BK / 4);
+  constexpr int R = 64 / BK;
+  return ((x / R) ^ ((x / (R / 2)) & 1)) % (BK / 4);
 }
+// physical row of x: neighbouring rows swap inside every second x quad, so that the pair-mode store of an
+// x-contiguous operand (all 16 lanes of a ds_write_b64 group write rows of ONE parity) still reaches both
+// halves of the 32 write banks.  scripts/kq_bank_check.py replays the three access patterns against the bank
+// rules of MI355X_MICROARCH.md: 0 conflicts for BK = 16 and 32 (without the swap: 4 cycles per pair store at BK = 16,
+// which SQ_LDS_BANK_CONFLICT confirmed: 128 cycles per 256x256x16 tile).
+__device__ __forceinline__ int kq_row(int x) { return x ^ ((x >> 2) & 1); }
 
 template <typename E, int BX, int BK, int NT, int MODE, bool KQ_ = false>
 struct TileLoader {
@@ -308,7 +318,7 @@ struct TileLoader {
       E2 w;
       w[0] = masked(2 * gi, c);
       w[1] = masked(2 * gi + 1, c);
-      *reinterpret_cast<E2 *>(lds + x * BK + 4 * chunk + ((k % 8) >> 1)) = w;
+      *reinterpret_cast<E2 *>(lds + kq_row(x) * BK + 4 * chunk + ((k % 8) >> 1)) = w;
     } else if constexpr (!ALONG_K) {
       int xq, k;
       piece_xk(t, i, xq, k);
@@ -326,7 +336,7 @@ struct TileLoader {
       E2 w;
       w[0] = masked(i, c);
       w[1] = masked(i, c + 2);
-      *reinterpret_cast<E2 *>(lds + x * BK + 4 * chunk + 2 * (kq % 2)) = w;
+      *reinterpret_cast<E2 *>(lds + kq_row(x) * BK + 4 * chunk + 2 * (kq % 2)) = w;
     } else {
       const int kq = idx % (BK / EPV), x = idx / (BK / EPV);
       const int xs = x ^ swz<E, BK>(EPV * kq);
@@ -551,6 +561,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   static_assert(NJ % KGRP == 0 && NG % 2 == 0 && NG >= 2, "BK must give an even number of fragment groups");
   E fa[2][KGRP][TM], fb[2][KGRP][TN];
   const int kqs = (KQA || KQB) ? kq_swz<(BK == 16 || BK == 32) ? BK : 16>(lo) : 0;  // block bases are multiples of 32: swizzle of x = of lo
+  const int lor = kq_row(lo);                                                       // likewise the physical row
   auto ldgroup = [&](const E *sA, const E *sB, int grp, int slot) __attribute__((always_inline)) {
     if constexpr (KQA || KQB) {
       typedef E E4 __attribute__((ext_vector_type(4)));
@@ -558,7 +569,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       if constexpr (KQA) {
 #pragma unroll
         for (int i = 0; i < TM; i++) {
-          const E4 q = *reinterpret_cast<const E4 *>(sA + (wm0 + MB * i + lo) * BK + chunk);
+          const E4 q = *reinterpret_cast<const E4 *>(sA + (wm0 + MB * i + lor) * BK + chunk);
 #pragma unroll
           for (int u = 0; u < 4; u++) fa[slot][u][i] = q[u];
         }
@@ -566,7 +577,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       if constexpr (KQB) {
 #pragma unroll
         for (int n = 0; n < TN; n++) {
-          const E4 q = *reinterpret_cast<const E4 *>(sB + (wn0 + MB * n + lo) * BK + chunk);
+          const E4 q = *reinterpret_cast<const E4 *>(sB + (wn0 + MB * n + lor) * BK + chunk);
 #pragma unroll
           for (int u = 0; u < 4; u++) fb[slot][u][n] = q[u];
         }
