@@ -25,6 +25,7 @@
 // Mid sizes (1024^3..4100^3, scripts/heuristic_check.py with three extra configurations built in): a
 // 3-stage 64x64x32 (+4 % at 1024^3 only), 128x64x16 (never best) and an 8-wave 128x128x16 (+8 % at 2048^3
 // laser-order only, where the grid is exactly 256 tiles) -- not worth three more translation units.
+// cfg 3 as a 3-stage ring with the k-quad image: +3 % at 1024^3, -4 % at 2048^3, -3 % at 8192^3: stays 2-stage.
 
 // float64 (v_mfma_f64_16x16x4_f64, 16x16 blocks, 4 k per instruction): the 8-wave 128x128 tile has the
 // same cadence as f32 cfg 0 (8 MFMAs of 64 cycles per k-step); laser-order needs acc 64 + run 64 regs.
