@@ -12,6 +12,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <thread>
@@ -48,7 +49,7 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 struct Context {
-  bool ready = false;
+  std::atomic<bool> ready{false};  // read lock-free on every call, written once under g_mu
   int device = -1;
   std::string arch;
   int float_mode = LASER_HIP_F32_LASER_ORDER;
