@@ -66,6 +66,9 @@ int laser_hip_f32_config_count(void);
  * B-tile loader (no workspace traffic); 0 = explicit im2col into the workspace + batched GEMM, the
  * reference's literal structure (conv2d_im2col.nim:126-166).  Results are bit-identical. */
 int laser_hip_set_conv_implicit(int on);
+/* 1 (default): the implicit conv reads its B operand from an LDS-resident input patch when that fits;
+ * 0: always the per-element gather (A/B timing) */
+int laser_hip_set_conv_patch(int on);
 /* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet) */
 int laser_hip_last_f32_config(void);
 /* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */

@@ -713,6 +713,10 @@ int laser_hip_set_i32_mfma(int on) {
 }
 // 1 = implicit GEMM (default), 0 = explicit im2col workspace + batched GEMM (comparison / A-B timing)
 int laser_hip_last_f32_config(void) { return g_last_f32_cfg; }
+int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from an LDS input patch (1) or gathered (0)
+  g_conv_patch = on != 0;
+  return LASER_HIP_OK;
+}
 int laser_hip_set_transpose_variant(int v) {  // tuning only (scripts/transpose_probe.py)
   g_transpose_variant = v;
   return LASER_HIP_OK;

@@ -35,6 +35,7 @@ struct GemmArgs {
   const T *bias;
   int64_t rsBias, csBias, bsBias;
   int32_t act;  // laser_hip_activation
+  int32_t cRp, cPWs, cCHM;  // LOAD_CONV_PATCH: patch rows per channel, patch row stride (floats), channels per K-tile
   int32_t cdc, cdr, cdq;  // per-K-tile advance of the implicit-GEMM loader's (channel, kernel row, kernel col): BK = cdc*kH*kW + cdr*kW + cdq
 };
 
@@ -53,6 +54,8 @@ enum LoadMode : int {
   // B operand only: im2col fused into the loader (implicit-GEMM convolution), lanes run along
   // the output pixel index j = oh*oW + ow, predicated gathers from the NCHW image, zeros for padding
   LOAD_IM2COL = 6,
+  LOAD_CONV_PATCH = 7,  // implicit-GEMM conv, B from an LDS-resident input patch: the tile's input rows are loaded once
+                        // (contiguous 16-B pieces) and the kH*kW shifted views are gathered by the fragment reads
 };
 
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
@@ -71,6 +74,7 @@ hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream
 size_t gemm_i32_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
 
+extern int g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
 extern int g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used
 extern int g_transpose_variant;  // tuning knob, 0 = production form
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,

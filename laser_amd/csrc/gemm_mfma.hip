@@ -91,8 +91,8 @@ static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = f
       {kCfgBig, 256, 256, 141.5, 0.0, 124.7, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},
       {kCfgWideExact, 256, 128, 136.1, 133.8, 117.0, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},  // (laser-order gather would spill: cfg 1)
       {kCfgWide, 256, 128, 134.0, 131.1, 116.0, 117.0, 2, 1, {0.95, 1.0, 1.0, 1.0}, false},
-      {kCfgMid, 128, 128, 136.4, 130.0, 116.0, 111.0, 3, 2, {0.755, 0.93, 1.0, 1.0}, true},
-      {kCfgSmall, 64, 64, 120.8, 118.8, 95.0, 90.0, 4, 3, {0.45, 0.75, 0.92, 1.0}, true},
+      {kCfgMid, 128, 128, 136.4, 130.0, 119.0, 114.0, 3, 2, {0.755, 0.93, 1.0, 1.0}, true},
+      {kCfgSmall, 64, 64, 120.8, 118.8, 99.0, 98.0, 4, 3, {0.45, 0.75, 0.92, 1.0}, true},
   };
   int best = kCfgSmall;
   double best_t = 1e300;
@@ -120,6 +120,7 @@ static int heuristic_cfg(const GemmArgs<double> &a, bool, bool = false) { return
 static int fallback_exact_cfg(const GemmArgs<double> &) { return 0; }
 static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 
+int g_conv_patch = 1;     // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
 int g_last_f32_cfg = -1;  // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
 template <typename E>
@@ -177,8 +178,13 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     g_last_f32_cfg = cfg;
     bool va, ea;
     pick_mode<float>(a.A, a.rsA, a.csA, a.bsA, a.M, a.K, c.bm, c.bk, &va, &ea);
-    if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, LOAD_IM2COL, exact, s);
-    if (a.csA == 1 && ea) return c.fn(a, LOAD_VEC_K_EDGE, LOAD_IM2COL, exact, s);
+    // B through an LDS-resident input patch when it fits the B region of a stage (else the per-element gather)
+    const int khw = a.ckH * a.ckW;
+    const int64_t patch = (int64_t)((c.bk + khw - 2) / khw + 1) * (((c.bn - 1) / a.coW + 1) * a.csH + a.ckH) * (a.cW + 8);
+    const bool patch_ok = g_conv_patch && a.cW % 4 == 0 && a.cpW <= 4 && patch <= (int64_t)c.bk * c.bn - c.bk - 4;
+    const int bmode = patch_ok ? LOAD_CONV_PATCH : LOAD_IM2COL;
+    if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, bmode, exact, s);
+    if (a.csA == 1 && ea) return c.fn(a, LOAD_VEC_K_EDGE, bmode, exact, s);
     if (c.gen) return c.fn(a, LOAD_GEN_K, LOAD_IM2COL, exact, s);
     cfg = heuristic_cfg(a, exact, true, true);
   }

@@ -191,8 +191,9 @@ struct TileLoader {
   static constexpr bool EDGE = (MODE == LOAD_VEC_X_EDGE || MODE == LOAD_VEC_K_EDGE);
   static constexpr bool VEC = (MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || EDGE);
   static constexpr bool CONV = (MODE == LOAD_IM2COL);
-  static constexpr bool MASKED = !(MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || CONV);  // CONV zeroes through the buffer's bounds check
-  static_assert(!CONV || std::is_same<E, float>::value, "the implicit-GEMM loader is fp32 only");
+  static constexpr bool PATCH = (MODE == LOAD_CONV_PATCH);
+  static constexpr bool MASKED = !(MODE == LOAD_VEC_X || MODE == LOAD_VEC_K || CONV || PATCH);  // CONV / PATCH zero through the buffer's bounds check
+  static_assert(!(CONV || PATCH) || std::is_same<E, float>::value, "the implicit-GEMM loaders are fp32 only");
   static_assert(ALONG_K || SwzShift<E, BK>::value >= (EPV == 4 ? 2 : 1), "16-byte pieces along x must stay contiguous");
   Vec v[NV];
   uint32_t msk[MASKED ? NV : 1];  // bit c: element c of piece i is real data (else it reads as zero)
@@ -233,6 +234,71 @@ struct TileLoader {
   __device__ __forceinline__ Vec buf_load(uint32_t byte_off) const {
     const auto q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
     return __builtin_bit_cast(Vec, q);
+  }
+
+  // LOAD_CONV_PATCH: the B "tile" of the implicit-GEMM convolution is an input PATCH -- for each of the cCHM
+  // channels a K-tile can touch, the cRp input rows the tile's output pixels reach, stored as rows of cPWs = W + 8
+  // floats (input column j at index 4 + j; everything else, the zero padding, stays 0 from the one-time clear).
+  // The patch rows are contiguous in HBM: each thread owns up to NV 16-byte pieces (channel slot, row, column
+  // quad), decoded once; per K-tile only the first channel c0 moves (running state, no division).  Rows outside
+  // the image and channels beyond C get offset 0xfffffffc: the buffer's bounds check returns zeros.
+  // The kH*kW shifted views of the patch are produced by the fragment reads (kernel, ldgroup), not here.
+  int32_t pg_off[PATCH ? NV : 1];   // element offset of the piece inside channel 0 of the image, or -1: never valid
+  int32_t pg_ch[PATCH ? NV : 1];    // channel slot of the piece
+  int32_t pl_dst[PATCH ? NV : 1];   // LDS destination (floats from the patch base), 16-byte aligned
+  int32_t p_c0, p_rem;              // first channel of the tile being loaded, and (tile's first k) mod kH*kW
+  // offset table: for every k of a tile, where its (channel slot, kernel row, kernel column) view starts in the
+  // patch -- written next to the patch by the store pass (thread t owns k = t % BK, a running state like the
+  // gather loader's), read by the fragment gathers: no index arithmetic in the MFMA loop.
+  int32_t tw_c0, tw_rem, tk_c, tk_r, tk_q;
+  static constexpr int TBL = BX * BK - BK;  // table = the last BK words of the B region of a stage (4 dummy words before it)
+  __device__ __forceinline__ void init_patch(const GemmArgs<E> &g, int64_t n0, int t, const E *image) {
+    if constexpr (PATCH) {
+      const uint64_t b = reinterpret_cast<uint64_t>(image);
+      const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+      const int khw = g.ckH * g.ckW, C = (int)(g.K / khw);
+      const int bytes = __builtin_amdgcn_readfirstlane(C * g.cH * g.cW * 4);
+      rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bu), 0, bytes, 0x00020000);
+      const int row0 = (int)(n0 / g.coW) * g.csH - g.cpH;  // first input row of the patch
+      const int w4 = g.cW / 4, per_ch = g.cRp * w4, total = g.cCHM * per_ch;
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int p = t + i * NT;
+        const int ch = p / per_ch, rr = (p - ch * per_ch) / w4, j = p - ch * per_ch - rr * w4;
+        const int row = row0 + rr;
+        const bool ok = p < total && (unsigned)row < (unsigned)g.cH;
+        pg_off[i] = ok ? row * g.cW + 4 * j : -1;
+        pg_ch[i] = ch;
+        pl_dst[i] = p < total ? ch * (g.cRp * g.cPWs) + rr * g.cPWs + 4 + 4 * j : TBL - 4;  // spare pieces: a dummy slot (no predicated store)
+      }
+      p_c0 = 0;
+      p_rem = 0;
+      tw_c0 = 0;
+      tw_rem = 0;
+      const int kl = t % BK;
+      tk_c = kl / khw;
+      tk_r = (kl - tk_c * khw) / g.ckW;
+      tk_q = kl - tk_c * khw - tk_r * g.ckW;
+    }
+  }
+  // store pass of one tile (called once per tile, tiles in order): this thread's k offset into the patch
+  __device__ __forceinline__ void store_table(E *__restrict__ lds, int t, const GemmArgs<E> *cg) {
+    if constexpr (PATCH) {
+      const int khw = cg->ckH * cg->ckW;
+      const int dc = min(max(tk_c - tw_c0, 0), cg->cCHM - 1);  // k beyond K stays inside the patch (A is zero there)
+      const int koff = dc * (cg->cRp * cg->cPWs) + tk_r * cg->cPWs + tk_q;
+      const int kl = t % BK;
+      reinterpret_cast<int32_t *>(lds)[TBL + (kl & 1) * (BK / 2) + (kl >> 1)] = koff;  // [hi][k-step]; same value from every owner of kl
+      int nq = tk_q + cg->cdq, nr = tk_r + cg->cdr, nc = tk_c + cg->cdc;
+      if (nq >= cg->ckW) { nq -= cg->ckW; nr++; }
+      if (nr >= cg->ckH) { nr -= cg->ckH; nc++; }
+      tk_q = nq; tk_r = nr; tk_c = nc;
+      const int r = tw_rem + cg->cdr * cg->ckW + cg->cdq;
+      const int w = (r >= khw) ? 1 : 0;
+      tw_rem = r - w * khw;
+      tw_c0 = tw_c0 + cg->cdc + w;
+    }
   }
 
   __device__ __forceinline__ void init_conv(const GemmArgs<E> &g, int64_t n0, int t, const E *image) {
@@ -308,6 +374,10 @@ struct TileLoader {
   __device__ __forceinline__ void store_op(E *__restrict__ lds, int t, int gi, int c) const {
     const int i = gi;  // (single-piece groups)
     const int idx = t + i * NT;
+    if constexpr (PATCH) {
+      *reinterpret_cast<Vec *>(lds + pl_dst[i]) = v[i];
+      return;
+    }
     if constexpr (PAIRS) {
       // element c of pieces 2gi (k) and 2gi + 1 (k + 2): adjacent words of chunk 2J + (k & 1) in row x = 4xq + c
       int xq, k;
@@ -349,6 +419,25 @@ struct TileLoader {
                                           const GemmArgs<E> *cg = nullptr) {
     const int idx = t + i * NT;
     constexpr uint32_t ALL = (1u << EPV) - 1u;
+    if constexpr (PATCH) {
+      // one 16-byte piece of the patch for the K-tile whose first channel is p_c0 (pieces are called in order
+      // i = 0 .. NV-1 once per tile: the last one advances the tile state by BK)
+      const int khw = cg->ckH * cg->ckW, C = (int)(klim / khw);
+      const int c = p_c0 + pg_ch[i];
+      // invalid piece or channel beyond C -> offset -1 (sign bits OR-ed in: a select here becomes an exec-masked
+      // region with a branch in the middle of the steady-state loop)
+      const int off = (c * (cg->cH * cg->cW) + pg_off[i]) | (pg_off[i] >> 31) | ((C - 1 - c) >> 31);
+      v[i] = buf_load((uint32_t)(off << 2));
+      if (i == NV - 1) {
+        // BK = cdc*kH*kW + cdr*kW + cdq (launcher); arithmetic carry, not a branch (uniform ifs become s_cbranch
+        // and cut the steady-state loop into basic blocks)
+        const int r = p_rem + cg->cdr * cg->ckW + cg->cdq;
+        const int w = (r >= khw) ? 1 : 0;
+        p_rem = r - w * khw;
+        p_c0 = p_c0 + cg->cdc + w;
+      }
+      return;
+    }
     if constexpr (CONV) {
       // gather the 4 pixels of this piece for k = (kc_, kr_, kq_), then advance k by BK
       const int c = kc_[i], kr = kr_[i], kq = kq_[i];
@@ -474,7 +563,8 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 
   const E *Ab = g.A + bz * g.bsA + m0 * g.rsA;  // x = row of A, k along csA
   // x = col of B, k along rsB; for the implicit-GEMM conv the "matrix" is the NCHW image itself
-  constexpr bool BCONV = (BMODE == LOAD_IM2COL);
+  constexpr bool BPATCH = (BMODE == LOAD_CONV_PATCH);
+  constexpr bool BCONV = (BMODE == LOAD_IM2COL) || BPATCH;
   const E *Bb = BCONV ? g.B + bz * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
   E *Cb = g.C + bz * g.bsC;
   const int64_t K = g.K;
@@ -501,6 +591,28 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   la.init_buf(Ab, (g.Mext - m0 - 1) * g.rsA + (g.Kext - 1) * g.csA + 1);
   lb.init_buf(Bb, (g.Next - n0 - 1) * g.csB + (g.Kext - 1) * g.rsB + 1);
   lb.init_conv(g, n0, t, Bb);
+  lb.init_patch(g, n0, t, Bb);
+  // LOAD_CONV_PATCH: per B block of this wave, where the lane's output pixel sits in the patch (float index of its
+  // window origin in channel slot 0), and the running k position of the fragment reads (uniform)
+  int pbase[BPATCH ? TN : 1];
+  if constexpr (BPATCH) {
+    const int row0 = (int)(n0 / g.coW) * g.csH - g.cpH;
+#pragma unroll
+    for (int n = 0; n < TN; n++) {
+      int64_t x = n0 + wn0 + MB * n + lo;
+      if (x >= g.N) x = g.N - 1;  // columns beyond N feed outputs that are never stored
+      const int oh = (int)(x / g.coW), ow = (int)(x - (int64_t)oh * g.coW);
+      pbase[n] = (oh * g.csH - g.cpH - row0) * g.cPWs + ow * g.csW - g.cpW + 4;
+    }
+    // one-time clear of the B regions of all stages: padding columns / never-loaded cells must read as zero
+    for (int o = t * 4; o < BK * BN; o += NT * 4)
+#pragma unroll
+      for (int st_ = 0; st_ < STAGES; st_++) {
+        typedef E E4z __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<E4z *>(smem + st_ * STAGE + BK * BM + o) = E4z{};
+      }
+    __syncthreads();
+  }
 
   Acc acc[TM][TN];
 #pragma unroll
@@ -593,7 +705,12 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 #pragma unroll
         for (int i = 0; i < TM; i++) fa[slot][u][i] = sA[k * BM + wm0 + MB * i + (lo ^ s)];
       }
-      if constexpr (!KQB) {
+      if constexpr (BPATCH) {
+        // this lane's k of step j -> its view's start in the patch, from the tile's offset table ([hi][k-step])
+        const int ko = reinterpret_cast<const int32_t *>(sB)[decltype(lb)::TBL + hi * (BK / 2) + j];
+#pragma unroll
+        for (int n = 0; n < TN; n++) fb[slot][u][n] = sB[pbase[BPATCH ? n : 0] + ko];
+      } else if constexpr (!KQB) {
 #pragma unroll
         for (int n = 0; n < TN; n++) fb[slot][u][n] = sB[k * BN + wn0 + MB * n + (lo ^ s)];
       }
@@ -630,6 +747,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t, &g);
     la.store(smem, t);
     lb.store(smem + BK * BM, t);
+    lb.store_table(smem + BK * BM, t, &g);
     __syncthreads();
     auto k_tile2 = [&](auto MORE_, int kt) __attribute__((always_inline)) {
       constexpr bool more = decltype(MORE_)::value;
@@ -654,6 +772,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
       E *dA = smem + ((kt + 1) & 1) * STAGE;
       la.store(dA, t);
       lb.store(dA + BK * BM, t);
+      lb.store_table(dA + BK * BM, t, &g);
       __syncthreads();
     };
     // slice folds live outside the steady-state loop (a test inside it is if-converted into
@@ -683,6 +802,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t, &g);
     la.store(smem, t);
     lb.store(smem + BK * BM, t);
+    lb.store_table(smem + BK * BM, t, &g);
     if (nkt > 1) {
       la.load(Ab, g.rsA, g.csA, BK, mlim, K, t);
       lb.load(Bb, g.csB, g.rsB, BK, nlim, K, t, &g);
@@ -726,6 +846,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
           const int gi = (o - NA) / P, c = (o - NA) % P;
           if (c < W) {
             if (!DBG || !(g.dbg & 2)) lb.store_op(wB, t, gi, c);
+            if (gi == 0 && c == 0) lb.store_table(wB, t, &g);
           } else if (more2 && (!DBG || !(g.dbg & 1))) {
             lb.load_op(Bb, g.csB, g.rsB, k2, nlim, K, t, gi * GN + (c - W), &g);
           }
@@ -856,6 +977,16 @@ hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
   GemmArgs<E> g = a;
   g.tiles_m = (int)((a.M + BM - 1) / BM);
   g.tiles_n = (int)((a.N + BN - 1) / BN);
+  if constexpr (BMODE == LOAD_CONV_PATCH) {
+    const int khw = a.ckH * a.ckW;
+    g.cdc = BK / khw;
+    g.cRp = ((BN - 1) / a.coW + 1) * a.csH + a.ckH;  // input rows reached by BN consecutive output pixels (upper bound)
+    g.cPWs = a.cW + 8;
+    g.cCHM = (BK + khw - 2) / khw + 1;
+    g.cdr = (BK % khw) / a.ckW;
+    g.cdq = (BK % khw) % a.ckW;
+    if ((int64_t)g.cCHM * g.cRp * g.cPWs > (int64_t)BK * BN - BK - 4 || a.cW % 4 != 0) return hipErrorInvalidValue;
+  }
   if constexpr (BMODE == LOAD_IM2COL) {
     const int khw = a.ckH * a.ckW;
     g.cdc = BK / khw;
@@ -887,6 +1018,8 @@ hipError_t launch_cfg_mode(const GemmArgs<E> &a, int amode, int bmode, hipStream
     if constexpr (std::is_same<E, float>::value) {
       LH_CASE(LOAD_VEC_K, LOAD_IM2COL)  // implicit-GEMM conv: filter [C_out][C_in*kH*kW] is k-contiguous
       LH_CASE(LOAD_VEC_K_EDGE, LOAD_IM2COL)
+      LH_CASE(LOAD_VEC_K, LOAD_CONV_PATCH)
+      LH_CASE(LOAD_VEC_K_EDGE, LOAD_CONV_PATCH)
     }
   }
   if constexpr (WITH_GEN) {

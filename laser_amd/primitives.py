@@ -94,6 +94,11 @@ def set_i32_mfma(on):
     _lib.check(_lib.lib().laser_hip_set_i32_mfma(1 if on else 0))
 
 
+def set_conv_patch(on):
+    """True (default): the implicit conv's B operand comes from an LDS-resident input patch where it fits."""
+    _lib.check(_lib.lib().laser_hip_set_conv_patch(1 if on else 0))
+
+
 def last_f32_config():
     """Index into f32_configs() of the tile configuration the last fp32 GEMM / conv launch used."""
     return _lib.lib().laser_hip_last_f32_config()
