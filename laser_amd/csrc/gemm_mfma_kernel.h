@@ -584,6 +584,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   constexpr bool A_XP = A_X && ((BM * BK / 4) / NT) % 2 == 0, B_XP = B_X && ((BN * BK / 4) / NT) % 2 == 0;  // pair mode possible
   constexpr bool KQ_ON = LH_KQ && STAGES == 3 && std::is_same<E, float>::value &&
                          (A_K || A_XP) && (B_K || B_XP);
+  // (a k-quad filter operand next to the patch-gathered B of the conv: measured 1 % slower on C4 -- both or none)
   constexpr bool KQA = KQ_ON, KQB = KQ_ON;
   TileLoader<E, BM, BK, NT, AMODE, KQA> la;
   TileLoader<E, BN, BK, NT, BMODE, KQB> lb;
