@@ -348,7 +348,14 @@ def test_im2col_and_conv_vs_oracle(la, oracle):
                                       ((1, 6, 19, 23), (9, 6, 8, 8), (4, 2), (1, 3)),        # 8x8: largest gathered kernel
                                       ((1, 2, 21, 22), (5, 2, 9, 9), (4, 4), (1, 1)),        # 9x9: explicit-workspace fallback
                                       ((2, 5, 12, 12), (6, 5, 3, 3), (3, 3), (1, 1)),        # padding wider than the kernel reach
-                                      ((1, 40, 15, 15), (33, 40, 5, 5), (2, 2), (1, 1))]:    # "same" 5x5, K = 1000: two slices
+                                      ((1, 40, 15, 15), (33, 40, 5, 5), (2, 2), (1, 1)),     # "same" 5x5, K = 1000: two slices
+                                      # W % 4 == 0: the LDS-resident input-patch form of the B operand
+                                      ((2, 8, 16, 24), (6, 8, 3, 3), (1, 1), (2, 2)),        # stride 2
+                                      ((1, 6, 12, 16), (4, 6, 5, 5), (2, 2), (1, 1)),        # 5x5 "same"
+                                      ((2, 3, 32, 32), (16, 3, 7, 7), (3, 3), (2, 2)),       # 7x7 / 2 stem
+                                      ((1, 70, 9, 8), (130, 70, 3, 3), (1, 1), (1, 1)),      # K = 630: two slices, tiny image
+                                      ((3, 16, 24, 20), (20, 16, 3, 2), (0, 1), (1, 2)),     # asymmetric kernel / pad / stride
+                                      ((1, 4, 8, 260), (5, 4, 3, 3), (1, 1), (1, 1))]:       # one tile spans < 1 image row
 
         x = rng.uniform(0, 1, ishape).astype(np.float32)   # conv2d_bench.nim:124-125
         w = rng.uniform(0, 1, kshape).astype(np.float32)
