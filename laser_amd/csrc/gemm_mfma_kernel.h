@@ -12,7 +12,7 @@
 //   (gemm_packing.nim:24-94)                       (= Laser's A~[k][ii] / B~[k][jj] layout) whatever
 //                                                  the source strides; ragged edges zero-filled like
 //                                                  the reference's zero-padded panels
-//   pc loop over kc=512 slices, C += per slice     K loop inside the workgroup, double-buffered LDS;
+//   pc loop over kc=512 slices, C += per slice     K loop inside the workgroup, 3-stage LDS ring;
 //   (gemm.nim:150-158)                             in LASER_ORDER mode the MFMA accumulator restarts
 //                                                  every kc and slices are folded into a running C
 //                                                  in ascending order -> bit-identical to Laser
@@ -27,6 +27,12 @@
 //   (b) 16-B vector writes along x (ds_write_b128, unit-stride-in-x operands)      are conflict-free,
 //   (c) transposing scalar writes (4 consecutive k of one x per lane, ds_write_b32) are conflict-free
 // with no padding (see DESIGN.md section 3 for the bank arithmetic).
+// fp32 operands of the 3-stage configurations use the k-quad image instead when both can (kq_swz / kq_row below):
+// [x][BK] rows whose 16-byte chunks hold what one MFMA half consumes over four k-steps -> ds_read_b128 fragments.
+//
+// Operand loaders (TileLoader): plain 16-byte vector loads; EDGE = the same through a bounds-checked buffer
+// descriptor (any alignment, ragged extents); GEN = scalar, any strides; LOAD_IM2COL / LOAD_CONV_PATCH = the
+// implicit-GEMM convolution's B operand (per-element gather / LDS-resident input patch).
 #pragma once
 #ifndef LH_KQ
 #define LH_KQ 1  // k-quad LDS image for k-contiguous fp32 operands (0: the k-major image everywhere, for A/B runs)
