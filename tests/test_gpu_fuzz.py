@@ -16,3 +16,11 @@ def test_fuzz_gemm_matches_oracle(seed):
                        capture_output=True, text=True, timeout=900)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-15:])
     assert r.returncode == 0 and "0 failures" in r.stdout, tail
+
+
+@pytest.mark.gpu
+def test_fuzz_conv_matches_oracle():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_conv.py"), "80", "5"],
+                       capture_output=True, text=True, timeout=900)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-15:])
+    assert r.returncode == 0 and "0 failures" in r.stdout, tail
