@@ -13,18 +13,24 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ncfg = len(laser_amd.f32_configs())
 fails = 0
 for it in range(cases):
-    dtype = np.float32 if rng.random() < 0.75 else np.float64
+    dtype = [np.float32, np.float64, np.int32, np.int64][int(rng.choice(4, p=[0.55, 0.15, 0.2, 0.1]))]
+    is_int = np.dtype(dtype).kind == "i"
     big = rng.random() < 0.25
     M, N, K = (int(rng.integers(1, 1400 if big else 300)) for _ in range(3))
     if rng.random() < 0.3: K = int(rng.integers(500, 1300))      # several kc slices
     ta, tb = rng.random() < 0.4, rng.random() < 0.4
     offA, offB, offC = (int(rng.integers(0, 4)) for _ in range(3))
     padA, padB, padC = (int(rng.integers(0, 6)) * int(rng.random() < 0.6) for _ in range(3))
-    alpha, beta = (dtype(rng.choice([1.0, 1.0, 0.0, -0.5, 2.0])) for _ in range(2))
+    alpha, beta = (dtype(rng.choice([1, 1, 0, -3, 2] if is_int else [1.0, 1.0, 0.0, -0.5, 2.0])) for _ in range(2))
+    def draw(n):
+        if is_int:
+            info = np.iinfo(dtype)
+            return rng.integers(info.min, info.max, n, dtype=dtype)   # full range: wrap-around arithmetic
+        return rng.uniform(-0.5, 0.5, n).astype(dtype)
     def make(rows, cols, trans, off, pad):
         r, c = (cols, rows) if trans else (rows, cols)
         ld = c + pad
-        buf = rng.uniform(-0.5, 0.5, off + r * ld + 8).astype(dtype)
+        buf = draw(off + r * ld + 8)
         view = np.lib.stride_tricks.as_strided(buf[off:], (r, c), (ld * buf.itemsize, buf.itemsize))
         dbuf = torch.from_numpy(buf).cuda()
         dview = torch.as_strided(dbuf, (r, c), (ld, 1), off)
@@ -32,7 +38,7 @@ for it in range(cases):
     A, dA = make(M, K, ta, offA, padA)
     B, dB = make(K, N, tb, offB, padB)
     ldc = N + padC
-    bufC = rng.uniform(-0.5, 0.5, offC + M * ldc + 8).astype(dtype)
+    bufC = draw(offC + M * ldc + 8)
     C0 = np.lib.stride_tricks.as_strided(bufC[offC:], (M, N), (ldc * bufC.itemsize, bufC.itemsize))
     dbufC = torch.from_numpy(bufC).cuda()
     dC = torch.as_strided(dbufC, (M, N), (ldc, 1), offC)
@@ -44,14 +50,14 @@ for it in range(cases):
     laser_amd.matmul(dA, dB, alpha, beta, dC)
     got = dC.cpu().numpy()
     untouched = np.array_equal(dbufC.cpu().numpy()[:offC], bufC[:offC])
-    if mode == 0:
+    if mode == 0 or is_int:
         ok = np.array_equal(got, want)
     else:
         ok = oracle.mean_relative_error(got, want) <= 1e-5
     if not (ok and untouched):
         fails += 1
         print("FAIL", dict(it=it, dtype=dtype.__name__, M=M, N=N, K=K, ta=ta, tb=tb, offs=(offA, offB, offC), pads=(padA, padB, padC),
-                           alpha=float(alpha), beta=float(beta), cfg=cfg, mode=mode, maxabs=float(np.max(np.abs(got - want)))), flush=True)
+                           alpha=float(alpha), beta=float(beta), cfg=cfg, mode=mode, nbad=int(np.sum(got != want))), flush=True)
 laser_amd.set_f32_config(-1); laser_amd.set_float_mode(0)
 print(f"fuzz: {cases} cases, {fails} failures")
 sys.exit(1 if fails else 0)
