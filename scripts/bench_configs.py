@@ -19,6 +19,12 @@ def ev_time(fn, iters=5, warm=3, inner=4):
     """median / min of `iters` timings, each over `inner` back-to-back launches (keeps the clocks up)."""
     for _ in range(warm):
         fn()
+    # after host-side work the GPU has dropped to an idle power state: keep launching for ~20 ms before timing
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.02:
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(iters):
