@@ -24,6 +24,14 @@ def _default_local_gemm(A, B, out):
     primitives.matmul(A, B, 1, 0, out)   # device-resident entry point; raises without the HIP library/GPU
 
 
+# While a panel multiplies, RCCL's all-gather of the previous panel is running on the same GPU: its persistent
+# workgroups (one per channel) hold some CUs for the whole transfer, and a 256x128-tile workgroup (144 KiB LDS,
+# 2 x 234 VGPRs per SIMD) cannot share a CU with them.  A panel of 512 such tiles is exactly two rounds on 256 CUs but
+# three on the ~224-240 left over; 128x128 tiles (2048 per panel, 2 per CU) degrade gracefully instead (about -3 % when
+# all CUs are free).  Multi-GPU runs therefore pin that configuration for the local products unless told otherwise.
+SHARDED_TILE_CONFIG = "128x128x16_w2x2_s3"
+
+
 @dataclass
 class PanelPlan:
     M: int
@@ -62,7 +70,7 @@ class ShardedGemm:
     """C[M,N] = A[M,K] . B[K,N] with A's row panels dealt over the ranks of `group`."""
 
     def __init__(self, M, N, K, dtype=torch.float32, device=None, group=None, panels_per_rank=4,
-                 local_gemm=None):
+                 local_gemm=None, tile_config=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -70,6 +78,10 @@ class ShardedGemm:
         self.dtype, self.device = dtype, device
         self.plan = make_plan(M, self.world, panels_per_rank)
         self.local_gemm = local_gemm or _default_local_gemm
+        # fp32 tile configuration for the local products: an index into laser_amd.f32_configs(), or None =
+        # SHARDED_TILE_CONFIG when more than one rank shares the work (single rank: the library heuristic)
+        self.tile_config = tile_config
+        self._pin_tiles = local_gemm is None and dtype == torch.float32
 
     # -- data placement helpers ------------------------------------------------------------------
     def local_rows(self):
@@ -100,6 +112,27 @@ class ShardedGemm:
         On return (after the stream/work sync at the end) every rank holds all of C."""
         p = self.plan
         works = []
+        cfg = self.tile_config
+        if self._pin_tiles and cfg is None and self.world > 1:
+            from . import primitives
+            names = primitives.f32_configs()
+            cfg = names.index(SHARDED_TILE_CONFIG) if SHARDED_TILE_CONFIG in names else None
+        if self._pin_tiles and cfg is not None:
+            from . import primitives
+            primitives.set_f32_config(cfg)
+        try:
+            works = self._run_panels(A_local, B, C_full)
+        finally:
+            if self._pin_tiles and cfg is not None:
+                from . import primitives
+                primitives.set_f32_config(-1)
+        for w in works:
+            w.wait()
+        return C_full[: self.M]
+
+    def _run_panels(self, A_local, B, C_full):
+        p = self.plan
+        works = []
         for s in range(p.panels_per_rank):
             start, valid = p.panel(s, self.rank)
             if valid > 0:
@@ -108,9 +141,7 @@ class ShardedGemm:
                 lo, hi = p.slab(s)
                 mine = C_full[start:start + p.rows]          # in-place: my slice of the slab
                 works.append(_all_gather_rows(C_full[lo:hi], mine, self.group))
-        for w in works:
-            w.wait()
-        return C_full[: self.M]
+        return works
 
 
 def _all_gather_rows(slab, mine, group):
