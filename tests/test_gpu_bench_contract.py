@@ -1,0 +1,43 @@
+"""bench.py's output contract on a GPU box: the single-GPU line, and the N > 1 code path (row-panel sharding, the
+cross-rank self-check, the roofline object) exercised with two ranks on ONE GPU over gloo through the
+LASER_BENCH_ONE_GPU test hook (RCCL itself refuses two ranks per device; timings are meaningless there)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--size", "2048",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _last_json(r.stdout)
+    assert KEYS <= set(out) and out["n_gpus"] == 1 and out["dtype"] == "f32" and out["higher_is_better"] is True
+    rl = out["roofline"]
+    assert rl["bound"] == "mfma" and 0 < rl["frac"] < 1 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_path_on_one_gpu():
+    env = dict(os.environ, LASER_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--size", "1024"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _last_json(r.stdout)
+    assert KEYS <= set(out) and out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["M"] == 2048 and "row-panels x2" in out["config"]["parallelism"]
+    assert out["roofline"]["traffic"] is None
