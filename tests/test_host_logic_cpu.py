@@ -1,0 +1,58 @@
+"""CPU-side checks of host logic that needs no GPU: the LDS bank model of the k-quad image, the Tensor twin's
+metadata arithmetic, and the loud failure of every device-touching call on a GPU-less host."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_k_quad_image_is_bank_conflict_free_in_the_model():
+    """scripts/kq_bank_check.py replays the three LDS access patterns of the k-quad image against the bank rules of
+    MI355X_MICROARCH.md; the swizzle + row swap the kernel uses must come out at zero extra cycles for BK = 16 and 32
+    (the variant without the row swap must not: that is the conflict SQ_LDS_BANK_CONFLICT showed on hardware)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "kq_bank_check.py")], capture_output=True, text=True, check=True)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    kernel = [l for l in lines if "kernel (kq_swz + kq_row)" in l]
+    assert len(kernel) == 2 and all(l.rstrip().endswith("total 0") for l in kernel), r.stdout
+    plain16 = [l for l in lines if l.startswith("16 no row swap")]
+    assert plain16 and not plain16[0].rstrip().endswith("total 0")
+
+
+def test_tensor_metadata_matches_numpy_without_touching_a_device():
+    from laser_amd.tensor import Tensor, _row_major_strides
+    for shape in [(3, 4, 5), (7,), (2, 1, 6, 1), (), (4, 0, 3)]:
+        strides, size = _row_major_strides(shape)
+        ref = np.zeros(shape, np.float32)
+        assert size == ref.size and strides == tuple(s // 4 for s in ref.strides) or ref.size == 0
+        t = Tensor(shape, strides, 0, None, np.float32)            # metadata only: storage is never dereferenced here
+        assert t.rank == ref.ndim and t.size == ref.size and t.is_C_contiguous()
+    t = Tensor((6, 8, 10), (80, 10, 1), 0, None, np.int64)
+    ref = np.arange(480).reshape(6, 8, 10)
+    assert t[-1, -2, -3].offset == 5 * 80 + 6 * 10 + 7 and t[-1, -2, -3].shape == ()
+    for idx in [(slice(1, 5, 2), 3, slice(None, None, -1)), (2,), (slice(None), slice(2, 8, 3))]:
+        v = t[idx]
+        r = ref[idx]
+        assert v.shape == r.shape and v.strides == tuple(s // ref.itemsize for s in r.strides)
+        assert v.offset == (r.__array_interface__["data"][0] - ref.__array_interface__["data"][0]) // ref.itemsize
+        assert v.is_C_contiguous() == (r.flags["C_CONTIGUOUS"] or r.size <= 1)
+    assert t.transpose(2, 0, 1).strides == tuple(s // 8 for s in ref.transpose(2, 0, 1).strides)
+    with pytest.raises(ValueError):
+        Tensor((1,) * 7, (1,) * 7, 0, None, np.float32)            # LASER_MAXRANK
+    with pytest.raises(IndexError):
+        t[6]
+
+
+def test_tensor_allocation_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import laser_amd
+    with pytest.raises(laser_amd.LaserHipError) as e:
+        laser_amd.newTensor(np.float32, 4, 4)
+    assert e.value.code == 3
+    with pytest.raises(laser_amd.LaserHipError):
+        laser_amd.toTensor([[1.0, 2.0], [3.0, 4.0]])
