@@ -207,45 +207,112 @@ template hipError_t launch_pack_pad<int32_t>(int32_t *, int64_t, int64_t, const 
 template hipError_t launch_pack_pad<int64_t>(int64_t *, int64_t, int64_t, const int64_t *, int64_t, int64_t, int64_t, int64_t, hipStream_t);
 
 // ---- rank-N strided copy: `forEachStrided d in dst, s in src: d = s` -----------------------------
-// (laser/tensor/initialization.nim:42-110: deepCopy / copyFrom of non-contiguous tensors.)  One element
-// per thread, index decoded from the innermost dimension outwards; consecutive threads walk the
-// innermost dimension, so unit-stride inner dimensions coalesce on that side.  HBM-bound.
+// (laser/tensor/initialization.nim:42-110: deepCopy / copyFrom of non-contiguous tensors.)  HBM-bound.
+// Host side first simplifies the iteration space: extent-1 dimensions are dropped and neighbouring dimensions
+// that are contiguous on BOTH sides are merged (a sliced row-major tensor collapses to rank 1-2).  Then
+//   * a pure 2-D transpose (source = a contiguous matrix read through swapped strides) goes to the transpose
+//     kernel -- the one pattern where "one element per thread" would read with a huge stride;
+//   * otherwise one workgroup copies 1024 consecutive elements of the innermost dimension of one outer "row":
+//     the outer index is decomposed once per workgroup (uniform), lanes walk the inner dimension.
 struct StridedCopyArgs {
-  int64_t shape[kMaxRank], dstride[kMaxRank], sstride[kMaxRank];
-  int64_t total;
+  int64_t shape[kMaxRank], dstride[kMaxRank], sstride[kMaxRank];  // dimension rank-1 is the inner one
+  int64_t inner, chunks;  // inner extent, workgroups per outer row
   int32_t rank;
 };
 template <typename T>
 __global__ void __launch_bounds__(256) copy_strided_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                                            StridedCopyArgs a) {
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += (int64_t)gridDim.x * 256) {
-    int64_t rem = idx, so = 0, dof = 0;
+  const int64_t row = blockIdx.x / a.chunks, chunk = blockIdx.x - row * a.chunks;
+  int64_t rem = row, so = 0, dof = 0;
 #pragma unroll
-    for (int d = kMaxRank - 1; d >= 0; d--) {
-      if (d < a.rank) {
-        const int64_t q = rem / a.shape[d], i = rem - q * a.shape[d];
-        so += i * a.sstride[d];
-        dof += i * a.dstride[d];
-        rem = q;
-      }
+  for (int d = kMaxRank - 2; d >= 0; d--) {
+    if (d < a.rank - 1) {
+      const int64_t q = rem / a.shape[d], i = rem - q * a.shape[d];
+      so += i * a.sstride[d];
+      dof += i * a.dstride[d];
+      rem = q;
     }
-    dst[dof] = src[so];
+  }
+  const int64_t is = a.sstride[a.rank - 1], id = a.dstride[a.rank - 1];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int64_t i = chunk * 1024 + threadIdx.x + 256 * j;
+    if (i < a.inner) dst[dof + i * id] = src[so + i * is];
+  }
+}
+// inner dimension shorter than a workgroup's 1024 elements: a workgroup takes 1024 / P consecutive outer rows
+// (P = inner extent rounded up to a power of two), lanes still walk the inner dimension; the outer index is
+// decomposed per (thread, slot).
+template <typename T>
+__global__ void __launch_bounds__(256) copy_strided_rows_kernel(T *__restrict__ dst, const T *__restrict__ src,
+                                                                StridedCopyArgs a, int64_t rows, int log2p) {
+  const int64_t is = a.sstride[a.rank - 1], id = a.dstride[a.rank - 1];
+  const int rows_per_wg = 1024 >> log2p;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int slot = threadIdx.x + 256 * j;
+    const int64_t row = (int64_t)blockIdx.x * rows_per_wg + (slot >> log2p), i = slot & ((1 << log2p) - 1);
+    if (row < rows && i < a.inner) {
+      int64_t rem = row, so = 0, dof = 0;
+#pragma unroll
+      for (int d = kMaxRank - 2; d >= 0; d--) {
+        if (d < a.rank - 1) {
+          const int64_t q = rem / a.shape[d], ii = rem - q * a.shape[d];
+          so += ii * a.sstride[d];
+          dof += ii * a.dstride[d];
+          rem = q;
+        }
+      }
+      dst[dof + i * id] = src[so + i * is];
+    }
   }
 }
 template <typename T>
 hipError_t launch_copy_strided(T *dst, const int64_t *dstrides, const T *src, const int64_t *sstrides,
                                const int64_t *shape, int rank, hipStream_t s) {
-  StridedCopyArgs a;
-  a.rank = rank;
-  a.total = 1;
-  for (int d = 0; d < kMaxRank; d++) {
-    a.shape[d] = d < rank ? shape[d] : 1;
-    a.dstride[d] = d < rank ? dstrides[d] : 0;
-    a.sstride[d] = d < rank ? sstrides[d] : 0;
-    a.total *= a.shape[d];
+  // drop extent-1 dimensions, merge dimension pairs (outer o, inner i) with stride_o == stride_i * extent_i on both sides
+  int64_t sh[kMaxRank], ds[kMaxRank], ss[kMaxRank];
+  int r = 0;
+  int64_t total = 1;
+  for (int d = 0; d < rank; d++) {
+    total *= shape[d];
+    if (shape[d] == 1) continue;
+    if (r > 0 && ds[r - 1] == dstrides[d] * shape[d] && ss[r - 1] == sstrides[d] * shape[d]) {
+      sh[r - 1] *= shape[d];
+      ds[r - 1] = dstrides[d];
+      ss[r - 1] = sstrides[d];
+    } else {
+      sh[r] = shape[d]; ds[r] = dstrides[d]; ss[r] = sstrides[d];
+      r++;
+    }
   }
-  if (a.total == 0) return hipSuccess;
-  const int64_t blocks = std::min<int64_t>((a.total + 255) / 256, 256 * 64);
+  if (total == 0) return hipSuccess;
+  if (r == 0) { sh[0] = 1; ds[0] = 1; ss[0] = 1; r = 1; }
+  // dst[i][j] = src viewed with strides (1, ld): a physical transpose of a contiguous [sh1][sh0] matrix
+  if (r == 2 && ds[1] == 1 && ds[0] == sh[1] && ss[0] == 1 && ss[1] == sh[0])
+    return launch_transpose_batched(dst, src, 1, sh[1], sh[0], (int)sizeof(T), s);
+  StridedCopyArgs a;
+  a.rank = r;
+  int64_t rows = 1;
+  for (int d = 0; d < kMaxRank; d++) {
+    a.shape[d] = d < r ? sh[d] : 1;
+    a.dstride[d] = d < r ? ds[d] : 0;
+    a.sstride[d] = d < r ? ss[d] : 0;
+    if (d < r - 1) rows *= sh[d];
+  }
+  a.inner = sh[r - 1];
+  if (a.inner < 1024 && r > 1) {  // short rows: several per workgroup
+    int log2p = 0;
+    while ((1 << log2p) < a.inner) log2p++;
+    const int64_t nb = (rows + (1024 >> log2p) - 1) / (1024 >> log2p);
+    if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.chunks = 1;
+    hipLaunchKernelGGL(copy_strided_rows_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, dst, src, a, rows, log2p);
+    return hipGetLastError();
+  }
+  a.chunks = (a.inner + 1023) / 1024;
+  const int64_t blocks = rows * a.chunks;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(copy_strided_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, a);
   return hipGetLastError();
 }
