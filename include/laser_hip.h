@@ -270,6 +270,8 @@ int laser_hip_conv2d_im2col_ex_f32_dev(float *d_output, const float *d_input, in
  *                    initialization.nim:42-110): rank <= 6 (LASER_MAXRANK), element strides, same shape */
 int laser_hip_storage_alloc(void **d_raw_buffer, int64_t bytes);
 int laser_hip_storage_free(void *d_raw_buffer);
+/* freed storages are cached per size for reuse (a device allocation costs ~100 us); this releases the cache */
+int laser_hip_storage_trim(void);
 int laser_hip_storage_upload(void *d_dst, const void *host_src, int64_t bytes);
 int laser_hip_storage_download(void *host_dst, const void *d_src, int64_t bytes);
 int laser_hip_storage_set_zero(void *d_buffer, int64_t bytes, void *stream);

@@ -116,7 +116,7 @@ def declared_symbols():
              "laser_hip_gemm_strided_ex_f32", "laser_hip_gemm_strided_ex_f32_dev",
              "laser_hip_gemm_strided_ex_f64", "laser_hip_gemm_strided_ex_f64_dev",
              "laser_hip_conv2d_im2col_ex_f32", "laser_hip_conv2d_im2col_ex_f32_dev",
-             "laser_hip_storage_alloc", "laser_hip_storage_free", "laser_hip_storage_upload",
+             "laser_hip_storage_alloc", "laser_hip_storage_free", "laser_hip_storage_trim", "laser_hip_storage_upload",
              "laser_hip_storage_download", "laser_hip_storage_set_zero",
              "laser_hip_copy_strided_b32_dev", "laser_hip_copy_strided_b64_dev"]
     for s in _CT:

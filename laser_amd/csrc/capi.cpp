@@ -386,6 +386,22 @@ struct DevPanel {
   size_t bytes;
 };
 std::unordered_map<uint64_t, DevPanel> g_panels;
+
+// device tensor storage: live blocks (ptr -> rounded size) and the free list keyed by size
+constexpr size_t kStorageCacheMax = (size_t)32 << 30;
+std::unordered_map<void *, size_t> g_live_storage;
+std::unordered_map<size_t, std::vector<void *>> g_free_storage;
+size_t g_free_storage_bytes = 0;
+void storage_trim() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto &kv : g_free_storage)
+    for (void *p : kv.second) {
+      (void)hipFree(p);
+      g_live_storage.erase(p);
+    }
+  g_free_storage.clear();
+  g_free_storage_bytes = 0;
+}
 uint64_t g_next_id = 1;
 
 template <typename T>
@@ -669,6 +685,13 @@ int laser_hip_finalize(void) {
   }
   for (auto &kv : g_panels) (void)hipFree(kv.second.ptr);
   g_panels.clear();
+  for (auto &kv : g_free_storage)
+    for (void *p : kv.second) {
+      (void)hipFree(p);
+      g_live_storage.erase(p);
+    }
+  g_free_storage.clear();
+  g_free_storage_bytes = 0;
   if (g_ctx.s_up) {
     (void)hipStreamDestroy(g_ctx.s_up);
     (void)hipStreamDestroy(g_ctx.s_comp);
@@ -988,24 +1011,61 @@ LH_DEF_GEMM_EX(f64, double)
 #undef LH_DEF_GEMM_EX
 
 // ---- device tensor storage -- laser/tensor/allocator.nim, initialization.nim -----------------------
+// Freed storages are kept on a per-size free list (exact match of the 256-byte-rounded size, at most
+// kStorageCacheMax bytes in total) so that chains of tensor-producing calls do not pay hipMalloc / hipFree -- a
+// device allocation costs ~100 us, more than a 2048^3 product.  Reused blocks are zero-filled again: the contract
+// stays allocShared0's.  laser_hip_storage_trim() / laser_hip_finalize() release the list.
 int laser_hip_storage_alloc(void **d, int64_t bytes) {
   if (!d || bytes < 0) return fail(LASER_HIP_E_INVALID, "storage_alloc: bad argument");
   if (int rc = ensure_init()) return rc;
   *d = nullptr;
   if (bytes == 0) return LASER_HIP_OK;
-  HIP_TRY(hipMalloc(d, (size_t)bytes));  // hipMalloc is 256-byte aligned >= LASER_MEM_ALIGN
-  hipError_t e = hipMemset(*d, 0, (size_t)bytes);
-  if (e != hipSuccess) {
-    (void)hipFree(*d);
-    *d = nullptr;
-    return fail(LASER_HIP_E_HIP, "hipMemset: %s", hipGetErrorString(e));
+  const size_t want = ((size_t)bytes + 255) & ~(size_t)255;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_free_storage.find(want);
+    if (it != g_free_storage.end() && !it->second.empty()) {
+      *d = it->second.back();
+      it->second.pop_back();
+      g_free_storage_bytes -= want;
+    }
   }
+  // a recycled block may still be read by work queued on any stream when its owner dropped it (hipFree would have
+  // waited for the device; the free list does not): wait here, where it is only paid on reuse
+  if (*d) HIP_TRY(hipDeviceSynchronize());
+  if (!*d) {
+    hipError_t e = hipMalloc(d, want);  // hipMalloc is 256-byte aligned >= LASER_MEM_ALIGN
+    if (e != hipSuccess) {             // out of memory: give the cached blocks back and retry once
+      storage_trim();
+      e = hipMalloc(d, want);
+    }
+    if (e != hipSuccess) return fail(LASER_HIP_E_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_live_storage[*d] = want;
+  }
+  hipError_t e = hipMemset(*d, 0, (size_t)bytes);
+  if (e != hipSuccess) return fail(LASER_HIP_E_HIP, "hipMemset: %s", hipGetErrorString(e));
   return LASER_HIP_OK;
 }
 int laser_hip_storage_free(void *d) {
   if (!d) return LASER_HIP_OK;
   if (int rc = ensure_init()) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_live_storage.find(d);
+  if (it == g_live_storage.end()) return fail(LASER_HIP_E_INVALID, "storage_free: not a laser_hip storage");
+  const size_t sz = it->second;
+  if (g_free_storage_bytes + sz <= kStorageCacheMax) {
+    g_free_storage[sz].push_back(d);
+    g_free_storage_bytes += sz;
+    return LASER_HIP_OK;
+  }
+  g_live_storage.erase(it);
   HIP_TRY(hipFree(d));
+  return LASER_HIP_OK;
+}
+int laser_hip_storage_trim(void) {
+  if (int rc = ensure_init()) return rc;
+  storage_trim();
   return LASER_HIP_OK;
 }
 int laser_hip_storage_upload(void *d, const void *h, int64_t bytes) {

@@ -277,5 +277,10 @@ def setZero(t, check_contiguous=True):
     return t
 
 
-__all__ = ["Tensor", "HipStorage", "newTensor", "toTensor", "fromTorch", "deepCopy", "copyFrom", "copyFromRaw", "setZero",
+def trimStorageCache():
+    """Release the device blocks the library keeps for reuse after tensors were freed (laser_hip_storage_trim)."""
+    _lib.check(_lib.lib().laser_hip_storage_trim())
+
+
+__all__ = ["trimStorageCache", "Tensor", "HipStorage", "newTensor", "toTensor", "fromTorch", "deepCopy", "copyFrom", "copyFromRaw", "setZero",
            "LASER_MAXRANK", "LASER_MEM_ALIGN"]

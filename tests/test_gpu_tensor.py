@@ -118,3 +118,20 @@ def test_conv_on_tensors_and_torch_interop(la, oracle):
     assert not back.storage.memowner and np.array_equal(back.to_numpy(), ref[:, 1:3])
     with pytest.raises(TypeError):
         la.matmul(la.toTensor(np.ones((2, 2), np.float32)), np.ones((2, 2), np.float32))   # mixed host / device
+
+
+def test_storage_cache_reuses_and_rezeroes(la):
+    """Freed storages are kept per size and handed out again -- zero-filled like a fresh allocShared0 block."""
+    la.tensor.trimStorageCache()
+    t = la.toTensor(np.full((513, 77), 7.0, np.float32))
+    addr = t.unsafe_raw_data()
+    del t
+    u = la.newTensor(np.float32, 513, 77)                 # same size: the cached block comes back
+    assert u.unsafe_raw_data() == addr
+    assert np.array_equal(u.to_numpy(), np.zeros((513, 77), np.float32))
+    v = la.newTensor(np.float32, 513, 78)                 # different size: a different block
+    assert v.unsafe_raw_data() != addr
+    del u, v
+    la.tensor.trimStorageCache()
+    w = la.newTensor(np.float64, 10)
+    assert np.array_equal(w.to_numpy(), np.zeros(10))
