@@ -71,6 +71,15 @@ def main():
     n = 8192
     A, B, C = rnd((n, n), 3), rnd((n, n), 4), torch.zeros((n, n), device="cuda")
     gemm_case("C2 fp32 8192^3 contiguous", n, n, n, A, B, C)
+    # the alpha != 1 / beta != 0 variant no reference test or bench covers: C read once, scaled, added
+    Cb = rnd((n, n), 33)
+    for mode in (0, 1):
+        laser_amd.set_float_mode(mode)
+        med, mn = ev_time(lambda: laser_amd.matmul(A, B, 0.5, 0.25, Cb))
+        emit(config="C2 fp32 8192^3 contiguous, alpha=0.5 beta=0.25", mode="laser_order" if mode == 0 else "fast", ms_med=round(med, 4),
+             ms_min=round(mn, 4), tflops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 2))
+    laser_amd.set_float_mode(0)
+    del Cb
     # C2 host-pointer end-to-end (PCIe inclusive, pageable host memory)
     Ah, Bh, Ch = A.cpu().numpy(), B.cpu().numpy(), np.zeros((n, n), np.float32)
     laser_amd.matmul(Ah, Bh, 1, 0, Ch)
