@@ -69,6 +69,9 @@ int laser_hip_set_conv_implicit(int on);
 /* 1 (default): the implicit conv reads its B operand from an LDS-resident input patch when that fits;
  * 0: always the per-element gather (A/B timing) */
 int laser_hip_set_conv_patch(int on);
+/* 1 (default): float32/float64 problems with M <= 8 or N <= 8 (matrix-vector products) run a streaming kernel,
+ * same arithmetic; 0: always the tiled kernels (A/B timing) */
+int laser_hip_set_skinny(int on);
 /* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet) */
 int laser_hip_last_f32_config(void);
 /* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */

@@ -57,6 +57,7 @@ struct Context {
   hipStream_t s_up = nullptr, s_comp = nullptr;  // host-pointer pipeline: uploads / kernels
   bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
+  bool skinny = true;         // M <= 8 or N <= 8: the streaming kernel (false: always the tiled kernels)
   bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
   // cached device scratch for the host-pointer paths, one growing buffer per role
   void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -121,11 +122,19 @@ template <typename T>
 hipError_t run_gemm(const GemmArgs<T> &a, hipStream_t s);
 template <>
 hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
+  if (g_ctx.f32_cfg < 0 && g_ctx.skinny) {  // matrix-vector-like shapes: an HBM stream, not a tile problem
+    const hipError_t e = launch_gemm_skinny<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 template <>
 hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
   const bool laser = g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER;
+  if (g_ctx.skinny) {
+    const hipError_t e = launch_gemm_skinny<double>(a, laser, 256, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (g_ctx.f64_mfma) return launch_gemm_f64(a, laser, s);  // v_mfma_f64_16x16x4_f64: a k-ordered fma chain
   return launch_gemm_valu<double>(a, laser, s);
 }
@@ -738,6 +747,10 @@ int laser_hip_set_i32_mfma(int on) {
 int laser_hip_last_f32_config(void) { return g_last_f32_cfg; }
 int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from an LDS input patch (1) or gathered (0)
   g_conv_patch = on != 0;
+  return LASER_HIP_OK;
+}
+int laser_hip_set_skinny(int on) {  // A/B knob: streaming kernel for matrix-vector-like shapes
+  g_ctx.skinny = on != 0;
   return LASER_HIP_OK;
 }
 int laser_hip_set_transpose_variant(int v) {  // tuning only (scripts/transpose_probe.py)

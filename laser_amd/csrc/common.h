@@ -66,6 +66,9 @@ hipError_t launch_gemm_f32_probe(const GemmArgs<float> &args, int dbg, hipStream
 int gemm_f32_config_count();
 const char *gemm_f32_config_name(int cfg);
 
+// matrix-vector-like problems (M <= 8 or N <= 8) as an HBM stream; hipErrorNotSupported = not skinny, use the tiled kernels
+template <typename T>
+hipError_t launch_gemm_skinny(const GemmArgs<T> &args, bool laser_order, int kc_elems, hipStream_t s);
 template <typename T>
 hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream_t s);
 

@@ -99,6 +99,11 @@ def set_conv_patch(on):
     _lib.check(_lib.lib().laser_hip_set_conv_patch(1 if on else 0))
 
 
+def set_skinny(on):
+    """True (default): M <= 8 or N <= 8 float problems run the streaming (matrix-vector) kernel."""
+    _lib.check(_lib.lib().laser_hip_set_skinny(1 if on else 0))
+
+
 def last_f32_config():
     """Index into f32_configs() of the tile configuration the last fp32 GEMM / conv launch used."""
     return _lib.lib().laser_hip_last_f32_config()
