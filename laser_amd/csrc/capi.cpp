@@ -142,6 +142,10 @@ template <>
 hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
   // Large single problems go to the int8 matrix cores (limb decomposition, gemm_i32_mfma.hip); the
   // limb planes live in stream-ordered scratch so concurrent streams never share a buffer.
+  if (g_ctx.skinny) {
+    const hipError_t e = launch_gemm_skinny<int32_t>(a, false, 512, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   const double work = (double)a.M * (double)a.N * (double)a.K;
   if (g_ctx.i32_mfma && a.batch == 1 && work >= 64.0 * 64.0 * 64.0 * 8.0) {
     void *ws = nullptr;
@@ -155,6 +159,10 @@ hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
 }
 template <>
 hipError_t run_gemm<int64_t>(const GemmArgs<int64_t> &a, hipStream_t s) {
+  if (g_ctx.skinny) {
+    const hipError_t e = launch_gemm_skinny<int64_t>(a, false, 256, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   return launch_gemm_valu<int64_t>(a, false, s);
 }
 

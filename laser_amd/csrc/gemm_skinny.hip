@@ -1,5 +1,5 @@
 // laser_amd/csrc/gemm_skinny.hip -- gemm_strided when one output dimension is tiny (M <= 8 or N <= 8: matrix-vector
-// products and their close relatives), float32 / float64.
+// products and their close relatives), all four element types.
 //
 // A 64x64 MFMA tile is 1/64 full on an N = 1 problem and the grid is a few dozen workgroups: the tiled kernels reach
 // ~1 TB/s on what is a pure HBM stream (8192 x 1 x 8192: 0.36 ms).  Here the problem is viewed as
@@ -45,15 +45,31 @@ __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return
 template <>
 __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// integers: two's-complement wrap-around c + a*b (gemm_ukernel_avx2.nim:10-11), done on the unsigned type
+template <>
+__device__ __forceinline__ int32_t fma_<int32_t>(int32_t a, int32_t b, int32_t c) { return (int32_t)((uint32_t)a * (uint32_t)b + (uint32_t)c); }
+template <>
+__device__ __forceinline__ int64_t fma_<int64_t>(int64_t a, int64_t b, int64_t c) { return (int64_t)((uint64_t)a * (uint64_t)b + (uint64_t)c); }
+
 template <typename E>
 __device__ __forceinline__ E mul_(E a, E b) {
+  if constexpr (std::is_integral<E>::value) {
+    using U = typename std::make_unsigned<E>::type;
+    return (E)((U)a * (U)b);
+  } else {
 #pragma clang fp contract(off)
-  return a * b;
+    return a * b;
+  }
 }
 template <typename E>
 __device__ __forceinline__ E add_(E a, E b) {
+  if constexpr (std::is_integral<E>::value) {
+    using U = typename std::make_unsigned<E>::type;
+    return (E)((U)a + (U)b);
+  } else {
 #pragma clang fp contract(off)
-  return a + b;
+    return a + b;
+  }
 }
 
 // Laser's kc slices are INDEPENDENT chains (each starts from +0); only their sums are added in order.  So the
@@ -198,5 +214,7 @@ hipError_t launch_gemm_skinny(const GemmArgs<E> &g, bool laser_order, int kc_ele
 }
 template hipError_t launch_gemm_skinny<float>(const GemmArgs<float> &, bool, int, hipStream_t);
 template hipError_t launch_gemm_skinny<double>(const GemmArgs<double> &, bool, int, hipStream_t);
+template hipError_t launch_gemm_skinny<int32_t>(const GemmArgs<int32_t> &, bool, int, hipStream_t);
+template hipError_t launch_gemm_skinny<int64_t>(const GemmArgs<int64_t> &, bool, int, hipStream_t);
 
 }  // namespace laser_hip

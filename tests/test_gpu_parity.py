@@ -623,7 +623,7 @@ def test_unaligned_bases_and_odd_leading_dimensions(la, oracle, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
 def test_skinny_matrix_vector_shapes_bit_exact(la, oracle, dtype):
     """M <= 8 or N <= 8 (matrix-vector products) run the streaming kernel: a VALU fma chain per output element in
     Laser's order -- must equal the oracle, and the tiled kernels, bit for bit; both orientations, transposed /
@@ -634,12 +634,12 @@ def test_skinny_matrix_vector_shapes_bit_exact(la, oracle, dtype):
     oracle.set_num_threads(8)     # tiny products: a 256-thread OpenMP team costs far more than the work
     for (M, N, K) in [(2048, 1, 3000), (1, 1500, 1100), (1000, 5, 777), (8, 1024, 520), (700, 8, 64), (513, 3, 1)]:
         for (ta, tb) in [(False, False), (True, False), (False, True), (True, True)]:
-            A = rand(rng, (K, M) if ta else (M, K + 3), dtype)
-            B = rand(rng, (N, K) if tb else (K, N + 1), dtype)
+            A = rand(rng, (K, M) if ta else (M, K + 3), dtype, full_range=True)
+            B = rand(rng, (N, K) if tb else (K, N + 1), dtype, full_range=True)
             Av = A.T if ta else A[:, 1:K + 1]          # transposed storage, or a column-offset (unaligned) view
             Bv = B.T if tb else B[:, :N]
             C0 = rand(rng, (M, N), dtype)
-            alpha, beta = dtype(-0.5), dtype(2.0)
+            alpha, beta = (dtype(-3), dtype(2)) if np.dtype(dtype).kind == "i" else (dtype(-0.5), dtype(2.0))
             want = oracle.matmul(np.ascontiguousarray(Av), np.ascontiguousarray(Bv), alpha=alpha, beta=beta, C_=C0.copy(), isa=isa)
             dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
             dAv = dA.t() if ta else dA[:, 1:K + 1]
@@ -651,6 +651,8 @@ def test_skinny_matrix_vector_shapes_bit_exact(la, oracle, dtype):
             la.set_skinny(True)
             assert np.array_equal(got, want), (M, N, K, ta, tb, dtype)
             assert np.array_equal(tiled, want), (M, N, K, ta, tb, dtype, "tiled")
+    if np.dtype(dtype).kind == "i":
+        return
     A = rand(rng, (2048, 4096), dtype); b = rand(rng, (4096, 1), dtype)
     ref = oracle.matmul(A, b, isa=isa)
     la.set_float_mode(1)
