@@ -72,6 +72,9 @@ int laser_hip_set_conv_patch(int on);
 /* 1 (default): float32/float64 problems with M <= 8 or N <= 8 (matrix-vector products) run a streaming kernel,
  * same arithmetic; 0: always the tiled kernels (A/B timing) */
 int laser_hip_set_skinny(int on);
+/* 1 (default): float problems with few output tiles and K >= 4 kc compute Laser's kc slices as one batched launch and
+ * fold them with an ordered combine pass (same arithmetic, same order); 0: always the sequential K loop */
+int laser_hip_set_slice_parallel(int on);
 /* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet) */
 int laser_hip_last_f32_config(void);
 /* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */

@@ -57,6 +57,8 @@ struct Context {
   hipStream_t s_up = nullptr, s_comp = nullptr;  // host-pointer pipeline: uploads / kernels
   bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
+  int64_t slice_parallel_tiles = 0;  // tuning override of the tile-count limit of the slice-parallel form (0 = built-in rule)
+  bool slice_parallel = true; // few tiles x long K: kc slices as one batched launch + ordered combine
   bool skinny = true;         // M <= 8 or N <= 8: the streaming kernel (false: always the tiled kernels)
   bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
   // cached device scratch for the host-pointer paths, one growing buffer per role
@@ -118,12 +120,66 @@ void view_span(int64_t R, int64_t C, int64_t rs, int64_t cs, int64_t *lo, int64_
   *hi = std::max<int64_t>(0, r) + std::max<int64_t>(0, c);
 }
 
+hipError_t launch_tiled(const GemmArgs<float> &a, hipStream_t s) {
+  return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+}
+hipError_t launch_tiled(const GemmArgs<double> &a, hipStream_t s) {
+  return launch_gemm_f64(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+}
+
+// Slice-parallel GEMM for problems with few output tiles and a long K (tall-skinny products, small M x N with a huge
+// K): Laser's kc slices are independent chains from +0 -- only their sums are added in order (gemm.nim:150-158) -- so
+// the slices are computed as ONE batched launch (batch = slice, K = kc, each a single-chain product into a workspace
+// W[p][M][N]) and folded by an ordered combine pass.  Same fused multiply-adds in the same order, same unfused
+// alpha / beta arithmetic => bit-identical to the sequential kernel, with ceil(K / kc) times the workgroups.
+// Returns hipErrorNotSupported when the shape does not call for it.
+template <typename T>
+hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s) {
+  if (!g_ctx.slice_parallel || a.batch != 1 || a.bias != nullptr || a.act != 0) return hipErrorNotSupported;
+  if (a.M <= 0 || a.N <= 0 || a.K < 4 * (int64_t)kc) return hipErrorNotSupported;
+  const int64_t tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+  const int64_t nfull = a.K / kc, nsl = (a.K + kc - 1) / kc;
+  const double ws_bytes = (double)nsl * (double)a.M * (double)a.N * sizeof(T);
+  // measured boundary (scripts/slice_parallel_threshold_probe.py): pays up to ~400 tiles of 64x64 (1280^2 x 2560: +17 %),
+  // up to ~600 with six or more slices (1536^2 x 6144: +24 %); loses from ~1000 tiles on (2048^3: -14 %)
+  const int64_t limit = g_ctx.slice_parallel_tiles > 0 ? g_ctx.slice_parallel_tiles : (nsl >= 6 ? 600 : 400);
+  if (tiles64 > limit || nsl > 65535 || ws_bytes > 1.5e9) return hipErrorNotSupported;  // enough tiles already / workspace too large
+  T *W = nullptr;
+  hipError_t e = hipMallocAsync((void **)&W, (size_t)ws_bytes, s);
+  if (e != hipSuccess) return e;
+  const int64_t mn = a.M * a.N;
+  GemmArgs<T> b = a;
+  b.alpha = (T)1; b.beta = (T)0;
+  b.C = W; b.rsC = a.N; b.csC = 1; b.bsC = mn;
+  b.K = kc; b.Kext = kc;
+  b.batch = (int32_t)nfull;
+  b.bsA = (int64_t)kc * a.csA;  // slice p starts kc columns of A / rows of B further on
+  b.bsB = (int64_t)kc * a.rsB;
+  e = launch_tiled(b, s);
+  if (e == hipSuccess && nsl > nfull) {  // the ragged last slice
+    GemmArgs<T> c = b;
+    c.batch = 1;
+    c.K = a.K - nfull * kc; c.Kext = c.K;
+    c.A = a.A + nfull * b.bsA;
+    c.B = a.B + nfull * b.bsB;
+    c.C = W + nfull * mn;
+    e = launch_tiled(c, s);
+  }
+  if (e == hipSuccess) e = launch_combine_slices<T>(a.C, a.rsC, a.csC, W, a.M, a.N, (int)nsl, a.alpha, a.beta, s);
+  const hipError_t e2 = hipFreeAsync(W, s);
+  return e != hipSuccess ? e : e2;
+}
+
 template <typename T>
 hipError_t run_gemm(const GemmArgs<T> &a, hipStream_t s);
 template <>
 hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
   if (g_ctx.f32_cfg < 0 && g_ctx.skinny) {  // matrix-vector-like shapes: an HBM stream, not a tile problem
     const hipError_t e = launch_gemm_skinny<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
+    if (e != hipErrorNotSupported) return e;
+  }
+  if (g_ctx.f32_cfg < 0) {
+    const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
   return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
@@ -135,7 +191,11 @@ hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
     const hipError_t e = launch_gemm_skinny<double>(a, laser, 256, s);
     if (e != hipErrorNotSupported) return e;
   }
-  if (g_ctx.f64_mfma) return launch_gemm_f64(a, laser, s);  // v_mfma_f64_16x16x4_f64: a k-ordered fma chain
+  if (g_ctx.f64_mfma) {
+    const hipError_t e = gemm_slice_parallel<double>(a, 256, s);
+    if (e != hipErrorNotSupported) return e;
+    return launch_gemm_f64(a, laser, s);
+  }  // v_mfma_f64_16x16x4_f64: a k-ordered fma chain
   return launch_gemm_valu<double>(a, laser, s);
 }
 template <>
@@ -755,6 +815,11 @@ int laser_hip_set_i32_mfma(int on) {
 int laser_hip_last_f32_config(void) { return g_last_f32_cfg; }
 int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from an LDS input patch (1) or gathered (0)
   g_conv_patch = on != 0;
+  return LASER_HIP_OK;
+}
+int laser_hip_set_slice_parallel(int on) {  // A/B knob: slice-parallel GEMM for few-tile / long-K problems
+  g_ctx.slice_parallel = on != 0;
+  if (on > 1) g_ctx.slice_parallel_tiles = on;  // (tuning: on > 1 sets the tile-count threshold)
   return LASER_HIP_OK;
 }
 int laser_hip_set_skinny(int on) {  // A/B knob: streaming kernel for matrix-vector-like shapes

@@ -86,6 +86,10 @@ hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in,
                              int64_t C, int64_t H, int64_t W, int64_t kH, int64_t kW, int64_t pH,
                              int64_t pW, int64_t sH, int64_t sW, hipStream_t s);
 // dst[r*ld + c] = (r < R && c < Ccols) ? src[r*rs + c*cs] : 0 for r < Rpad, c < Cpad
+// ordered combine of per-kc-slice partial products W[nsl][M][N] into C (slice-parallel GEMM)
+template <typename E>
+hipError_t launch_combine_slices(E *C, int64_t rsC, int64_t csC, const E *W, int64_t M, int64_t N, int nsl, E alpha, E beta,
+                                 hipStream_t s);
 // rank-N strided element copy (tensor deepCopy / copyFrom); LASER_MAXRANK = 6 (laser/dynamic_stack_arrays.nim:6)
 constexpr int kMaxRank = 6;
 template <typename T>

@@ -316,6 +316,42 @@ hipError_t launch_copy_strided(T *dst, const int64_t *dstrides, const T *src, co
   hipLaunchKernelGGL(copy_strided_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, a);
   return hipGetLastError();
 }
+// ---- ordered combine of per-slice partial products (slice-parallel GEMM, capi.cpp: gemm_slice_parallel) ----
+// C[i,j] = (..((beta*C0 or 0) + alpha*W[0][i,j]) + alpha*W[1][i,j] ..) + alpha*W[nsl-1][i,j], unfused, ascending slice:
+// exactly the sequence of Laser's pc loop (gemm.nim:150-158) with W[p] = the kc-slice product S_p.  HBM-bound.
+template <typename E>
+__global__ void __launch_bounds__(256) combine_slices_kernel(E *__restrict__ C, int64_t rsC, int64_t csC, const E *__restrict__ W,
+                                                             int64_t M, int64_t N, int nsl, E alpha, E beta) {
+  const int64_t total = M * N;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t i = idx / N, j = idx - i * N;
+    E *p = C + i * rsC + j * csC;
+    E run = (E)0;
+    if (beta != (E)0) {  // beta == 0 never reads C
+      run = *p;
+      if (beta != (E)1) {
+#pragma clang fp contract(off)
+        run = run * beta;
+      }
+    }
+    for (int q = 0; q < nsl; q++) {
+#pragma clang fp contract(off)
+      const E t = alpha * W[(int64_t)q * total + idx];
+      run = run + t;
+    }
+    *p = run;
+  }
+}
+template <typename E>
+hipError_t launch_combine_slices(E *C, int64_t rsC, int64_t csC, const E *W, int64_t M, int64_t N, int nsl, E alpha, E beta,
+                                 hipStream_t s) {
+  const int64_t blocks = std::min<int64_t>((M * N + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(combine_slices_kernel<E>, dim3((unsigned)blocks), dim3(256), 0, s, C, rsC, csC, W, M, N, nsl, alpha, beta);
+  return hipGetLastError();
+}
+template hipError_t launch_combine_slices<float>(float *, int64_t, int64_t, const float *, int64_t, int64_t, int, float, float, hipStream_t);
+template hipError_t launch_combine_slices<double>(double *, int64_t, int64_t, const double *, int64_t, int64_t, int, double, double, hipStream_t);
+
 template hipError_t launch_copy_strided<uint32_t>(uint32_t *, const int64_t *, const uint32_t *, const int64_t *, const int64_t *, int, hipStream_t);
 template hipError_t launch_copy_strided<uint64_t>(uint64_t *, const int64_t *, const uint64_t *, const int64_t *, const int64_t *, int, hipStream_t);
 

@@ -99,6 +99,11 @@ def set_conv_patch(on):
     _lib.check(_lib.lib().laser_hip_set_conv_patch(1 if on else 0))
 
 
+def set_slice_parallel(on):
+    """True (default): few-tile / long-K float problems run Laser's kc slices in parallel + an ordered combine."""
+    _lib.check(_lib.lib().laser_hip_set_slice_parallel(int(on)))
+
+
 def set_skinny(on):
     """True (default): M <= 8 or N <= 8 float problems run the streaming (matrix-vector) kernel."""
     _lib.check(_lib.lib().laser_hip_set_skinny(1 if on else 0))

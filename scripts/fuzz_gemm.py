@@ -53,7 +53,10 @@ for it in range(cases):
     if mode == 0 or is_int:
         ok = np.array_equal(got, want)
     else:
-        ok = oracle.mean_relative_error(got, want) <= 1e-5
+        # FAST = one chain over K instead of Laser's kc slices: same products, different rounding points.  The mean
+        # relative error of the reference's own check (error_functions.nim) is ill-conditioned when the results are
+        # centred on zero, as they are here; bound the absolute deviation by the size of the rounding noise instead
+        ok = float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64)))) <= 4e-7 * K * (1.0 + abs(float(beta)))
     if not (ok and untouched):
         fails += 1
         print("FAIL", dict(it=it, dtype=dtype.__name__, M=M, N=N, K=K, ta=ta, tb=tb, offs=(offA, offB, offC), pads=(padA, padB, padC),

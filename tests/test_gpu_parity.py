@@ -660,3 +660,39 @@ def test_skinny_matrix_vector_shapes_bit_exact(la, oracle, dtype):
     la.set_float_mode(0)
     assert oracle.mean_relative_error(fast, ref) <= 1e-5
     assert np.array_equal(la.matmul(A, b, beta=0.0, out=np.full((2048, 1), np.nan, dtype)), ref)   # beta == 0 never reads C
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_slice_parallel_gemm_bit_exact(la, oracle, dtype):
+    """Few output tiles x long K: the kc slices run as one batched launch and are folded by an ordered combine pass.
+    Must equal the oracle (and the sequential K loop) bit for bit: ragged last slice, alpha / beta, strided /
+    transposed operands, C with a column stride, beta == 0 over NaNs."""
+    import torch
+    rng = np.random.default_rng(41)
+    isa = oracle.fused_isa(dtype)
+    kc = 512 if dtype == np.float32 else 256
+    oracle.set_num_threads(8)
+    for (M, N, K, ta, tb) in [(300, 70, 4 * kc, False, False), (129, 257, 5 * kc + 37, True, False), (64, 1000, 9 * kc + 1, False, True),
+                              (1000, 100, 4 * kc + kc // 2, True, True), (1, 9, 6 * kc, False, False)]:
+        A = rand(rng, (K, M) if ta else (M, K + 2), dtype)
+        B = rand(rng, (N, K) if tb else (K, N + 3), dtype)
+        Av, Bv = (A.T if ta else A[:, 2:]), (B.T if tb else B[:, 1:N + 1])
+        C0 = rand(rng, (M, 2 * N), dtype)
+        for (alpha, beta) in [(dtype(1), dtype(0)), (dtype(-0.5), dtype(2.0)), (dtype(1), dtype(1))]:
+            want = oracle.matmul(np.ascontiguousarray(Av), np.ascontiguousarray(Bv), alpha=alpha, beta=beta,
+                                 C_=np.ascontiguousarray(C0[:, ::2]).copy(), isa=isa)
+            dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+            dAv, dBv = (dA.t() if ta else dA[:, 2:]), (dB.t() if tb else dB[:, 1:N + 1])
+            res = {}
+            for on in (True, False):
+                la.set_slice_parallel(on)
+                dC = torch.from_numpy(C0.copy()).cuda()
+                if beta == 0:
+                    dC[:, ::2] = float("nan")
+                la.matmul(dAv, dBv, alpha, beta, dC[:, ::2])
+                res[on] = dC.cpu().numpy()
+            la.set_slice_parallel(True)
+            assert np.array_equal(res[True][:, ::2], want), (M, N, K, ta, tb, float(alpha), float(beta))
+            assert np.array_equal(res[False][:, ::2], want), (M, N, K, "sequential")
+            assert np.array_equal(res[True][:, 1::2], C0[:, 1::2])          # the gaps of the strided C stay untouched
