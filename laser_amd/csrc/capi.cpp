@@ -57,6 +57,7 @@ struct Context {
   hipStream_t s_up = nullptr, s_comp = nullptr;  // host-pointer pipeline: uploads / kernels
   bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
+  int slice_parallel_min = 2;        // (tuning override only) fewest kc slices worth splitting
   int64_t slice_parallel_tiles = 0;  // tuning override of the tile-count limit of the slice-parallel form (0 = built-in rule)
   bool slice_parallel = true; // few tiles x long K: kc slices as one batched launch + ordered combine
   bool skinny = true;         // M <= 8 or N <= 8: the streaming kernel (false: always the tiled kernels)
@@ -136,14 +137,18 @@ hipError_t launch_tiled(const GemmArgs<double> &a, hipStream_t s) {
 template <typename T>
 hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s) {
   if (!g_ctx.slice_parallel || a.batch != 1 || a.bias != nullptr || a.act != 0) return hipErrorNotSupported;
-  if (a.M <= 0 || a.N <= 0 || a.K < 4 * (int64_t)kc) return hipErrorNotSupported;
+  if (a.M <= 0 || a.N <= 0 || a.K <= kc) return hipErrorNotSupported;
   const int64_t tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
   const int64_t nfull = a.K / kc, nsl = (a.K + kc - 1) / kc;
   const double ws_bytes = (double)nsl * (double)a.M * (double)a.N * sizeof(T);
-  // measured boundary (scripts/slice_parallel_threshold_probe.py): pays up to ~400 tiles of 64x64 (1280^2 x 2560: +17 %),
-  // up to ~600 with six or more slices (1536^2 x 6144: +24 %); loses from ~1000 tiles on (2048^3: -14 %)
-  const int64_t limit = g_ctx.slice_parallel_tiles > 0 ? g_ctx.slice_parallel_tiles : (nsl >= 6 ? 600 : 400);
-  if (tiles64 > limit || nsl > 65535 || ws_bytes > 1.5e9) return hipErrorNotSupported;  // enough tiles already / workspace too large
+  // measured boundary (scripts/slice_parallel_threshold_probe.py, slice_parallel_min_probe.py): the fewer the tiles the
+  // fewer slices it takes to pay -- up to ~150 tiles of 64x64 from two slices on (768^2 x 1536: +20 %), up to ~400 from
+  // five (1280^2 x 2560: +17 %; 1024^2 x 2048 with four: -3 %), up to ~600 from six (1536^2 x 6144: +24 %); from ~1000
+  // tiles on the sequential loop wins (2048^3: -14 %)
+  int64_t need = tiles64 <= 150 ? 2 : tiles64 <= 400 ? 5 : tiles64 <= 600 ? 6 : (int64_t)1 << 40;
+  if (a.K % kc != 0 && need < 3) need = 3;  // a ragged last slice is a launch of its own: 768^3 (512 + 256) loses
+  if (g_ctx.slice_parallel_tiles > 0) need = tiles64 <= g_ctx.slice_parallel_tiles ? g_ctx.slice_parallel_min : (int64_t)1 << 40;  // tuning override
+  if (nsl < need || nsl > 65535 || ws_bytes > 1.5e9) return hipErrorNotSupported;
   T *W = nullptr;
   hipError_t e = hipMallocAsync((void **)&W, (size_t)ws_bytes, s);
   if (e != hipSuccess) return e;
@@ -819,7 +824,8 @@ int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from
 }
 int laser_hip_set_slice_parallel(int on) {  // A/B knob: slice-parallel GEMM for few-tile / long-K problems
   g_ctx.slice_parallel = on != 0;
-  if (on > 1) g_ctx.slice_parallel_tiles = on;  // (tuning: on > 1 sets the tile-count threshold)
+  if (on > 100) g_ctx.slice_parallel_tiles = on;  // (tuning: on > 100 sets the tile-count threshold,
+  if (on >= 2 && on <= 100) g_ctx.slice_parallel_min = on;  //  2..100 the minimum slice count)
   return LASER_HIP_OK;
 }
 int laser_hip_set_skinny(int on) {  // A/B knob: streaming kernel for matrix-vector-like shapes
