@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does the tile heuristic pick (close to) the fastest configuration?  For each shape and accumulation mode:
 time the automatic choice and every forced configuration (GPU box).  One JSON line per shape/mode."""
-import json, os, sys
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, laser_amd
 
@@ -15,6 +15,9 @@ if len(sys.argv) > 1:
 def bench(fn, flop):
     reps = max(2, min(40, int(2e-3 / max(flop / 100e12, 1e-6))))
     for _ in range(2): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.02: fn()      # ramp the clocks back up after host-side work
+    torch.cuda.synchronize()
     ts = []
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
