@@ -75,6 +75,12 @@ int laser_hip_set_skinny(int on);
 /* 1 (default): float problems with few output tiles and K >= 4 kc compute Laser's kc slices as one batched launch and
  * fold them with an ordered combine pass (same arithmetic, same order); 0: always the sequential K loop */
 int laser_hip_set_slice_parallel(int on);
+/* 1 (default): a float32 problem whose last round of workgroup tiles would be badly filled is cut along N into a
+ * main launch (whole rounds of the large tile) and a tail launch (small tiles); tiles are independent and every
+ * configuration computes identical bits, so results do not change; 0: always one launch (A/B timing) */
+int laser_hip_set_split_tail(int on);
+/* diagnostics: the column where the last float GEMM / conv launch was cut (0: it ran as one launch) */
+int64_t laser_hip_last_split(void);
 /* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet) */
 int laser_hip_last_f32_config(void);
 /* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */

@@ -828,6 +828,11 @@ int laser_hip_set_slice_parallel(int on) {  // A/B knob: slice-parallel GEMM for
   if (on >= 2 && on <= 100) g_ctx.slice_parallel_min = on;  //  2..100 the minimum slice count)
   return LASER_HIP_OK;
 }
+int laser_hip_set_split_tail(int on) {  // A/B knob: main + tail launches when the last round of tiles is badly filled
+  g_split_tail = on != 0;
+  return LASER_HIP_OK;
+}
+int64_t laser_hip_last_split(void) { return g_last_split; }
 int laser_hip_set_skinny(int on) {  // A/B knob: streaming kernel for matrix-vector-like shapes
   g_ctx.skinny = on != 0;
   return LASER_HIP_OK;
@@ -838,13 +843,6 @@ int laser_hip_set_transpose_variant(int v) {  // tuning only (scripts/transpose_
 }
 int laser_hip_set_conv_implicit(int on) {
   g_ctx.conv_implicit = on != 0;
-  return LASER_HIP_OK;
-}
-// tuning probe (not declared in laser_hip.h): contiguous row-major device operands, multiples of 256
-int laser_hip_probe_f32_dev(int64_t n, const float *A, const float *B, float *C, int dbg, void *stream) {
-  if (int rc = ensure_init()) return rc;
-  GemmArgs<float> a = make_args<float>(1, n, n, n, 1.0f, A, n, 1, 0, B, n, 1, 0, 0.0f, C, n, 1, 0);
-  HIP_TRY(launch_gemm_f32_probe(a, dbg, (hipStream_t)stream));
   return LASER_HIP_OK;
 }
 const char *laser_hip_f32_config_name(int cfg) { return gemm_f32_config_name(cfg); }

@@ -3,7 +3,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace laser_hip {
+
+// One-time-per-DEVICE initialisation of a kernel (hipFuncSetAttribute acts on the current device's instance of the
+// function): a single process may drive all 8 GPUs of a node (the sharded entry points), so "done" is a bit per
+// device ordinal, not a per-process flag.
+struct PerDeviceOnce {
+  std::atomic<uint64_t> mask{0};
+  template <typename F>
+  hipError_t run(F &&f) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = f();
+    if (e == hipSuccess) mask.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
 
 // One (possibly batched) strided GEMM problem: C <- alpha*A*B + beta*C, element X[r,c] at
 // X[r*rs + c*cs] (strides in elements) -- the MatrixView triple of gemm_utils.nim:36-60.
@@ -37,6 +57,10 @@ struct GemmArgs {
   int32_t act;  // laser_hip_activation
   int32_t cRp, cPWs, cCHM;  // LOAD_CONV_PATCH: patch rows per channel, patch row stride (floats), channels per K-tile
   int32_t cdc, cdr, cdq;  // per-K-tile advance of the implicit-GEMM loader's (channel, kernel row, kernel col): BK = cdc*kH*kW + cdr*kW + cdq
+  // First column of C this launch computes: the launch covers columns [col0, N).  Lets one problem be cut into a
+  // "main" launch of whole rounds of large tiles (N = the cut) and a "tail" launch of small tiles (col0 = the cut);
+  // tiles are independent and every configuration is bit-identical, so the result does not depend on the cut.
+  int64_t col0;
 };
 
 // How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of
@@ -62,7 +86,6 @@ hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_orde
 hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
 // args.B = NCHW input, args.bsB = C*H*W, args.c* = geometry, N = oH*oW, K = C*kH*kW; A = filter
 hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
-hipError_t launch_gemm_f32_probe(const GemmArgs<float> &args, int dbg, hipStream_t s);
 int gemm_f32_config_count();
 const char *gemm_f32_config_name(int cfg);
 
@@ -78,6 +101,8 @@ size_t gemm_i32_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
 
 extern int g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
+extern int g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches
+extern int64_t g_last_split;    // diagnostics: column cut of the last MFMA launch (0 = one launch)
 extern int g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used
 extern int g_transpose_variant;  // tuning knob, 0 = production form
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,

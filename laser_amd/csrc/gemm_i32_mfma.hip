@@ -288,12 +288,11 @@ hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &a, void *ws, hipStream_
   static_assert(lds <= 160 * 1024, "LDS budget");
   const bool need_fold = Kpad > IFOLD_K;
   auto kern = need_fold ? gemm_i8limb_kernel<true> : gemm_i8limb_kernel<false>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[need_fold]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done[need_fold] = true;
-  }
+  static PerDeviceOnce attr[2];  // per kernel variant, per device
+  e = attr[need_fold].run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  if (e != hipSuccess) return e;
   I8Args g;
   g.Ap = Ap; g.Bp = Bp;
   g.planeA = Mpad * Kpad; g.planeB = Npad * Kpad; g.Kpad = Kpad;

@@ -79,38 +79,87 @@ static int64_t tiles_of(const GemmArgs<E> &a, int bm, int bn) {
 // This is what makes 4100^3 take 128x128 tiles instead of 256x256 (2 rounds, the second 13 % full) and
 // 1024^3..3072^3 take the 64x64 tiles (62 / 74 / 101 / 106 TFLOP/s measured vs 25 / 58 / 101 / 98 on 128x128).
 constexpr int kCfgBig = 0, kCfgWide = 1, kCfgMid = 2, kCfgSmall = 3, kCfgWideExact = 4;
-static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = false, bool conv = false) {
-  struct Cand {
-    int cfg, bm, bn;
-    double fast, laser, conv_fast, conv_laser;  // TFLOP/s at full residency; conv_*: with the gathering B loader (C4)
-    int r_fast, r_laser;                        // co-resident workgroups per CU
-    double occ[4];                              // relative CU throughput with 1..4 workgroups resident
-    bool gen;
-  };
-  static const Cand cands[] = {
-      {kCfgBig, 256, 256, 141.5, 0.0, 124.7, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},
-      {kCfgWideExact, 256, 128, 136.1, 133.8, 117.0, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},  // (laser-order gather would spill: cfg 1)
-      {kCfgWide, 256, 128, 134.0, 131.1, 116.0, 117.0, 2, 1, {0.95, 1.0, 1.0, 1.0}, false},
-      {kCfgMid, 128, 128, 136.4, 130.0, 119.0, 114.0, 3, 2, {0.755, 0.93, 1.0, 1.0}, true},
-      {kCfgSmall, 64, 64, 120.8, 118.8, 99.0, 98.0, 4, 3, {0.45, 0.75, 0.92, 1.0}, true},
-  };
+struct Cand {
+  int cfg, bm, bn;
+  double fast, laser, conv_fast, conv_laser;  // TFLOP/s at full residency; conv_*: with the gathering B loader (C4)
+  int r_fast, r_laser;                        // co-resident workgroups per CU
+  double occ[4];                              // relative CU throughput with 1..4 workgroups resident
+  bool gen;
+};
+static const Cand kCands[] = {
+    {kCfgBig, 256, 256, 141.5, 0.0, 124.7, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},
+    {kCfgWideExact, 256, 128, 136.1, 133.8, 117.0, 0.0, 1, 1, {1.0, 1.0, 1.0, 1.0}, false},  // (laser-order gather would spill: cfg 1)
+    {kCfgWide, 256, 128, 134.0, 131.1, 116.0, 117.0, 2, 1, {0.95, 1.0, 1.0, 1.0}, false},
+    {kCfgMid, 128, 128, 136.4, 130.0, 119.0, 114.0, 3, 2, {0.755, 0.93, 1.0, 1.0}, true},
+    {kCfgSmall, 64, 64, 120.8, 118.8, 99.0, 98.0, 4, 3, {0.45, 0.75, 0.92, 1.0}, true},
+};
+// predicted time of `tiles` tiles of candidate c, in units of (tile area / TFLOP/s): seconds = units * 2K * 256 / 1e12
+static double cand_time(const Cand &c, int64_t tiles, bool exact, bool conv) {
+  const double speed = conv ? (exact ? c.conv_laser : c.conv_fast) : (exact ? c.laser : c.fast);
+  if (speed <= 0.0) return 1e300;
+  const int R = exact ? c.r_laser : c.r_fast;
+  const int64_t slots = 256 * (int64_t)R;
+  const int64_t q = tiles / slots, rem = tiles % slots;
+  const int w = (int)((rem + 255) / 256);
+  const double tail = w ? (double)w * c.occ[R - 1] / c.occ[w - 1] : 0.0;
+  return ((double)(q * R) + tail) * c.bm * c.bn / speed;
+}
+static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = false, bool conv = false, double *t_out = nullptr) {
   int best = kCfgSmall;
   double best_t = 1e300;
-  for (const Cand &c : cands) {
-    const double speed = conv ? (exact ? c.conv_laser : c.conv_fast) : (exact ? c.laser : c.fast);
-    if (speed <= 0.0 || (need_gen && !c.gen)) continue;
-    const int R = exact ? c.r_laser : c.r_fast;
-    const int64_t tiles = tiles_of(a, c.bm, c.bn), slots = 256 * (int64_t)R;
-    const int64_t q = tiles / slots, rem = tiles % slots;
-    const int w = (int)((rem + 255) / 256);
-    const double tail = w ? (double)w * c.occ[R - 1] / c.occ[w - 1] : 0.0;
-    const double t = ((double)(q * R) + tail) * c.bm * c.bn / speed;
+  for (const Cand &c : kCands) {
+    if (need_gen && !c.gen) continue;
+    const double t = cand_time(c, tiles_of(a, c.bm, c.bn), exact, conv);
     if (t < best_t * 0.999) {  // ties go to the earlier (larger-tile) candidate: less L2 traffic
       best_t = t;
       best = c.cfg;
     }
   }
+  if (t_out) *t_out = best_t;
   return best;
+}
+
+// Main + tail cut.  The round model above says where a single tile configuration loses: the last, under-filled round
+// (C4's 1600 tiles of 128x128 on 512 resident slots are 3.125 rounds and cost 3.6).  Output tiles are independent
+// and every configuration is bit-identical, so the columns are cut at n_cut (a multiple of the main tile's BN):
+// the main launch covers [0, n_cut) in (nearly) whole rounds of large tiles, the tail launch [n_cut, N) with a
+// smaller tile.  Taken only when the model predicts >= 3 % (boundary between the launches ~3 us priced in).
+struct SplitPlan {
+  int cfg_main = -1, cfg_tail = -1;
+  int64_t n_cut = 0;  // 0: one launch
+};
+int g_split_tail = 1;  // knob (laser_hip_set_split_tail): 0 = never cut
+int64_t g_last_split = 0;  // diagnostics: column cut of the last MFMA GEMM / conv launch (0: single launch)
+static SplitPlan plan_split(const GemmArgs<float> &a, bool exact, bool need_gen, bool conv, bool bn_multiple_only) {
+  SplitPlan p;
+  double t_single;
+  p.cfg_main = heuristic_cfg(a, exact, need_gen, conv, &t_single);
+  if (!g_split_tail) return p;
+  const double boundary = 3.0e6 / (512.0 * (double)a.K);  // ~3 us in model units
+  double best = t_single * 0.97;
+  for (const Cand &c : kCands) {
+    if (need_gen && !c.gen) continue;
+    const int64_t tm = (a.M + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn;
+    if (tm * tn * a.batch < 256) continue;  // under one round: other mechanisms (slice-parallel, small tiles) apply
+    for (int64_t k = tn - 1; k >= 1 && k >= tn - 16; k--) {
+      const double t_main = cand_time(c, tm * k * a.batch, exact, conv);
+      if (t_main >= best) continue;
+      const int64_t n_tail = a.N - k * c.bn;
+      for (const Cand &d : kCands) {
+        if ((need_gen && !d.gen) || d.bm * d.bn >= c.bm * c.bn) continue;
+        if (bn_multiple_only && (k * c.bn) % d.bn != 0) continue;
+        const int64_t tt = ((a.M + d.bm - 1) / d.bm) * ((n_tail + d.bn - 1) / d.bn) * a.batch;
+        const double t = t_main + cand_time(d, tt, exact, conv) + boundary;
+        if (t < best) {
+          best = t;
+          p.cfg_main = c.cfg;
+          p.cfg_tail = d.cfg;
+          p.n_cut = k * c.bn;
+        }
+      }
+    }
+  }
+  return p;
 }
 static int fallback_exact_cfg(const GemmArgs<float> &) { return kCfgWideExact; }
 static int gen_cfg(const GemmArgs<float> &a, bool exact) { return heuristic_cfg(a, exact, true); }
@@ -123,24 +172,12 @@ static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 int g_conv_patch = 1;     // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
 int g_last_f32_cfg = -1;  // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
+// one launch of configuration `cfg` (falling back to a configuration with the scalar loaders when the operands need them)
 template <typename E>
-static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, int ncfg, int cfg, bool laser_order,
-                              int kc_elems, hipStream_t s) {
-  if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
-  GemmArgs<E> a = args;
-  if (a.Mext < a.M) a.Mext = a.M;
-  if (a.Next < a.N) a.Next = a.N;
-  if (a.Kext < a.K) a.Kext = a.K;
-  a.dbg = 0;
-  // K <= kc is ONE accumulation slice: the single-chain kernel already is Laser's arithmetic, so the
-  // second accumulator set of the laser-order kernels is only paid for when K > kc.
-  const bool exact = laser_order && a.K > kc_elems;
-  a.kc = exact ? kc_elems : 0;  // gemm_tiling.nim:310: kc = 2048 / sizeof(T)
-  if (cfg < 0 || cfg >= ncfg) cfg = heuristic_cfg(a, exact);
-  if (exact && !cfgs[cfg].exact) cfg = fallback_exact_cfg(a);
+static hipError_t launch_mfma_cfg(const GemmArgs<E> &a, const CfgInfo<E> *cfgs, int cfg, bool exact, hipStream_t s) {
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo<E> &c = cfgs[cfg];
-    if (std::is_same<E, float>::value) g_last_f32_cfg = cfg;
+    if (std::is_same<E, float>::value && a.col0 == 0) g_last_f32_cfg = cfg;
     bool va, vb, ea, eb;
     const int am = pick_mode<E>(a.A, a.rsA, a.csA, a.bsA, a.Mext, a.Kext, c.bm, c.bk, &va, &ea);
     const int bm = pick_mode<E>(a.B, a.csB, a.rsB, a.bsB, a.Next, a.Kext, c.bn, c.bk, &vb, &eb);
@@ -152,6 +189,46 @@ static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, i
   return hipErrorInvalidValue;
 }
 
+static SplitPlan plan_for(const GemmArgs<float> &a, bool exact) { return plan_split(a, exact, false, false, false); }
+static SplitPlan plan_for(const GemmArgs<double> &a, bool exact) {
+  SplitPlan p;
+  p.cfg_main = heuristic_cfg(a, exact);
+  return p;
+}
+
+template <typename E>
+static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, int ncfg, int cfg, bool laser_order,
+                              int kc_elems, hipStream_t s) {
+  if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
+  GemmArgs<E> a = args;
+  const bool plain_n = a.Next <= a.N;  // not a tile-padded pre-pack image: the readable extent is N itself
+  if (a.Mext < a.M) a.Mext = a.M;
+  if (a.Next < a.N) a.Next = a.N;
+  if (a.Kext < a.K) a.Kext = a.K;
+  a.dbg = 0;
+  a.col0 = 0;
+  // K <= kc is ONE accumulation slice: the single-chain kernel already is Laser's arithmetic, so the
+  // second accumulator set of the laser-order kernels is only paid for when K > kc.
+  const bool exact = laser_order && a.K > kc_elems;
+  a.kc = exact ? kc_elems : 0;  // gemm_tiling.nim:310: kc = 2048 / sizeof(T)
+  SplitPlan plan;
+  if (cfg < 0 || cfg >= ncfg)
+    plan = plan_for(a, exact);
+  else
+    plan.cfg_main = cfg;
+  if (exact && !cfgs[plan.cfg_main].exact) plan.cfg_main = fallback_exact_cfg(a);
+  g_last_split = plan.n_cut;
+  if (plan.n_cut <= 0) return launch_mfma_cfg<E>(a, cfgs, plan.cfg_main, exact, s);
+  GemmArgs<E> m = a;  // columns [0, n_cut): whole tiles of the main configuration
+  m.N = plan.n_cut;
+  if (plain_n) m.Next = plan.n_cut;
+  hipError_t e = launch_mfma_cfg<E>(m, cfgs, plan.cfg_main, exact, s);
+  if (e != hipSuccess) return e;
+  GemmArgs<E> t = a;  // columns [n_cut, N)
+  t.col0 = plan.n_cut;
+  return launch_mfma_cfg<E>(t, cfgs, plan.cfg_tail, exact, s);
+}
+
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
   return launch_mfma<float>(args, kCfgsF32, LH_F32_NUM_CONFIGS, cfg, laser_order, 512, s);
 }
@@ -160,22 +237,11 @@ hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipSt
   return launch_mfma<double>(args, kCfgsF64, LH_F64_NUM_CONFIGS, -1, laser_order, 256, s);
 }
 
-// Implicit-GEMM convolution: same kernels, B loader = LOAD_IM2COL.  M = C_out, N = oH*oW, K = C_in*kH*kW,
-// batch = images; A (the filter bank) is always k-contiguous.
-hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
-  if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
-  GemmArgs<float> a = args;
-  a.Mext = a.M; a.Next = a.N; a.Kext = a.K;
-  a.dbg = 0;
-  const bool exact = laser_order && a.K > 512;
-  a.kc = exact ? 512 : 0;
-  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS) cfg = heuristic_cfg(a, exact, false, true);
-  if (exact && !kCfgsF32[cfg].exact) cfg = kCfgWideExact;
-  // the BK=32 laser-order kernel has no registers left for the gather state (it would spill): same tile at BK=16
-  if (exact && cfg == kCfgWideExact) cfg = kCfgWide;
+// one launch of the implicit-GEMM convolution with configuration `cfg`
+static hipError_t launch_conv_cfg(const GemmArgs<float> &a, int cfg, bool exact, hipStream_t s) {
   for (int attempt = 0; attempt < 2; attempt++) {
     const CfgInfo<float> &c = kCfgsF32[cfg];
-    g_last_f32_cfg = cfg;
+    if (a.col0 == 0) g_last_f32_cfg = cfg;
     bool va, ea;
     pick_mode<float>(a.A, a.rsA, a.csA, a.bsA, a.M, a.K, c.bm, c.bk, &va, &ea);
     // B through an LDS-resident input patch when it fits the B region of a stage (else the per-element gather)
@@ -189,6 +255,39 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     cfg = heuristic_cfg(a, exact, true, true);
   }
   return hipErrorInvalidValue;
+}
+
+// Implicit-GEMM convolution: same kernels, B loader = LOAD_IM2COL / LOAD_CONV_PATCH.  M = C_out, N = oH*oW,
+// K = C_in*kH*kW, batch = images; A (the filter bank) is always k-contiguous.
+hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
+  if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
+  GemmArgs<float> a = args;
+  a.Mext = a.M; a.Next = a.N; a.Kext = a.K;
+  a.dbg = 0;
+  a.col0 = 0;
+  const bool exact = laser_order && a.K > 512;
+  a.kc = exact ? 512 : 0;
+  // the BK=32 laser-order kernel has no registers left for the gather state (it would spill): same tile at BK=16
+  auto fix = [&](int c) {
+    if (exact && !kCfgsF32[c].exact) c = kCfgWideExact;
+    if (exact && c == kCfgWideExact) c = kCfgWide;
+    return c;
+  };
+  SplitPlan plan;
+  if (cfg < 0 || cfg >= LH_F32_NUM_CONFIGS)
+    plan = plan_split(a, exact, false, true, false);
+  else
+    plan.cfg_main = cfg;
+  plan.cfg_main = fix(plan.cfg_main);
+  g_last_split = plan.n_cut;
+  if (plan.n_cut <= 0) return launch_conv_cfg(a, plan.cfg_main, exact, s);
+  GemmArgs<float> m = a;  // output pixels [0, n_cut) of every image
+  m.N = plan.n_cut; m.Next = plan.n_cut;
+  hipError_t e = launch_conv_cfg(m, plan.cfg_main, exact, s);
+  if (e != hipSuccess) return e;
+  GemmArgs<float> t = a;  // output pixels [n_cut, oH*oW)
+  t.col0 = plan.n_cut;
+  return launch_conv_cfg(t, fix(plan.cfg_tail), exact, s);
 }
 
 }  // namespace laser_hip

@@ -37,6 +37,9 @@
 #ifndef LH_KQ
 #define LH_KQ 1  // k-quad LDS image for k-contiguous fp32 operands (0: the k-major image everywhere, for A/B runs)
 #endif
+#ifndef LH_FOLD_SCALAR
+#define LH_FOLD_SCALAR 1  // alpha == 1 laser-order slice fold as scalar v_add_f32 (0: vector-typed -> v_pk_add_f32, for A/B runs)
+#endif
 #include <type_traits>
 
 #include "common.h"
@@ -85,6 +88,24 @@ struct Mma<float> {
     const Acc t = ab * alpha;
     return run + t;
   }
+  // alpha == 1: 1*x is x bit for bit, the multiply is dropped; 16 scalar v_add_f32 per accumulator block, as
+  // inline asm so that the SLP vectoriser cannot pair them up: packed f32 VALU beside MFMAs costs ~13 cycles per
+  // instruction more than the scalar form (MI355X_MICROARCH.md "price of one filler beside MFMAs"), and this
+  // block rides between two MFMAs of the fold tile
+  static __device__ __forceinline__ Acc fold_acc1(Acc run, Acc ab) {
+#if LH_FOLD_SCALAR
+#pragma unroll
+    for (int e = 0; e < ACC; e++) {
+      float r = run[e];
+      asm("v_add_f32 %0, %0, %1" : "+v"(r) : "v"(ab[e]));
+      run[e] = r;
+    }
+    return run;
+#else
+#pragma clang fp contract(off)
+    return run + ab;
+#endif
+  }
 };
 template <>
 struct Mma<double> {
@@ -111,6 +132,10 @@ struct Mma<double> {
 #pragma clang fp contract(off)
     const Acc t = ab * alpha;
     return run + t;
+  }
+  static __device__ __forceinline__ Acc fold_acc1(Acc run, Acc ab) {
+#pragma clang fp contract(off)
+    return run + ab;
   }
 };
 
@@ -524,8 +549,10 @@ struct TileLoader {
 // Fragments are register double-buffered (k-step j+1 is read from LDS while step j's MFMAs issue).
 //
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for.
+// A1: the launcher saw alpha == 1 (the only value any reference caller uses): 1*x is x bit for bit, so the laser-order
+// slice fold drops its multiply -- 16 scalar adds per accumulator block between two MFMAs instead of 32 operations.
 template <typename E, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
-          bool DBG = false, bool EPI = false>
+          bool DBG = false, bool EPI = false, bool A1 = false>
 __global__ void __launch_bounds__(WM *WN * 64, OCC)
     gemm_mfma_kernel(const GemmArgs<E> g) {
   using M_ = Mma<E>;
@@ -559,7 +586,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   const int gsz = min(g.tiles_m - first_m, GROUP_M);
   const int pid_m = first_m + (wgid % width) % gsz;
   const int pid_n = (wgid % width) / gsz;
-  const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN;
+  const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN + g.col0;
   const int64_t bz = blockIdx.y;
 
   const int t = threadIdx.x;
@@ -881,7 +908,10 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 #pragma unroll
             for (int n = 0; n < TN; n++) {
               if (fold_here && gi == 0 && u == 0) {
-                run[EXACT ? i : 0][EXACT ? n : 0] = M_::fold_acc(run[EXACT ? i : 0][EXACT ? n : 0], acc[i][n], alpha);
+                if constexpr (A1)
+                  run[EXACT ? i : 0][EXACT ? n : 0] = M_::fold_acc1(run[EXACT ? i : 0][EXACT ? n : 0], acc[i][n]);
+                else
+                  run[EXACT ? i : 0][EXACT ? n : 0] = M_::fold_acc(run[EXACT ? i : 0][EXACT ? n : 0], acc[i][n], alpha);
                 acc[i][n] = M_::mma(fa[0][0][i], fb[0][0][n], Acc{});
               } else {
                 acc[i][n] = M_::mma(fa[gi & 1][u][i], fb[gi & 1][u][n], acc[i][n]);
@@ -969,21 +999,20 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 
 // ---- per-configuration launcher ---------------------------------------------------------------------
 template <typename E, int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool EXACT, int STAGES, int OCC,
-          bool DBG = false, bool EPI = false>
+          bool DBG = false, bool EPI = false, bool A1 = false>
 hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
-  auto kern = gemm_mfma_kernel<E, BM, BN, BK, WM, WN, AMODE, BMODE, EXACT, STAGES, OCC, DBG, EPI>;
+  auto kern = gemm_mfma_kernel<E, BM, BN, BK, WM, WN, AMODE, BMODE, EXACT, STAGES, OCC, DBG, EPI, A1>;
   constexpr size_t lds = (size_t)STAGES * BK * (BM + BN) * sizeof(E);
   static_assert(lds <= 160 * 1024, "LDS budget is 160 KiB per CU");
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static PerDeviceOnce attr;  // one per instantiation
+  if (hipError_t e = attr.run([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      });
+      e != hipSuccess)
+    return e;
   GemmArgs<E> g = a;
   g.tiles_m = (int)((a.M + BM - 1) / BM);
-  g.tiles_n = (int)((a.N + BN - 1) / BN);
+  g.tiles_n = (int)((a.N - a.col0 + BN - 1) / BN);
   if constexpr (BMODE == LOAD_CONV_PATCH) {
     const int khw = a.ckH * a.ckW;
     g.cdc = BK / khw;
@@ -1009,10 +1038,17 @@ hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
 template <typename E, int BM, int BN, int BK, int WM, int WN, int STAGES, int OCC, bool WITH_VEC, bool WITH_GEN, bool EXACT>
 hipError_t launch_cfg_mode(const GemmArgs<E> &a, int amode, int bmode, hipStream_t s) {
   const bool fused = a.bias != nullptr || a.act != 0;  // fused epilogue: separate instantiation
+  // alpha == 1 variant of the laser-order kernels (plain epilogue, float32 only: the headline path)
+  const bool a1 = EXACT && std::is_same<E, float>::value && !fused && a.alpha == (E)1;
+  (void)a1;
 #define LH_CASE(AM, BMD) \
-  if (amode == AM && bmode == BMD)                                                                           \
+  if (amode == AM && bmode == BMD) {                                                                          \
+    if constexpr (EXACT && std::is_same<E, float>::value) {                                                    \
+      if (a1) return launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC, false, false, true>(a, s);  \
+    }                                                                                                          \
     return fused ? launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC, false, true>(a, s)            \
-                 : launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC, false, false>(a, s);
+                 : launch_one<E, BM, BN, BK, WM, WN, AM, BMD, EXACT, STAGES, OCC, false, false>(a, s);          \
+  }
   if constexpr (WITH_VEC) {
     LH_CASE(LOAD_VEC_K, LOAD_VEC_X)
     LH_CASE(LOAD_VEC_K, LOAD_VEC_K)
@@ -1022,7 +1058,10 @@ hipError_t launch_cfg_mode(const GemmArgs<E> &a, int amode, int bmode, hipStream
     LH_CASE(LOAD_VEC_K_EDGE, LOAD_VEC_K_EDGE)
     LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_X_EDGE)
     LH_CASE(LOAD_VEC_X_EDGE, LOAD_VEC_K_EDGE)
-    if constexpr (std::is_same<E, float>::value) {
+    // (the laser-order 256x128x32 kernel has no registers left for the gather state -- the conv launcher maps it
+    // to the BK = 16 form of the same tile -- so its conv instantiations are not built at all)
+    constexpr bool CONV_OK = !(EXACT && BM == 256 && BN == 128 && BK == 32);
+    if constexpr (std::is_same<E, float>::value && CONV_OK) {
       LH_CASE(LOAD_VEC_K, LOAD_IM2COL)  // implicit-GEMM conv: filter [C_out][C_in*kH*kW] is k-contiguous
       LH_CASE(LOAD_VEC_K_EDGE, LOAD_IM2COL)
       LH_CASE(LOAD_VEC_K, LOAD_CONV_PATCH)

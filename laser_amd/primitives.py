@@ -104,6 +104,16 @@ def set_slice_parallel(on):
     _lib.check(_lib.lib().laser_hip_set_slice_parallel(int(on)))
 
 
+def set_split_tail(on):
+    """True (default): fp32 problems whose last round of tiles would be badly filled run as main + tail launches."""
+    _lib.check(_lib.lib().laser_hip_set_split_tail(1 if on else 0))
+
+
+def last_split():
+    """Column where the last float GEMM / conv launch was cut into main + tail (0: one launch)."""
+    return _lib.lib().laser_hip_last_split()
+
+
 def set_skinny(on):
     """True (default): M <= 8 or N <= 8 float problems run the streaming (matrix-vector) kernel."""
     _lib.check(_lib.lib().laser_hip_set_skinny(1 if on else 0))

@@ -40,10 +40,13 @@ for (M, N, K) in SHAPES:
             laser_amd.set_f32_config(cfg)
             times[cfg] = bench(lambda: laser_amd.matmul(A, B, 1, 0, C), flop)
             if cfg == -1:
-                chosen = laser_amd.last_f32_config()
+                chosen, cut = laser_amd.last_f32_config(), laser_amd.last_split()
+                laser_amd.set_split_tail(0)
+                nosplit = bench(lambda: laser_amd.matmul(A, B, 1, 0, C), flop)
+                laser_amd.set_split_tail(1)
         best = min((c for c in times if c >= 0), key=lambda c: times[c])
         print(json.dumps({"shape": [M, N, K], "mode": "laser_order" if mode == 0 else "fast", "chosen": names[chosen],
-                          "best": names[best], "auto_ms": round(times[-1], 4), "best_ms": round(times[best], 4),
+                          "best": names[best], "cut": cut, "auto_ms": round(times[-1], 4), "auto_nosplit_ms": round(nosplit, 4), "best_ms": round(times[best], 4),
                           "auto_tflops": round(flop / times[-1] / 1e9, 1), "auto_over_best": round(times[-1] / times[best], 3),
                           "all_ms": {names[c]: round(t, 4) for c, t in times.items() if c >= 0}}), flush=True)
 laser_amd.set_f32_config(-1); laser_amd.set_float_mode(0)
