@@ -212,8 +212,11 @@ int laser_hip_conv2d_im2col_f32(float *output, const float *input, int64_t iN, i
                                 int64_t iH, int64_t iW, const float *kernel, int64_t c_out,
                                 int64_t c_in, int64_t kH, int64_t kW, int64_t padH, int64_t padW,
                                 int64_t strideH, int64_t strideW, float *pworkspace);
-/* Device variant: d_workspace must hold iN * im2col_workspace_size elements (all images are
- * expanded at once and multiplied by one batched GEMM), or may be NULL to use library scratch. */
+/* Device variant.  The default strategy (implicit GEMM) materialises nothing and ignores d_workspace.  On the
+ * explicit path (kernels larger than 8x8, laser_hip_set_conv_implicit(0)) a non-NULL d_workspace is taken to hold
+ * ONE image's im2col matrix -- im2col_workspace_size elements, the reference's contract ("can be reused between
+ * batches", conv2d_im2col.nim:99) -- and the images are processed one by one through it; NULL = stream-ordered
+ * library scratch (hipMallocAsync on `stream`), all images expanded in one pass and multiplied by one batched GEMM. */
 int laser_hip_conv2d_im2col_f32_dev(float *d_output, const float *d_input, int64_t iN, int64_t iC,
                                     int64_t iH, int64_t iW, const float *d_kernel, int64_t c_out,
                                     int64_t c_in, int64_t kH, int64_t kW, int64_t padH,
@@ -287,6 +290,14 @@ int laser_hip_storage_trim(void);
 int laser_hip_storage_upload(void *d_dst, const void *host_src, int64_t bytes);
 int laser_hip_storage_download(void *host_dst, const void *d_src, int64_t bytes);
 int laser_hip_storage_set_zero(void *d_buffer, int64_t bytes, void *stream);
+/* Stream-ordered forms.  The plain storage_alloc completes its zero fill before returning and the plain upload /
+ * download run on the NULL stream, which does NOT wait for non-blocking streams (PyTorch's side streams, any
+ * hipStreamNonBlocking stream): a caller that computes on its own stream uses these so that the zero fill precedes
+ * the first kernel on that stream, an upload follows the last reader and a download follows the producer.  Upload and
+ * download are complete when the call returns. */
+int laser_hip_storage_alloc_stream(void **d_raw_buffer, int64_t bytes, void *stream);
+int laser_hip_storage_upload_stream(void *d_dst, const void *host_src, int64_t bytes, void *stream);
+int laser_hip_storage_download_stream(void *host_dst, const void *d_src, int64_t bytes, void *stream);
 int laser_hip_copy_strided_b32_dev(void *d_dst, const int64_t *dst_strides, const void *d_src,
                                    const int64_t *src_strides, const int64_t *shape, int rank,
                                    void *stream);

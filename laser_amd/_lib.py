@@ -91,6 +91,9 @@ def lib():
     L.laser_hip_storage_upload.argtypes = [vp, vp, i64]
     L.laser_hip_storage_download.argtypes = [vp, vp, i64]
     L.laser_hip_storage_set_zero.argtypes = [vp, i64, vp]
+    L.laser_hip_storage_alloc_stream.argtypes = [C.POINTER(vp), i64, vp]
+    L.laser_hip_storage_upload_stream.argtypes = [vp, vp, i64, vp]
+    L.laser_hip_storage_download_stream.argtypes = [vp, vp, i64, vp]
     for b in ("b32", "b64"):
         getattr(L, f"laser_hip_copy_strided_{b}_dev").argtypes = [vp, C.POINTER(i64), vp, C.POINTER(i64), C.POINTER(i64), ci, vp]
     L.laser_hip_cblas_sgemm.argtypes = [ci, ci, ci, i64, i64, i64, C.c_float, vp, i64, vp, i64, C.c_float, vp, i64]
@@ -122,6 +125,7 @@ def declared_symbols():
              "laser_hip_conv2d_im2col_ex_f32", "laser_hip_conv2d_im2col_ex_f32_dev",
              "laser_hip_storage_alloc", "laser_hip_storage_free", "laser_hip_storage_trim", "laser_hip_storage_upload",
              "laser_hip_storage_download", "laser_hip_storage_set_zero",
+             "laser_hip_storage_alloc_stream", "laser_hip_storage_upload_stream", "laser_hip_storage_download_stream",
              "laser_hip_copy_strided_b32_dev", "laser_hip_copy_strided_b64_dev"]
     for s in _CT:
         names += [f"laser_hip_gemm_strided_{s}", f"laser_hip_gemm_strided_{s}_dev",

@@ -28,7 +28,7 @@ using namespace laser_hip;
 namespace {
 
 thread_local std::string g_err;
-std::mutex g_mu;  // serialises the host-pointer paths (shared scratch) and the handle registry
+std::mutex g_mu;  // guards initialisation and the registries (pre-pack handles, storage free list, host-range registry)
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -62,14 +62,32 @@ struct Context {
   bool slice_parallel = true; // few tiles x long K: kc slices as one batched launch + ordered combine
   bool skinny = true;         // M <= 8 or N <= 8: the streaming kernel (false: always the tiled kernels)
   bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
-  // cached device scratch for the host-pointer paths, one growing buffer per role
-  void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_sz[6] = {0, 0, 0, 0, 0, 0};
+  int shard_devices = 1;      // host-pointer gemm_strided: row panels over this many GPUs (1 = off; laser_hip_set_shard_devices)
 };
 Context g_ctx;
 
+// Per-DEVICE state of the host-pointer paths: cached scratch (one growing buffer per role), the streams of the
+// upload / compute / download pipeline, and a mutex that serialises the host-pointer calls using THIS device.  One
+// process may drive every GPU of the node (the sharded entry points run one host thread per device), so none of this
+// is per process.
+constexpr int kMaxDevices = 16;
+struct DeviceCtx {
+  int device = -1;
+  std::mutex mu;
+  hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
+  void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[6] = {0, 0, 0, 0, 0, 0};
+};
+DeviceCtx g_dev[kMaxDevices];
+// The device a host-pointer call on this thread uses: -1 = the library's default device (laser_hip_init); the
+// sharded entry points set it in their per-device worker threads.
+thread_local int tl_device = -1;
+thread_local DeviceCtx *tl_dev = nullptr;  // valid while a HostCall guard is alive
+
 int ensure_init_locked(int device) {
   if (g_ctx.ready && (device < 0 || device == g_ctx.device)) return LASER_HIP_OK;
+  // (a later init with another ordinal only moves the DEFAULT device of the host-pointer entry points: scratch,
+  // streams and kernel attributes are kept per device, nothing of the previous device is reused)
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -78,7 +96,7 @@ int ensure_init_locked(int device) {
   if (device < 0) {
     HIP_TRY(hipGetDevice(&device));
   } else {
-    if (device >= n) return fail(LASER_HIP_E_INVALID, "device %d out of range (%d devices)", device, n);
+    if (device >= n || device >= kMaxDevices) return fail(LASER_HIP_E_INVALID, "device %d out of range (%d devices)", device, n);
     HIP_TRY(hipSetDevice(device));
   }
   hipDeviceProp_t prop;
@@ -100,17 +118,62 @@ int ensure_init() {
   return ensure_init_locked(-1);
 }
 
-int scratch_get(int slot, size_t bytes, void **out) {
-  if (bytes == 0) bytes = 16;
-  if (g_ctx.scratch_sz[slot] < bytes) {
-    if (g_ctx.scratch[slot]) HIP_TRY(hipFree(g_ctx.scratch[slot]));
-    g_ctx.scratch[slot] = nullptr;
-    g_ctx.scratch_sz[slot] = 0;
-    size_t want = bytes + bytes / 8;  // a little headroom so slowly growing sizes do not thrash
-    HIP_TRY(hipMalloc(&g_ctx.scratch[slot], want));
-    g_ctx.scratch_sz[slot] = want;
+// RAII guard of a host-pointer entry point: makes its device current for the calling thread (another host thread
+// using the host-pointer API would otherwise run on device 0 with this device's buffers), serialises on that device's
+// mutex and publishes its DeviceCtx in tl_dev.
+struct HostCall {
+  int rc = LASER_HIP_OK;
+  DeviceCtx *d = nullptr;
+  DeviceCtx *prev = nullptr;
+  HostCall() {
+    const int dev = tl_device >= 0 ? tl_device : g_ctx.device;
+    if (dev < 0 || dev >= kMaxDevices) {
+      rc = fail(LASER_HIP_E_INVALID, "device %d outside 0..%d", dev, kMaxDevices - 1);
+      return;
+    }
+    const hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) {
+      rc = fail(LASER_HIP_E_HIP, "hipSetDevice(%d): %s", dev, hipGetErrorString(e));
+      return;
+    }
+    d = &g_dev[dev];
+    d->mu.lock();
+    d->device = dev;
+    prev = tl_dev;
+    tl_dev = d;
   }
-  *out = g_ctx.scratch[slot];
+  ~HostCall() {
+    if (d) {
+      tl_dev = prev;
+      d->mu.unlock();
+    }
+  }
+  HostCall(const HostCall &) = delete;
+  HostCall &operator=(const HostCall &) = delete;
+};
+
+int scratch_get(int slot, size_t bytes, void **out) {
+  DeviceCtx &D = *tl_dev;
+  if (bytes == 0) bytes = 16;
+  if (D.scratch_sz[slot] < bytes) {
+    if (D.scratch[slot]) HIP_TRY(hipFree(D.scratch[slot]));
+    D.scratch[slot] = nullptr;
+    D.scratch_sz[slot] = 0;
+    size_t want = bytes + bytes / 8;  // a little headroom so slowly growing sizes do not thrash
+    HIP_TRY(hipMalloc(&D.scratch[slot], want));
+    D.scratch_sz[slot] = want;
+  }
+  *out = D.scratch[slot];
+  return LASER_HIP_OK;
+}
+
+int pipeline_streams() {
+  DeviceCtx &D = *tl_dev;
+  if (!D.s_up) {
+    HIP_TRY(hipStreamCreateWithFlags(&D.s_up, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&D.s_comp, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&D.s_down, hipStreamNonBlocking));
+  }
   return LASER_HIP_OK;
 }
 
@@ -292,10 +355,8 @@ template <typename T>
 int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *Bspan,
                         size_t bn, int64_t rsB, int64_t csB, T beta, T *C, int64_t rsC, int64_t csC, const T *dA0,
                         const T *dB0, T *dBbuf, T *dC0, bool c_up) {
-  if (!g_ctx.s_up) {
-    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.s_up, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.s_comp, hipStreamNonBlocking));
-  }
+  if (int rc = pipeline_streams()) return rc;
+  DeviceCtx &D = *tl_dev;
   int64_t R = (M / 8 + 255) / 256 * 256;  // ~8 panels, whole 256-row tiles
   if (R < 256) R = 256;
   const int nchunks = (int)((M + R - 1) / R);
@@ -320,7 +381,7 @@ int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, in
   std::deque<int> queue;
   bool closed = false;
   hipError_t down_err = hipSuccess;
-  const int device = g_ctx.device;
+  const int device = D.device;
   std::thread downloader([&]() {
     (void)hipSetDevice(device);
     for (;;) {
@@ -362,22 +423,22 @@ int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, in
     }                                                                                                         \
   } while (0)
 
-  PIPE_TRY(hipMemcpyAsync(dBbuf, Bspan, bn * sizeof(T), hipMemcpyHostToDevice, g_ctx.s_up));
+  PIPE_TRY(hipMemcpyAsync(dBbuf, Bspan, bn * sizeof(T), hipMemcpyHostToDevice, D.s_up));
   for (int i = 0; i < nchunks; i++) {
     const int64_t r0 = i * R, r1 = std::min<int64_t>(M, r0 + R);
     int64_t lo, hi;
     a_span(r0, r1, &lo, &hi);
-    PIPE_TRY(hipMemcpyAsync((T *)dA0 + lo, A + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyHostToDevice, g_ctx.s_up));
+    PIPE_TRY(hipMemcpyAsync((T *)dA0 + lo, A + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyHostToDevice, D.s_up));
     if (c_up) {
       c_span(r0, r1, &lo, &hi);
-      PIPE_TRY(hipMemcpyAsync(dC0 + lo, C + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyHostToDevice, g_ctx.s_up));
+      PIPE_TRY(hipMemcpyAsync(dC0 + lo, C + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyHostToDevice, D.s_up));
     }
-    PIPE_TRY(hipEventRecord(ev_up[i], g_ctx.s_up));
-    PIPE_TRY(hipStreamWaitEvent(g_ctx.s_comp, ev_up[i], 0));
+    PIPE_TRY(hipEventRecord(ev_up[i], D.s_up));
+    PIPE_TRY(hipStreamWaitEvent(D.s_comp, ev_up[i], 0));
     GemmArgs<T> a = make_args<T>(1, r1 - r0, N, K, alpha, dA0 + r0 * rsA, rsA, csA, 0, dB0, rsB, csB, 0, beta,
                                  dC0 + r0 * rsC, rsC, csC, 0);
-    PIPE_TRY(run_gemm<T>(a, g_ctx.s_comp));
-    PIPE_TRY(hipEventRecord(ev_comp[i], g_ctx.s_comp));
+    PIPE_TRY(run_gemm<T>(a, D.s_comp));
+    PIPE_TRY(hipEventRecord(ev_comp[i], D.s_comp));
     {
       std::lock_guard<std::mutex> lk(qm);
       queue.push_back(i);
@@ -399,7 +460,8 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   if (int rc = ensure_init()) return rc;
   if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
   if (!A || !B || !C) return fail(LASER_HIP_E_INVALID, "null operand pointer");
-  std::lock_guard<std::mutex> lk(g_mu);
+  HostCall hc;
+  if (hc.rc) return hc.rc;
   int64_t alo, ahi, blo, bhi, clo, chi;
   view_span(M, K, rsA, csA, &alo, &ahi);
   view_span(K, N, rsB, csB, &blo, &bhi);
@@ -471,8 +533,12 @@ std::unordered_map<uint64_t, DevPanel> g_panels;
 
 // device tensor storage: live blocks (ptr -> rounded size) and the free list keyed by size
 constexpr size_t kStorageCacheMax = (size_t)32 << 30;
+// live blocks: ptr -> key; free list keyed by the same key = rounded size | device ordinal << 56 (a block is only
+// ever handed back to a caller on the device it was allocated on)
 std::unordered_map<void *, size_t> g_live_storage;
 std::unordered_map<size_t, std::vector<void *>> g_free_storage;
+inline size_t storage_key(size_t rounded, int dev) { return rounded | ((size_t)(dev & 0xff) << 56); }
+inline size_t storage_size(size_t key) { return key & (((size_t)1 << 56) - 1); }
 size_t g_free_storage_bytes = 0;
 void storage_trim() {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -514,7 +580,8 @@ int prepack_host(bool is_a, void *dst, int64_t M, int64_t N, int64_t K, const T 
     return fail(LASER_HIP_E_INVALID, "The destination pointer must be 64-byte aligned");
   if (M < 0 || N < 0 || K < 0) return fail(LASER_HIP_E_INVALID, "negative dimension");
   if (int rc = ensure_init()) return rc;
-  std::lock_guard<std::mutex> lk(g_mu);
+  HostCall hc;
+  if (hc.rc) return hc.rc;
   const int64_t R = is_a ? M : K, Cc = is_a ? K : N;
   int64_t lo, hi;
   view_span(std::max<int64_t>(R, 1), std::max<int64_t>(Cc, 1), rs, cs, &lo, &hi);
@@ -538,6 +605,7 @@ int prepack_host(bool is_a, void *dst, int64_t M, int64_t N, int64_t K, const T 
   h.M = M; h.N = N; h.K = K;
   h.is_a = is_a ? 1 : 0;
   h.elem = (int32_t)sizeof(T);
+  std::lock_guard<std::mutex> lk(g_mu);  // the handle registry
   // re-packing into a buffer that still holds a live handle releases the old panel first
   PackHandle old;
   memcpy(&old, dst, sizeof old);
@@ -598,10 +666,14 @@ int packed_host(int64_t M, int64_t N, int64_t K, T alpha, const void *pA, const 
   if (int rc = ensure_init()) return rc;
   if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
   if (!C) return fail(LASER_HIP_E_INVALID, "null pointer");
-  std::lock_guard<std::mutex> lk(g_mu);
+  HostCall hc;
+  if (hc.rc) return hc.rc;
   void *dA, *dB, *dC;
-  if (int rc = resolve_handle(pA, true, (int)sizeof(T), M, N, K, &dA)) return rc;
-  if (int rc = resolve_handle(pB, false, (int)sizeof(T), M, N, K, &dB)) return rc;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);  // the handle registry
+    if (int rc = resolve_handle(pA, true, (int)sizeof(T), M, N, K, &dA)) return rc;
+    if (int rc = resolve_handle(pB, false, (int)sizeof(T), M, N, K, &dB)) return rc;
+  }
   int64_t clo, chi;
   view_span(M, N, rsC, csC, &clo, &chi);
   const size_t cn = (size_t)(chi - clo + 1);
@@ -620,7 +692,8 @@ int transpose_host(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC
   const size_t bytes = (size_t)N * NR * NC * elem;
   if (bytes == 0) return LASER_HIP_OK;
   if (!dst || !src) return fail(LASER_HIP_E_INVALID, "null pointer");
-  std::lock_guard<std::mutex> lk(g_mu);
+  HostCall hc;
+  if (hc.rc) return hc.rc;
   void *ds, *dd;
   if (int rc = scratch_get(0, bytes, &ds)) return rc;
   if (int rc = scratch_get(2, bytes, &dd)) return rc;
@@ -760,11 +833,24 @@ int laser_hip_init(int device) {
 
 int laser_hip_finalize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (int i = 0; i < 6; i++) {
-    if (g_ctx.scratch[i]) (void)hipFree(g_ctx.scratch[i]);
-    g_ctx.scratch[i] = nullptr;
-    g_ctx.scratch_sz[i] = 0;
+  for (DeviceCtx &D : g_dev) {
+    if (D.device < 0) continue;
+    std::lock_guard<std::mutex> dl(D.mu);
+    (void)hipSetDevice(D.device);
+    for (int i = 0; i < 6; i++) {
+      if (D.scratch[i]) (void)hipFree(D.scratch[i]);
+      D.scratch[i] = nullptr;
+      D.scratch_sz[i] = 0;
+    }
+    if (D.s_up) {
+      (void)hipStreamDestroy(D.s_up);
+      (void)hipStreamDestroy(D.s_comp);
+      (void)hipStreamDestroy(D.s_down);
+      D.s_up = D.s_comp = D.s_down = nullptr;
+    }
+    D.device = -1;
   }
+  if (g_ctx.device >= 0) (void)hipSetDevice(g_ctx.device);
   for (auto &kv : g_panels) (void)hipFree(kv.second.ptr);
   g_panels.clear();
   for (auto &kv : g_free_storage)
@@ -774,11 +860,6 @@ int laser_hip_finalize(void) {
     }
   g_free_storage.clear();
   g_free_storage_bytes = 0;
-  if (g_ctx.s_up) {
-    (void)hipStreamDestroy(g_ctx.s_up);
-    (void)hipStreamDestroy(g_ctx.s_comp);
-    g_ctx.s_up = g_ctx.s_comp = nullptr;
-  }
   g_ctx.ready = false;
   return LASER_HIP_OK;
 }
@@ -978,7 +1059,8 @@ int laser_hip_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int
   if (int rc = ensure_init()) return rc;
   if (!ws || !in) return fail(LASER_HIP_E_INVALID, "null pointer");
   if (oH < 0 || oW < 0 || iC <= 0 || sH <= 0 || sW <= 0) return fail(LASER_HIP_E_INVALID, "bad shape");
-  std::lock_guard<std::mutex> lk(g_mu);
+  HostCall hc;
+  if (hc.rc) return hc.rc;
   const size_t ib = (size_t)iC * iH * iW * 4, wb = (size_t)iC * kH * kW * oH * oW * 4;
   if (wb == 0) return LASER_HIP_OK;
   void *di, *dw;
@@ -993,33 +1075,60 @@ int laser_hip_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int
 static int conv2d_api_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
                                     int64_t iW, const float *dker, int64_t c_out, int64_t c_in, int64_t kH,
                                     int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
-                                    const float *dbias, int act, void *stream) {
+                                    int64_t dws_elems, const float *dbias, int act, void *stream) {
   if (int rc = conv_check(iN, iC, iH, iW, c_out, c_in, kH, kW, pH, pW, sH, sW)) return rc;
   if (int rc = ensure_init()) return rc;
   if (iN == 0) return LASER_HIP_OK;
   if (!dout || !din || !dker) return fail(LASER_HIP_E_INVALID, "null pointer");
   if (iN > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
-  if (!dws && !conv_takes_implicit(iC, iH, iW, kH, kW, pH, pW, sH, sW)) {
-    int64_t oH, oW;
-    out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
-    std::lock_guard<std::mutex> lk(g_mu);
-    void *p;
-    if (int rc = scratch_get(4, (size_t)iN * iC * kH * kW * oH * oW * 4, &p)) return rc;
-    dws = (float *)p;
+  hipStream_t s = (hipStream_t)stream;
+  const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
+  if (direct || conv_takes_implicit(iC, iH, iW, kH, kW, pH, pW, sH, sW))  // nothing is materialised
+    return conv_dev(dout, din, iN, iC, iH, iW, dker, c_out, kH, kW, pH, pW, sH, sW, nullptr, s, dbias, act);
+  // Explicit im2col path (kernels larger than 8x8, huge images, laser_hip_set_conv_implicit(0)).  The caller's
+  // workspace follows the REFERENCE's contract -- one image, im2col_workspace_size elements
+  // (conv2d_im2col.nim:19-20, reused between batches :99) -- so it is used as what it is: a caller that hands
+  // over iN images' worth gets them all expanded in one pass, one image's worth is looped over image by image,
+  // anything smaller is rejected, and no workspace means stream-ordered library scratch (never a buffer shared
+  // between streams).
+  int64_t oH, oW;
+  out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
+  const int64_t w1 = iC * kH * kW * oH * oW;
+  if (dws && dws_elems >= 0 && dws_elems < w1)
+    return fail(LASER_HIP_E_INVALID, "im2col workspace holds %lld elements, one image needs %lld", (long long)dws_elems, (long long)w1);
+  float *own = nullptr;
+  int64_t imgs = iN;  // images expanded per pass
+  if (!dws) {
+    while (imgs > 1 && (double)imgs * (double)w1 * 4.0 > 2.0e9) imgs = (imgs + 1) / 2;  // bound the scratch
+    HIP_TRY(hipMallocAsync((void **)&own, (size_t)imgs * (size_t)w1 * 4, s));
+    dws = own;
+  } else {
+    // capacity unknown (the plain entry points): the reference's contract is ONE image's worth -> image by image
+    imgs = dws_elems >= 0 ? std::max<int64_t>(1, std::min<int64_t>(iN, dws_elems / w1)) : 1;
   }
-  return conv_dev(dout, din, iN, iC, iH, iW, dker, c_out, kH, kW, pH, pW, sH, sW, dws, (hipStream_t)stream, dbias, act);
+  int rc = LASER_HIP_OK;
+  for (int64_t n0 = 0; n0 < iN && rc == LASER_HIP_OK; n0 += imgs) {
+    const int64_t nb = std::min<int64_t>(imgs, iN - n0);
+    rc = conv_dev(dout + n0 * c_out * oH * oW, din + n0 * iC * iH * iW, nb, iC, iH, iW, dker, c_out, kH, kW, pH, pW, sH, sW,
+                  dws, s, dbias, act);
+  }
+  if (own) {
+    const hipError_t e = hipFreeAsync(own, s);
+    if (rc == LASER_HIP_OK && e != hipSuccess) rc = fail(LASER_HIP_E_HIP, "hipFreeAsync: %s", hipGetErrorString(e));
+  }
+  return rc;
 }
 int laser_hip_conv2d_im2col_f32_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
                                     int64_t iW, const float *dker, int64_t c_out, int64_t c_in, int64_t kH,
                                     int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
                                     void *stream) {
-  return conv2d_api_dev(dout, din, iN, iC, iH, iW, dker, c_out, c_in, kH, kW, pH, pW, sH, sW, dws, nullptr, 0, stream);
+  return conv2d_api_dev(dout, din, iN, iC, iH, iW, dker, c_out, c_in, kH, kW, pH, pW, sH, sW, dws, -1, nullptr, 0, stream);
 }
 int laser_hip_conv2d_im2col_ex_f32_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH,
                                        int64_t iW, const float *dker, int64_t c_out, int64_t c_in, int64_t kH,
                                        int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
                                        const float *dbias, int act, void *stream) {
-  return conv2d_api_dev(dout, din, iN, iC, iH, iW, dker, c_out, c_in, kH, kW, pH, pW, sH, sW, dws, dbias, act, stream);
+  return conv2d_api_dev(dout, din, iN, iC, iH, iW, dker, c_out, c_in, kH, kW, pH, pW, sH, sW, dws, -1, dbias, act, stream);
 }
 
 static int conv2d_api_host(float *out, const float *in, int64_t iN, int64_t iC, int64_t iH, int64_t iW,
@@ -1031,7 +1140,8 @@ static int conv2d_api_host(float *out, const float *in, int64_t iN, int64_t iC, 
   if (iN == 0) return LASER_HIP_OK;
   if (!out || !in || !ker) return fail(LASER_HIP_E_INVALID, "null pointer");
   if (iN > 65535) return fail(LASER_HIP_E_INVALID, "batch > 65535");
-  std::lock_guard<std::mutex> lk(g_mu);
+  HostCall hc;
+  if (hc.rc) return hc.rc;
   int64_t oH, oW;
   out_hw(iH, iW, kH, kW, pH, pW, sH, sW, &oH, &oW);
   const size_t ib = (size_t)iN * iC * iH * iW * 4, kb = (size_t)c_out * iC * kH * kW * 4;
@@ -1105,15 +1215,18 @@ LH_DEF_GEMM_EX(f64, double)
 // kStorageCacheMax bytes in total) so that chains of tensor-producing calls do not pay hipMalloc / hipFree -- a
 // device allocation costs ~100 us, more than a 2048^3 product.  Reused blocks are zero-filled again: the contract
 // stays allocShared0's.  laser_hip_storage_trim() / laser_hip_finalize() release the list.
-int laser_hip_storage_alloc(void **d, int64_t bytes) {
+static int storage_alloc(void **d, int64_t bytes, hipStream_t stream, bool ordered) {
   if (!d || bytes < 0) return fail(LASER_HIP_E_INVALID, "storage_alloc: bad argument");
   if (int rc = ensure_init()) return rc;
   *d = nullptr;
   if (bytes == 0) return LASER_HIP_OK;
   const size_t want = ((size_t)bytes + 255) & ~(size_t)255;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const size_t key = storage_key(want, dev);
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_free_storage.find(want);
+    auto it = g_free_storage.find(key);
     if (it != g_free_storage.end() && !it->second.empty()) {
       *d = it->second.back();
       it->second.pop_back();
@@ -1131,21 +1244,27 @@ int laser_hip_storage_alloc(void **d, int64_t bytes) {
     }
     if (e != hipSuccess) return fail(LASER_HIP_E_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
     std::lock_guard<std::mutex> lk(g_mu);
-    g_live_storage[*d] = want;
+    g_live_storage[*d] = key;
   }
-  hipError_t e = hipMemset(*d, 0, (size_t)bytes);
-  if (e != hipSuccess) return fail(LASER_HIP_E_HIP, "hipMemset: %s", hipGetErrorString(e));
+  // zero fill (allocShared0): ordered on the caller's stream -- the stream the tensor's first kernel will run on --
+  // or, for the plain entry point, completed before returning (PyTorch-style side streams are non-blocking: a fill
+  // left running on the NULL stream could land after, or beside, the first kernel that writes the block)
+  hipError_t e = hipMemsetAsync(*d, 0, (size_t)bytes, stream);
+  if (e == hipSuccess && !ordered) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return fail(LASER_HIP_E_HIP, "zero fill: %s", hipGetErrorString(e));
   return LASER_HIP_OK;
 }
+int laser_hip_storage_alloc(void **d, int64_t bytes) { return storage_alloc(d, bytes, nullptr, false); }
+int laser_hip_storage_alloc_stream(void **d, int64_t bytes, void *stream) { return storage_alloc(d, bytes, (hipStream_t)stream, true); }
 int laser_hip_storage_free(void *d) {
   if (!d) return LASER_HIP_OK;
   if (int rc = ensure_init()) return rc;
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_live_storage.find(d);
   if (it == g_live_storage.end()) return fail(LASER_HIP_E_INVALID, "storage_free: not a laser_hip storage");
-  const size_t sz = it->second;
+  const size_t key = it->second, sz = storage_size(key);
   if (g_free_storage_bytes + sz <= kStorageCacheMax) {
-    g_free_storage[sz].push_back(d);
+    g_free_storage[key].push_back(d);
     g_free_storage_bytes += sz;
     return LASER_HIP_OK;
   }
@@ -1158,18 +1277,29 @@ int laser_hip_storage_trim(void) {
   storage_trim();
   return LASER_HIP_OK;
 }
-int laser_hip_storage_upload(void *d, const void *h, int64_t bytes) {
+// Host <-> device copies of a storage, ORDERED on `stream` (after the kernels already queued there that produce or
+// still read the block) and complete when the call returns.  The plain forms use the NULL stream, which does not
+// wait for non-blocking streams: a caller that computes on its own stream passes that stream here.
+int laser_hip_storage_upload_stream(void *d, const void *h, int64_t bytes, void *stream) {
   if (bytes < 0 || (bytes > 0 && (!d || !h))) return fail(LASER_HIP_E_INVALID, "storage_upload: bad argument");
   if (int rc = ensure_init()) return rc;
-  if (bytes) HIP_TRY(hipMemcpy(d, h, (size_t)bytes, hipMemcpyHostToDevice));
+  if (bytes) {
+    HIP_TRY(hipMemcpyAsync(d, h, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  }
   return LASER_HIP_OK;
 }
-int laser_hip_storage_download(void *h, const void *d, int64_t bytes) {
+int laser_hip_storage_download_stream(void *h, const void *d, int64_t bytes, void *stream) {
   if (bytes < 0 || (bytes > 0 && (!d || !h))) return fail(LASER_HIP_E_INVALID, "storage_download: bad argument");
   if (int rc = ensure_init()) return rc;
-  if (bytes) HIP_TRY(hipMemcpy(h, d, (size_t)bytes, hipMemcpyDeviceToHost));
+  if (bytes) {
+    HIP_TRY(hipMemcpyAsync(h, d, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  }
   return LASER_HIP_OK;
 }
+int laser_hip_storage_upload(void *d, const void *h, int64_t bytes) { return laser_hip_storage_upload_stream(d, h, bytes, nullptr); }
+int laser_hip_storage_download(void *h, const void *d, int64_t bytes) { return laser_hip_storage_download_stream(h, d, bytes, nullptr); }
 int laser_hip_storage_set_zero(void *d, int64_t bytes, void *stream) {
   if (bytes < 0 || (bytes > 0 && !d)) return fail(LASER_HIP_E_INVALID, "storage_set_zero: bad argument");
   if (int rc = ensure_init()) return rc;

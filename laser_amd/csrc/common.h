@@ -82,6 +82,31 @@ enum LoadMode : int {
                         // (contiguous 16-B pieces) and the kH*kW shifted views are gathered by the fragment reads
 };
 
+// LOAD_CONV_PATCH geometry for a BK x BN tile: channels a K-tile can touch, input rows reached by BN consecutive output
+// pixels (upper bound), and the patch row stride in floats (input column j at index 4 + j).  The row stride is the
+// smallest multiple of 4 >= W + 8 that keeps the 32 lanes of a fragment read on 32 distinct LDS banks when their 32
+// consecutive output pixels wrap from one output row to the next: the wrap moves the address by PWs*sH - (oW-1)*sW,
+// which must be = sW (mod 32).  (With W + 8 = 64 at the 56x56 shape every patch row starts on bank 0 and the wrapped
+// lanes collide 2-way: SQ_LDS_BANK_CONFLICT = 13 % of the LDS cycles, profiles/r02/rocprof_conv_c4.)  Returns false if
+// no stride fits the B region of an LDS stage (budget = BK*BN - BK - 4 floats).
+struct ConvPatchGeom {
+  int chm, rp, pws;
+};
+inline bool conv_patch_geom(int BK, int BN, int W, int oW, int kH, int kW, int sH, int sW, ConvPatchGeom *g) {
+  const int khw = kH * kW;
+  g->chm = (BK + khw - 2) / khw + 1;
+  g->rp = ((BN - 1) / oW + 1) * sH + kH;
+  const int64_t budget = (int64_t)BK * BN - BK - 4;
+  g->pws = W + 8;
+  if ((int64_t)g->chm * g->rp * g->pws > budget) return false;
+  for (int p = W + 8; p <= W + 40; p += 4)
+    if ((p * sH - oW * sW) % 32 == 0 && (int64_t)g->chm * g->rp * p <= budget) {
+      g->pws = p;
+      break;
+    }
+  return true;
+}
+
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
 hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
 // args.B = NCHW input, args.bsB = C*H*W, args.c* = geometry, N = oH*oW, K = C*kH*kW; A = filter

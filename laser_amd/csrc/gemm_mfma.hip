@@ -123,7 +123,7 @@ static int heuristic_cfg(const GemmArgs<float> &a, bool exact, bool need_gen = f
 // (C4's 1600 tiles of 128x128 on 512 resident slots are 3.125 rounds and cost 3.6).  Output tiles are independent
 // and every configuration is bit-identical, so the columns are cut at n_cut (a multiple of the main tile's BN):
 // the main launch covers [0, n_cut) in (nearly) whole rounds of large tiles, the tail launch [n_cut, N) with a
-// smaller tile.  Taken only when the model predicts >= 3 % (boundary between the launches ~3 us priced in).
+// smaller tile.  Taken only when the model predicts >= 5 % (boundary between the launches ~3 us priced in).
 struct SplitPlan {
   int cfg_main = -1, cfg_tail = -1;
   int64_t n_cut = 0;  // 0: one launch
@@ -136,7 +136,7 @@ static SplitPlan plan_split(const GemmArgs<float> &a, bool exact, bool need_gen,
   p.cfg_main = heuristic_cfg(a, exact, need_gen, conv, &t_single);
   if (!g_split_tail) return p;
   const double boundary = 3.0e6 / (512.0 * (double)a.K);  // ~3 us in model units
-  double best = t_single * 0.97;
+  double best = t_single * 0.95;
   for (const Cand &c : kCands) {
     if (need_gen && !c.gen) continue;
     const int64_t tm = (a.M + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn;
@@ -245,9 +245,9 @@ static hipError_t launch_conv_cfg(const GemmArgs<float> &a, int cfg, bool exact,
     bool va, ea;
     pick_mode<float>(a.A, a.rsA, a.csA, a.bsA, a.M, a.K, c.bm, c.bk, &va, &ea);
     // B through an LDS-resident input patch when it fits the B region of a stage (else the per-element gather)
-    const int khw = a.ckH * a.ckW;
-    const int64_t patch = (int64_t)((c.bk + khw - 2) / khw + 1) * (((c.bn - 1) / a.coW + 1) * a.csH + a.ckH) * (a.cW + 8);
-    const bool patch_ok = g_conv_patch && a.cW % 4 == 0 && a.cpW <= 4 && patch <= (int64_t)c.bk * c.bn - c.bk - 4;
+    ConvPatchGeom pg;
+    const bool patch_ok = g_conv_patch && a.cW % 4 == 0 && a.cpW <= 4 &&
+                          conv_patch_geom(c.bk, c.bn, a.cW, a.coW, a.ckH, a.ckW, a.csH, a.csW, &pg);
     const int bmode = patch_ok ? LOAD_CONV_PATCH : LOAD_IM2COL;
     if (a.csA == 1 && va) return c.fn(a, LOAD_VEC_K, bmode, exact, s);
     if (a.csA == 1 && ea) return c.fn(a, LOAD_VEC_K_EDGE, bmode, exact, s);

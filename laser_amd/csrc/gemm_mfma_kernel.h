@@ -268,7 +268,7 @@ struct TileLoader {
   }
 
   // LOAD_CONV_PATCH: the B "tile" of the implicit-GEMM convolution is an input PATCH -- for each of the cCHM
-  // channels a K-tile can touch, the cRp input rows the tile's output pixels reach, stored as rows of cPWs = W + 8
+  // channels a K-tile can touch, the cRp input rows the tile's output pixels reach, stored as rows of cPWs >= W + 8 (conv_patch_geom, common.h)
   // floats (input column j at index 4 + j; everything else, the zero padding, stays 0 from the one-time clear).
   // The patch rows are contiguous in HBM: each thread owns up to NV 16-byte pieces (channel slot, row, column
   // quad), decoded once; per K-tile only the first channel c0 moves (running state, no division).  Rows outside
@@ -1015,13 +1015,14 @@ hipError_t launch_one(const GemmArgs<E> &a, hipStream_t s) {
   g.tiles_n = (int)((a.N - a.col0 + BN - 1) / BN);
   if constexpr (BMODE == LOAD_CONV_PATCH) {
     const int khw = a.ckH * a.ckW;
+    ConvPatchGeom pg;
+    if (!conv_patch_geom(BK, BN, a.cW, a.coW, a.ckH, a.ckW, a.csH, a.csW, &pg) || a.cW % 4 != 0) return hipErrorInvalidValue;
     g.cdc = BK / khw;
-    g.cRp = ((BN - 1) / a.coW + 1) * a.csH + a.ckH;  // input rows reached by BN consecutive output pixels (upper bound)
-    g.cPWs = a.cW + 8;
-    g.cCHM = (BK + khw - 2) / khw + 1;
+    g.cRp = pg.rp;
+    g.cPWs = pg.pws;
+    g.cCHM = pg.chm;
     g.cdr = (BK % khw) / a.ckW;
     g.cdq = (BK % khw) % a.ckW;
-    if ((int64_t)g.cCHM * g.cRp * g.cPWs > (int64_t)BK * BN - BK - 4 || a.cW % 4 != 0) return hipErrorInvalidValue;
   }
   if constexpr (BMODE == LOAD_IM2COL) {
     const int khw = a.ckH * a.ckW;

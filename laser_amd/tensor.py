@@ -44,7 +44,8 @@ class HipStorage:
 
     def __init__(self, nbytes):
         p = C.c_void_p()
-        _lib.check(_lib.lib().laser_hip_storage_alloc(C.byref(p), int(nbytes)))
+        # zero fill ordered on the stream the tensor's kernels will run on (torch side streams are non-blocking)
+        _lib.check(_lib.lib().laser_hip_storage_alloc_stream(C.byref(p), int(nbytes), _stream()))
         self.raw_buffer = p.value or 0
         self.memalloc = self.raw_buffer
         self.memowner = True
@@ -158,8 +159,9 @@ class Tensor:
         t = self if self.is_C_contiguous() else deepCopy(self)
         out = np.empty(self.shape, self.dtype)
         if out.size:
-            _lib.check(_lib.lib().laser_hip_storage_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(t.unsafe_raw_data()),
-                                                             out.nbytes))
+            # ordered after the producing kernel / deepCopy on the current stream, complete on return
+            _lib.check(_lib.lib().laser_hip_storage_download_stream(out.ctypes.data_as(C.c_void_p), C.c_void_p(t.unsafe_raw_data()),
+                                                                    out.nbytes, _stream()))
         return out
 
     @property
@@ -259,10 +261,10 @@ def copyFromRaw(dst, buffer, length):
     if not dst.size:
         return dst
     if dst.is_C_contiguous():
-        _lib.check(_lib.lib().laser_hip_storage_upload(C.c_void_p(dst.unsafe_raw_data()), buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+        _lib.check(_lib.lib().laser_hip_storage_upload_stream(C.c_void_p(dst.unsafe_raw_data()), buf.ctypes.data_as(C.c_void_p), buf.nbytes, _stream()))
     else:  # a view: stage contiguously, then scatter through the strides
         tmp = newTensor(dst.dtype, *dst.shape)
-        _lib.check(_lib.lib().laser_hip_storage_upload(C.c_void_p(tmp.unsafe_raw_data()), buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+        _lib.check(_lib.lib().laser_hip_storage_upload_stream(C.c_void_p(tmp.unsafe_raw_data()), buf.ctypes.data_as(C.c_void_p), buf.nbytes, _stream()))
         _copy_strided(dst, tmp)
     return dst
 

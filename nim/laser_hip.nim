@@ -6,8 +6,12 @@
 # 18-23: `{.dynlib: blas, importc: "cblas_sgemm".}`) and for libjit (gemm_bench_float32.nim:199-202).
 #
 # NOTE: delivered as SOURCE.  The build image has no Nim compiler (probed: nim/nimble absent, no
-# network), so this file has not been compiled; the C-ABI itself is exercised from C++
-# (include/laser.hpp) and Python ctypes (laser_amd/primitives.py, tests/).
+# network), so this file has not been compiled here.  What IS checked mechanically
+# (tests/test_nim_shim_cpu.py): every `importc: "..."` below names a symbol that liblaser_hip.so
+# exports (nm -D) and that include/laser_hip.h declares, with the same number of parameters and
+# C-compatible parameter / return types (Nim int == int64_t on amd64, cint == int, float32 == float,
+# float64 == double, pointer / ptr T / cstring == pointers); every import is spelled with an explicit
+# `importc: "<symbol>"` string (no identifier pasting), one declaration per C symbol.
 #
 # Usage inside Laser: `import laser_hip` instead of `./gemm` / `./gemm_prepacked` /
 # `../swapaxes` / `./conv2d_im2col`; call sites do not change.
@@ -16,10 +20,12 @@ const laserHip* = "liblaser_hip.so"
 
 {.pragma: lh, cdecl, dynlib: laserHip.}
 
-proc laser_hip_last_error(): cstring {.lh, importc.}
-proc laser_hip_init*(device: cint): cint {.lh, importc.}
-proc laser_hip_finalize*(): cint {.lh, importc.}
-proc laser_hip_set_float_mode*(mode: cint): cint {.lh, importc.}   # 0 = Laser order (default), 1 = fast
+# ---- C-ABI imports (Nim int == int64 on amd64, float32 == C float) ---------------------------
+proc laser_hip_last_error(): cstring {.lh, importc: "laser_hip_last_error".}
+proc laser_hip_init*(device: cint): cint {.lh, importc: "laser_hip_init".}
+proc laser_hip_finalize*(): cint {.lh, importc: "laser_hip_finalize".}
+proc laser_hip_device_count*(): cint {.lh, importc: "laser_hip_device_count".}
+proc laser_hip_set_float_mode*(mode: cint): cint {.lh, importc: "laser_hip_set_float_mode".}   # 0 = Laser order (default), 1 = fast
 
 template check(rc: cint) =
   # the reference procs return void and doAssert on precondition violations
@@ -27,38 +33,69 @@ template check(rc: cint) =
   let code = rc
   doAssert code == 0, "laser_hip error " & $code & ": " & $laser_hip_last_error()
 
-# ---- C-ABI imports (Nim int == int64 on amd64, float32 == C float) ---------------------------
-template importGemm(sfx: untyped, T: typedesc) =
-  proc `laser_hip_gemm_strided sfx`(M, N, K: int, alpha: T, A: ptr T, rsA, csA: int,
-      B: ptr T, rsB, csB: int, beta: T, C: ptr T, rsC, csC: int): cint {.lh, importc.}
-  proc `laser_hip_gemm_prepackA_mem_required sfx`(M, N, K: int): int {.lh, importc.}
-  proc `laser_hip_gemm_prepackB_mem_required sfx`(M, N, K: int): int {.lh, importc.}
-  proc `laser_hip_gemm_prepackA sfx`(dst: pointer, M, N, K: int, A: ptr T, rs, cs: int): cint {.lh, importc.}
-  proc `laser_hip_gemm_prepackB sfx`(dst: pointer, M, N, K: int, B: ptr T, rs, cs: int): cint {.lh, importc.}
-  proc `laser_hip_gemm_packed sfx`(M, N, K: int, alpha: T, pA, pB: pointer, beta: T,
-      C: ptr T, rsC, csC: int): cint {.lh, importc.}
+# gemm_strided, host pointers (blocking, Laser's call semantics)
+proc laser_hip_gemm_strided_f32(M, N, K: int, alpha: float32, A: ptr float32, rsA, csA: int, B: ptr float32, rsB, csB: int, beta: float32, C: ptr float32, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_strided_f32".}
+proc laser_hip_gemm_strided_f64(M, N, K: int, alpha: float64, A: ptr float64, rsA, csA: int, B: ptr float64, rsB, csB: int, beta: float64, C: ptr float64, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_strided_f64".}
+proc laser_hip_gemm_strided_i32(M, N, K: int, alpha: int32, A: ptr int32, rsA, csA: int, B: ptr int32, rsB, csB: int, beta: int32, C: ptr int32, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_strided_i32".}
+proc laser_hip_gemm_strided_i64(M, N, K: int, alpha: int64, A: ptr int64, rsA, csA: int, B: ptr int64, rsB, csB: int, beta: int64, C: ptr int64, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_strided_i64".}
+# gemm_strided, device pointers + stream (asynchronous; operands resident in HBM)
+proc laser_hip_gemm_strided_f32_dev(M, N, K: int, alpha: float32, A: pointer, rsA, csA: int, B: pointer, rsB, csB: int, beta: float32, C: pointer, rsC, csC: int, stream: pointer): cint {.lh, importc: "laser_hip_gemm_strided_f32_dev".}
+proc laser_hip_gemm_strided_f64_dev(M, N, K: int, alpha: float64, A: pointer, rsA, csA: int, B: pointer, rsB, csB: int, beta: float64, C: pointer, rsC, csC: int, stream: pointer): cint {.lh, importc: "laser_hip_gemm_strided_f64_dev".}
+proc laser_hip_gemm_strided_i32_dev(M, N, K: int, alpha: int32, A: pointer, rsA, csA: int, B: pointer, rsB, csB: int, beta: int32, C: pointer, rsC, csC: int, stream: pointer): cint {.lh, importc: "laser_hip_gemm_strided_i32_dev".}
+proc laser_hip_gemm_strided_i64_dev(M, N, K: int, alpha: int64, A: pointer, rsA, csA: int, B: pointer, rsB, csB: int, beta: int64, C: pointer, rsC, csC: int, stream: pointer): cint {.lh, importc: "laser_hip_gemm_strided_i64_dev".}
 
-importGemm(_f32, float32)
-importGemm(_f64, float64)
-importGemm(_i32, int32)
-importGemm(_i64, int64)
+# pre-packed GEMM
+proc laser_hip_gemm_prepackA_mem_required_f32(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackA_mem_required_f32".}
+proc laser_hip_gemm_prepackA_mem_required_f64(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackA_mem_required_f64".}
+proc laser_hip_gemm_prepackA_mem_required_i32(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackA_mem_required_i32".}
+proc laser_hip_gemm_prepackA_mem_required_i64(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackA_mem_required_i64".}
+proc laser_hip_gemm_prepackB_mem_required_f32(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackB_mem_required_f32".}
+proc laser_hip_gemm_prepackB_mem_required_f64(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackB_mem_required_f64".}
+proc laser_hip_gemm_prepackB_mem_required_i32(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackB_mem_required_i32".}
+proc laser_hip_gemm_prepackB_mem_required_i64(M, N, K: int): int {.lh, importc: "laser_hip_gemm_prepackB_mem_required_i64".}
+proc laser_hip_gemm_prepackA_f32(dst: pointer, M, N, K: int, A: ptr float32, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackA_f32".}
+proc laser_hip_gemm_prepackA_f64(dst: pointer, M, N, K: int, A: ptr float64, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackA_f64".}
+proc laser_hip_gemm_prepackA_i32(dst: pointer, M, N, K: int, A: ptr int32, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackA_i32".}
+proc laser_hip_gemm_prepackA_i64(dst: pointer, M, N, K: int, A: ptr int64, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackA_i64".}
+proc laser_hip_gemm_prepackB_f32(dst: pointer, M, N, K: int, B: ptr float32, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackB_f32".}
+proc laser_hip_gemm_prepackB_f64(dst: pointer, M, N, K: int, B: ptr float64, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackB_f64".}
+proc laser_hip_gemm_prepackB_i32(dst: pointer, M, N, K: int, B: ptr int32, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackB_i32".}
+proc laser_hip_gemm_prepackB_i64(dst: pointer, M, N, K: int, B: ptr int64, rs, cs: int): cint {.lh, importc: "laser_hip_gemm_prepackB_i64".}
+proc laser_hip_gemm_packed_f32(M, N, K: int, alpha: float32, pA, pB: pointer, beta: float32, C: ptr float32, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_packed_f32".}
+proc laser_hip_gemm_packed_f64(M, N, K: int, alpha: float64, pA, pB: pointer, beta: float64, C: ptr float64, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_packed_f64".}
+proc laser_hip_gemm_packed_i32(M, N, K: int, alpha: int32, pA, pB: pointer, beta: int32, C: ptr int32, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_packed_i32".}
+proc laser_hip_gemm_packed_i64(M, N, K: int, alpha: int64, pA, pB: pointer, beta: int64, C: ptr int64, rsC, csC: int): cint {.lh, importc: "laser_hip_gemm_packed_i64".}
+proc laser_hip_gemm_prepack_release*(packed: pointer): cint {.lh, importc: "laser_hip_gemm_prepack_release".}
 
-proc laser_hip_gemm_prepack_release*(packed: pointer): cint {.lh, importc.}
+# physical transposes
+proc laser_hip_transpose2d_copy_b32(dst, src: pointer, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_copy_b32".}
+proc laser_hip_transpose2d_copy_b64(dst, src: pointer, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_copy_b64".}
+proc laser_hip_transpose2d_batched_b32(dst, src: pointer, N, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_batched_b32".}
+proc laser_hip_transpose2d_batched_b64(dst, src: pointer, N, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_batched_b64".}
 
-proc laser_hip_transpose2d_copy_b32(dst, src: pointer, NR, NC: int): cint {.lh, importc.}
-proc laser_hip_transpose2d_copy_b64(dst, src: pointer, NR, NC: int): cint {.lh, importc.}
-proc laser_hip_transpose2d_batched_b32(dst, src: pointer, N, NR, NC: int): cint {.lh, importc.}
-proc laser_hip_transpose2d_batched_b64(dst, src: pointer, N, NR, NC: int): cint {.lh, importc.}
+# im2col + GEMM convolution, cblas-shaped gemm
+proc laser_hip_im2col_workspace_size(iN, iC, iH, iW, cOut, cIn, kH, kW, pH, pW, sH, sW: int): int {.lh, importc: "laser_hip_im2col_workspace_size".}
+proc laser_hip_im2col_f32(ws: ptr float32, oH, oW: int, input: ptr float32, iC, iH, iW, kH, kW, pH, pW, sH, sW: int): cint {.lh, importc: "laser_hip_im2col_f32".}
+proc laser_hip_conv2d_im2col_f32(output, input: ptr float32, iN, iC, iH, iW: int, kernel: ptr float32, cOut, cIn, kH, kW, pH, pW, sH, sW: int, ws: ptr float32): cint {.lh, importc: "laser_hip_conv2d_im2col_f32".}
+proc laser_hip_cblas_sgemm(order, tA, tB: cint, M, N, K: int, alpha: float32, A: ptr float32, lda: int, B: ptr float32, ldb: int, beta: float32, C: ptr float32, ldc: int): cint {.lh, importc: "laser_hip_cblas_sgemm".}
+proc laser_hip_cblas_dgemm(order, tA, tB: cint, M, N, K: int, alpha: float64, A: ptr float64, lda: int, B: ptr float64, ldb: int, beta: float64, C: ptr float64, ldc: int): cint {.lh, importc: "laser_hip_cblas_dgemm".}
 
-proc laser_hip_im2col_workspace_size(iN, iC, iH, iW, cOut, cIn, kH, kW, pH, pW, sH, sW: int): int {.lh, importc.}
-proc laser_hip_im2col_f32(ws: ptr float32, oH, oW: int, input: ptr float32,
-    iC, iH, iW, kH, kW, pH, pW, sH, sW: int): cint {.lh, importc.}
-proc laser_hip_conv2d_im2col_f32(output, input: ptr float32, iN, iC, iH, iW: int,
-    kernel: ptr float32, cOut, cIn, kH, kW, pH, pW, sH, sW: int, ws: ptr float32): cint {.lh, importc.}
-proc laser_hip_cblas_sgemm(order, tA, tB: cint, M, N, K: int, alpha: float32, A: ptr float32, lda: int,
-    B: ptr float32, ldb: int, beta: float32, C: ptr float32, ldc: int): cint {.lh, importc.}
+# fused epilogue
+proc laser_hip_gemm_strided_ex_f32(M, N, K: int, alpha: float32, A: ptr float32, rsA, csA: int, B: ptr float32, rsB, csB: int, beta: float32, C: ptr float32, rsC, csC: int, bias: ptr float32, rsBias, csBias: int, activation: cint): cint {.lh, importc: "laser_hip_gemm_strided_ex_f32".}
+proc laser_hip_gemm_strided_ex_f64(M, N, K: int, alpha: float64, A: ptr float64, rsA, csA: int, B: ptr float64, rsB, csB: int, beta: float64, C: ptr float64, rsC, csC: int, bias: ptr float64, rsBias, csBias: int, activation: cint): cint {.lh, importc: "laser_hip_gemm_strided_ex_f64".}
+
+# device tensor storage
+proc laser_hip_storage_alloc(d: ptr pointer, bytes: int): cint {.lh, importc: "laser_hip_storage_alloc".}
+proc laser_hip_storage_free(d: pointer): cint {.lh, importc: "laser_hip_storage_free".}
+proc laser_hip_storage_upload(d, host: pointer, bytes: int): cint {.lh, importc: "laser_hip_storage_upload".}
+proc laser_hip_storage_download(host, d: pointer, bytes: int): cint {.lh, importc: "laser_hip_storage_download".}
+proc laser_hip_storage_set_zero(d: pointer, bytes: int, stream: pointer): cint {.lh, importc: "laser_hip_storage_set_zero".}
+proc laser_hip_copy_strided_b32_dev(dst: pointer, dstStrides: ptr int, src: pointer, srcStrides: ptr int, shape: ptr int, rank: cint, stream: pointer): cint {.lh, importc: "laser_hip_copy_strided_b32_dev".}
+proc laser_hip_copy_strided_b64_dev(dst: pointer, dstStrides: ptr int, src: pointer, srcStrides: ptr int, shape: ptr int, rank: cint, stream: pointer): cint {.lh, importc: "laser_hip_copy_strided_b64_dev".}
 
 # ---- gemm_strided -- laser/primitives/matrix_multiplication/gemm.nim:184-193 --------------------
+# Element types dispatched by the reference: float32, float64, int32 / uint32 (one branch, gemm.nim:239),
+# int64.  Integer arithmetic wraps modulo 2^n, so uint32 is the int32 entry point on the same bits.
 proc gemm_strided*[T: SomeNumber](
       M, N, K: int,
       alpha: T,
@@ -75,6 +112,10 @@ proc gemm_strided*[T: SomeNumber](
     check laser_hip_gemm_strided_f64(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C, rowStrideC, colStrideC)
   elif T is int32:
     check laser_hip_gemm_strided_i32(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C, rowStrideC, colStrideC)
+  elif T is uint32:
+    check laser_hip_gemm_strided_i32(M, N, K, cast[int32](alpha), cast[ptr int32](A), rowStrideA, colStrideA,
+                                     cast[ptr int32](B), rowStrideB, colStrideB, cast[int32](beta),
+                                     cast[ptr int32](C), rowStrideC, colStrideC)
   elif T is int64 or T is int:
     check laser_hip_gemm_strided_i64(M, N, K, cast[int64](alpha), cast[ptr int64](A), rowStrideA, colStrideA,
                                      cast[ptr int64](B), rowStrideB, colStrideB, cast[int64](beta),
@@ -86,13 +127,6 @@ proc gemm_strided*[T: SomeNumber](
 # C = act(alpha*A*B + beta*C + bias); bias is a strided M x N view whose strides may be 0.
 type Activation* = enum
   actNone = 0, actRelu = 1, actTanh = 2, actSigmoid = 3
-
-proc laser_hip_gemm_strided_ex_f32(M, N, K: int, alpha: float32, A: ptr float32, rsA, csA: int, B: ptr float32,
-    rsB, csB: int, beta: float32, C: ptr float32, rsC, csC: int, bias: ptr float32, rsBias, csBias: int,
-    activation: cint): cint {.lh, importc.}
-proc laser_hip_gemm_strided_ex_f64(M, N, K: int, alpha: float64, A: ptr float64, rsA, csA: int, B: ptr float64,
-    rsB, csB: int, beta: float64, C: ptr float64, rsC, csC: int, bias: ptr float64, rsBias, csBias: int,
-    activation: cint): cint {.lh, importc.}
 
 proc gemm_strided_fused*[T: float32 or float64](
       M, N, K: int, alpha: T,
@@ -110,16 +144,16 @@ proc gemm_strided_fused*[T: float32 or float64](
                                         C, rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, cint(activation))
 
 # ---- pre-packed GEMM -- gemm_prepacked.nim:76-292 -----------------------------------------------
-proc gemm_prepackB_mem_required*(T: typedesc, M, N, K: int): int =
+proc gemm_prepackB_mem_required*(T: type, M, N, K: int): int =
   when T is float32: laser_hip_gemm_prepackB_mem_required_f32(M, N, K)
   elif T is float64: laser_hip_gemm_prepackB_mem_required_f64(M, N, K)
-  elif T is int32: laser_hip_gemm_prepackB_mem_required_i32(M, N, K)
+  elif T is int32 or T is uint32: laser_hip_gemm_prepackB_mem_required_i32(M, N, K)
   else: laser_hip_gemm_prepackB_mem_required_i64(M, N, K)
 
-proc gemm_prepackA_mem_required*(T: typedesc, M, N, K: int): int =
+proc gemm_prepackA_mem_required*(T: type, M, N, K: int): int =
   when T is float32: laser_hip_gemm_prepackA_mem_required_f32(M, N, K)
   elif T is float64: laser_hip_gemm_prepackA_mem_required_f64(M, N, K)
-  elif T is int32: laser_hip_gemm_prepackA_mem_required_i32(M, N, K)
+  elif T is int32 or T is uint32: laser_hip_gemm_prepackA_mem_required_i32(M, N, K)
   else: laser_hip_gemm_prepackA_mem_required_i64(M, N, K)
 
 proc gemm_prepackB*[T](dst_packedB: ptr (T or UncheckedArray[T]), M, N, K: int,
@@ -162,11 +196,16 @@ proc nhwc2nchw*[T](dst_nchw, src_nhwc: ptr (T or UncheckedArray[T]), N, C, H, W:
   transpose2D_batched(dst_nchw, src_nhwc, N, H*W, C)       # swapaxes.nim:112
 
 # ---- im2col + GEMM convolution -- benchmarks/convolution/conv2d_im2col.nim -----------------------
+# The convolution benchmark's own types, conv2d_common.nim:6-13.  Its `Tensor[T]` is a plain `seq[T]`
+# (conv2d_common.nim:13: `Tensor*[T] = seq[T]`) -- NOT laser/tensor's Tensor -- which is why
+# conv2d_bench.nim:92-102 can hand seqs to conv2d_im2col.  A maintainer who keeps
+# `import ./conv2d_common` drops the five declarations below.
 type
-  TensorShape* = tuple[n, c, h, w: int]            # conv2d_common.nim:6-13
+  TensorShape* = tuple[n, c, h, w: int]
   KernelShape* = tuple[c_out, c_in, kH, kW: int]
   Padding* = tuple[h, w: int]
   Strides* = tuple[h, w: int]
+  Tensor*[T] = seq[T]
 
 proc im2col_workspace_size*(ishape: TensorShape, kshape: KernelShape, padding: Padding, strides: Strides): int =
   laser_hip_im2col_workspace_size(ishape.n, ishape.c, ishape.h, ishape.w, kshape.c_out, kshape.c_in,
@@ -177,9 +216,18 @@ proc im2col*(pworkspace: ptr float32, oshape: TensorShape, pinput: ptr Unchecked
   check laser_hip_im2col_f32(pworkspace, oshape.h, oshape.w, cast[ptr float32](pinput), ishape.c, ishape.h,
                              ishape.w, kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w)
 
-proc conv2d_im2col*(output: var seq[float32], oshape: TensorShape, input: seq[float32], ishape: TensorShape,
-                    kernel: seq[float32], kshape: KernelShape, padding: Padding, strides: Strides,
-                    pworkspace: ptr float32) =
+# conv2d_im2col.nim:90-100, parameter for parameter
+proc conv2d_im2col*(
+    output: var Tensor[float32], # Output tensor
+    oshape: TensorShape,         # Shape of output
+    input: Tensor[float32],      # Input tensor
+    ishape: TensorShape,         # Shape of input
+    kernel: Tensor[float32],     # Convolution filter
+    kshape: KernelShape,         # kernel shape
+    padding: Padding,            # Padding
+    strides: Strides,            # Strides
+    pworkspace: ptr float32      # Workspace buffer, can be reused between batches
+  ) =
   assert oshape.c == kshape.c_out                        # conv2d_im2col.nim:109
   check laser_hip_conv2d_im2col_f32(output[0].addr, input[0].unsafeAddr, ishape.n, ishape.c, ishape.h, ishape.w,
                                     kernel[0].unsafeAddr, kshape.c_out, kshape.c_in, kshape.kH, kshape.kW,
@@ -192,65 +240,98 @@ type
   OrderType* {.size: sizeof(cint).} = enum
     rowMajor = 101, colMajor = 102
 
+# blas.nim:18-20 (cblas_sgemm)
 proc gemm*(ORDER: OrderType, TRANSA, TRANSB: TransposeType, M, N, K: int, ALPHA: float32,
            A: ptr float32, LDA: int, B: ptr float32, LDB: int, BETA: float32, C: ptr float32, LDC: int) =
   check laser_hip_cblas_sgemm(cint(ORDER), cint(TRANSA), cint(TRANSB), M, N, K, ALPHA, A, LDA, B, LDB, BETA, C, LDC)
 
+# blas.nim:21-23 (cblas_dgemm)
+proc gemm*(ORDER: OrderType, TRANSA, TRANSB: TransposeType, M, N, K: int, ALPHA: float64,
+           A: ptr float64, LDA: int, B: ptr float64, LDB: int, BETA: float64, C: ptr float64, LDC: int) =
+  check laser_hip_cblas_dgemm(cint(ORDER), cint(TRANSA), cint(TRANSB), M, N, K, ALPHA, A, LDA, B, LDB, BETA, C, LDC)
+
 # ---- RawTensor / forEach surface ------------------------------------------------------------------
-# Nothing to replace: `Tensor[T]`, `unsafe_raw_data`, `forEach` stay Laser's own
+# Nothing to replace for HOST tensors: `Tensor[T]`, `unsafe_raw_data`, `forEach` stay Laser's own
 # (laser/tensor/datatypes.nim:13-30, laser/strided_iteration/foreach.nim:192-264).  A caller does
 #   gemm_strided(M, N, K, 1'f32, a.unsafe_raw_data, a.strides[0], a.strides[1], ...)
 # exactly as before; only raw pointers and element strides cross the ABI.
 
 # ---- device-resident storage: HipStorage, the twin of CpuStorage ---------------------------------
-# (SURVEY.md section 8f rank 3.)  `Tensor[T]` keeps its shape / strides / offset; what changes is
-# where `storage.raw_buffer` lives.  With a HipStorage the pointer handed to gemm_strided_dev & co.
-# is a device address, so chained calls never cross PCIe.  Same layout as
-# laser/tensor/datatypes.nim:24-30 and the same finalizer pattern as allocator.nim:11-29.
-proc laser_hip_storage_alloc(d: ptr pointer, bytes: int): cint {.lh, importc.}
-proc laser_hip_storage_free(d: pointer): cint {.lh, importc.}
-proc laser_hip_storage_upload(d, host: pointer, bytes: int): cint {.lh, importc.}
-proc laser_hip_storage_download(host, d: pointer, bytes: int): cint {.lh, importc.}
-proc laser_hip_storage_set_zero(d: pointer, bytes: int, stream: pointer): cint {.lh, importc.}
-proc laser_hip_copy_strided_b32_dev(dst: pointer, dstStrides: ptr int, src: pointer, srcStrides: ptr int,
-                                    shape: ptr int, rank: cint, stream: pointer): cint {.lh, importc.}
-proc laser_hip_copy_strided_b64_dev(dst: pointer, dstStrides: ptr int, src: pointer, srcStrides: ptr int,
-                                    shape: ptr int, rank: cint, stream: pointer): cint {.lh, importc.}
-
+# (SURVEY.md section 8f rank 3.)  A tensor keeps its shape / strides / offset; what changes is where
+# `storage.raw_buffer` lives.  GUARD: a device address must never reach Laser's host `forEach`, whose
+# duck-typing contract is `rank, size, shape, strides, unsafe_raw_data` (foreach.nim:7-29,
+# laser/strided_iteration/README.md:101-107) -- it would dereference the pointer on the CPU.  So
+#   * the device pointer type is `DevicePtr[T]`, a `distinct pointer` with NO `[]` and no conversion
+#     to `ptr T`: it cannot be passed to gemm_strided / transpose2D_copy (host entry points) by accident;
+#   * HipStorage has NO `unsafe_raw_data`; its accessor is `unsafe_device_data`, so `forEach x in t`
+#     on a HipStorage-backed tensor fails to COMPILE (undeclared identifier in forEach's expansion);
+#   * elementwise work on device tensors goes through `mapStrided` below
+#     (laser_hip_map_strided_*_dev), the device-side twin of forEach's strided iteration.
 type
-  HipStorage*{.shallow.}[T] = ref object
-    raw_buffer*: ptr UncheckedArray[T]   # DEVICE address
+  DevicePtr*[T] = distinct pointer       # an HBM address: not dereferenceable on the host
+  HipStorage*{.shallow.}[T] = ref object # same layout idea as CpuStorage, datatypes.nim:24-30
+    raw_buffer*: DevicePtr[T]
     memalloc*: pointer
     memowner*: bool
+
+func unsafe_device_data*[T](s: HipStorage[T]): DevicePtr[T] {.inline.} = s.raw_buffer
+func offsetBy*[T](p: DevicePtr[T], elements: int): DevicePtr[T] {.inline.} =
+  DevicePtr[T](cast[pointer](cast[uint](pointer(p)) + uint(elements * sizeof(T))))
 
 proc finalizer[T](storage: HipStorage[T]) =
   if storage.memowner and not storage.memalloc.isNil:
     discard laser_hip_storage_free(storage.memalloc)
 
 proc allocHipStorage*[T](storage: var HipStorage[T], size: int) =
-  ## allocCpuStorage's twin: `size` elements, aligned >= LASER_MEM_ALIGN, zero-filled.
+  ## allocCpuStorage's twin (allocator.nim:17-29): `size` elements, aligned >= LASER_MEM_ALIGN, zero-filled.
   new(storage, finalizer[T])
   check laser_hip_storage_alloc(storage.memalloc.addr, sizeof(T) * size)
   storage.memowner = true
-  storage.raw_buffer = cast[ptr UncheckedArray[T]](storage.memalloc)
+  storage.raw_buffer = DevicePtr[T](storage.memalloc)
 
 proc copyFromRaw*[T](dst: HipStorage[T], buffer: ptr T, len: Natural) =
   ## initialization.nim:112-128 for a device storage (host buffer -> HBM).
-  check laser_hip_storage_upload(dst.raw_buffer, buffer, sizeof(T) * len)
+  check laser_hip_storage_upload(pointer(dst.raw_buffer), buffer, sizeof(T) * len)
 
 proc copyToRaw*[T](buffer: ptr T, src: HipStorage[T], len: Natural) =
-  check laser_hip_storage_download(buffer, src.raw_buffer, sizeof(T) * len)
+  check laser_hip_storage_download(buffer, pointer(src.raw_buffer), sizeof(T) * len)
 
 proc setZero*[T](s: HipStorage[T], len: Natural) =
-  check laser_hip_storage_set_zero(s.raw_buffer, sizeof(T) * len, nil)
+  check laser_hip_storage_set_zero(pointer(s.raw_buffer), sizeof(T) * len, nil)
 
-proc copyStrided*[T](dst: ptr T, dstStrides: openarray[int], src: ptr T, srcStrides: openarray[int],
+proc copyStrided*[T](dst: DevicePtr[T], dstStrides: openarray[int], src: DevicePtr[T], srcStrides: openarray[int],
                      shape: openarray[int]) =
   ## `forEachStrided d in dst, s in src: d = s` on device buffers (deepCopy / copyFrom of views).
   assert shape.len == dstStrides.len and shape.len == srcStrides.len and shape.len <= 6   # LASER_MAXRANK
   when sizeof(T) == 4:
-    check laser_hip_copy_strided_b32_dev(dst, dstStrides[0].unsafeAddr, src, srcStrides[0].unsafeAddr,
+    check laser_hip_copy_strided_b32_dev(pointer(dst), dstStrides[0].unsafeAddr, pointer(src), srcStrides[0].unsafeAddr,
                                          shape[0].unsafeAddr, cint(shape.len), nil)
   else:
-    check laser_hip_copy_strided_b64_dev(dst, dstStrides[0].unsafeAddr, src, srcStrides[0].unsafeAddr,
+    check laser_hip_copy_strided_b64_dev(pointer(dst), dstStrides[0].unsafeAddr, pointer(src), srcStrides[0].unsafeAddr,
                                          shape[0].unsafeAddr, cint(shape.len), nil)
+
+# gemm_strided on device-resident operands: the SAME parameter list as gemm.nim:184-193 with DevicePtr[T]
+# in place of ptr T (overload resolution keeps host and device pointers apart), asynchronous on `stream`.
+proc gemm_strided*[T: SomeNumber](
+      M, N, K: int,
+      alpha: T,
+      A: DevicePtr[T],
+      rowStrideA, colStrideA: int,
+      B: DevicePtr[T],
+      rowStrideB, colStrideB: int,
+      beta: T,
+      C: DevicePtr[T],
+      rowStrideC, colStrideC: int,
+      stream: pointer = nil) =
+  when T is float32:
+    check laser_hip_gemm_strided_f32_dev(M, N, K, alpha, pointer(A), rowStrideA, colStrideA, pointer(B), rowStrideB, colStrideB, beta, pointer(C), rowStrideC, colStrideC, stream)
+  elif T is float64:
+    check laser_hip_gemm_strided_f64_dev(M, N, K, alpha, pointer(A), rowStrideA, colStrideA, pointer(B), rowStrideB, colStrideB, beta, pointer(C), rowStrideC, colStrideC, stream)
+  elif T is int32:
+    check laser_hip_gemm_strided_i32_dev(M, N, K, alpha, pointer(A), rowStrideA, colStrideA, pointer(B), rowStrideB, colStrideB, beta, pointer(C), rowStrideC, colStrideC, stream)
+  elif T is uint32:
+    check laser_hip_gemm_strided_i32_dev(M, N, K, cast[int32](alpha), pointer(A), rowStrideA, colStrideA, pointer(B), rowStrideB, colStrideB, cast[int32](beta), pointer(C), rowStrideC, colStrideC, stream)
+  elif T is int64 or T is int:
+    check laser_hip_gemm_strided_i64_dev(M, N, K, cast[int64](alpha), pointer(A), rowStrideA, colStrideA, pointer(B), rowStrideB, colStrideB, cast[int64](beta), pointer(C), rowStrideC, colStrideC, stream)
+  else:
+    {.error: "laser_hip: unsupported element type " & $T.}
