@@ -305,6 +305,58 @@ int laser_hip_copy_strided_b64_dev(void *d_dst, const int64_t *dst_strides, cons
                                    const int64_t *src_strides, const int64_t *shape, int rank,
                                    void *stream);
 
+/* ---- row-panel sharded gemm_strided over the GPUs of one node, ONE process ---------------------------------------
+ * Laser partitions M across its OpenMP threads with no cross-thread reduction (gemm.nim:160-176: `omp for` over the
+ * ic row blocks), so rows of C are independent units: each GPU owns row panels of A, all of B, and produces the
+ * matching rows of C.  No K split => no reduction => every element is computed exactly as on one GPU (bit-identical,
+ * whatever the device count).  `devices`: ndev HIP ordinals, or NULL for 0..ndev-1; ndev <= 0 = every visible GPU.
+ * Both forms are synchronous (return when every device is done); one host thread per GPU drives it.
+ *
+ * Host pointers (the drop-in form -- same parameter list as gemm_strided after the device list): the rows are cut
+ * into one contiguous range per GPU, each GPU runs the ordinary host-pointer pipeline on its own PCIe link and writes
+ * its rows of C straight back to host memory (no inter-GPU traffic).  laser_hip_set_shard_devices(n) makes the PLAIN
+ * laser_hip_gemm_strided_* entry points route large problems here (n = 1: off, the default; 0: every GPU), so an
+ * unchanged Nim gemm_strided call uses the node. */
+int laser_hip_set_shard_devices(int ndev);
+int laser_hip_get_shard_devices(void);
+/* Device-resident form (operands already in HBM; what the roofline is measured on).  Rows are dealt block-cyclically:
+ * panel (s, g) -- sub-panel s of device slot g -- is rows [(s*ndev + g)*R, +R) of C, R = rows_per_panel from
+ * laser_hip_shard_plan (a multiple of 256 when M allows; panels_per_dev is reduced if steps would be empty).
+ *   dA_panels[g]  device slot g's panels of A stacked in local order: row s*R + i = global row (s*ndev + g)*R + i
+ *                 (element strides rowStrideA / colStrideA)
+ *   dB[g]         B, replicated on every device (strides rowStrideB / colStrideB)
+ *   dC[g]         the FULL row-major C on every device (colStride 1, rowStrideC >= N): device g computes its panels in
+ *                 place and, with a gather mode, receives everybody else's -- the all-gather of C over xGMI -- sub-panel
+ *                 s being sent while sub-panel s+1 multiplies.  beta != 0 reads the device's own copy of its rows.
+ *   gather        LASER_HIP_GATHER_NONE  every device keeps only its own rows;
+ *                 LASER_HIP_GATHER_PEER  the owner pushes finished rows to every peer with hipMemcpyPeerAsync on one
+ *                                        copy stream per peer (all xGMI links at once, SDMA engines, no CUs);
+ *                 LASER_HIP_GATHER_RCCL  ncclAllGather per slab (librccl.so loaded on first use; needs
+ *                                        rowStrideC == N and dC[g] sized for padded_M rows).
+ *   flags         LASER_HIP_SHARD_PIN_TILE: 128x128 tiles for the local products (RCCL's kernels hold CUs meanwhile). */
+#define LASER_HIP_GATHER_NONE 0
+#define LASER_HIP_GATHER_PEER 1
+#define LASER_HIP_GATHER_RCCL 2
+#define LASER_HIP_SHARD_PIN_TILE 1
+int laser_hip_shard_plan(int64_t M, int ndev, int panels_per_dev, int64_t *rows_per_panel,
+                         int *panels_per_dev_used, int64_t *padded_M);
+#define LASER_HIP_DECL_SHARDED(SFX, T)                                                            \
+  int laser_hip_gemm_strided_##SFX##_sharded(int ndev, const int *devices, int64_t M, int64_t N,  \
+                                             int64_t K, T alpha, const T *A, int64_t rowStrideA,  \
+                                             int64_t colStrideA, const T *B, int64_t rowStrideB,  \
+                                             int64_t colStrideB, T beta, T *C, int64_t rowStrideC,\
+                                             int64_t colStrideC);                                 \
+  int laser_hip_gemm_strided_##SFX##_sharded_dev(                                                 \
+      int ndev, const int *devices, int64_t M, int64_t N, int64_t K, T alpha,                     \
+      const T *const *dA_panels, int64_t rowStrideA, int64_t colStrideA, const T *const *dB,      \
+      int64_t rowStrideB, int64_t colStrideB, T beta, T *const *dC, int64_t rowStrideC,           \
+      int panels_per_dev, int gather, int flags);
+LASER_HIP_DECL_SHARDED(f32, float)
+LASER_HIP_DECL_SHARDED(f64, double)
+LASER_HIP_DECL_SHARDED(i32, int32_t)
+LASER_HIP_DECL_SHARDED(i64, int64_t)
+#undef LASER_HIP_DECL_SHARDED
+
 /* ---- cblas-shaped GEMM -- benchmarks/third_party/blas.nim:12-23 ---------------------------------
  * The call conv2d_im2col makes (conv2d_im2col.nim:161-166); ORDER 101 rowMajor / 102 colMajor,
  * TRANS 111 noTranspose / 112 transpose / 113 conjTranspose.  Mapped onto gemm_strided strides. */

@@ -7,6 +7,9 @@ from ._lib import LaserHipError, LIB_PATH, lib  # noqa: F401
 from .primitives import *  # noqa: F401,F403
 from . import primitives  # noqa: F401
 from . import tensor  # noqa: F401
+from . import sharded  # noqa: F401
+from .sharded import (shard_plan, set_shard_devices, get_shard_devices, gemm_strided_sharded, matmul_sharded,  # noqa: F401
+                      gemm_strided_sharded_dev, shard_rows, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SHARD_PIN_TILE)
 from .tensor import (Tensor, HipStorage, newTensor, toTensor, fromTorch, deepCopy, copyFrom, copyFromRaw,  # noqa: F401
                      setZero)
 

@@ -65,6 +65,12 @@ def lib():
             getattr(L, f"laser_hip_gemm_prepack{ab}_{sfx}_dev").argtypes = [vp, i64, i64, i64, vp, i64, i64, vp]
         getattr(L, f"laser_hip_gemm_packed_{sfx}").argtypes = [i64, i64, i64, ct, vp, vp, ct, vp, i64, i64]
         getattr(L, f"laser_hip_gemm_packed_{sfx}_dev").argtypes = [i64, i64, i64, ct, vp, vp, ct, vp, i64, i64, vp]
+        pp = C.POINTER(vp)  # table of per-device pointers
+        getattr(L, f"laser_hip_gemm_strided_{sfx}_sharded").argtypes = [ci, C.POINTER(ci)] + g
+        getattr(L, f"laser_hip_gemm_strided_{sfx}_sharded_dev").argtypes = [
+            ci, C.POINTER(ci), i64, i64, i64, ct, pp, i64, i64, pp, i64, i64, ct, pp, i64, ci, ci, ci]
+    L.laser_hip_shard_plan.argtypes = [i64, ci, ci, C.POINTER(i64), C.POINTER(ci), C.POINTER(i64)]
+    L.laser_hip_set_shard_devices.argtypes = [ci]
     for sfx in ("f32", "f64"):  # fused epilogue: + bias view (ptr, rowStride, colStride) + activation
         ct = _CT[sfx]
         g = [i64, i64, i64, ct, vp, i64, i64, vp, i64, i64, ct, vp, i64, i64, vp, i64, i64, ci]
@@ -126,10 +132,12 @@ def declared_symbols():
              "laser_hip_storage_alloc", "laser_hip_storage_free", "laser_hip_storage_trim", "laser_hip_storage_upload",
              "laser_hip_storage_download", "laser_hip_storage_set_zero",
              "laser_hip_storage_alloc_stream", "laser_hip_storage_upload_stream", "laser_hip_storage_download_stream",
-             "laser_hip_copy_strided_b32_dev", "laser_hip_copy_strided_b64_dev"]
+             "laser_hip_copy_strided_b32_dev", "laser_hip_copy_strided_b64_dev",
+             "laser_hip_shard_plan", "laser_hip_set_shard_devices", "laser_hip_get_shard_devices"]
     for s in _CT:
         names += [f"laser_hip_gemm_strided_{s}", f"laser_hip_gemm_strided_{s}_dev",
                   f"laser_hip_gemm_strided_batched_{s}_dev", f"laser_hip_gemm_packed_{s}",
+                  f"laser_hip_gemm_strided_{s}_sharded", f"laser_hip_gemm_strided_{s}_sharded_dev",
                   f"laser_hip_gemm_packed_{s}_dev"]
         for ab in "AB":
             names += [f"laser_hip_gemm_prepack{ab}_mem_required_{s}", f"laser_hip_gemm_prepack{ab}_{s}",

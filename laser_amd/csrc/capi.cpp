@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/laser_hip.h"
+#include "capi_internal.h"
 #include "common.h"
 
 using namespace laser_hip;
@@ -460,6 +461,15 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   if (int rc = ensure_init()) return rc;
   if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
   if (!A || !B || !C) return fail(LASER_HIP_E_INVALID, "null operand pointer");
+  // laser_hip_set_shard_devices(n != 1): a large plain gemm_strided call is cut into row ranges over n GPUs (rows of
+  // C are independent, gemm.nim:160-176, so the arithmetic is unchanged).  Not for calls that already ARE a shard
+  // (tl_device set by the sharded entry point's worker thread) and not worth it below ~4 tile rows per GPU.
+  if (g_ctx.shard_devices != 1 && tl_device < 0 && !(hepi && (hepi->bias || hepi->act))) {
+    int ndev = g_ctx.shard_devices;
+    if (ndev <= 0 && hipGetDeviceCount(&ndev) != hipSuccess) ndev = 1;
+    if (ndev > 1 && M >= (int64_t)1024 * ndev && (double)M * (double)N * (double)K >= 64.0 * 1024 * 1024 * 1024)
+      return api_sharded_host<T>(ndev, M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, C, rsC, csC);
+  }
   HostCall hc;
   if (hc.rc) return hc.rc;
   int64_t alo, ahi, blo, bhi, clo, chi;
@@ -824,6 +834,21 @@ int copy_strided_api(void *dst, const int64_t *ds, const void *src, const int64_
 }
 }  // namespace
 
+namespace laser_hip {
+int api_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+int api_ensure_init() { return ensure_init(); }
+void api_set_thread_device(int device) { tl_device = device; }
+int api_thread_device() { return tl_device; }
+}  // namespace laser_hip
+
 extern "C" {
 
 int laser_hip_init(int device) {
@@ -914,6 +939,12 @@ int laser_hip_set_split_tail(int on) {  // A/B knob: main + tail launches when t
   return LASER_HIP_OK;
 }
 int64_t laser_hip_last_split(void) { return g_last_split; }
+int laser_hip_set_shard_devices(int ndev) {  // host-pointer gemm_strided over ndev GPUs (1 = off, 0 = every visible GPU)
+  if (ndev < 0 || ndev > kMaxDevices) return fail(LASER_HIP_E_INVALID, "shard devices outside 0..%d", kMaxDevices);
+  g_ctx.shard_devices = ndev;
+  return LASER_HIP_OK;
+}
+int laser_hip_get_shard_devices(void) { return g_ctx.shard_devices; }
 int laser_hip_set_skinny(int on) {  // A/B knob: streaming kernel for matrix-vector-like shapes
   g_ctx.skinny = on != 0;
   return LASER_HIP_OK;

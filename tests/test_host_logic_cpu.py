@@ -56,3 +56,16 @@ def test_tensor_allocation_fails_loudly_without_gpu():
     assert e.value.code == 3
     with pytest.raises(laser_amd.LaserHipError):
         laser_amd.toTensor([[1.0, 2.0], [3.0, 4.0]])
+
+
+def test_shard_plan_matches_the_per_process_plan():
+    """laser_hip_shard_plan (single-process sharded entry points) deals rows exactly like
+    laser_amd.distributed.make_plan (one process per GPU), so both paths lay C out identically."""
+    import itertools
+    import laser_amd
+    from laser_amd.distributed import make_plan
+    for M, n, p in itertools.product([1, 5, 255, 256, 1000, 4100, 8192, 65536, 65537, 100000], [1, 2, 3, 4, 8], [1, 2, 4, 8, 16]):
+        b = make_plan(M, n, p)
+        assert laser_amd.shard_plan(M, n, p) == (b.rows, b.panels_per_rank, b.padded_M), (M, n, p)
+    rows, ppd, padded = laser_amd.shard_plan(65536, 8, 4)
+    assert (rows, ppd, padded) == (2048, 4, 65536)     # BASELINE configs[4]: 4 panels of 2048 rows per GPU
