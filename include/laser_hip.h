@@ -72,16 +72,23 @@ int laser_hip_set_conv_patch(int on);
 /* 1 (default): float32/float64 problems with M <= 8 or N <= 8 (matrix-vector products) run a streaming kernel,
  * same arithmetic; 0: always the tiled kernels (A/B timing) */
 int laser_hip_set_skinny(int on);
+/* 1 (default): small float32 / float64 problems (at most 256 blocks of 32x32 / 16x16 outputs, K <= 1024 -- BASELINE's
+ * 128^3 -- and batches of matrices up to 64x64) run the small-matrix kernel: one wave per block of C, operands loaded
+ * straight into the matrix-instruction registers, no LDS staging (the reference plans such a path: README.md:257-263);
+ * same arithmetic, same bits; 0: always the tiled kernels (A/B timing) */
+int laser_hip_set_small_path(int on);
 /* 1 (default): float problems with few output tiles and K >= 4 kc compute Laser's kc slices as one batched launch and
  * fold them with an ordered combine pass (same arithmetic, same order); 0: always the sequential K loop */
 int laser_hip_set_slice_parallel(int on);
 /* 1 (default): a float32 problem whose last round of workgroup tiles would be badly filled is cut along N into a
  * main launch (whole rounds of the large tile) and a tail launch (small tiles); tiles are independent and every
- * configuration computes identical bits, so results do not change; 0: always one launch (A/B timing) */
+ * configuration computes identical bits, so results do not change.  The tail runs on a library-owned side stream
+ * beside the main launch (event fork / join on the caller's stream: asynchronous, capturable).
+ * 0: always one launch; 2: tail after the main launch on the caller's stream (both for A/B timing) */
 int laser_hip_set_split_tail(int on);
 /* diagnostics: the column where the last float GEMM / conv launch was cut (0: it ran as one launch) */
 int64_t laser_hip_last_split(void);
-/* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet) */
+/* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet; -2: the small-matrix kernel) */
 int laser_hip_last_f32_config(void);
 /* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */
 int laser_hip_set_transpose_variant(int variant);

@@ -78,6 +78,8 @@ struct DeviceCtx {
   hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
   void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[6] = {0, 0, 0, 0, 0, 0};
+  void *zc = nullptr;  // pinned host buffer mapped into the device: zero-copy staging of the small-problem host path
+  size_t zc_sz = 0;
 };
 DeviceCtx g_dev[kMaxDevices];
 // The device a host-pointer call on this thread uses: -1 = the library's default device (laser_hip_init); the
@@ -168,6 +170,24 @@ int scratch_get(int slot, size_t bytes, void **out) {
   return LASER_HIP_OK;
 }
 
+// Pinned, device-mapped host staging for small host-pointer problems (<= kZeroCopyMax bytes of operands): the kernel
+// reads A and B from it and writes C into it across PCIe -- one round trip, because the small-matrix kernel issues all
+// of a block's loads up front -- instead of three blocking hipMemcpy calls (~10-15 us each for 64 KiB).
+constexpr size_t kZeroCopyMax = (size_t)1 << 20;
+int zero_copy_get(size_t bytes, void **out) {
+  DeviceCtx &D = *tl_dev;
+  if (D.zc_sz < bytes) {
+    if (D.zc) HIP_TRY(hipHostFree(D.zc));
+    D.zc = nullptr;
+    D.zc_sz = 0;
+    const size_t want = std::max<size_t>(bytes, (size_t)256 << 10);
+    HIP_TRY(hipHostMalloc(&D.zc, want, hipHostMallocDefault));
+    D.zc_sz = want;
+  }
+  *out = D.zc;
+  return LASER_HIP_OK;
+}
+
 int pipeline_streams() {
   DeviceCtx &D = *tl_dev;
   if (!D.s_up) {
@@ -247,6 +267,10 @@ hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
     const hipError_t e = launch_gemm_skinny<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
+  if (g_ctx.f32_cfg < 0) {  // few 32x32 blocks / batches of tiny matrices: one wave per block, no LDS round trips
+    const hipError_t e = launch_gemm_small<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (g_ctx.f32_cfg < 0) {
     const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
@@ -261,6 +285,8 @@ hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
     if (e != hipErrorNotSupported) return e;
   }
   if (g_ctx.f64_mfma) {
+    const hipError_t es = launch_gemm_small<double>(a, laser, 256, s);
+    if (es != hipErrorNotSupported) return es;
     const hipError_t e = gemm_slice_parallel<double>(a, 256, s);
     if (e != hipErrorNotSupported) return e;
     return launch_gemm_f64(a, laser, s);
@@ -477,6 +503,28 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   view_span(K, N, rsB, csB, &blo, &bhi);
   view_span(M, N, rsC, csC, &clo, &chi);
   const size_t an = (size_t)(ahi - alo + 1), bn = (size_t)(bhi - blo + 1), cn = (size_t)(chi - clo + 1);
+  // small problems (BASELINE configs[0], fp32 128^3): zero-copy through the pinned staging buffer
+  {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t ab = up(an * sizeof(T)), bb = up(bn * sizeof(T)), cb = up(cn * sizeof(T));
+    const bool has_epi = hepi && (hepi->bias || hepi->act);
+    if (!has_epi && g_ctx.f32_cfg < 0 && ab + bb + cb <= kZeroCopyMax && gemm_small_takes((int)sizeof(T), M, N, K, 1) &&
+        std::is_floating_point<T>::value) {
+      void *z;
+      if (int rc = zero_copy_get(ab + bb + cb, &z)) return rc;
+      if (int rc = pipeline_streams()) return rc;
+      T *hA = (T *)z, *hB = (T *)((char *)z + ab), *hC = (T *)((char *)z + ab + bb);
+      memcpy(hA, A + alo, an * sizeof(T));
+      memcpy(hB, B + blo, bn * sizeof(T));
+      const bool c_in = (beta != (T)0) || cn != (size_t)M * (size_t)N;  // read, or a span with gaps that belong to the caller
+      if (c_in) memcpy(hC, C + clo, cn * sizeof(T));
+      GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, hA - alo, rsA, csA, 0, hB - blo, rsB, csB, 0, beta, hC - clo, rsC, csC, 0);
+      HIP_TRY(run_gemm<T>(a, tl_dev->s_comp));
+      HIP_TRY(hipStreamSynchronize(tl_dev->s_comp));
+      memcpy(C + clo, hC, cn * sizeof(T));
+      return LASER_HIP_OK;
+    }
+  }
   void *dA, *dB, *dC;
   if (int rc = scratch_get(0, an * sizeof(T), &dA)) return rc;
   if (int rc = scratch_get(1, bn * sizeof(T), &dB)) return rc;
@@ -873,6 +921,9 @@ int laser_hip_finalize(void) {
       (void)hipStreamDestroy(D.s_down);
       D.s_up = D.s_comp = D.s_down = nullptr;
     }
+    if (D.zc) (void)hipHostFree(D.zc);
+    D.zc = nullptr;
+    D.zc_sz = 0;
     D.device = -1;
   }
   if (g_ctx.device >= 0) (void)hipSetDevice(g_ctx.device);
@@ -935,7 +986,7 @@ int laser_hip_set_slice_parallel(int on) {  // A/B knob: slice-parallel GEMM for
   return LASER_HIP_OK;
 }
 int laser_hip_set_split_tail(int on) {  // A/B knob: main + tail launches when the last round of tiles is badly filled
-  g_split_tail = on != 0;
+  g_split_tail = on < 0 ? 0 : on > 2 ? 1 : on;  // 0 never, 1 tail beside the main launch (default), 2 tail after it
   return LASER_HIP_OK;
 }
 int64_t laser_hip_last_split(void) { return g_last_split; }
@@ -945,6 +996,10 @@ int laser_hip_set_shard_devices(int ndev) {  // host-pointer gemm_strided over n
   return LASER_HIP_OK;
 }
 int laser_hip_get_shard_devices(void) { return g_ctx.shard_devices; }
+int laser_hip_set_small_path(int on) {  // A/B knob: one-wave-per-block kernel for small / batched-tiny problems
+  g_small_path = on != 0;
+  return LASER_HIP_OK;
+}
 int laser_hip_set_skinny(int on) {  // A/B knob: streaming kernel for matrix-vector-like shapes
   g_ctx.skinny = on != 0;
   return LASER_HIP_OK;

@@ -117,6 +117,12 @@ const char *gemm_f32_config_name(int cfg);
 // matrix-vector-like problems (M <= 8 or N <= 8) as an HBM stream; hipErrorNotSupported = not skinny, use the tiled kernels
 template <typename T>
 hipError_t launch_gemm_skinny(const GemmArgs<T> &args, bool laser_order, int kc_elems, hipStream_t s);
+// small-matrix path (gemm_small.hip): one wave per 32x32 (f64: 16x16) block of C, operands loaded straight into the
+// MFMA operand registers; hipErrorNotSupported = not a small problem, use the tiled kernels.  float32 / float64.
+template <typename T>
+hipError_t launch_gemm_small(const GemmArgs<T> &args, bool laser_order, int kc_elems, hipStream_t s);
+extern int g_small_path;
+bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch);  // the dispatch rule of launch_gemm_small
 template <typename T>
 hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream_t s);
 

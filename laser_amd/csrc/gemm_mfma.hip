@@ -2,6 +2,8 @@
 // configuration and, per operand, the HBM->LDS "packing" loader that matches its strides.
 // This replaces the reference's run-time ISA dispatch (gemm.nim:228-247) and its Tiles/partitionMNK
 // geometry (gemm_tiling.nim:276-341) -- on the GPU the geometry is the workgroup tile.
+#include <mutex>
+
 #include "common.h"
 #include "gemm_mfma_cfgs.h"
 
@@ -128,7 +130,7 @@ struct SplitPlan {
   int cfg_main = -1, cfg_tail = -1;
   int64_t n_cut = 0;  // 0: one launch
 };
-int g_split_tail = 1;  // knob (laser_hip_set_split_tail): 0 = never cut
+int g_split_tail = 1;  // knob (laser_hip_set_split_tail): 0 = never cut, 1 = cut, tail beside the main launch, 2 = cut, tail after it
 int64_t g_last_split = 0;  // diagnostics: column cut of the last MFMA GEMM / conv launch (0: single launch)
 static SplitPlan plan_split(const GemmArgs<float> &a, bool exact, bool need_gen, bool conv, bool bn_multiple_only) {
   SplitPlan p;
@@ -171,6 +173,40 @@ static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 
 int g_conv_patch = 1;     // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
 int g_last_f32_cfg = -1;  // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
+
+// Main + tail as a fork / join: the tail runs on a side stream BESIDE the main launch -- its few small workgroups are
+// dispatched first and the main launch's workgroups fill the remaining CUs, then take over the tail's CUs as they free
+// up -- instead of after it, where half the chip would idle for the tail's whole duration.  Event record / wait only:
+// nothing here blocks the host, and a stream capture sees an ordinary fork / join.
+struct ForkJoin {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::mutex mu;  // the record / wait pairs of one call must not interleave with another host thread's
+};
+static ForkJoin g_fj[64];
+template <typename MainFn, typename TailFn>
+static hipError_t launch_main_and_tail(hipStream_t s, MainFn &&main_fn, TailFn &&tail_fn) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (g_split_tail == 2 || dev < 0 || dev >= 64) {  // sequential form (A/B timing)
+    e = main_fn(s);
+    return e != hipSuccess ? e : tail_fn(s);
+  }
+  ForkJoin &fj = g_fj[dev];
+  std::lock_guard<std::mutex> lk(fj.mu);
+  if (!fj.side) {
+    if ((e = hipStreamCreateWithFlags(&fj.side, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&fj.fork, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&fj.join, hipEventDisableTiming)) != hipSuccess) return e;
+  }
+  if ((e = hipEventRecord(fj.fork, s)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(fj.side, fj.fork, 0)) != hipSuccess) return e;
+  if ((e = tail_fn(fj.side)) != hipSuccess) return e;
+  if ((e = hipEventRecord(fj.join, fj.side)) != hipSuccess) return e;
+  if ((e = main_fn(s)) != hipSuccess) return e;
+  return hipStreamWaitEvent(s, fj.join, 0);
+}
 
 // one launch of configuration `cfg` (falling back to a configuration with the scalar loaders when the operands need them)
 template <typename E>
@@ -222,11 +258,11 @@ static hipError_t launch_mfma(const GemmArgs<E> &args, const CfgInfo<E> *cfgs, i
   GemmArgs<E> m = a;  // columns [0, n_cut): whole tiles of the main configuration
   m.N = plan.n_cut;
   if (plain_n) m.Next = plan.n_cut;
-  hipError_t e = launch_mfma_cfg<E>(m, cfgs, plan.cfg_main, exact, s);
-  if (e != hipSuccess) return e;
   GemmArgs<E> t = a;  // columns [n_cut, N)
   t.col0 = plan.n_cut;
-  return launch_mfma_cfg<E>(t, cfgs, plan.cfg_tail, exact, s);
+  return launch_main_and_tail(
+      s, [&](hipStream_t q) { return launch_mfma_cfg<E>(m, cfgs, plan.cfg_main, exact, q); },
+      [&](hipStream_t q) { return launch_mfma_cfg<E>(t, cfgs, plan.cfg_tail, exact, q); });
 }
 
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s) {
@@ -283,11 +319,12 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   if (plan.n_cut <= 0) return launch_conv_cfg(a, plan.cfg_main, exact, s);
   GemmArgs<float> m = a;  // output pixels [0, n_cut) of every image
   m.N = plan.n_cut; m.Next = plan.n_cut;
-  hipError_t e = launch_conv_cfg(m, plan.cfg_main, exact, s);
-  if (e != hipSuccess) return e;
   GemmArgs<float> t = a;  // output pixels [n_cut, oH*oW)
   t.col0 = plan.n_cut;
-  return launch_conv_cfg(t, fix(plan.cfg_tail), exact, s);
+  const int cfg_tail = fix(plan.cfg_tail);
+  return launch_main_and_tail(
+      s, [&](hipStream_t q) { return launch_conv_cfg(m, plan.cfg_main, exact, q); },
+      [&](hipStream_t q) { return launch_conv_cfg(t, cfg_tail, exact, q); });
 }
 
 }  // namespace laser_hip

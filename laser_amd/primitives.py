@@ -106,12 +106,17 @@ def set_slice_parallel(on):
 
 def set_split_tail(on):
     """True (default): fp32 problems whose last round of tiles would be badly filled run as main + tail launches."""
-    _lib.check(_lib.lib().laser_hip_set_split_tail(1 if on else 0))
+    _lib.check(_lib.lib().laser_hip_set_split_tail(int(on)))   # 2: tail launch AFTER the main one (A/B timing of the fork/join)
 
 
 def last_split():
     """Column where the last float GEMM / conv launch was cut into main + tail (0: one launch)."""
     return _lib.lib().laser_hip_last_split()
+
+
+def set_small_path(on):
+    """True (default): small / batched-tiny float problems run the one-wave-per-block small-matrix kernel."""
+    _lib.check(_lib.lib().laser_hip_set_small_path(1 if on else 0))
 
 
 def set_skinny(on):

@@ -750,3 +750,79 @@ def test_slice_parallel_gemm_bit_exact(la, oracle, dtype):
             assert np.array_equal(res[True][:, ::2], want), (M, N, K, ta, tb, float(alpha), float(beta))
             assert np.array_equal(res[False][:, ::2], want), (M, N, K, "sequential")
             assert np.array_equal(res[True][:, 1::2], C0[:, 1::2])          # the gaps of the strided C stay untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_small_matrix_path_bit_exact(la, oracle, dtype):
+    """The small-matrix kernel (one wave per 32x32 / 16x16 block of C, operands straight into the MFMA registers;
+    the reference plans such a path, README.md:257-263): BASELINE configs[0] and friends, host pointers (zero-copy
+    staging) and device-resident, ragged shapes, transposed / strided operands, alpha / beta, two kc slices, fused
+    epilogue -- bit-identical to the oracle and to the tiled kernels it replaces."""
+    import torch
+    rng = np.random.default_rng(11)
+    shapes = [(128, 128, 128), (1, 1, 1), (33, 47, 129), (64, 64, 1000), (256, 256, 512), (500, 500, 300), (17, 300, 65), (96, 40, 700)]
+    for (M, N, K) in shapes:
+        A, B = rand(rng, (M, K), dtype), rand(rng, (K, N), dtype)
+        C0 = rand(rng, (M, N), dtype)
+        for alpha, beta in ((1, 0), (0.5, 0.25)):
+            want = oracle.matmul(A, B, alpha, beta, C0.copy())
+            got = la.matmul(A, B, alpha, beta, C0.copy())                      # host pointers
+            assert np.array_equal(got, want), (M, N, K, alpha, beta, "host")
+            dC = torch.from_numpy(C0.copy()).cuda()
+            la.matmul(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), alpha, beta, dC)
+            if dtype == np.float32:
+                assert la.last_f32_config() == -2, "the small-matrix kernel did not run"
+            assert np.array_equal(dC.cpu().numpy(), want), (M, N, K, alpha, beta, "device")
+        # transposed B, strided A and C through the same kernel (addresses are the only thing that changes)
+        Abig = rand(rng, (2 * M, K + 3), dtype)
+        Av = Abig[::2, 1:K + 1]
+        Bt = np.ascontiguousarray(B.T).T
+        Cbuf = np.full((M, 3 * N), 5, dtype=dtype)
+        Cv = Cbuf[:, ::3]
+        la.gemm_strided(M, N, K, 1, Av, Av.strides[0] // Av.itemsize, 1, Bt, 1, K, 0, Cv, 3 * N, 3)
+        assert np.array_equal(Cv, oracle.matmul(np.ascontiguousarray(Av), B))
+        assert (Cbuf[:, 1::3] == 5).all() and (Cbuf[:, 2::3] == 5).all()
+    # NaN-safe beta == 0, K == 0
+    A, B = rand(rng, (64, 64), dtype), rand(rng, (64, 64), dtype)
+    Cn = np.full((64, 64), np.nan, dtype=dtype)
+    la.matmul(A, B, 1, 0, Cn)
+    assert np.array_equal(Cn, oracle.matmul(A, B))
+    # the tiled kernels compute the same bits
+    try:
+        la.set_small_path(0)
+        assert np.array_equal(la.matmul(A, B), Cn)
+    finally:
+        la.set_small_path(1)
+    # fused epilogue through the small kernel
+    bias = rand(rng, (64,), dtype)
+    got = la.matmul(A, B, 1, 0, None, bias, "relu")
+    assert np.array_equal(got, np.maximum(oracle.matmul(A, B) + bias[None, :], 0).astype(dtype))
+
+
+@pytest.mark.gpu
+def test_batched_small_matrices_bit_exact(la, oracle):
+    """Batched-small entry: batch x (M, N <= 64) problems are batch x blocks independent waves of the small kernel."""
+    import torch
+    rng = np.random.default_rng(12)
+    for (batch, M, N, K) in [(1000, 32, 32, 32), (37, 50, 60, 70), (300, 8, 64, 600), (5, 64, 64, 1024)]:
+        A = torch.from_numpy(rand(rng, (batch, M, K), np.float32)).cuda()
+        B = torch.from_numpy(rand(rng, (batch, K, N), np.float32)).cuda()
+        C = torch.full((batch, M, N), float("nan"), device="cuda")
+        la.gemm_strided_batched(batch, M, N, K, 1.0, A, K, 1, M * K, B, N, 1, K * N, 0.0, C, N, 1, M * N)
+        assert la.last_f32_config() == -2
+        for b in sorted({0, batch // 2, batch - 1}):
+            assert np.array_equal(C[b].cpu().numpy(), oracle.matmul(A[b].cpu().numpy(), B[b].cpu().numpy())), (batch, M, N, K, b)
+        try:
+            la.set_small_path(0)
+            C2 = torch.zeros_like(C)
+            la.gemm_strided_batched(batch, M, N, K, 1.0, A, K, 1, M * K, B, N, 1, K * N, 0.0, C2, N, 1, M * N)
+            assert torch.equal(C, C2)
+        finally:
+            la.set_small_path(1)
+    # shared B (batch stride 0), int32 goes to its own path untouched
+    A = torch.from_numpy(rand(rng, (10, 40, 50), np.float32)).cuda()
+    B = torch.from_numpy(rand(rng, (50, 30), np.float32)).cuda()
+    C = torch.zeros((10, 40, 30), device="cuda")
+    la.gemm_strided_batched(10, 40, 30, 50, 1.0, A, 50, 1, 2000, B, 30, 1, 0, 0.0, C, 30, 1, 1200)
+    assert np.array_equal(C[7].cpu().numpy(), oracle.matmul(A[7].cpu().numpy(), B.cpu().numpy()))
