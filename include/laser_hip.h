@@ -72,19 +72,20 @@ int laser_hip_set_conv_patch(int on);
 /* 1 (default): float32/float64 problems with M <= 8 or N <= 8 (matrix-vector products) run a streaming kernel,
  * same arithmetic; 0: always the tiled kernels (A/B timing) */
 int laser_hip_set_skinny(int on);
-/* 1 (default): small float32 / float64 problems (at most 256 blocks of 32x32 / 16x16 outputs, K <= 1024 -- BASELINE's
- * 128^3 -- and batches of matrices up to 64x64) run the small-matrix kernel: one wave per block of C, operands loaded
- * straight into the matrix-instruction registers, no LDS staging (the reference plans such a path: README.md:257-263);
- * same arithmetic, same bits; 0: always the tiled kernels (A/B timing) */
+/* 1 (default): small float32 / float64 problems -- at most 256 blocks of 32x32 (f64: 16x16) outputs, or a batch of
+ * matrices up to 64x64 -- run the small-matrix kernel (one wave per block of C, operands loaded straight into the
+ * matrix-instruction registers, no LDS staging; the reference plans such a path: README.md:257-263): device-resident
+ * operands for K <= 128 (BASELINE's 128^3), host-pointer calls for K <= 1024 and <= 1 MiB of operands, where the
+ * kernel reads A / B from and writes C to a pinned staging buffer mapped into the device (one PCIe round trip
+ * instead of three blocking copies).  Same arithmetic, same bits; 0: always the tiled kernels (A/B timing) */
 int laser_hip_set_small_path(int on);
 /* 1 (default): float problems with few output tiles and K >= 4 kc compute Laser's kc slices as one batched launch and
  * fold them with an ordered combine pass (same arithmetic, same order); 0: always the sequential K loop */
 int laser_hip_set_slice_parallel(int on);
 /* 1 (default): a float32 problem whose last round of workgroup tiles would be badly filled is cut along N into a
  * main launch (whole rounds of the large tile) and a tail launch (small tiles); tiles are independent and every
- * configuration computes identical bits, so results do not change.  The tail runs on a library-owned side stream
- * beside the main launch (event fork / join on the caller's stream: asynchronous, capturable).
- * 0: always one launch; 2: tail after the main launch on the caller's stream (both for A/B timing) */
+ * configuration computes identical bits, so results do not change.  0: always one launch; 2: the tail on a
+ * library-owned side stream beside the main launch (event fork / join; measured slower, kept for A/B timing) */
 int laser_hip_set_split_tail(int on);
 /* diagnostics: the column where the last float GEMM / conv launch was cut (0: it ran as one launch) */
 int64_t laser_hip_last_split(void);
@@ -311,6 +312,53 @@ int laser_hip_copy_strided_b32_dev(void *d_dst, const int64_t *dst_strides, cons
 int laser_hip_copy_strided_b64_dev(void *d_dst, const int64_t *dst_strides, const void *d_src,
                                    const int64_t *src_strides, const int64_t *shape, int rank,
                                    void *stream);
+
+/* ---- elementwise map over strided device views: the device twin of forEach ----------------------------------------
+ * Laser's forEach / forEachStrided (laser/strided_iteration/foreach.nim:192-264) is a host macro over raw pointers
+ * (`unsafe_raw_data`) with an odometer over shape / strides (foreach_common.nim:102-120).  A tensor whose storage lives
+ * in HBM must never be handed to it (the host would dereference a device address: the Nim shim gives device storage a
+ * distinct pointer type and no unsafe_raw_data for exactly that reason).  These entry points are what such tensors use
+ * instead:      dst[idx] = f(a[idx])      /      dst[idx] = f(a[idx], b[idx])       for every index of `shape`
+ * rank <= 6 (LASER_MAXRANK), every operand with its own ELEMENT strides (0 = broadcast along that dimension), dst may
+ * alias a or b element for element.  alpha / beta are parameters of SCALE / FILL / AXPY / AXPBY (integers: exact up to
+ * 2^53).  Element types f32, f64, i32, i64; the transcendental maps, RECIP and DIV are floating-point only
+ * (LASER_HIP_E_INVALID otherwise).  HBM-bound, asynchronous on `stream`. */
+#define LASER_HIP_MAP_COPY 0     /* a                     (= copy_strided) */
+#define LASER_HIP_MAP_FILL 1     /* alpha                 (no operand read; `a` may be NULL) */
+#define LASER_HIP_MAP_NEG 2
+#define LASER_HIP_MAP_ABS 3
+#define LASER_HIP_MAP_RELU 4     /* a > 0 ? a : 0 */
+#define LASER_HIP_MAP_SCALE 5    /* alpha*a + beta        (two roundings) */
+#define LASER_HIP_MAP_SQUARE 6
+#define LASER_HIP_MAP_EXP 7
+#define LASER_HIP_MAP_LOG 8
+#define LASER_HIP_MAP_TANH 9
+#define LASER_HIP_MAP_SIGMOID 10
+#define LASER_HIP_MAP_SQRT 11
+#define LASER_HIP_MAP_RECIP 12
+#define LASER_HIP_MAP_ADD 32     /* binary from here on */
+#define LASER_HIP_MAP_SUB 33
+#define LASER_HIP_MAP_MUL 34
+#define LASER_HIP_MAP_DIV 35
+#define LASER_HIP_MAP_MAX 36
+#define LASER_HIP_MAP_MIN 37
+#define LASER_HIP_MAP_AXPY 38    /* alpha*a + b */
+#define LASER_HIP_MAP_AXPBY 39   /* alpha*a + beta*b */
+#define LASER_HIP_DECL_MAP(SFX, T)                                                                \
+  int laser_hip_map_strided_unary_##SFX##_dev(int op, T *d_dst, const int64_t *dst_strides,        \
+                                              const T *d_a, const int64_t *a_strides,              \
+                                              const int64_t *shape, int rank, double alpha,        \
+                                              double beta, void *stream);                          \
+  int laser_hip_map_strided_binary_##SFX##_dev(int op, T *d_dst, const int64_t *dst_strides,       \
+                                               const T *d_a, const int64_t *a_strides,             \
+                                               const T *d_b, const int64_t *b_strides,             \
+                                               const int64_t *shape, int rank, double alpha,       \
+                                               double beta, void *stream);
+LASER_HIP_DECL_MAP(f32, float)
+LASER_HIP_DECL_MAP(f64, double)
+LASER_HIP_DECL_MAP(i32, int32_t)
+LASER_HIP_DECL_MAP(i64, int64_t)
+#undef LASER_HIP_DECL_MAP
 
 /* ---- row-panel sharded gemm_strided over the GPUs of one node, ONE process ---------------------------------------
  * Laser partitions M across its OpenMP threads with no cross-thread reduction (gemm.nim:160-176: `omp for` over the

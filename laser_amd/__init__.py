@@ -11,6 +11,6 @@ from . import sharded  # noqa: F401
 from .sharded import (shard_plan, set_shard_devices, get_shard_devices, gemm_strided_sharded, matmul_sharded,  # noqa: F401
                       gemm_strided_sharded_dev, shard_rows, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SHARD_PIN_TILE)
 from .tensor import (Tensor, HipStorage, newTensor, toTensor, fromTorch, deepCopy, copyFrom, copyFromRaw,  # noqa: F401
-                     setZero)
+                     setZero, forEachMap, MAP_OPS)
 
 __version__ = "0.1.0"

@@ -70,6 +70,10 @@ def lib():
         getattr(L, f"laser_hip_gemm_strided_{sfx}_sharded").argtypes = [ci, C.POINTER(ci)] + g
         getattr(L, f"laser_hip_gemm_strided_{sfx}_sharded_dev").argtypes = [
             ci, C.POINTER(ci), i64, i64, i64, ct, pp, i64, i64, pp, i64, i64, ct, pp, i64, ci, ci, ci]
+    for sfx, ct in _CT.items():
+        pi = C.POINTER(i64)
+        getattr(L, f"laser_hip_map_strided_unary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, pi, ci, C.c_double, C.c_double, vp]
+        getattr(L, f"laser_hip_map_strided_binary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, vp, pi, pi, ci, C.c_double, C.c_double, vp]
     L.laser_hip_shard_plan.argtypes = [i64, ci, ci, C.POINTER(i64), C.POINTER(ci), C.POINTER(i64)]
     L.laser_hip_set_shard_devices.argtypes = [ci]
     for sfx in ("f32", "f64"):  # fused epilogue: + bias view (ptr, rowStride, colStride) + activation
@@ -139,6 +143,7 @@ def declared_symbols():
         names += [f"laser_hip_gemm_strided_{s}", f"laser_hip_gemm_strided_{s}_dev",
                   f"laser_hip_gemm_strided_batched_{s}_dev", f"laser_hip_gemm_packed_{s}",
                   f"laser_hip_gemm_strided_{s}_sharded", f"laser_hip_gemm_strided_{s}_sharded_dev",
+                  f"laser_hip_map_strided_unary_{s}_dev", f"laser_hip_map_strided_binary_{s}_dev",
                   f"laser_hip_gemm_packed_{s}_dev"]
         for ab in "AB":
             names += [f"laser_hip_gemm_prepack{ab}_mem_required_{s}", f"laser_hip_gemm_prepack{ab}_{s}",

@@ -321,6 +321,17 @@ hipError_t run_gemm<int64_t>(const GemmArgs<int64_t> &a, hipStream_t s) {
   return launch_gemm_valu<int64_t>(a, false, s);
 }
 
+// the small-matrix kernel on operands that live in host memory mapped into the device (gemm_host's zero-copy staging)
+template <typename T>
+hipError_t run_small_mapped(const GemmArgs<T> &a, hipStream_t s) {
+  if constexpr (std::is_same<T, float>::value)
+    return launch_gemm_small<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s, true);
+  else if constexpr (std::is_same<T, double>::value)
+    return launch_gemm_small<double>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 256, s, true);
+  else
+    return hipErrorNotSupported;
+}
+
 template <typename T>
 GemmArgs<T> make_args(int64_t batch, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
                       int64_t csA, int64_t bsA, const T *B, int64_t rsB, int64_t csB, int64_t bsB, T beta,
@@ -508,7 +519,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t ab = up(an * sizeof(T)), bb = up(bn * sizeof(T)), cb = up(cn * sizeof(T));
     const bool has_epi = hepi && (hepi->bias || hepi->act);
-    if (!has_epi && g_ctx.f32_cfg < 0 && ab + bb + cb <= kZeroCopyMax && gemm_small_takes((int)sizeof(T), M, N, K, 1) &&
+    if (!has_epi && g_ctx.f32_cfg < 0 && ab + bb + cb <= kZeroCopyMax && gemm_small_takes((int)sizeof(T), M, N, K, 1, true) &&
         std::is_floating_point<T>::value) {
       void *z;
       if (int rc = zero_copy_get(ab + bb + cb, &z)) return rc;
@@ -519,7 +530,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
       const bool c_in = (beta != (T)0) || cn != (size_t)M * (size_t)N;  // read, or a span with gaps that belong to the caller
       if (c_in) memcpy(hC, C + clo, cn * sizeof(T));
       GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, hA - alo, rsA, csA, 0, hB - blo, rsB, csB, 0, beta, hC - clo, rsC, csC, 0);
-      HIP_TRY(run_gemm<T>(a, tl_dev->s_comp));
+      HIP_TRY(run_small_mapped<T>(a, tl_dev->s_comp));
       HIP_TRY(hipStreamSynchronize(tl_dev->s_comp));
       memcpy(C + clo, hC, cn * sizeof(T));
       return LASER_HIP_OK;
@@ -986,7 +997,7 @@ int laser_hip_set_slice_parallel(int on) {  // A/B knob: slice-parallel GEMM for
   return LASER_HIP_OK;
 }
 int laser_hip_set_split_tail(int on) {  // A/B knob: main + tail launches when the last round of tiles is badly filled
-  g_split_tail = on < 0 ? 0 : on > 2 ? 1 : on;  // 0 never, 1 tail beside the main launch (default), 2 tail after it
+  g_split_tail = on < 0 ? 0 : on > 2 ? 1 : on;  // 0 never, 1 tail after the main launch (default), 2 tail beside it (A/B arm, measured slower)
   return LASER_HIP_OK;
 }
 int64_t laser_hip_last_split(void) { return g_last_split; }
@@ -1400,6 +1411,52 @@ int laser_hip_copy_strided_b64_dev(void *dst, const int64_t *ds, const void *src
                                    const int64_t *shape, int rank, void *stream) {
   return copy_strided_api<uint64_t>(dst, ds, src, ss, shape, rank, stream);
 }
+
+}  // extern "C"  (a template follows)
+
+// ---- elementwise map over strided views: the device twin of forEach (map_strided.hip) ---------------------------
+namespace {
+template <typename T>
+int map_api(int op, bool binary, T *dst, const int64_t *ds, const T *a, const int64_t *as, const T *b, const int64_t *bs,
+            const int64_t *shape, int rank, double alpha, double beta, void *stream) {
+  if (rank < 0 || rank > kMaxRank) return fail(LASER_HIP_E_INVALID, "rank %d outside 0..%d (LASER_MAXRANK)", rank, kMaxRank);
+  const bool is_bin = op >= LASER_HIP_MAP_ADD && op <= LASER_HIP_MAP_AXPBY;
+  const bool is_un = op >= LASER_HIP_MAP_COPY && op <= LASER_HIP_MAP_RECIP;
+  if (binary ? !is_bin : !is_un) return fail(LASER_HIP_E_INVALID, "map op %d is not a %s op", op, binary ? "binary" : "unary");
+  const bool fp_only = (op >= LASER_HIP_MAP_EXP && op <= LASER_HIP_MAP_RECIP) || op == LASER_HIP_MAP_DIV;
+  if (fp_only && !std::is_floating_point<T>::value) return fail(LASER_HIP_E_INVALID, "map op %d is floating-point only", op);
+  const int nin = binary ? 2 : (op == LASER_HIP_MAP_FILL ? 0 : 1);
+  if (rank > 0 && (!ds || !shape || (nin >= 1 && !as) || (nin >= 2 && !bs))) return fail(LASER_HIP_E_INVALID, "null shape/strides");
+  int64_t total = 1;
+  for (int d = 0; d < rank; d++) {
+    if (shape[d] < 0) return fail(LASER_HIP_E_INVALID, "negative extent");
+    total *= shape[d];
+  }
+  if (int rc = ensure_init()) return rc;
+  if (total == 0) return LASER_HIP_OK;
+  if (!dst || (nin >= 1 && !a) || (nin >= 2 && !b)) return fail(LASER_HIP_E_INVALID, "null buffer");
+  HIP_TRY(launch_map_strided<T>(op, nin, dst, ds, a, as, b, bs, shape, rank, alpha, beta, (hipStream_t)stream));
+  return LASER_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+#define LH_DEF_MAP(SFX, T)                                                                                              \
+  int laser_hip_map_strided_unary_##SFX##_dev(int op, T *dst, const int64_t *ds, const T *a, const int64_t *as,          \
+                                              const int64_t *shape, int rank, double alpha, double beta, void *stream) { \
+    return map_api<T>(op, false, dst, ds, a, as, nullptr, nullptr, shape, rank, alpha, beta, stream);                    \
+  }                                                                                                                     \
+  int laser_hip_map_strided_binary_##SFX##_dev(int op, T *dst, const int64_t *ds, const T *a, const int64_t *as,         \
+                                               const T *b, const int64_t *bs, const int64_t *shape, int rank,            \
+                                               double alpha, double beta, void *stream) {                               \
+    return map_api<T>(op, true, dst, ds, a, as, b, bs, shape, rank, alpha, beta, stream);                                \
+  }
+LH_DEF_MAP(f32, float)
+LH_DEF_MAP(f64, double)
+LH_DEF_MAP(i32, int32_t)
+LH_DEF_MAP(i64, int64_t)
+#undef LH_DEF_MAP
 
 int laser_hip_cblas_sgemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, float alpha, const float *A,
                           int64_t lda, const float *B, int64_t ldb, float beta, float *C, int64_t ldc) {

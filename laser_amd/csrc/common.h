@@ -120,9 +120,10 @@ hipError_t launch_gemm_skinny(const GemmArgs<T> &args, bool laser_order, int kc_
 // small-matrix path (gemm_small.hip): one wave per 32x32 (f64: 16x16) block of C, operands loaded straight into the
 // MFMA operand registers; hipErrorNotSupported = not a small problem, use the tiled kernels.  float32 / float64.
 template <typename T>
-hipError_t launch_gemm_small(const GemmArgs<T> &args, bool laser_order, int kc_elems, hipStream_t s);
+hipError_t launch_gemm_small(const GemmArgs<T> &args, bool laser_order, int kc_elems, hipStream_t s, bool mapped = false);
 extern int g_small_path;
-bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch);  // the dispatch rule of launch_gemm_small
+// the dispatch rule of launch_gemm_small (mapped: the operands live in host memory mapped into the device)
+bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch, bool mapped = false);
 template <typename T>
 hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream_t s);
 
@@ -151,6 +152,10 @@ constexpr int kMaxRank = 6;
 template <typename T>
 hipError_t launch_copy_strided(T *dst, const int64_t *dstrides, const T *src, const int64_t *sstrides,
                                const int64_t *shape, int rank, hipStream_t s);
+// elementwise map over strided rank <= 6 views (map_strided.hip): dst = f(a [, b]); nin = operands read (0: fill)
+template <typename T>
+hipError_t launch_map_strided(int op, int nin, T *dst, const int64_t *dstrides, const T *a, const int64_t *astrides, const T *b,
+                              const int64_t *bstrides, const int64_t *shape, int rank, double alpha, double beta, hipStream_t s);
 template <typename T>
 hipError_t launch_pack_pad(T *dst, int64_t Rpad, int64_t Cpad, const T *src, int64_t R,
                            int64_t Ccols, int64_t rs, int64_t cs, hipStream_t s);

@@ -130,7 +130,7 @@ struct SplitPlan {
   int cfg_main = -1, cfg_tail = -1;
   int64_t n_cut = 0;  // 0: one launch
 };
-int g_split_tail = 1;  // knob (laser_hip_set_split_tail): 0 = never cut, 1 = cut, tail beside the main launch, 2 = cut, tail after it
+int g_split_tail = 1;  // knob (laser_hip_set_split_tail): 0 = never cut, 1 = cut, tail after the main launch, 2 = cut, tail beside it
 int64_t g_last_split = 0;  // diagnostics: column cut of the last MFMA GEMM / conv launch (0: single launch)
 static SplitPlan plan_split(const GemmArgs<float> &a, bool exact, bool need_gen, bool conv, bool bn_multiple_only) {
   SplitPlan p;
@@ -174,10 +174,12 @@ static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 int g_conv_patch = 1;     // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
 int g_last_f32_cfg = -1;  // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
-// Main + tail as a fork / join: the tail runs on a side stream BESIDE the main launch -- its few small workgroups are
-// dispatched first and the main launch's workgroups fill the remaining CUs, then take over the tail's CUs as they free
-// up -- instead of after it, where half the chip would idle for the tail's whole duration.  Event record / wait only:
-// nothing here blocks the host, and a stream capture sees an ordinary fork / join.
+// Main + tail.  Default: the tail launch follows the main launch on the caller's stream.  Knob value 2 runs the tail
+// on a side stream BESIDE the main launch (event fork / join, nothing blocks the host) -- the idea being that its few
+// small workgroups fill CUs the main launch would leave idle in its last round.  MEASURED WORSE on every shape tried
+// (C4 conv 0.590 vs 0.553 ms, profiles/r02/conv_c4_v3.log; 5000^3 2.50 vs 2.24 ms): the tail's workgroups take
+// LDS / register slots that delay whole main-launch workgroups, which costs more than the idle CUs did.  Kept only
+// as the A/B arm that shows it.
 struct ForkJoin {
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -189,7 +191,7 @@ static hipError_t launch_main_and_tail(hipStream_t s, MainFn &&main_fn, TailFn &
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (g_split_tail == 2 || dev < 0 || dev >= 64) {  // sequential form (A/B timing)
+  if (g_split_tail != 2 || dev < 0 || dev >= 64) {  // the production form: tail after main, same stream
     e = main_fn(s);
     return e != hipSuccess ? e : tail_fn(s);
   }

@@ -19,11 +19,20 @@
 
 namespace laser_hip {
 
-template <typename E, bool EXACT>
+// what a lane loads for k >= K: zeros, like Laser's zero-padded panels (gemm_packing.nim:46-55) -- by ADDRESS (the
+// load is pointed here), so no select sits between a load and the MFMA that consumes it
+__device__ __attribute__((aligned(16))) const double g_small_zero[2] = {0.0, 0.0};
+
+// AV / BV: the operand is unit-stride along k (A row-major: colStrideA == 1; B passed transposed: rowStrideB == 1), so
+// a lane fetches 16 bytes = 4 (f64: 2) consecutive k with one load and keeps the ones its MFMA half consumes (the lane
+// halves / quarters take alternate k: half of a vector is used, but the instruction count halves).  Otherwise one
+// scalar load per (lane, k-step).
+template <typename E, bool EXACT, bool AV, bool BV>
 __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
   using M_ = Mma<E>;
   using Acc = typename M_::Acc;
-  constexpr int MB = M_::MB, KS = M_::KS, ACC = M_::ACC;
+  using Vec = typename M_::Vec;
+  constexpr int MB = M_::MB, KS = M_::KS, ACC = M_::ACC, EPV = M_::EPV;
   constexpr int KCH = 64;        // k per register chunk
   constexpr int NJ = KCH / KS;   // MFMA k-steps per chunk (f32: 32, f64: 16)
   const int lane = threadIdx.x, lo = M_::lx(lane), hi = M_::lk(lane);
@@ -52,16 +61,43 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
     return beta == (E)1 ? c0 : M_::mul(c0, beta);
   };
 
+  // register image of a chunk: element [j] = what this lane feeds to k-step j (k = k0 + KS*j + hi).
+  // ONE code path for full and ragged chunks (a 5 us kernel cannot afford several unrolled copies of itself in the
+  // instruction cache): the address is one v_mad_i64_i32 off the row / column base (byte strides fit 32 bits: the
+  // launcher checks), or the address of a zero constant for k >= K.
   E fa[2][NJ], fb[2][NJ];
-  // chunk c -> register set s: lane feeds k = k0 + KS*j + hi of k-step j; clamped address, zero beyond K
-  auto load_chunk = [&](int64_t k0, int s) __attribute__((always_inline)) {
+  const int Km1 = (int)K - 1;
+  const int sab = (int)(g.csA * (int64_t)sizeof(E)), sbb = (int)(g.rsB * (int64_t)sizeof(E));  // byte strides along k
+  auto load_operand = [&](E (&f)[NJ], const E *p, int skb, bool vec, int k0) __attribute__((always_inline)) {
+    // (explicit global address space: a select between two generic pointers would lower to flat loads)
+    typedef const __attribute__((address_space(1))) char *gptr;
+    typedef const __attribute__((address_space(1))) Vec *gvec;
+    typedef const __attribute__((address_space(1))) E *gelem;
+    const gptr pc = (gptr)(uintptr_t)p;
+    const gptr zero = (gptr)(uintptr_t)g_small_zero;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int64_t k = k0 + KS * j + hi;
-      const int64_t kc_ = k < K ? k : K - 1;
-      fa[s][j] = pa[kc_ * g.csA];
-      fb[s][j] = pb[kc_ * g.rsB];
+      if (vec) {
+        // unit stride along k: the 16-byte piece holding k-offset KS*j + hi (K % EPV == 0: the launcher checks).
+        // f32 (KS = 2, EPV = 4): steps 2q, 2q+1 share piece q (one load after CSE), element 2(j%2) + hi;
+        // f64 (KS = 4, EPV = 2): lane quarters hi = 0,1 / 2,3 take pieces 2j / 2j + 1, element hi % 2.
+        const int kp = sizeof(E) == 4 ? k0 + EPV * (j / 2) : k0 + KS * j + 2 * (hi >> 1);
+        const gptr ad = pc + (int64_t)kp * (int64_t)sizeof(E);
+        const Vec v = *(gvec)(kp <= Km1 ? ad : zero);
+        if constexpr (sizeof(E) == 4)
+          f[j] = hi ? v[2 * (j & 1) + 1] : v[2 * (j & 1)];
+        else
+          f[j] = (hi & 1) ? v[1] : v[0];
+      } else {
+        const int k = k0 + KS * j + hi;
+        const gptr ad = pc + (int64_t)k * (int64_t)skb;
+        f[j] = *(gelem)(k <= Km1 ? ad : zero);
+      }
     }
+  };
+  auto load_chunk = [&](int c, int s) __attribute__((always_inline)) {
+    load_operand(fa[s], pa, sab, AV, c * KCH);
+    load_operand(fb[s], pb, sbb, BV, c * KCH);
   };
   Acc acc, run;
 #pragma unroll
@@ -71,17 +107,8 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
     for (int r = 0; r < ACC; r++) run[r] = scaled_c0(r);
   }
   const int nch = (int)((K + KCH - 1) / KCH);
-  const int kc_chunks = EXACT ? g.kc / KCH : 0;
-  load_chunk(0, 0);
-  if (nch > 1) load_chunk(KCH, 1);
-  auto mfma_chunk = [&](int64_t k0, int s) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const bool in = k0 + KS * j + hi < K;  // (k-steps wholly beyond K add +0*0: the chain is unchanged)
-      acc = M_::mma(in ? fa[s][j] : (E)0, in ? fb[s][j] : (E)0, acc);
-    }
-  };
-  for (int c = 0; c < nch; c += 2) {
+  const int kc_chunks = EXACT ? g.kc / KCH : 1;
+  auto mfma_chunk = [&](int c, int s) __attribute__((always_inline)) {
     if constexpr (EXACT) {
       // Laser's pc loop: the accumulator restarts at +0 every kc and the slice sum is added into C (gemm.nim:150-158)
       if (c > 0 && c % kc_chunks == 0) {
@@ -92,21 +119,15 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
         }
       }
     }
-    mfma_chunk((int64_t)c * KCH, 0);
-    if (c + 2 < nch) load_chunk((int64_t)(c + 2) * KCH, 0);
-    if (c + 1 < nch) {
-      if constexpr (EXACT) {
-        if ((c + 1) % kc_chunks == 0) {
 #pragma unroll
-          for (int r = 0; r < ACC; r++) {
-            run[r] = M_::add(run[r], M_::mul(alpha, acc[r]));
-            acc[r] = (E)0;
-          }
-        }
-      }
-      mfma_chunk((int64_t)(c + 1) * KCH, 1);
-      if (c + 3 < nch) load_chunk((int64_t)(c + 3) * KCH, 1);
-    }
+    for (int j = 0; j < NJ; j++) acc = M_::mma(fa[s][j], fb[s][j], acc);  // (k >= K: +0 * +0, the chain is unchanged)
+  };
+  load_chunk(0, 0);
+  for (int c = 0; c < nch; c += 2) {
+    if (c + 1 < nch) load_chunk(c + 1, 1);
+    mfma_chunk(c, 0);
+    if (c + 2 < nch) load_chunk(c + 2, 0);
+    if (c + 1 < nch) mfma_chunk(c + 1, 1);
   }
   // epilogue: C = (beta*C0 or run) + alpha*acc, unfused (gemm_ukernel_generic.nim:68-76); optional fused bias / activation
 #pragma unroll
@@ -133,23 +154,28 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
   }
 }
 
-// Small-problem test: few enough 32x32 (16x16) blocks that one wave per block beats the tiled kernels -- at most one
-// wave per CU for a single problem (256 blocks), any count for batches of tiny matrices (M, N <= 64: a 64x64 LDS tile
-// would be mostly padding) -- and a K short enough that the per-block MFMA chain (K/2 x 64 cycles) stays in the
-// microseconds.  hipErrorNotSupported: not small, use the tiled kernels.
+// Dispatch rule.  The kernel's serial part is the per-block MFMA chain (K/2 x 64 cycles) and its loads are not shared
+// between blocks, so it pays where the tiled kernels are latency-bound, not where they are busy:
+//   device-resident operands: at most 256 blocks (one wave per CU) or a batch of matrices up to 64x64, and K <= 128 --
+//     measured (profiles/r02/small_path_probe*.log, small_gemm*.jsonl): equal to the 64x64-tile kernel at K = 128,
+//     1.3-2.3x slower from K = 256 on (the tiled kernel's 4 waves share every operand element through LDS);
+//   host-mapped operands (the zero-copy staging of the host-pointer entry point, `mapped`): K <= 1024 -- every load
+//     crosses PCIe, and this kernel has them all in flight after one round trip where the tiled kernel pays one round
+//     trip per K-tile.
+// hipErrorNotSupported: not small, use the tiled kernels.
 int g_small_path = 1;  // knob (laser_hip_set_small_path)
-bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch) {
+bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch, bool mapped) {
   if (!g_small_path || (elem_size != 4 && elem_size != 8)) return false;
   const int mb = elem_size == 4 ? 32 : 16;
   const int64_t tm = (M + mb - 1) / mb, tn = (N + mb - 1) / mb;
   const bool tiny_batched = batch > 1 && M <= 64 && N <= 64;
-  return (tm * tn * batch <= 256 || tiny_batched) && K <= 1024;
+  return (tm * tn * batch <= 256 || tiny_batched) && K <= (mapped ? 1024 : 128);
 }
 template <typename E>
-hipError_t launch_gemm_small(const GemmArgs<E> &args, bool laser_order, int kc_elems, hipStream_t s) {
+hipError_t launch_gemm_small(const GemmArgs<E> &args, bool laser_order, int kc_elems, hipStream_t s, bool mapped) {
   using M_ = Mma<E>;
   if (args.M <= 0 || args.N <= 0 || args.K <= 0 || args.batch <= 0) return hipSuccess;
-  if (!gemm_small_takes((int)sizeof(E), args.M, args.N, args.K, args.batch)) return hipErrorNotSupported;
+  if (!gemm_small_takes((int)sizeof(E), args.M, args.N, args.K, args.batch, mapped)) return hipErrorNotSupported;
   const int64_t tm = (args.M + M_::MB - 1) / M_::MB, tn = (args.N + M_::MB - 1) / M_::MB;
   GemmArgs<E> g = args;
   g.tiles_m = (int)tm;
@@ -157,14 +183,31 @@ hipError_t launch_gemm_small(const GemmArgs<E> &args, bool laser_order, int kc_e
   const bool exact = laser_order && args.K > kc_elems;
   g.kc = exact ? kc_elems : 0;
   if (std::is_same<E, float>::value) g_last_f32_cfg = -2;  // diagnostics: "the small-matrix kernel ran"
+  // 16-byte loads along k need an aligned base and strides that keep every row / column on a 16-byte boundary
+  constexpr int64_t EPV = 16 / sizeof(E);
+  auto aligned = [&](const E *p, int64_t sx, int64_t bs) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && sx % EPV == 0 && bs % EPV == 0; };
+  const bool av = args.csA == 1 && args.K % EPV == 0 && aligned(args.A, args.rsA, args.bsA);
+  const bool bv = args.rsB == 1 && args.K % EPV == 0 && aligned(args.B, args.csB, args.bsB);
+  // 32-bit byte strides along k (one v_mad_i64_i32 per address); anything wider goes to the tiled kernels
+  auto fits = [](int64_t st) { return st * (int64_t)sizeof(E) < (1ll << 31) && st * (int64_t)sizeof(E) > -(1ll << 31); };
+  if (!fits(args.csA) || !fits(args.rsB) || args.K >= (1ll << 30)) return hipErrorNotSupported;
   dim3 grid((unsigned)(tm * tn), (unsigned)args.batch, 1), block(64, 1, 1);
-  if (exact)
-    hipLaunchKernelGGL((gemm_small_kernel<E, true>), grid, block, 0, s, g);
-  else
-    hipLaunchKernelGGL((gemm_small_kernel<E, false>), grid, block, 0, s, g);
+#define LH_SMALL(EX, AVV, BVV) hipLaunchKernelGGL((gemm_small_kernel<E, EX, AVV, BVV>), grid, block, 0, s, g)
+  if (exact) {
+    if (av && bv) LH_SMALL(true, true, true);
+    else if (av) LH_SMALL(true, true, false);
+    else if (bv) LH_SMALL(true, false, true);
+    else LH_SMALL(true, false, false);
+  } else {
+    if (av && bv) LH_SMALL(false, true, true);
+    else if (av) LH_SMALL(false, true, false);
+    else if (bv) LH_SMALL(false, false, true);
+    else LH_SMALL(false, false, false);
+  }
+#undef LH_SMALL
   return hipGetLastError();
 }
-template hipError_t launch_gemm_small<float>(const GemmArgs<float> &, bool, int, hipStream_t);
-template hipError_t launch_gemm_small<double>(const GemmArgs<double> &, bool, int, hipStream_t);
+template hipError_t launch_gemm_small<float>(const GemmArgs<float> &, bool, int, hipStream_t, bool);
+template hipError_t launch_gemm_small<double>(const GemmArgs<double> &, bool, int, hipStream_t, bool);
 
 }  // namespace laser_hip

@@ -106,7 +106,7 @@ def set_slice_parallel(on):
 
 def set_split_tail(on):
     """True (default): fp32 problems whose last round of tiles would be badly filled run as main + tail launches."""
-    _lib.check(_lib.lib().laser_hip_set_split_tail(int(on)))   # 2: tail launch AFTER the main one (A/B timing of the fork/join)
+    _lib.check(_lib.lib().laser_hip_set_split_tail(int(on)))   # 2: tail launch BESIDE the main one (A/B arm, measured slower)
 
 
 def last_split():

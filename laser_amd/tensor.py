@@ -286,3 +286,64 @@ def trimStorageCache():
 
 __all__ = ["trimStorageCache", "Tensor", "HipStorage", "newTensor", "toTensor", "fromTorch", "deepCopy", "copyFrom", "copyFromRaw", "setZero",
            "LASER_MAXRANK", "LASER_MEM_ALIGN"]
+
+
+# ---- elementwise maps: the device twin of forEach ---------------------------------------------------
+# Laser's forEach (laser/strided_iteration/foreach.nim:192-264) walks raw HOST pointers; a Tensor whose storage
+# lives in HBM goes through laser_hip_map_strided_*_dev instead (map_strided.hip): dst[idx] = f(a[idx] [, b[idx]])
+# over strided rank <= 6 views, strides of 0 broadcast.
+MAP_OPS = {"copy": 0, "fill": 1, "neg": 2, "abs": 3, "relu": 4, "scale": 5, "square": 6, "exp": 7, "log": 8, "tanh": 9,
+           "sigmoid": 10, "sqrt": 11, "recip": 12, "add": 32, "sub": 33, "mul": 34, "div": 35, "max": 36, "min": 37,
+           "axpy": 38, "axpby": 39}
+_MAP_SFX = {"float32": "f32", "float64": "f64", "int32": "i32", "int64": "i64"}
+
+
+def _bcast_strides(t, shape):
+    """Element strides of t viewed with `shape` (numpy broadcasting: missing / extent-1 dimensions get stride 0)."""
+    pad = len(shape) - t.rank
+    if pad < 0:
+        raise ValueError("operand has more dimensions than the destination")
+    out = []
+    for d, n in enumerate(shape):
+        if d < pad:
+            out.append(0)
+        else:
+            e, st = t.shape[d - pad], t.strides[d - pad]
+            if e == n:
+                out.append(st if n != 1 else 0)
+            elif e == 1:
+                out.append(0)
+            else:
+                raise ValueError(f"operand shape {tuple(t.shape)} does not broadcast to {tuple(shape)}")
+    return out
+
+
+def forEachMap(op, dst, a=None, b=None, alpha=1.0, beta=0.0):
+    """dst[idx] = op(a[idx] [, b[idx]]) for every index of dst -- `forEach x in dst, y in a, z in b: x = f(y, z)` for
+    tensors with DEVICE storage.  op: a key of MAP_OPS; a / b broadcast against dst; dst may alias a or b."""
+    code = MAP_OPS[op] if isinstance(op, str) else int(op)
+    binary = code >= 32
+    sfx = _MAP_SFX[dst.dtype.name]
+    for x in (a, b):
+        if x is not None and x.dtype != dst.dtype:
+            raise TypeError("operands must share the destination's element type")
+    if binary and (a is None or b is None):
+        raise ValueError(f"{op} needs two operands")
+    if not binary and code != MAP_OPS["fill"] and a is None:
+        raise ValueError(f"{op} needs an operand")
+    r = dst.rank
+    if r > LASER_MAXRANK:
+        raise ValueError("rank > LASER_MAXRANK")
+    arr = lambda v: (C.c_int64 * max(r, 1))(*v)
+    L = _lib.lib()
+    pa = C.c_void_p(a.unsafe_raw_data()) if a is not None else None
+    sa = arr(_bcast_strides(a, dst.shape)) if a is not None else arr([0] * r)
+    if binary:
+        fn = getattr(L, f"laser_hip_map_strided_binary_{sfx}_dev")
+        _lib.check(fn(code, C.c_void_p(dst.unsafe_raw_data()), arr(dst.strides), pa, sa, C.c_void_p(b.unsafe_raw_data()),
+                      arr(_bcast_strides(b, dst.shape)), arr(dst.shape), r, float(alpha), float(beta), _stream()))
+    else:
+        fn = getattr(L, f"laser_hip_map_strided_unary_{sfx}_dev")
+        _lib.check(fn(code, C.c_void_p(dst.unsafe_raw_data()), arr(dst.strides), pa, sa, arr(dst.shape), r, float(alpha),
+                      float(beta), _stream()))
+    return dst

@@ -17,7 +17,7 @@ names = laser_amd.f32_configs()
 ref = None
 for patch in (1, 0):
     for mode in (0, 1):
-        for split in (1, 2, 0):   # 1: main + tail, tail beside the main launch; 2: tail after it; 0: one launch
+        for split in (1, 2, 0):   # 1: main + tail (tail after the main launch); 2: tail beside it; 0: one launch
             laser_amd.set_conv_patch(patch); laser_amd.set_float_mode(mode); laser_amd.set_split_tail(split)
             fn = lambda: laser_amd.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None)
             for _ in range(3): fn()
