@@ -412,6 +412,16 @@ LASER_HIP_DECL_SHARDED(i32, int32_t)
 LASER_HIP_DECL_SHARDED(i64, int64_t)
 #undef LASER_HIP_DECL_SHARDED
 
+/* ---- pinned host memory (optional) ---------------------------------------------------------------------------------
+ * The host-pointer entry points accept ANY host memory.  From pageable memory the runtime stages or pins every copy on
+ * the fly; a tensor allocator that wants the full PCIe rate allocates its buffers with host_alloc (64-byte aligned, as
+ * LASER_MEM_ALIGN asks) or registers existing ones -- Laser leaves buffer management to the caller (Design.md:5-7).
+ * The same entry points then move the operands by direct asynchronous DMA; results are identical. */
+int laser_hip_host_alloc(void **host_ptr, int64_t bytes);
+int laser_hip_host_free(void *host_ptr);
+int laser_hip_host_register(void *host_ptr, int64_t bytes);
+int laser_hip_host_unregister(void *host_ptr);
+
 /* ---- cblas-shaped GEMM -- benchmarks/third_party/blas.nim:12-23 ---------------------------------
  * The call conv2d_im2col makes (conv2d_im2col.nim:161-166); ORDER 101 rowMajor / 102 colMajor,
  * TRANS 111 noTranspose / 112 transpose / 113 conjTranspose.  Mapped onto gemm_strided strides. */

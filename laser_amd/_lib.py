@@ -74,6 +74,10 @@ def lib():
         pi = C.POINTER(i64)
         getattr(L, f"laser_hip_map_strided_unary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, pi, ci, C.c_double, C.c_double, vp]
         getattr(L, f"laser_hip_map_strided_binary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, vp, pi, pi, ci, C.c_double, C.c_double, vp]
+    L.laser_hip_host_alloc.argtypes = [C.POINTER(vp), i64]
+    L.laser_hip_host_free.argtypes = [vp]
+    L.laser_hip_host_register.argtypes = [vp, i64]
+    L.laser_hip_host_unregister.argtypes = [vp]
     L.laser_hip_shard_plan.argtypes = [i64, ci, ci, C.POINTER(i64), C.POINTER(ci), C.POINTER(i64)]
     L.laser_hip_set_shard_devices.argtypes = [ci]
     for sfx in ("f32", "f64"):  # fused epilogue: + bias view (ptr, rowStride, colStride) + activation
@@ -138,6 +142,7 @@ def declared_symbols():
              "laser_hip_storage_download", "laser_hip_storage_set_zero",
              "laser_hip_storage_alloc_stream", "laser_hip_storage_upload_stream", "laser_hip_storage_download_stream",
              "laser_hip_copy_strided_b32_dev", "laser_hip_copy_strided_b64_dev",
+             "laser_hip_host_alloc", "laser_hip_host_free", "laser_hip_host_register", "laser_hip_host_unregister",
              "laser_hip_shard_plan", "laser_hip_set_shard_devices", "laser_hip_get_shard_devices"]
     for s in _CT:
         names += [f"laser_hip_gemm_strided_{s}", f"laser_hip_gemm_strided_{s}_dev",

@@ -1458,6 +1458,37 @@ LH_DEF_MAP(i32, int32_t)
 LH_DEF_MAP(i64, int64_t)
 #undef LH_DEF_MAP
 
+// ---- pinned host memory for the host-pointer entry points -----------------------------------------------------------
+// Laser leaves buffer management to the caller ("creating or reusing buffers is left at the discretion of the
+// high-level lib", Design.md:5-7).  The host-pointer entry points work on any memory; from PAGEABLE memory every
+// hipMemcpy is staged or pinned on the fly by the runtime.  A tensor allocator that wants the full PCIe rate allocates
+// its buffers here (or registers what it already has): the same entry points then run their uploads / downloads as
+// direct asynchronous DMA.  Nothing else changes; results are identical.
+int laser_hip_host_alloc(void **host_ptr, int64_t bytes) {
+  if (!host_ptr || bytes < 0) return fail(LASER_HIP_E_INVALID, "host_alloc: bad argument");
+  if (int rc = ensure_init()) return rc;
+  *host_ptr = nullptr;
+  if (bytes == 0) return LASER_HIP_OK;
+  HIP_TRY(hipHostMalloc(host_ptr, (size_t)bytes, hipHostMallocDefault));
+  return LASER_HIP_OK;
+}
+int laser_hip_host_free(void *host_ptr) {
+  if (!host_ptr) return LASER_HIP_OK;
+  HIP_TRY(hipHostFree(host_ptr));
+  return LASER_HIP_OK;
+}
+int laser_hip_host_register(void *host_ptr, int64_t bytes) {
+  if (!host_ptr || bytes <= 0) return fail(LASER_HIP_E_INVALID, "host_register: bad argument");
+  if (int rc = ensure_init()) return rc;
+  HIP_TRY(hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterDefault));
+  return LASER_HIP_OK;
+}
+int laser_hip_host_unregister(void *host_ptr) {
+  if (!host_ptr) return fail(LASER_HIP_E_INVALID, "host_unregister: null pointer");
+  HIP_TRY(hipHostUnregister(host_ptr));
+  return LASER_HIP_OK;
+}
+
 int laser_hip_cblas_sgemm(int order, int tA, int tB, int64_t M, int64_t N, int64_t K, float alpha, const float *A,
                           int64_t lda, const float *B, int64_t ldb, float beta, float *C, int64_t ldc) {
   return cblas_gemm<float>(order, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);

@@ -290,6 +290,28 @@ def aligned_host_buffer(nbytes, dtype=np.uint8, align=64):
     return raw[off:off + nbytes].view(dtype)
 
 
+def pinned_host_buffer(shape, dtype=np.float32):
+    """A numpy array over pinned host memory from laser_hip_host_alloc (what a tensor allocator would use to give the
+    host-pointer entry points direct-DMA uploads); freed when the array is garbage-collected."""
+    import weakref
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _lib.check(_lib.lib().laser_hip_host_alloc(C.byref(p), max(n, 1)))
+    buf = (C.c_char * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, _lib.lib().laser_hip_host_free, C.c_void_p(p.value))
+    return arr
+
+
+def host_register(arr):
+    """Pin an existing numpy array's memory (laser_hip_host_register); pair with host_unregister."""
+    _lib.check(_lib.lib().laser_hip_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+
+def host_unregister(arr):
+    _lib.check(_lib.lib().laser_hip_host_unregister(C.c_void_p(arr.ctypes.data)))
+
+
 # ---- transposes ------------------------------------------------------------------------------------
 def _bsfx(x):
     size = x.element_size() if (_is_dev(x) and not _is_lt(x)) else x.dtype.itemsize
@@ -341,9 +363,27 @@ def im2col_workspace_size(ishape, kshape, padding, strides):
     return _lib.lib().laser_hip_im2col_workspace_size(*ishape, *kshape, *padding, *strides)
 
 
+def _f32_dense(name, x, min_elems):
+    """The conv / im2col / cblas mirrors pass raw pointers of dense float32 buffers: refuse anything else instead of
+    reinterpreting it (a float64 or non-contiguous array would silently be read as garbage, or out of bounds)."""
+    if x is None:
+        return
+    dt = str(x.dtype).replace("torch.", "")
+    if dt != "float32":
+        raise TypeError(f"{name}: float32 expected, got {x.dtype}")
+    contiguous = x.is_contiguous() if (_is_dev(x) and not _is_lt(x)) else (x.is_C_contiguous() if _is_lt(x) else x.flags["C_CONTIGUOUS"])
+    if not contiguous:
+        raise ValueError(f"{name}: a dense (C-contiguous) buffer is required")
+    n = x.numel() if (_is_dev(x) and not _is_lt(x)) else int(x.size)
+    if n < min_elems:
+        raise ValueError(f"{name}: holds {n} elements, {min_elems} are needed")
+
+
 def im2col(pworkspace, oshape, pinput, ishape, kshape, padding, strides):
     """One image [c,h,w] -> pworkspace [c*kH*kW, oH*oW]."""
     L = _lib.lib()
+    _f32_dense("pworkspace", pworkspace, ishape[1] * kshape[2] * kshape[3] * oshape[2] * oshape[3])
+    _f32_dense("pinput", pinput, ishape[1] * ishape[2] * ishape[3])
     if _same_side(pworkspace, pinput):
         _lib.check(L.laser_hip_im2col_f32_dev(_ptr(pworkspace), oshape[2], oshape[3], _ptr(pinput), 1, ishape[1],
                                               ishape[2], ishape[3], kshape[2], kshape[3], *padding, *strides, _stream()))
@@ -362,6 +402,11 @@ def conv2d_im2col(output, oshape, input_, ishape, kernel, kshape, padding, strid
         raise ValueError("oshape does not match conv2d_out_shape(ishape, kshape, padding, strides)")
     if oshape[1] != kshape[0]:
         raise ValueError("oshape.c != kshape.c_out")  # conv2d_im2col.nim:109
+    _f32_dense("output", output, int(np.prod(oshape)))
+    _f32_dense("input", input_, int(np.prod(ishape)))
+    _f32_dense("kernel", kernel, int(np.prod(kshape)))
+    _f32_dense("pworkspace", pworkspace, im2col_workspace_size(ishape, kshape, padding, strides))   # ONE image's worth (the reference's contract)
+    _f32_dense("bias", bias, kshape[0])
     args = [_ptr(output), _ptr(input_), *ishape, _ptr(kernel), *kshape, *padding, *strides, _ptr(pworkspace)]
     act = _activation_code(activation)
     if bias is not None or act:
@@ -389,6 +434,19 @@ def gemm(ORDER, TRANSA, TRANSB, M, N, K, ALPHA, A, LDA, B, LDB, BETA, C_, LDC):
     """cblas-shaped gemm, the call conv2d_im2col makes in the reference (conv2d_im2col.nim:161-166)."""
     L = _lib.lib()
     s = _sfx(C_)
+    if s not in ("f32", "f64") or _sfx(A) != s or _sfx(B) != s:
+        raise TypeError("cblas-shaped gemm: A, B, C must all be float32 or all float64 (blas.nim:18-23)")
+    if _is_dev(A) or _is_dev(B) or _is_dev(C_):
+        raise TypeError("cblas-shaped gemm is a host-pointer entry point (numpy buffers)")
+    rowm = ORDER == rowMajor
+    for name, x, ld, r, c in (("A", A, LDA, (M if TRANSA == noTranspose else K), (K if TRANSA == noTranspose else M)),
+                              ("B", B, LDB, (K if TRANSB == noTranspose else N), (N if TRANSB == noTranspose else K)),
+                              ("C", C_, LDC, M, N)):
+        outer, inner = (r, c) if rowm else (c, r)
+        if ld < inner:
+            raise ValueError(f"{name}: leading dimension {ld} < {inner}")
+        if int(x.size) < (outer - 1) * ld + inner:
+            raise ValueError(f"{name}: buffer too small for {outer} x {inner} with leading dimension {ld}")
     fn = {"f32": L.laser_hip_cblas_sgemm, "f64": L.laser_hip_cblas_dgemm}[s]
     _lib.check(fn(ORDER, TRANSA, TRANSB, M, N, K, ALPHA, _ptr(A), LDA, _ptr(B), LDB, BETA, _ptr(C_), LDC))
     return C_

@@ -86,7 +86,21 @@ def main():
     t0 = time.perf_counter(); laser_amd.matmul(Ah, Bh, 1, 0, Ch); dt = time.perf_counter() - t0
     emit(config="C2 fp32 8192^3 host-pointer end-to-end (H2D A,B + kernel + D2H C, pageable)", ms_med=round(dt * 1e3, 2),
          tflops=round(2.0 * n ** 3 / dt / 1e12, 2))
-    del Ah, Bh, Ch
+    # the same call on pinned host memory (laser_hip_host_alloc: what a tensor allocator would hand out) and through the
+    # sharded host-pointer entry point on one device (the drop-in form of the multi-GPU path)
+    Ap, Bp, Cp = laser_amd.pinned_host_buffer((n, n)), laser_amd.pinned_host_buffer((n, n)), laser_amd.pinned_host_buffer((n, n))
+    Ap[:] = Ah; Bp[:] = Bh
+    laser_amd.matmul(Ap, Bp, 1, 0, Cp)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); laser_amd.matmul(Ap, Bp, 1, 0, Cp); ts.append(time.perf_counter() - t0)
+    assert np.array_equal(Cp, Ch)
+    emit(config="C2 fp32 8192^3 host-pointer end-to-end, pinned host memory (laser_hip_host_alloc)", ms_med=round(sorted(ts)[1] * 1e3, 2),
+         tflops=round(2.0 * n ** 3 / sorted(ts)[1] / 1e12, 2))
+    laser_amd.matmul_sharded(Ap, Bp, [0], out=Cp)
+    t0 = time.perf_counter(); laser_amd.matmul_sharded(Ap, Bp, [0], out=Cp); dt = time.perf_counter() - t0
+    emit(config="C2 fp32 8192^3 laser_hip_gemm_strided_f32_sharded (host pointers, 1 device), pinned", ms_med=round(dt * 1e3, 2))
+    del Ah, Bh, Ch, Ap, Bp, Cp
     # C3: strided / transposed-B 4096^3
     n = 4096
     Abig, Bt, Cbuf = rnd((2 * n, n), 5), rnd((n, n), 6), torch.zeros((n, 2 * n), device="cuda")
@@ -108,7 +122,7 @@ def main():
         laser_amd.set_conv_implicit(implicit)
         for mode in (0, 1):
             laser_amd.set_float_mode(mode)
-            med, mn = ev_time(lambda: laser_amd.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, ws))
+            med, mn = ev_time(lambda: laser_amd.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None))   # NULL workspace: stream-ordered library scratch, all images in one pass
             emit(config="C4 conv 32x128x56x56 * 256x128x3x3 pad1 stride1 " +
                  ("(implicit GEMM: im2col fused into the B loader)" if implicit else "(explicit im2col kernel + batched GEMM)"),
                  mode="laser_order" if mode == 0 else "fast", ms_med=round(med, 4), ms_min=round(mn, 4),

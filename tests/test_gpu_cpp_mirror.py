@@ -32,7 +32,7 @@ def test_cpp_mirror_kats(tmp_path):
 def _build_small(tmp):
     exe = os.path.join(tmp, "small_gemm_bench")
     lib = os.path.join(ROOT, "laser_amd", "lib")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+    subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I/opt/rocm/include",
                     os.path.join(ROOT, "tests", "cpp", "small_gemm_bench.cpp"), "-o", exe, "-L", lib,
                     "-llaser_hip", f"-Wl,-rpath,{lib}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"],
                    check=True)

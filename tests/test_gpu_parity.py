@@ -391,6 +391,45 @@ def test_im2col_and_conv_vs_oracle(la, oracle):
         assert oracle.mean_relative_error(out, oracle.conv2d_direct(x, w, pad, st)) <= 1e-5
 
 
+def test_conv_device_workspace_contract(la, oracle):
+    """on the explicit path a device workspace sized the REFERENCE way (one image, im2col_workspace_size
+    elements) must be enough for any batch -- the images go through it one by one -- and NULL means stream-ordered
+    library scratch; concurrent convolutions on different streams never share a buffer."""
+    import torch
+    rng = np.random.default_rng(23)
+    for (ishape, kshape, pad, st) in [((5, 3, 21, 22), (6, 3, 9, 9), (4, 4), (1, 1)),      # 9x9: always explicit
+                                      ((4, 8, 16, 16), (12, 8, 3, 3), (1, 1), (1, 1))]:    # explicit via the knob
+        x = torch.from_numpy(rng.uniform(0, 1, ishape).astype(np.float32)).cuda()
+        w = torch.from_numpy(rng.uniform(0, 1, kshape).astype(np.float32)).cuda()
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+        want = oracle.conv2d_im2col(x.cpu().numpy(), w.cpu().numpy(), pad, st)
+        w1 = la.im2col_workspace_size(ishape, kshape, pad, st)
+        try:
+            la.set_conv_implicit(False)
+            guard = 64
+            ws = torch.full((w1 + guard,), 7.0, device="cuda")          # one image's worth + a canary
+            out = torch.zeros(oshape, device="cuda")
+            la.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, ws[:w1])
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+            assert (ws[w1:] == 7.0).all(), "the convolution wrote past a single-image workspace"
+            out2 = torch.zeros(oshape, device="cuda")
+            la.conv2d_im2col(out2, oshape, x, ishape, w, kshape, pad, st, None)    # library scratch
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            o1, o2 = torch.zeros(oshape, device="cuda"), torch.zeros(oshape, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(3):                                            # two streams at once: no shared scratch
+                with torch.cuda.stream(s1):
+                    la.conv2d_im2col(o1, oshape, x, ishape, w, kshape, pad, st, None)
+                with torch.cuda.stream(s2):
+                    la.conv2d_im2col(o2, oshape, x.flip(0).contiguous(), ishape, w, kshape, pad, st, None)
+            torch.cuda.synchronize()
+            assert torch.equal(out2, out) and torch.equal(o1, out)
+            assert np.array_equal(o2.cpu().numpy(), want[::-1])
+        finally:
+            la.set_conv_implicit(True)
+
+
 def test_cblas_shaped_gemm(la, oracle):
     rng = np.random.default_rng(20)
     M, N, K = 50, 60, 70
