@@ -96,6 +96,9 @@ int laser_hip_set_transpose_variant(int variant);
 /* int32 GEMM strategy: 1 (default) = signed 8-bit limb decomposition on the int8 matrix cores
  * (bit-exact mod 2^32); 0 = the VALU kernel.  Results are bit-identical. */
 int laser_hip_set_i32_mfma(int on);
+/* int64 GEMM strategy (the reference's int64 micro-kernel: gemm_ukernel_avx512.nim:58-74): 1 (default) = eight signed
+ * 8-bit limbs, 36 limb products on the int8 matrix cores (bit-exact mod 2^64); 0 = the VALU kernel.  Bit-identical. */
+int laser_hip_set_i64_mfma(int on);
 /* float64 GEMM strategy: 1 (default) = v_mfma_f64_16x16x4_f64 (bitwise a k-ordered fma chain, so the
  * laser-order result is unchanged); 0 = the VALU kernel.  Results are bit-identical. */
 int laser_hip_set_f64_mfma(int on);

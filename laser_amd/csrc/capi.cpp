@@ -58,6 +58,7 @@ struct Context {
   hipStream_t s_up = nullptr, s_comp = nullptr;  // host-pointer pipeline: uploads / kernels
   bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
+  bool i64_mfma = true;       // int64 GEMM on the int8 matrix cores (false: VALU kernel)
   int slice_parallel_min = 2;        // (tuning override only) fewest kc slices worth splitting
   int64_t slice_parallel_tiles = 0;  // tuning override of the tile-count limit of the slice-parallel form (0 = built-in rule)
   bool slice_parallel = true; // few tiles x long K: kc slices as one batched launch + ordered combine
@@ -317,6 +318,16 @@ hipError_t run_gemm<int64_t>(const GemmArgs<int64_t> &a, hipStream_t s) {
   if (g_ctx.skinny) {
     const hipError_t e = launch_gemm_skinny<int64_t>(a, false, 256, s);
     if (e != hipErrorNotSupported) return e;
+  }
+  // Large single problems: eight int8 limbs on the matrix cores (gemm_i64_mfma.hip), planes in stream-ordered scratch
+  const double work = (double)a.M * (double)a.N * (double)a.K;
+  if (g_ctx.i64_mfma && a.batch == 1 && work >= 64.0 * 64.0 * 64.0 * 8.0) {
+    void *ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, gemm_i64_mfma_workspace_bytes(a.M, a.N, a.K), s);
+    if (e != hipSuccess) return e;
+    e = launch_gemm_i64_mfma(a, ws, s);
+    hipError_t e2 = hipFreeAsync(ws, s);
+    return e != hipSuccess ? e : e2;
   }
   return launch_gemm_valu<int64_t>(a, false, s);
 }
@@ -982,6 +993,11 @@ int laser_hip_set_f64_mfma(int on) {
 // 1 = int32 GEMM via int8-limb MFMA (default), 0 = VALU kernel (comparison / A-B timing)
 int laser_hip_set_i32_mfma(int on) {
   g_ctx.i32_mfma = on != 0;
+  return LASER_HIP_OK;
+}
+// 1 = int64 GEMM via int8-limb MFMA (default), 0 = VALU kernel (comparison / A-B timing)
+int laser_hip_set_i64_mfma(int on) {
+  g_ctx.i64_mfma = on != 0;
   return LASER_HIP_OK;
 }
 // 1 = implicit GEMM (default), 0 = explicit im2col workspace + batched GEMM (comparison / A-B timing)

@@ -61,6 +61,10 @@ struct GemmArgs {
   // "main" launch of whole rounds of large tiles (N = the cut) and a "tail" launch of small tiles (col0 = the cut);
   // tiles are independent and every configuration is bit-identical, so the result does not depend on the cut.
   int64_t col0;
+  // Implicit-GEMM conv, K-slice-parallel form (tail launches of the laser-order conv): batch = cs_imgs images x nsl kc slices,
+  // workgroup z = blockIdx.y computes image z % cs_imgs over k in [slice*cs_len, min(K, (slice+1)*cs_len)), slice = z / cs_imgs,
+  // as ONE chain into C + z*bsC (a workspace the ordered combine pass folds); cs_len is a multiple of every BK.  0 = off.
+  int32_t cs_imgs, cs_len;
 };
 
 // How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of
@@ -131,6 +135,10 @@ hipError_t launch_gemm_valu(const GemmArgs<T> &args, bool laser_order, hipStream
 // ws = device scratch of gemm_i32_mfma_workspace_bytes(M, N, K) bytes, valid on stream s.
 size_t gemm_i32_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
+// int64 GEMM on the int8 matrix cores (eight signed 8-bit limbs, 36 limb products, bit-exact mod 2^64; K in chunks of
+// 8192 per launch); ws = device scratch of gemm_i64_mfma_workspace_bytes(M, N, K) bytes, valid on stream s.
+size_t gemm_i64_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
+hipError_t launch_gemm_i64_mfma(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 
 extern int g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
 extern int g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches

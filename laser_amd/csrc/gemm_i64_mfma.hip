@@ -199,10 +199,15 @@ __global__ void __launch_bounds__(i64mfma::THREADS, 2) gemm_i8limb64_kernel(cons
     const int8_t *nx = ismem64 + ((kt + 1) & 1) * STAGE;
     const int64_t k2 = (int64_t)(kt + 2) * BKB;
     // -- X: A_hi x B_lo; the rest of this step's fragments are read meanwhile (neighbours hit different groups) --
+    // (the reads go BEHIND the first two MFMAs: hipcc cannot count LDS operations across the loop's back edge, so the
+    // first MFMA of a step waits for lgkmcnt(0) -- with this step's eight reads already issued that would be their
+    // full latency; issued after it, the wait only covers the long-finished reads of the previous step)
+    LH_PROD(7, 0) LH_PROD(6, 0)
+    __builtin_amdgcn_sched_barrier(0);
     ld_a(st, 0);
     ld_b(st, 4);
     __builtin_amdgcn_sched_barrier(0);
-    LH_PROD(7, 0) LH_PROD(6, 0) LH_PROD(6, 1) LH_PROD(5, 0) LH_PROD(5, 2)
+    LH_PROD(6, 1) LH_PROD(5, 0) LH_PROD(5, 2)
     LH_PROD(5, 1) LH_PROD(4, 3) LH_PROD(4, 2) LH_PROD(4, 1) LH_PROD(4, 0)
     __builtin_amdgcn_sched_barrier(0);
     // this stage is fully read (by this wave) and the next one has landed (this wave's pieces): rendezvous
@@ -215,10 +220,13 @@ __global__ void __launch_bounds__(i64mfma::THREADS, 2) gemm_i8limb64_kernel(cons
     if (more) ld_a(nx, 4);
     __builtin_amdgcn_sched_barrier(0);
     LH_PROD(0, 0) LH_PROD(0, 1) LH_PROD(0, 2) LH_PROD(0, 3)
+    __builtin_amdgcn_sched_barrier(0);
     if (more2) dma_piece(kt & 1, k2, 0);
     LH_PROD(1, 0) LH_PROD(1, 1) LH_PROD(1, 2) LH_PROD(1, 3)
+    __builtin_amdgcn_sched_barrier(0);
     if (more2) dma_piece(kt & 1, k2, 1);
     LH_PROD(2, 0) LH_PROD(2, 1) LH_PROD(2, 2) LH_PROD(2, 3)
+    __builtin_amdgcn_sched_barrier(0);
     if (more2) dma_piece(kt & 1, k2, 2);
     LH_PROD(3, 0) LH_PROD(3, 1) LH_PROD(3, 2) LH_PROD(3, 3)
     __builtin_amdgcn_sched_barrier(0);
@@ -226,15 +234,17 @@ __global__ void __launch_bounds__(i64mfma::THREADS, 2) gemm_i8limb64_kernel(cons
     if (more) ld_b(nx, 0);
     __builtin_amdgcn_sched_barrier(0);
     LH_PROD(0, 7) LH_PROD(0, 6) LH_PROD(1, 6)
+    __builtin_amdgcn_sched_barrier(0);
     if (more2) dma_piece(kt & 1, k2, 3);
     LH_PROD(0, 5) LH_PROD(2, 5) LH_PROD(1, 5)
+    __builtin_amdgcn_sched_barrier(0);
     if (more2) dma_piece(kt & 1, k2, 4);
     LH_PROD(3, 4) LH_PROD(2, 4) LH_PROD(1, 4)
+    __builtin_amdgcn_sched_barrier(0);
     if (more2) dma_piece(kt & 1, k2, 5);
     LH_PROD(0, 4)
     __builtin_amdgcn_sched_barrier(0);
   };
-#undef LH_PROD_DECL
   int kt = 0;
   for (; kt < nkt - 2; kt++) k_step(std::true_type{}, std::true_type{}, kt);
   if (kt < nkt - 1) {

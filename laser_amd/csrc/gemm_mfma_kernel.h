@@ -283,7 +283,7 @@ struct TileLoader {
   // gather loader's), read by the fragment gathers: no index arithmetic in the MFMA loop.
   int32_t tw_c0, tw_rem, tk_c, tk_r, tk_q;
   static constexpr int TBL = BX * BK - BK;  // table = the last BK words of the B region of a stage (4 dummy words before it)
-  __device__ __forceinline__ void init_patch(const GemmArgs<E> &g, int64_t n0, int t, const E *image) {
+  __device__ __forceinline__ void init_patch(const GemmArgs<E> &g, int64_t n0, int t, const E *image, int kbase = 0) {
     if constexpr (PATCH) {
       const uint64_t b = reinterpret_cast<uint64_t>(image);
       const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
@@ -303,11 +303,12 @@ struct TileLoader {
         pg_ch[i] = ch;
         pl_dst[i] = p < total ? ch * (g.cRp * g.cPWs) + rr * g.cPWs + 4 + 4 * j : TBL - 4;  // spare pieces: a dummy slot (no predicated store)
       }
-      p_c0 = 0;
-      p_rem = 0;
-      tw_c0 = 0;
-      tw_rem = 0;
-      const int kl = t % BK;
+      // (kbase: first k this workgroup computes -- 0, or the start of its kc slice in the K-slice-parallel form)
+      p_c0 = kbase / khw;
+      p_rem = kbase - p_c0 * khw;
+      tw_c0 = p_c0;
+      tw_rem = p_rem;
+      const int kl = t % BK + kbase;
       tk_c = kl / khw;
       tk_r = (kl - tk_c * khw) / g.ckW;
       tk_q = kl - tk_c * khw - tk_r * g.ckW;
@@ -332,7 +333,7 @@ struct TileLoader {
     }
   }
 
-  __device__ __forceinline__ void init_conv(const GemmArgs<E> &g, int64_t n0, int t, const E *image) {
+  __device__ __forceinline__ void init_conv(const GemmArgs<E> &g, int64_t n0, int t, const E *image, int kbase = 0) {
     if constexpr (CONV) {
       // readfirstlane: tell the compiler the descriptor is uniform (else every load becomes a waterfall loop)
       const uint64_t b = reinterpret_cast<uint64_t>(image);
@@ -345,6 +346,7 @@ struct TileLoader {
       for (int i = 0; i < NV; i++) {
         int xq, k;
         piece_xk(t, i, xq, k);
+        k += kbase;
         kc_[i] = k / khw;
         const int rem = k - kc_[i] * khw;
         kr_[i] = rem / g.ckW;
@@ -598,7 +600,19 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   // x = col of B, k along rsB; for the implicit-GEMM conv the "matrix" is the NCHW image itself
   constexpr bool BPATCH = (BMODE == LOAD_CONV_PATCH);
   constexpr bool BCONV = (BMODE == LOAD_IM2COL) || BPATCH;
-  const E *Bb = BCONV ? g.B + bz * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
+  // K-slice-parallel conv (GemmArgs::cs_imgs): z -> (image, kc slice); this workgroup covers K-tiles [kt0, nkt).
+  // cs_len is a multiple of 2*BK, so kt0 is even (the 2-stage form's stage parity is kt & 1).
+  int kt0 = 0;
+  int64_t kend = g.K, bimg = bz;
+  if constexpr (BCONV) {
+    if (g.cs_imgs > 0) {
+      const int slice = (int)(bz / g.cs_imgs);
+      bimg = bz - (int64_t)slice * g.cs_imgs;
+      kt0 = slice * (g.cs_len / BK);
+      kend = min(g.K, (int64_t)(slice + 1) * g.cs_len);
+    }
+  }
+  const E *Bb = BCONV ? g.B + bimg * g.bsB : g.B + bz * g.bsB + n0 * g.csB;
   E *Cb = g.C + bz * g.bsC;
   const int64_t K = g.K;
   const int64_t mlim = g.M - m0, nlim = g.N - n0;
@@ -624,8 +638,8 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   // (EDGE modes) operand panels as bounds-checked buffers: span = offset of the panel's last valid element + 1
   la.init_buf(Ab, (g.Mext - m0 - 1) * g.rsA + (g.Kext - 1) * g.csA + 1);
   lb.init_buf(Bb, (g.Next - n0 - 1) * g.csB + (g.Kext - 1) * g.rsB + 1);
-  lb.init_conv(g, n0, t, Bb);
-  lb.init_patch(g, n0, t, Bb);
+  lb.init_conv(g, n0, t, Bb, kt0 * BK);
+  lb.init_patch(g, n0, t, Bb, kt0 * BK);
   // LOAD_CONV_PATCH: per B block of this wave, where the lane's output pixel sits in the patch (float index of its
   // window origin in channel slot 0), and the running k position of the fragment reads (uniform)
   int pbase[BPATCH ? TN : 1];
@@ -688,7 +702,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
         for (int r = 0; r < ACC; r++) run[i][n][r] = scaled_c0(i, n, r);
   }
 
-  const int nkt = (int)((K + BK - 1) / BK);
+  const int nkt = (int)((kend + BK - 1) / BK);
   const int kc_tiles = EXACT ? (g.kc / BK) : 0;
 
   // fragment of k-step j: lane feeds k = KS*j + lk(lane) (the MFMA consumes them in ascending order,
@@ -776,9 +790,9 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
   };
 
   if constexpr (STAGES == 2) {
-    // -- prologue: tile 0 -> LDS stage 0 --
-    la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
-    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t, &g);
+    // -- prologue: tile kt0 (0 but for the K-slice form) -> LDS stage 0 --
+    la.load(Ab, g.rsA, g.csA, (int64_t)kt0 * BK, mlim, K, t);
+    lb.load(Bb, g.csB, g.rsB, (int64_t)kt0 * BK, nlim, K, t, &g);
     la.store(smem, t);
     lb.store(smem + BK * BM, t);
     lb.store_table(smem + BK * BM, t, &g);
@@ -811,7 +825,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     };
     // slice folds live outside the steady-state loop (a test inside it is if-converted into
     // predicated VALU work on every tile)
-    int kt = 0;
+    int kt = kt0;
     int next_fold = (EXACT && kc_tiles > 0) ? kc_tiles : 0x7fffffff;
     for (;;) {
       const int stop = min(next_fold - 1, nkt - 1);  // tiles [kt, stop) are followed by another tile of the same slice
@@ -831,15 +845,15 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     }
     if (kt < nkt) k_tile2(std::false_type{}, kt);
   } else {
-    // -- prologue: tile 0 -> LDS stage 0; tile 1 -> registers --
-    la.load(Ab, g.rsA, g.csA, 0, mlim, K, t);
-    lb.load(Bb, g.csB, g.rsB, 0, nlim, K, t, &g);
+    // -- prologue: tile kt0 (0 but for the K-slice form) -> LDS stage 0; tile kt0+1 -> registers --
+    la.load(Ab, g.rsA, g.csA, (int64_t)kt0 * BK, mlim, K, t);
+    lb.load(Bb, g.csB, g.rsB, (int64_t)kt0 * BK, nlim, K, t, &g);
     la.store(smem, t);
     lb.store(smem + BK * BM, t);
     lb.store_table(smem + BK * BM, t, &g);
-    if (nkt > 1) {
-      la.load(Ab, g.rsA, g.csA, BK, mlim, K, t);
-      lb.load(Bb, g.csB, g.rsB, BK, nlim, K, t, &g);
+    if (nkt > kt0 + 1) {
+      la.load(Ab, g.rsA, g.csA, (int64_t)(kt0 + 1) * BK, mlim, K, t);
+      lb.load(Bb, g.csB, g.rsB, (int64_t)(kt0 + 1) * BK, nlim, K, t, &g);
     }
     __syncthreads();
     ldgroup(smem, smem + BK * BM, 0, 0);
@@ -930,7 +944,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
     using F_ = std::false_type;
     // Slice boundaries are handled OUTSIDE the steady-state loop: a fold test inside it gets
     // if-converted by hipcc into 256 predicated VALU ops per K-tile (measured -3 %).
-    int kt = 0;
+    int kt = kt0;
     int next_fold = (EXACT && kc_tiles > 0) ? kc_tiles : 0x7fffffff;  // fold once tiles [.., next_fold) are done
     for (;;) {
       const int stop = min(next_fold, nkt - 2);

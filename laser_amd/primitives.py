@@ -94,6 +94,11 @@ def set_i32_mfma(on):
     _lib.check(_lib.lib().laser_hip_set_i32_mfma(1 if on else 0))
 
 
+def set_i64_mfma(on):
+    """True (default): int64 GEMM on the int8 matrix cores (eight limbs, 36 products); False: VALU kernel."""
+    _lib.check(_lib.lib().laser_hip_set_i64_mfma(1 if on else 0))
+
+
 def set_conv_patch(on):
     """True (default): the implicit conv's B operand comes from an LDS-resident input patch where it fits."""
     _lib.check(_lib.lib().laser_hip_set_conv_patch(1 if on else 0))

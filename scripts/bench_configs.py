@@ -170,12 +170,19 @@ def main():
                      frac_f64_peak=round(2.0 * n ** 3 / (med * 1e-3) / 1e12 / 78.6, 4))
         laser_amd.set_float_mode(0)
         laser_amd.set_f64_mfma(True)
-    n = 960
-    A = torch.randint(0, 101, (n, n), device="cuda", dtype=torch.int64)
-    B = torch.randint(0, 101, (n, n), device="cuda", dtype=torch.int64)
-    C = torch.zeros((n, n), device="cuda", dtype=torch.int64)
-    med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C))
-    emit(config=f"gemm int64 {n}^3 (VALU kernel)", ms_med=round(med, 4), tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
+    # int64 (reference bench shape 960^3, plus the sizes the int32 lines use): eight int8 limbs on the matrix cores vs VALU
+    for n in (960, 1920, 4096, 8192):
+        A = torch.randint(-2 ** 62, 2 ** 62, (n, n), device="cuda", dtype=torch.int64)
+        B = torch.randint(-2 ** 62, 2 ** 62, (n, n), device="cuda", dtype=torch.int64)
+        C = torch.zeros((n, n), device="cuda", dtype=torch.int64)
+        for on in (True, False):
+            if not on and n > 4096:
+                continue
+            laser_amd.set_i64_mfma(on)
+            med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C), iters=5 if n > 4096 else 9)
+            emit(config=f"gemm int64 {n}^3 " + ("(int8-limb MFMA, 36 limb products)" if on else "(VALU kernel)"), ms_med=round(med, 4),
+                 tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
+        laser_amd.set_i64_mfma(True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/configs.jsonl", "w") as f:
         for r in OUT:

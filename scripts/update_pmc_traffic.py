@@ -2,6 +2,8 @@
 """Rewrite profiles/pmc_traffic.json from a gpu_profile_bench.sh output directory (its summary.md): per-launch
 FETCH_SIZE / WRITE_SIZE of bench.py's two headline kernels, stamped with the hash of the kernel sources they were
 measured on (bench.py quotes `roofline.traffic` only while that hash still matches).
+Run it on the GPU box right after the passes (gpu_profile_bench.sh does), so that the hash is taken from the very tree
+the counters were measured on; it writes <prof_dir>/pmc_traffic.json, which is then copied to profiles/pmc_traffic.json.
 usage: update_pmc_traffic.py <prof_dir> [source-label]"""
 import json
 import os
@@ -42,7 +44,7 @@ def main():
         f, w = per[k]["FETCH_SIZE"], per[k]["WRITE_SIZE"]
         out[mode] = {"bytes_per_launch": int(round((2 * f + w) * 1024)), "fetch_size_kib": f, "write_size_kib": w,
                      "kernel": k, "grid_threads": per[k].get("_grid"), "dispatches": per[k].get("_dispatches"), "source": label}
-    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as fh:
+    with open(os.path.join(prof, "pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
         fh.write("\n")
     print(json.dumps(out, indent=1))

@@ -235,6 +235,47 @@ def test_int32_mfma_limb_path_bit_exact(la, oracle):
         assert np.array_equal(la.matmul(B.T.copy(), A.T.copy()), oracle.matmul(B.T.copy(), A.T.copy())), val
 
 
+def test_int64_mfma_limb_path_bit_exact(la, oracle):
+    """int64 on the int8 matrix cores (eight signed 8-bit limbs, 36 limb products; the reference's int64 micro-kernel is
+    gemm_ukernel_avx512.nim:58-74) == VALU kernel == oracle: full-range operands (wrap-around mod 2^64), every stride
+    flavour, alpha/beta, ragged shapes, K past the 8192-k launch chunk, extreme limb digits."""
+    import torch
+    rng = np.random.default_rng(23)
+    info = np.iinfo(np.int64)
+    for (M, N, K) in [(128, 64, 32), (128, 128, 64), (130, 257, 100), (64, 64, 8192 + 70), (513, 129, 1000), (200, 300, 16500)]:
+        A = rng.integers(info.min, info.max, (M, K), dtype=np.int64)
+        B = rng.integers(info.min, info.max, (K, N), dtype=np.int64)
+        C0 = rng.integers(info.min, info.max, (M, N), dtype=np.int64)
+        for alpha, beta in [(1, 0), (-3, 7), (int(info.min), 1)]:
+            want = oracle.matmul(A, B, alpha, beta, C0.copy())
+            got = la.matmul(A, B, alpha, beta, C0.copy())
+            assert np.array_equal(got, want), (M, N, K, alpha, beta)
+        # strided / transposed views on the device-resident path
+        dA = torch.from_numpy(np.asfortranarray(A)).cuda()          # column-major A
+        dBt = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t()  # transposed B
+        dC = torch.zeros((M, 2 * N), dtype=torch.int64, device="cuda")
+        la.matmul(dA, dBt, 1, 0, dC[:, ::2])
+        want = oracle.matmul(A, B)
+        assert np.array_equal(dC[:, ::2].cpu().numpy(), want)
+        assert (dC[:, 1::2] == 0).all()
+        try:
+            la.set_i64_mfma(False)
+            assert np.array_equal(la.matmul(A, B), want)
+        finally:
+            la.set_i64_mfma(True)
+    # extreme digits: every limb at its limits, carries rippling through all eight limbs
+    for val in (int(info.min), int(info.max), -1, 0x7f7f7f7f7f7f7f7f, -0x7f7f7f7f7f7f7f80, 0x0080808080808080,
+                128, 127, -128, -129, 1 << 32, (1 << 32) - 1, -(1 << 56)):
+        A = np.full((64, 96), val, dtype=np.int64)
+        B = rng.integers(info.min, info.max, (96, 64), dtype=np.int64)
+        assert np.array_equal(la.matmul(A, B), oracle.matmul(A, B)), val
+        assert np.array_equal(la.matmul(B.T.copy(), A.T.copy()), oracle.matmul(B.T.copy(), A.T.copy())), val
+    # small values too (only the low limbs populated; the high ones are sign extension)
+    A = rng.integers(-100, 101, (256, 512), dtype=np.int64)
+    B = rng.integers(-100, 101, (512, 192), dtype=np.int64)
+    assert np.array_equal(la.matmul(A, B), A @ B)
+
+
 def test_device_resident_path_matches_host_path(la, oracle):
     import torch
     rng = np.random.default_rng(15)
