@@ -67,8 +67,12 @@ int laser_hip_f32_config_count(void);
  * reference's literal structure (conv2d_im2col.nim:126-166).  Results are bit-identical. */
 int laser_hip_set_conv_implicit(int on);
 /* 1 (default): the implicit conv reads its B operand from an LDS-resident input patch when that fits;
- * 0: always the per-element gather (A/B timing) */
+ * 0: always the per-element gather (A/B timing).  Results are bit-identical. */
 int laser_hip_set_conv_patch(int on);
+/* 1 (default): the tail launch of a laser-order implicit conv (the output pixels past the last whole round of large
+ * tiles) runs Laser's kc slices (gemm.nim:150-158) as parallel workgroup sets + an ordered combine; 0: one workgroup per
+ * tail tile over all of K.  Results are bit-identical. */
+int laser_hip_set_conv_kslice(int on);
 /* 1 (default): float32/float64 problems with M <= 8 or N <= 8 (matrix-vector products) run a streaming kernel,
  * same arithmetic; 0: always the tiled kernels (A/B timing) */
 int laser_hip_set_skinny(int on);

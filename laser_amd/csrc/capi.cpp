@@ -1006,6 +1006,10 @@ int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from
   g_conv_patch = on != 0;
   return LASER_HIP_OK;
 }
+int laser_hip_set_conv_kslice(int on) {  // A/B knob: laser-order conv tail as parallel kc slices + ordered combine (1) or one launch (0)
+  g_conv_kslice = on != 0;
+  return LASER_HIP_OK;
+}
 int laser_hip_set_slice_parallel(int on) {  // A/B knob: slice-parallel GEMM for few-tile / long-K problems
   g_ctx.slice_parallel = on != 0;
   if (on > 100) g_ctx.slice_parallel_tiles = on;  // (tuning: on > 100 sets the tile-count threshold,

@@ -141,6 +141,7 @@ size_t gemm_i64_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_i64_mfma(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 
 extern int g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
+extern int g_conv_kslice;        // laser-order conv tail as parallel kc slices + ordered combine (1, default)
 extern int g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches
 extern int64_t g_last_split;    // diagnostics: column cut of the last MFMA launch (0 = one launch)
 extern int g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used

@@ -19,15 +19,15 @@
 //      transposed on the way, like pack_B, gemm_packing.nim:63-94), zero-padded to tile multiples;
 //   2. gemm_i8limb64_kernel: 128x64 workgroup tile, 8 waves, ONE 32x32 block per wave -- the eight accumulator groups
 //      (one per power of 256) are 128 registers, which is what caps the wave tile.  32 k per LDS stage (48 KiB: 8 A planes
-//      + 8 B planes of 32-byte rows), double buffered, filled by LDS-DMA (`global_load_lds_dwordx4`); the 16-byte chunk c
+//      + 8 B planes of 32-byte rows), a ring of three (a stage is requested two steps ahead), filled by LDS-DMA (`global_load_lds_dwordx4`); the 16-byte chunk c
 //      of row r sits at slot c ^ ((r>>3)&1) -- applied on the DMA's source address and on the fragment read -- which puts
 //      the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) on 16 distinct 16-byte slots (conflict-free,
 //      no padding).  A k-step is three phases that keep all 64 fragment registers single-buffered:
 //          X: A_hi x B_lo (10 MFMAs)   while the A_lo / B_hi fragments of this step are read
 //          Y: A_lo x B_lo (16 MFMAs)   while the A_hi fragments of the NEXT step are read (dead since X)
 //          Z: A_lo x B_hi (10 MFMAs)   while the B_lo fragments of the NEXT step are read (dead since Y)
-//      with the barrier between X and Y (next stage landed; this stage fully read) and the six DMA pieces of the stage
-//      after next riding between the MFMAs of Y and Z.
+//      with the barrier between X and Y (next stage landed; this stage fully read) and the six DMA pieces of step t+3
+//      riding between the MFMAs of Y and Z into the ring slot step t just freed.
 //      Epilogue: sum_s G_s << 8s in 64-bit (G_0..3 sign-extended; of G_4..7 only the low 32 - 8(s-4) bits survive the
 //      shift), alpha / beta wrapping, strided store.
 #include <type_traits>
@@ -177,27 +177,40 @@ __global__ void __launch_bounds__(i64mfma::THREADS, 2) gemm_i8limb64_kernel(cons
 
   const int nkt = (int)(g.Kpad / BKB);
 
-  // prologue: stages 0 and 1 in flight, then the fragments phase X of step 0 needs
+  // prologue: stages 0, 1, 2 in flight (ring of three: a stage is requested two whole steps before it is read, which
+  // is what covers an HBM round trip -- with two buffers and one step of distance the kernel ran at 37 % of the matrix
+  // rate, waiting on the DMA at every step), then the fragments phase X of step 0 needs
 #pragma unroll
   for (int j = 0; j < PIECES_PER_WAVE; j++) dma_piece(0, 0, j);
   if (nkt > 1) {
 #pragma unroll
     for (int j = 0; j < PIECES_PER_WAVE; j++) dma_piece(1, BKB, j);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage 0 landed (the 6 pieces of stage 1 may still fly)
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  if (nkt > 2) {
+#pragma unroll
+    for (int j = 0; j < PIECES_PER_WAVE; j++) dma_piece(2, 2 * BKB, j);
+  }
+  // stage 0 landed (the pieces of stages 1 and 2 may still fly)
+  if (nkt > 2)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nkt > 1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   ld_a(ismem64, 4);
   ld_b(ismem64, 0);
 
+  int sb = 0;  // ring slot of the step being computed
 #define LH_PROD(P, Q) acc[P + Q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[P], fb[Q], acc[P + Q], 0, 0, 0);
-  // MORE: step kt+1 exists; MORE2: step kt+2 exists
-  auto k_step = [&](auto MORE_, auto MORE2_, int kt) __attribute__((always_inline)) {
-    constexpr bool more = decltype(MORE_)::value, more2 = decltype(MORE2_)::value;
-    const int8_t *st = ismem64 + (kt & 1) * STAGE;
-    const int8_t *nx = ismem64 + ((kt + 1) & 1) * STAGE;
-    const int64_t k2 = (int64_t)(kt + 2) * BKB;
+  // MORE: step kt+1 exists; MORE2: step kt+2 exists (its pieces are in flight at this step's barrier); MORE3: step kt+3
+  // exists (its pieces are requested during this step, into the slot this step frees)
+  auto k_step = [&](auto MORE_, auto MORE2_, auto MORE3_, int kt) __attribute__((always_inline)) {
+    constexpr bool more = decltype(MORE_)::value, more2 = decltype(MORE2_)::value, more3 = decltype(MORE3_)::value;
+    const int sb1 = (sb == 2) ? 0 : sb + 1;
+    const int8_t *st = ismem64 + sb * STAGE;
+    const int8_t *nx = ismem64 + sb1 * STAGE;
+    const int64_t k3 = (int64_t)(kt + 3) * BKB;
     // -- X: A_hi x B_lo; the rest of this step's fragments are read meanwhile (neighbours hit different groups) --
     // (the reads go BEHIND the first two MFMAs: hipcc cannot count LDS operations across the loop's back edge, so the
     // first MFMA of a step waits for lgkmcnt(0) -- with this step's eight reads already issued that would be their
@@ -210,24 +223,27 @@ __global__ void __launch_bounds__(i64mfma::THREADS, 2) gemm_i8limb64_kernel(cons
     LH_PROD(6, 1) LH_PROD(5, 0) LH_PROD(5, 2)
     LH_PROD(5, 1) LH_PROD(4, 3) LH_PROD(4, 2) LH_PROD(4, 1) LH_PROD(4, 0)
     __builtin_amdgcn_sched_barrier(0);
-    // this stage is fully read (by this wave) and the next one has landed (this wave's pieces): rendezvous
-    if (more)
+    // this stage is fully read (by this wave) and the next one has landed (this wave's pieces; the six pieces of the
+    // stage after next stay in flight): rendezvous
+    if (more2)
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if (more)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (more) __syncthreads();
-    // -- Y: A_lo x B_lo; A_hi of the next step is read, three DMA pieces of the step after next are issued --
+    // -- Y: A_lo x B_lo; A_hi of the next step is read, three DMA pieces of step kt+3 go into the slot just freed --
     if (more) ld_a(nx, 4);
     __builtin_amdgcn_sched_barrier(0);
     LH_PROD(0, 0) LH_PROD(0, 1) LH_PROD(0, 2) LH_PROD(0, 3)
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) dma_piece(kt & 1, k2, 0);
+    if (more3) dma_piece(sb, k3, 0);
     LH_PROD(1, 0) LH_PROD(1, 1) LH_PROD(1, 2) LH_PROD(1, 3)
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) dma_piece(kt & 1, k2, 1);
+    if (more3) dma_piece(sb, k3, 1);
     LH_PROD(2, 0) LH_PROD(2, 1) LH_PROD(2, 2) LH_PROD(2, 3)
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) dma_piece(kt & 1, k2, 2);
+    if (more3) dma_piece(sb, k3, 2);
     LH_PROD(3, 0) LH_PROD(3, 1) LH_PROD(3, 2) LH_PROD(3, 3)
     __builtin_amdgcn_sched_barrier(0);
     // -- Z: A_lo x B_hi; B_lo of the next step is read, the other three DMA pieces are issued --
@@ -235,23 +251,30 @@ __global__ void __launch_bounds__(i64mfma::THREADS, 2) gemm_i8limb64_kernel(cons
     __builtin_amdgcn_sched_barrier(0);
     LH_PROD(0, 7) LH_PROD(0, 6) LH_PROD(1, 6)
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) dma_piece(kt & 1, k2, 3);
+    if (more3) dma_piece(sb, k3, 3);
     LH_PROD(0, 5) LH_PROD(2, 5) LH_PROD(1, 5)
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) dma_piece(kt & 1, k2, 4);
+    if (more3) dma_piece(sb, k3, 4);
     LH_PROD(3, 4) LH_PROD(2, 4) LH_PROD(1, 4)
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) dma_piece(kt & 1, k2, 5);
+    if (more3) dma_piece(sb, k3, 5);
     LH_PROD(0, 4)
     __builtin_amdgcn_sched_barrier(0);
+    sb = sb1;
   };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
   int kt = 0;
-  for (; kt < nkt - 2; kt++) k_step(std::true_type{}, std::true_type{}, kt);
-  if (kt < nkt - 1) {
-    k_step(std::true_type{}, std::false_type{}, kt);
+  for (; kt < nkt - 3; kt++) k_step(T_{}, T_{}, T_{}, kt);
+  if (kt < nkt - 2) {
+    k_step(T_{}, T_{}, F_{}, kt);
     kt++;
   }
-  if (kt < nkt) k_step(std::false_type{}, std::false_type{}, kt);
+  if (kt < nkt - 1) {
+    k_step(T_{}, F_{}, F_{}, kt);
+    kt++;
+  }
+  if (kt < nkt) k_step(F_{}, F_{}, F_{}, kt);
 #undef LH_PROD
 
   // epilogue: C = beta*C0 + alpha*sum_s (G_s << 8s), all mod 2^64; beta == 0 never reads C
@@ -286,7 +309,7 @@ hipError_t launch_gemm_i64_mfma(const GemmArgs<int64_t> &a, void *ws, hipStream_
   using namespace i64mfma;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipSuccess;
   const int64_t Mpad = rup64i(a.M, BM), Npad = rup64i(a.N, BN);
-  constexpr size_t lds = 2 * STAGE;
+  constexpr size_t lds = 3 * STAGE;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static_assert(PIECES_PER_WAVE * 8 == PIECES && PIECES_PER_WAVE == 6, "six DMA pieces per wave per stage");
   static PerDeviceOnce attr;

@@ -172,6 +172,7 @@ static int fallback_exact_cfg(const GemmArgs<double> &) { return 0; }
 static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 
 int g_conv_patch = 1;     // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
+int g_conv_kslice = 1;    // laser-order conv: tail launch as parallel kc slices + ordered combine (0: one workgroup per tail tile)
 int g_last_f32_cfg = -1;  // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
 // Main + tail.  Default: the tail launch follows the main launch on the caller's stream.  Knob value 2 runs the tail
@@ -284,6 +285,8 @@ static hipError_t launch_conv_cfg(const GemmArgs<float> &a, int cfg, bool exact,
     pick_mode<float>(a.A, a.rsA, a.csA, a.bsA, a.M, a.K, c.bm, c.bk, &va, &ea);
     // B through an LDS-resident input patch when it fits the B region of a stage (else the per-element gather)
     ConvPatchGeom pg;
+    // (patch vs gather on the 8-wave 256x128x16 laser-order kernel is box-to-box noise: C4 0.557 vs 0.541 ms in
+    // profiles/r02/conv_c4_v6.log, 0.528 vs 0.530 ms in conv_c4_v7.log -- no per-configuration rule)
     const bool patch_ok = g_conv_patch && a.cW % 4 == 0 && a.cpW <= 4 &&
                           conv_patch_geom(c.bk, c.bn, a.cW, a.coW, a.ckH, a.ckW, a.csH, a.csW, &pg);
     const int bmode = patch_ok ? LOAD_CONV_PATCH : LOAD_IM2COL;
@@ -303,6 +306,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   a.Mext = a.M; a.Next = a.N; a.Kext = a.K;
   a.dbg = 0;
   a.col0 = 0;
+  a.cs_imgs = 0; a.cs_len = 0;
   const bool exact = laser_order && a.K > 512;
   a.kc = exact ? 512 : 0;
   // the BK=32 laser-order kernel has no registers left for the gather state (it would spill): same tile at BK=16
@@ -324,6 +328,30 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   GemmArgs<float> t = a;  // output pixels [n_cut, oH*oW)
   t.col0 = plan.n_cut;
   const int cfg_tail = fix(plan.cfg_tail);
+  // Laser-order tail, K-slice-parallel: the tail launch is a few small workgroups whose K loop is latency-bound (C4: 128
+  // workgroups of 64x64, 44 us for 2 % of the work).  Laser's kc slices are independent chains from +0 whose sums are
+  // added in order (gemm.nim:150-158), so the tail runs as images x slices workgroup sets, each ONE chain over its 512 k
+  // into a workspace, and the ordered combine pass folds them: same fused multiply-adds, same order => bit-identical.
+  const int64_t nsl = (a.K + 511) / 512, ntail = a.N - plan.n_cut;
+  if (exact && g_conv_kslice && g_split_tail == 1 && nsl >= 2 && a.bias == nullptr && a.act == 0 && a.bsC == a.M * a.rsC &&
+      (int64_t)a.batch * nsl <= 65535) {
+    if (hipError_t e = launch_conv_cfg(m, plan.cfg_main, exact, s); e != hipSuccess) return e;
+    const int64_t mn = a.M * ntail;
+    float *W = nullptr;
+    if (hipError_t e = hipMallocAsync((void **)&W, (size_t)(nsl * a.batch * mn) * sizeof(float), s); e != hipSuccess) return e;
+    t.alpha = 1.0f; t.beta = 0.0f;
+    t.kc = 0;
+    t.cs_imgs = a.batch; t.cs_len = 512;
+    t.batch = (int32_t)(a.batch * nsl);
+    t.C = W - plan.n_cut;  // the kernel addresses C by absolute column: column n_cut + j of slice-image z lands at W[z][i][j]
+    t.rsC = ntail; t.csC = 1; t.bsC = mn;
+    hipError_t e = launch_conv_cfg(t, plan.cfg_tail, false, s);
+    // images stack as rows of one (batch*M) x ntail view of the output's tail columns
+    if (e == hipSuccess)
+      e = launch_combine_slices<float>(a.C + plan.n_cut * a.csC, a.rsC, a.csC, W, (int64_t)a.batch * a.M, ntail, (int)nsl, a.alpha, a.beta, s);
+    const hipError_t e2 = hipFreeAsync(W, s);
+    return e != hipSuccess ? e : e2;
+  }
   return launch_main_and_tail(
       s, [&](hipStream_t q) { return launch_conv_cfg(m, plan.cfg_main, exact, q); },
       [&](hipStream_t q) { return launch_conv_cfg(t, cfg_tail, exact, q); });

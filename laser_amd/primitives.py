@@ -104,6 +104,11 @@ def set_conv_patch(on):
     _lib.check(_lib.lib().laser_hip_set_conv_patch(1 if on else 0))
 
 
+def set_conv_kslice(on):
+    """True (default): laser-order conv tail launches run Laser's kc slices in parallel + an ordered combine."""
+    _lib.check(_lib.lib().laser_hip_set_conv_kslice(1 if on else 0))
+
+
 def set_slice_parallel(on):
     """True (default): few-tile / long-K float problems run Laser's kc slices in parallel + an ordered combine."""
     _lib.check(_lib.lib().laser_hip_set_slice_parallel(int(on)))

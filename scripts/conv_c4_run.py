@@ -15,10 +15,12 @@ out = torch.zeros(oshape, device="cuda")
 flops = 2.0 * oshape[0] * oshape[1] * oshape[2] * oshape[3] * kshape[1] * 9
 names = laser_amd.f32_configs()
 ref = None
-for patch in (1, 0):
+for patch in (1, 0):          # LDS input patch / per-element gather
     for mode in (0, 1):
-        for split in (1, 2, 0):   # 1: main + tail (tail after the main launch); 2: tail beside it; 0: one launch
-            laser_amd.set_conv_patch(patch); laser_amd.set_float_mode(mode); laser_amd.set_split_tail(split)
+        for split, ks in ((1, 1), (1, 0), (0, 1)):   # main + tail with the K-slice-parallel tail / sequential tail; one launch
+            if mode == 1 and ks == 0:
+                continue                              # (the K-slice tail is a laser-order mechanism)
+            laser_amd.set_conv_patch(patch); laser_amd.set_float_mode(mode); laser_amd.set_split_tail(split); laser_amd.set_conv_kslice(ks)
             fn = lambda: laser_amd.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None)
             for _ in range(3): fn()
             ts = []
@@ -31,7 +33,7 @@ for patch in (1, 0):
             if mode == 0:
                 if ref is None: ref = out.clone()
                 assert torch.equal(ref, out), "laser-order result depends on the launch plan / loader"
-            print(f"loader={'patch ' if patch else 'gather'} {'laser' if mode == 0 else 'fast '} split={split} "
+            print(f"loader={('gather', 'patch ')[patch]} {'laser' if mode == 0 else 'fast '} split={split} kslice={ks} "
                   f"cfg={names[laser_amd.last_f32_config()]} cut={laser_amd.last_split()} "
                   f"{ts[2]:.4f} ms (min {ts[0]:.4f}) {flops/ts[2]/1e9:6.1f} TF", flush=True)
-laser_amd.set_conv_patch(1); laser_amd.set_float_mode(0); laser_amd.set_split_tail(1)
+laser_amd.set_conv_patch(1); laser_amd.set_float_mode(0); laser_amd.set_split_tail(1); laser_amd.set_conv_kslice(1)

@@ -604,6 +604,41 @@ def test_full_size_conv_c4_every_image(la, oracle):
     assert cut > 0 and cut % 128 == 0, "C4 (1600 tiles of 128x128 = 3.1 rounds) is expected to run as main + tail"
 
 
+def test_conv_tail_kslice_parallel_bit_exact(la, oracle):
+    """Laser-order implicit conv whose launch plan has a tail: the tail runs Laser's kc slices (gemm.nim:150-158) as
+    parallel workgroup sets + an ordered combine.  Same bits as the sequential tail (knob off), as the single launch and
+    as the oracle -- C_in*kH*kW = 1152 (two whole slices + 128), 576 (one slice + 64), 900 (a ragged last slice that is
+    no multiple of the K-tile), both B loaders."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(45)
+    cases = [((32, 128, 56, 56), (256, 128, 3, 3), (1, 1), (1, 1)),
+             ((32, 64, 56, 56), (256, 64, 3, 3), (1, 1), (1, 1)),
+             ((32, 100, 56, 56), (256, 100, 3, 3), (1, 1), (1, 1)),
+             ((24, 128, 60, 60), (192, 128, 3, 3), (1, 1), (2, 2))]
+    took = 0
+    for ishape, kshape, pad, st in cases:
+        x = torch.rand(ishape, generator=g, device="cuda") - 0.5
+        w = torch.rand(kshape, generator=g, device="cuda") - 0.5
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+        want = None
+        for patch in (1, 0):
+            outs = {}
+            for ks in (1, 0):
+                try:
+                    la.set_conv_patch(patch); la.set_conv_kslice(ks)
+                    out = torch.full(oshape, 7.0, device="cuda")
+                    la.conv2d_im2col(out, oshape, x, ishape, w, kshape, pad, st, None)
+                    took += la.last_split() > 0
+                    outs[ks] = out
+                finally:
+                    la.set_conv_patch(1); la.set_conv_kslice(1)
+            assert torch.equal(outs[1], outs[0]), (ishape, kshape, patch)
+            if want is None:
+                want = oracle.conv2d_im2col(x.cpu().numpy(), w.cpu().numpy(), pad, st)
+            assert np.array_equal(outs[1].cpu().numpy(), want), (ishape, kshape, patch)
+    assert took >= 4, "at least the C4-like cases are expected to run as main + tail"
+
+
 def test_split_tail_launch_plans_bit_exact(la, oracle):
     """Main + tail cut (columns [0, cut) in whole rounds of large tiles, [cut, N) in small tiles): shapes whose last round
     of tiles is badly filled.  Same bits as the single launch and as the oracle, for plain, transposed and batched
