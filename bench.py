@@ -481,11 +481,11 @@ def main():
                 cmd = [sys.executable, os.path.abspath(__file__), "--single-process", str(world), "--size", str(n), "--steps",
                        str(min(args.steps, 5)), "--warmup", "2"] + (["--mode", args.mode] if args.mode else [])
                 try:
-                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
                     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                     out["single_process_sharded"] = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]}
                 except subprocess.TimeoutExpired:
-                    out["single_process_sharded"] = {"error": "timed out after 420 s"}
+                    out["single_process_sharded"] = {"error": "timed out after 240 s"}
                 except Exception as e:
                     out["single_process_sharded"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             print(json.dumps(out), flush=True)

@@ -117,15 +117,17 @@ class ShardedGemm:
             from . import primitives
             names = primitives.f32_configs()
             cfg = names.index(SHARDED_TILE_CONFIG) if SHARDED_TILE_CONFIG in names else None
+        prev = None
         if self._pin_tiles and cfg is not None:
             from . import primitives
+            prev = primitives.get_f32_config()     # the caller's own setting is restored, not clobbered
             primitives.set_f32_config(cfg)
         try:
             works = self._run_panels(A_local, B, C_full)
         finally:
-            if self._pin_tiles and cfg is not None:
+            if prev is not None:
                 from . import primitives
-                primitives.set_f32_config(-1)
+                primitives.set_f32_config(prev)
         for w in works:
             w.wait()
         return C_full[: self.M]

@@ -80,8 +80,19 @@ def get_float_mode():
     return _lib.lib().laser_hip_get_float_mode()
 
 
+_f32_config = -1   # what this process last asked for (the library has no getter; -1 = its heuristic)
+
+
 def set_f32_config(cfg):
+    """Force an fp32 tile configuration (index into f32_configs()); -1 = the library's heuristic."""
+    global _f32_config
     _lib.check(_lib.lib().laser_hip_set_f32_config(int(cfg)))
+    _f32_config = int(cfg)
+
+
+def get_f32_config():
+    """The configuration set_f32_config last selected in this process (-1 = heuristic)."""
+    return _f32_config
 
 
 def set_f64_mfma(on):
