@@ -59,6 +59,7 @@ struct Context {
   bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
   bool i64_mfma = true;       // int64 GEMM on the int8 matrix cores (false: VALU kernel)
+  bool host_pipeline_2d = true;  // large row-major host-pointer calls: row panels x column panels (false: row panels only)
   int slice_parallel_min = 2;        // (tuning override only) fewest kc slices worth splitting
   int64_t slice_parallel_tiles = 0;  // tuning override of the tile-count limit of the slice-parallel form (0 = built-in rule)
   bool slice_parallel = true; // few tiles x long K: kc slices as one batched launch + ordered combine
@@ -431,6 +432,7 @@ int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, in
   bool closed = false;
   hipError_t down_err = hipSuccess;
   const int device = D.device;
+  const hipStream_t s_down = D.s_down;
   std::thread downloader([&]() {
     (void)hipSetDevice(device);
     for (;;) {
@@ -445,8 +447,11 @@ int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, in
       const int64_t r0 = i * R, r1 = std::min<int64_t>(M, r0 + R);
       int64_t lo, hi;
       c_span(r0, r1, &lo, &hi);
+      // (asynchronous copy on its own stream + synchronise, not a blocking hipMemcpy: beside the uploads of s_up the
+      // blocking form gets 26 GB/s each way, this one 46 -- scripts/pcie_probe.py, pageable memory)
       hipError_t e = hipEventSynchronize(ev_comp[i]);
-      if (e == hipSuccess) e = hipMemcpy(C + lo, dC0 + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpyAsync(C + lo, dC0 + lo, (size_t)(hi - lo + 1) * sizeof(T), hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipStreamSynchronize(s_down);
       if (e != hipSuccess && down_err == hipSuccess) down_err = e;
     }
   });
@@ -497,6 +502,129 @@ int gemm_host_pipelined(int64_t M, int64_t N, int64_t K, T alpha, const T *A, in
 #undef PIPE_TRY
   finish();
   if (down_err != hipSuccess) return fail(LASER_HIP_E_HIP, "D2H of a C panel failed: %s", hipGetErrorString(down_err));
+  return LASER_HIP_OK;
+}
+
+// 2-D pipelined host path: row panels of A x column panels of B.  The row-panel pipeline above cannot start a kernel
+// before ALL of B has crossed PCIe (8192^3: 4.7 of its ~14 ms); here B is cut into column panels as well and the
+// uploads grow the computable region as a square -- B_0, A_0, then whichever of the next A row panel / B column panel
+// keeps (rows up)/M ~ (cols up)/N -- so the first tile multiplies after one panel of each, every upload releases a row
+// or column STRIP of C as one launch (the new row panel x every column already up, or the new column panel x every row
+// already up: 12 launches at 8192^3, growing with what is on the device -- one launch per TILE left three quarters of
+// the chip idle, 17.7 ms vs 15.5 ms for the row-panel form), and every finished strip is copied back while later panels
+// are still arriving.  Elements of C are independent and each is ONE chain over all of K, so the arithmetic is unchanged.  Needs row-major-like
+// operands (unit column stride; the column panels of B and the tiles of C are pitched 2-D copies).
+template <typename T>
+int gemm_host_pipelined2d(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, const T *B, int64_t rsB, T beta,
+                          T *C, int64_t rsC, const T *dA0, const T *dB0, T *dC0, bool c_up) {
+  if (int rc = pipeline_streams()) return rc;
+  DeviceCtx &D = *tl_dev;
+  int64_t R = (M / 8 + 255) / 256 * 256;  // ~8 row panels of whole 256-row tiles
+  if (R < 256) R = 256;
+  const int nI = (int)((M + R - 1) / R);
+  int64_t W = (N / 4 + 255) / 256 * 256;  // ~4 column panels of whole 256-column tiles
+  if (W < 256) W = 256;
+  const int nJ = (int)((N + W - 1) / W);
+  // one strip of C per upload: the new row panel x every column already up, or the new column panel x every row already up
+  struct Strip { int64_t r0, r1, c0, c1; hipEvent_t done; };
+  std::vector<Strip> strips;
+  strips.reserve((size_t)nI + nJ);
+  std::vector<hipEvent_t> ev_up;
+  std::mutex qm;
+  std::condition_variable qcv;
+  std::deque<int> queue;
+  bool closed = false;
+  hipError_t down_err = hipSuccess;
+  const int device = D.device;
+  const hipStream_t s_down = D.s_down;
+  std::thread downloader([&]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      Strip t;
+      {
+        std::unique_lock<std::mutex> lk(qm);
+        qcv.wait(lk, [&] { return !queue.empty() || closed; });
+        if (queue.empty()) return;
+        t = strips[queue.front()];
+        queue.pop_front();
+      }
+      hipError_t e = hipEventSynchronize(t.done);
+      if (e == hipSuccess) {
+        // (asynchronous copies on their own stream + synchronise: see gemm_host_pipelined)
+        if (t.c0 == 0 && t.c1 == N)  // whole rows: one contiguous span
+          e = hipMemcpyAsync(C + t.r0 * rsC, dC0 + t.r0 * rsC, (size_t)((t.r1 - t.r0 - 1) * rsC + N) * sizeof(T), hipMemcpyDeviceToHost, s_down);
+        else
+          e = hipMemcpy2DAsync(C + t.r0 * rsC + t.c0, (size_t)rsC * sizeof(T), dC0 + t.r0 * rsC + t.c0, (size_t)rsC * sizeof(T),
+                               (size_t)(t.c1 - t.c0) * sizeof(T), (size_t)(t.r1 - t.r0), hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+      }
+      if (e != hipSuccess && down_err == hipSuccess) down_err = e;
+    }
+  });
+  auto finish = [&]() {
+    {
+      std::lock_guard<std::mutex> lk(qm);
+      closed = true;
+    }
+    qcv.notify_all();
+    downloader.join();
+    for (hipEvent_t e : ev_up) (void)hipEventDestroy(e);
+    for (Strip &t : strips) (void)hipEventDestroy(t.done);
+  };
+#define PIPE_TRY(expr)                                                                                        \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) {                                                                                   \
+      finish();                                                                                               \
+      (void)hipDeviceSynchronize();                                                                           \
+      return fail(LASER_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                                         \
+  } while (0)
+  // one upload (row panel of A [+ of C when it is read], or column panel of B), then the strip of C it completes
+  int a_up = 0, b_up = 0;
+  auto upload_and_launch = [&](bool is_a) -> int {
+    hipEvent_t ev;
+    PIPE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ev_up.push_back(ev);
+    Strip t;
+    if (is_a) {
+      t.r0 = a_up * R; t.r1 = std::min<int64_t>(M, t.r0 + R);
+      t.c0 = 0; t.c1 = std::min<int64_t>(N, b_up * W);
+      PIPE_TRY(hipMemcpyAsync((T *)dA0 + t.r0 * rsA, A + t.r0 * rsA, (size_t)((t.r1 - t.r0 - 1) * rsA + K) * sizeof(T), hipMemcpyHostToDevice, D.s_up));
+      if (c_up)
+        PIPE_TRY(hipMemcpyAsync(dC0 + t.r0 * rsC, C + t.r0 * rsC, (size_t)((t.r1 - t.r0 - 1) * rsC + N) * sizeof(T), hipMemcpyHostToDevice, D.s_up));
+      a_up++;
+    } else {
+      t.c0 = b_up * W; t.c1 = std::min<int64_t>(N, t.c0 + W);
+      t.r0 = 0; t.r1 = std::min<int64_t>(M, a_up * R);
+      PIPE_TRY(hipMemcpy2DAsync((T *)dB0 + t.c0, (size_t)rsB * sizeof(T), B + t.c0, (size_t)rsB * sizeof(T), (size_t)(t.c1 - t.c0) * sizeof(T),
+                                (size_t)K, hipMemcpyHostToDevice, D.s_up));
+      b_up++;
+    }
+    if (t.r1 <= t.r0 || t.c1 <= t.c0) return LASER_HIP_OK;  // the very first upload has no partner yet
+    PIPE_TRY(hipEventRecord(ev, D.s_up));
+    PIPE_TRY(hipStreamWaitEvent(D.s_comp, ev, 0));  // s_up is in order: this event covers every earlier upload too
+    GemmArgs<T> a = make_args<T>(1, t.r1 - t.r0, t.c1 - t.c0, K, alpha, dA0 + t.r0 * rsA, rsA, 1, 0, dB0 + t.c0, rsB, 1, 0, beta,
+                                 dC0 + t.r0 * rsC + t.c0, rsC, 1, 0);
+    PIPE_TRY(run_gemm<T>(a, D.s_comp));
+    PIPE_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    PIPE_TRY(hipEventRecord(t.done, D.s_comp));
+    {
+      std::lock_guard<std::mutex> lk(qm);
+      strips.push_back(t);
+      queue.push_back((int)strips.size() - 1);
+    }
+    qcv.notify_one();
+    return LASER_HIP_OK;
+  };
+  while (a_up < nI || b_up < nJ) {
+    // B first, then keep the uploaded fractions level (ties go to A: its panels are the cheaper, contiguous copies)
+    const bool take_b = b_up < nJ && (a_up >= nI || b_up == 0 || (int64_t)b_up * nI < (int64_t)a_up * nJ);
+    if (int rc = upload_and_launch(!take_b)) return rc;
+  }
+#undef PIPE_TRY
+  finish();
+  if (down_err != hipSuccess) return fail(LASER_HIP_E_HIP, "D2H of a C strip failed: %s", hipGetErrorString(down_err));
   return LASER_HIP_OK;
 }
 
@@ -578,6 +706,10 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
       depi.bias = (const T *)dbias - lo;
     }
   }
+  // both operands and C row-major-like, and big enough that B's upload is worth hiding: the 2-D form
+  if (!fused && g_ctx.host_pipeline_2d && csA == 1 && csB == 1 && csC == 1 && rsA >= K && rsB >= N && rsC >= N && M >= 2048 &&
+      N >= 2048 && bn * sizeof(T) >= ((size_t)32 << 20) && (an + bn + cn) * sizeof(T) >= ((size_t)128 << 20))
+    return gemm_host_pipelined2d<T>(M, N, K, alpha, A, rsA, B, rsB, beta, C, rsC, dA0, dB0, dC0, c_up);
   if (!fused && panels_disjoint && M >= 2048 && (an + bn + cn) * sizeof(T) >= ((size_t)64 << 20))
     return gemm_host_pipelined<T>(M, N, K, alpha, A, rsA, csA, B + blo, bn, rsB, csB, beta, C, rsC, csC, dA0, dB0,
                                   (T *)dB, dC0, c_up);
@@ -1004,6 +1136,10 @@ int laser_hip_set_i64_mfma(int on) {
 int laser_hip_last_f32_config(void) { return g_last_f32_cfg; }
 int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from an LDS input patch (1) or gathered (0)
   g_conv_patch = on != 0;
+  return LASER_HIP_OK;
+}
+int laser_hip_set_host_pipeline(int mode) {  // A/B knob: 1 = 2-D (row x column panel) host pipeline where it applies, 0 = row panels only
+  g_ctx.host_pipeline_2d = mode != 0;
   return LASER_HIP_OK;
 }
 int laser_hip_set_conv_kslice(int on) {  // A/B knob: laser-order conv tail as parallel kc slices + ordered combine (1) or one launch (0)

@@ -120,6 +120,11 @@ def set_conv_kslice(on):
     _lib.check(_lib.lib().laser_hip_set_conv_kslice(1 if on else 0))
 
 
+def set_host_pipeline(mode):
+    """1 (default): large row-major host-pointer calls stream row panels x column panels; 0: row panels only."""
+    _lib.check(_lib.lib().laser_hip_set_host_pipeline(int(mode)))
+
+
 def set_slice_parallel(on):
     """True (default): few-tile / long-K float problems run Laser's kc slices in parallel + an ordered combine."""
     _lib.check(_lib.lib().laser_hip_set_slice_parallel(int(on)))

@@ -314,6 +314,43 @@ def test_host_pointer_pipelined_path(la, oracle):
     assert np.array_equal(la.matmul(Ai, Bi), oracle.matmul(Ai, Bi))
 
 
+def test_host_pointer_2d_pipelined_path(la, oracle):
+    """Large row-major host-pointer calls stream row panels of A x column panels of B (the first kernel starts after one
+    panel of each; every finished tile of C is copied back by a pitched 2-D copy): same bits as the oracle and as the
+    row-panel pipeline (knob off) -- ragged panel edges, beta != 0, padded leading dimensions on all three operands with
+    caller-owned gaps, pinned host memory, float32 and int32."""
+    rng = np.random.default_rng(24)
+    M, N, K = 4100, 4352, 2000          # 136 MB of operands; 4100 rows / 4352 columns leave ragged last panels
+    A = rand(rng, (M, K), np.float32)
+    B = rand(rng, (K, N), np.float32)
+    C0 = rand(rng, (M, N), np.float32)
+    want = oracle.matmul(A, B)
+    got = la.matmul(A, B)
+    assert np.array_equal(got, want)
+    try:
+        la.set_host_pipeline(0)
+        assert np.array_equal(la.matmul(A, B), want)
+    finally:
+        la.set_host_pipeline(1)
+    want2 = oracle.matmul(A, B, 0.5, 0.25, C0.copy())
+    assert np.array_equal(la.matmul(A, B, 0.5, 0.25, C0.copy()), want2)
+    # padded leading dimensions: the gaps belong to the caller and must come back untouched
+    Abuf = np.full((M, K + 24), np.nan, dtype=np.float32); Abuf[:, :K] = A
+    Bbuf = np.full((K, N + 40), np.nan, dtype=np.float32); Bbuf[:, :N] = B
+    Cbuf = np.full((M, N + 8), np.nan, dtype=np.float32)
+    la.matmul(Abuf[:, :K], Bbuf[:, :N], 1, 0, Cbuf[:, :N])
+    assert np.array_equal(Cbuf[:, :N], want)
+    assert np.isnan(Cbuf[:, N:]).all()
+    # pinned host memory (laser_hip_host_alloc)
+    Ap, Bp, Cp = la.pinned_host_buffer((M, K)), la.pinned_host_buffer((K, N)), la.pinned_host_buffer((M, N))
+    Ap[:] = A; Bp[:] = B; Cp[:] = 0
+    la.matmul(Ap, Bp, 1, 0, Cp)
+    assert np.array_equal(Cp, want)
+    Ai = rng.integers(-2**31, 2**31 - 1, (M, K), dtype=np.int32)
+    Bi = rng.integers(-2**31, 2**31 - 1, (K, N), dtype=np.int32)
+    assert np.array_equal(la.matmul(Ai, Bi), oracle.matmul(Ai, Bi))
+
+
 def test_batched_device_gemm(la, oracle):
     import torch
     rng = np.random.default_rng(16)
