@@ -17,7 +17,7 @@
 // top digit may be any representative mod 256 because 256^4 == 0).
 //
 // Structure (the GPU analogue of Laser's explicit packing pass, gemm_packing.nim:24-94):
-//   1. limb_planes_kernel: strided int32 operand -> four int8 planes P_p[x][k], k-contiguous for BOTH
+//   1. limb_planes_tiled_kernel (limb_planes.h): strided int32 operand -> four int8 planes P_p[x][k], k-contiguous for BOTH
 //      operands (B is transposed on the way, like pack_B), zero-padded to tile multiples, so the GEMM
 //      kernel has no edge handling at all on its loads;
 //   2. gemm_i8limb_kernel: 128x128 workgroup tile, 8 waves of 32x64, 64 k per LDS stage, double
@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "limb_planes.h"
 
 namespace laser_hip {
 
@@ -52,44 +53,7 @@ constexpr int ISTAGE = 8 * IPLANE;   // 4 A planes + 4 B planes = 64 KiB; two st
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-// ---- 1. limb planes ---------------------------------------------------------------------------------
-// planes[p][x][k] (int8), x < Xpad, k < Kpad; element (x, k) of the source at src[x*sx + k*sk].
-// One thread = one x and 16 consecutive k -> one 16-byte store per plane.
-__global__ void __launch_bounds__(256) limb_planes_kernel(int8_t *__restrict__ planes, const int32_t *__restrict__ src,
-                                                          int64_t X, int64_t K, int64_t sx, int64_t sk, int64_t Xpad,
-                                                          int64_t Kpad, int x_fast) {
-  const int64_t kchunks = Kpad / 16;
-  const int64_t total = Xpad * kchunks;
-  const int64_t plane = Xpad * Kpad;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    // lanes run along whichever source axis is contiguous so the 32-bit loads coalesce
-    const int64_t x = x_fast ? e % Xpad : e / kchunks;
-    const int64_t kq = x_fast ? e / Xpad : e % kchunks;
-    uint32_t out[4][4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      uint32_t w[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int64_t k = kq * 16 + g * 4 + c;
-        const uint32_t a = (x < X && k < K) ? (uint32_t)src[x * sx + k * sk] : 0u;
-        w[c] = (a + 0x00808080u) ^ 0x00808080u;  // bytes = balanced base-256 digits of a
-      }
-      // 4x4 byte transpose: out[p][g] = { digit p of the 4 consecutive k }
-      const uint32_t lo01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), hi01 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
-      const uint32_t lo23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), hi23 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
-      out[0][g] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
-      out[1][g] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
-      out[2][g] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
-      out[3][g] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const i32x4 q = {(int)out[p][0], (int)out[p][1], (int)out[p][2], (int)out[p][3]};
-      *reinterpret_cast<i32x4 *>(planes + p * plane + x * Kpad + kq * 16) = q;
-    }
-  }
-}
+// ---- 1. limb planes: limb_planes.h (32 x 128 tiles through LDS, both HBM sides coalesced) ----------------------
 
 // ---- 2. GEMM on the limb planes ------------------------------------------------------------------------
 struct I8Args {
@@ -273,12 +237,7 @@ hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &a, void *ws, hipStream_
   const int64_t Mpad = rup64(a.M, IBM), Npad = rup64(a.N, IBN), Kpad = rup64(a.K, IBKB);
   int8_t *Ap = (int8_t *)ws, *Bp = Ap + 4 * Mpad * Kpad;
   auto planes = [&](int8_t *dst, const int32_t *src, int64_t X, int64_t sx, int64_t sk, int64_t Xpad) {
-    const int64_t total = Xpad * (Kpad / 16);
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    const int x_fast = (sx < 0 ? -sx : sx) < (sk < 0 ? -sk : sk);
-    hipLaunchKernelGGL(limb_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, X, a.K, sx, sk, Xpad, Kpad, x_fast);
-    return hipGetLastError();
+    return launch_limb_planes<int32_t>(dst, src, X, a.K, sx, sk, Xpad, Kpad, s);
   };
   hipError_t e = planes(Ap, a.A, a.M, a.rsA, a.csA, Mpad);
   if (e != hipSuccess) return e;

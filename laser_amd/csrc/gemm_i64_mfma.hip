@@ -15,7 +15,7 @@
 // nothing here depends on how the hardware treats accumulator overflow.
 //
 // Structure:
-//   1. limb_planes64_kernel: strided int64 operand -> eight int8 planes P_p[x][k], k-contiguous for both operands (B is
+//   1. limb_planes_tiled_kernel (limb_planes.h): strided int64 operand -> eight int8 planes P_p[x][k], k-contiguous for both operands (B is
 //      transposed on the way, like pack_B, gemm_packing.nim:63-94), zero-padded to tile multiples;
 //   2. gemm_i8limb64_kernel: 128x64 workgroup tile, 8 waves, ONE 32x32 block per wave -- the eight accumulator groups
 //      (one per power of 256) are 128 registers, which is what caps the wave tile.  32 k per LDS stage (48 KiB: 8 A planes
@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "limb_planes.h"
 
 namespace laser_hip {
 
@@ -54,52 +55,7 @@ constexpr int PIECES_PER_WAVE = PIECES / 8;
 typedef __attribute__((address_space(3))) void lds_void64_t;
 typedef __attribute__((address_space(1))) const void glb_void64_t;
 
-// ---- 1. limb planes ---------------------------------------------------------------------------------
-// planes[p][x][k] (int8), x < Xpad, k < Kpad; element (x, k) of the source at src[x*sx + k*sk], k in [0, K).
-// One thread = one x and 16 consecutive k -> one 16-byte store per plane.
-__global__ void __launch_bounds__(256) limb_planes64_kernel(int8_t *__restrict__ planes, const int64_t *__restrict__ src, int64_t X,
-                                                            int64_t K, int64_t sx, int64_t sk, int64_t Xpad, int64_t Kpad,
-                                                            int x_fast) {
-  const int64_t kchunks = Kpad / 16;
-  const int64_t total = Xpad * kchunks;
-  const int64_t plane = Xpad * Kpad;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    // lanes run along whichever source axis is contiguous so the loads coalesce
-    const int64_t x = x_fast ? e % Xpad : e / kchunks;
-    const int64_t kq = x_fast ? e / Xpad : e % kchunks;
-    uint32_t out[8][4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      uint32_t wl[4], wh[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int64_t k = kq * 16 + g * 4 + c;
-        const uint64_t a = (x < X && k < K) ? (uint64_t)src[x * sx + k * sk] : 0ull;
-        // bytes = balanced base-256 digits of a: add 128 to the seven low bytes with carry propagation, then flip their
-        // sign bits (the top digit may be any representative mod 256 because 256^8 == 0)
-        const uint64_t d = (a + 0x0080808080808080ull) ^ 0x0080808080808080ull;
-        wl[c] = (uint32_t)d;
-        wh[c] = (uint32_t)(d >> 32);
-      }
-      // two 4x4 byte transposes: out[p][g] = { digit p of the 4 consecutive k }
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const uint32_t *w = h ? wh : wl;
-        const uint32_t lo01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), hi01 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
-        const uint32_t lo23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), hi23 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
-        out[4 * h + 0][g] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
-        out[4 * h + 1][g] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
-        out[4 * h + 2][g] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
-        out[4 * h + 3][g] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      const i32x4 q = {(int)out[p][0], (int)out[p][1], (int)out[p][2], (int)out[p][3]};
-      *reinterpret_cast<i32x4 *>(planes + p * plane + x * Kpad + kq * 16) = q;
-    }
-  }
-}
+// ---- 1. limb planes: limb_planes.h (32 x 128 tiles through LDS, both HBM sides coalesced) ----------------------
 
 // ---- 2. GEMM on the limb planes ------------------------------------------------------------------------
 struct I8Args64 {
@@ -322,12 +278,7 @@ hipError_t launch_gemm_i64_mfma(const GemmArgs<int64_t> &a, void *ws, hipStream_
     const int64_t Kpad = rup64i(kc, BKB);
     int8_t *Ap = (int8_t *)ws, *Bp = Ap + 8 * Mpad * Kpad;
     auto planes = [&](int8_t *dst, const int64_t *src, int64_t X, int64_t sx, int64_t sk, int64_t Xpad) {
-      const int64_t total = Xpad * (Kpad / 16);
-      int64_t blocks = (total + 255) / 256;
-      if (blocks > 256 * 16) blocks = 256 * 16;
-      const int x_fast = (sx < 0 ? -sx : sx) < (sk < 0 ? -sk : sk);
-      hipLaunchKernelGGL(limb_planes64_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, X, kc, sx, sk, Xpad, Kpad, x_fast);
-      return hipGetLastError();
+      return launch_limb_planes<int64_t>(dst, src, X, kc, sx, sk, Xpad, Kpad, s);
     };
     e = planes(Ap, a.A + k0 * a.csA, a.M, a.rsA, a.csA, Mpad);
     if (e != hipSuccess) return e;
