@@ -263,8 +263,70 @@ hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s) {
 
 template <typename T>
 hipError_t run_gemm(const GemmArgs<T> &a, hipStream_t s);
+template <typename T>
+hipError_t run_gemm_core(const GemmArgs<T> &a, hipStream_t s);
+template <>
+hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s);
+template <>
+hipError_t run_gemm_core<double>(const GemmArgs<double> &a, hipStream_t s);
+
+// Ragged-by-a-few problems (4100^3, 4095 x 4097 x 4099): 1..8 rows / columns past a multiple of 64 cost a whole extra row /
+// column of tiles (4100 = 16 x 256 + 4: 17 tile rows for 16.02 tile rows of work).  Elements of C are independent and the
+// streaming kernel for M <= 8 or N <= 8 (gemm_skinny.hip) runs the same k-ascending, kc-sliced chain per element as the tiled
+// kernels, so those few rows / columns are peeled off and streamed (HBM-bound, ~20 us each at 4100^3), and the tiled
+// launch sees whole tiles: bit-identical to the single launch.  Laser-order arithmetic only (the streaming kernel always
+// restarts its chain every kc), i.e. laser-order mode or K <= kc; plain (unfused, unbatched, not pre-packed) problems.
+template <typename T>
+hipError_t run_gemm_peeled(const GemmArgs<T> &a, int kc, bool laser, bool *taken, hipStream_t s) {
+  *taken = false;
+  if (!g_ctx.skinny || !g_split_tail || a.batch != 1 || a.bias != nullptr || a.act != 0) return hipSuccess;
+  if (!(laser || a.K <= kc) || a.Mext != a.M || a.Next != a.N || a.K < 256) return hipSuccess;
+  const int64_t rM = a.M % 64, rN = a.N % 64;
+  const bool peel_m = rM >= 1 && rM <= 8 && a.M >= 1024 && a.N >= 512;
+  const bool peel_n = rN >= 1 && rN <= 8 && a.N >= 1024 && a.M - (peel_m ? rM : 0) >= 512;
+  if (!peel_m && !peel_n) return hipSuccess;
+  *taken = true;
+  const int64_t M1 = peel_m ? a.M - rM : a.M, N1 = peel_n ? a.N - rN : a.N;
+  GemmArgs<T> m = a;  // whole tiles
+  m.M = M1; m.Mext = M1; m.N = N1; m.Next = N1;
+  hipError_t e = run_gemm_core<T>(m, s);
+  if (e == hipSuccess && peel_n) {  // columns [N1, N) of rows [0, M1)
+    GemmArgs<T> r = a;
+    r.M = M1; r.Mext = M1; r.N = rN; r.Next = rN;
+    r.B = a.B + N1 * a.csB;
+    r.C = a.C + N1 * a.csC;
+    e = launch_gemm_skinny<T>(r, true, kc, s);
+  }
+  if (e == hipSuccess && peel_m) {  // rows [M1, M), every column
+    GemmArgs<T> b = a;
+    b.M = rM; b.Mext = rM;
+    b.A = a.A + M1 * a.rsA;
+    b.C = a.C + M1 * a.rsC;
+    e = launch_gemm_skinny<T>(b, true, kc, s);
+  }
+  return e == hipErrorNotSupported ? hipErrorInvalidValue : e;
+}
+
 template <>
 hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
+  if (g_ctx.f32_cfg < 0) {
+    bool taken;
+    const hipError_t e = run_gemm_peeled<float>(a, 512, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, &taken, s);
+    if (taken) return e;
+  }
+  return run_gemm_core<float>(a, s);
+}
+template <>
+hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
+  if (g_ctx.f64_mfma) {
+    bool taken;
+    const hipError_t e = run_gemm_peeled<double>(a, 256, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, &taken, s);
+    if (taken) return e;
+  }
+  return run_gemm_core<double>(a, s);
+}
+template <>
+hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s) {
   if (g_ctx.f32_cfg < 0 && g_ctx.skinny) {  // matrix-vector-like shapes: an HBM stream, not a tile problem
     const hipError_t e = launch_gemm_skinny<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
     if (e != hipErrorNotSupported) return e;
@@ -280,7 +342,7 @@ hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
   return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 template <>
-hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
+hipError_t run_gemm_core<double>(const GemmArgs<double> &a, hipStream_t s) {
   const bool laser = g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER;
   if (g_ctx.skinny) {
     const hipError_t e = launch_gemm_skinny<double>(a, laser, 256, s);

@@ -641,6 +641,39 @@ def test_full_size_conv_c4_every_image(la, oracle):
     assert cut > 0 and cut % 128 == 0, "C4 (1600 tiles of 128x128 = 3.1 rounds) is expected to run as main + tail"
 
 
+def test_ragged_by_a_few_rows_columns_peeled_bit_exact(la, oracle):
+    """M or N a few (1..8) past a multiple of 64: the extra rows / columns are peeled off and streamed by the M <= 8 / N <= 8
+    kernel, the tiled launch sees whole tiles.  Same bits as the single launch (peeling off) and as the oracle: both
+    remainders, alpha / beta, transposed and row-padded operands, float32 and float64."""
+    import torch
+    rng = np.random.default_rng(31)
+    for dtype, shapes in ((np.float32, [(4100, 4097, 1100), (1028, 2051, 600), (2049, 1024, 2000)]), (np.float64, [(1026, 1031, 700)])):
+        for (M, N, K) in shapes:
+            A = rand(rng, (M, K), dtype)
+            B = rand(rng, (K, N), dtype)
+            C0 = rand(rng, (M, N), dtype)
+            dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+            for alpha, beta in [(1, 0), (0.5, 0.25)]:
+                want = oracle.matmul(A, B, alpha, beta, C0.copy())
+                dC = torch.from_numpy(C0.copy()).cuda()
+                la.matmul(dA, dB, alpha, beta, dC)
+                assert np.array_equal(dC.cpu().numpy(), want), (dtype, M, N, K, alpha, beta)
+                try:
+                    la.set_split_tail(0)      # launch-plan knob: no peeling, no main + tail cut
+                    dC2 = torch.from_numpy(C0.copy()).cuda()
+                    la.matmul(dA, dB, alpha, beta, dC2)
+                finally:
+                    la.set_split_tail(1)
+                assert torch.equal(dC, dC2), (dtype, M, N, K, alpha, beta)
+            # column-major A, transposed B, C inside a wider buffer whose other columns must stay untouched
+            dAc = torch.from_numpy(np.asfortranarray(A)).cuda()
+            dBt = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t()
+            wide = torch.full((M, N + 5), 3.0, dtype=dA.dtype, device="cuda")
+            la.matmul(dAc, dBt, 1, 0, wide[:, :N])
+            assert np.array_equal(wide[:, :N].cpu().numpy(), oracle.matmul(A, B)), (dtype, M, N, K)
+            assert (wide[:, N:] == 3.0).all()
+
+
 def test_conv_tail_kslice_parallel_bit_exact(la, oracle):
     """Laser-order implicit conv whose launch plan has a tail: the tail runs Laser's kc slices (gemm.nim:150-158) as
     parallel workgroup sets + an ordered combine.  Same bits as the sequential tail (knob off), as the single launch and
