@@ -1085,7 +1085,15 @@ hipError_t launch_cfg_mode(const GemmArgs<E> &a, int amode, int bmode, hipStream
   }
   if constexpr (WITH_GEN) {
     LH_CASE(LOAD_GEN_K, LOAD_GEN_X)
-    LH_CASE(LOAD_GEN_K, LOAD_GEN_K)
+    // (both operands through the scalar k-walking loaders hold the most address state: at 3 waves per SIMD -- 168
+    // registers -- that pair spilled 2 VGPRs on the 128x128 tile; it is built for 2)
+    if constexpr (OCC > 2) {
+      if (amode == LOAD_GEN_K && bmode == LOAD_GEN_K)
+        return fused ? launch_one<E, BM, BN, BK, WM, WN, LOAD_GEN_K, LOAD_GEN_K, EXACT, STAGES, 2, false, true>(a, s)
+                     : launch_one<E, BM, BN, BK, WM, WN, LOAD_GEN_K, LOAD_GEN_K, EXACT, STAGES, 2, false, false>(a, s);
+    } else {
+      LH_CASE(LOAD_GEN_K, LOAD_GEN_K)
+    }
     LH_CASE(LOAD_GEN_X, LOAD_GEN_X)
     LH_CASE(LOAD_GEN_X, LOAD_GEN_K)
     if constexpr (std::is_same<E, float>::value) {
