@@ -768,8 +768,19 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
       depi.bias = (const T *)dbias - lo;
     }
   }
-  // both operands and C row-major-like, and big enough that B's upload is worth hiding: the 2-D form
-  if (!fused && g_ctx.host_pipeline_2d && csA == 1 && csB == 1 && csC == 1 && rsA >= K && rsB >= N && rsC >= N && M >= 2048 &&
+  // both operands and C row-major-like, and big enough that B's upload is worth hiding: the 2-D form.  Pinned (or
+  // registered) B and C only: their column panels / strips move as pitched 2-D copies, which are DMA transfers from
+  // pinned memory but row-by-row staging from pageable memory (8192^3: 15.0 ms in one harness, 23 ms in another, against
+  // 15.7 ms for the row-panel form -- profiles/r02/host_pipeline_v2.jsonl, configs_v12.jsonl)
+  auto pinned = [](const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+      (void)hipGetLastError();  // an ordinary pageable pointer is "invalid value" to the runtime: not an error here
+      return false;
+    }
+    return at.type == hipMemoryTypeHost;
+  };
+  if (!fused && g_ctx.host_pipeline_2d && pinned(B) && pinned(C) && csA == 1 && csB == 1 && csC == 1 && rsA >= K && rsB >= N && rsC >= N && M >= 2048 &&
       N >= 2048 && bn * sizeof(T) >= ((size_t)32 << 20) && (an + bn + cn) * sizeof(T) >= ((size_t)128 << 20))
     return gemm_host_pipelined2d<T>(M, N, K, alpha, A, rsA, B, rsB, beta, C, rsC, dA0, dB0, dC0, c_up);
   if (!fused && panels_disjoint && M >= 2048 && (an + bn + cn) * sizeof(T) >= ((size_t)64 << 20))

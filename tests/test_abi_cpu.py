@@ -64,3 +64,55 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower() or f == "__never__", f"{f} mentions the oracle"
+
+
+def _device_kernels(path):
+    """(name, metadata) of every gfx950 kernel embedded in the library: walk the clang offload bundles, pull out the
+    amdgcn code objects, read the msgpack kernel metadata of their NT_AMDGPU_METADATA note."""
+    import struct
+    import msgpack
+    blob = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out = []
+    at = blob.find(magic)
+    while at >= 0:
+        n = struct.unpack_from("<Q", blob, at + 24)[0]
+        off = at + 32
+        for _ in range(n):
+            o, size, ts = struct.unpack_from("<QQQ", blob, off)
+            triple = blob[off + 24: off + 24 + ts]
+            off += 24 + ts
+            if size == 0 or b"gfx950" not in triple:
+                continue
+            elf = blob[at + o: at + o + size]
+            assert elf[:4] == b"\x7fELF"
+            shoff = struct.unpack_from("<Q", elf, 0x28)[0]
+            shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+            for i in range(shnum):
+                sh = elf[shoff + i * shentsize: shoff + (i + 1) * shentsize]
+                sh_type, sh_off, sh_size = struct.unpack_from("<I", sh, 4)[0], struct.unpack_from("<Q", sh, 0x18)[0], struct.unpack_from("<Q", sh, 0x20)[0]
+                if sh_type != 7:      # SHT_NOTE
+                    continue
+                p, end = sh_off, sh_off + sh_size
+                while p + 12 <= end:
+                    namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+                    name = elf[p + 12: p + 12 + namesz]
+                    d0 = p + 12 + (namesz + 3) // 4 * 4
+                    if ntype == 32 and name.startswith(b"AMDGPU"):      # NT_AMDGPU_METADATA
+                        md = msgpack.unpackb(elf[d0: d0 + descsz], raw=False, strict_map_key=False)
+                        for k in md.get("amdhsa.kernels", []):
+                            out.append((k[".name"], k))
+                    p = d0 + (descsz + 3) // 4 * 4
+        at = blob.find(magic, at + 24)
+    return out
+
+
+def test_no_kernel_in_the_library_spills():
+    """Every gfx950 kernel shipped in liblaser_hip.so: zero spilled VGPRs / SGPRs and no scratch (a spilling main loop is a
+    silent 2-10x slowdown; the check reads the code objects' own metadata, so it needs no GPU)."""
+    import laser_amd
+    ks = _device_kernels(laser_amd.LIB_PATH)
+    assert len(ks) > 300, len(ks)           # the tile-configuration x loader-mode instantiations alone are ~500
+    bad = [(n, k.get(".vgpr_spill_count"), k.get(".sgpr_spill_count"), k.get(".private_segment_fixed_size")) for n, k in ks
+           if k.get(".vgpr_spill_count", 0) or k.get(".private_segment_fixed_size", 0)]
+    assert not bad, bad[:5]

@@ -325,30 +325,40 @@ def test_host_pointer_2d_pipelined_path(la, oracle):
     B = rand(rng, (K, N), np.float32)
     C0 = rand(rng, (M, N), np.float32)
     want = oracle.matmul(A, B)
-    got = la.matmul(A, B)
-    assert np.array_equal(got, want)
+    want2 = oracle.matmul(A, B, 0.5, 0.25, C0.copy())
+    assert np.array_equal(la.matmul(A, B), want)          # pageable operands: the row-panel form
+    # pinned host memory (laser_hip_host_alloc): the 2-D form; A may stay pageable (its panels are contiguous copies)
+    Bp, Cp = la.pinned_host_buffer((K, N)), la.pinned_host_buffer((M, N))
+    Bp[:] = B; Cp[:] = 0
+    la.matmul(A, Bp, 1, 0, Cp)
+    assert np.array_equal(Cp, want)
     try:
         la.set_host_pipeline(0)
-        assert np.array_equal(la.matmul(A, B), want)
+        Cp[:] = 0
+        la.matmul(A, Bp, 1, 0, Cp)
+        assert np.array_equal(Cp, want)
     finally:
         la.set_host_pipeline(1)
-    want2 = oracle.matmul(A, B, 0.5, 0.25, C0.copy())
-    assert np.array_equal(la.matmul(A, B, 0.5, 0.25, C0.copy()), want2)
-    # padded leading dimensions: the gaps belong to the caller and must come back untouched
+    Cp[:] = C0
+    la.matmul(A, Bp, 0.5, 0.25, Cp)
+    assert np.array_equal(Cp, want2)
+    # padded leading dimensions inside registered (laser_hip_host_register) buffers: the gaps belong to the caller and must
+    # come back untouched
     Abuf = np.full((M, K + 24), np.nan, dtype=np.float32); Abuf[:, :K] = A
     Bbuf = np.full((K, N + 40), np.nan, dtype=np.float32); Bbuf[:, :N] = B
     Cbuf = np.full((M, N + 8), np.nan, dtype=np.float32)
-    la.matmul(Abuf[:, :K], Bbuf[:, :N], 1, 0, Cbuf[:, :N])
+    la.host_register(Bbuf); la.host_register(Cbuf)
+    try:
+        la.matmul(Abuf[:, :K], Bbuf[:, :N], 1, 0, Cbuf[:, :N])
+    finally:
+        la.host_unregister(Bbuf); la.host_unregister(Cbuf)
     assert np.array_equal(Cbuf[:, :N], want)
     assert np.isnan(Cbuf[:, N:]).all()
-    # pinned host memory (laser_hip_host_alloc)
-    Ap, Bp, Cp = la.pinned_host_buffer((M, K)), la.pinned_host_buffer((K, N)), la.pinned_host_buffer((M, N))
-    Ap[:] = A; Bp[:] = B; Cp[:] = 0
-    la.matmul(Ap, Bp, 1, 0, Cp)
-    assert np.array_equal(Cp, want)
     Ai = rng.integers(-2**31, 2**31 - 1, (M, K), dtype=np.int32)
-    Bi = rng.integers(-2**31, 2**31 - 1, (K, N), dtype=np.int32)
-    assert np.array_equal(la.matmul(Ai, Bi), oracle.matmul(Ai, Bi))
+    Bi = la.pinned_host_buffer((K, N), np.int32); Bi[:] = rng.integers(-2**31, 2**31 - 1, (K, N), dtype=np.int32)
+    Ci = la.pinned_host_buffer((M, N), np.int32); Ci[:] = 0
+    la.matmul(Ai, Bi, 1, 0, Ci)
+    assert np.array_equal(Ci, oracle.matmul(Ai, np.array(Bi)))
 
 
 def test_batched_device_gemm(la, oracle):
