@@ -69,9 +69,11 @@ int laser_hip_set_conv_implicit(int on);
 /* 1 (default): the implicit conv reads its B operand from an LDS-resident input patch when that fits;
  * 0: always the per-element gather (A/B timing).  Results are bit-identical. */
 int laser_hip_set_conv_patch(int on);
-/* Large host-pointer gemm_strided calls on row-major-like operands: 1 (default) = row panels of A x column panels of B,
- * uploaded so the computable region grows as a square, every finished tile of C copied back at once (the first kernel
- * starts after one panel of each operand instead of after all of B); 0 = row panels only.  Bit-identical. */
+/* Host-pointer gemm_strided pipelines (A/B knob, default 1).  Bit 0: large calls on row-major-like operands with pinned B
+ * and C run row panels of A x column panels of B, uploaded so the computable region grows as a square, every finished
+ * strip of C copied back at once (the first kernel starts after one panel of each operand instead of after all of B);
+ * clear = row panels only.  Bit 1: set = the small zero-copy path synchronises its stream instead of polling the
+ * kernel's completion flags in mapped host memory.  Bit-identical. */
 int laser_hip_set_host_pipeline(int mode);
 /* 1 (default): the tail launch of a laser-order implicit conv (the output pixels past the last whole round of large
  * tiles) runs Laser's kc slices (gemm.nim:150-158) as parallel workgroup sets + an ordered combine; 0: one workgroup per

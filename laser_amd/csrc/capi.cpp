@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <deque>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <type_traits>
 #include <thread>
@@ -59,6 +60,7 @@ struct Context {
   bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
   bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
   bool i64_mfma = true;       // int64 GEMM on the int8 matrix cores (false: VALU kernel)
+  bool zc_poll = true;           // small host-pointer calls: poll completion flags in mapped memory (false: synchronise the stream)
   bool host_pipeline_2d = true;  // large row-major host-pointer calls: row panels x column panels (false: row panels only)
   int slice_parallel_min = 2;        // (tuning override only) fewest kc slices worth splitting
   int64_t slice_parallel_tiles = 0;  // tuning override of the tile-count limit of the slice-parallel form (0 = built-in rule)
@@ -80,6 +82,7 @@ struct DeviceCtx {
   hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
   void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t zc_seq = 0;  // sequence number of the zero-copy path's completion flags (never 0 in a flag)
   void *zc = nullptr;  // pinned host buffer mapped into the device: zero-copy staging of the small-problem host path
   size_t zc_sz = 0;
 };
@@ -722,17 +725,43 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
     const bool has_epi = hepi && (hepi->bias || hepi->act);
     if (!has_epi && g_ctx.f32_cfg < 0 && ab + bb + cb <= kZeroCopyMax && gemm_small_takes((int)sizeof(T), M, N, K, 1, true) &&
         std::is_floating_point<T>::value) {
+      // completion flags, one per workgroup (= per 32x32 / 16x16 block of C; at most 256 by the dispatch rule), behind C
+      const int mb = sizeof(T) == 4 ? 32 : 16;
+      const size_t nblk = (size_t)((M + mb - 1) / mb) * (size_t)((N + mb - 1) / mb);
+      const size_t fb = up(nblk * sizeof(uint32_t));
       void *z;
-      if (int rc = zero_copy_get(ab + bb + cb, &z)) return rc;
+      if (int rc = zero_copy_get(ab + bb + cb + fb, &z)) return rc;
       if (int rc = pipeline_streams()) return rc;
       T *hA = (T *)z, *hB = (T *)((char *)z + ab), *hC = (T *)((char *)z + ab + bb);
+      volatile uint32_t *flags = (volatile uint32_t *)((char *)z + ab + bb + cb);
       memcpy(hA, A + alo, an * sizeof(T));
       memcpy(hB, B + blo, bn * sizeof(T));
       const bool c_in = (beta != (T)0) || cn != (size_t)M * (size_t)N;  // read, or a span with gaps that belong to the caller
       if (c_in) memcpy(hC, C + clo, cn * sizeof(T));
       GemmArgs<T> a = make_args<T>(1, M, N, K, alpha, hA - alo, rsA, csA, 0, hB - blo, rsB, csB, 0, beta, hC - clo, rsC, csC, 0);
+      uint32_t seq = ++tl_dev->zc_seq;
+      if (seq == 0) seq = ++tl_dev->zc_seq;  // flags hold the sequence number of the call that set them; 0 = never
+      if (g_ctx.zc_poll) {
+        a.done_flags = (uint32_t *)flags;
+        a.done_seq = seq;
+      }
       HIP_TRY(run_small_mapped<T>(a, tl_dev->s_comp));
-      HIP_TRY(hipStreamSynchronize(tl_dev->s_comp));
+      // Wait for the blocks' flags in mapped memory instead of synchronising the stream (the runtime's completion path
+      // costs more than this kernel).  Bounded: after ~2 ms of polling fall back to the synchronise, which also reports
+      // a failed launch.
+      bool polled = false;
+      if (g_ctx.zc_poll) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        size_t i = 0;
+        for (unsigned spins = 0; i < nblk; spins++) {
+          if (flags[i] == seq) { i++; continue; }
+          if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() > t_end) break;
+          __builtin_ia32_pause();
+        }
+        polled = i == nblk;
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+      if (!polled) HIP_TRY(hipStreamSynchronize(tl_dev->s_comp));
       memcpy(C + clo, hC, cn * sizeof(T));
       return LASER_HIP_OK;
     }
@@ -1211,8 +1240,9 @@ int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from
   g_conv_patch = on != 0;
   return LASER_HIP_OK;
 }
-int laser_hip_set_host_pipeline(int mode) {  // A/B knob: 1 = 2-D (row x column panel) host pipeline where it applies, 0 = row panels only
-  g_ctx.host_pipeline_2d = mode != 0;
+int laser_hip_set_host_pipeline(int mode) {  // A/B knob: bit 0 = 2-D (row x column panel) host pipeline where it applies (0: row panels
+  g_ctx.host_pipeline_2d = (mode & 1) != 0;  // only); bit 1 CLEAR = the small zero-copy path polls completion flags (set: it synchronises)
+  g_ctx.zc_poll = (mode & 2) == 0;
   return LASER_HIP_OK;
 }
 int laser_hip_set_conv_kslice(int on) {  // A/B knob: laser-order conv tail as parallel kc slices + ordered combine (1) or one launch (0)

@@ -65,6 +65,11 @@ struct GemmArgs {
   // workgroup z = blockIdx.y computes image z % cs_imgs over k in [slice*cs_len, min(K, (slice+1)*cs_len)), slice = z / cs_imgs,
   // as ONE chain into C + z*bsC (a workspace the ordered combine pass folds); cs_len is a multiple of every BK.  0 = off.
   int32_t cs_imgs, cs_len;
+  // Completion flags (small-matrix kernel on host-mapped operands only; nullptr = off): workgroup w stores done_seq to
+  // done_flags[w] (system scope, after its C stores) so the host-pointer entry point can poll mapped memory instead of
+  // paying a stream synchronise.
+  uint32_t *done_flags;
+  uint32_t done_seq;
 };
 
 // How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of

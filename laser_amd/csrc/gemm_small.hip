@@ -152,6 +152,13 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
     }
     if (ok) *p = out;
   }
+  // host-mapped run (capi.cpp: gemm_host): tell the polling host this block is done -- release at system scope first, so
+  // the block's stores to C have left the device before its flag can be seen
+  if (g.done_flags != nullptr) {
+    __threadfence_system();
+    if (lane == 0)
+      __hip_atomic_store(g.done_flags + (bz * gridDim.x + blockIdx.x), g.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // Dispatch rule.  The kernel's serial part is the per-block MFMA chain (K/2 x 64 cycles) and its loads are not shared

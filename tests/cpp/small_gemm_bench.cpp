@@ -121,11 +121,16 @@ int main() {
   for (int on = 1; on >= 0; on--)
     if (measure(on, &h[on], &d[on], &ds[on], &b[on], &bad)) return 1;
   laser_hip_set_small_path(1);
+  // the host-pointer call again with the zero-copy path synchronising its stream instead of polling completion flags
+  double h_sync = 0, d_tmp, ds_tmp, b_tmp;
+  CK(laser_hip_set_host_pipeline(3));
+  if (measure(1, &h_sync, &d_tmp, &ds_tmp, &b_tmp, &bad)) return 1;
+  CK(laser_hip_set_host_pipeline(1));
   // Laser's own path for this size is single-threaded (M*N*K > 128^3 is false: gemm.nim:141): a plain fmaf triple loop
   // on this host for scale (the oracle's timed single-thread number is in bench_configs.py's output)
   printf("{\"config\": \"C1 fp32 gemm M=N=K=128 from a compiled caller\", \"host_us\": %.2f, \"dev_us\": %.2f, \"dev_single_us\": %.2f, "
          "\"batched_1000x32cubed_us\": %.2f, \"tiled_kernels\": {\"host_us\": %.2f, \"dev_us\": %.2f, \"dev_single_us\": %.2f, "
-         "\"batched_1000x32cubed_us\": %.2f}, \"mismatches\": %d}\n",
-         h[1], d[1], ds[1], b[1], h[0], d[0], ds[0], b[0], bad);
+         "\"batched_1000x32cubed_us\": %.2f}, \"host_us_stream_synchronise\": %.2f, \"mismatches\": %d}\n",
+         h[1], d[1], ds[1], b[1], h[0], d[0], ds[0], b[0], h_sync, bad);
   return bad ? 2 : 0;
 }
