@@ -161,22 +161,25 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
   }
 }
 
-// Dispatch rule.  The kernel's serial part is the per-block MFMA chain (K/2 x 64 cycles) and its loads are not shared
-// between blocks, so it pays where the tiled kernels are latency-bound, not where they are busy:
-//   device-resident operands: at most 256 blocks (one wave per CU) or a batch of matrices up to 64x64, and K <= 128 --
-//     measured (profiles/r02/small_path_probe*.log, small_gemm*.jsonl): equal to the 64x64-tile kernel at K = 128,
-//     1.3-2.3x slower from K = 256 on (the tiled kernel's 4 waves share every operand element through LDS);
-//   host-mapped operands (the zero-copy staging of the host-pointer entry point, `mapped`): K <= 1024 -- every load
-//     crosses PCIe, and this kernel has them all in flight after one round trip where the tiled kernel pays one round
-//     trip per K-tile.
-// hipErrorNotSupported: not small, use the tiled kernels.
+// Dispatch rule, from measurements with a compiled caller (tests/cpp/small_sweep.cpp, small_gemm_bench.cpp;
+// profiles/r02/small_sweep_v1.jsonl, small_gemm_v13.jsonl).  The kernel's serial part is the per-block MFMA chain
+// (K/2 x 64 cycles) and its loads are not shared between blocks, so it pays only where the tiled kernels cannot amortise
+// anything:
+//   host-mapped operands (the zero-copy staging of the host-pointer entry point, `mapped`), <= 256 blocks, K <= 1024:
+//     every load crosses PCIe, and this kernel has them all in flight after one round trip where the tiled kernel pays
+//     one round trip per K-tile (128^3 end to end: 22.9 vs 52 us);
+//   device-resident BATCHES of matrices up to 64x64, K <= 128: batch x blocks independent waves (1000 x 32^3: 6.4 vs
+//     7.2 us per launch).
+//   A single device-resident problem never: on all 18 shapes of the sweep (32^3 .. 512x512x128) the 64x64-tile kernel,
+//     whose 4 waves share every operand element through LDS, is 4-30 % faster (128^3: 5.9 vs 6.7 us per launch).
+// hipErrorNotSupported: not this kernel's case, use the tiled kernels.
 int g_small_path = 1;  // knob (laser_hip_set_small_path)
 bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch, bool mapped) {
   if (!g_small_path || (elem_size != 4 && elem_size != 8)) return false;
   const int mb = elem_size == 4 ? 32 : 16;
   const int64_t tm = (M + mb - 1) / mb, tn = (N + mb - 1) / mb;
-  const bool tiny_batched = batch > 1 && M <= 64 && N <= 64;
-  return (tm * tn * batch <= 256 || tiny_batched) && K <= (mapped ? 1024 : 128);
+  if (mapped) return tm * tn * batch <= 256 && K <= 1024;
+  return batch > 1 && M <= 64 && N <= 64 && K <= 128;
 }
 template <typename E>
 hipError_t launch_gemm_small(const GemmArgs<E> &args, bool laser_order, int kc_elems, hipStream_t s, bool mapped) {

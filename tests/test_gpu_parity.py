@@ -963,11 +963,15 @@ def test_small_matrix_path_bit_exact(la, oracle, dtype):
         for alpha, beta in ((1, 0), (0.5, 0.25)):
             want = oracle.matmul(A, B, alpha, beta, C0.copy())
             got = la.matmul(A, B, alpha, beta, C0.copy())                      # host pointers
+            up = lambda v: (v + 255) // 256 * 256      # the staging buffer's 256-byte slots (capi.cpp: gemm_host)
+            if (dtype == np.float32 and K <= 1024 and -(-M // 32) * -(-N // 32) <= 256 and
+                    up(4 * M * K) + up(4 * K * N) + up(4 * M * N) <= (1 << 20)):
+                assert la.last_f32_config() == -2, "the small-matrix kernel did not run on the zero-copy host path"
             assert np.array_equal(got, want), (M, N, K, alpha, beta, "host")
             dC = torch.from_numpy(C0.copy()).cuda()
             la.matmul(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), alpha, beta, dC)
-            if dtype == np.float32 and K <= 128 and -(-M // 32) * -(-N // 32) <= 256:
-                assert la.last_f32_config() == -2, "the small-matrix kernel did not run"
+            if dtype == np.float32:   # a single device-resident problem stays on the tiled kernels (measured faster)
+                assert la.last_f32_config() != -2
             assert np.array_equal(dC.cpu().numpy(), want), (M, N, K, alpha, beta, "device")
         # transposed B, strided A and C through the same kernel (addresses are the only thing that changes)
         Abig = rand(rng, (2 * M, K + 3), dtype)
