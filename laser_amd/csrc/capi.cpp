@@ -187,6 +187,7 @@ int zero_copy_get(size_t bytes, void **out) {
     D.zc_sz = 0;
     const size_t want = std::max<size_t>(bytes, (size_t)256 << 10);
     HIP_TRY(hipHostMalloc(&D.zc, want, hipHostMallocDefault));
+    memset(D.zc, 0, want);  // completion flags live here: a fresh buffer must not hold a value that looks like a sequence number
     D.zc_sz = want;
   }
   *out = D.zc;
