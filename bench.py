@@ -244,7 +244,9 @@ def main():
     ap.add_argument("--mode", choices=["laser_order", "fast"], default=None, help="fp32 accumulation mode (default: library default)")
     ap.add_argument("--cfg", type=int, default=-1, help="force an f32 tile configuration (-1 = heuristic)")
     ap.add_argument("--size", type=int, default=SIZE)
-    ap.add_argument("--panels-per-rank", type=int, default=4)
+    ap.add_argument("--panels-per-rank", type=int, default=0,
+                    help="block-cyclic row panels per rank for N > 1 (0 = pick among {4, 8} x {128x128 tile pinned, heuristic tile} "
+                         "from a short untimed calibration before the warm-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-process", type=int, default=0, metavar="NDEV",
                     help="run ONLY the single-process sharded entry point of the C-ABI over NDEV GPUs and print its JSON")
@@ -298,8 +300,6 @@ def main():
     n = args.size
     M_total, N, K = n * world, n, n
     from laser_amd.distributed import ShardedGemm, SHARDED_TILE_CONFIG
-    sg = ShardedGemm(M_total, N, K, torch.float32, dev, None, args.panels_per_rank if world > 1 else 1,
-                     tile_config=args.cfg if args.cfg >= 0 else None)
 
     # Operands: uniform [-0.1, 0.1) like the reference's bench inputs (gemm_bench_float32.nim:343-344).
     # Random data is mandatory: zero-filled operands run at a higher DVFS clock and inflate TF/s.
@@ -315,22 +315,54 @@ def main():
         return ((h & 0xFFFFFF).to(torch.float32) / 16777216.0 - 0.5) * 0.2
 
     B = hashed(range(K), N, 7)
-    p = sg.plan
-    A_local = torch.zeros((p.panels_per_rank * p.rows, K), dtype=torch.float32, device=dev)
-    for s_ in range(p.panels_per_rank):
-        start, valid = p.panel(s_, rank)
-        if valid > 0:
-            A_local[s_ * p.rows: s_ * p.rows + valid] = hashed(range(start, start + valid), K, 1)
-    C = sg.alloc_C()
-
-    def step():
-        sg.run(A_local, B, C)
 
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def build(ppr, tile):
+        """The sharded problem for `ppr` block-cyclic panels per rank; tile: None = the 128x128 pin of sharded runs,
+        -1 = the library heuristic, >= 0 = that configuration.  Returns (ShardedGemm, this rank's A panels, full C)."""
+        g = ShardedGemm(M_total, N, K, torch.float32, dev, None, ppr if world > 1 else 1, tile_config=tile)
+        pl = g.plan
+        a = torch.zeros((pl.panels_per_rank * pl.rows, K), dtype=torch.float32, device=dev)
+        for s_ in range(pl.panels_per_rank):
+            start, valid = pl.panel(s_, rank)
+            if valid > 0:
+                a[s_ * pl.rows: s_ * pl.rows + valid] = hashed(range(start, start + valid), K, 1)
+        return g, a, g.alloc_C()
+
+    # N > 1: how many panels per rank (a shorter exposed last all-gather vs larger local products) and whether the local
+    # products share the CUs with RCCL better on the pinned 128x128 tile are box questions -- answered by a short UNTIMED
+    # calibration (1 + 2 steps per candidate, max over ranks), like the tile heuristic answers the single-GPU ones.
+    calibration = None
+    tile_choice = args.cfg if args.cfg >= 0 else None
+    ppr_choice = args.panels_per_rank if args.panels_per_rank > 0 else 4
+    if world > 1 and args.panels_per_rank <= 0:
+        calibration = []
+        cands = [(4, tile_choice), (8, tile_choice)] + ([(4, -1), (8, -1)] if args.cfg < 0 else [])
+        for ppr, tile in cands:
+            g_, a_, c_ = build(ppr, tile)
+            g_.run(a_, B, c_)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                g_.run(a_, B, c_)
+            fence()
+            tt = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            calibration.append({"panels_per_rank": g_.plan.panels_per_rank, "tile": "128x128 pinned" if tile is None else
+                                ("heuristic" if tile == -1 else laser_amd.f32_configs()[tile]), "ms_per_step": round(float(tt.item()) * 1e3, 4)})
+            del g_, a_, c_
+        best = min(range(len(cands)), key=lambda i: calibration[i]["ms_per_step"])   # identical on every rank (all-reduced times)
+        ppr_choice, tile_choice = cands[best]
+    sg, A_local, C = build(ppr_choice, tile_choice)
+    p = sg.plan
+
+    def step():
+        sg.run(A_local, B, C)
 
     for _ in range(args.warmup):
         step()
@@ -373,7 +405,7 @@ def main():
     if world > 1:
         rows_local = min(n, A_local.shape[0])
         names = laser_amd.f32_configs()   # same tile configuration as the sharded run used
-        laser_amd.set_f32_config(args.cfg if args.cfg >= 0 else names.index(SHARDED_TILE_CONFIG))
+        laser_amd.set_f32_config(tile_choice if tile_choice is not None else names.index(SHARDED_TILE_CONFIG))
         Cs = torch.zeros((rows_local, N), dtype=torch.float32, device=dev)
         for _ in range(2):
             laser_amd.matmul(A_local[:rows_local], B, 1, 0, Cs)
@@ -404,11 +436,14 @@ def main():
                              f"RCCL all-gather of C inside the timed region (BASELINE configs[4] shape at 8 GPUs)"),
                 "M": M_total, "N": N, "K": K, "accumulation": mode,
                 "tile_config": (laser_amd.f32_configs()[args.cfg] if args.cfg >= 0 else
-                                "heuristic" if world == 1 else SHARDED_TILE_CONFIG + " (pinned for sharded runs: shares the CUs with RCCL)"),
+                                "heuristic" if (world == 1 or tile_choice == -1) else
+                                SHARDED_TILE_CONFIG + " (pinned for sharded runs: shares the CUs with RCCL)"),
                 "parallelism": f"row-panels x{world}" + (f", {sg.plan.panels_per_rank} block-cyclic panels/rank" if world > 1 else ""),
                 "pct_of_fp32_mfma_peak": round(100.0 * value / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 2),
             },
         }
+        if calibration is not None:
+            out["config"]["calibration_untimed"] = calibration   # the candidates the warm-up phase tried; the fastest one ran
         if world == 1:
             # one step == one launch of the GEMM kernel on torch's current stream, bracketed by HIP
             # events on that same stream: average launch duration = ev_ms / steps
