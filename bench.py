@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--panels-per-rank", type=int, default=0,
                     help="block-cyclic row panels per rank for N > 1 (0 = pick among {4, 8} x {128x128 tile pinned, heuristic tile} "
                          "from a short untimed calibration before the warm-up)")
+    ap.add_argument("--gather", choices=["auto", "collective", "p2p"], default="auto",
+                    help="N > 1: all-gather of C as one collective per slab, as grouped point-to-point sends, or (auto) whichever the "
+                         "untimed calibration measures faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-process", type=int, default=0, metavar="NDEV",
                     help="run ONLY the single-process sharded entry point of the C-ABI over NDEV GPUs and print its JSON")
@@ -322,10 +325,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def build(ppr, tile):
+    def build(ppr, tile, gather="collective"):
         """The sharded problem for `ppr` block-cyclic panels per rank; tile: None = the 128x128 pin of sharded runs,
-        -1 = the library heuristic, >= 0 = that configuration.  Returns (ShardedGemm, this rank's A panels, full C)."""
-        g = ShardedGemm(M_total, N, K, torch.float32, dev, None, ppr if world > 1 else 1, tile_config=tile)
+        -1 = the library heuristic, >= 0 = that configuration; gather: one all-gather collective per slab, or the same
+        exchange as grouped point-to-point sends.  Returns (ShardedGemm, this rank's A panels, full C)."""
+        g = ShardedGemm(M_total, N, K, torch.float32, dev, None, ppr if world > 1 else 1, tile_config=tile, gather=gather)
         pl = g.plan
         a = torch.zeros((pl.panels_per_rank * pl.rows, K), dtype=torch.float32, device=dev)
         for s_ in range(pl.panels_per_rank):
@@ -340,25 +344,39 @@ def main():
     calibration = None
     tile_choice = args.cfg if args.cfg >= 0 else None
     ppr_choice = args.panels_per_rank if args.panels_per_rank > 0 else 4
-    if world > 1 and args.panels_per_rank <= 0:
+    gather_choice = args.gather if args.gather != "auto" else "collective"
+    if world > 1 and (args.panels_per_rank <= 0 or args.gather == "auto"):
         calibration = []
-        cands = [(4, tile_choice), (8, tile_choice)] + ([(4, -1), (8, -1)] if args.cfg < 0 else [])
-        for ppr, tile in cands:
-            g_, a_, c_ = build(ppr, tile)
-            g_.run(a_, B, c_)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(2):
+        pprs = [args.panels_per_rank] if args.panels_per_rank > 0 else [4, 8]
+        tiles = [tile_choice] + ([-1] if args.cfg < 0 else [])
+        gathers = [args.gather] if args.gather != "auto" else ["collective", "p2p"]
+        cands = [(ppr, tile, ga) for ga in gathers for tile in tiles for ppr in pprs]
+        for ppr, tile, ga in cands:
+            rec = {"panels_per_rank": ppr, "tile": "128x128 pinned" if tile is None else
+                   ("heuristic" if tile == -1 else laser_amd.f32_configs()[tile]), "gather": ga}
+            ok = 1.0
+            try:
+                g_, a_, c_ = build(ppr, tile, ga)
                 g_.run(a_, B, c_)
-            fence()
-            tt = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            calibration.append({"panels_per_rank": g_.plan.panels_per_rank, "tile": "128x128 pinned" if tile is None else
-                                ("heuristic" if tile == -1 else laser_amd.f32_configs()[tile]), "ms_per_step": round(float(tt.item()) * 1e3, 4)})
-            del g_, a_, c_
-        best = min(range(len(cands)), key=lambda i: calibration[i]["ms_per_step"])   # identical on every rank (all-reduced times)
-        ppr_choice, tile_choice = cands[best]
-    sg, A_local, C = build(ppr_choice, tile_choice)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    g_.run(a_, B, c_)
+                fence()
+                dt = (time.perf_counter() - t0) / 2
+                del g_, a_, c_
+            except Exception as e:       # a candidate one rank cannot run is dropped by every rank (flag all-reduced below)
+                ok, dt = 0.0, 1e9
+                rec["error"] = f"{type(e).__name__}: {e}"[:200]
+            tt = torch.tensor([dt, -ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # max time; max of -ok = 0 if any rank failed
+            rec["ms_per_step"] = round(float(tt[0].item()) * 1e3, 4) if float(tt[1].item()) < 0 else None
+            calibration.append(rec)
+        good = [i for i in range(len(cands)) if calibration[i]["ms_per_step"] is not None]
+        if good:
+            best = min(good, key=lambda i: calibration[i]["ms_per_step"])   # identical on every rank (all-reduced values)
+            ppr_choice, tile_choice, gather_choice = cands[best]
+    sg, A_local, C = build(ppr_choice, tile_choice, gather_choice)
     p = sg.plan
 
     def step():
@@ -433,7 +451,8 @@ def main():
                 "workload": (f"fp32 sgemm M=N=K={n} contiguous row-major, alpha=1 beta=0, 1xMI355X (BASELINE configs[1])"
                              if world == 1 else
                              f"fp32 sgemm M={M_total} N={N} K={K} row-panel sharded over {world}xMI355X, "
-                             f"RCCL all-gather of C inside the timed region (BASELINE configs[4] shape at 8 GPUs)"),
+                             f"RCCL all-gather of C ({'one collective per slab' if gather_choice == 'collective' else 'grouped point-to-point sends'}) "
+                             f"inside the timed region (BASELINE configs[4] shape at 8 GPUs)"),
                 "M": M_total, "N": N, "K": K, "accumulation": mode,
                 "tile_config": (laser_amd.f32_configs()[args.cfg] if args.cfg >= 0 else
                                 "heuristic" if (world == 1 or tile_choice == -1) else

@@ -70,7 +70,7 @@ class ShardedGemm:
     """C[M,N] = A[M,K] . B[K,N] with A's row panels dealt over the ranks of `group`."""
 
     def __init__(self, M, N, K, dtype=torch.float32, device=None, group=None, panels_per_rank=4,
-                 local_gemm=None, tile_config=None):
+                 local_gemm=None, tile_config=None, gather="collective"):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -82,6 +82,13 @@ class ShardedGemm:
         # SHARDED_TILE_CONFIG when more than one rank shares the work (single rank: the library heuristic)
         self.tile_config = tile_config
         self._pin_tiles = local_gemm is None and dtype == torch.float32
+        # how sub-panel s reaches the other ranks: "collective" = one in-place all_gather_into_tensor per slab;
+        # "p2p" = the same exchange as world-1 grouped send/recv pairs (ncclGroup of point-to-point operations): every
+        # rank pushes its rows straight to each peer, which on a fully connected xGMI node puts all 7 links to work
+        # whatever ring / tree the collective's algorithm picks
+        if gather not in ("collective", "p2p"):
+            raise ValueError("gather is 'collective' or 'p2p'")
+        self.gather = gather
 
     # -- data placement helpers ------------------------------------------------------------------
     def local_rows(self):
@@ -142,7 +149,10 @@ class ShardedGemm:
             if self.world > 1:
                 lo, hi = p.slab(s)
                 mine = C_full[start:start + p.rows]          # in-place: my slice of the slab
-                works.append(_all_gather_rows(C_full[lo:hi], mine, self.group))
+                if self.gather == "p2p":
+                    works.extend(_p2p_gather_rows(C_full[lo:hi], mine, self.rank, self.world, self.group))
+                else:
+                    works.append(_all_gather_rows(C_full[lo:hi], mine, self.group))
         return works
 
 
@@ -156,3 +166,17 @@ def _all_gather_rows(slab, mine, group):
         rows = mine.shape[0]
         outs = [slab[r * rows:(r + 1) * rows] for r in range(world)]
         return dist.all_gather(outs, mine.clone(), group=group, async_op=True)
+
+
+def _p2p_gather_rows(slab, mine, rank, world, group):
+    """The same exchange as grouped point-to-point operations: send my rows to every peer, receive every peer's rows into
+    its slot of the slab (in place).  Returns the list of work handles."""
+    rows = mine.shape[0]
+    ops = []
+    for d in range(1, world):          # rotate the peer order per rank so no single rank is everyone's first target
+        peer = (rank + d) % world
+        src = (rank - d) % world
+        ops.append(dist.P2POp(dist.isend, mine, peer, group))
+        ops.append(dist.P2POp(dist.irecv, slab[src * rows:(src + 1) * rows], src, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, M, N, K, ppr, ret):
+def _worker(rank, world, port, M, N, K, ppr, ret, gather="collective"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,7 +30,7 @@ def _worker(rank, world, port, M, N, K, ppr, ret):
         rng = np.random.default_rng(99)
         A = torch.from_numpy(rng.uniform(-0.1, 0.1, (M, K)).astype(np.float32))
         B = torch.from_numpy(rng.uniform(-0.1, 0.1, (K, N)).astype(np.float32))
-        sg = ShardedGemm(M, N, K, torch.float32, None, None, ppr, local_gemm)
+        sg = ShardedGemm(M, N, K, torch.float32, None, None, ppr, local_gemm, gather=gather)
         C = sg.alloc_C()
         out = sg.run(sg.shard_A(A), B, C)
         want = oracle.matmul(A.numpy(), B.numpy())
@@ -51,6 +51,18 @@ def test_sharded_gemm_world2_gloo(shape, ppr):
     mp.spawn(_worker, args=(world, port, M, N, K, ppr, ret), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world)), dict(ret)
     assert sum(ret[r][1] for r in range(world)) == M   # every row owned exactly once
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gemm_p2p_gather_gloo(world):
+    """The point-to-point form of the gather of C (grouped isend / irecv pairs): same result on every rank."""
+    M, N, K = 700, 48, 40
+    port = 31500 + (os.getpid() + world) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, M, N, K, 3, ret, "p2p"), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world)), dict(ret)
+    assert sum(ret[r][1] for r in range(world)) == M
 
 
 def test_panel_plan_covers_rows_once():
