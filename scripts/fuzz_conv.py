@@ -22,6 +22,10 @@ for it in range(cases):
     if not (sH < H and sW < W and H + 2 * pH >= kH and W + 2 * pW >= kW):
         continue
     n, C, Co = int(rng.integers(1, 4)), int(rng.integers(1, 70)), int(rng.integers(1, 150))
+    if rng.random() < 0.08:    # enough tiles for the main + tail launch plan (and its K-slice-parallel tail in laser-order mode)
+        kH = kW = 3; pH = pW = int(rng.integers(0, 2)); sH = sW = 1
+        H = W = int(rng.choice([28, 30, 54, 56, 58]))
+        n, C, Co = int(rng.integers(8, 33)), int(rng.choice([32, 57, 64, 100, 128])), int(rng.choice([128, 192, 256]))
     ishape, kshape, pad, st = (n, C, H, W), (Co, C, kH, kW), (pH, pW), (sH, sW)
     x = rng.uniform(-1, 1, ishape).astype(np.float32); w = rng.uniform(-1, 1, kshape).astype(np.float32)
     oshape = laser_amd.conv2d_out_shape(ishape, kshape, pad, st)
@@ -36,7 +40,7 @@ for it in range(cases):
     b = rng.uniform(-1, 1, Co).astype(np.float32) if use_epi else None
     if use_epi: want = oracle.apply_epilogue(want, b.reshape(1, -1, 1, 1), "relu")
     dout = torch.full(oshape, float("nan"), device="cuda")
-    laser_amd.set_conv_patch(bool(rng.random() < 0.8))
+    laser_amd.set_conv_patch(bool(rng.random() < 0.8)); laser_amd.set_conv_kslice(bool(rng.random() < 0.8))
     laser_amd.conv2d_im2col(dout, oshape, torch.from_numpy(x).cuda(), ishape, torch.from_numpy(w).cuda(), kshape, pad, st, None,
                             bias=None if b is None else torch.from_numpy(b).cuda(), activation="relu" if use_epi else None)
     got = dout.cpu().numpy()
@@ -44,6 +48,6 @@ for it in range(cases):
     if not ok:
         fails += 1
         print("FAIL", dict(it=it, ishape=ishape, kshape=kshape, pad=pad, st=st, epi=use_epi, maxabs=float(np.nanmax(np.abs(got - want)))), flush=True)
-laser_amd.set_conv_patch(True)
+laser_amd.set_conv_patch(True); laser_amd.set_conv_kslice(True)
 print(f"fuzz_conv: {cases} cases, {fails} failures")
 sys.exit(1 if fails else 0)

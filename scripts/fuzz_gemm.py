@@ -27,6 +27,12 @@ for it in range(cases):
         M, N, K = int(rng.integers(64, 400)), int(rng.integers(64, 400)), int(rng.integers(1100, 5000))
     elif shape_kind < 0.34:    # small: the one-wave-per-block kernel
         M, N, K = int(rng.integers(1, 200)), int(rng.integers(1, 200)), int(rng.integers(1, 129))
+    elif shape_kind < 0.42:    # 1..8 rows / columns past a multiple of 64: the peeled launch plan
+        M = 64 * int(rng.integers(16, 28)) + (int(rng.integers(1, 9)) if rng.random() < 0.7 else 0)
+        N = 64 * int(rng.integers(16, 28)) + (int(rng.integers(1, 9)) if rng.random() < 0.7 else 0)
+        K = int(rng.integers(256, 1400))
+    elif shape_kind < 0.45 and is_int:   # integer K past the limb kernels' 8192-k launch chunk / fold interval
+        M, N, K = int(rng.integers(64, 200)), int(rng.integers(64, 200)), int(rng.integers(8193, 17000))
     ta, tb = rng.random() < 0.4, rng.random() < 0.4
     offA, offB, offC = (int(rng.integers(0, 4)) for _ in range(3))
     padA, padB, padC = (int(rng.integers(0, 6)) * int(rng.random() < 0.6) for _ in range(3))
