@@ -54,20 +54,22 @@ struct Context {
   std::atomic<bool> ready{false};  // read lock-free on every call, written once under g_mu
   int device = -1;
   std::string arch;
-  int float_mode = LASER_HIP_F32_LASER_ORDER;
-  int f32_cfg = -1;
+  // run-time knobs: set by one thread, read by every call on every thread -> relaxed atomics (a knob flipped while a
+  // call is in flight applies to that call or the next, never tears)
+  std::atomic<int> float_mode{LASER_HIP_F32_LASER_ORDER};
+  std::atomic<int> f32_cfg{-1};
   hipStream_t s_up = nullptr, s_comp = nullptr;  // host-pointer pipeline: uploads / kernels
-  bool f64_mfma = true;       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
-  bool i32_mfma = true;       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
-  bool i64_mfma = true;       // int64 GEMM on the int8 matrix cores (false: VALU kernel)
-  bool zc_poll = true;           // small host-pointer calls: poll completion flags in mapped memory (false: synchronise the stream)
-  bool host_pipeline_2d = true;  // large row-major host-pointer calls: row panels x column panels (false: row panels only)
-  int slice_parallel_min = 2;        // (tuning override only) fewest kc slices worth splitting
-  int64_t slice_parallel_tiles = 0;  // tuning override of the tile-count limit of the slice-parallel form (0 = built-in rule)
-  bool slice_parallel = true; // few tiles x long K: kc slices as one batched launch + ordered combine
-  bool skinny = true;         // M <= 8 or N <= 8: the streaming kernel (false: always the tiled kernels)
-  bool conv_implicit = true;  // fuse im2col into the GEMM's B loader (false: explicit workspace)
-  int shard_devices = 1;      // host-pointer gemm_strided: row panels over this many GPUs (1 = off; laser_hip_set_shard_devices)
+  std::atomic<bool> f64_mfma{true};       // float64 GEMM on the f64 matrix cores (false: VALU kernel)
+  std::atomic<bool> i32_mfma{true};       // int32 GEMM on the int8 matrix cores (false: VALU kernel)
+  std::atomic<bool> i64_mfma{true};       // int64 GEMM on the int8 matrix cores (false: VALU kernel)
+  std::atomic<bool> zc_poll{true};           // small host-pointer calls: poll completion flags in mapped memory (false: synchronise the stream)
+  std::atomic<bool> host_pipeline_2d{true};  // large row-major host-pointer calls: row panels x column panels (false: row panels only)
+  std::atomic<int> slice_parallel_min{2};        // (tuning override only) fewest kc slices worth splitting
+  std::atomic<int64_t> slice_parallel_tiles{0};  // tuning override of the tile-count limit of the slice-parallel form (0 = built-in rule)
+  std::atomic<bool> slice_parallel{true}; // few tiles x long K: kc slices as one batched launch + ordered combine
+  std::atomic<bool> skinny{true};         // M <= 8 or N <= 8: the streaming kernel (false: always the tiled kernels)
+  std::atomic<bool> conv_implicit{true};  // fuse im2col into the GEMM's B loader (false: explicit workspace)
+  std::atomic<int> shard_devices{1};      // host-pointer gemm_strided: row panels over this many GPUs (1 = off; laser_hip_set_shard_devices)
 };
 Context g_ctx;
 
@@ -237,7 +239,7 @@ hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s) {
   // tiles on the sequential loop wins (2048^3: -14 %)
   int64_t need = tiles64 <= 150 ? 2 : tiles64 <= 400 ? 5 : tiles64 <= 600 ? 6 : (int64_t)1 << 40;
   if (a.K % kc != 0 && need < 3) need = 3;  // a ragged last slice is a launch of its own: 768^3 (512 + 256) loses
-  if (g_ctx.slice_parallel_tiles > 0) need = tiles64 <= g_ctx.slice_parallel_tiles ? g_ctx.slice_parallel_min : (int64_t)1 << 40;  // tuning override
+  if (g_ctx.slice_parallel_tiles > 0) need = tiles64 <= g_ctx.slice_parallel_tiles.load() ? (int64_t)g_ctx.slice_parallel_min.load() : (int64_t)1 << 40;  // tuning override
   if (nsl < need || nsl > 65535 || ws_bytes > 1.5e9) return hipErrorNotSupported;
   T *W = nullptr;
   hipError_t e = hipMallocAsync((void **)&W, (size_t)ws_bytes, s);

@@ -130,7 +130,7 @@ hipError_t launch_gemm_skinny(const GemmArgs<T> &args, bool laser_order, int kc_
 // MFMA operand registers; hipErrorNotSupported = not a small problem, use the tiled kernels.  float32 / float64.
 template <typename T>
 hipError_t launch_gemm_small(const GemmArgs<T> &args, bool laser_order, int kc_elems, hipStream_t s, bool mapped = false);
-extern int g_small_path;
+extern std::atomic<int> g_small_path;
 // the dispatch rule of launch_gemm_small (mapped: the operands live in host memory mapped into the device)
 bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch, bool mapped = false);
 template <typename T>
@@ -145,12 +145,12 @@ hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &args, void *ws, hipStre
 size_t gemm_i64_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_i64_mfma(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 
-extern int g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
-extern int g_conv_kslice;        // laser-order conv tail as parallel kc slices + ordered combine (1, default)
-extern int g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches
-extern int64_t g_last_split;    // diagnostics: column cut of the last MFMA launch (0 = one launch)
-extern int g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used
-extern int g_transpose_variant;  // tuning knob, 0 = production form
+extern std::atomic<int> g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
+extern std::atomic<int> g_conv_kslice;        // laser-order conv tail as parallel kc slices + ordered combine (1, default)
+extern std::atomic<int> g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches
+extern std::atomic<int64_t> g_last_split;    // diagnostics: column cut of the last MFMA launch (0 = one launch)
+extern std::atomic<int> g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used
+extern std::atomic<int> g_transpose_variant;  // tuning knob, 0 = production form
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,
                                     int elem_size, hipStream_t s);
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ 
   }
 }
 
-int g_transpose_variant = 0;  // tuning knob (laser_hip_set_transpose_variant): tile shape / streaming hints
+std::atomic<int> g_transpose_variant{0};  // tuning knob (laser_hip_set_transpose_variant): tile shape / streaming hints
 
 template <typename T, int TR, int TC, bool NT>
 static hipError_t launch_transpose_v(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s) {

@@ -130,8 +130,8 @@ struct SplitPlan {
   int cfg_main = -1, cfg_tail = -1;
   int64_t n_cut = 0;  // 0: one launch
 };
-int g_split_tail = 1;  // knob (laser_hip_set_split_tail): 0 = never cut, 1 = cut, tail after the main launch, 2 = cut, tail beside it
-int64_t g_last_split = 0;  // diagnostics: column cut of the last MFMA GEMM / conv launch (0: single launch)
+std::atomic<int> g_split_tail{1};  // knob (laser_hip_set_split_tail): 0 = never cut, 1 = cut, tail after the main launch, 2 = cut, tail beside it
+std::atomic<int64_t> g_last_split{0};  // diagnostics: column cut of the last MFMA GEMM / conv launch (0: single launch)
 static SplitPlan plan_split(const GemmArgs<float> &a, bool exact, bool need_gen, bool conv, bool bn_multiple_only) {
   SplitPlan p;
   double t_single;
@@ -171,9 +171,9 @@ static int heuristic_cfg(const GemmArgs<double> &a, bool, bool = false) { return
 static int fallback_exact_cfg(const GemmArgs<double> &) { return 0; }
 static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 
-int g_conv_patch = 1;     // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
-int g_conv_kslice = 1;    // laser-order conv: tail launch as parallel kc slices + ordered combine (0: one workgroup per tail tile)
-int g_last_f32_cfg = -1;  // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
+std::atomic<int> g_conv_patch{1}; // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
+std::atomic<int> g_conv_kslice{1}; // laser-order conv: tail launch as parallel kc slices + ordered combine (0: one workgroup per tail tile)
+std::atomic<int> g_last_f32_cfg{-1}; // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
 // Main + tail.  Default: the tail launch follows the main launch on the caller's stream.  Knob value 2 runs the tail
 // on a side stream BESIDE the main launch (event fork / join, nothing blocks the host) -- the idea being that its few

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(const GemmArgs<E> g) {
 //   A single device-resident problem never: on all 18 shapes of the sweep (32^3 .. 512x512x128) the 64x64-tile kernel,
 //     whose 4 waves share every operand element through LDS, is 4-30 % faster (128^3: 5.9 vs 6.7 us per launch).
 // hipErrorNotSupported: not this kernel's case, use the tiled kernels.
-int g_small_path = 1;  // knob (laser_hip_set_small_path)
+std::atomic<int> g_small_path{1};  // knob (laser_hip_set_small_path)
 bool gemm_small_takes(int elem_size, int64_t M, int64_t N, int64_t K, int64_t batch, bool mapped) {
   if (!g_small_path || (elem_size != 4 && elem_size != 8)) return false;
   const int mb = elem_size == 4 ? 32 : 16;
