@@ -803,7 +803,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   // both operands and C row-major-like, and big enough that B's upload is worth hiding: the 2-D form.  Pinned (or
   // registered) B and C only: their column panels / strips move as pitched 2-D copies, which are DMA transfers from
   // pinned memory but row-by-row staging from pageable memory (8192^3: 15.0 ms in one harness, 23 ms in another, against
-  // 15.7 ms for the row-panel form -- profiles/r02/host_pipeline_v2.jsonl, configs_v12.jsonl)
+  // 15.7 ms for the row-panel form -- profiles/r02/host_pipeline_v2.jsonl, configs_v19.jsonl)
   auto pinned = [](const void *p) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {

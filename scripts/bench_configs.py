@@ -132,6 +132,19 @@ def main():
                  tflops=round(flops / (med * 1e-3) / 1e12, 2), frac_mfma_peak=round(flops / (med * 1e-3) / 1e12 / PEAK_TF, 4))
     laser_amd.set_float_mode(0)
     laser_amd.set_conv_implicit(True)
+    # the reference bench's own default geometry: pad 0 (54x54 outputs), conv2d_bench.nim:58-59 -- secondary line
+    pad0 = (0, 0)
+    oshape0 = laser_amd.conv2d_out_shape(ishape, kshape, pad0, st)
+    out0 = torch.zeros(oshape0, device="cuda")
+    flops0 = 2.0 * oshape0[0] * oshape0[1] * oshape0[2] * oshape0[3] * kshape[1] * 9
+    for mode in (0, 1):
+        laser_amd.set_float_mode(mode)
+        med, mn = ev_time(lambda: laser_amd.conv2d_im2col(out0, oshape0, x, ishape, w, kshape, pad0, st, None))
+        emit(config="C4' conv 32x128x56x56 * 256x128x3x3 pad0 stride1 (the reference bench's default geometry; implicit GEMM)",
+             mode="laser_order" if mode == 0 else "fast", ms_med=round(med, 4), ms_min=round(mn, 4),
+             tflops=round(flops0 / (med * 1e-3) / 1e12, 2), frac_mfma_peak=round(flops0 / (med * 1e-3) / 1e12 / PEAK_TF, 4))
+    laser_amd.set_float_mode(0)
+    del out0
     L = laser_amd.lib()
     med, mn = ev_time(lambda: L.laser_hip_im2col_f32_dev(ws.data_ptr(), 56, 56, x.data_ptr(), 32, 128, 56, 56, 3, 3, 1, 1, 1, 1,
                                                          torch.cuda.current_stream().cuda_stream))
