@@ -25,6 +25,14 @@
 // Mid sizes (1024^3..4100^3, scripts/heuristic_check.py with three extra configurations built in): a
 // 3-stage 64x64x32 (+4 % at 1024^3 only), 128x64x16 (never best) and an 8-wave 128x128x16 (+8 % at 2048^3
 // laser-order only, where the grid is exactly 256 tiles) -- not worth three more translation units.
+// One wave per SIMD (4-wave workgroups, 512 registers per wave, accumulators in AGPRs) -- the shape the vendor library's
+// assembly kernels use (torch.matmul -> rocBLAS / hipBLASLt on the same box: 154 TFLOP/s at 8192^3,
+// profiles/r02/vendor_blas_v1.jsonl) -- measured again in round 2 with the k-quad image: 256x256x16 as 2x2 waves of
+// 128x128 (16 MFMA blocks per wave, 512 registers, no spills) runs 134.1 TFLOP/s fast against 139.7 for the 8-wave form of
+// the same tile: without a partner wave every barrier and every counted wait idles the matrix pipe, and the compiler's
+// schedule does not close that gap.  The laser-order sibling (256x128x32 as 2x2 waves of 128x64, acc + run = 256
+// registers) spills 120-286 VGPRs as written: VALU cannot read AGPRs, so the running sum lands in VGPRs next to the
+// fragment and staging registers.  Neither is built.
 // cfg 3 as a 3-stage ring with the k-quad image: +3 % at 1024^3, -4 % at 2048^3, -3 % at 8192^3: stays 2-stage.
 
 // float64 (v_mfma_f64_16x16x4_f64, 16x16 blocks, 4 k per instruction): the 8-wave 128x128 tile has the
