@@ -44,6 +44,17 @@
 
 #include "common.h"
 
+// Ablation switches of the main loop (timing only, results are wrong when one is on): 1 = no HBM loads of later tiles,
+// 2 = no LDS stores, 4 = no mid-tile barrier.  Production builds: the DBG template flag is false and the test is compiled
+// away.  -DLH_DBG_MASK=<bits> builds an experimental library whose PRODUCTION instantiations have the pieces removed at
+// compile time (scripts/ablate_exact.py) -- unlike the run-time g.dbg switches of the probe instantiation, that leaves the
+// steady-state loop one basic block with its counted waits intact, so the deltas are the pieces' real prices.
+#ifdef LH_DBG_MASK
+#define LH_DBG_KEEP(bit) (!((LH_DBG_MASK) & (bit)))
+#else
+#define LH_DBG_KEEP(bit) (!DBG || !(g.dbg & (bit)))
+#endif
+
 namespace laser_hip {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -885,17 +896,17 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
           constexpr int P = decltype(la)::OPS_PER_GROUP, W = decltype(la)::WOPS, GN = decltype(la)::GROUPN;
           const int gi = o / P, c = o % P;
           if (c < W) {
-            if (!DBG || !(g.dbg & 2)) la.store_op(wA, t, gi, c);
-          } else if (more2 && (!DBG || !(g.dbg & 1))) {
+            if (LH_DBG_KEEP(2)) la.store_op(wA, t, gi, c);
+          } else if (more2 && LH_DBG_KEEP(1)) {
             la.load_op(Ab, g.rsA, g.csA, k2, mlim, K, t, gi * GN + (c - W));
           }
         } else if (o < NA + NB) {
           constexpr int P = decltype(lb)::OPS_PER_GROUP, W = decltype(lb)::WOPS, GN = decltype(lb)::GROUPN;
           const int gi = (o - NA) / P, c = (o - NA) % P;
           if (c < W) {
-            if (!DBG || !(g.dbg & 2)) lb.store_op(wB, t, gi, c);
+            if (LH_DBG_KEEP(2)) lb.store_op(wB, t, gi, c);
             if (gi == 0 && c == 0) lb.store_table(wB, t, &g);
-          } else if (more2 && (!DBG || !(g.dbg & 1))) {
+          } else if (more2 && LH_DBG_KEEP(1)) {
             lb.load_op(Bb, g.csB, g.rsB, k2, nlim, K, t, gi * GN + (c - W), &g);
           }
         }
@@ -907,7 +918,7 @@ __global__ void __launch_bounds__(WM *WN * 64, OCC)
 #pragma unroll
       for (int gi = 0; gi < NG; gi++) {
         // everyone's stores of tile kt+1 are done past this point
-        if (gi == NG / 2 && (!DBG || !(g.dbg & 4))) __syncthreads();
+        if (gi == NG / 2 && LH_DBG_KEEP(4)) __syncthreads();
         if (gi + 1 < NG)
           ldgroup(sA, sB, gi + 1, (gi + 1) & 1);
         else if (more)
