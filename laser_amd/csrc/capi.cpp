@@ -345,6 +345,10 @@ hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s) {
     const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
+  if (g_ctx.f32_cfg < 0 && g_f32_dma) {  // (experiment, off by default) row-major operands in whole 256x128x32 tiles: the LDS-DMA kernel
+    const hipError_t e = launch_gemm_f32_dma(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 template <>
@@ -1246,6 +1250,10 @@ int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from
 int laser_hip_set_host_pipeline(int mode) {  // A/B knob: bit 0 = 2-D (row x column panel) host pipeline where it applies (0: row panels
   g_ctx.host_pipeline_2d = (mode & 1) != 0;  // only); bit 1 CLEAR = the small zero-copy path polls completion flags (set: it synchronises)
   g_ctx.zc_poll = (mode & 2) == 0;
+  return LASER_HIP_OK;
+}
+int laser_hip_set_f32_dma(int on) {  // A/B knob: 1 = float32 row-major whole-tile problems on the LDS-DMA kernel, 0 = register-staged kernels (default)
+  g_f32_dma = on != 0;
   return LASER_HIP_OK;
 }
 int laser_hip_set_conv_kslice(int on) {  // A/B knob: laser-order conv tail as parallel kc slices + ordered combine (1) or one launch (0)

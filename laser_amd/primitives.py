@@ -100,6 +100,11 @@ def set_f64_mfma(on):
     _lib.check(_lib.lib().laser_hip_set_f64_mfma(1 if on else 0))
 
 
+def set_f32_dma(on):
+    """True: float32 row-major whole-tile problems run the experimental LDS-DMA kernel; False (default): the register-staged kernels."""
+    _lib.check(_lib.lib().laser_hip_set_f32_dma(1 if on else 0))
+
+
 def set_i32_mfma(on):
     """True (default): int32 GEMM on the int8 matrix cores (limb decomposition); False: VALU kernel."""
     _lib.check(_lib.lib().laser_hip_set_i32_mfma(1 if on else 0))

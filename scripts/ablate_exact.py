@@ -20,7 +20,11 @@ n = 8192
 A = (torch.rand((n, n), device="cuda") - 0.5) * 0.2; B = (torch.rand((n, n), device="cuda") - 0.5) * 0.2; Cc = torch.zeros((n, n), device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 def run(L): assert L.laser_hip_gemm_strided_f32_dev(n, n, n, 1.0, A.data_ptr(), n, 1, B.data_ptr(), n, 1, 0.0, Cc.data_ptr(), n, 1, st) == 0
-for cfg, mode, label in ((0, 1, "256x256x16 8 waves, fast"), (4, 0, "256x128x32 8 waves, laser-order"), (4, 1, "256x128x32 8 waves, fast")):
+CASES = ((0, 1, "256x256x16 8 waves, fast"), (4, 0, "256x128x32 8 waves, laser-order"), (4, 1, "256x128x32 8 waves, fast"))
+if len(sys.argv) > 1 and sys.argv[1] == "dma":      # the LDS-DMA kernel's own variants (cfg -1: the library's dispatch)
+    CASES = ((-1, 0, "LDS-DMA 256x128x32, laser-order"), (-1, 1, "LDS-DMA 256x128x32, fast"))
+    what.update(mask1="DMA pieces late in each group", mask2="no DMA requests (MFMA + fragment reads + selects only)")
+for cfg, mode, label in CASES:
     res = {k: [] for k in libs}
     for L in libs.values():
         L.laser_hip_set_float_mode(mode); L.laser_hip_set_f32_config(cfg)

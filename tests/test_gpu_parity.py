@@ -651,6 +651,54 @@ def test_full_size_conv_c4_every_image(la, oracle):
     assert cut > 0 and cut % 128 == 0, "C4 (1600 tiles of 128x128 = 3.1 rounds) is expected to run as main + tail"
 
 
+def test_f32_dma_kernel_bit_exact(la, oracle):
+    """The experimental LDS-DMA float32 kernel (laser_hip_set_f32_dma(1); row-major A and B in whole 256x128x32 tiles): same bits as the register-staged kernels (knob
+    off) in both accumulation modes, and as the oracle in laser-order mode -- K with a ragged last kc slice and with a slice
+    boundary in the last two tiles, alpha / beta, padded leading dimensions, a strided C, a batch."""
+    import torch
+    rng = np.random.default_rng(41)
+    took = 0
+    for (M, N, K) in [(4096, 4096, 1024), (2048, 8192, 1568), (8192, 2048, 1056), (4096, 4096, 2080)]:
+        A = rand(rng, (M, K + 8), np.float32)[:, :K]          # leading dimension K + 8
+        B = rand(rng, (K, N + 12), np.float32)[:, :N]
+        dAb = torch.from_numpy(np.ascontiguousarray(A.base)).cuda(); dA = dAb[:, :K]
+        dBb = torch.from_numpy(np.ascontiguousarray(B.base)).cuda(); dB = dBb[:, :N]
+        C0 = rand(rng, (M, N), np.float32)
+        for mode in (0, 1):
+            for alpha, beta in ((1, 0), (0.5, 0.25)):
+                la.set_float_mode(mode)
+                try:
+                    la.set_f32_dma(True)
+                    dC = torch.from_numpy(C0.copy()).cuda()
+                    la.matmul(dA, dB, alpha, beta, dC)
+                    la.set_f32_dma(False)
+                    dC2 = torch.from_numpy(C0.copy()).cuda()
+                    la.matmul(dA, dB, alpha, beta, dC2)
+                finally:
+                    la.set_f32_dma(False); la.set_float_mode(0)
+                assert torch.equal(dC, dC2), (M, N, K, mode, alpha, beta)
+                if mode == 0 and (alpha, beta) == (1, 0):
+                    assert np.array_equal(dC.cpu().numpy(), oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B))), (M, N, K)
+        took += 1
+    # strided C (every second column of a wider buffer) and a batch of two problems sharing B
+    M, N, K = 2048, 4096, 1024
+    A = torch.from_numpy(rand(rng, (2, M, K), np.float32)).cuda()
+    B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
+    wide = torch.full((2, M, 2 * N), 9.0, device="cuda")
+    ref = torch.stack([la.matmul(A[b], B) for b in range(2)])          # register-staged kernels
+    try:
+        la.set_f32_dma(True)
+        for b in range(2):
+            la.matmul(A[b], B, 1, 0, wide[b][:, ::2])
+        Cb = torch.zeros((2, M, N), device="cuda")
+        la.gemm_strided_batched(2, M, N, K, 1.0, A, K, 1, M * K, B, N, 1, 0, 0.0, Cb, N, 1, M * N)
+    finally:
+        la.set_f32_dma(False)
+    assert torch.equal(wide[:, :, ::2], ref) and (wide[:, :, 1::2] == 9.0).all()
+    assert torch.equal(Cb, ref)
+    assert took == 4
+
+
 def test_ragged_by_a_few_rows_columns_peeled_bit_exact(la, oracle):
     """M or N a few (1..8) past a multiple of 64: the extra rows / columns are peeled off and streamed by the M <= 8 / N <= 8
     kernel, the tiled launch sees whole tiles.  Same bits as the single launch (peeling off) and as the oracle: both
