@@ -69,3 +69,47 @@ def test_shard_plan_matches_the_per_process_plan():
         assert laser_amd.shard_plan(M, n, p) == (b.rows, b.panels_per_rank, b.padded_M), (M, n, p)
     rows, ppd, padded = laser_amd.shard_plan(65536, 8, 4)
     assert (rows, ppd, padded) == (2048, 4, 65536)     # BASELINE configs[4]: 4 panels of 2048 rows per GPU
+
+
+def _balanced_limbs(a, nlimbs):
+    """The limb split the integer kernels use (gemm_i32_mfma.hip / gemm_i64_mfma.hip, limb_planes.h): bytes of
+    (a + 0x..808080) ^ 0x..808080 read as int8 -- balanced base-256 digits, top digit any representative mod 256."""
+    bits = 8 * nlimbs
+    mask = (1 << bits) - 1
+    bias = int("00" + "80" * (nlimbs - 1), 16)
+    out = np.zeros((nlimbs,) + a.shape, dtype=np.int64)
+    flat = [((int(v) & mask) + bias & mask) ^ bias for v in a.reshape(-1)]
+    for p in range(nlimbs):
+        d = np.array([(v >> (8 * p)) & 0xFF for v in flat], dtype=np.int64).reshape(a.shape)
+        out[p] = np.where(d >= 128, d - 256, d)
+    return out
+
+
+@pytest.mark.parametrize("dtype,nlimbs", [(np.int32, 4), (np.int64, 8)])
+def test_limb_decomposition_identity(dtype, nlimbs):
+    """The arithmetic the int8-limb kernels rest on, replayed in numpy: a == sum_p s_p 256^p (mod 2^n) with s_p in
+    [-128, 127]; a.b == sum_{p+q<n/8} s_p(a) s_q(b) 256^(p+q) (mod 2^n); and with K <= 8192 per accumulation chunk every
+    per-power partial sum G_s stays inside int32 (|G_s| <= (s+1) * K * 2^14 <= 2^30), so nothing depends on overflow."""
+    rng = np.random.default_rng(5)
+    info = np.iinfo(dtype)
+    bits = 8 * nlimbs
+    M, N, K = 9, 7, 64
+    A = rng.integers(info.min, info.max, (M, K), dtype=dtype)
+    B = rng.integers(info.min, info.max, (K, N), dtype=dtype)
+    A[0, :4] = [info.min, info.max, -1, 0]
+    B[:4, 0] = [info.max, info.min, 127, -129]
+    la, lb = _balanced_limbs(A, nlimbs), _balanced_limbs(B, nlimbs)
+    assert la.min() >= -128 and la.max() <= 127
+    # digits recompose the value mod 2^bits
+    rec = sum(int(la[p][0, 1]) * 256 ** p for p in range(nlimbs)) % (1 << bits)
+    assert rec == int(A[0, 1]) % (1 << bits)
+    # per-power partial products, combined exactly as the kernels' epilogues do
+    want = (A.astype(object) @ B.astype(object)) % (1 << bits)
+    got = np.zeros((M, N), dtype=object)
+    for s in range(nlimbs):
+        G = sum(la[p] @ lb[s - p] for p in range(s + 1))           # int64 numpy: exact
+        assert np.abs(G).max() <= (s + 1) * K * 2 ** 14
+        got = (got + G.astype(object) * 256 ** s) % (1 << bits)
+    assert (got == want).all()
+    # the bound that sizes the launch chunk / fold interval
+    assert 8 * 8192 * 2 ** 14 == 2 ** 30 and 4 * 8192 * 2 ** 14 == 2 ** 29      # int64: 8 pairs at most per power; int32: 4
