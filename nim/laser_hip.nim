@@ -310,6 +310,72 @@ proc copyStrided*[T](dst: DevicePtr[T], dstStrides: openarray[int], src: DeviceP
     check laser_hip_copy_strided_b64_dev(pointer(dst), dstStrides[0].unsafeAddr, pointer(src), srcStrides[0].unsafeAddr,
                                          shape[0].unsafeAddr, cint(shape.len), nil)
 
+# ---- mapStrided: the device twin of forEach / forEachStrided (foreach.nim:192-264) ----------------
+# dst[idx] = f(a[idx]) / f(a[idx], b[idx]) over rank <= 6 (LASER_MAXRANK) strided views, strides in elements, 0 = broadcast.
+type MapOp* = enum
+  mapCopy = 0, mapFill = 1, mapNeg = 2, mapAbs = 3, mapRelu = 4, mapScale = 5, mapSquare = 6, mapExp = 7, mapLog = 8,
+  mapTanh = 9, mapSigmoid = 10, mapSqrt = 11, mapRecip = 12,
+  mapAdd = 32, mapSub = 33, mapMul = 34, mapDiv = 35, mapMax = 36, mapMin = 37, mapAxpy = 38, mapAxpby = 39
+
+proc laser_hip_map_strided_unary_f32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_f32_dev".}
+proc laser_hip_map_strided_unary_f64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_f64_dev".}
+proc laser_hip_map_strided_unary_i32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_i32_dev".}
+proc laser_hip_map_strided_unary_i64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_i64_dev".}
+proc laser_hip_map_strided_binary_f32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_f32_dev".}
+proc laser_hip_map_strided_binary_f64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_f64_dev".}
+proc laser_hip_map_strided_binary_i32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_i32_dev".}
+proc laser_hip_map_strided_binary_i64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_i64_dev".}
+
+proc mapStrided*[T: float32 or float64 or int32 or int64](op: MapOp, dst: DevicePtr[T], dstStrides: openarray[int],
+                 a: DevicePtr[T], aStrides: openarray[int], shape: openarray[int],
+                 alpha = 1.0, beta = 0.0, stream: pointer = nil) =
+  ## `forEachStrided d in dst, x in a: d = f(x)` on device buffers (fill: `a` may be a nil DevicePtr).
+  assert shape.len == dstStrides.len and shape.len == aStrides.len and shape.len <= 6 and ord(op) < 32
+  when T is float32:
+    check laser_hip_map_strided_unary_f32_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+  elif T is float64:
+    check laser_hip_map_strided_unary_f64_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+  elif T is int32:
+    check laser_hip_map_strided_unary_i32_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+  else:
+    check laser_hip_map_strided_unary_i64_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+
+proc mapStrided*[T: float32 or float64 or int32 or int64](op: MapOp, dst: DevicePtr[T], dstStrides: openarray[int],
+                 a: DevicePtr[T], aStrides: openarray[int], b: DevicePtr[T], bStrides: openarray[int],
+                 shape: openarray[int], alpha = 1.0, beta = 1.0, stream: pointer = nil) =
+  ## `forEachStrided d in dst, x in a, y in b: d = f(x, y)` on device buffers.
+  assert shape.len == dstStrides.len and shape.len == aStrides.len and shape.len == bStrides.len and shape.len <= 6 and ord(op) >= 32
+  when T is float32:
+    check laser_hip_map_strided_binary_f32_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, pointer(b), bStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+  elif T is float64:
+    check laser_hip_map_strided_binary_f64_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, pointer(b), bStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+  elif T is int32:
+    check laser_hip_map_strided_binary_i32_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, pointer(b), bStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+  else:
+    check laser_hip_map_strided_binary_i64_dev(cint(ord(op)), pointer(dst), dstStrides[0].unsafeAddr, pointer(a), aStrides[0].unsafeAddr, pointer(b), bStrides[0].unsafeAddr, shape[0].unsafeAddr, cint(shape.len), alpha, beta, stream)
+
+# ---- the whole node behind an unchanged gemm_strided call, and pinned host memory ------------------------------------
+# Laser parallelises one gemm_strided call over OpenMP threads by ic row blocks (gemm.nim:160-176); here the same row blocks
+# go to the GPUs of the node: after `laserHipShardDevices(0)` (0 = every visible GPU, n = that many, 1 = off) the plain
+# host-pointer gemm_strided above cuts large problems into one row range per GPU inside the library -- call sites unchanged.
+proc laser_hip_set_shard_devices(ndev: cint): cint {.lh, importc: "laser_hip_set_shard_devices".}
+proc laser_hip_get_shard_devices(): cint {.lh, importc: "laser_hip_get_shard_devices".}
+proc laser_hip_host_alloc(hostPtr: ptr pointer, bytes: int): cint {.lh, importc: "laser_hip_host_alloc".}
+proc laser_hip_host_free(hostPtr: pointer): cint {.lh, importc: "laser_hip_host_free".}
+proc laser_hip_host_register(hostPtr: pointer, bytes: int): cint {.lh, importc: "laser_hip_host_register".}
+proc laser_hip_host_unregister(hostPtr: pointer): cint {.lh, importc: "laser_hip_host_unregister".}
+
+proc laserHipShardDevices*(ndev: int) = check laser_hip_set_shard_devices(cint(ndev))
+proc laserHipShardDevices*(): int = int(laser_hip_get_shard_devices())
+proc allocPinned*[T](len: int): ptr UncheckedArray[T] =
+  ## page-locked host memory for operands of the host-pointer calls (what an allocator would hand to Tensor[T])
+  var p: pointer
+  check laser_hip_host_alloc(p.addr, sizeof(T) * len)
+  cast[ptr UncheckedArray[T]](p)
+proc freePinned*(p: pointer) = check laser_hip_host_free(p)
+proc registerPinned*(p: pointer, bytes: int) = check laser_hip_host_register(p, bytes)
+proc unregisterPinned*(p: pointer) = check laser_hip_host_unregister(p)
+
 # gemm_strided on device-resident operands: the SAME parameter list as gemm.nim:184-193 with DevicePtr[T]
 # in place of ptr T (overload resolution keeps host and device pointers apart), asynchronous on `stream`.
 proc gemm_strided*[T: SomeNumber](
