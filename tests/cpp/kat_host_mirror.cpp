@@ -77,6 +77,15 @@ int main() {
     auto ct = C.transposed().to_host();                     // deepCopy of a non-contiguous view
     fails += (ct[0] != 58) + (ct[1] != 139) + (ct[2] != 64) + (ct[3] != 154);
     fails += !C.is_C_contiguous() + C.transposed().is_C_contiguous() + (laser::newTensor<double>({4, 0, 2}).size() != 0);
+    // forEach's device twin on a strided view: E = relu(C^T - 100), then E += C^T
+    auto E = laser::newTensor<float>({2, 2});
+    auto Ct = C.transposed();
+    laser::forEachMap(LASER_HIP_MAP_SCALE, E, Ct, 1.0, -100.0);          // [[-42, 39], [-36, 54]]
+    laser::forEachMap(LASER_HIP_MAP_RELU, E, E);                         // [[0, 39], [0, 54]]
+    laser::forEachMap(LASER_HIP_MAP_ADD, E, E, Ct);                      // [[58, 178], [64, 208]]
+    const float want_e[4] = {58, 178, 64, 208};
+    auto e = E.to_host();
+    for (int i = 0; i < 4; i++) fails += (e[i] != want_e[i]);
     laser::setZero(C);
     for (float v : C.to_host()) fails += (v != 0.f);
   }
