@@ -103,10 +103,12 @@ int64_t laser_hip_last_split(void);
 int laser_hip_last_f32_config(void);
 /* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */
 int laser_hip_set_transpose_variant(int variant);
-/* float32 gemm_strided on row-major A and B in whole 256x128x32 tiles: 1 = the experimental kernel whose operand tiles
- * reach LDS by LDS-DMA (no staging registers, no LDS stores); 0 (default) = the register-staged kernels, which measure the
- * same or better (gemm_f32_dma.hip).  Results are bit-identical. */
-int laser_hip_set_f32_dma(int on);
+/* float32 gemm_strided with unit column strides, alpha == 1, beta == 0 and K a multiple of the K-tile: 1 (default) = the
+ * hand-scheduled assembly kernels (one wave per SIMD, accumulators in AGPRs; laser_amd/asmgen/) when the tiles fill the
+ * chip; 0 = always the compiler-scheduled kernels; 2 = whenever the problem is eligible (tests).  Bit-identical. */
+int laser_hip_set_f32_asm(int on);
+/* diagnostics: 0 = the last float32 GEMM launch was a compiler-scheduled kernel, 1 / 2 = the laser-order / fast assembly kernel */
+int laser_hip_last_f32_asm(void);
 /* int32 GEMM strategy: 1 (default) = signed 8-bit limb decomposition on the int8 matrix cores
  * (bit-exact mod 2^32); 0 = the VALU kernel.  Results are bit-identical. */
 int laser_hip_set_i32_mfma(int on);

@@ -51,7 +51,7 @@ def lib():
     L.laser_hip_set_conv_kslice.argtypes = [ci]
     L.laser_hip_set_host_pipeline.argtypes = [ci]
     L.laser_hip_set_i32_mfma.argtypes = [ci]
-    L.laser_hip_set_f32_dma.argtypes = [ci]
+    L.laser_hip_set_f32_asm.argtypes = [ci]
     L.laser_hip_set_i64_mfma.argtypes = [ci]
     L.laser_hip_set_f64_mfma.argtypes = [ci]
     L.laser_hip_f32_config_name.argtypes = [ci]
@@ -135,7 +135,7 @@ def declared_symbols():
     names = ["laser_hip_init", "laser_hip_finalize", "laser_hip_last_error", "laser_hip_version",
              "laser_hip_device_count", "laser_hip_arch", "laser_hip_set_float_mode",
              "laser_hip_get_float_mode", "laser_hip_set_f32_config", "laser_hip_f32_config_count",
-             "laser_hip_f32_config_name", "laser_hip_set_conv_implicit", "laser_hip_set_transpose_variant", "laser_hip_set_skinny", "laser_hip_set_slice_parallel", "laser_hip_set_split_tail", "laser_hip_set_small_path", "laser_hip_last_split", "laser_hip_set_conv_patch", "laser_hip_set_conv_kslice", "laser_hip_set_host_pipeline", "laser_hip_last_f32_config", "laser_hip_set_i32_mfma", "laser_hip_set_f32_dma", "laser_hip_set_i64_mfma", "laser_hip_set_f64_mfma", "laser_hip_gemm_prepack_release",
+             "laser_hip_f32_config_name", "laser_hip_set_conv_implicit", "laser_hip_set_transpose_variant", "laser_hip_set_skinny", "laser_hip_set_slice_parallel", "laser_hip_set_split_tail", "laser_hip_set_small_path", "laser_hip_last_split", "laser_hip_set_conv_patch", "laser_hip_set_conv_kslice", "laser_hip_set_host_pipeline", "laser_hip_last_f32_config", "laser_hip_set_i32_mfma", "laser_hip_set_f32_asm", "laser_hip_last_f32_asm", "laser_hip_set_i64_mfma", "laser_hip_set_f64_mfma", "laser_hip_gemm_prepack_release",
              "laser_hip_conv2d_out_shape", "laser_hip_im2col_workspace_size", "laser_hip_im2col_f32",
              "laser_hip_im2col_f32_dev", "laser_hip_conv2d_im2col_f32", "laser_hip_conv2d_im2col_f32_dev",
              "laser_hip_cblas_sgemm", "laser_hip_cblas_dgemm",

@@ -1,0 +1,83 @@
+"""Run a generated kernel through the interpreter on a small problem and compare with the accumulation-order model
+(S_p = fmaf chain over each kc = 512 slice from +0, C = (..(0 + S_0) + S_1 ..) in order)."""
+import struct
+import sys
+import time
+
+import numpy as np
+
+from . import f32_kernel as K
+from .sim import Memory, Workgroup, fma32
+
+
+def reference(A, B, kc):
+    M, Kd = A.shape
+    N = B.shape[1]
+    run = np.zeros((M, N), dtype=np.float32)
+    first = True
+    for k0 in range(0, Kd, kc if kc else Kd):
+        acc = np.zeros((M, N), dtype=np.float32)
+        for k in range(k0, min(Kd, k0 + (kc if kc else Kd))):
+            acc = fma32(A[:, k:k + 1] * np.ones((1, N), np.float32), np.ones((M, 1), np.float32) * B[k:k + 1, :], acc)
+        if kc:
+            run = (run + acc).astype(np.float32)
+        else:
+            run = acc
+        first = False
+    return run
+
+
+def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True):
+    g = K.make(name, **(over or {}))
+    g.build()
+    c = g.c
+    rng = np.random.default_rng(seed)
+    lda, ldb, ldc = lda or Kd, ldb or N, ldc or N
+    Af = np.zeros((M, lda), dtype=np.float32)
+    Bf = np.zeros((Kd, ldb), dtype=np.float32)
+    if integer:
+        Af[:, :Kd] = rng.integers(-3, 4, (M, Kd))
+        Bf[:, :N] = rng.integers(-3, 4, (Kd, N))
+    else:
+        Af[:, :Kd] = rng.uniform(-0.1, 0.1, (M, Kd))
+        Bf[:, :N] = rng.uniform(-0.1, 0.1, (Kd, N))
+    # trim the allocations to exactly the operand spans: any read past them is a simulator error
+    Aflat = Af.reshape(-1)[:(M - 1) * lda + Kd].copy()
+    Bflat = Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
+    Cflat = np.full((M - 1) * ldc + N, np.nan, dtype=np.float32)
+    tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
+    table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
+    mem = Memory()
+    a_, b_, c_, t_ = mem.alloc(Aflat), mem.alloc(Bflat), mem.alloc(Cflat), mem.alloc(table)
+    ka = struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 0, 0)
+    ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    t0 = time.time()
+    stats = None
+    for wg in range(len(table)):
+        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_bytes)
+        w.run(order=order)
+        stats = w.waves[0].stats
+    Cout = np.full((M, ldc), np.nan, dtype=np.float32).reshape(-1)
+    Cout[:len(Cflat)] = mem.get(c_, np.float32, (len(Cflat),))
+    Cout = Cout.reshape(M, ldc)[:, :N]
+    want = reference(Af[:, :Kd], Bf[:Kd, :N], 512 if c.exact else 0)
+    ok = np.array_equal(Cout, want)
+    pad_ok = True
+    if ldc > N:
+        full = np.full(M * ldc, np.nan, dtype=np.float32)
+        full[:len(Cflat)] = mem.get(c_, np.float32, (len(Cflat),))
+        pad_ok = bool(np.all(np.isnan(full.reshape(M, ldc)[:, N:][:-1])))
+    if verbose:
+        print(f"{name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc} int={integer}: "
+              f"{'OK' if ok and pad_ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, bank-conflict cycles {stats['bank_conflict_cycles']}, "
+              f"{stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
+        if not ok:
+            bad = np.argwhere(Cout != want)
+            print("  first mismatches:", bad[:8].tolist(), Cout[tuple(bad[0])], want[tuple(bad[0])], "count", len(bad))
+    return ok and pad_ok
+
+
+if __name__ == "__main__":
+    name = sys.argv[1] if len(sys.argv) > 1 else "exact_256x128x32"
+    ok = run_case(name, 256, 128 if "128x32" in name else 256, 64, integer=True)
+    sys.exit(0 if ok else 1)

@@ -1,0 +1,726 @@
+"""Generator of the hand-scheduled fp32 GEMM kernels (gfx950 assembly), the MI355X twin of the reference's generated
+micro-kernels (laser/primitives/matrix_multiplication/gemm_ukernel_generator.nim:140-250: every load, broadcast and FMA
+placed by the author) and of its packing + loop nest (gemm_packing.nim:24-94, gemm.nim:109-176).
+
+Shape of the kernel (one workgroup = one BM x BN tile of C, 4 waves = ONE wave per SIMD, 512 registers per lane):
+  * wave tile (BM/2) x (BN/2) of 32x32 v_mfma_f32_32x32x2_f32 blocks, accumulators in AGPRs; in laser-order mode a second
+    AGPR set holds the running sum of Laser's kc = 512 slices (gemm.nim:150-158: every slice is a chain from +0, the
+    slice sums are added in order) -- bit-identical to the reference on an FMA host;
+  * operand tiles HBM -> registers (16-byte buffer loads, bounds-checked descriptors: anything past the operand reads as
+    0) -> LDS in the k-quad panel image (one ds_read_b128 hands a lane four k-steps of a fragment) -- this
+    IS Laser's packing stage; 3-stage LDS ring, one s_barrier per K-tile placed where every wave has an MFMA in flight;
+  * the K-tile body is one straight-line block: 128 MFMAs with every ds_read / ds_write / buffer_load / SALU op assigned
+    to a fixed gap between two MFMAs and every s_waitcnt counted by the generator from its own model of the two
+    memory queues (never 0 for vmcnt in the steady state: tile t+2 is in flight while tile t multiplies).
+Restrictions (the launcher falls back to the compiler-scheduled kernels otherwise): float32, A and C row-major-like
+(unit column stride), B unit column stride (NN) or unit row stride (NT), K a multiple of BK, alpha == 1, beta == 0.
+"""
+from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF
+
+
+class Cfg:
+    def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
+                 b_store="write2", ablate=(), r_step=1):
+        self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
+        self.WTM, self.WTN = BM // 2, BN // 2
+        self.TM, self.TN = self.WTM // 32, self.WTN // 32
+        self.NB = self.TM * self.TN
+        self.NG = BK // 8            # fragment groups (4 k-steps each) per K-tile
+        self.NMF = self.NB * (BK // 2)  # MFMAs per K-tile per wave
+        self.GM = self.NMF // self.NG   # MFMAs per group
+        self.STAGE = BK * (BM + BN) * 4
+        self.NPA = BM * BK // 4 // 256   # 16-byte pieces of A per thread per tile
+        self.NPB = BN * BK // 4 // 256
+        assert self.NPB % 2 == 0
+        self.KC_TILES = 512 // BK        # gemm_tiling.nim:310: kc = 2048 / sizeof(float32)
+        self.bar_gap = bar_gap if bar_gap is not None else (self.NMF - self.GM - 1)
+        self.w_start, self.w_step = w_start, w_step
+        self.trace = trace
+        self.b_kcontig = b_kcontig
+        self.b_store = b_store      # "write2": ds_write2_b32 straight from the two pieces; "swap64": 4 v_swap + 4 ds_write_b64
+        self.ablate = set(ablate)   # timing experiments only (results are wrong): "loads", "stores", "reads", "barrier"
+        self.r_step = r_step
+        self.lds_bytes = 3 * self.STAGE
+        assert self.lds_bytes <= 160 * 1024
+
+
+CONFIGS = {
+    "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True),
+    "fast_256x256x16": dict(BM=256, BN=256, BK=16, exact=False),
+}
+
+# kernel argument block (bytes)
+KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 8, 16, 24, 32, 36, 40, 44, 48, 52, 64
+KERNARG_SIZE = 72
+
+
+class Gen:
+    def __init__(self, cfg):
+        self.c = cfg
+        self.p = Prog()
+        self.vmq = []   # tags of outstanding VMEM loads, oldest first
+        self.lgq = []   # tags of outstanding LDS ops
+        self.alloc()
+
+    # ------------------------------------------------------------------ registers
+    def alloc(self):
+        c, p = self.c, self.p
+        S, V = p.salloc, p.valloc
+        self.sA, self.sB, self.sC, self.sTAB = None, None, None, None
+        self.ka0 = S(8, align=4)   # A, B, C, TAB pointers
+        self.ka1 = S(8, align=4)   # lda ldb ldc M N K - -
+        self.s_lda, self.s_ldb, self.s_ldc, self.s_M, self.s_N, self.s_K = (self.ka1[i] for i in range(6))
+        self.srdA, self.srdB, self.srdC = S(4), S(4), S(4)
+        self.s_cur, self.s_nxt = S(), S()
+        self.s_rem, self.s_cnt, self.s_runlen = S(), S(), S()
+        self.s_bstep = S()
+        self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
+        self.s_t = [S() for _ in range(6)]
+        self.s_ldc4, self.s_ldc20 = S(), S()
+        # accumulators
+        self.acc = [p.aalloc(16) for _ in range(c.NB)]
+        self.run = [p.aalloc(16) for _ in range(c.NB)] if c.exact else None
+        # fragments: 2 slots
+        self.fa = [[V(4) for _ in range(c.TM)] for _ in range(2)]
+        self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
+        # staging pieces
+        self.stA = [V(4) for _ in range(c.NPA)]
+        self.stB = [V(4) for _ in range(c.NPB)]
+        # per-lane constants
+        self.vX = [V() for _ in range(c.NG)]
+        self.v_rowA, self.v_rowB = V(), V()
+        self.v_ra, self.v_rb = V(), V()          # absolute fragment-read addresses of the group being read
+        self.vWA = [V(), V()]
+        self.vWAabs = [V(), V()]
+        self.vWB = [[V() for _ in range(4)] for _ in range(c.NPB // 2)]
+        self.vWBabs = [[V() for _ in range(4)] for _ in range(c.NPB // 2)]
+        self.vVA = [V() for _ in range(c.NPA)]
+        self.vVB = [V() for _ in range(c.NPB)]
+        self.vC = [V() for _ in range(c.TN)]
+        self.vT = [V(16), V(16)]
+        self.vt = [V() for _ in range(10)]
+
+    # ------------------------------------------------------------------ queue models -> counted waits
+    def vm_issue(self, tag):
+        self.vmq.append(tag)
+
+    def vm_wait(self, tag):
+        if tag not in self.vmq:
+            return
+        idx = self.vmq.index(tag)
+        n = len(self.vmq) - 1 - idx
+        assert n <= 63
+        self.p.emit("s_waitcnt", vmcnt=n)
+        del self.vmq[:idx + 1]
+
+    def lg_issue(self, tag):
+        self.lgq.append(tag)
+
+    def lg_wait(self, tags=None):
+        """wait until every outstanding LDS op whose tag is in `tags` (None: all) has completed"""
+        idxs = [i for i, t in enumerate(self.lgq) if tags is None or t in tags]
+        if not idxs:
+            return
+        idx = max(idxs)
+        n = len(self.lgq) - 1 - idx
+        assert n <= 15, n
+        self.p.emit("s_waitcnt", lgkmcnt=n)
+        del self.lgq[:idx + 1]
+
+    # ------------------------------------------------------------------ small helpers
+    def kq_swz(self, dst, x, tmp):
+        """dst = kq_swz<BK>(x): BK 32: ((x>>1) ^ (x&1)) & 7; BK 16: ((x>>2) ^ ((x>>1)&1)) & 3"""
+        e = self.p.emit
+        if self.c.BK == 32:
+            e("v_lshrrev_b32", dst, 1, x)
+            e("v_and_b32", tmp, 1, x)
+            e("v_xor_b32", dst, dst, tmp)
+            e("v_and_b32", dst, 7, dst)
+        else:
+            e("v_lshrrev_b32", dst, 2, x)
+            e("v_bfe_u32", tmp, x, 1, 1)
+            e("v_xor_b32", dst, dst, tmp)
+            e("v_and_b32", dst, 3, dst)
+
+    def kq_row(self, dst, x, tmp):
+        e = self.p.emit
+        e("v_bfe_u32", tmp, x, 2, 1)
+        e("v_xor_b32", dst, x, tmp)
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self):
+        c, p = self.c, self.p
+        e = p.emit
+        t = self.vt
+        st = self.s_t
+        p.note(f"{c.name}: {c.BM}x{c.BN}x{c.BK} tile, 4 waves (one per SIMD), wave tile {c.WTM}x{c.WTN}, "
+               f"{'laser-order (kc = 512 slices)' if c.exact else 'one accumulation chain'}")
+        e("s_load_dwordx8", self.ka0, s(0, 2), KA_A)
+        e("s_load_dwordx8", self.ka1, s(0, 2), KA_LDA)
+        e("s_lshl_b32", st[0], s(2), 2)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16 (XCD-aware raster made by the host)")
+        # ---- lane decode (independent of the tile) ----
+        tid = v(0)
+        lane, lo, hi, lor, kqs = t[0], t[1], t[2], t[3], t[4]
+        e("v_and_b32", lane, 63, tid)
+        e("v_lshrrev_b32", t[5], 6, tid)
+        e("v_readfirstlane_b32", self.s_wave, t[5])
+        e("v_and_b32", lo, 31, lane)
+        e("v_lshrrev_b32", hi, 5, lane)
+        self.kq_row(lor, lo, t[5])
+        self.kq_swz(kqs, lo, t[5])
+        e("s_lshr_b32", st[2], self.s_wave, 1)
+        e("s_mul_i32", self.s_wm0, st[2], c.WTM)
+        e("s_and_b32", st[2], self.s_wave, 1)
+        e("s_mul_i32", self.s_wn0, st[2], c.WTN)
+        # fragment reads: X[g] = 16 * ((2g + hi) ^ kqs); rowA = (wm0 + lor) * BK * 4; rowB = BK*BM*4 + (wn0 + lor) * BK * 4
+        for g in range(c.NG):
+            e("v_or_b32", t[5], 2 * g, hi)
+            e("v_xor_b32", t[5], t[5], kqs)
+            e("v_lshlrev_b32", self.vX[g], 4, t[5])
+        e("v_add_u32", t[5], self.s_wm0, lor)
+        e("v_mul_u32_u24", self.v_rowA, c.BK * 4, t[5])
+        e("v_add_u32", t[5], self.s_wn0, lor)
+        e("v_mul_u32_u24", self.v_rowB, c.BK * 4, t[5])
+        e("v_add_u32", self.v_rowB, c.BK * c.BM * 4, self.v_rowB)
+        # A pieces (k-contiguous, 16 B = 4 consecutive k of row x): kq = tid % (BK/4), x = tid / (BK/4) (+ XS per piece)
+        nkq = c.BK // 4
+        kq, x, row, sw = t[0], t[1], t[2], t[3]
+        e("v_and_b32", kq, nkq - 1, tid)
+        e("v_lshrrev_b32", x, nkq.bit_length() - 1, tid)
+        self.kq_row(row, x, t[5])
+        self.kq_swz(sw, x, t[5])
+        e("v_lshrrev_b32", t[5], 1, kq)          # kq / 2
+        e("v_lshlrev_b32", t[5], 1, t[5])        # 2 * (kq / 2)
+        e("v_and_b32", t[6], 1, kq)              # kq % 2
+        e("v_mul_u32_u24", t[7], c.BK * 4, row)  # row * BK * 4
+        e("v_lshl_add_u32", t[7], t[6], 3, t[7])  # + 8 * (kq % 2)
+        for cc in range(2):
+            e("v_or_b32", t[8], cc, t[5])
+            e("v_xor_b32", t[8], t[8], sw)
+            e("v_lshl_add_u32", self.vWA[cc], t[8], 4, t[7])
+        # global offsets of the A pieces: VA_i = (x + i*XS) * lda * 4 + kq * 16
+        XS = 256 // nkq
+        e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
+        e("v_mul_lo_u32", t[7], x, st[3])
+        e("v_lshl_add_u32", self.vVA[0], kq, 4, t[7])
+        e("s_mul_i32", st[4], st[3], XS)
+        for i in range(1, c.NPA):
+            e("v_add_u32", self.vVA[i], st[4], self.vVA[i - 1])
+        # B pieces (x-contiguous, 16 B = 4 consecutive x of row k), handled in pairs (k, k+2) -- DESIGN.md 3.2 pair mode
+        aa, pp, hh, c0, xq, kb0 = t[0], t[1], t[2], t[3], t[4], t[6]
+        BX16 = c.BN // 16
+        KG = 8 * 16 // BX16
+        e("v_and_b32", aa, 3, tid)
+        e("v_bfe_u32", pp, tid, 2, 1)
+        e("v_bfe_u32", hh, tid, 3, 1)
+        e("v_lshrrev_b32", c0, 4, tid)
+        e("v_and_b32", t[5], BX16 - 1, c0)
+        e("v_lshl_add_u32", xq, t[5], 2, aa)                 # xq = (c0 % BX16) * 4 + a
+        e("v_lshrrev_b32", t[5], BX16.bit_length() - 1, c0)  # c0 / BX16
+        e("v_lshlrev_b32", t[5], 3, t[5])
+        e("v_lshl_add_u32", kb0, hh, 2, t[5])
+        e("v_add_u32", kb0, kb0, pp)                         # kb0 = 8 * (c0 / BX16) + 4h + p
+        e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
+        e("v_mul_lo_u32", t[7], kb0, st[5])
+        e("v_lshl_add_u32", self.vVB[0], xq, 4, t[7])        # VB(gi = 0, j = 0)
+        e("s_lshl_b32", st[4], st[5], 1)                     # 2 * ldb * 4
+        e("s_mul_i32", st[3], st[5], KG)                     # KG * ldb * 4
+        for gi in range(c.NPB // 2):
+            if gi:
+                e("v_add_u32", self.vVB[2 * gi], st[3], self.vVB[2 * gi - 2])
+            e("v_add_u32", self.vVB[2 * gi + 1], st[4], self.vVB[2 * gi])
+        e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
+        # LDS write addresses of the B pairs: for element e of the pieces: x = 4xq + e, row = 4xq + (e ^ (xq & 1)),
+        #   L = 2 * (k / 8) + (k & 1), word = (k % 8) >> 1;  WB = BK*BM*4 + row*BK*4 + 16 * (L ^ kq_swz(x)) + 4 * word
+        e("s_mov_b32", st[0], c.BK * c.BM * 4, comment="the B panel follows the A panel in a stage")
+        for gi in range(c.NPB // 2):
+            kk = t[7]
+            e("v_add_u32", kk, gi * KG, kb0)
+            e("v_lshrrev_b32", t[8], 3, kk)
+            e("v_lshlrev_b32", t[8], 1, t[8])
+            e("v_and_b32", t[9], 1, kk)
+            e("v_or_b32", t[8], t[8], t[9])                  # L
+            e("v_bfe_u32", t[9], kk, 1, 2)                   # word = (k & 7) >> 1  (k % 8 in {0,1,4,5} -> 0 or 2)
+            e("v_lshlrev_b32", t[9], 2, t[9])                # 4 * word
+            for ee in range(4):
+                xx, rr, ss = t[0], t[1], t[2]  # aa / pp / hh are dead from here on
+                if gi == 0 and ee == 0:
+                    pass
+                e("v_lshl_add_u32", xx, xq, 2, ee)           # x = 4xq + e
+                self.kq_row(rr, xx, t[5])
+                self.kq_swz(ss, xx, t[5])
+                e("v_xor_b32", ss, ss, t[8])                 # L ^ swz
+                e("v_mul_u32_u24", rr, c.BK * 4, rr)
+                e("v_lshl_add_u32", rr, ss, 4, rr)
+                e("v_add3_u32", self.vWB[gi][ee], rr, t[9], st[0])
+        # ---- tile coordinates, descriptors ----
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_and_b32", st[0], st[1], 0xffff)
+        e("s_lshr_b32", st[1], st[1], 16)
+        e("s_mul_i32", self.s_m0, st[0], c.BM)
+        e("s_mul_i32", self.s_n0, st[1], c.BN)
+        A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
+        # A panel: base = A + m0 * lda * 4; bytes = (min(M - m0, BM) - 1) * lda * 4 + K * 4
+        e("s_lshl_b32", st[3], self.s_lda, 2)
+        e("s_mul_hi_u32", st[2], self.s_m0, st[3])
+        e("s_mul_i32", st[0], self.s_m0, st[3])
+        e("s_add_u32", self.srdA[0], A_[0], st[0])
+        e("s_addc_u32", self.srdA[1], A_[1], st[2])
+        e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_M, self.s_m0)
+        e("s_min_u32", st[0], st[0], c.BM)
+        e("s_sub_u32", st[0], st[0], 1)
+        e("s_mul_i32", st[0], st[0], st[3])
+        e("s_lshl_b32", st[2], self.s_K, 2)
+        e("s_add_u32", self.srdA[2], st[0], st[2])
+        e("s_mov_b32", self.srdA[3], 0x00020000)
+        # B panel: base = B + n0 * 4; bytes = (K - 1) * ldb * 4 + (N - n0) * 4
+        e("s_lshl_b32", st[0], self.s_n0, 2)
+        e("s_add_u32", self.srdB[0], B_[0], st[0])
+        e("s_addc_u32", self.srdB[1], B_[1], 0)
+        e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_K, 1)
+        e("s_mul_i32", st[0], st[0], st[5])
+        e("s_sub_u32", st[2], self.s_N, self.s_n0)
+        e("s_lshl_b32", st[2], st[2], 2)
+        e("s_add_u32", self.srdB[2], st[0], st[2])
+        e("s_mov_b32", self.srdB[3], 0x00020000)
+        # C: the whole matrix, bytes = (M - 1) * ldc * 4 + N * 4
+        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
+        e("s_mov_b32", self.srdC[0], C_[0])
+        e("s_and_b32", self.srdC[1], C_[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_M, 1)
+        e("s_mul_i32", st[0], st[0], self.s_ldc4)
+        e("s_lshl_b32", st[2], self.s_N, 2)
+        e("s_add_u32", self.srdC[2], st[0], st[2])
+        e("s_mov_b32", self.srdC[3], 0x00020000)
+        e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
+        # number of K-tiles
+        e("s_lshr_b32", self.s_rem, self.s_K, (c.BK).bit_length() - 1)
+        # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
+        e("s_mov_b32", self.s_cur, 0)
+        e("s_mov_b32", self.s_nxt, 0)
+        self.issue_loads_all()
+        self.advance_srds()
+        self.write_addrs()
+        for pi in range(c.NPA):
+            self.store_A_piece(pi)
+        for gi in range(c.NPB // 2):
+            self.store_B_pair(gi)
+        self.issue_loads_all()
+        self.advance_srds()
+        e("s_mov_b32", self.s_nxt, c.STAGE)
+        # accumulators start at +0
+        for b in range(c.NB):
+            for r in range(16):
+                e("v_accvgpr_write_b32", self.acc[b][r], 0)
+                if c.exact:
+                    e("v_accvgpr_write_b32", self.run[b][r], 0)
+        self.lg_wait(None)
+        e("s_barrier")
+        self.read_group(0, self.s_cur, 0)
+        e("s_mov_b32", self.s_runlen, c.KC_TILES)
+
+    def issue_loads_all(self):
+        for pi in range(self.c.NPA):
+            self.load_A_piece(pi)
+        for pj in range(self.c.NPB):
+            self.load_B_piece(pj)
+
+    def load_A_piece(self, pi):
+        self.p.emit("buffer_load_dwordx4", self.stA[pi], self.vVA[pi], self.srdA, 0, offen=True)
+        self.vm_issue(("A", pi))
+
+    def load_B_piece(self, pj):
+        self.p.emit("buffer_load_dwordx4", self.stB[pj], self.vVB[pj], self.srdB, 0, offen=True)
+        self.vm_issue(("B", pj))
+
+    def advance_srds(self, which=None):
+        """descriptors move one K-tile along k: base += step, bytes = max(bytes - step, 0)"""
+        e = self.p.emit
+        ops = []
+        for srd, step in ((self.srdA, self.c.BK * 4), (self.srdB, self.s_bstep)):
+            ops += [("s_add_u32", srd[0], srd[0], step), ("s_addc_u32", srd[1], srd[1], 0),
+                    ("s_sub_u32", srd[2], srd[2], step), ("s_cselect_b32", srd[2], 0, srd[2])]
+        if which is None:
+            for o in ops:
+                e(*o)
+        return ops
+
+    def write_addrs(self):
+        """absolute LDS write addresses for the stage s_nxt"""
+        e = self.p.emit
+        for cc in range(2):
+            e("v_add_u32", self.vWAabs[cc], self.s_nxt, self.vWA[cc])
+        for gi in range(self.c.NPB // 2):
+            for ee in range(4):
+                e("v_add_u32", self.vWBabs[gi][ee], self.s_nxt, self.vWB[gi][ee])
+
+    def store_A_piece(self, pi, ops=None):
+        """piece = 4 consecutive k (e0 e1 e2 e3) of one row: (e0, e2) -> chunk of MFMA half 0, (e1, e3) -> half 1"""
+        out = []
+        r = self.stA[pi]
+        out.append(("vmwait", ("A", pi)))
+        out.append(("ins", "v_swap_b32", (r[1], r[2]), {}))
+        off = pi * 4096
+        out.append(("ldsw", "ds_write_b64", (self.vWAabs[0], r.sub(0, 2)), {"offset": off}))
+        out.append(("ldsw", "ds_write_b64", (self.vWAabs[1], r.sub(2, 2)), {"offset": off}))
+        if ops is None:
+            self.run_ops(out)
+        return out
+
+    def store_B_pair(self, gi, ops=None):
+        """pieces P (row k) and Q (row k + 2) of one x quad: element e of both -> adjacent words of row x = 4xq + e"""
+        out = []
+        P, Q = self.stB[2 * gi], self.stB[2 * gi + 1]
+        out.append(("vmwait", ("B", 2 * gi + 1)))
+        if self.c.b_store == "write2":
+            for ee in range(4):
+                out.append(("ldsw", "ds_write2_b32", (self.vWBabs[gi][ee], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
+        else:
+            # (P0 P1 P2 P3 Q0 Q1 Q2 Q3) -> (P0 Q0 P1 Q1 P2 Q2 P3 Q3): two 3-cycles = 4 swaps; P, Q are adjacent registers
+            assert Q.idx == P.idx + 4
+            r = [v(P.idx + k) for k in range(8)]
+            for x, y in ((1, 4), (2, 4), (3, 5), (6, 5)):
+                out.append(("ins", "v_swap_b32", (r[x], r[y]), {}))
+            for ee in range(4):
+                out.append(("ldsw", "ds_write_b64", (self.vWBabs[gi][ee], v(P.idx + 2 * ee, 2)), {}))
+        if ops is None:
+            self.run_ops(out)
+        return out
+
+    def run_ops(self, ops):
+        for o in ops:
+            self.run_op(o)
+
+    def run_op(self, o):
+        kind = o[0]
+        ab = self.c.ablate
+        if (kind == "ldsw" and "stores" in ab) or (kind == "ldsr" and "reads" in ab) or (kind in ("loadA", "loadB") and "loads" in ab):
+            return
+        if kind == "ins" and o[1] == "v_swap_b32" and "stores" in ab:
+            return
+        if kind == "barrier" and "barrier" in ab:
+            self.lg_wait(None)
+            return
+        if kind == "vmwait":
+            self.vm_wait(o[1])
+        elif kind == "lgwait":
+            self.lg_wait(o[1])
+        elif kind == "ins":
+            self.p.emit(o[1], *o[2], **o[3])
+        elif kind == "ldsw":
+            self.p.emit(o[1], *o[2], **o[3])
+            self.lg_issue(("W",))
+        elif kind == "ldsr":
+            self.p.emit(o[1], *o[2], **o[3])
+            self.lg_issue(o[4])
+        elif kind == "loadA":
+            self.load_A_piece(o[1])
+        elif kind == "loadB":
+            self.load_B_piece(o[1])
+        elif kind == "barrier":
+            self.lg_wait(None)
+            self.p.emit("s_barrier")
+        elif kind == "call":
+            o[1]()
+        else:
+            raise ValueError(kind)
+
+    def read_group_ops(self, g, stage, slot):
+        """fragment reads of group g (4 k-steps) of the tile in LDS stage `stage` into register slot `slot`"""
+        c = self.c
+        ops = [("ins", "v_add3_u32", (self.v_ra, stage, self.v_rowA, self.vX[g]), {}),
+               ("ins", "v_add3_u32", (self.v_rb, stage, self.v_rowB, self.vX[g]), {})]
+        blk = 32 * c.BK * 4
+        for i in range(c.TM):
+            ops.append(("ldsr", "ds_read_b128", (self.fa[slot][i], self.v_ra), {"offset": i * blk}, ("R", slot)))
+        for n in range(c.TN):
+            ops.append(("ldsr", "ds_read_b128", (self.fb[slot][n], self.v_rb), {"offset": n * blk}, ("R", slot)))
+        return ops
+
+    def read_group(self, g, stage, slot):
+        self.run_ops(self.read_group_ops(g, stage, slot))
+
+    # ------------------------------------------------------------------ one K-tile
+    def tile_body(self, fold):
+        c, p = self.c, self.p
+        e = p.emit
+        gaps = {m: [] for m in range(-1, c.NMF)}   # gap m: ops issued right after MFMA m (gap -1: before MFMA 0)
+
+        def put(m, op):
+            gaps[min(max(m, -1), c.NMF - 1)].append(op)
+
+        first_free = 0
+        if fold:
+            first_free = c.NB + 1   # gaps 0..NB-1 carry the slice fold
+        # fragment reads: group g+1 (or group 0 of the next tile) during group g
+        for g in range(c.NG):
+            nxt_tile = (g + 1 == c.NG)
+            ops = self.read_group_ops(0 if nxt_tile else g + 1, self.s_nxt if nxt_tile else self.s_cur, (g + 1) & 1)
+            base = g * c.GM + 1
+            if nxt_tile:
+                base = max(base, c.bar_gap + 1)
+            if fold and g == 0:
+                base = first_free
+            for k, op in enumerate(ops):
+                put(base + k * c.r_step, op)
+            # the group's fragments must have landed before its first MFMA (the next tile's first group: top of the body)
+            if not nxt_tile:
+                put((g + 1) * c.GM - 1, ("lgwait", {("R", (g + 1) & 1)}))
+        # staging: LDS stores of tile t+1 (from registers), then the HBM loads of tile t+2 into the drained registers
+        stg = []
+        stg.append(("call", self.write_addrs))
+        for pi in range(c.NPA):
+            stg += self.store_A_piece(pi, ops=[])
+            stg.append(("loadA", pi))
+        for gi in range(c.NPB // 2):
+            stg += self.store_B_pair(gi, ops=[])
+            stg.append(("loadB", 2 * gi))
+            stg.append(("loadB", 2 * gi + 1))
+        # waits ride with the op that follows them
+        units = []
+        for op in stg:
+            if units and units[-1][-1][0] in ("vmwait",):
+                units[-1].append(op)
+            else:
+                units.append([op])
+        w0 = max(c.w_start, first_free + (c.TM + c.TN + 2 if fold else 0))
+        span = c.bar_gap - 1 - w0
+        step = c.w_step or max(1.0, span / max(1, len(units)))
+        for k, u in enumerate(units):
+            m = int(w0 + k * step)
+            assert m < c.bar_gap, "staging does not fit before the barrier"
+            for op in u:
+                put(m, op)
+        put(c.bar_gap, ("barrier",))
+        # scalar bookkeeping after the last load of the tile
+        tail = c.bar_gap + 2
+        for k, o in enumerate(self.advance_srds(which="ops")):
+            put(tail + k, ("ins", o[0], o[1:], {}))
+
+        def rotate():
+            e("s_mov_b32", self.s_cur, self.s_nxt)
+            e("s_add_u32", self.s_nxt, self.s_nxt, c.STAGE)
+            e("s_cmp_eq_u32", self.s_nxt, 3 * c.STAGE)
+            e("s_cselect_b32", self.s_nxt, 0, self.s_nxt)
+        put(c.NMF - 2, ("call", rotate))
+
+        # ---- emit ----
+        # the first group's fragments were requested during the previous tile
+        self.lg_wait({("R", 0)})
+        m = 0
+        for g in range(c.NG):
+            slot = g & 1
+            for u in range(4):
+                for i in range(c.TM):
+                    for n in range(c.TN):
+                        b = i * c.TN + n
+                        srcc = self.acc[b]
+                        if fold and g == 0 and u == 0:
+                            # Laser's pc loop (gemm.nim:150-158): the finished slice sum leaves the accumulator (16 reads in
+                            # the shadow of the previous MFMA), this MFMA starts the next chain from a literal +0, and
+                            # run += slice rides behind it
+                            T = self.vT[b & 1]
+                            for r in range(16):
+                                e("v_accvgpr_read_b32", T[r], self.acc[b][r])
+                            srcc = 0
+                        e("v_mfma_f32_32x32x2_f32", self.acc[b], self.fa[slot][i][u], self.fb[slot][n][u], srcc)
+                        if fold and g == 0 and u == 0:
+                            T = self.vT[b & 1]
+                            for r in range(16):
+                                tt = self.vt[r % 4]
+                                e("v_accvgpr_read_b32", tt, self.run[b][r])
+                                e("v_add_f32", tt, tt, T[r])
+                                e("v_accvgpr_write_b32", self.run[b][r], tt)
+                        for op in gaps[m]:
+                            self.run_op(op)
+                        m += 1
+        assert m == c.NMF
+
+    # ------------------------------------------------------------------ main loop + epilogue
+    def main_loop(self):
+        c, p = self.c, self.p
+        e = p.emit
+        L_outer, L_norm, L_check, L_done = p.label("outer"), p.label("tile"), p.label("check"), p.label("done")
+        state0 = (list(self.vmq), list(self.lgq))
+        if not c.exact:
+            e("s_mov_b32", self.s_cnt, self.s_rem)
+            e("raw", ".p2align 6")
+            p.place(L_norm)
+            self.tile_body(False)
+            assert (self.vmq, self.lgq) == (state0[0], state0[1]), "loop-carried queue state differs"
+            e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
+            e("s_cmp_lg_u32", self.s_cnt, 0)
+            e("s_cbranch_scc1", L_norm)
+            return
+        p.place(L_outer)
+        e("s_min_u32", self.s_cnt, self.s_runlen, self.s_rem)
+        e("s_sub_u32", self.s_rem, self.s_rem, self.s_cnt)
+        e("s_cmp_eq_u32", self.s_cnt, 0)
+        e("s_cbranch_scc1", L_check)
+        e("raw", ".p2align 6")
+        p.place(L_norm)
+        self.tile_body(False)
+        assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs"
+        e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
+        e("s_cmp_lg_u32", self.s_cnt, 0)
+        e("s_cbranch_scc1", L_norm)
+        p.place(L_check)
+        e("s_cmp_eq_u32", self.s_rem, 0)
+        e("s_cbranch_scc1", L_done)
+        self.tile_body(True)
+        assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs (fold tile)"
+        e("s_sub_u32", self.s_rem, self.s_rem, 1)
+        e("s_mov_b32", self.s_runlen, c.KC_TILES - 1)
+        e("s_branch", L_outer)
+        p.place(L_done)
+
+    def epilogue(self):
+        """C = run + acc (alpha == 1, beta == 0: gemm_ukernel_generic.nim:53-76), predicated by the descriptor's bounds check"""
+        c, p = self.c, self.p
+        e = p.emit
+        t = self.vt
+        st = self.s_t
+        e("s_nop", 15)
+        e("s_nop", 7)
+        # drain what the loop left in flight (prefetched tile beyond K: never used)
+        e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        self.vmq.clear()
+        self.lgq.clear()
+        tid = v(0)
+        lane, lo, hi = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, tid)
+        e("v_and_b32", lo, 31, lane)
+        e("v_lshrrev_b32", hi, 5, lane)
+        # row = m0 + wm0 + 4 * hi (+ 32 i + 8 q + rr); col = n0 + wn0 + lo (+ 32 n)
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("v_lshl_add_u32", t[3], hi, 2, st[0])
+        e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], lo)              # col of block n = 0
+        e("v_lshl_add_u32", t[3], t[4], 2, t[3])     # byte offset of (row, col)
+        for n in range(c.TN):
+            # columns beyond N: an offset the bounds check always rejects (C is kept under 2 GB by the launcher)
+            e("v_add_u32", t[5], 32 * n, t[4])
+            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
+            e("v_add_u32", t[6], 128 * n, t[3])
+            e("v_mov_b32", t[7], 0x80000000)
+            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+        for i in range(c.TM):
+            for q in range(4):
+                for rr in range(4):
+                    r = 4 * q + rr
+                    for n in range(c.TN):
+                        b = i * c.TN + n
+                        tt = t[(2 * n) % 8]
+                        e("v_accvgpr_read_b32", tt, self.acc[b][r])
+                        if c.exact:
+                            uu = t[(2 * n + 1) % 8]
+                            e("v_accvgpr_read_b32", uu, self.run[b][r])
+                            e("v_add_f32", tt, uu, tt)
+                        e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
+                    last = (i == c.TM - 1 and q == 3 and rr == 3)
+                    if not last:
+                        step = self.s_ldc4 if rr < 3 else self.s_ldc20
+                        for n in range(c.TN):
+                            e("v_add_u32", self.vC[n], step, self.vC[n])
+        e("s_endpgm")
+
+    def build(self):
+        self.prologue()
+        self.main_loop()
+        self.epilogue()
+        return self.p
+
+
+def make(name, **over):
+    kw = dict(CONFIGS[name])
+    kw.update(over)
+    return Gen(Cfg(name, **kw))
+
+
+def kernel_text(gen, symbol):
+    """complete .s file: code + kernel descriptor + code-object metadata"""
+    c = gen.c
+    body = gen.p.text()
+    nv = 256
+    return f"""\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.text
+\t.globl\t{symbol}
+\t.p2align\t8
+\t.type\t{symbol},@function
+{symbol}:
+{body}.Lfunc_end_{symbol}:
+\t.size\t{symbol}, .Lfunc_end_{symbol}-{symbol}
+\t.rodata
+\t.p2align\t6
+\t.amdhsa_kernel {symbol}
+\t\t.amdhsa_group_segment_fixed_size {c.lds_bytes}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size {KERNARG_SIZE}
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 1
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_sgpr 100
+\t\t.amdhsa_accum_offset {nv}
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+\t.amdgpu_metadata
+---
+amdhsa.version: [1, 2]
+amdhsa.target: amdgcn-amd-amdhsa--gfx950
+amdhsa.kernels:
+  - .name: {symbol}
+    .symbol: {symbol}.kd
+    .kernarg_segment_size: {KERNARG_SIZE}
+    .kernarg_segment_align: 8
+    .group_segment_fixed_size: {c.lds_bytes}
+    .private_segment_fixed_size: 0
+    .wavefront_size: 64
+    .sgpr_count: 100
+    .vgpr_count: {nv}
+    .agpr_count: 256
+    .max_flat_workgroup_size: 256
+    .args:
+      - {{.size: 8, .offset: 0, .value_kind: global_buffer, .address_space: global}}
+      - {{.size: 8, .offset: 8, .value_kind: global_buffer, .address_space: global}}
+      - {{.size: 8, .offset: 16, .value_kind: global_buffer, .address_space: global}}
+      - {{.size: 8, .offset: 24, .value_kind: global_buffer, .address_space: global}}
+      - {{.size: 4, .offset: 32, .value_kind: by_value}}
+      - {{.size: 4, .offset: 36, .value_kind: by_value}}
+      - {{.size: 4, .offset: 40, .value_kind: by_value}}
+      - {{.size: 4, .offset: 44, .value_kind: by_value}}
+      - {{.size: 4, .offset: 48, .value_kind: by_value}}
+      - {{.size: 4, .offset: 52, .value_kind: by_value}}
+      - {{.size: 8, .offset: 56, .value_kind: by_value}}
+      - {{.size: 8, .offset: 64, .value_kind: global_buffer, .address_space: global}}
+...
+\t.end_amdgpu_metadata
+"""
+
+
+if __name__ == "__main__":
+    import argparse
+    import os
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for name in CONFIGS:
+        g = make(name)
+        g.build()
+        sym = "lh_f32_" + name
+        with open(os.path.join(args.out, sym + ".s"), "w") as f:
+            f.write(kernel_text(g, sym))
+        print(sym, len(g.p.ins), "instructions")

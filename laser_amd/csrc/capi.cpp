@@ -345,8 +345,9 @@ hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s) {
     const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
-  if (g_ctx.f32_cfg < 0 && g_f32_dma) {  // (experiment, off by default) row-major operands in whole 256x128x32 tiles: the LDS-DMA kernel
-    const hipError_t e = launch_gemm_f32_dma(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+  g_last_f32_asm = 0;
+  if (g_ctx.f32_cfg < 0) {  // large row-major-like products: the hand-scheduled assembly kernels (one wave per SIMD)
+    const hipError_t e = launch_gemm_f32_asm(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
     if (e != hipErrorNotSupported) return e;
   }
   return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
@@ -1252,10 +1253,11 @@ int laser_hip_set_host_pipeline(int mode) {  // A/B knob: bit 0 = 2-D (row x col
   g_ctx.zc_poll = (mode & 2) == 0;
   return LASER_HIP_OK;
 }
-int laser_hip_set_f32_dma(int on) {  // A/B knob: 1 = float32 row-major whole-tile problems on the LDS-DMA kernel, 0 = register-staged kernels (default)
-  g_f32_dma = on != 0;
+int laser_hip_set_f32_asm(int on) {  // 1 (default) = hand-scheduled assembly kernels where they apply, 0 = never, 2 = whenever eligible (tests)
+  g_f32_asm = on;
   return LASER_HIP_OK;
 }
+int laser_hip_last_f32_asm(void) { return g_last_f32_asm; }
 int laser_hip_set_conv_kslice(int on) {  // A/B knob: laser-order conv tail as parallel kc slices + ordered combine (1) or one launch (0)
   g_conv_kslice = on != 0;
   return LASER_HIP_OK;

@@ -1,0 +1,161 @@
+// laser_amd/csrc/gemm_f32_asm.cpp -- host side of the hand-scheduled fp32 GEMM kernels (gfx950 assembly emitted by
+// laser_amd/asmgen/f32_kernel.py, assembled at build time, carried in this library as a code object and loaded with
+// hipModuleLoadData).  One workgroup = one tile of C, 4 waves = one wave per SIMD with the accumulators in AGPRs -- the
+// register-level design of the reference's generated micro-kernels (gemm_ukernel_generator.nim:140-250) with the loop
+// nest of gemm.nim:109-176 around it.  The workgroup -> tile map (the ic / jr partition of gemm.nim:160-176) is a
+// table made here: XCD-aware, grouped raster, so neighbouring workgroups of an XCD share operand panels in its L2.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+#include "f32_asm_blob.h"  // generated: lh_f32_asm_hsaco[], lh_f32_asm_hsaco_len
+
+namespace laser_hip {
+
+std::atomic<int> g_f32_asm{1};       // 1 (default): eligible problems run on the hand-scheduled kernels
+std::atomic<int> g_last_f32_asm{0};  // diagnostics: the last f32 GEMM launch used them (1 laser-order kernel, 2 fast kernel)
+
+namespace {
+
+struct KernelInfo {
+  const char *symbol;
+  int bm, bn, bk;
+};
+const KernelInfo kExact = {"lh_f32_exact_256x128x32", 256, 128, 32};
+const KernelInfo kFast = {"lh_f32_fast_256x256x16", 256, 256, 16};
+
+struct DeviceModule {
+  hipModule_t mod = nullptr;
+  hipFunction_t exact = nullptr, fast = nullptr;
+  // tile tables by (tiles_m, tiles_n, group_m); entries live until the process ends
+  std::map<std::tuple<int, int, int>, std::pair<uint32_t *, std::vector<uint32_t> *>> tables;
+};
+constexpr int kMaxDev = 16;
+DeviceModule g_mods[kMaxDev];
+std::mutex g_mods_mu;
+
+struct KernArgs {
+  const float *A, *B;
+  float *C;
+  const uint32_t *table;
+  uint32_t lda, ldb, ldc, M, N, K;
+  uint64_t reserved;
+  void *dbg;
+};
+static_assert(sizeof(KernArgs) == 72, "kernel argument block layout (f32_kernel.py KA_*)");
+
+// blockIdx -> tile: block b runs on XCD b % 8; give every XCD a contiguous chunk of tile ids (bijective for any grid),
+// then walk the tiles in groups of group_m tile rows so the ~32 workgroups resident on an XCD form a compact patch.
+void make_table(int tiles_m, int tiles_n, int group_m, std::vector<uint32_t> &out) {
+  const int nwg = tiles_m * tiles_n;
+  out.resize((size_t)nwg);
+  for (int bid = 0; bid < nwg; bid++) {
+    const int xcd = bid % 8, loc = bid / 8, q = nwg / 8, r = nwg % 8;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int width = group_m * tiles_n;
+    const int group = wgid / width;
+    const int first_m = group * group_m;
+    const int gsz = std::min(tiles_m - first_m, group_m);
+    const int pid_m = first_m + (wgid % width) % gsz;
+    const int pid_n = (wgid % width) / gsz;
+    out[(size_t)bid] = (uint32_t)pid_m | ((uint32_t)pid_n << 16);
+  }
+}
+
+hipError_t get_module(int dev, DeviceModule **out) {
+  if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+  DeviceModule &m = g_mods[dev];
+  if (!m.mod) {
+    hipError_t e = hipModuleLoadData(&m.mod, lh_f32_asm_hsaco);
+    if (e != hipSuccess) return e;
+    e = hipModuleGetFunction(&m.exact, m.mod, kExact.symbol);
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.fast, m.mod, kFast.symbol);
+    if (e != hipSuccess) {
+      (void)hipModuleUnload(m.mod);
+      m.mod = nullptr;
+      return e;
+    }
+  }
+  *out = &m;
+  return hipSuccess;
+}
+
+}  // namespace
+
+// hipErrorNotSupported: not this kernel's class of problem -- the caller takes the compiler-scheduled kernels
+hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
+  if (!g_f32_asm) return hipErrorNotSupported;
+  if (a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
+  if (a.csA != 1 || a.csB != 1 || a.csC != 1) return hipErrorNotSupported;
+  if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
+  if (a.rsA < a.K || a.rsB < a.N || a.rsC < a.N) return hipErrorNotSupported;
+  // laser-order results need the kc = 512 slices only when K > 512; one chain otherwise (either kernel is exact then)
+  const bool exact = laser_order && a.K > 512;
+  const KernelInfo &ki = exact ? kExact : (a.K > 512 ? kFast : kExact);
+  const bool use_exact_kernel = (&ki == &kExact);
+  if (a.K < ki.bk || a.K % ki.bk != 0) return hipErrorNotSupported;
+  // 32-bit byte offsets inside the descriptors
+  if ((double)a.rsA * 4.0 * ki.bm >= 4.0e9 || (double)a.K * (double)a.rsB * 4.0 >= 4.0e9) return hipErrorNotSupported;
+  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0) return hipErrorNotSupported;
+  if (a.M > 0xffff * (int64_t)ki.bm || a.N > 0xffff * (int64_t)ki.bn) return hipErrorNotSupported;
+  const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  // one workgroup per CU: worth it from one full round of the chip on, with a well-filled last round
+  const int64_t rounds = (tiles + 255) / 256;
+  if (g_f32_asm < 2 && (tiles < 224 || (double)tiles / (double)(rounds * 256) < 0.80)) return hipErrorNotSupported;
+
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(g_mods_mu);
+  DeviceModule *m = nullptr;
+  e = get_module(dev, &m);
+  if (e != hipSuccess) return e;
+  const int group_m = (ki.bm >= 2 * ki.bn) ? 4 : 8;
+  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
+  auto it = m->tables.find(key);
+  if (it == m->tables.end()) {
+    auto *host = new std::vector<uint32_t>();
+    make_table(tiles_m, tiles_n, group_m, *host);
+    uint32_t *devp = nullptr;
+    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
+    if (e != hipSuccess) {
+      delete host;
+      return e;
+    }
+    // stream-ordered ahead of the launch; the host copy stays alive with the cache entry
+    e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      (void)hipFree(devp);
+      delete host;
+      return e;
+    }
+    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
+  }
+  KernArgs ka;
+  ka.A = a.A;
+  ka.B = a.B;
+  ka.C = a.C;
+  ka.table = it->second.first;
+  ka.lda = (uint32_t)a.rsA;
+  ka.ldb = (uint32_t)a.rsB;
+  ka.ldc = (uint32_t)a.rsC;
+  ka.M = (uint32_t)a.M;
+  ka.N = (uint32_t)a.N;
+  ka.K = (uint32_t)a.K;
+  ka.reserved = 0;
+  ka.dbg = nullptr;
+  size_t sz = sizeof(ka);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(use_exact_kernel ? m->exact : m->fast, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  if (e == hipSuccess) g_last_f32_asm = use_exact_kernel ? 1 : 2;
+  return e;
+}
+
+}  // namespace laser_hip

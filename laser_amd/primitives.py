@@ -100,9 +100,15 @@ def set_f64_mfma(on):
     _lib.check(_lib.lib().laser_hip_set_f64_mfma(1 if on else 0))
 
 
-def set_f32_dma(on):
-    """True: float32 row-major whole-tile problems run the experimental LDS-DMA kernel; False (default): the register-staged kernels."""
-    _lib.check(_lib.lib().laser_hip_set_f32_dma(1 if on else 0))
+def set_f32_asm(mode):
+    """1 (default): eligible float32 problems that fill the chip run the hand-scheduled assembly kernels; 0: never;
+    2: whenever eligible, whatever the tile count (tests)."""
+    _lib.check(_lib.lib().laser_hip_set_f32_asm(int(mode)))
+
+
+def last_f32_asm():
+    """0: the last float32 GEMM launch was a compiler-scheduled kernel; 1 / 2: the laser-order / fast assembly kernel."""
+    return int(_lib.lib().laser_hip_last_f32_asm())
 
 
 def set_i32_mfma(on):

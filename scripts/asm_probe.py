@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Schedule sweep of the hand-scheduled fp32 kernels (laser_amd/asmgen/f32_kernel.py): every variant is generated,
+assembled and loaded as its own code object, checked against torch.matmul (unless it is an ablation) and timed at
+8192^3 in interleaved rounds.  Writes one JSON line per variant (profiles/r03/asm_probe_*.jsonl are copies of that).
+
+usage: asm_probe.py [variants.json] [--n 8192] [--out file.jsonl]
+variants.json: [{"name": "...", "kernel": "exact_256x128x32", "over": {"bar_gap": 63}}, ...]"""
+import ctypes as C
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from laser_amd.asmgen import f32_kernel as K  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+LLD = "/opt/rocm/lib/llvm/bin/ld.lld"
+hip = C.CDLL("libamdhip64.so")
+hip.hipModuleLoad.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
+hip.hipModuleGetFunction.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_char_p]
+hip.hipModuleLaunchKernel.argtypes = [C.c_void_p] + [C.c_uint] * 6 + [C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def make_table(tiles_m, tiles_n, group_m):
+    nwg = tiles_m * tiles_n
+    out = []
+    for bid in range(nwg):
+        xcd, loc, q, r = bid % 8, bid // 8, nwg // 8, nwg % 8
+        wgid = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + loc
+        width = group_m * tiles_n
+        group = wgid // width
+        first_m = group * group_m
+        gsz = min(tiles_m - first_m, group_m)
+        out.append((first_m + (wgid % width) % gsz) | (((wgid % width) // gsz) << 16))
+    return out
+
+
+def build(var, tmp):
+    g = K.make(var["kernel"], **var.get("over", {}))
+    g.build()
+    sym = "lh_probe"
+    spath = os.path.join(tmp, var["name"] + ".s")
+    open(spath, "w").write(K.kernel_text(g, sym))
+    subprocess.check_call([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", spath, "-o", spath + ".o"])
+    subprocess.check_call([LLD, "-shared", spath + ".o", "-o", spath + ".hsaco"])
+    mod, fn = C.c_void_p(), C.c_void_p()
+    assert hip.hipModuleLoad(C.byref(mod), (spath + ".hsaco").encode()) == 0
+    assert hip.hipModuleGetFunction(C.byref(fn), mod, sym.encode()) == 0
+    return g.c, fn
+
+
+def main():
+    args = sys.argv[1:]
+    n = 8192
+    out = None
+    if "--n" in args:
+        n = int(args[args.index("--n") + 1])
+    if "--out" in args:
+        out = args[args.index("--out") + 1]
+    files = [a for a in args if a.endswith(".json")]
+    variants = json.load(open(files[0])) if files else [
+        {"name": "exact_base", "kernel": "exact_256x128x32"},
+        {"name": "fast_base", "kernel": "fast_256x256x16"},
+    ]
+    torch.manual_seed(0)
+    A = (torch.rand((n, n), device="cuda") - 0.5) * 0.2
+    B = (torch.rand((n, n), device="cuda") - 0.5) * 0.2
+    Cm = torch.zeros((n, n), device="cuda")
+    ref = None
+    st = torch.cuda.current_stream().cuda_stream
+    tmp = tempfile.mkdtemp()
+    built = []
+    tables = {}
+    for var in variants:
+        cfg, fn = build(var, tmp)
+        tm, tn = (n + cfg.BM - 1) // cfg.BM, (n + cfg.BN - 1) // cfg.BN
+        gm = 4 if cfg.BM >= 2 * cfg.BN else 8
+        key = (tm, tn, gm)
+        if key not in tables:
+            tables[key] = torch.tensor(make_table(tm, tn, gm), dtype=torch.int32, device="cuda")
+        ka = struct.pack("<QQQQIIIIIIQQ", A.data_ptr(), B.data_ptr(), Cm.data_ptr(), tables[key].data_ptr(), n, n, n, n, n, n, 0, 0)
+        buf = C.create_string_buffer(ka, len(ka))
+        size = C.c_size_t(len(ka))
+        extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)
+        built.append((var, cfg, fn, tm * tn, buf, size, extra))
+
+    def launch(b):
+        rc = hip.hipModuleLaunchKernel(b[2], b[3], 1, 1, 256, 1, 1, 0, st, None, b[6])
+        assert rc == 0, rc
+
+    res = {b[0]["name"]: [] for b in built}
+    err = {}
+    for b in built:
+        Cm.zero_()
+        launch(b)
+        torch.cuda.synchronize()
+        if not b[0].get("over", {}).get("ablate"):
+            if ref is None:
+                ref = A @ B
+            err[b[0]["name"]] = float(((Cm - ref).abs().max() / ref.abs().max()).item())
+    for r in range(6):
+        for b in built:
+            launch(b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                launch(b)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                res[b[0]["name"]].append(e0.elapsed_time(e1) / 4)
+    lines = []
+    for b in built:
+        v_ = sorted(res[b[0]["name"]])
+        med = v_[len(v_) // 2]
+        line = {"variant": b[0]["name"], "kernel": b[0]["kernel"], "over": b[0].get("over", {}), "n": n, "ms_median": round(med, 4),
+                "ms_min": round(v_[0], 4), "tflops": round(2.0 * n ** 3 / med / 1e9, 1), "frac_mfma_peak": round(2.0 * n ** 3 / med / 1e9 / 157.3, 4),
+                "max_rel_err_vs_torch": err.get(b[0]["name"])}
+        print(json.dumps(line), flush=True)
+        lines.append(line)
+    if out:
+        with open(out, "w") as f:
+            for ln in lines:
+                f.write(json.dumps(ln) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -651,52 +651,58 @@ def test_full_size_conv_c4_every_image(la, oracle):
     assert cut > 0 and cut % 128 == 0, "C4 (1600 tiles of 128x128 = 3.1 rounds) is expected to run as main + tail"
 
 
-def test_f32_dma_kernel_bit_exact(la, oracle):
-    """The experimental LDS-DMA float32 kernel (laser_hip_set_f32_dma(1); row-major A and B in whole 256x128x32 tiles): same bits as the register-staged kernels (knob
-    off) in both accumulation modes, and as the oracle in laser-order mode -- K with a ragged last kc slice and with a slice
-    boundary in the last two tiles, alpha / beta, padded leading dimensions, a strided C, a batch."""
+def test_f32_asm_kernels_bit_exact(la, oracle):
+    """The hand-scheduled assembly kernels (laser_amd/asmgen/f32_kernel.py; laser_hip_set_f32_asm): same bits as the
+    compiler-scheduled kernels (knob 0) in both accumulation modes, and as the oracle in laser-order mode -- K with a ragged last
+    kc slice, a fold tile as the very last tile, a single slice, ragged M / N (predicated by the descriptors' bounds
+    checks), padded leading dimensions on all three operands; ineligible calls (alpha / beta, a strided C) fall through."""
     import torch
     rng = np.random.default_rng(41)
     took = 0
-    for (M, N, K) in [(4096, 4096, 1024), (2048, 8192, 1568), (8192, 2048, 1056), (4096, 4096, 2080)]:
+    shapes = [(4096, 4096, 1024), (2048, 8192, 1568), (8192, 2048, 1056), (4096, 4096, 544), (1000, 900, 2080), (256, 128, 512),
+              (300, 260, 32), (2048, 2048, 96)]
+    for (M, N, K) in shapes:
         A = rand(rng, (M, K + 8), np.float32)[:, :K]          # leading dimension K + 8
         B = rand(rng, (K, N + 12), np.float32)[:, :N]
         dAb = torch.from_numpy(np.ascontiguousarray(A.base)).cuda(); dA = dAb[:, :K]
         dBb = torch.from_numpy(np.ascontiguousarray(B.base)).cuda(); dB = dBb[:, :N]
-        C0 = rand(rng, (M, N), np.float32)
+        wide = torch.full((M, N + 20), 7.0, device="cuda")
         for mode in (0, 1):
-            for alpha, beta in ((1, 0), (0.5, 0.25)):
-                la.set_float_mode(mode)
-                try:
-                    la.set_f32_dma(True)
-                    dC = torch.from_numpy(C0.copy()).cuda()
-                    la.matmul(dA, dB, alpha, beta, dC)
-                    la.set_f32_dma(False)
-                    dC2 = torch.from_numpy(C0.copy()).cuda()
-                    la.matmul(dA, dB, alpha, beta, dC2)
-                finally:
-                    la.set_f32_dma(False); la.set_float_mode(0)
-                assert torch.equal(dC, dC2), (M, N, K, mode, alpha, beta)
-                if mode == 0 and (alpha, beta) == (1, 0):
-                    assert np.array_equal(dC.cpu().numpy(), oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B))), (M, N, K)
+            la.set_float_mode(mode)
+            try:
+                la.set_f32_asm(2)
+                dC = wide.clone()
+                la.matmul(dA, dB, 1, 0, dC[:, :N])
+                used = la.last_f32_asm()
+                la.set_f32_asm(0)
+                dC2 = wide.clone()
+                la.matmul(dA, dB, 1, 0, dC2[:, :N])
+                assert la.last_f32_asm() == 0
+            finally:
+                la.set_f32_asm(1); la.set_float_mode(0)
+            assert used == (1 if (mode == 0 or K <= 512) else 2), (M, N, K, mode, used)
+            assert torch.equal(dC, dC2), (M, N, K, mode)
+            assert (dC[:, N:] == 7.0).all(), "wrote outside C"
+            if mode == 0:
+                assert np.array_equal(dC[:, :N].cpu().numpy(), oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B))), (M, N, K)
         took += 1
-    # strided C (every second column of a wider buffer) and a batch of two problems sharing B
-    M, N, K = 2048, 4096, 1024
-    A = torch.from_numpy(rand(rng, (2, M, K), np.float32)).cuda()
+    # not this kernel's class: alpha / beta, a strided C -> the compiler-scheduled kernels, same results as ever
+    M, N, K = 2048, 2048, 1024
+    A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
     B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
-    wide = torch.full((2, M, 2 * N), 9.0, device="cuda")
-    ref = torch.stack([la.matmul(A[b], B) for b in range(2)])          # register-staged kernels
+    C0 = torch.from_numpy(rand(rng, (M, N), np.float32)).cuda()
     try:
-        la.set_f32_dma(True)
-        for b in range(2):
-            la.matmul(A[b], B, 1, 0, wide[b][:, ::2])
-        Cb = torch.zeros((2, M, N), device="cuda")
-        la.gemm_strided_batched(2, M, N, K, 1.0, A, K, 1, M * K, B, N, 1, 0, 0.0, Cb, N, 1, M * N)
+        la.set_f32_asm(2)
+        c1 = C0.clone(); la.matmul(A, B, 0.5, 0.25, c1)
+        assert la.last_f32_asm() == 0
+        w = torch.full((M, 2 * N), 9.0, device="cuda"); la.matmul(A, B, 1, 0, w[:, ::2])
+        assert la.last_f32_asm() == 0
+        ref = la.matmul(A, B)
+        assert la.last_f32_asm() == 1
     finally:
-        la.set_f32_dma(False)
-    assert torch.equal(wide[:, :, ::2], ref) and (wide[:, :, 1::2] == 9.0).all()
-    assert torch.equal(Cb, ref)
-    assert took == 4
+        la.set_f32_asm(1)
+    assert torch.equal(w[:, ::2], ref) and (w[:, 1::2] == 9.0).all()
+    assert took == len(shapes)
 
 
 def test_ragged_by_a_few_rows_columns_peeled_bit_exact(la, oracle):

@@ -135,14 +135,14 @@ def _b128_extra_cycles(addr_of_lane):
 
 
 def test_dma_fed_lds_layouts_are_bank_conflict_free_in_the_model():
-    """The two layouts filled by LDS-DMA, replayed against the same bank rules: the int64 limb kernel's 32-byte plane rows
-    (chunk c of row r at slot c ^ ((r>>3)&1), gemm_i64_mfma.hip) and the experimental f32 kernel's 128-byte A rows (chunk c
-    of row x at slot c ^ ((x>>1)&7), gemm_f32_dma.hip).  Without their swizzles both patterns collide."""
+    """The layouts filled by LDS-DMA, replayed against the same bank rules: the int64 limb kernel's 32-byte plane rows
+    (chunk c of row r at slot c ^ ((r>>3)&1), gemm_i64_mfma.hip), a 128-byte-row image (chunk c of row x at slot
+    c ^ ((x>>1)&7)) and the int32 limb planes.  Without their swizzles the patterns collide."""
     # int64 limb planes: lane (lo = l%32, hi = l//32) reads chunk hi of row lo
     swz = lambda l: (l % 32) * 32 + 16 * ((l // 32) ^ (((l % 32) >> 3) & 1))
     raw = lambda l: (l % 32) * 32 + 16 * (l // 32)
     assert _b128_extra_cycles(swz) == 0 and _b128_extra_cycles(raw) > 0
-    # f32 DMA kernel, A rows of 128 bytes: every lane of a group reads logical chunk c of its row
+    # rows of 128 bytes: every lane of a group reads logical chunk c of its row
     for c in range(8):
         swz = lambda l, c=c: (l % 32) * 128 + 16 * (c ^ (((l % 32) >> 1) & 7))
         raw = lambda l, c=c: (l % 32) * 128 + 16 * c
