@@ -20,7 +20,7 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF
 
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
-                 b_store="write2", ablate=(), r_step=1):
+                 b_store="write2", ablate=(), r_step=1, debug=False):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
         self.WTM, self.WTN = BM // 2, BN // 2
         self.TM, self.TN = self.WTM // 32, self.WTN // 32
@@ -40,6 +40,7 @@ class Cfg:
         self.b_store = b_store      # "write2": ds_write2_b32 straight from the two pieces; "swap64": 4 v_swap + 4 ds_write_b64
         self.ablate = set(ablate)   # timing experiments only (results are wrong): "loads", "stores", "reads", "barrier"
         self.r_step = r_step
+        self.debug = debug          # dump intermediate state of workgroup 0 to the kernarg's debug buffer (asm_debug.py)
         self.lds_bytes = 3 * self.STAGE
         assert self.lds_bytes <= 160 * 1024
 
@@ -97,6 +98,11 @@ class Gen:
         self.vVA = [V() for _ in range(c.NPA)]
         self.vVB = [V() for _ in range(c.NPB)]
         self.vC = [V() for _ in range(c.TN)]
+        self.srdD = S(4)
+        self.s_dslot = S()
+        self.v_dbg = V()
+        self.ndump = 0
+        self.dump_names = []
         self.vT = [V(16), V(16)]
         self.vt = [V() for _ in range(10)]
 
@@ -147,6 +153,37 @@ class Gen:
         e("v_bfe_u32", tmp, x, 2, 1)
         e("v_xor_b32", dst, x, tmp)
 
+    def dump(self, name, reg):
+        """debug builds: workgroup 0 stores `reg` of every lane to slot `ndump` of the debug buffer (slot = 256 dwords)"""
+        if not self.c.debug:
+            return
+        e = self.p.emit
+        skip = self.p.label("nodump")
+        e("s_cmp_lg_u32", s(2), 0)
+        e("s_cbranch_scc1", skip)
+        src = reg
+        if isinstance(reg, Reg) and reg.kind == "s":
+            e("v_mov_b32", self.vt[9], reg)
+            src = self.vt[9]
+        elif isinstance(reg, Reg) and reg.kind == "a":
+            e("v_accvgpr_read_b32", self.vt[9], reg)
+            src = self.vt[9]
+        e("s_mov_b32", self.s_dslot, self.ndump * 1024)
+        e("buffer_store_dword", src, self.v_dbg, self.srdD, self.s_dslot, offen=True)
+        self.p.place(skip)
+        self.dump_names.append(name)
+        self.ndump += 1
+
+    def dump_lds(self, name, byte_off):
+        """debug: every lane reads LDS dword byte_off + 4*tid and dumps it"""
+        if not self.c.debug:
+            return
+        e = self.p.emit
+        e("v_add_u32", self.vt[8], byte_off, self.v_dbg)
+        e("ds_read_b32", self.vt[8], self.vt[8])
+        e("s_waitcnt", lgkmcnt=0)
+        self.dump(name, self.vt[8])
+
     # ------------------------------------------------------------------ prologue
     def prologue(self):
         c, p = self.c, self.p
@@ -160,12 +197,26 @@ class Gen:
         e("s_lshl_b32", st[0], s(2), 2)
         e("s_waitcnt", lgkmcnt=0)
         e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16 (XCD-aware raster made by the host)")
+        if c.debug:
+            e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_and_b32", self.srdD[1], self.srdD[1], 0xffff)
+            e("s_mov_b32", self.srdD[2], 0x10000000)
+            e("s_mov_b32", self.srdD[3], 0x00020000)
+            e("v_lshlrev_b32", self.v_dbg, 2, v(0))
+            self.dump("tid", v(0))
+            self.dump("wgid_x", s(2))
+            self.dump("lda", self.s_lda)
+            self.dump("K", self.s_K)
+            self.dump("tile_word", st[1])
         # ---- lane decode (independent of the tile) ----
         tid = v(0)
         lane, lo, hi, lor, kqs = t[0], t[1], t[2], t[3], t[4]
         e("v_and_b32", lane, 63, tid)
         e("v_lshrrev_b32", t[5], 6, tid)
+        e("s_nop", 1, comment="VALU write -> v_readfirstlane of the same VGPR needs wait states (seen on hardware: it read the old value)")
         e("v_readfirstlane_b32", self.s_wave, t[5])
+        e("s_nop", 3)
         e("v_and_b32", lo, 31, lane)
         e("v_lshrrev_b32", hi, 5, lane)
         self.kq_row(lor, lo, t[5])
@@ -302,13 +353,44 @@ class Gen:
         # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
         e("s_mov_b32", self.s_cur, 0)
         e("s_mov_b32", self.s_nxt, 0)
+        if c.debug:
+            for k_ in range(4):
+                self.dump(f"srdA[{k_}]", self.srdA[k_])
+            for k_ in range(4):
+                self.dump(f"srdB[{k_}]", self.srdB[k_])
+            self.dump("vVA0", self.vVA[0])
+            self.dump("vVA1", self.vVA[1])
+            self.dump("vVB0", self.vVB[0])
+            self.dump("vVB1", self.vVB[1])
+            self.dump("vWA0", self.vWA[0])
+            self.dump("vWA1", self.vWA[1])
+            self.dump("vWB00", self.vWB[0][0])
+            self.dump("vWB03", self.vWB[0][3])
+            self.dump("vX0", self.vX[0])
+            self.dump("v_rowA", self.v_rowA)
+            self.dump("v_rowB", self.v_rowB)
         self.issue_loads_all()
         self.advance_srds()
+        if c.debug:
+            e("s_waitcnt", vmcnt=0)
+            self.vmq.clear()
+            for k_ in range(4):
+                self.dump(f"stA0[{k_}]", self.stA[0][k_])
+            for k_ in range(4):
+                self.dump(f"stB0[{k_}]", self.stB[0][k_])
+            self.dump("stA_last[3]", self.stA[-1][3])
         self.write_addrs()
         for pi in range(c.NPA):
             self.store_A_piece(pi)
         for gi in range(c.NPB // 2):
             self.store_B_pair(gi)
+        if c.debug:
+            self.lg_wait(None)
+            e("s_barrier")
+            for k_ in range(0, 8):
+                self.dump_lds(f"lds[{k_ * 1024}+4tid]", k_ * 1024)
+            self.dump_lds("ldsB[0+4tid]", c.BK * c.BM * 4)
+            e("s_barrier")
         self.issue_loads_all()
         self.advance_srds()
         e("s_mov_b32", self.s_nxt, c.STAGE)
@@ -321,6 +403,14 @@ class Gen:
         self.lg_wait(None)
         e("s_barrier")
         self.read_group(0, self.s_cur, 0)
+        if c.debug:
+            self.lg_wait(None)
+            for k_ in range(4):
+                self.dump(f"fa[0][0][{k_}]", self.fa[0][0][k_])
+            for k_ in range(4):
+                self.dump(f"fb[0][0][{k_}]", self.fb[0][0][k_])
+            for _ in range(c.TM + c.TN):
+                self.lg_issue(("R", 0))   # (keeps the loop-carried queue model: the body's first wait becomes a no-op wait)
         e("s_mov_b32", self.s_runlen, c.KC_TILES)
 
     def issue_loads_all(self):
@@ -330,10 +420,14 @@ class Gen:
             self.load_B_piece(pj)
 
     def load_A_piece(self, pi):
+        if "loads" in self.c.ablate:
+            return
         self.p.emit("buffer_load_dwordx4", self.stA[pi], self.vVA[pi], self.srdA, 0, offen=True)
         self.vm_issue(("A", pi))
 
     def load_B_piece(self, pj):
+        if "loads" in self.c.ablate:
+            return
         self.p.emit("buffer_load_dwordx4", self.stB[pj], self.vVB[pj], self.srdB, 0, offen=True)
         self.vm_issue(("B", pj))
 
@@ -590,6 +684,15 @@ class Gen:
         e("s_waitcnt", vmcnt=0, lgkmcnt=0)
         self.vmq.clear()
         self.lgq.clear()
+        if c.debug:
+            for k_ in range(4):
+                self.dump(f"acc[0][{k_}]", self.acc[0][k_])
+            self.dump("acc[last][15]", self.acc[-1][15])
+            if c.exact:
+                self.dump("run[0][0]", self.run[0][0])
+            for k_ in range(4):
+                self.dump(f"srdC[{k_}]", self.srdC[k_])
+            self.dump("s_rem", self.s_rem)
         tid = v(0)
         lane, lo, hi = t[0], t[1], t[2]
         e("v_and_b32", lane, 63, tid)
@@ -609,6 +712,7 @@ class Gen:
             e("v_add_u32", t[6], 128 * n, t[3])
             e("v_mov_b32", t[7], 0x80000000)
             e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+            self.dump(f"vC[{n}]", self.vC[n])
         for i in range(c.TM):
             for q in range(4):
                 for rr in range(4):

@@ -394,6 +394,10 @@ class Workgroup:
                  "v_add3_u32": lambda: x + y + z, "v_xad_u32": lambda: (x ^ y) + z}[op]()
             self.wr_v(w, A[0], (r & 0xffffffff).astype(U32))
         elif op == "v_readfirstlane_b32":
+            k_ = (A[1].kind, A[1].idx)
+            if self.check and k_ in w.valu_wr_state and w.state - w.valu_wr_state[k_] < 3:
+                raise SimError(f"wave {w.wid} pc {w.pc}: v_readfirstlane reads {A[1]} {w.state - w.valu_wr_state[k_]} states after a VALU "
+                               f"wrote it (hardware returned the OLD value without wait states)")
             first = next(l for l in range(LANES) if (w.exec >> l) & 1)
             sw(A[0], int(rv(w, A[1])[first]))
             w.valu_sgpr_wr[A[0].idx] = w.state

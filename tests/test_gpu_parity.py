@@ -680,7 +680,9 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 assert la.last_f32_asm() == 0
             finally:
                 la.set_f32_asm(1); la.set_float_mode(0)
-            assert used == (1 if (mode == 0 or K <= 512) else 2), (M, N, K, mode, used)
+            want = 1 if (mode == 0 or K <= 512) else 2
+            # (tiny problems are taken by the small-matrix / slice-parallel paths before the tiled kernels are asked)
+            assert used == want or (used == 0 and M * N <= 1024 * 1024), (M, N, K, mode, used)
             assert torch.equal(dC, dC2), (M, N, K, mode)
             assert (dC[:, N:] == 7.0).all(), "wrote outside C"
             if mode == 0:
