@@ -135,8 +135,8 @@ def kernel_source_sha16():
     """Identity of the headline kernel's sources: the committed PMC traffic figure is only quoted for these."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_mfma_kernel.h", "gemm_mfma_cfgs.h", "gemm_mfma.hip", "common.h"):
-        with open(os.path.join(ROOT, "laser_amd", "csrc", f), "rb") as fh:
+    for f in ("asmgen/f32_kernel.py", "asmgen/core.py", "csrc/gemm_f32_asm.cpp", "csrc/common.h"):
+        with open(os.path.join(ROOT, "laser_amd", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
@@ -475,8 +475,9 @@ def main():
                 "stddev": round((sum((x - mean) ** 2 for x in per) / max(1, len(per) - 1)) ** 0.5, 4)}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "gemm_mfma_kernel<float,...>", "kernel_ms": round(k_ms, 4),
-                               "algorithmic_flops_per_launch": 2.0 * n * n * n}
+                               "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)"}.get(
+                                   laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
+                               "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": 2.0 * n * n * n}
             tr = pmc_traffic(mode) if (n == SIZE and args.cfg < 0) else None   # the profiled shape / configuration only
             if tr is not None:
                 out["roofline"]["traffic"] = tr["bytes_per_launch"]

@@ -54,7 +54,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     t0 = time.time()
     stats = None
     for wg in range(len(table)):
-        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_bytes)
+        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc)
         w.run(order=order)
         stats = w.waves[0].stats
     Cout = np.full((M, ldc), np.nan, dtype=np.float32).reshape(-1)

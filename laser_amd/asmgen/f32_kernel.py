@@ -20,7 +20,7 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF
 
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
-                 b_store="write2", ablate=(), r_step=1, debug=False):
+                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
         self.WTM, self.WTN = BM // 2, BN // 2
         self.TM, self.TN = self.WTM // 32, self.WTN // 32
@@ -40,14 +40,18 @@ class Cfg:
         self.b_store = b_store      # "write2": ds_write2_b32 straight from the two pieces; "swap64": 4 v_swap + 4 ds_write_b64
         self.ablate = set(ablate)   # timing experiments only (results are wrong): "loads", "stores", "reads", "barrier"
         self.r_step = r_step
+        self.filler, self.filler_every = filler, filler_every   # pricing experiments: one extra instruction of this kind per gap
         self.debug = debug          # dump intermediate state of workgroup 0 to the kernarg's debug buffer (asm_debug.py)
         self.lds_bytes = 3 * self.STAGE
         assert self.lds_bytes <= 160 * 1024
+        self.lds_alloc = self.lds_bytes + (16384 if filler else 0)
+        assert self.lds_alloc <= 160 * 1024
 
 
 CONFIGS = {
-    "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True),
-    "fast_256x256x16": dict(BM=256, BN=256, BK=16, exact=False),
+    # barrier positions from the schedule sweeps (profiles/r03/asm_probe_v1.jsonl, asm_probe_v2.jsonl)
+    "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95),
+    "fast_256x256x16": dict(BM=256, BN=256, BK=16, exact=False, bar_gap=95),
 }
 
 # kernel argument block (bytes)
@@ -72,8 +76,7 @@ class Gen:
         self.ka1 = S(8, align=4)   # lda ldb ldc M N K - -
         self.s_lda, self.s_ldb, self.s_ldc, self.s_M, self.s_N, self.s_K = (self.ka1[i] for i in range(6))
         self.srdA, self.srdB, self.srdC = S(4), S(4), S(4)
-        self.s_cur, self.s_nxt = S(), S()
-        self.s_rem, self.s_cnt, self.s_runlen = S(), S(), S()
+        self.s_rem, self.s_cnt = S(), S()
         self.s_bstep = S()
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
@@ -87,14 +90,14 @@ class Gen:
         # staging pieces
         self.stA = [V(4) for _ in range(c.NPA)]
         self.stB = [V(4) for _ in range(c.NPB)]
-        # per-lane constants
-        self.vX = [V() for _ in range(c.NG)]
-        self.v_rowA, self.v_rowB = V(), V()
-        self.v_ra, self.v_rb = V(), V()          # absolute fragment-read addresses of the group being read
-        self.vWA = [V(), V()]
-        self.vWAabs = [V(), V()]
-        self.vWB = [[V() for _ in range(4)] for _ in range(c.NPB // 2)]
-        self.vWBabs = [[V() for _ in range(4)] for _ in range(c.NPB // 2)]
+        # per-lane LDS addresses, one register per LDS stage: [0] = the stage the tile being multiplied lives in (reads) /
+        # the stage being filled (writes), [1] = the next one, [2] = the third; rotated with v_swap_b32 once per K-tile --
+        # v_swap is free beside the MFMA stream while any other VALU op costs ~11 cycles of matrix-pipe time
+        # (profiles/r03/asm_probe_v3_fillers.jsonl, asm_probe_v4_fillers.jsonl), so the loop computes no address at all
+        self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
+        self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
+        self.WA = [[[V() for _ in range(3)] for _ in range(c.NPA)] for _ in range(2)]   # [MFMA half][piece][stage]
+        self.WB = [[[V() for _ in range(3)] for _ in range(4)] for _ in range(c.NPB // 2)]
         self.vVA = [V() for _ in range(c.NPA)]
         self.vVB = [V() for _ in range(c.NPB)]
         self.vC = [V() for _ in range(c.TN)]
@@ -103,8 +106,11 @@ class Gen:
         self.v_dbg = V()
         self.ndump = 0
         self.dump_names = []
-        self.vT = [V(16), V(16)]
-        self.vt = [V() for _ in range(10)]
+        self.vT = [V(16)]
+        blk = V(12, align=4)
+        self.vt = [blk[i] for i in range(10)]
+        # filler experiments (timing only): dummy data / address registers that alias temporaries the loop does not use
+        self.vF, self.vFaddr, self.vFoff = blk.sub(4, 4), blk[10], blk[11]
 
     # ------------------------------------------------------------------ queue models -> counted waits
     def vm_issue(self, tag):
@@ -116,7 +122,8 @@ class Gen:
         idx = self.vmq.index(tag)
         n = len(self.vmq) - 1 - idx
         assert n <= 63
-        self.p.emit("s_waitcnt", vmcnt=n)
+        if "vmwaits" not in self.c.ablate:
+            self.p.emit("s_waitcnt", vmcnt=n)
         del self.vmq[:idx + 1]
 
     def lg_issue(self, tag):
@@ -128,10 +135,9 @@ class Gen:
         if not idxs:
             return
         idx = max(idxs)
-        n = len(self.lgq) - 1 - idx
-        assert n <= 15, n
+        n = min(len(self.lgq) - 1 - idx, 15)   # (the counter saturates the 4-bit field: waiting for more is still correct)
         self.p.emit("s_waitcnt", lgkmcnt=n)
-        del self.lgq[:idx + 1]
+        del self.lgq[:len(self.lgq) - n]
 
     # ------------------------------------------------------------------ small helpers
     def kq_swz(self, dst, x, tmp):
@@ -225,16 +231,20 @@ class Gen:
         e("s_mul_i32", self.s_wm0, st[2], c.WTM)
         e("s_and_b32", st[2], self.s_wave, 1)
         e("s_mul_i32", self.s_wn0, st[2], c.WTN)
-        # fragment reads: X[g] = 16 * ((2g + hi) ^ kqs); rowA = (wm0 + lor) * BK * 4; rowB = BK*BM*4 + (wn0 + lor) * BK * 4
+        # fragment reads of group g: (wm0 + lor) * BK * 4 [+ BK*BM*4 + (wn0 + lor) * BK * 4 for B] + 16 * ((2g + hi) ^ kqs)
+        e("v_add_u32", t[5], self.s_wm0, lor)
+        e("v_mul_u32_u24", t[6], c.BK * 4, t[5])
+        e("v_add_u32", t[5], self.s_wn0, lor)
+        e("v_mul_u32_u24", t[7], c.BK * 4, t[5])
+        e("v_add_u32", t[7], c.BK * c.BM * 4, t[7])
         for g in range(c.NG):
             e("v_or_b32", t[5], 2 * g, hi)
             e("v_xor_b32", t[5], t[5], kqs)
-            e("v_lshlrev_b32", self.vX[g], 4, t[5])
-        e("v_add_u32", t[5], self.s_wm0, lor)
-        e("v_mul_u32_u24", self.v_rowA, c.BK * 4, t[5])
-        e("v_add_u32", t[5], self.s_wn0, lor)
-        e("v_mul_u32_u24", self.v_rowB, c.BK * 4, t[5])
-        e("v_add_u32", self.v_rowB, c.BK * c.BM * 4, self.v_rowB)
+            e("v_lshlrev_b32", t[5], 4, t[5])
+            for R, row in ((self.RA, t[6]), (self.RB, t[7])):
+                e("v_add_u32", R[g][0], t[5], row)
+                e("v_add_u32", R[g][1], c.STAGE, R[g][0])
+                e("v_add_u32", R[g][2], 2 * c.STAGE, R[g][0])
         # A pieces (k-contiguous, 16 B = 4 consecutive k of row x): kq = tid % (BK/4), x = tid / (BK/4) (+ XS per piece)
         nkq = c.BK // 4
         kq, x, row, sw = t[0], t[1], t[2], t[3]
@@ -250,7 +260,12 @@ class Gen:
         for cc in range(2):
             e("v_or_b32", t[8], cc, t[5])
             e("v_xor_b32", t[8], t[8], sw)
-            e("v_lshl_add_u32", self.vWA[cc], t[8], 4, t[7])
+            e("v_lshl_add_u32", self.WA[cc][0][2], t[8], 4, t[7])
+            for pi in range(c.NPA):
+                if pi:
+                    e("v_add_u32", self.WA[cc][pi][2], 4096 * pi, self.WA[cc][0][2])
+                e("v_add_u32", self.WA[cc][pi][0], c.STAGE, self.WA[cc][pi][2])
+                e("v_add_u32", self.WA[cc][pi][1], 2 * c.STAGE, self.WA[cc][pi][2])
         # global offsets of the A pieces: VA_i = (x + i*XS) * lda * 4 + kq * 16
         XS = 256 // nkq
         e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
@@ -305,7 +320,9 @@ class Gen:
                 e("v_xor_b32", ss, ss, t[8])                 # L ^ swz
                 e("v_mul_u32_u24", rr, c.BK * 4, rr)
                 e("v_lshl_add_u32", rr, ss, 4, rr)
-                e("v_add3_u32", self.vWB[gi][ee], rr, t[9], st[0])
+                e("v_add3_u32", self.WB[gi][ee][2], rr, t[9], st[0])
+                e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
+                e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
         # ---- tile coordinates, descriptors ----
         e("s_waitcnt", lgkmcnt=0)
         e("s_and_b32", st[0], st[1], 0xffff)
@@ -351,8 +368,6 @@ class Gen:
         # number of K-tiles
         e("s_lshr_b32", self.s_rem, self.s_K, (c.BK).bit_length() - 1)
         # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
-        e("s_mov_b32", self.s_cur, 0)
-        e("s_mov_b32", self.s_nxt, 0)
         if c.debug:
             for k_ in range(4):
                 self.dump(f"srdA[{k_}]", self.srdA[k_])
@@ -362,13 +377,12 @@ class Gen:
             self.dump("vVA1", self.vVA[1])
             self.dump("vVB0", self.vVB[0])
             self.dump("vVB1", self.vVB[1])
-            self.dump("vWA0", self.vWA[0])
-            self.dump("vWA1", self.vWA[1])
-            self.dump("vWB00", self.vWB[0][0])
-            self.dump("vWB03", self.vWB[0][3])
-            self.dump("vX0", self.vX[0])
-            self.dump("v_rowA", self.v_rowA)
-            self.dump("v_rowB", self.v_rowB)
+            self.dump("WA0", self.WA[0][0][2])
+            self.dump("WA1", self.WA[1][0][2])
+            self.dump("WB00", self.WB[0][0][2])
+            self.dump("WB03", self.WB[0][3][2])
+            self.dump("RA0", self.RA[0][0])
+            self.dump("RB0", self.RB[0][0])
         self.issue_loads_all()
         self.advance_srds()
         if c.debug:
@@ -379,11 +393,10 @@ class Gen:
             for k_ in range(4):
                 self.dump(f"stB0[{k_}]", self.stB[0][k_])
             self.dump("stA_last[3]", self.stA[-1][3])
-        self.write_addrs()
         for pi in range(c.NPA):
-            self.store_A_piece(pi)
+            self.store_A_piece(pi, k=2)     # tile 0 goes to LDS stage 0 = the "third" stage of the write triples
         for gi in range(c.NPB // 2):
-            self.store_B_pair(gi)
+            self.store_B_pair(gi, k=2)
         if c.debug:
             self.lg_wait(None)
             e("s_barrier")
@@ -393,7 +406,6 @@ class Gen:
             e("s_barrier")
         self.issue_loads_all()
         self.advance_srds()
-        e("s_mov_b32", self.s_nxt, c.STAGE)
         # accumulators start at +0
         for b in range(c.NB):
             for r in range(16):
@@ -402,7 +414,7 @@ class Gen:
                     e("v_accvgpr_write_b32", self.run[b][r], 0)
         self.lg_wait(None)
         e("s_barrier")
-        self.read_group(0, self.s_cur, 0)
+        self.read_group(0, 0, 0)
         if c.debug:
             self.lg_wait(None)
             for k_ in range(4):
@@ -411,7 +423,10 @@ class Gen:
                 self.dump(f"fb[0][0][{k_}]", self.fb[0][0][k_])
             for _ in range(c.TM + c.TN):
                 self.lg_issue(("R", 0))   # (keeps the loop-carried queue model: the body's first wait becomes a no-op wait)
-        e("s_mov_b32", self.s_runlen, c.KC_TILES)
+        if c.filler:
+            e("v_lshlrev_b32", self.vFaddr, 4, v(0))
+            e("v_add_u32", self.vFaddr, c.lds_bytes, self.vFaddr, comment="filler experiments: 16 B per lane past the kernel's LDS")
+            e("v_lshlrev_b32", self.vFoff, 4, v(0))
 
     def issue_loads_all(self):
         for pi in range(self.c.NPA):
@@ -443,36 +458,28 @@ class Gen:
                 e(*o)
         return ops
 
-    def write_addrs(self):
-        """absolute LDS write addresses for the stage s_nxt"""
-        e = self.p.emit
-        for cc in range(2):
-            e("v_add_u32", self.vWAabs[cc], self.s_nxt, self.vWA[cc])
-        for gi in range(self.c.NPB // 2):
-            for ee in range(4):
-                e("v_add_u32", self.vWBabs[gi][ee], self.s_nxt, self.vWB[gi][ee])
-
-    def store_A_piece(self, pi, ops=None):
+    def store_A_piece(self, pi, ops=None, k=0):
         """piece = 4 consecutive k (e0 e1 e2 e3) of one row: (e0, e2) -> chunk of MFMA half 0, (e1, e3) -> half 1"""
         out = []
         r = self.stA[pi]
         out.append(("vmwait", ("A", pi)))
-        out.append(("ins", "v_swap_b32", (r[1], r[2]), {}))
-        off = pi * 4096
-        out.append(("ldsw", "ds_write_b64", (self.vWAabs[0], r.sub(0, 2)), {"offset": off}))
-        out.append(("ldsw", "ds_write_b64", (self.vWAabs[1], r.sub(2, 2)), {"offset": off}))
+        # ds_write2_b32 takes its two dwords from two independent registers: no repacking VALU op (a v_swap on freshly
+        # loaded registers cost 16 cycles of matrix-pipe time per piece, profiles/r03/asm_probe_v7.jsonl); the price is one
+        # address register per (piece, half, stage)
+        out.append(("ldsw", "ds_write2_b32", (self.WA[0][pi][k], r[0], r[2]), {"offset0": 0, "offset1": 1}))
+        out.append(("ldsw", "ds_write2_b32", (self.WA[1][pi][k], r[1], r[3]), {"offset0": 0, "offset1": 1}))
         if ops is None:
             self.run_ops(out)
         return out
 
-    def store_B_pair(self, gi, ops=None):
+    def store_B_pair(self, gi, ops=None, k=0):
         """pieces P (row k) and Q (row k + 2) of one x quad: element e of both -> adjacent words of row x = 4xq + e"""
         out = []
         P, Q = self.stB[2 * gi], self.stB[2 * gi + 1]
         out.append(("vmwait", ("B", 2 * gi + 1)))
         if self.c.b_store == "write2":
             for ee in range(4):
-                out.append(("ldsw", "ds_write2_b32", (self.vWBabs[gi][ee], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
+                out.append(("ldsw", "ds_write2_b32", (self.WB[gi][ee][k], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
         else:
             # (P0 P1 P2 P3 Q0 Q1 Q2 Q3) -> (P0 Q0 P1 Q1 P2 Q2 P3 Q3): two 3-cycles = 4 swaps; P, Q are adjacent registers
             assert Q.idx == P.idx + 4
@@ -480,7 +487,7 @@ class Gen:
             for x, y in ((1, 4), (2, 4), (3, 5), (6, 5)):
                 out.append(("ins", "v_swap_b32", (r[x], r[y]), {}))
             for ee in range(4):
-                out.append(("ldsw", "ds_write_b64", (self.vWBabs[gi][ee], v(P.idx + 2 * ee, 2)), {}))
+                out.append(("ldsw", "ds_write_b64", (self.WB[gi][ee][k], v(P.idx + 2 * ee, 2)), {}))
         if ops is None:
             self.run_ops(out)
         return out
@@ -494,7 +501,9 @@ class Gen:
         ab = self.c.ablate
         if (kind == "ldsw" and "stores" in ab) or (kind == "ldsr" and "reads" in ab) or (kind in ("loadA", "loadB") and "loads" in ab):
             return
-        if kind == "ins" and o[1] == "v_swap_b32" and "stores" in ab:
+        if kind == "ins" and o[1] == "v_swap_b32" and ("stores" in ab or "swaps" in ab):
+            return
+        if kind == "ldsw" and ((o[1] == "ds_write_b64" and "awrites" in ab) or (o[1] == "ds_write2_b32" and "bwrites" in ab)):
             return
         if kind == "barrier" and "barrier" in ab:
             self.lg_wait(None)
@@ -524,22 +533,21 @@ class Gen:
             raise ValueError(kind)
 
     def read_group_ops(self, g, stage, slot):
-        """fragment reads of group g (4 k-steps) of the tile in LDS stage `stage` into register slot `slot`"""
+        """fragment reads of group g (4 k-steps) into register slot `slot`; stage 0: the tile being multiplied, 1: the next tile"""
         c = self.c
-        ops = [("ins", "v_add3_u32", (self.v_ra, stage, self.v_rowA, self.vX[g]), {}),
-               ("ins", "v_add3_u32", (self.v_rb, stage, self.v_rowB, self.vX[g]), {})]
+        ops = []
         blk = 32 * c.BK * 4
         for i in range(c.TM):
-            ops.append(("ldsr", "ds_read_b128", (self.fa[slot][i], self.v_ra), {"offset": i * blk}, ("R", slot)))
+            ops.append(("ldsr", "ds_read_b128", (self.fa[slot][i], self.RA[g][stage]), {"offset": i * blk}, ("R", slot)))
         for n in range(c.TN):
-            ops.append(("ldsr", "ds_read_b128", (self.fb[slot][n], self.v_rb), {"offset": n * blk}, ("R", slot)))
+            ops.append(("ldsr", "ds_read_b128", (self.fb[slot][n], self.RB[g][stage]), {"offset": n * blk}, ("R", slot)))
         return ops
 
     def read_group(self, g, stage, slot):
         self.run_ops(self.read_group_ops(g, stage, slot))
 
     # ------------------------------------------------------------------ one K-tile
-    def tile_body(self, fold):
+    def tile_body(self, fold, stage=None):
         c, p = self.c, self.p
         e = p.emit
         gaps = {m: [] for m in range(-1, c.NMF)}   # gap m: ops issued right after MFMA m (gap -1: before MFMA 0)
@@ -547,31 +555,38 @@ class Gen:
         def put(m, op):
             gaps[min(max(m, -1), c.NMF - 1)].append(op)
 
+        # (a fold tile carries the slice fold in its first gaps: its staging starts later, so its barrier sits late)
+        bar = max(c.bar_gap, c.NMF - c.GM - 1) if fold else c.bar_gap
         first_free = 0
         if fold:
-            first_free = c.NB + 1   # gaps 0..NB-1 carry the slice fold
+            first_free = c.NB + 1           # gaps 0..NB-1 carry the slice fold
         # fragment reads: group g+1 (or group 0 of the next tile) during group g
         for g in range(c.NG):
             nxt_tile = (g + 1 == c.NG)
-            ops = self.read_group_ops(0 if nxt_tile else g + 1, self.s_nxt if nxt_tile else self.s_cur, (g + 1) & 1)
+            which = (stage + 1) % 3 if nxt_tile else stage
+            ops = self.read_group_ops(0 if nxt_tile else g + 1, which, (g + 1) & 1)
             base = g * c.GM + 1
             if nxt_tile:
-                base = max(base, c.bar_gap + 1)
+                base = max(base, bar + 1)
             if fold and g == 0:
                 base = first_free
             for k, op in enumerate(ops):
-                put(base + k * c.r_step, op)
+                at = base + k * c.r_step
+                assert nxt_tile or at < (g + 1) * c.GM - 1, "fragment reads must be issued before the group's wait"
+                put(at, op)
             # the group's fragments must have landed before its first MFMA (the next tile's first group: top of the body)
             if not nxt_tile:
                 put((g + 1) * c.GM - 1, ("lgwait", {("R", (g + 1) & 1)}))
         # staging: LDS stores of tile t+1 (from registers), then the HBM loads of tile t+2 into the drained registers
+        # register of a triple: [0] / [1] = this tile's / the next tile's stage when the triples rotate; with one body per
+        # stage, reads of stage k use index k and writes index (k + 2) % 3 (the triples were initialised for stage 0)
+        wr_k = ((stage + 1) % 3 + 2) % 3
         stg = []
-        stg.append(("call", self.write_addrs))
         for pi in range(c.NPA):
-            stg += self.store_A_piece(pi, ops=[])
+            stg += self.store_A_piece(pi, ops=[], k=wr_k)
             stg.append(("loadA", pi))
         for gi in range(c.NPB // 2):
-            stg += self.store_B_pair(gi, ops=[])
+            stg += self.store_B_pair(gi, ops=[], k=wr_k)
             stg.append(("loadB", 2 * gi))
             stg.append(("loadB", 2 * gi + 1))
         # waits ride with the op that follows them
@@ -582,95 +597,153 @@ class Gen:
             else:
                 units.append([op])
         w0 = max(c.w_start, first_free + (c.TM + c.TN + 2 if fold else 0))
-        span = c.bar_gap - 1 - w0
+        span = bar - 1 - w0
         step = c.w_step or max(1.0, span / max(1, len(units)))
         for k, u in enumerate(units):
             m = int(w0 + k * step)
-            assert m < c.bar_gap, "staging does not fit before the barrier"
+            assert m < bar, "staging does not fit before the barrier"
             for op in u:
                 put(m, op)
-        put(c.bar_gap, ("barrier",))
+        put(bar, ("barrier",))
         # scalar bookkeeping after the last load of the tile
-        tail = c.bar_gap + 2
+        tail = bar + 2
         for k, o in enumerate(self.advance_srds(which="ops")):
             put(tail + k, ("ins", o[0], o[1:], {}))
 
-        def rotate():
-            e("s_mov_b32", self.s_cur, self.s_nxt)
-            e("s_add_u32", self.s_nxt, self.s_nxt, c.STAGE)
-            e("s_cmp_eq_u32", self.s_nxt, 3 * c.STAGE)
-            e("s_cselect_b32", self.s_nxt, 0, self.s_nxt)
-        put(c.NMF - 2, ("call", rotate))
+        # MFMA order: k-step-major -- NB independent accumulators between two uses of one
+        order = [(g, u, b) for g in range(c.NG) for u in range(4) for b in range(c.NB)]
 
+        if c.filler:
+            nvm = 0
+            for m_ in range(0, c.NMF, c.filler_every):
+                f = c.filler
+                if f in ("ds_write_b64", "ds_write_b128", "ds_write_b32"):
+                    n_ = {"ds_write_b32": 1, "ds_write_b64": 2, "ds_write_b128": 4}[f]
+                    put(m_, ("ins", f, (self.vFaddr, self.vF.sub(0, n_) if n_ > 1 else self.vF[0]), {}))
+                elif f == "ds_write2_b32":
+                    put(m_, ("ins", f, (self.vFaddr, self.vF[0], self.vF[2]), {"offset0": 0, "offset1": 1}))
+                elif f == "ds_read_b128":
+                    put(m_, ("ins", f, (self.vF, self.vFaddr), {}))
+                elif f == "buffer_load_dwordx4":
+                    put(m_, ("ins", f, (self.vF, self.vFoff, self.srdA, 0), {"offen": True}))
+                    nvm += 1
+                    if nvm % 16 == 0:
+                        put(m_, ("ins", "s_waitcnt", (), {"vmcnt": 8}))
+                elif f in ("v_swap_b32",):
+                    put(m_, ("ins", f, (self.vF[0], self.vF[1]), {}))
+                elif f == "v_swap_distinct":
+                    put(m_, ("ins", "v_swap_b32", (self.vT[0][m_ % 16], self.vT[0][(m_ + 5) % 16]), {}))
+                elif f == "v_swap_x3":
+                    for q_ in range(3):
+                        put(m_, ("ins", "v_swap_b32", (self.vT[0][(m_ + q_) % 16], self.vT[0][(m_ + 5 + q_) % 16]), {}))
+                elif f == "v_swap_dep":
+                    put(m_, ("ins", "v_swap_b32", (self.vT[0][m_ % 16], self.vT[0][(m_ + 3) % 16]), {}))
+                    put(m_, ("ins", "v_swap_b32", (self.vT[0][(m_ + 3) % 16], self.vT[0][(m_ + 7) % 16]), {}))
+                elif f in ("v_mov_b32",):
+                    put(m_, ("ins", f, (self.vF[0], self.vF[1]), {}))
+                elif f == "v_add_u32":
+                    put(m_, ("ins", f, (self.vF[0], self.s_t[5], self.vF[1]), {}))
+                elif f == "v_accvgpr_read_b32":
+                    put(m_, ("ins", f, (self.vF[0], self.run[0][m_ % 16] if c.exact else self.acc[0][0]), {}))
+                elif f == "v_accvgpr_write_b32":
+                    put(m_, ("ins", f, (self.run[0][m_ % 16], self.vF[0]), {}))
+                elif f == "v_accvgpr_rw":
+                    put(m_, ("ins", "v_accvgpr_read_b32", (self.vF[0], self.run[0][m_ % 16]), {}))
+                    put(m_, ("ins", "v_accvgpr_write_b32", (self.run[1][m_ % 16], self.vF[1]), {}))
+                elif f == "v_add_f32":
+                    put(m_, ("ins", f, (self.vF[0], self.vF[1], self.vF[2]), {}))
+                elif f == "v_mov_x2":
+                    put(m_, ("ins", "v_mov_b32", (self.vF[0], self.vF[1]), {}))
+                    put(m_, ("ins", "v_mov_b32", (self.vF[2], self.vF[3]), {}))
+                elif f == "v_nop":
+                    put(m_, ("ins", f, (), {}))
+                elif f == "v_mov_sgpr":
+                    put(m_, ("ins", "v_mov_b32", (self.vF[0], self.s_t[5]), {}))
+                elif f == "v_pk_add_f32":
+                    put(m_, ("ins", f, (self.vF.sub(0, 2), self.vF.sub(0, 2), self.vF.sub(2, 2)), {}))
+                elif f == "s_nop":
+                    put(m_, ("ins", f, (0,), {}))
+                elif f == "s_add_u32":
+                    put(m_, ("ins", f, (self.s_t[5], self.s_t[5], 1), {}))
+                else:
+                    raise ValueError(f)
         # ---- emit ----
         # the first group's fragments were requested during the previous tile
         self.lg_wait({("R", 0)})
-        m = 0
-        for g in range(c.NG):
+        for op in gaps[-1]:
+            self.run_op(op)
+        for m, (g, u, b) in enumerate(order):
             slot = g & 1
-            for u in range(4):
-                for i in range(c.TM):
-                    for n in range(c.TN):
-                        b = i * c.TN + n
-                        srcc = self.acc[b]
-                        if fold and g == 0 and u == 0:
-                            # Laser's pc loop (gemm.nim:150-158): the finished slice sum leaves the accumulator (16 reads in
-                            # the shadow of the previous MFMA), this MFMA starts the next chain from a literal +0, and
-                            # run += slice rides behind it
-                            T = self.vT[b & 1]
-                            for r in range(16):
-                                e("v_accvgpr_read_b32", T[r], self.acc[b][r])
-                            srcc = 0
-                        e("v_mfma_f32_32x32x2_f32", self.acc[b], self.fa[slot][i][u], self.fb[slot][n][u], srcc)
-                        if fold and g == 0 and u == 0:
-                            T = self.vT[b & 1]
-                            for r in range(16):
-                                tt = self.vt[r % 4]
-                                e("v_accvgpr_read_b32", tt, self.run[b][r])
-                                e("v_add_f32", tt, tt, T[r])
-                                e("v_accvgpr_write_b32", self.run[b][r], tt)
-                        for op in gaps[m]:
-                            self.run_op(op)
-                        m += 1
-        assert m == c.NMF
+            i, n = b // c.TN, b % c.TN
+            srcc = self.acc[b]
+            first = fold and g == 0 and u == 0
+            if first:
+                # Laser's pc loop (gemm.nim:150-158): the finished slice sum leaves the accumulator (16 reads in the shadow of
+                # the previous MFMA), this MFMA starts the next chain from a literal +0, and run += slice follows it -- all
+                # 64 VALU operations of a block in ONE gap: beside the f32 MFMA stream the first VALU instruction of a gap
+                # costs ~11 cycles of matrix-pipe time and every further one ~4 (profiles/r03/asm_probe_v4_fillers.jsonl), so
+                # VALU work is batched, never spread.  (Moving the sums AGPR -> LDS -> VGPR instead, which needs no VALU
+                # moves, measured slower: profiles/r03/asm_probe_v8.jsonl "exact_lds".)
+                T = self.vT[0]
+                for r in range(16):
+                    e("v_accvgpr_read_b32", T[r], self.acc[b][r])
+            if first:
+                srcc = 0
+            e("v_mfma_f32_32x32x2_f32", self.acc[b], self.fa[slot][i][u], self.fb[slot][n][u], srcc)
+            if first:
+                T = self.vT[0]
+                for r in range(16):
+                    tt = self.vt[r % 4]
+                    e("v_accvgpr_read_b32", tt, self.run[b][r])
+                    e("v_add_f32", tt, tt, T[r])
+                    e("v_accvgpr_write_b32", self.run[b][r], tt)
+            for op in gaps[m]:
+                self.run_op(op)
+        assert len(order) == c.NMF
 
     # ------------------------------------------------------------------ main loop + epilogue
     def main_loop(self):
         c, p = self.c, self.p
         e = p.emit
-        L_outer, L_norm, L_check, L_done = p.label("outer"), p.label("tile"), p.label("check"), p.label("done")
         state0 = (list(self.vmq), list(self.lgq))
-        if not c.exact:
-            e("s_mov_b32", self.s_cnt, self.s_rem)
+        if True:
+            # One K-tile body per LDS stage (and per kind: ordinary / first tile of a kc slice): a body names its stage's
+            # address registers, so the loop computes no address -- any VALU op beside the MFMA stream costs matrix-pipe
+            # time; rotating register triples with v_swap_b32 instead of unrolling measured 4 % slower
+            # (profiles/r03/asm_probe_v6.jsonl).  Every body ends with the same dispatch: done? -> slice boundary? -> the
+            # next stage's body.
+            L_done = p.label("done")
+            N = [p.label(f"tile_s{k}") for k in range(3)]
+            F = [p.label(f"fold_s{k}") for k in range(3)] if c.exact else None
+            e("s_mov_b32", self.s_cnt, c.KC_TILES if c.exact else 0x7fffffff)
+
+            def tail(k, fall_through):
+                nk = (k + 1) % 3
+                e("s_sub_u32", self.s_rem, self.s_rem, 1)
+                e("s_cmp_eq_u32", self.s_rem, 0)
+                e("s_cbranch_scc1", L_done)
+                if c.exact:
+                    e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
+                    e("s_cmp_eq_u32", self.s_cnt, 0)
+                    e("s_cbranch_scc1", F[nk])
+                if not fall_through:
+                    e("s_branch", N[nk])
             e("raw", ".p2align 6")
-            p.place(L_norm)
-            self.tile_body(False)
-            assert (self.vmq, self.lgq) == (state0[0], state0[1]), "loop-carried queue state differs"
-            e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
-            e("s_cmp_lg_u32", self.s_cnt, 0)
-            e("s_cbranch_scc1", L_norm)
+            for k in range(3):
+                p.place(N[k])
+                self.tile_body(False, stage=k)
+                assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs"
+                tail(k, fall_through=(k < 2))
+            if c.exact:
+                assert c.KC_TILES > 1
+                for k in range(3):
+                    p.place(F[k])
+                    e("s_mov_b32", self.s_cnt, c.KC_TILES)
+                    self.tile_body(True, stage=k)
+                    assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs (fold tile)"
+                    tail(k, fall_through=False)
+            p.place(L_done)
             return
-        p.place(L_outer)
-        e("s_min_u32", self.s_cnt, self.s_runlen, self.s_rem)
-        e("s_sub_u32", self.s_rem, self.s_rem, self.s_cnt)
-        e("s_cmp_eq_u32", self.s_cnt, 0)
-        e("s_cbranch_scc1", L_check)
-        e("raw", ".p2align 6")
-        p.place(L_norm)
-        self.tile_body(False)
-        assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs"
-        e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
-        e("s_cmp_lg_u32", self.s_cnt, 0)
-        e("s_cbranch_scc1", L_norm)
-        p.place(L_check)
-        e("s_cmp_eq_u32", self.s_rem, 0)
-        e("s_cbranch_scc1", L_done)
-        self.tile_body(True)
-        assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs (fold tile)"
-        e("s_sub_u32", self.s_rem, self.s_rem, 1)
-        e("s_mov_b32", self.s_runlen, c.KC_TILES - 1)
-        e("s_branch", L_outer)
-        p.place(L_done)
 
     def epilogue(self):
         """C = run + acc (alpha == 1, beta == 0: gemm_ukernel_generic.nim:53-76), predicated by the descriptor's bounds check"""
@@ -762,7 +835,7 @@ def kernel_text(gen, symbol):
 \t.rodata
 \t.p2align\t6
 \t.amdhsa_kernel {symbol}
-\t\t.amdhsa_group_segment_fixed_size {c.lds_bytes}
+\t\t.amdhsa_group_segment_fixed_size {c.lds_alloc}
 \t\t.amdhsa_private_segment_fixed_size 0
 \t\t.amdhsa_kernarg_size {KERNARG_SIZE}
 \t\t.amdhsa_user_sgpr_count 2
@@ -789,7 +862,7 @@ amdhsa.kernels:
     .symbol: {symbol}.kd
     .kernarg_segment_size: {KERNARG_SIZE}
     .kernarg_segment_align: 8
-    .group_segment_fixed_size: {c.lds_bytes}
+    .group_segment_fixed_size: {c.lds_alloc}
     .private_segment_fixed_size: 0
     .wavefront_size: 64
     .sgpr_count: 100

@@ -416,6 +416,12 @@ class Workgroup:
             with np.errstate(all="ignore"):
                 r = {"v_add_f32": x + y, "v_mul_f32": x * y, "v_sub_f32": x - y}[op]
             self.wr_v(w, A[0], u32(r.astype(np.float32)))
+        elif op == "v_pk_add_f32":
+            assert A[0].n == 2 and A[1].n == 2 and A[2].n == 2
+            for h in range(2):
+                x, y = f32(rv(w, A[1][h])), f32(rv(w, A[2][h]))
+                with np.errstate(all="ignore"):
+                    self.wr_v(w, A[0][h], u32((x + y).astype(np.float32)))
         elif op.startswith("v_cmp_"):
             rel, ty = op.split("_")[2], op.split("_")[3]
             x, y = rv(w, A[1]), rv(w, A[2])
@@ -548,7 +554,8 @@ class Workgroup:
         if op.startswith("v_") and not op.startswith("v_mfma") and not op.startswith("v_cmp") and op != "v_readfirstlane_b32":
             for x in (A[:2] if op == "v_swap_b32" else A[:1]):
                 if isinstance(x, Reg):
-                    w.valu_wr_state[(x.kind, x.idx)] = w.state
+                    for kk in x.regs():
+                        w.valu_wr_state[kk] = w.state
         w.state += cost
         w.pc = nxt
         return None

@@ -34,7 +34,7 @@ a_, b_, c_, t_ = mem.alloc(A), mem.alloc(B), mem.alloc(np.full((M, N), np.nan, n
 d_ = mem.alloc(np.zeros(NS * 256 + 64, dtype=np.uint32))
 ka_ = mem.alloc(np.frombuffer(struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, Kd, N, N, M, N, Kd, 0, d_), dtype=np.uint8))
 for wg in range(len(table)):
-    Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_bytes).run()
+    Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc).run()
 sim_dump = mem.get(d_, np.uint32, (NS * 256 + 64,))[:NS * 256].reshape(NS, 256).copy()
 sim_C = mem.get(c_, np.float32, (M, N)).copy()
 want = (A.astype(np.float64) @ B.astype(np.float64))

@@ -35,8 +35,7 @@ def main():
                     "MI355X_MICROARCH.md HBM section); it counts L2 fabric-side requests, Infinity-Cache hits included. "
                     "Algorithmic bytes are 0.805 GB: the rest is operand panels re-fetched by the 8 XCD-private L2s.",
            "kernel_source_sha16": bench.kernel_source_sha16()}
-    for mode, pat in (("laser_order", r"gemm_mfma_kernel<float, 256, 128, 32, 4, 2, 1, 0, true"),
-                      ("fast", r"gemm_mfma_kernel<float, 256, 256, 16, 2, 4, 1, 0, false")):
+    for mode, pat in (("laser_order", r"lh_f32_exact_256x128x32"), ("fast", r"lh_f32_fast_256x256x16")):
         ks = [k for k in per if re.search(pat, k) and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]]
         if not ks:
             continue
