@@ -2,9 +2,10 @@
 """bench.py -- BASELINE.json's headline metric: fp32 sgemm GFLOP/s and fraction of the MI355X fp32
 MFMA roofline at M=N=K=8192 (configs[1]), on 1/2/4/8 GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W                      (any N: ONE process drives the N GPUs through the
+                                                                      C-ABI's laser_hip_gemm_strided_f32_sharded_dev)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W       (one process per GPU, RCCL through torch.distributed)
 
 A "step" is one pass of the hot path: C <- A.B through laser_hip's device-resident entry point
 (operands already resident in HBM; the PCIe-inclusive host-pointer rate is reported in DESIGN.md,
@@ -22,6 +23,12 @@ import json
 import os
 import sys
 import time
+
+# Thread placement for the CPU baseline's OpenMP team: must be in the environment before the first OpenMP runtime of this
+# process initialises (torch / numpy load one on import).  Without it Laser's nest -- ceil(M/192) ic tasks + jr tasks over
+# two sockets -- migrates between cores and its timing swings by an order of magnitude (r02: 291 vs 3772 GFLOP/s).
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -62,13 +69,13 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(samples=5):
+def cpu_baseline(samples=3):
     """Laser's OpenMP CPU path (the oracle's C restatement, kind "port") on the FULL 8192^3 job, the reference's own
-    protocol (benchmarks/gemm/gemm_bench_float32.nim:8-40,57: warm-up, then N timed samples of the whole product,
-    mean / min / max / stddev like printStats): OMP_NUM_THREADS = the host's physical cores, 1 warm-up + `samples`
-    samples.  Laser's nest exposes only ceil(M/192) ic tasks + jr tasks behind a serial pc loop (gemm.nim:150-176), so
-    "all cores" is not its best team on a 128-core host: the best of a small team-size calibration is reported beside
-    it (side field `calibrated`), never as `value`."""
+    protocol (benchmarks/gemm/gemm_bench_float32.nim:8-40,57: warm-up, then timed samples of the whole product, mean /
+    min / max / stddev like printStats), threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores).  Two team sizes with equal
+    prominence: every physical core (`all_physical_cores`) and the best team of a short calibration (`best_team`) --
+    Laser's nest exposes only ceil(M/192) = 43 ic tasks (+ jr tasks) behind a serial pc loop (gemm.nim:150-176), so on a
+    128-core two-socket host "all cores" is far from its best team.  `value` / `cores` quote the best team."""
     import numpy as np
     from oracle import oracle
     oracle.build()
@@ -85,22 +92,21 @@ def cpu_baseline(samples=5):
         oracle.gemm_strided(rows, n, n, 1.0, A, n, 1, B, n, 1, 0.0, C, n, 1, isa=isa)
         return time.perf_counter() - t0
 
-    def stats(ts):
+    def stats(ts, threads):
         mean = sum(ts) / len(ts)
         sd = (sum((t - mean) ** 2 for t in ts) / max(1, len(ts) - 1)) ** 0.5
-        return {"mean_s": round(mean, 4), "min_s": round(min(ts), 4), "max_s": round(max(ts), 4), "stddev_s": round(sd, 4)}
+        return {"threads": threads, "gflops": round(flop / mean / 1e9, 1), "mean_s": round(mean, 4), "min_s": round(min(ts), 4),
+                "max_s": round(max(ts), 4), "stddev_s": round(sd, 4), "samples": len(ts)}
 
     ncpu, model = host_info()
     cores = min(physical_cores(), oracle.num_threads())
     oracle.set_num_threads(cores)
     run(192)                      # page faults, thread pool
     run()                         # the warm-up sample
-    ts = [run() for _ in range(samples)]
-    st = stats(ts)
-    gflops = flop / st["mean_s"] / 1e9
-    # side field: team-size calibration on 1920 rows (10 ic tasks), then the same protocol at the best team size
+    all_cores = stats([run() for _ in range(samples)], cores)
+    # team-size calibration on 1920 rows (10 ic tasks), then the same protocol at the best team size
     best = None
-    for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 32), min(cores, 16)}):
+    for th in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 32), min(cores, 16), min(cores, 8)}):
         oracle.set_num_threads(th)
         run(1920)
         t_cal = min(run(1920) for _ in range(2))
@@ -108,27 +114,238 @@ def cpu_baseline(samples=5):
             best = (th, t_cal)
     oracle.set_num_threads(best[0])
     run()
-    tc = [run() for _ in range(samples)]
-    sc = stats(tc)
+    best_team = stats([run() for _ in range(samples)], best[0]) if best[0] != cores else dict(all_cores)
     names = {0: "generic", 1: "sse", 2: "sse2", 3: "sse4.1", 4: "avx", 5: "avx+fma", 6: "avx2", 7: "avx512"}
     # the reference's own comparator ("vendor BLAS", gemm_bench_float32.nim:191-197): numpy == OpenBLAS
     _ = A[:512] @ B
     tb = []
-    for _ in range(3):
+    for _ in range(2):
         t0 = time.perf_counter()
         _ = A @ B
         tb.append(time.perf_counter() - t0)
     blas_gflops = flop / (sum(tb) / len(tb)) / 1e9
     log(f"[cpu_baseline] host: {ncpu} logical / {physical_cores()} physical CPUs, {model}; isa {names.get(isa)}; "
-        f"{cores} threads: {gflops:.1f} GFLOP/s (mean of {samples}); best team {best[0]}: "
-        f"{flop / sc['mean_s'] / 1e9:.1f} GFLOP/s; numpy/OpenBLAS {blas_gflops:.1f} GFLOP/s")
-    return {"value": round(gflops, 2), "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "stats": dict(st, samples=samples, gflops_at_min=round(flop / st["min_s"] / 1e9, 1)),
-            "calibrated": dict(sc, threads=best[0], gflops=round(flop / sc["mean_s"] / 1e9, 1), samples=samples),
-            "openblas_same_job_gflops": round(blas_gflops, 1),
-            "sample": f"the whole {n}^3 sgemm (M=N=K={n}), 1 warm-up + {samples} timed samples, Laser's algorithm restated in C "
-                      f"(oracle/), OpenMP {cores} threads = physical cores, ukernel {names.get(isa)}, "
-                      f"{st['mean_s']:.2f} s per sample; host {model}"}
+        f"{cores} threads: {all_cores['gflops']:.1f} GFLOP/s; best team {best[0]}: {best_team['gflops']:.1f} GFLOP/s; "
+        f"numpy/OpenBLAS {blas_gflops:.1f} GFLOP/s")
+    return {"value": best_team["gflops"], "unit": "GFLOP/s", "cores": best_team["threads"], "kind": "port",
+            "best_team": best_team, "all_physical_cores": all_cores, "openblas_same_job_gflops": round(blas_gflops, 1),
+            "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+            "sample": f"the whole {n}^3 sgemm (M=N=K={n}), 1 warm-up + {samples} timed samples per team, Laser's algorithm restated in "
+                      f"C (oracle/), ukernel {names.get(isa)}, threads pinned to cores; `value` = the best team of a calibration over "
+                      f"{{all, 1/2, 1/4, 32, 16, 8}} threads ({best_team['threads']} threads, {best_team['mean_s']:.2f} s per sample), "
+                      f"`all_physical_cores` = {cores} threads ({all_cores['mean_s']:.2f} s): Laser's loop nest offers only "
+                      f"ceil(M/192) = {(n + 191) // 192} row-block tasks per kc slice, so large teams mostly wait; host {model}"}
+
+
+def side_configs(budget_s=10.0):
+    """BASELINE.json's other single-GPU configs and the reference's own published shapes, one compact line each (ms, TFLOP/s,
+    fraction of the fp32 MFMA peak, and the oracle's CPU time for the same call beside it): C1 128^3, the reference's
+    headline 1920^3 (benchmarks/gemm/gemm_bench_float32.nim:383-410), C3 4096^3 with B transposed, C4 conv pad 1, and the
+    reference's conv bench geometry (16,3,224,224) * (20,3,3,3) pad 0 (benchmarks/convolution/conv2d_bench.nim:130-170)."""
+    import numpy as np
+    import torch
+    import laser_amd
+    from oracle import oracle
+    oracle.build()
+    out = []
+    t_start = time.perf_counter()
+
+    def gpu_ms(fn, inner=4, reps=3):
+        fn(); fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(inner):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / inner)
+        return sorted(ts)[len(ts) // 2]
+
+    def rnd(shape, seed, lo=-0.1, hi=0.1):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        return torch.rand(shape, generator=g, device="cuda") * (hi - lo) + lo
+
+    def cpu_s(fn):
+        if time.perf_counter() - t_start > budget_s:
+            return None
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        return round(time.perf_counter() - t0, 4)
+
+    def gemm_line(name, M, N, K, A, B, C):
+        ms = gpu_ms(lambda: laser_amd.matmul(A, B, 1, 0, C))
+        tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+        Ah, Bh = A.cpu().numpy(), B.cpu().numpy()
+        cs = cpu_s(lambda: oracle.matmul(Ah, Bh))
+        out.append({"config": name, "ms": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "cpu_oracle_s": cs})
+
+    try:
+        gemm_line("C1 fp32 128^3 (device-resident; launch-bound)", 128, 128, 128, rnd((128, 128), 1), rnd((128, 128), 2),
+                  torch.zeros((128, 128), device="cuda"))
+        n = 1920
+        gemm_line("fp32 1920^3 (the reference's published shape)", n, n, n, rnd((n, n), 3), rnd((n, n), 4), torch.zeros((n, n), device="cuda"))
+        n = 4096
+        gemm_line("C3 fp32 4096^3, B transposed (rowStrideB=1, colStrideB=K)", n, n, n, rnd((n, n), 5), rnd((n, n), 6).t(),
+                  torch.zeros((n, n), device="cuda"))
+        for name, ishape, kshape, pad in (("C4 conv (32,128,56,56)*(256,128,3,3) pad 1", (32, 128, 56, 56), (256, 128, 3, 3), (1, 1)),
+                                         ("reference conv bench (16,3,224,224)*(20,3,3,3) pad 0", (16, 3, 224, 224), (20, 3, 3, 3), (0, 0))):
+            st = (1, 1)
+            x, w = rnd(ishape, 7, 0, 1), rnd(kshape, 8, 0, 1)
+            oshape = laser_amd.conv2d_out_shape(ishape, kshape, pad, st)
+            o = torch.zeros(oshape, device="cuda")
+            ms = gpu_ms(lambda: laser_amd.conv2d_im2col(o, oshape, x, ishape, w, kshape, pad, st, None))
+            fl = 2.0 * oshape[0] * oshape[1] * oshape[2] * oshape[3] * kshape[1] * kshape[2] * kshape[3]
+            tf = fl / (ms * 1e-3) / 1e12
+            xh, wh = x.cpu().numpy(), w.cpu().numpy()
+            cs = cpu_s(lambda: oracle.conv2d_im2col(xh, wh, pad, st))
+            out.append({"config": name, "ms": round(ms, 4), "tflops": round(tf, 2), "frac_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "cpu_oracle_s": cs})
+    except Exception as e:      # a side line must never cost the headline
+        out.append({"error": f"{type(e).__name__}: {e}"[:300]})
+    return out
+
+
+def single_process_primary(args):
+    """`python bench.py --gpus N` without torchrun: ONE process drives the N GPUs through the product boundary --
+    laser_hip_gemm_strided_f32_sharded_dev (block-cyclic row panels of A, B replicated, C gathered on every GPU inside
+    the timed region; the parallelism lives inside one call, like gemm.nim:160-176).  Weak scaling: M = size * N."""
+    import torch
+    import laser_amd
+    ndev, n = args.gpus, args.size
+    one_gpu = os.environ.get("LASER_BENCH_ONE_GPU") == "1"   # test hook: every device slot on GPU 0 (timings meaningless)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; laser_amd has no CPU fallback")
+    if not one_gpu and torch.cuda.device_count() < ndev:
+        raise SystemExit(f"--gpus {ndev} but only {torch.cuda.device_count()} GPUs are visible")
+    devices = [0] * ndev if one_gpu else list(range(ndev))
+    laser_amd._lib.check(laser_amd.lib().laser_hip_init(0))
+    if args.mode is not None:
+        laser_amd.set_float_mode(0 if args.mode == "laser_order" else 1)
+    laser_amd.set_f32_config(args.cfg)
+    mode = "laser_order" if laser_amd.get_float_mode() == 0 else "fast"
+    M, N, K = n * ndev, n, n
+    tdev = [torch.device("cuda", d) for d in devices]
+
+    def hashed(dev, rows, cols, salt):
+        r = torch.as_tensor(rows, dtype=torch.int64, device=dev).view(-1, 1)
+        c = torch.arange(cols, dtype=torch.int64, device=dev).view(1, -1)
+        h = (r * 2654435761 + c * 40503 + salt) & 0xFFFFFFFF
+        h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+        h = (h ^ (h >> 13)) * 3266489917 & 0xFFFFFFFF
+        h = h ^ (h >> 16)
+        return ((h & 0xFFFFFF).to(torch.float32) / 16777216.0 - 0.5) * 0.2
+
+    Bs = [hashed(tdev[g], range(K), N, 7) for g in range(ndev)]
+    gm = {"none": laser_amd.GATHER_NONE, "peer": laser_amd.GATHER_PEER, "rccl": laser_amd.GATHER_RCCL}
+
+    def build(ppd):
+        rows, ppd_used, padded = laser_amd.shard_plan(M, ndev, ppd)
+        Ap, Cs = [], []
+        for g in range(ndev):
+            a = torch.zeros((ppd_used * rows, K), dtype=torch.float32, device=tdev[g])
+            for s_ in range(ppd_used):
+                start = (s_ * ndev + g) * rows
+                valid = max(0, min(rows, M - start))
+                if valid > 0:
+                    a[s_ * rows: s_ * rows + valid] = hashed(tdev[g], range(start, start + valid), K, 1)
+            Ap.append(a)
+            Cs.append(torch.zeros((padded, N), dtype=torch.float32, device=tdev[g]))
+        return rows, ppd_used, Ap, Cs
+
+    def call(Ap, Cs, ppd, gather):
+        laser_amd.gemm_strided_sharded_dev(devices, M, N, K, 1.0, Ap, K, 1, Bs, N, 1, 0.0, Cs, N, ppd, gm[gather], 0)
+
+    # untimed calibration of the two box questions (panels per GPU; transport of the gather), 1 + 2 steps per candidate
+    cands = [(args.panels_per_rank, "peer")] if args.panels_per_rank > 0 else [(4, "peer"), (8, "peer")]
+    if ndev > 1 and not one_gpu and args.panels_per_rank <= 0:
+        cands += [(4, "rccl"), (8, "rccl")]
+    if ndev == 1:
+        cands = [(1, "peer")]
+    calibration = []
+    for ppd, gather in cands:
+        rec = {"panels_per_dev": ppd, "gather": gather}
+        try:
+            _, _, Ap, Cs = build(ppd)
+            call(Ap, Cs, ppd, gather)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                call(Ap, Cs, ppd, gather)
+            rec["ms_per_step"] = round((time.perf_counter() - t0) / 2 * 1e3, 4)
+            del Ap, Cs
+        except Exception as e:
+            rec["error"] = f"{type(e).__name__}: {e}"[:200]
+        calibration.append(rec)
+    good = [r for r in calibration if "ms_per_step" in r]
+    if not good:
+        raise SystemExit(f"no sharded configuration ran: {calibration}")
+    pick = min(good, key=lambda r: r["ms_per_step"])
+    ppd, gather = pick["panels_per_dev"], pick["gather"]
+    rows, ppd_used, Ap, Cs = build(ppd)
+    for _ in range(args.warmup):
+        call(Ap, Cs, ppd, gather)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call(Ap, Cs, ppd, gather)          # synchronous: returns when every GPU holds all of C
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    wall = time.perf_counter() - t0
+    # self-check on every device: a few rows owned by EVERY slot (only right if the gather delivered them), vs fp64
+    err = 0.0
+    for g in range(ndev):
+        chk = []
+        for r_ in range(ndev):
+            start = ((ppd_used - 1) * ndev + r_) * rows
+            chk += list(range(start, min(M, start + 2))) + list(range(r_ * rows, min(M, r_ * rows + 2)))
+        ref = hashed(tdev[g], chk, K, 1).double() @ Bs[g].double()
+        err = max(err, (Cs[g][chk].double() - ref).abs().max().item())
+    assert err < 1e-4, f"bench self-check failed: max abs err {err}"
+    # roofline: the GEMM kernel alone on device slot 0 (its n-row share as one launch), HIP events on the launch stream
+    torch.cuda.set_device(devices[0])
+    Cl = torch.zeros((n, N), dtype=torch.float32, device=tdev[0])
+    Al = Ap[0][:n]
+    for _ in range(2):
+        laser_amd.matmul(Al, Bs[0], 1, 0, Cl)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        laser_amd.matmul(Al, Bs[0], 1, 0, Cl)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / args.steps
+    fl = 2.0 * n * N * K
+    ach = fl / (k_ms * 1e-3) / 1e12
+    value = 2.0 * M * N * K / (wall / args.steps) / 1e9
+    out = {
+        "metric": "sgemm GFLOP/s and %MFMA-peak, M=N=K=8192, 1/2/4/8 MI355X",
+        "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"fp32 sgemm M={M} N={N} K={K} row-panel sharded over {ndev}xMI355X in ONE process, C gathered on every GPU "
+                        f"inside the timed region (BASELINE configs[4] shape at 8 GPUs)",
+            "entry_point": "laser_hip_gemm_strided_f32_sharded_dev (C-ABI; one host thread per GPU inside the call)",
+            "M": M, "N": N, "K": K, "accumulation": mode, "panels_per_dev": ppd_used, "rows_per_panel": rows, "gather": gather,
+            "parallelism": f"row-panels x{ndev}, {ppd_used} block-cyclic panels/GPU",
+            "pct_of_fp32_mfma_peak": round(100.0 * value / 1e3 / (FP32_MFMA_PEAK_TFLOPS * ndev), 2),
+            "calibration_untimed": calibration, "max_abs_err_vs_fp64": err,
+            "device_slots": "all on GPU 0 (LASER_BENCH_ONE_GPU test hook: timings meaningless)" if one_gpu else devices,
+        },
+        "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)"}.get(
+                         laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
+                     "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": fl,
+                     "note": "per-GPU kernel alone (device slot 0's row share as one launch), timed after the sharded run"},
+    }
+    print(json.dumps(out), flush=True)
 
 
 def kernel_source_sha16():
@@ -251,6 +468,7 @@ def main():
                     help="N > 1: all-gather of C as one collective per slab, as grouped point-to-point sends, or (auto) whichever the "
                          "untimed calibration measures faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the compact per-config side field (C1, 1920^3, C3, C4, the reference's conv shape)")
     ap.add_argument("--single-process", type=int, default=0, metavar="NDEV",
                     help="run ONLY the single-process sharded entry point of the C-ABI over NDEV GPUs and print its JSON")
     ap.add_argument("--no-single-process", action="store_true", help="skip the single-process sharded side measurement")
@@ -272,10 +490,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        return single_process_primary(args)     # plain `bench.py --gpus N`: one process, the C-ABI's sharded entry point
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; laser_amd has no CPU fallback")
@@ -500,6 +717,8 @@ def main():
             out["config"]["other_mode"] = {"accumulation": "fast" if other == 1 else "laser_order",
                                            "ms_per_step": round(o_ms, 4), "gflops": round(o_tf * 1e3, 1),
                                            "frac_mfma_peak": round(o_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+            if not args.no_side_configs:
+                out["configs"] = side_configs()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         else:

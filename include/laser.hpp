@@ -292,6 +292,30 @@ void forEachMap(int op, Tensor<T> &dst, const Tensor<T> &a, const Tensor<T> &b, 
 // the node behind an unchanged host-pointer gemm_strided call (0 = every visible GPU, 1 = off)
 inline void set_shard_devices(int ndev) { check(laser_hip_set_shard_devices(ndev)); }
 
+// One gemm_strided over every GPU with the operands resident in HBM and C all-gathered over xGMI
+// (laser_hip_gemm_strided_*_sharded_dev): block-cyclic row panels, no K split -- bit-identical to one GPU.
+struct ShardPlan {
+  int64_t rows_per_panel = 0, padded_M = 0;
+  int panels_per_dev = 0;
+};
+inline ShardPlan shard_plan(int64_t M, int ndev, int panels_per_dev = 4) {
+  ShardPlan p;
+  check(laser_hip_shard_plan(M, ndev, panels_per_dev, &p.rows_per_panel, &p.panels_per_dev, &p.padded_M));
+  return p;
+}
+template <typename T>
+void gemm_strided_sharded_dev(const std::vector<int> &devices, int64_t M, int64_t N, int64_t K, T alpha,
+                              const std::vector<const T *> &dA_panels, int64_t rsA, int64_t csA, const std::vector<const T *> &dB,
+                              int64_t rsB, int64_t csB, T beta, const std::vector<T *> &dC, int64_t rsC, int panels_per_dev = 4,
+                              int gather = LASER_HIP_GATHER_PEER, int flags = 0) {
+  if (dA_panels.size() != devices.size() || dB.size() != devices.size() || dC.size() != devices.size())
+    throw Error(LASER_HIP_E_INVALID, "gemm_strided_sharded_dev: one pointer per device slot");
+#define LASER_ARGS (int)devices.size(), devices.data(), M, N, K, alpha, dA_panels.data(), rsA, csA, dB.data(), rsB, csB, beta, dC.data(), rsC, panels_per_dev, gather, flags
+  LASER_DISPATCH(T, check(laser_hip_gemm_strided_f32_sharded_dev(LASER_ARGS)), check(laser_hip_gemm_strided_f64_sharded_dev(LASER_ARGS)),
+                 check(laser_hip_gemm_strided_i32_sharded_dev(LASER_ARGS)), check(laser_hip_gemm_strided_i64_sharded_dev(LASER_ARGS)))
+#undef LASER_ARGS
+}
+
 // C (M x N) = alpha * A (M x K) * B (K x N) + beta * C on 2-D Tensors of any strides, all device-resident
 template <typename T>
 void gemm(T alpha, const Tensor<T> &A, const Tensor<T> &B, T beta, Tensor<T> &C) {

@@ -92,6 +92,8 @@ DeviceCtx g_dev[kMaxDevices];
 // The device a host-pointer call on this thread uses: -1 = the library's default device (laser_hip_init); the
 // sharded entry points set it in their per-device worker threads.
 thread_local int tl_device = -1;
+thread_local int tl_f32_cfg = -2;  // per-thread override of g_ctx.f32_cfg (-2 = none), api_set_thread_f32_config
+inline int f32_cfg_now() { return tl_f32_cfg >= -1 ? tl_f32_cfg : g_ctx.f32_cfg.load(); }
 thread_local DeviceCtx *tl_dev = nullptr;  // valid while a HostCall guard is alive
 
 int ensure_init_locked(int device) {
@@ -135,7 +137,10 @@ struct HostCall {
   int rc = LASER_HIP_OK;
   DeviceCtx *d = nullptr;
   DeviceCtx *prev = nullptr;
+  int caller_dev = -1;  // the caller's current device, restored on exit: an application thread driving another GPU must
+                        // not find itself on the library's device after a host-pointer call
   HostCall() {
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
     const int dev = tl_device >= 0 ? tl_device : g_ctx.device;
     if (dev < 0 || dev >= kMaxDevices) {
       rc = fail(LASER_HIP_E_INVALID, "device %d outside 0..%d", dev, kMaxDevices - 1);
@@ -157,6 +162,7 @@ struct HostCall {
       tl_dev = prev;
       d->mu.unlock();
     }
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
   }
   HostCall(const HostCall &) = delete;
   HostCall &operator=(const HostCall &) = delete;
@@ -214,7 +220,7 @@ void view_span(int64_t R, int64_t C, int64_t rs, int64_t cs, int64_t *lo, int64_
 }
 
 hipError_t launch_tiled(const GemmArgs<float> &a, hipStream_t s) {
-  return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+  return launch_gemm_f32(a, f32_cfg_now(), g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 hipError_t launch_tiled(const GemmArgs<double> &a, hipStream_t s) {
   return launch_gemm_f64(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
@@ -315,7 +321,7 @@ hipError_t run_gemm_peeled(const GemmArgs<T> &a, int kc, bool laser, bool *taken
 
 template <>
 hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
-  if (g_ctx.f32_cfg < 0) {
+  if (f32_cfg_now() < 0) {
     bool taken;
     const hipError_t e = run_gemm_peeled<float>(a, 512, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, &taken, s);
     if (taken) return e;
@@ -333,24 +339,24 @@ hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
 }
 template <>
 hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s) {
-  if (g_ctx.f32_cfg < 0 && g_ctx.skinny) {  // matrix-vector-like shapes: an HBM stream, not a tile problem
+  if (f32_cfg_now() < 0 && g_ctx.skinny) {  // matrix-vector-like shapes: an HBM stream, not a tile problem
     const hipError_t e = launch_gemm_skinny<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
-  if (g_ctx.f32_cfg < 0) {  // few 32x32 blocks / batches of tiny matrices: one wave per block, no LDS round trips
+  if (f32_cfg_now() < 0) {  // few 32x32 blocks / batches of tiny matrices: one wave per block, no LDS round trips
     const hipError_t e = launch_gemm_small<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
-  if (g_ctx.f32_cfg < 0) {
+  if (f32_cfg_now() < 0) {
     const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
   g_last_f32_asm = 0;
-  if (g_ctx.f32_cfg < 0) {  // large row-major-like products: the hand-scheduled assembly kernels (one wave per SIMD)
+  if (f32_cfg_now() < 0) {  // large row-major-like products: the hand-scheduled assembly kernels (one wave per SIMD)
     const hipError_t e = launch_gemm_f32_asm(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
     if (e != hipErrorNotSupported) return e;
   }
-  return launch_gemm_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+  return launch_gemm_f32(a, f32_cfg_now(), g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 template <>
 hipError_t run_gemm_core<double>(const GemmArgs<double> &a, hipStream_t s) {
@@ -731,7 +737,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t ab = up(an * sizeof(T)), bb = up(bn * sizeof(T)), cb = up(cn * sizeof(T));
     const bool has_epi = hepi && (hepi->bias || hepi->act);
-    if (!has_epi && g_ctx.f32_cfg < 0 && ab + bb + cb <= kZeroCopyMax && gemm_small_takes((int)sizeof(T), M, N, K, 1, true) &&
+    if (!has_epi && f32_cfg_now() < 0 && ab + bb + cb <= kZeroCopyMax && gemm_small_takes((int)sizeof(T), M, N, K, 1, true) &&
         std::is_floating_point<T>::value) {
       // completion flags, one per workgroup (= per 32x32 / 16x16 block of C; at most 256 by the dispatch rule), behind C
       const int mb = sizeof(T) == 4 ? 32 : 16;
@@ -742,6 +748,9 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
       if (int rc = pipeline_streams()) return rc;
       T *hA = (T *)z, *hB = (T *)((char *)z + ab), *hC = (T *)((char *)z + ab + bb);
       volatile uint32_t *flags = (volatile uint32_t *)((char *)z + ab + bb + cb);
+      // the flag words sit where an earlier call of another shape kept payload: a stale word that happens to equal this
+      // call's sequence number would read as "block done" -- clear them before the launch
+      for (size_t i = 0; i < nblk; i++) flags[i] = 0;
       memcpy(hA, A + alo, an * sizeof(T));
       memcpy(hB, B + blo, bn * sizeof(T));
       const bool c_in = (beta != (T)0) || cn != (size_t)M * (size_t)N;  // read, or a span with gaps that belong to the caller
@@ -1073,7 +1082,7 @@ int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, 
     a.cH = (int32_t)iH; a.cW = (int32_t)iW; a.ckH = (int32_t)kH; a.ckW = (int32_t)kW; a.coW = (int32_t)oW;
     a.cpH = (int32_t)pH; a.cpW = (int32_t)pW; a.csH = (int32_t)sH; a.csW = (int32_t)sW;
     epi_apply(a, &epi);
-    HIP_TRY(launch_conv_implicit_f32(a, g_ctx.f32_cfg, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s));
+    HIP_TRY(launch_conv_implicit_f32(a, f32_cfg_now(), g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s));
     return LASER_HIP_OK;
   }
   const float *Bm = din;
@@ -1158,6 +1167,7 @@ int api_fail(int code, const char *fmt, ...) {
 }
 int api_ensure_init() { return ensure_init(); }
 void api_set_thread_device(int device) { tl_device = device; }
+void api_set_thread_f32_config(int cfg) { tl_f32_cfg = cfg; }
 int api_thread_device() { return tl_device; }
 }  // namespace laser_hip
 
@@ -1169,10 +1179,11 @@ int laser_hip_init(int device) {
 }
 
 int laser_hip_finalize(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  // lock order everywhere: a device's mutex BEFORE g_mu (the host-pointer entry points hold their device's mutex when
+  // they touch the registries) -- so the per-device state is released first, one device at a time, then the registries
   for (DeviceCtx &D : g_dev) {
-    if (D.device < 0) continue;
     std::lock_guard<std::mutex> dl(D.mu);
+    if (D.device < 0) continue;
     (void)hipSetDevice(D.device);
     for (int i = 0; i < 6; i++) {
       if (D.scratch[i]) (void)hipFree(D.scratch[i]);
@@ -1190,6 +1201,7 @@ int laser_hip_finalize(void) {
     D.zc_sz = 0;
     D.device = -1;
   }
+  std::lock_guard<std::mutex> lk(g_mu);
   if (g_ctx.device >= 0) (void)hipSetDevice(g_ctx.device);
   for (auto &kv : g_panels) (void)hipFree(kv.second.ptr);
   g_panels.clear();

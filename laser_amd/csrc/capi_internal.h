@@ -11,6 +11,9 @@ int api_ensure_init();
 // host path sets it in its per-GPU worker threads.
 void api_set_thread_device(int device);
 int api_thread_device();
+// Tile-configuration override for the f32 launches made BY THIS THREAD (-2 = none: the process-wide setting applies).
+// The sharded entry point's workers use it to pin the 128x128 tile for one call without touching global state.
+void api_set_thread_f32_config(int cfg);
 // sharded.cpp: host-pointer gemm_strided cut into one row range per GPU (ndev <= 0: every visible GPU)
 template <typename T>
 int api_sharded_host(int ndev, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *B,

@@ -27,7 +27,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -151,6 +154,7 @@ struct Rccl {
   void *h = nullptr;
   int (*CommInitAll)(ncclComm_t_ *, int, const int *) = nullptr;
   int (*CommDestroy)(ncclComm_t_) = nullptr;
+  int (*CommAbort)(ncclComm_t_) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -171,6 +175,7 @@ int rccl_load() {
   if (!g_rccl.field) return api_fail(LASER_HIP_E_INVALID, "librccl.so has no symbol %s", name);
   LD(CommInitAll, "ncclCommInitAll")
   LD(CommDestroy, "ncclCommDestroy")
+  LD(CommAbort, "ncclCommAbort")
   LD(AllGather, "ncclAllGather")
   LD(GroupStart, "ncclGroupStart")
   LD(GroupEnd, "ncclGroupEnd")
@@ -193,6 +198,32 @@ int rccl_comms(const std::vector<int> &dev) {
   }
   g_rccl.devs = dev;
   return LASER_HIP_OK;
+}
+
+// A rank failed (or the bounded wait expired) while collectives may still be pending: abort every communicator so no
+// peer stays blocked inside ncclAllGather, and drop the cache -- the next call builds fresh communicators.
+void rccl_abort_all() {
+  for (auto c : g_rccl.comms)
+    if (c) (void)g_rccl.CommAbort(c);
+  g_rccl.comms.clear();
+  g_rccl.devs.clear();
+}
+
+// Bounded wait for a stream: hipStreamSynchronize can block forever when a peer never enters a collective.
+// LASER_HIP_SHARD_TIMEOUT_S (default 120) seconds, then hipErrorTimeout.
+hipError_t sync_bounded(hipStream_t s) {
+  static const double limit = [] {
+    const char *e = getenv("LASER_HIP_SHARD_TIMEOUT_S");
+    const double v = e ? atof(e) : 120.0;
+    return v > 0 ? v : 120.0;
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return hipErrorLaunchTimeOut;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
 }
 
 constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclInt32 = 2, kNcclInt64 = 4;  // ncclDataType_t (rccl.h)
@@ -244,7 +275,9 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
   int prev_dev = 0;
   (void)hipGetDevice(&prev_dev);
   if (gather == LASER_HIP_GATHER_PEER && ndev > 1) enable_peers(dev);
-  if (gather == LASER_HIP_GATHER_RCCL && ndev > 1) {
+  // (RCCL also with ONE rank: a 1-rank communicator runs the same dlopen / ncclCommInitAll / in-place pointer arithmetic
+  // as 8 ranks do, so a single-GPU box exercises this transport)
+  if (gather == LASER_HIP_GATHER_RCCL) {
     if (int rc = rccl_comms(dev)) return rc;
   }
   for (int g = 0; g < ndev; g++)
@@ -253,33 +286,42 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
       return rc;
     }
   // the local products may be pinned to the 128x128 tile (RCCL's kernels hold CUs while the next panel multiplies)
+  // The pin is per CALL: every worker thread sets a thread-local override that only its own launches read -- the
+  // process-wide configuration (and any concurrent caller's kernel choice) is never touched.
   const bool pin = (flags & LASER_HIP_SHARD_PIN_TILE) != 0 && std::is_same<T, float>::value;
   const int pin_cfg = 2;  // 128x128x16_w2x2_s3 (gemm_mfma_cfgs.h)
-  if (pin) (void)laser_hip_set_f32_config(pin_cfg);
+  std::atomic<bool> failed{false};
 
   std::vector<int> rc(ndev, LASER_HIP_OK);
   std::vector<std::string> msg(ndev);
   auto worker = [&](int g) {
+    // A failing rank records its error and KEEPS GOING through the remaining collectives (without its products): its
+    // peers are inside the same sequence of ncclAllGather calls and would otherwise wait for it forever.  The call as a
+    // whole reports the error; C is then unspecified.
     auto bail = [&](int code) {
-      rc[g] = code;
-      msg[g] = laser_hip_last_error();
+      if (rc[g] == LASER_HIP_OK) {
+        rc[g] = code;
+        msg[g] = laser_hip_last_error();
+      }
+      failed = true;
     };
     RankCtx &R = g_rank[g];
     hipError_t e = hipSetDevice(dev[g]);
-    if (e != hipSuccess) return bail(api_fail(LASER_HIP_E_HIP, "hipSetDevice(%d): %s", dev[g], hipGetErrorString(e)));
+    if (e != hipSuccess) bail(api_fail(LASER_HIP_E_HIP, "hipSetDevice(%d): %s", dev[g], hipGetErrorString(e)));
+    if (pin) api_set_thread_f32_config(pin_cfg);
     for (int s = 0; s < plan.ppd; s++) {
       int64_t start, valid;
       plan.panel(s, g, &start, &valid);
-      if (valid > 0) {
+      if (valid > 0 && rc[g] == LASER_HIP_OK) {
         const int r = Api<T>::dev(valid, N, K, alpha, dA[g] + (int64_t)s * plan.rows * rsA, rsA, csA, dB[g], rsB, csB, beta,
                                   dC[g] + start * rsC, rsC, 1, R.comp);
-        if (r != LASER_HIP_OK) return bail(r);
+        if (r != LASER_HIP_OK) bail(r);
       }
-      if (ndev == 1 || gather == LASER_HIP_GATHER_NONE) continue;
+      if (gather == LASER_HIP_GATHER_NONE || (ndev == 1 && gather != LASER_HIP_GATHER_RCCL)) continue;
       e = hipEventRecord(R.ev[s], R.comp);
-      if (e != hipSuccess) return bail(api_fail(LASER_HIP_E_HIP, "hipEventRecord: %s", hipGetErrorString(e)));
+      if (e != hipSuccess) bail(api_fail(LASER_HIP_E_HIP, "hipEventRecord: %s", hipGetErrorString(e)));
       if (gather == LASER_HIP_GATHER_PEER) {
-        if (valid <= 0) continue;
+        if (valid <= 0 || rc[g] != LASER_HIP_OK) continue;
         for (int p = 0; p < ndev; p++) {
           if (p == g) continue;
           e = hipStreamWaitEvent(R.peer[p], R.ev[s], 0);
@@ -291,24 +333,31 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
               e = hipMemcpy2DAsync(dC[p] + start * rsC, (size_t)rsC * sizeof(T), dC[g] + start * rsC, (size_t)rsC * sizeof(T),
                                    (size_t)N * sizeof(T), (size_t)valid, hipMemcpyDeviceToDevice, R.peer[p]);
           }
-          if (e != hipSuccess) return bail(api_fail(LASER_HIP_E_HIP, "peer copy %d -> %d: %s", dev[g], dev[p], hipGetErrorString(e)));
+          if (e != hipSuccess) {
+            bail(api_fail(LASER_HIP_E_HIP, "peer copy %d -> %d: %s", dev[g], dev[p], hipGetErrorString(e)));
+            break;
+          }
         }
       } else {  // RCCL: in-place all-gather of slab s (sub-panel s of every rank = one contiguous block of C)
         e = hipStreamWaitEvent(R.comm, R.ev[s], 0);
-        if (e != hipSuccess) return bail(api_fail(LASER_HIP_E_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)));
+        if (e != hipSuccess) bail(api_fail(LASER_HIP_E_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)));
         T *slab = dC[g] + (int64_t)s * ndev * plan.rows * N;
         const int r = g_rccl.AllGather(slab + (int64_t)g * plan.rows * N, slab, (size_t)plan.rows * N, NcclType<T>::v,
                                        g_rccl.comms[g], R.comm);
-        if (r != 0) return bail(api_fail(LASER_HIP_E_HIP, "ncclAllGather (rank %d): %s", g, g_rccl.GetErrorString(r)));
+        if (r != 0) {  // the collective itself is broken: nobody may wait for it
+          bail(api_fail(LASER_HIP_E_HIP, "ncclAllGather (rank %d): %s", g, g_rccl.GetErrorString(r)));
+          break;
+        }
       }
     }
-    // this rank's GEMMs and everything it sent
-    e = hipStreamSynchronize(R.comp);
+    if (pin) api_set_thread_f32_config(-2);
+    // this rank's GEMMs and everything it sent -- bounded: a peer that never arrives must not hang the caller
+    e = sync_bounded(R.comp);
     if (e == hipSuccess && ndev > 1 && gather == LASER_HIP_GATHER_PEER)
       for (int p = 0; p < ndev && e == hipSuccess; p++)
-        if (p != g) e = hipStreamSynchronize(R.peer[p]);
-    if (e == hipSuccess && ndev > 1 && gather == LASER_HIP_GATHER_RCCL) e = hipStreamSynchronize(R.comm);
-    if (e != hipSuccess) return bail(api_fail(LASER_HIP_E_HIP, "synchronising device %d: %s", dev[g], hipGetErrorString(e)));
+        if (p != g) e = sync_bounded(R.peer[p]);
+    if (e == hipSuccess && gather == LASER_HIP_GATHER_RCCL) e = sync_bounded(R.comm);
+    if (e != hipSuccess) bail(api_fail(LASER_HIP_E_HIP, "synchronising device %d: %s", dev[g], hipGetErrorString(e)));
   };
   if (ndev == 1) {
     worker(0);
@@ -317,7 +366,7 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
     for (int g = 0; g < ndev; g++) th.emplace_back(worker, g);
     for (auto &t : th) t.join();
   }
-  if (pin) (void)laser_hip_set_f32_config(-1);
+  if (failed && gather == LASER_HIP_GATHER_RCCL) rccl_abort_all();  // pending collectives of a failed call must not outlive it
   (void)hipSetDevice(prev_dev);
   for (int g = 0; g < ndev; g++)
     if (rc[g] != LASER_HIP_OK) return api_fail(rc[g], "device slot %d: %s", g, msg[g].c_str());
@@ -335,16 +384,30 @@ int sharded_host(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t 
   if (M == 0 || N == 0 || K == 0) return LASER_HIP_OK;
   if (!A || !B || !C) return api_fail(LASER_HIP_E_INVALID, "null operand pointer");
   int ndev = (int)dev.size();
-  // whole 256-row tiles per GPU; fewer GPUs when M is small
-  int64_t rows = (M + ndev - 1) / ndev;
+  // Every worker stages the memory SPAN of its share of C (upload when the span has gaps it does not own, copy the
+  // whole span back): two workers' spans must therefore never overlap.  Row ranges are disjoint in memory only when the
+  // rows of C do not interleave (row-major-like: rsC >= |csC| * (N - 1) + 1); a column-major-like C (csC >= |rsC| *
+  // (M - 1) + 1) is cut into COLUMN ranges instead -- B and C by columns, A replicated: columns of C are as independent
+  // as rows (no K split either way, so the arithmetic does not change); anything else (overlapping or negative strides
+  // on both axes) runs on one device.
+  const auto iabs = [](int64_t v) { return v < 0 ? -v : v; };
+  const bool by_rows = rsC > 0 && rsC >= iabs(csC) * (N - 1) + 1;
+  const bool by_cols = !by_rows && csC > 0 && csC >= iabs(rsC) * (M - 1) + 1;
+  if (!by_rows && !by_cols) ndev = 1;
+  const int64_t extent = by_cols ? N : M;
+  // whole 256-wide tiles per GPU; fewer GPUs when the extent is small
+  int64_t rows = (extent + ndev - 1) / ndev;
   if (rows >= 256) rows = (rows + 255) / 256 * 256;
-  ndev = (int)std::min<int64_t>(ndev, (M + rows - 1) / rows);
+  ndev = (int)std::min<int64_t>(ndev, (extent + rows - 1) / rows);
   std::vector<int> rc(ndev, LASER_HIP_OK);
   std::vector<std::string> msg(ndev);
   auto worker = [&](int g) {
-    const int64_t r0 = (int64_t)g * rows, r1 = std::min<int64_t>(M, r0 + rows);
+    const int64_t r0 = (int64_t)g * rows, r1 = std::min<int64_t>(extent, r0 + rows);
     api_set_thread_device(dev[g]);  // the host-pointer entry point below runs on this GPU, with its own scratch / streams
-    rc[g] = Api<T>::host(r1 - r0, N, K, alpha, A + r0 * rsA, rsA, csA, B, rsB, csB, beta, C + r0 * rsC, rsC, csC);
+    if (by_cols)
+      rc[g] = Api<T>::host(M, r1 - r0, K, alpha, A, rsA, csA, B + r0 * csB, rsB, csB, beta, C + r0 * csC, rsC, csC);
+    else
+      rc[g] = Api<T>::host(r1 - r0, N, K, alpha, A + r0 * rsA, rsA, csA, B, rsB, csB, beta, C + r0 * rsC, rsC, csC);
     if (rc[g] != LASER_HIP_OK) msg[g] = laser_hip_last_error();
     api_set_thread_device(-1);
   };

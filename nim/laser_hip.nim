@@ -367,6 +367,58 @@ proc laser_hip_host_unregister(hostPtr: pointer): cint {.lh, importc: "laser_hip
 
 proc laserHipShardDevices*(ndev: int) = check laser_hip_set_shard_devices(cint(ndev))
 proc laserHipShardDevices*(): int = int(laser_hip_get_shard_devices())
+
+# ---- one gemm_strided call over every GPU, operands resident in HBM, C all-gathered over xGMI ------------------------
+# The device-resident form of the same partition: rows of C are dealt block-cyclically (`shardPlan`), device slot g holds
+# its row panels of A, all of B, and the FULL C; with a gather mode every device ends up with all of C -- sub-panel s is
+# sent (peer copies on every xGMI link at once, or RCCL's ncclAllGather) while sub-panel s+1 multiplies.  No K split, so
+# every element is computed exactly as on one GPU (gemm.nim:160-176 partitions M the same way across threads).
+type
+  ShardGather* = enum
+    gatherNone = 0, gatherPeer = 1, gatherRccl = 2
+  ShardPlan* = object
+    rowsPerPanel*: int   ## rows of one (sub-panel, device) block; a multiple of 256 when M allows
+    panelsPerDev*: int   ## sub-panels per device actually used
+    paddedM*: int        ## rows the per-device C buffers must hold for gatherRccl (whole panels)
+const shardPinTile* = 1  ## flags: 128x128 tiles for the local products (RCCL's kernels hold CUs meanwhile)
+
+proc laser_hip_shard_plan(M: int, ndev, panelsPerDev: cint, rowsPerPanel: ptr int, panelsPerDevUsed: ptr cint, paddedM: ptr int): cint {.lh, importc: "laser_hip_shard_plan".}
+proc laser_hip_gemm_strided_f32_sharded_dev(ndev: cint, devices: ptr cint, M, N, K: int, alpha: float32, dA: ptr pointer, rsA, csA: int, dB: ptr pointer, rsB, csB: int, beta: float32, dC: ptr pointer, rsC: int, panelsPerDev, gather, flags: cint): cint {.lh, importc: "laser_hip_gemm_strided_f32_sharded_dev".}
+proc laser_hip_gemm_strided_f64_sharded_dev(ndev: cint, devices: ptr cint, M, N, K: int, alpha: float64, dA: ptr pointer, rsA, csA: int, dB: ptr pointer, rsB, csB: int, beta: float64, dC: ptr pointer, rsC: int, panelsPerDev, gather, flags: cint): cint {.lh, importc: "laser_hip_gemm_strided_f64_sharded_dev".}
+proc laser_hip_gemm_strided_i32_sharded_dev(ndev: cint, devices: ptr cint, M, N, K: int, alpha: int32, dA: ptr pointer, rsA, csA: int, dB: ptr pointer, rsB, csB: int, beta: int32, dC: ptr pointer, rsC: int, panelsPerDev, gather, flags: cint): cint {.lh, importc: "laser_hip_gemm_strided_i32_sharded_dev".}
+proc laser_hip_gemm_strided_i64_sharded_dev(ndev: cint, devices: ptr cint, M, N, K: int, alpha: int64, dA: ptr pointer, rsA, csA: int, dB: ptr pointer, rsB, csB: int, beta: int64, dC: ptr pointer, rsC: int, panelsPerDev, gather, flags: cint): cint {.lh, importc: "laser_hip_gemm_strided_i64_sharded_dev".}
+
+proc shardPlan*(M, ndev: int, panelsPerDev = 4): ShardPlan =
+  var ppd: cint
+  check laser_hip_shard_plan(M, cint(ndev), cint(panelsPerDev), result.rowsPerPanel.addr, ppd.addr, result.paddedM.addr)
+  result.panelsPerDev = int(ppd)
+
+proc gemm_strided_sharded*[T: float32 or float64 or int32 or int64](
+      devices: openarray[cint],                 ## HIP ordinals, one per device slot
+      M, N, K: int, alpha: T,
+      A_panels: openarray[DevicePtr[T]],        ## per slot: its row panels of A, stacked in local order
+      rowStrideA, colStrideA: int,
+      B: openarray[DevicePtr[T]],               ## per slot: B (replicated)
+      rowStrideB, colStrideB: int,
+      beta: T,
+      C: openarray[DevicePtr[T]],               ## per slot: the full row-major C
+      rowStrideC: int,
+      panelsPerDev = 4, gather = gatherPeer, flags = 0) =
+  ## Same arithmetic as `gemm_strided` (bit-identical for every device count); synchronous.
+  assert A_panels.len == devices.len and B.len == devices.len and C.len == devices.len
+  let n = cint(devices.len)
+  let dv = devices[0].unsafeAddr
+  let a = cast[ptr pointer](A_panels[0].unsafeAddr)
+  let b = cast[ptr pointer](B[0].unsafeAddr)
+  let c = cast[ptr pointer](C[0].unsafeAddr)
+  when T is float32:
+    check laser_hip_gemm_strided_f32_sharded_dev(n, dv, M, N, K, alpha, a, rowStrideA, colStrideA, b, rowStrideB, colStrideB, beta, c, rowStrideC, cint(panelsPerDev), cint(ord(gather)), cint(flags))
+  elif T is float64:
+    check laser_hip_gemm_strided_f64_sharded_dev(n, dv, M, N, K, alpha, a, rowStrideA, colStrideA, b, rowStrideB, colStrideB, beta, c, rowStrideC, cint(panelsPerDev), cint(ord(gather)), cint(flags))
+  elif T is int32:
+    check laser_hip_gemm_strided_i32_sharded_dev(n, dv, M, N, K, alpha, a, rowStrideA, colStrideA, b, rowStrideB, colStrideB, beta, c, rowStrideC, cint(panelsPerDev), cint(ord(gather)), cint(flags))
+  else:
+    check laser_hip_gemm_strided_i64_sharded_dev(n, dv, M, N, K, alpha, a, rowStrideA, colStrideA, b, rowStrideB, colStrideB, beta, c, rowStrideC, cint(panelsPerDev), cint(ord(gather)), cint(flags))
 proc allocPinned*[T](len: int): ptr UncheckedArray[T] =
   ## page-locked host memory for operands of the host-pointer calls (what an allocator would hand to Tensor[T])
   var p: pointer

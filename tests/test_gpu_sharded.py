@@ -167,3 +167,103 @@ print("SHARDED_WORLD1_OK")
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "SHARDED_WORLD1_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_sharded_host_column_major_c_is_cut_by_columns(la):
+    """with a column-major C the rows interleave in memory, so row ranges per GPU would stage
+    overlapping spans and overwrite each other's finished rows.  The host form now cuts such a C into COLUMN ranges
+    (B and C by columns, A replicated); a C whose rows AND columns interleave runs on one device.  Two and three device
+    slots on the one GPU, every layout of C, against the oracle bit for bit."""
+    from oracle import oracle
+    oracle.build()
+    rng = np.random.default_rng(11)
+    for (M, N, K) in [(1200, 900, 300), (700, 2100, 64), (33, 17, 9)]:
+        A = rng.uniform(-0.1, 0.1, (M, K)).astype(np.float32)
+        B = rng.uniform(-0.1, 0.1, (K, N)).astype(np.float32)
+        want = oracle.matmul(A, B)
+        for devices in ([0, 0], [0, 0, 0]):
+            Cf = np.full((N, M + 3), 5, dtype=np.float32)          # column-major C with a padded leading dimension
+            Cv = Cf[:, :M].T
+            assert Cv.strides == (4, 4 * (M + 3))
+            la.gemm_strided_sharded(devices, M, N, K, 1.0, A, K, 1, B, N, 1, 0.0, Cv, 1, M + 3)
+            assert np.array_equal(Cv, want), (M, N, K, devices, "column-major C")
+            assert (Cf[:, M:] == 5).all(), "padding of the column-major C was touched"
+            # beta != 0 reads C: same layout
+            C0 = rng.uniform(-1, 1, (N, M)).astype(np.float32)
+            Cv = C0.copy().T
+            la.gemm_strided_sharded(devices, M, N, K, 0.5, A, K, 1, B, N, 1, 0.25, Cv, 1, M)
+            one = C0.copy().T
+            la.gemm_strided_sharded([0], M, N, K, 0.5, A, K, 1, B, N, 1, 0.25, one, 1, M)
+            assert np.array_equal(Cv, one), (M, N, K, devices, "column-major C, beta != 0")
+    # the routing knob takes the same path for an unchanged gemm_strided call
+    M, N, K = 4096, 4096, 4096
+    A = rng.uniform(-0.1, 0.1, (M, K)).astype(np.float32)
+    B = rng.uniform(-0.1, 0.1, (K, N)).astype(np.float32)
+    want = la.matmul(A, B)
+    Cv = np.zeros((N, M), dtype=np.float32).T
+    try:
+        la.set_shard_devices(0)
+        la.gemm_strided(M, N, K, 1.0, A, K, 1, B, N, 1, 0.0, Cv, 1, M)
+    finally:
+        la.set_shard_devices(1)
+    assert np.array_equal(Cv, want)
+
+
+def test_sharded_dev_rccl_transport_at_one_rank(la):
+    """GATHER_RCCL with ONE rank: dlopen of librccl.so, ncclCommInitAll, the in-place ncclAllGather pointer arithmetic and
+    the bounded wait all execute on a single-GPU box (RCCL refuses two ranks on one device, so this is the widest it can
+    run here).  Bit-identical to the single-GPU product; float32 and int32 (the ncclDataType_t constants)."""
+    import torch
+    for dtype in (np.float32, np.int32):
+        M, N, K, ppd = 2048, 384, 640, 4
+        A, B = _operands(M, N, K, dtype, seed=3)
+        want = la.matmul(A, B)
+        rows, ppd_used, padded = la.shard_plan(M, 1, ppd)
+        C = torch.zeros((padded, N), dtype=want.dtype, device="cuda")
+        la.gemm_strided_sharded_dev([0], M, N, K, 1, [la.shard_rows(A, 1, 0, ppd)], K, 1, [B], N, 1, 0, [C], N, ppd, la.GATHER_RCCL, 0)
+        assert torch.equal(C[:M], want), dtype
+    # a dense C is required by the flat slab sends
+    with pytest.raises(la.LaserHipError):
+        Cw = torch.zeros((padded, N + 8), device="cuda")
+        A, B = _operands(M, N, K, np.float32, seed=3)
+        la.gemm_strided_sharded_dev([0], M, N, K, 1.0, [la.shard_rows(A, 1, 0, ppd)], K, 1, [B], N, 1, 0.0, [Cw], N + 8, ppd, la.GATHER_RCCL, 0)
+
+
+def test_sharded_tile_pin_is_per_call_not_global(la):
+    """LASER_HIP_SHARD_PIN_TILE used to write the process-global f32 configuration and reset it to
+    -1.  It is a per-thread override now: a configuration the caller forced survives the call, the result is unchanged."""
+    import torch
+    M, N, K, ppd = 2048, 512, 1100, 2
+    A, B = _operands(M, N, K, np.float32, seed=9)
+    want = la.matmul(A, B)
+    rows, ppd_used, padded = la.shard_plan(M, 2, ppd)
+    try:
+        la.set_f32_config(3)
+        Cs = [torch.zeros((padded, N), device="cuda") for _ in range(2)]
+        la.gemm_strided_sharded_dev([0, 0], M, N, K, 1.0, [la.shard_rows(A, 2, g, ppd) for g in range(2)], K, 1, [B, B], N, 1, 0.0, Cs, N,
+                                    ppd, la.GATHER_PEER, la.SHARD_PIN_TILE)
+        assert la.lib().laser_hip_last_f32_config() == 2, "the pinned 128x128 tile did not run"
+        la.matmul(A, B)
+        assert la.lib().laser_hip_last_f32_config() == 3, "the caller's forced configuration was clobbered by the pin"
+    finally:
+        la.set_f32_config(-1)
+    for g in range(2):
+        assert torch.equal(Cs[g][:M], want)
+
+
+def test_bench_gpus2_without_torchrun_runs_through_the_c_abi():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the shape of the driver's command) must itself
+    produce the line -- through laser_hip_gemm_strided_f32_sharded_dev in this process.  Two device slots on the one GPU
+    here (LASER_BENCH_ONE_GPU=1); timings are meaningless, the contract and the self-check are what is tested."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["LASER_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "2048"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "GFLOP/s" and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["M"] == 4096 and "sharded_dev" in d["config"]["entry_point"]
+    assert "roofline" in d and d["roofline"]["bound"] == "mfma"
