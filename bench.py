@@ -340,7 +340,8 @@ def single_process_primary(args):
         },
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)"}.get(
+                     "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)",
+                                           3: "lh_f32_exact_128x128x16 (hand-scheduled assembly)", 4: "lh_f32_fast_128x128x16 (hand-scheduled assembly)"}.get(
                          laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
                      "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": fl,
                      "note": "per-GPU kernel alone (device slot 0's row share as one launch), timed after the sharded run"},
@@ -692,7 +693,8 @@ def main():
                 "stddev": round((sum((x - mean) ** 2 for x in per) / max(1, len(per) - 1)) ** 0.5, 4)}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)"}.get(
+                               "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)",
+                                           3: "lh_f32_exact_128x128x16 (hand-scheduled assembly)", 4: "lh_f32_fast_128x128x16 (hand-scheduled assembly)"}.get(
                                    laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
                                "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": 2.0 * n * n * n}
             tr = pmc_traffic(mode) if (n == SIZE and args.cfg < 0) else None   # the profiled shape / configuration only

@@ -52,6 +52,10 @@ CONFIGS = {
     # barrier positions from the schedule sweeps (profiles/r03/asm_probe_v1.jsonl, asm_probe_v2.jsonl)
     "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95),
     "fast_256x256x16": dict(BM=256, BN=256, BK=16, exact=False, bar_gap=95),
+    # mid-size problems (fewer than one round of the large tiles): 128 VGPRs + 128 AGPRs and 48 KiB of LDS per workgroup, so
+    # two workgroups share a CU -- two waves per SIMD that cover each other's barrier and waits
+    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True),
+    "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False),
 }
 
 # kernel argument block (bytes)
@@ -557,6 +561,8 @@ class Gen:
 
         # (a fold tile carries the slice fold in its first gaps: its staging starts later, so its barrier sits late)
         bar = max(c.bar_gap, c.NMF - c.GM - 1) if fold else c.bar_gap
+        if fold and bar - 1 - (c.NB + 1 + c.TM + c.TN + 2) < 2 * c.NPA + 3 * c.NPB:   # small tiles: as late as the prefetch allows
+            bar = c.NMF - (c.TM + c.TN) * c.r_step - 3
         first_free = 0
         if fold:
             first_free = c.NB + 1           # gaps 0..NB-1 carry the slice fold
@@ -823,7 +829,8 @@ def kernel_text(gen, symbol):
     """complete .s file: code + kernel descriptor + code-object metadata"""
     c = gen.c
     body = gen.p.text()
-    nv = 256
+    nv = (gen.p._v + 7) // 8 * 8          # arch VGPRs (allocation granule 8); the AGPRs follow at accum_offset
+    na = (gen.p._a + 7) // 8 * 8
     return f"""\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
 \t.text
 \t.globl\t{symbol}
@@ -843,7 +850,7 @@ def kernel_text(gen, symbol):
 \t\t.amdhsa_system_sgpr_workgroup_id_x 1
 \t\t.amdhsa_system_sgpr_workgroup_id_y 1
 \t\t.amdhsa_system_vgpr_workitem_id 0
-\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_vgpr {nv + na}
 \t\t.amdhsa_next_free_sgpr 100
 \t\t.amdhsa_accum_offset {nv}
 \t\t.amdhsa_reserve_vcc 1
@@ -867,7 +874,7 @@ amdhsa.kernels:
     .wavefront_size: 64
     .sgpr_count: 100
     .vgpr_count: {nv}
-    .agpr_count: 256
+    .agpr_count: {na}
     .max_flat_workgroup_size: 256
     .args:
       - {{.size: 8, .offset: 0, .value_kind: global_buffer, .address_space: global}}

@@ -18,7 +18,7 @@
 namespace laser_hip {
 
 std::atomic<int> g_f32_asm{1};       // 1 (default): eligible problems run on the hand-scheduled kernels
-std::atomic<int> g_last_f32_asm{0};  // diagnostics: the last f32 GEMM launch used them (1 laser-order kernel, 2 fast kernel)
+std::atomic<int> g_last_f32_asm{0};  // diagnostics: 0 = compiler-scheduled kernel; 1 + index into kKernels otherwise
 
 namespace {
 
@@ -26,12 +26,13 @@ struct KernelInfo {
   const char *symbol;
   int bm, bn, bk;
 };
-const KernelInfo kExact = {"lh_f32_exact_256x128x32", 256, 128, 32};
-const KernelInfo kFast = {"lh_f32_fast_256x256x16", 256, 256, 16};
+// [0] laser-order, large tile  [1] one chain, large tile  [2] laser-order, 128x128  [3] one chain, 128x128
+const KernelInfo kKernels[4] = {{"lh_f32_exact_256x128x32", 256, 128, 32}, {"lh_f32_fast_256x256x16", 256, 256, 16},
+                                {"lh_f32_exact_128x128x16", 128, 128, 16}, {"lh_f32_fast_128x128x16", 128, 128, 16}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
-  hipFunction_t exact = nullptr, fast = nullptr;
+  hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};
   // tile tables by (tiles_m, tiles_n, group_m); entries live until the process ends
   std::map<std::tuple<int, int, int>, std::pair<uint32_t *, std::vector<uint32_t> *>> tables;
 };
@@ -73,8 +74,7 @@ hipError_t get_module(int dev, DeviceModule **out) {
   if (!m.mod) {
     hipError_t e = hipModuleLoadData(&m.mod, lh_f32_asm_hsaco);
     if (e != hipSuccess) return e;
-    e = hipModuleGetFunction(&m.exact, m.mod, kExact.symbol);
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.fast, m.mod, kFast.symbol);
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipModuleGetFunction(&m.fn[k], m.mod, kKernels[k].symbol);
     if (e != hipSuccess) {
       (void)hipModuleUnload(m.mod);
       m.mod = nullptr;
@@ -95,20 +95,35 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (a.csA != 1 || a.csB != 1 || a.csC != 1) return hipErrorNotSupported;
   if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
   if (a.rsA < a.K || a.rsB < a.N || a.rsC < a.N) return hipErrorNotSupported;
-  // laser-order results need the kc = 512 slices only when K > 512; one chain otherwise (either kernel is exact then)
+  // laser-order results need the kc = 512 slices only when K > 512; one chain otherwise (the laser-order kernels are
+  // plain single-chain kernels then: their fold tile is never reached)
   const bool exact = laser_order && a.K > 512;
-  const KernelInfo &ki = exact ? kExact : (a.K > 512 ? kFast : kExact);
-  const bool use_exact_kernel = (&ki == &kExact);
-  if (a.K < ki.bk || a.K % ki.bk != 0) return hipErrorNotSupported;
+  const int big = exact ? 0 : (a.K > 512 ? 1 : 0), small = exact ? 2 : (a.K > 512 ? 3 : 2);
   // 32-bit byte offsets inside the descriptors
-  if ((double)a.rsA * 4.0 * ki.bm >= 4.0e9 || (double)a.K * (double)a.rsB * 4.0 >= 4.0e9) return hipErrorNotSupported;
+  if ((double)a.rsA * 4.0 * 256 >= 4.0e9 || (double)a.K * (double)a.rsB * 4.0 >= 4.0e9) return hipErrorNotSupported;
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0) return hipErrorNotSupported;
-  if (a.M > 0xffff * (int64_t)ki.bm || a.N > 0xffff * (int64_t)ki.bn) return hipErrorNotSupported;
+  if (a.M > 0xffff * (int64_t)128 || a.N > 0xffff * (int64_t)128) return hipErrorNotSupported;
+  const auto tiles_of = [&](const KernelInfo &k) { return ((a.M + k.bm - 1) / k.bm) * ((a.N + k.bn - 1) / k.bn); };
+  // Which tile: time in units of "one 128x128 tile of this K on a fully used CU".  The large tiles run one workgroup per
+  // CU at ~0.96 of the matrix peak; the 128x128 tiles run two per CU (two waves per SIMD) at ~0.9 and need a quarter /
+  // half of the work per workgroup, so they win whenever the large tiles would leave CUs idle or under-fill their last
+  // round (2048^3 = 128 large tiles on 256 CUs, but exactly one round of 256 small ones).
+  int pick = -1;
+  double best = 1e300;
+  for (int k : {big, small}) {
+    const KernelInfo &ki_ = kKernels[k];
+    if (a.K < ki_.bk || a.K % ki_.bk != 0) continue;
+    const int64_t t = tiles_of(ki_);
+    const double units = (double)ki_.bm * ki_.bn / (128.0 * 128.0);
+    const double time = (double)((t + 255) / 256) * units / (k < 2 ? 0.96 : 0.90);
+    // below ~5/8 of a round the compiler-scheduled small-tile kernels (more workgroups per CU, slice-parallel form) do better
+    if (g_f32_asm < 2 && t < 160) continue;
+    if (time < best) best = time, pick = k;
+  }
+  if (pick < 0) return hipErrorNotSupported;
+  const KernelInfo &ki = kKernels[pick];
   const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
-  // one workgroup per CU: worth it from one full round of the chip on, with a well-filled last round
-  const int64_t rounds = (tiles + 255) / 256;
-  if (g_f32_asm < 2 && (tiles < 224 || (double)tiles / (double)(rounds * 256) < 0.80)) return hipErrorNotSupported;
 
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -153,8 +168,8 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.dbg = nullptr;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(use_exact_kernel ? m->exact : m->fast, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
-  if (e == hipSuccess) g_last_f32_asm = use_exact_kernel ? 1 : 2;
+  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  if (e == hipSuccess) g_last_f32_asm = 1 + pick;
   return e;
 }
 

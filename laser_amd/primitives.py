@@ -107,7 +107,8 @@ def set_f32_asm(mode):
 
 
 def last_f32_asm():
-    """0: the last float32 GEMM launch was a compiler-scheduled kernel; 1 / 2: the laser-order / fast assembly kernel."""
+    """0: the last float32 GEMM launch was a compiler-scheduled kernel; 1 / 2: the laser-order / fast assembly kernel on the
+    large tile, 3 / 4: the same on the 128x128 tile."""
     return int(_lib.lib().laser_hip_last_f32_asm())
 
 

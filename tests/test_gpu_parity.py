@@ -680,9 +680,9 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 assert la.last_f32_asm() == 0
             finally:
                 la.set_f32_asm(1); la.set_float_mode(0)
-            want = 1 if (mode == 0 or K <= 512) else 2
+            want = (1, 3) if (mode == 0 or K <= 512) else (2, 4)   # (large tile, 128x128 tile)
             # (tiny problems are taken by the small-matrix / slice-parallel paths before the tiled kernels are asked)
-            assert used == want or (used == 0 and M * N <= 1024 * 1024), (M, N, K, mode, used)
+            assert used in want or (used == 0 and M * N <= 1024 * 1024), (M, N, K, mode, used)
             assert torch.equal(dC, dC2), (M, N, K, mode)
             assert (dC[:, N:] == 7.0).all(), "wrote outside C"
             if mode == 0:
@@ -700,7 +700,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
         w = torch.full((M, 2 * N), 9.0, device="cuda"); la.matmul(A, B, 1, 0, w[:, ::2])
         assert la.last_f32_asm() == 0
         ref = la.matmul(A, B)
-        assert la.last_f32_asm() == 1
+        assert la.last_f32_asm() in (1, 3)
     finally:
         la.set_f32_asm(1)
     assert torch.equal(w[:, ::2], ref) and (w[:, 1::2] == 9.0).all()
