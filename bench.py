@@ -34,6 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+# laser_hip_last_f32_asm() -> the hand-scheduled assembly kernel the last launch ran (laser_amd/csrc/gemm_f32_asm.cpp)
+ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerate(
+    ["lh_f32_exact_256x128x32", "lh_f32_fast_256x256x16", "lh_f32_exact_128x128x16", "lh_f32_fast_128x128x16",
+     "lh_f32_exact_256x128x32_nt", "lh_f32_fast_256x256x16_nt", "lh_f32_exact_128x128x16_nt", "lh_f32_fast_128x128x16_nt",
+     "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt"])}
 SIZE = 8192
 
 
@@ -340,8 +345,7 @@ def single_process_primary(args):
         },
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)",
-                                           3: "lh_f32_exact_128x128x16 (hand-scheduled assembly)", 4: "lh_f32_fast_128x128x16 (hand-scheduled assembly)"}.get(
+                     "kernel": ASM_KERNEL_NAMES.get(
                          laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
                      "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": fl,
                      "note": "per-GPU kernel alone (device slot 0's row share as one launch), timed after the sharded run"},
@@ -693,8 +697,7 @@ def main():
                 "stddev": round((sum((x - mean) ** 2 for x in per) / max(1, len(per) - 1)) ** 0.5, 4)}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": {1: "lh_f32_exact_256x128x32 (hand-scheduled assembly)", 2: "lh_f32_fast_256x256x16 (hand-scheduled assembly)",
-                                           3: "lh_f32_exact_128x128x16 (hand-scheduled assembly)", 4: "lh_f32_fast_128x128x16 (hand-scheduled assembly)"}.get(
+                               "kernel": ASM_KERNEL_NAMES.get(
                                    laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
                                "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": 2.0 * n * n * n}
             tr = pmc_traffic(mode) if (n == SIZE and args.cfg < 0) else None   # the profiled shape / configuration only

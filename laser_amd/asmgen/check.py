@@ -33,17 +33,23 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     c = g.c
     rng = np.random.default_rng(seed)
     lda, ldb, ldc = lda or Kd, ldb or N, ldc or N
+    nt = c.b_kcontig
+    if nt:
+        ldb = ldb if (ldb and ldb >= Kd) else Kd
     Af = np.zeros((M, lda), dtype=np.float32)
-    Bf = np.zeros((Kd, ldb), dtype=np.float32)
-    if integer:
-        Af[:, :Kd] = rng.integers(-3, 4, (M, Kd))
-        Bf[:, :N] = rng.integers(-3, 4, (Kd, N))
+    Bf = np.zeros((N, ldb), dtype=np.float32) if nt else np.zeros((Kd, ldb), dtype=np.float32)
+    Bm = rng.integers(-3, 4, (Kd, N)).astype(np.float32) if integer else rng.uniform(-0.1, 0.1, (Kd, N)).astype(np.float32)
+    Af[:, :Kd] = rng.integers(-3, 4, (M, Kd)) if integer else rng.uniform(-0.1, 0.1, (M, Kd))
+    Af[:, Kd:] = np.nan       # whatever lies between the rows must never reach the result
+    if nt:
+        Bf[:, :Kd] = Bm.T
+        Bf[:, Kd:] = np.nan
     else:
-        Af[:, :Kd] = rng.uniform(-0.1, 0.1, (M, Kd))
-        Bf[:, :N] = rng.uniform(-0.1, 0.1, (Kd, N))
+        Bf[:, :N] = Bm
+        Bf[:, N:] = np.nan
     # trim the allocations to exactly the operand spans: any read past them is a simulator error
     Aflat = Af.reshape(-1)[:(M - 1) * lda + Kd].copy()
-    Bflat = Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
+    Bflat = Bf.reshape(-1)[:(N - 1) * ldb + Kd].copy() if nt else Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
     Cflat = np.full((M - 1) * ldc + N, np.nan, dtype=np.float32)
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
@@ -60,7 +66,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     Cout = np.full((M, ldc), np.nan, dtype=np.float32).reshape(-1)
     Cout[:len(Cflat)] = mem.get(c_, np.float32, (len(Cflat),))
     Cout = Cout.reshape(M, ldc)[:, :N]
-    want = reference(Af[:, :Kd], Bf[:Kd, :N], 512 if c.exact else 0)
+    want = reference(Af[:, :Kd], Bm, 512 if c.exact else 0)
     ok = np.array_equal(Cout, want)
     pad_ok = True
     if ldc > N:

@@ -31,7 +31,7 @@ class Cfg:
         self.STAGE = BK * (BM + BN) * 4
         self.NPA = BM * BK // 4 // 256   # 16-byte pieces of A per thread per tile
         self.NPB = BN * BK // 4 // 256
-        assert self.NPB % 2 == 0
+        assert self.NPB % 2 == 0 or b_kcontig
         self.KC_TILES = 512 // BK        # gemm_tiling.nim:310: kc = 2048 / sizeof(float32)
         self.bar_gap = bar_gap if bar_gap is not None else (self.NMF - self.GM - 1)
         self.w_start, self.w_step = w_start, w_step
@@ -56,6 +56,15 @@ CONFIGS = {
     # two workgroups share a CU -- two waves per SIMD that cover each other's barrier and waits
     "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True),
     "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False),
+    # B passed transposed (rowStrideB == 1: k-contiguous like A) -- BASELINE configs[2]
+    "exact_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, b_kcontig=True),
+    "fast_256x256x16_nt": dict(BM=256, BN=256, BK=16, exact=False, bar_gap=95, b_kcontig=True),
+    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True),
+    "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
+    # one chain on the laser-order kernels' tile: halves the tile quantisation of the 256x256 tile (4100^3: 289 tiles of
+    # 256x256 are 1.13 rounds of the chip, 561 tiles of 256x128 are 2.19)
+    "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
+    "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
 }
 
 # kernel argument block (bytes)
@@ -101,7 +110,13 @@ class Gen:
         self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.WA = [[[V() for _ in range(3)] for _ in range(c.NPA)] for _ in range(2)]   # [MFMA half][piece][stage]
-        self.WB = [[[V() for _ in range(3)] for _ in range(4)] for _ in range(c.NPB // 2)]
+        if c.b_kcontig:
+            self.WB = [[[V() for _ in range(3)] for _ in range(c.NPB)] for _ in range(2)]   # like A: [MFMA half][piece][stage]
+        else:
+            self.WB = [[[V() for _ in range(3)] for _ in range(4)] for _ in range(c.NPB // 2)]   # [pair][element][stage]
+        self.v_oob = V()            # 0x80000000: a buffer offset the bounds check always rejects (reads as 0)
+        self.s_tm = S(2)            # lanes whose 16-byte piece of a k-contiguous operand is real data in the LAST K-tile
+        self.s_ktail = S()
         self.vVA = [V() for _ in range(c.NPA)]
         self.vVB = [V() for _ in range(c.NPB)]
         self.vC = [V() for _ in range(c.TN)]
@@ -249,84 +264,102 @@ class Gen:
                 e("v_add_u32", R[g][0], t[5], row)
                 e("v_add_u32", R[g][1], c.STAGE, R[g][0])
                 e("v_add_u32", R[g][2], 2 * c.STAGE, R[g][0])
-        # A pieces (k-contiguous, 16 B = 4 consecutive k of row x): kq = tid % (BK/4), x = tid / (BK/4) (+ XS per piece)
+        # k-contiguous operand (A always; B when it is passed transposed): a 16-byte piece = 4 consecutive k of row x,
+        # kq = tid % (BK/4), x = tid / (BK/4) (+ XS per piece)
         nkq = c.BK // 4
+        XS = 256 // nkq
         kq, x, row, sw = t[0], t[1], t[2], t[3]
         e("v_and_b32", kq, nkq - 1, tid)
         e("v_lshrrev_b32", x, nkq.bit_length() - 1, tid)
         self.kq_row(row, x, t[5])
         self.kq_swz(sw, x, t[5])
-        e("v_lshrrev_b32", t[5], 1, kq)          # kq / 2
-        e("v_lshlrev_b32", t[5], 1, t[5])        # 2 * (kq / 2)
-        e("v_and_b32", t[6], 1, kq)              # kq % 2
-        e("v_mul_u32_u24", t[7], c.BK * 4, row)  # row * BK * 4
-        e("v_lshl_add_u32", t[7], t[6], 3, t[7])  # + 8 * (kq % 2)
-        for cc in range(2):
-            e("v_or_b32", t[8], cc, t[5])
-            e("v_xor_b32", t[8], t[8], sw)
-            e("v_lshl_add_u32", self.WA[cc][0][2], t[8], 4, t[7])
-            for pi in range(c.NPA):
-                if pi:
-                    e("v_add_u32", self.WA[cc][pi][2], 4096 * pi, self.WA[cc][0][2])
-                e("v_add_u32", self.WA[cc][pi][0], c.STAGE, self.WA[cc][pi][2])
-                e("v_add_u32", self.WA[cc][pi][1], 2 * c.STAGE, self.WA[cc][pi][2])
-        # global offsets of the A pieces: VA_i = (x + i*XS) * lda * 4 + kq * 16
-        XS = 256 // nkq
+        # K tail: pieces of the last K-tile that lie beyond K get an offset the bounds check rejects (they read as 0, like
+        # Laser's zero-padded panels, gemm_packing.nim:46-55); K is a multiple of 4 (launcher), so pieces are all-or-nothing
+        e("s_and_b32", self.s_ktail, self.s_K, c.BK - 1)
+        e("v_lshlrev_b32", t[5], 2, kq)
+        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
+        e("v_mov_b32", self.v_oob, 0x80000000)
+        e("s_nop", 4)
+
+        def kcontig(W, Voff, NP, ld_bytes, lds_off):
+            e("v_lshrrev_b32", t[5], 1, kq)          # kq / 2
+            e("v_lshlrev_b32", t[5], 1, t[5])        # 2 * (kq / 2)
+            e("v_and_b32", t[6], 1, kq)              # kq % 2
+            e("v_mul_u32_u24", t[7], c.BK * 4, row)  # row * BK * 4
+            e("v_lshl_add_u32", t[7], t[6], 3, t[7])  # + 8 * (kq % 2)
+            if lds_off:
+                e("v_add_u32", t[7], lds_off, t[7])
+            for cc in range(2):
+                e("v_or_b32", t[8], cc, t[5])
+                e("v_xor_b32", t[8], t[8], sw)
+                e("v_lshl_add_u32", W[cc][0][2], t[8], 4, t[7])
+                for pi in range(NP):
+                    if pi:
+                        e("v_add_u32", W[cc][pi][2], 4096 * pi, W[cc][0][2])
+                    e("v_add_u32", W[cc][pi][0], c.STAGE, W[cc][pi][2])
+                    e("v_add_u32", W[cc][pi][1], 2 * c.STAGE, W[cc][pi][2])
+            # global offsets of the pieces: V_i = (x + i*XS) * ld * 4 + kq * 16
+            e("v_mul_lo_u32", t[7], x, ld_bytes)
+            e("v_lshl_add_u32", Voff[0], kq, 4, t[7])
+            e("s_mul_i32", st[4], ld_bytes, XS)
+            for i in range(1, NP):
+                e("v_add_u32", Voff[i], st[4], Voff[i - 1])
+
         e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
-        e("v_mul_lo_u32", t[7], x, st[3])
-        e("v_lshl_add_u32", self.vVA[0], kq, 4, t[7])
-        e("s_mul_i32", st[4], st[3], XS)
-        for i in range(1, c.NPA):
-            e("v_add_u32", self.vVA[i], st[4], self.vVA[i - 1])
-        # B pieces (x-contiguous, 16 B = 4 consecutive x of row k), handled in pairs (k, k+2) -- DESIGN.md 3.2 pair mode
-        aa, pp, hh, c0, xq, kb0 = t[0], t[1], t[2], t[3], t[4], t[6]
-        BX16 = c.BN // 16
-        KG = 8 * 16 // BX16
-        e("v_and_b32", aa, 3, tid)
-        e("v_bfe_u32", pp, tid, 2, 1)
-        e("v_bfe_u32", hh, tid, 3, 1)
-        e("v_lshrrev_b32", c0, 4, tid)
-        e("v_and_b32", t[5], BX16 - 1, c0)
-        e("v_lshl_add_u32", xq, t[5], 2, aa)                 # xq = (c0 % BX16) * 4 + a
-        e("v_lshrrev_b32", t[5], BX16.bit_length() - 1, c0)  # c0 / BX16
-        e("v_lshlrev_b32", t[5], 3, t[5])
-        e("v_lshl_add_u32", kb0, hh, 2, t[5])
-        e("v_add_u32", kb0, kb0, pp)                         # kb0 = 8 * (c0 / BX16) + 4h + p
+        kcontig(self.WA, self.vVA, c.NPA, st[3], 0)
         e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
-        e("v_mul_lo_u32", t[7], kb0, st[5])
-        e("v_lshl_add_u32", self.vVB[0], xq, 4, t[7])        # VB(gi = 0, j = 0)
-        e("s_lshl_b32", st[4], st[5], 1)                     # 2 * ldb * 4
-        e("s_mul_i32", st[3], st[5], KG)                     # KG * ldb * 4
-        for gi in range(c.NPB // 2):
-            if gi:
-                e("v_add_u32", self.vVB[2 * gi], st[3], self.vVB[2 * gi - 2])
-            e("v_add_u32", self.vVB[2 * gi + 1], st[4], self.vVB[2 * gi])
-        e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
-        # LDS write addresses of the B pairs: for element e of the pieces: x = 4xq + e, row = 4xq + (e ^ (xq & 1)),
-        #   L = 2 * (k / 8) + (k & 1), word = (k % 8) >> 1;  WB = BK*BM*4 + row*BK*4 + 16 * (L ^ kq_swz(x)) + 4 * word
-        e("s_mov_b32", st[0], c.BK * c.BM * 4, comment="the B panel follows the A panel in a stage")
-        for gi in range(c.NPB // 2):
-            kk = t[7]
-            e("v_add_u32", kk, gi * KG, kb0)
-            e("v_lshrrev_b32", t[8], 3, kk)
-            e("v_lshlrev_b32", t[8], 1, t[8])
-            e("v_and_b32", t[9], 1, kk)
-            e("v_or_b32", t[8], t[8], t[9])                  # L
-            e("v_bfe_u32", t[9], kk, 1, 2)                   # word = (k & 7) >> 1  (k % 8 in {0,1,4,5} -> 0 or 2)
-            e("v_lshlrev_b32", t[9], 2, t[9])                # 4 * word
-            for ee in range(4):
-                xx, rr, ss = t[0], t[1], t[2]  # aa / pp / hh are dead from here on
-                if gi == 0 and ee == 0:
-                    pass
-                e("v_lshl_add_u32", xx, xq, 2, ee)           # x = 4xq + e
-                self.kq_row(rr, xx, t[5])
-                self.kq_swz(ss, xx, t[5])
-                e("v_xor_b32", ss, ss, t[8])                 # L ^ swz
-                e("v_mul_u32_u24", rr, c.BK * 4, rr)
-                e("v_lshl_add_u32", rr, ss, 4, rr)
-                e("v_add3_u32", self.WB[gi][ee][2], rr, t[9], st[0])
-                e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
-                e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
+        if c.b_kcontig:
+            kcontig(self.WB, self.vVB, c.NPB, st[5], c.BK * c.BM * 4)
+            e("s_mov_b32", self.s_bstep, c.BK * 4, comment="B (stored transposed) advances BK elements along its rows per K-tile")
+        if not c.b_kcontig:
+            # B pieces (x-contiguous, 16 B = 4 consecutive x of row k), handled in pairs (k, k+2) -- DESIGN.md 3.2 pair mode
+            aa, pp, hh, c0, xq, kb0 = t[0], t[1], t[2], t[3], t[4], t[6]
+            BX16 = c.BN // 16
+            KG = 8 * 16 // BX16
+            e("v_and_b32", aa, 3, tid)
+            e("v_bfe_u32", pp, tid, 2, 1)
+            e("v_bfe_u32", hh, tid, 3, 1)
+            e("v_lshrrev_b32", c0, 4, tid)
+            e("v_and_b32", t[5], BX16 - 1, c0)
+            e("v_lshl_add_u32", xq, t[5], 2, aa)                 # xq = (c0 % BX16) * 4 + a
+            e("v_lshrrev_b32", t[5], BX16.bit_length() - 1, c0)  # c0 / BX16
+            e("v_lshlrev_b32", t[5], 3, t[5])
+            e("v_lshl_add_u32", kb0, hh, 2, t[5])
+            e("v_add_u32", kb0, kb0, pp)                         # kb0 = 8 * (c0 / BX16) + 4h + p
+            e("v_mul_lo_u32", t[7], kb0, st[5])
+            e("v_lshl_add_u32", self.vVB[0], xq, 4, t[7])        # VB(gi = 0, j = 0)
+            e("s_lshl_b32", st[4], st[5], 1)                     # 2 * ldb * 4
+            e("s_mul_i32", st[3], st[5], KG)                     # KG * ldb * 4
+            for gi in range(c.NPB // 2):
+                if gi:
+                    e("v_add_u32", self.vVB[2 * gi], st[3], self.vVB[2 * gi - 2])
+                e("v_add_u32", self.vVB[2 * gi + 1], st[4], self.vVB[2 * gi])
+            e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
+            # LDS write addresses of the B pairs: for element e of the pieces: x = 4xq + e, row = 4xq + (e ^ (xq & 1)),
+            #   L = 2 * (k / 8) + (k & 1), word = (k % 8) >> 1;  WB = BK*BM*4 + row*BK*4 + 16 * (L ^ kq_swz(x)) + 4 * word
+            e("s_mov_b32", st[0], c.BK * c.BM * 4, comment="the B panel follows the A panel in a stage")
+            for gi in range(c.NPB // 2):
+                kk = t[7]
+                e("v_add_u32", kk, gi * KG, kb0)
+                e("v_lshrrev_b32", t[8], 3, kk)
+                e("v_lshlrev_b32", t[8], 1, t[8])
+                e("v_and_b32", t[9], 1, kk)
+                e("v_or_b32", t[8], t[8], t[9])                  # L
+                e("v_bfe_u32", t[9], kk, 1, 2)                   # word = (k & 7) >> 1  (k % 8 in {0,1,4,5} -> 0 or 2)
+                e("v_lshlrev_b32", t[9], 2, t[9])                # 4 * word
+                for ee in range(4):
+                    xx, rr, ss = t[0], t[1], t[2]  # aa / pp / hh are dead from here on
+                    if gi == 0 and ee == 0:
+                        pass
+                    e("v_lshl_add_u32", xx, xq, 2, ee)           # x = 4xq + e
+                    self.kq_row(rr, xx, t[5])
+                    self.kq_swz(ss, xx, t[5])
+                    e("v_xor_b32", ss, ss, t[8])                 # L ^ swz
+                    e("v_mul_u32_u24", rr, c.BK * 4, rr)
+                    e("v_lshl_add_u32", rr, ss, 4, rr)
+                    e("v_add3_u32", self.WB[gi][ee][2], rr, t[9], st[0])
+                    e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
+                    e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
         # ---- tile coordinates, descriptors ----
         e("s_waitcnt", lgkmcnt=0)
         e("s_and_b32", st[0], st[1], 0xffff)
@@ -348,16 +381,30 @@ class Gen:
         e("s_lshl_b32", st[2], self.s_K, 2)
         e("s_add_u32", self.srdA[2], st[0], st[2])
         e("s_mov_b32", self.srdA[3], 0x00020000)
-        # B panel: base = B + n0 * 4; bytes = (K - 1) * ldb * 4 + (N - n0) * 4
-        e("s_lshl_b32", st[0], self.s_n0, 2)
-        e("s_add_u32", self.srdB[0], B_[0], st[0])
-        e("s_addc_u32", self.srdB[1], B_[1], 0)
-        e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
-        e("s_sub_u32", st[0], self.s_K, 1)
-        e("s_mul_i32", st[0], st[0], st[5])
-        e("s_sub_u32", st[2], self.s_N, self.s_n0)
-        e("s_lshl_b32", st[2], st[2], 2)
-        e("s_add_u32", self.srdB[2], st[0], st[2])
+        if c.b_kcontig:
+            # B^T panel: base = B + n0 * ldb * 4; bytes = (min(N - n0, BN) - 1) * ldb * 4 + K * 4
+            e("s_mul_hi_u32", st[2], self.s_n0, st[5])
+            e("s_mul_i32", st[0], self.s_n0, st[5])
+            e("s_add_u32", self.srdB[0], B_[0], st[0])
+            e("s_addc_u32", self.srdB[1], B_[1], st[2])
+            e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+            e("s_sub_u32", st[0], self.s_N, self.s_n0)
+            e("s_min_u32", st[0], st[0], c.BN)
+            e("s_sub_u32", st[0], st[0], 1)
+            e("s_mul_i32", st[0], st[0], st[5])
+            e("s_lshl_b32", st[2], self.s_K, 2)
+            e("s_add_u32", self.srdB[2], st[0], st[2])
+        else:
+            # B panel: base = B + n0 * 4; bytes = (K - 1) * ldb * 4 + (N - n0) * 4
+            e("s_lshl_b32", st[0], self.s_n0, 2)
+            e("s_add_u32", self.srdB[0], B_[0], st[0])
+            e("s_addc_u32", self.srdB[1], B_[1], 0)
+            e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+            e("s_sub_u32", st[0], self.s_K, 1)
+            e("s_mul_i32", st[0], st[0], st[5])
+            e("s_sub_u32", st[2], self.s_N, self.s_n0)
+            e("s_lshl_b32", st[2], st[2], 2)
+            e("s_add_u32", self.srdB[2], st[0], st[2])
         e("s_mov_b32", self.srdB[3], 0x00020000)
         # C: the whole matrix, bytes = (M - 1) * ldc * 4 + N * 4
         e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
@@ -370,7 +417,8 @@ class Gen:
         e("s_mov_b32", self.srdC[3], 0x00020000)
         e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
         # number of K-tiles
-        e("s_lshr_b32", self.s_rem, self.s_K, (c.BK).bit_length() - 1)
+        e("s_add_u32", self.s_rem, self.s_K, c.BK - 1)
+        e("s_lshr_b32", self.s_rem, self.s_rem, (c.BK).bit_length() - 1)
         # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
         if c.debug:
             for k_ in range(4):
@@ -384,9 +432,9 @@ class Gen:
             self.dump("WA0", self.WA[0][0][2])
             self.dump("WA1", self.WA[1][0][2])
             self.dump("WB00", self.WB[0][0][2])
-            self.dump("WB03", self.WB[0][3][2])
             self.dump("RA0", self.RA[0][0])
             self.dump("RB0", self.RB[0][0])
+        self.tail_mask_if(self.s_rem, 1)        # a single K-tile: tile 0 is the last one
         self.issue_loads_all()
         self.advance_srds()
         if c.debug:
@@ -399,8 +447,12 @@ class Gen:
             self.dump("stA_last[3]", self.stA[-1][3])
         for pi in range(c.NPA):
             self.store_A_piece(pi, k=2)     # tile 0 goes to LDS stage 0 = the "third" stage of the write triples
-        for gi in range(c.NPB // 2):
-            self.store_B_pair(gi, k=2)
+        if c.b_kcontig:
+            for pj in range(c.NPB):
+                self.store_B_kpiece(pj, k=2)
+        else:
+            for gi in range(c.NPB // 2):
+                self.store_B_pair(gi, k=2)
         if c.debug:
             self.lg_wait(None)
             e("s_barrier")
@@ -408,8 +460,10 @@ class Gen:
                 self.dump_lds(f"lds[{k_ * 1024}+4tid]", k_ * 1024)
             self.dump_lds("ldsB[0+4tid]", c.BK * c.BM * 4)
             e("s_barrier")
+        self.tail_mask_if(self.s_rem, 2)
         self.issue_loads_all()
         self.advance_srds()
+        self.tail_mask_if(self.s_rem, 3)        # the first loop body loads tile 2
         # accumulators start at +0
         for b in range(c.NB):
             for r in range(16):
@@ -475,6 +529,35 @@ class Gen:
         if ops is None:
             self.run_ops(out)
         return out
+
+    def store_B_kpiece(self, pj, ops=None, k=0):
+        """B passed transposed (k-contiguous): the same two ds_write2_b32 per piece as A"""
+        out = []
+        r = self.stB[pj]
+        out.append(("vmwait", ("B", pj)))
+        out.append(("ldsw", "ds_write2_b32", (self.WB[0][pj][k], r[0], r[2]), {"offset0": 0, "offset1": 1}))
+        out.append(("ldsw", "ds_write2_b32", (self.WB[1][pj][k], r[1], r[3]), {"offset0": 0, "offset1": 1}))
+        if ops is None:
+            self.run_ops(out)
+        return out
+
+    def apply_tail_mask(self):
+        """the loads issued from here on fetch the last K-tile: pieces beyond K read as 0"""
+        e = self.p.emit
+        regs = list(self.vVA) + (list(self.vVB) if self.c.b_kcontig else [])
+        for r in regs:
+            e("v_cndmask_b32", r, self.v_oob, r, self.s_tm)
+
+    def tail_mask_if(self, sreg, value):
+        """apply_tail_mask when K has a tail and `sreg` == value (uniform branch around ~12 VALU instructions, once per workgroup)"""
+        e = self.p.emit
+        skip = self.p.label("notail")
+        e("s_cmp_eq_u32", self.s_ktail, 0)
+        e("s_cbranch_scc1", skip)
+        e("s_cmp_lg_u32", sreg, value)
+        e("s_cbranch_scc1", skip)
+        self.apply_tail_mask()
+        self.p.place(skip)
 
     def store_B_pair(self, gi, ops=None, k=0):
         """pieces P (row k) and Q (row k + 2) of one x quad: element e of both -> adjacent words of row x = 4xq + e"""
@@ -591,10 +674,15 @@ class Gen:
         for pi in range(c.NPA):
             stg += self.store_A_piece(pi, ops=[], k=wr_k)
             stg.append(("loadA", pi))
-        for gi in range(c.NPB // 2):
-            stg += self.store_B_pair(gi, ops=[], k=wr_k)
-            stg.append(("loadB", 2 * gi))
-            stg.append(("loadB", 2 * gi + 1))
+        if c.b_kcontig:
+            for pj in range(c.NPB):
+                stg += self.store_B_kpiece(pj, ops=[], k=wr_k)
+                stg.append(("loadB", pj))
+        else:
+            for gi in range(c.NPB // 2):
+                stg += self.store_B_pair(gi, ops=[], k=wr_k)
+                stg.append(("loadB", 2 * gi))
+                stg.append(("loadB", 2 * gi + 1))
         # waits ride with the op that follows them
         units = []
         for op in stg:
@@ -728,6 +816,7 @@ class Gen:
                 e("s_sub_u32", self.s_rem, self.s_rem, 1)
                 e("s_cmp_eq_u32", self.s_rem, 0)
                 e("s_cbranch_scc1", L_done)
+                self.tail_mask_if(self.s_rem, 3)    # the next body loads the last K-tile
                 if c.exact:
                     e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
                     e("s_cmp_eq_u32", self.s_cnt, 0)

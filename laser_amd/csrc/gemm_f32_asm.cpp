@@ -26,13 +26,20 @@ struct KernelInfo {
   const char *symbol;
   int bm, bn, bk;
 };
-// [0] laser-order, large tile  [1] one chain, large tile  [2] laser-order, 128x128  [3] one chain, 128x128
-const KernelInfo kKernels[4] = {{"lh_f32_exact_256x128x32", 256, 128, 32}, {"lh_f32_fast_256x256x16", 256, 256, 16},
-                                {"lh_f32_exact_128x128x16", 128, 128, 16}, {"lh_f32_fast_128x128x16", 128, 128, 16}};
+// [0] laser-order, large tile  [1] one chain, large tile  [2] laser-order, 128x128  [3] one chain, 128x128;
+// [4..7] the same with B passed transposed (unit ROW stride: k-contiguous like A, BASELINE configs[2])
+// [8] / [9]: one chain on the 256x128x32 tile (plain / B transposed): finer tile quantisation for the fast mode
+constexpr int kNumKernels = 10;
+const KernelInfo kKernels[kNumKernels] = {
+    {"lh_f32_exact_256x128x32", 256, 128, 32},    {"lh_f32_fast_256x256x16", 256, 256, 16},
+    {"lh_f32_exact_128x128x16", 128, 128, 16},    {"lh_f32_fast_128x128x16", 128, 128, 16},
+    {"lh_f32_exact_256x128x32_nt", 256, 128, 32}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16},
+    {"lh_f32_exact_128x128x16_nt", 128, 128, 16}, {"lh_f32_fast_128x128x16_nt", 128, 128, 16},
+    {"lh_f32_fast_256x128x32", 256, 128, 32},     {"lh_f32_fast_256x128x32_nt", 256, 128, 32}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
-  hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipFunction_t fn[kNumKernels] = {};
   // tile tables by (tiles_m, tiles_n, group_m); entries live until the process ends
   std::map<std::tuple<int, int, int>, std::pair<uint32_t *, std::vector<uint32_t> *>> tables;
 };
@@ -74,7 +81,7 @@ hipError_t get_module(int dev, DeviceModule **out) {
   if (!m.mod) {
     hipError_t e = hipModuleLoadData(&m.mod, lh_f32_asm_hsaco);
     if (e != hipSuccess) return e;
-    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipModuleGetFunction(&m.fn[k], m.mod, kKernels[k].symbol);
+    for (int k = 0; k < kNumKernels && e == hipSuccess; k++) e = hipModuleGetFunction(&m.fn[k], m.mod, kKernels[k].symbol);
     if (e != hipSuccess) {
       (void)hipModuleUnload(m.mod);
       m.mod = nullptr;
@@ -92,15 +99,22 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (!g_f32_asm) return hipErrorNotSupported;
   if (a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
   if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
-  if (a.csA != 1 || a.csB != 1 || a.csC != 1) return hipErrorNotSupported;
+  if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
   if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
-  if (a.rsA < a.K || a.rsB < a.N || a.rsC < a.N) return hipErrorNotSupported;
+  // B: row-major-like (unit column stride), or passed transposed (unit row stride: every column is k-contiguous)
+  const bool nt = a.csB != 1 && a.rsB == 1;
+  if (!nt && a.csB != 1) return hipErrorNotSupported;
+  const int64_t ldb = nt ? a.csB : a.rsB;
+  if (a.rsA < a.K || ldb < (nt ? a.K : a.N) || a.rsC < a.N) return hipErrorNotSupported;
+  // a ragged last K-tile is zero-filled piece-wise (16 bytes = 4 k): K must be a multiple of 4
+  if (a.K < 4 || a.K % 4 != 0) return hipErrorNotSupported;
   // laser-order results need the kc = 512 slices only when K > 512; one chain otherwise (the laser-order kernels are
   // plain single-chain kernels then: their fold tile is never reached)
   const bool exact = laser_order && a.K > 512;
-  const int big = exact ? 0 : (a.K > 512 ? 1 : 0), small = exact ? 2 : (a.K > 512 ? 3 : 2);
+  const int big = (exact ? 0 : (a.K > 512 ? 1 : 0)) + (nt ? 4 : 0), small = (exact ? 2 : (a.K > 512 ? 3 : 2)) + (nt ? 4 : 0);
   // 32-bit byte offsets inside the descriptors
-  if ((double)a.rsA * 4.0 * 256 >= 4.0e9 || (double)a.K * (double)a.rsB * 4.0 >= 4.0e9) return hipErrorNotSupported;
+  if ((double)a.rsA * 4.0 * 256 >= 4.0e9) return hipErrorNotSupported;
+  if ((nt ? (double)ldb * 4.0 * 256 : (double)a.K * (double)ldb * 4.0) >= 4.0e9) return hipErrorNotSupported;
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0) return hipErrorNotSupported;
   if (a.M > 0xffff * (int64_t)128 || a.N > 0xffff * (int64_t)128) return hipErrorNotSupported;
   const auto tiles_of = [&](const KernelInfo &k) { return ((a.M + k.bm - 1) / k.bm) * ((a.N + k.bn - 1) / k.bn); };
@@ -110,12 +124,14 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   // round (2048^3 = 128 large tiles on 256 CUs, but exactly one round of 256 small ones).
   int pick = -1;
   double best = 1e300;
-  for (int k : {big, small}) {
+  const int mid = (!exact && a.K > 512) ? (nt ? 9 : 8) : -1;   // one chain over a long K: also the 256x128 tile
+  for (int k : {big, mid, small}) {
+    if (k < 0) continue;
     const KernelInfo &ki_ = kKernels[k];
-    if (a.K < ki_.bk || a.K % ki_.bk != 0) continue;
     const int64_t t = tiles_of(ki_);
     const double units = (double)ki_.bm * ki_.bn / (128.0 * 128.0);
-    const double time = (double)((t + 255) / 256) * units / (k < 2 ? 0.96 : 0.90);
+    const bool large = k >= 8 || (k & 3) < 2;
+    const double time = (double)((t + 255) / 256) * units / (large ? 0.96 : 0.90);
     // below ~5/8 of a round the compiler-scheduled small-tile kernels (more workgroups per CU, slice-parallel form) do better
     if (g_f32_asm < 2 && t < 160) continue;
     if (time < best) best = time, pick = k;
@@ -159,7 +175,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.C = a.C;
   ka.table = it->second.first;
   ka.lda = (uint32_t)a.rsA;
-  ka.ldb = (uint32_t)a.rsB;
+  ka.ldb = (uint32_t)ldb;
   ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M;
   ka.N = (uint32_t)a.N;

@@ -11,6 +11,8 @@ for (M, N, K) in shapes:
     g = torch.Generator(device="cuda").manual_seed(1)
     A = (torch.rand((M, K), generator=g, device="cuda") - 0.5) * 0.2
     B = (torch.rand((K, N), generator=g, device="cuda") - 0.5) * 0.2
+    if len(sys.argv) > 1 and sys.argv[1] == "nt":          # B passed transposed (BASELINE configs[2])
+        B = B.t().contiguous().t()
     C = torch.zeros((M, N), device="cuda")
     for mode in (0, 1):
         laser_amd.set_float_mode(mode)

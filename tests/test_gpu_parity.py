@@ -660,12 +660,18 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
     rng = np.random.default_rng(41)
     took = 0
     shapes = [(4096, 4096, 1024), (2048, 8192, 1568), (8192, 2048, 1056), (4096, 4096, 544), (1000, 900, 2080), (256, 128, 512),
-              (300, 260, 32), (2048, 2048, 96)]
-    for (M, N, K) in shapes:
+              (300, 260, 32), (2048, 2048, 96), (2048, 2048, 1060), (1920, 1920, 1924), (4100, 4100, 516), (2048, 2048, 20),
+              (1024, 4096, 36), (3000, 2500, 68)]
+    for si, (M, N, K) in enumerate(shapes):
         A = rand(rng, (M, K + 8), np.float32)[:, :K]          # leading dimension K + 8
-        B = rand(rng, (K, N + 12), np.float32)[:, :N]
         dAb = torch.from_numpy(np.ascontiguousarray(A.base)).cuda(); dA = dAb[:, :K]
-        dBb = torch.from_numpy(np.ascontiguousarray(B.base)).cuda(); dB = dBb[:, :N]
+        if si % 2 == 0:
+            B = rand(rng, (K, N + 12), np.float32)[:, :N]
+            dBb = torch.from_numpy(np.ascontiguousarray(B.base)).cuda(); dB = dBb[:, :N]
+        else:                                                 # B passed transposed: rowStrideB = 1, colStrideB = K + 4
+            Bt = rand(rng, (N, K + 4), np.float32)
+            B = Bt[:, :K].T
+            dBb = torch.from_numpy(Bt).cuda(); dB = dBb[:, :K].t()
         wide = torch.full((M, N + 20), 7.0, device="cuda")
         for mode in (0, 1):
             la.set_float_mode(mode)
@@ -680,7 +686,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 assert la.last_f32_asm() == 0
             finally:
                 la.set_f32_asm(1); la.set_float_mode(0)
-            want = (1, 3) if (mode == 0 or K <= 512) else (2, 4)   # (large tile, 128x128 tile)
+            want = (1, 3, 5, 7) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10)   # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128)
             # (tiny problems are taken by the small-matrix / slice-parallel paths before the tiled kernels are asked)
             assert used in want or (used == 0 and M * N <= 1024 * 1024), (M, N, K, mode, used)
             assert torch.equal(dC, dC2), (M, N, K, mode)
@@ -701,6 +707,8 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
         assert la.last_f32_asm() == 0
         ref = la.matmul(A, B)
         assert la.last_f32_asm() in (1, 3)
+        odd = la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous())      # K not a multiple of 4: the compiler-scheduled kernels
+        assert la.last_f32_asm() == 0
     finally:
         la.set_f32_asm(1)
     assert torch.equal(w[:, ::2], ref) and (w[:, 1::2] == 9.0).all()
