@@ -274,7 +274,7 @@ std::vector<T> Tensor<T>::to_host() const {
 // forEach's device twin (laser/strided_iteration/foreach.nim:192-264): dst[idx] = f(a[idx]) / f(a[idx], b[idx]) over strided
 // views of one shape (b may broadcast through zero strides set by the caller); op = LASER_HIP_MAP_* of laser_hip.h
 template <typename T>
-void forEachMap(int op, Tensor<T> &dst, const Tensor<T> &a, double alpha = 1.0, double beta = 0.0) {
+void forEachMap(int op, Tensor<T> &dst, const Tensor<T> &a, T alpha = T(1), T beta = T(0)) {
   if (dst.shape != a.shape) throw Error(LASER_HIP_E_INVALID, "shapes differ");
 #define LASER_ARGS op, dst.unsafe_raw_data(), dst.strides.data(), a.unsafe_raw_data(), a.strides.data(), dst.shape.data(), dst.rank(), alpha, beta, nullptr
   LASER_DISPATCH(T, check(laser_hip_map_strided_unary_f32_dev(LASER_ARGS)), check(laser_hip_map_strided_unary_f64_dev(LASER_ARGS)),
@@ -282,12 +282,19 @@ void forEachMap(int op, Tensor<T> &dst, const Tensor<T> &a, double alpha = 1.0, 
 #undef LASER_ARGS
 }
 template <typename T>
-void forEachMap(int op, Tensor<T> &dst, const Tensor<T> &a, const Tensor<T> &b, double alpha = 1.0, double beta = 1.0) {
+void forEachMap(int op, Tensor<T> &dst, const Tensor<T> &a, const Tensor<T> &b, T alpha = T(1), T beta = T(1)) {
   if (dst.shape != a.shape || dst.shape != b.shape) throw Error(LASER_HIP_E_INVALID, "shapes differ");
 #define LASER_ARGS op, dst.unsafe_raw_data(), dst.strides.data(), a.unsafe_raw_data(), a.strides.data(), b.unsafe_raw_data(), b.strides.data(), dst.shape.data(), dst.rank(), alpha, beta, nullptr
   LASER_DISPATCH(T, check(laser_hip_map_strided_binary_f32_dev(LASER_ARGS)), check(laser_hip_map_strided_binary_f64_dev(LASER_ARGS)),
                  check(laser_hip_map_strided_binary_i32_dev(LASER_ARGS)), check(laser_hip_map_strided_binary_i64_dev(LASER_ARGS)))
 #undef LASER_ARGS
+}
+// every tuning / A-B switch by name, and the diagnostics of the last launch (include/laser_hip.h lists them)
+inline void set_option(const char *name, int value) { check(laser_hip_set_option(name, value)); }
+inline int64_t get_option(const char *name) {
+  int64_t v = 0;
+  check(laser_hip_get_option(name, &v));
+  return v;
 }
 // the node behind an unchanged host-pointer gemm_strided call (0 = every visible GPU, 1 = off)
 inline void set_shard_devices(int ndev) { check(laser_hip_set_shard_devices(ndev)); }

@@ -62,62 +62,31 @@ int laser_hip_get_float_mode(void);
 /* Force one tile configuration of the f32 MFMA kernel (-1 = heuristic).  For tuning/benchmarks. */
 int laser_hip_set_f32_config(int cfg);
 int laser_hip_f32_config_count(void);
-/* Convolution strategy: 1 (default) = implicit GEMM, im2col's index arithmetic fused into the GEMM's
- * B-tile loader (no workspace traffic); 0 = explicit im2col into the workspace + batched GEMM, the
- * reference's literal structure (conv2d_im2col.nim:126-166).  Results are bit-identical. */
-int laser_hip_set_conv_implicit(int on);
-/* 1 (default): the implicit conv reads its B operand from an LDS-resident input patch when that fits;
- * 0: always the per-element gather (A/B timing).  Results are bit-identical. */
-int laser_hip_set_conv_patch(int on);
-/* Host-pointer gemm_strided pipelines (A/B knob, default 1).  Bit 0: large calls on row-major-like operands with pinned B
- * and C run row panels of A x column panels of B, uploaded so the computable region grows as a square, every finished
- * strip of C copied back at once (the first kernel starts after one panel of each operand instead of after all of B);
- * clear = row panels only.  Bit 1: set = the small zero-copy path synchronises its stream instead of polling the
- * kernel's completion flags in mapped host memory.  Bit-identical. */
-int laser_hip_set_host_pipeline(int mode);
-/* 1 (default): the tail launch of a laser-order implicit conv (the output pixels past the last whole round of large
- * tiles) runs Laser's kc slices (gemm.nim:150-158) as parallel workgroup sets + an ordered combine; 0: one workgroup per
- * tail tile over all of K.  Results are bit-identical. */
-int laser_hip_set_conv_kslice(int on);
-/* 1 (default): float32/float64 problems with M <= 8 or N <= 8 (matrix-vector products) run a streaming kernel,
- * same arithmetic; 0: always the tiled kernels (A/B timing) */
-int laser_hip_set_skinny(int on);
-/* 1 (default): small float32 / float64 problems -- at most 256 blocks of 32x32 (f64: 16x16) outputs, or a batch of
- * matrices up to 64x64 -- run the small-matrix kernel (one wave per block of C, operands loaded straight into the
- * matrix-instruction registers, no LDS staging; the reference plans such a path: README.md:257-263): device-resident
- * operands for K <= 128 (BASELINE's 128^3), host-pointer calls for K <= 1024 and <= 1 MiB of operands, where the
- * kernel reads A / B from and writes C to a pinned staging buffer mapped into the device (one PCIe round trip
- * instead of three blocking copies).  Same arithmetic, same bits; 0: always the tiled kernels (A/B timing) */
-int laser_hip_set_small_path(int on);
-/* 1 (default): float problems with few output tiles and K >= 4 kc compute Laser's kc slices as one batched launch and
- * fold them with an ordered combine pass (same arithmetic, same order); 0: always the sequential K loop */
-int laser_hip_set_slice_parallel(int on);
-/* 1 (default): a float32 problem whose last round of workgroup tiles would be badly filled is cut along N into a
- * main launch (whole rounds of the large tile) and a tail launch (small tiles); tiles are independent and every
- * configuration computes identical bits, so results do not change.  0: always one launch; 2: the tail on a
- * library-owned side stream beside the main launch (event fork / join; measured slower, kept for A/B timing) */
-int laser_hip_set_split_tail(int on);
-/* diagnostics: the column where the last float GEMM / conv launch was cut (0: it ran as one launch) */
-int64_t laser_hip_last_split(void);
-/* diagnostics: index of the f32 tile configuration the last GEMM / conv launch used (-1: none yet; -2: the small-matrix kernel) */
-int laser_hip_last_f32_config(void);
-/* tuning knob for the transpose kernels' tile shape / streaming hints (0 = production form) */
-int laser_hip_set_transpose_variant(int variant);
-/* float32 gemm_strided with unit column strides, alpha == 1, beta == 0 and K a multiple of the K-tile: 1 (default) = the
- * hand-scheduled assembly kernels (one wave per SIMD, accumulators in AGPRs; laser_amd/asmgen/) when the tiles fill the
- * chip; 0 = always the compiler-scheduled kernels; 2 = whenever the problem is eligible (tests).  Bit-identical. */
-int laser_hip_set_f32_asm(int on);
-/* diagnostics: 0 = the last float32 GEMM launch was a compiler-scheduled kernel, 1 / 2 = the laser-order / fast assembly kernel */
-int laser_hip_last_f32_asm(void);
-/* int32 GEMM strategy: 1 (default) = signed 8-bit limb decomposition on the int8 matrix cores
- * (bit-exact mod 2^32); 0 = the VALU kernel.  Results are bit-identical. */
-int laser_hip_set_i32_mfma(int on);
-/* int64 GEMM strategy (the reference's int64 micro-kernel: gemm_ukernel_avx512.nim:58-74): 1 (default) = eight signed
- * 8-bit limbs, 36 limb products on the int8 matrix cores (bit-exact mod 2^64); 0 = the VALU kernel.  Bit-identical. */
-int laser_hip_set_i64_mfma(int on);
-/* float64 GEMM strategy: 1 (default) = v_mfma_f64_16x16x4_f64 (bitwise a k-ordered fma chain, so the
- * laser-order result is unchanged); 0 = the VALU kernel.  Results are bit-identical. */
-int laser_hip_set_f64_mfma(int on);
+/* ---- options: one entry point for every tuning / A-B switch ------------------------------------------------------------
+ * laser_hip_set_option(name, value); unknown names are LASER_HIP_E_INVALID.  Every switch leaves results bit-identical
+ * (it selects between implementations of the same arithmetic); defaults in brackets.
+ *   "f32_asm"          [1] float32 gemm_strided with unit column strides on A and C, B row-major or passed transposed,
+ *                          alpha == 1, beta == 0, K a multiple of 4: the hand-scheduled assembly kernels (one wave per SIMD,
+ *                          accumulators in AGPRs; laser_amd/asmgen/) when the problem fills the chip; 0 = never (the
+ *                          compiler-scheduled kernels); 2 = whenever eligible, whatever the tile count (tests)
+ *   "f64_mfma" "i32_mfma" "i64_mfma"  [1] matrix-core kernels (f64 MFMA; int8-limb decomposition for the integers, the
+ *                          reference's integer micro-kernels: gemm_ukernel_avx512.nim:40-74); 0 = the VALU kernels
+ *   "conv_implicit"    [1] im2col fused into the GEMM's B loader; 0 = explicit im2col workspace + batched GEMM, the
+ *                          reference's literal structure (conv2d_im2col.nim:126-166)
+ *   "conv_patch"       [1] implicit conv reads B from an LDS-resident input patch when it fits; 0 = per-element gather
+ *   "conv_kslice"      [1] laser-order conv tail as parallel kc slices (gemm.nim:150-158) + ordered combine
+ *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only
+ *   "zero_copy_poll"   [1] small host-pointer calls poll completion flags in mapped memory; 0 = synchronise the stream
+ *   "skinny"           [1] M <= 8 or N <= 8: the streaming kernel        "small_path" [1] the one-wave-per-block kernel
+ *   "split_tail"       [1] main + tail launches when the last round of tiles would be badly filled
+ *   "slice_parallel"   [1] few tiles x long K: kc slices as one batched launch + ordered combine
+ *   "slice_parallel_min" / "slice_parallel_tiles"  tuning overrides of that rule (0 = built-in)
+ * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
+ *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel)
+ *   "last_f32_asm"     0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
+ *   "last_split"       column where the last float GEMM / conv launch was cut (0 = one launch) */
+int laser_hip_set_option(const char *name, int value);
+int laser_hip_get_option(const char *name, int64_t *value);
 const char *laser_hip_f32_config_name(int cfg);
 
 /* ---- gemm_strided -- laser/primitives/matrix_multiplication/gemm.nim:184-193 ------------------
@@ -339,9 +308,10 @@ int laser_hip_copy_strided_b64_dev(void *d_dst, const int64_t *dst_strides, cons
  * distinct pointer type and no unsafe_raw_data for exactly that reason).  These entry points are what such tensors use
  * instead:      dst[idx] = f(a[idx])      /      dst[idx] = f(a[idx], b[idx])       for every index of `shape`
  * rank <= 6 (LASER_MAXRANK), every operand with its own ELEMENT strides (0 = broadcast along that dimension), dst may
- * alias a or b element for element.  alpha / beta are parameters of SCALE / FILL / AXPY / AXPBY (integers: exact up to
- * 2^53).  Element types f32, f64, i32, i64; the transcendental maps, RECIP and DIV are floating-point only
- * (LASER_HIP_E_INVALID otherwise).  HBM-bound, asynchronous on `stream`. */
+ * alias a or b element for element.  alpha / beta (of the ELEMENT type, like gemm_strided's) are parameters of SCALE /
+ * FILL / AXPY / AXPBY.  Element types f32, f64, i32, i64.  The ops are the arithmetic ones tensor initialisation needs
+ * (laser/tensor/initialization.nim:42-154); SIMD exp / log and friends are out of scope.  HBM-bound,
+ * asynchronous on `stream`. */
 #define LASER_HIP_MAP_COPY 0     /* a                     (= copy_strided) */
 #define LASER_HIP_MAP_FILL 1     /* alpha                 (no operand read; `a` may be NULL) */
 #define LASER_HIP_MAP_NEG 2
@@ -349,16 +319,9 @@ int laser_hip_copy_strided_b64_dev(void *d_dst, const int64_t *dst_strides, cons
 #define LASER_HIP_MAP_RELU 4     /* a > 0 ? a : 0 */
 #define LASER_HIP_MAP_SCALE 5    /* alpha*a + beta        (two roundings) */
 #define LASER_HIP_MAP_SQUARE 6
-#define LASER_HIP_MAP_EXP 7
-#define LASER_HIP_MAP_LOG 8
-#define LASER_HIP_MAP_TANH 9
-#define LASER_HIP_MAP_SIGMOID 10
-#define LASER_HIP_MAP_SQRT 11
-#define LASER_HIP_MAP_RECIP 12
 #define LASER_HIP_MAP_ADD 32     /* binary from here on */
 #define LASER_HIP_MAP_SUB 33
 #define LASER_HIP_MAP_MUL 34
-#define LASER_HIP_MAP_DIV 35
 #define LASER_HIP_MAP_MAX 36
 #define LASER_HIP_MAP_MIN 37
 #define LASER_HIP_MAP_AXPY 38    /* alpha*a + b */
@@ -366,13 +329,13 @@ int laser_hip_copy_strided_b64_dev(void *d_dst, const int64_t *dst_strides, cons
 #define LASER_HIP_DECL_MAP(SFX, T)                                                                \
   int laser_hip_map_strided_unary_##SFX##_dev(int op, T *d_dst, const int64_t *dst_strides,        \
                                               const T *d_a, const int64_t *a_strides,              \
-                                              const int64_t *shape, int rank, double alpha,        \
-                                              double beta, void *stream);                          \
+                                              const int64_t *shape, int rank, T alpha, T beta,     \
+                                              void *stream);                                       \
   int laser_hip_map_strided_binary_##SFX##_dev(int op, T *d_dst, const int64_t *dst_strides,       \
                                                const T *d_a, const int64_t *a_strides,             \
                                                const T *d_b, const int64_t *b_strides,             \
-                                               const int64_t *shape, int rank, double alpha,       \
-                                               double beta, void *stream);
+                                               const int64_t *shape, int rank, T alpha, T beta,    \
+                                               void *stream);
 LASER_HIP_DECL_MAP(f32, float)
 LASER_HIP_DECL_MAP(f64, double)
 LASER_HIP_DECL_MAP(i32, int32_t)

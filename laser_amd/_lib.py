@@ -40,20 +40,8 @@ def lib():
     L.laser_hip_arch.restype = C.c_char_p
     L.laser_hip_set_float_mode.argtypes = [ci]
     L.laser_hip_set_f32_config.argtypes = [ci]
-    L.laser_hip_set_conv_implicit.argtypes = [ci]
-    L.laser_hip_set_transpose_variant.argtypes = [ci]
-    L.laser_hip_set_skinny.argtypes = [ci]
-    L.laser_hip_set_slice_parallel.argtypes = [ci]
-    L.laser_hip_set_split_tail.argtypes = [ci]
-    L.laser_hip_set_small_path.argtypes = [ci]
-    L.laser_hip_last_split.restype = i64
-    L.laser_hip_set_conv_patch.argtypes = [ci]
-    L.laser_hip_set_conv_kslice.argtypes = [ci]
-    L.laser_hip_set_host_pipeline.argtypes = [ci]
-    L.laser_hip_set_i32_mfma.argtypes = [ci]
-    L.laser_hip_set_f32_asm.argtypes = [ci]
-    L.laser_hip_set_i64_mfma.argtypes = [ci]
-    L.laser_hip_set_f64_mfma.argtypes = [ci]
+    L.laser_hip_set_option.argtypes = [C.c_char_p, ci]
+    L.laser_hip_get_option.argtypes = [C.c_char_p, C.POINTER(i64)]
     L.laser_hip_f32_config_name.argtypes = [ci]
     L.laser_hip_f32_config_name.restype = C.c_char_p
     for sfx, ct in _CT.items():
@@ -76,8 +64,8 @@ def lib():
             ci, C.POINTER(ci), i64, i64, i64, ct, pp, i64, i64, pp, i64, i64, ct, pp, i64, ci, ci, ci]
     for sfx, ct in _CT.items():
         pi = C.POINTER(i64)
-        getattr(L, f"laser_hip_map_strided_unary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, pi, ci, C.c_double, C.c_double, vp]
-        getattr(L, f"laser_hip_map_strided_binary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, vp, pi, pi, ci, C.c_double, C.c_double, vp]
+        getattr(L, f"laser_hip_map_strided_unary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, pi, ci, ct, ct, vp]
+        getattr(L, f"laser_hip_map_strided_binary_{sfx}_dev").argtypes = [ci, vp, pi, vp, pi, vp, pi, pi, ci, ct, ct, vp]
     L.laser_hip_host_alloc.argtypes = [C.POINTER(vp), i64]
     L.laser_hip_host_free.argtypes = [vp]
     L.laser_hip_host_register.argtypes = [vp, i64]
@@ -135,7 +123,7 @@ def declared_symbols():
     names = ["laser_hip_init", "laser_hip_finalize", "laser_hip_last_error", "laser_hip_version",
              "laser_hip_device_count", "laser_hip_arch", "laser_hip_set_float_mode",
              "laser_hip_get_float_mode", "laser_hip_set_f32_config", "laser_hip_f32_config_count",
-             "laser_hip_f32_config_name", "laser_hip_set_conv_implicit", "laser_hip_set_transpose_variant", "laser_hip_set_skinny", "laser_hip_set_slice_parallel", "laser_hip_set_split_tail", "laser_hip_set_small_path", "laser_hip_last_split", "laser_hip_set_conv_patch", "laser_hip_set_conv_kslice", "laser_hip_set_host_pipeline", "laser_hip_last_f32_config", "laser_hip_set_i32_mfma", "laser_hip_set_f32_asm", "laser_hip_last_f32_asm", "laser_hip_set_i64_mfma", "laser_hip_set_f64_mfma", "laser_hip_gemm_prepack_release",
+             "laser_hip_f32_config_name", "laser_hip_set_option", "laser_hip_get_option", "laser_hip_gemm_prepack_release",
              "laser_hip_conv2d_out_shape", "laser_hip_im2col_workspace_size", "laser_hip_im2col_f32",
              "laser_hip_im2col_f32_dev", "laser_hip_conv2d_im2col_f32", "laser_hip_conv2d_im2col_f32_dev",
              "laser_hip_cblas_sgemm", "laser_hip_cblas_dgemm",

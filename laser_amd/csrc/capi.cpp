@@ -1239,74 +1239,61 @@ int laser_hip_set_f32_config(int cfg) {
   return LASER_HIP_OK;
 }
 int laser_hip_f32_config_count(void) { return gemm_f32_config_count(); }
-// 1 = float64 GEMM on the f64 matrix cores (default), 0 = VALU kernel (comparison / A-B timing)
-int laser_hip_set_f64_mfma(int on) {
-  g_ctx.f64_mfma = on != 0;
+// ---- options: every tuning / A-B switch behind ONE entry point (name, value); diagnostics behind laser_hip_get_option ----
+// (the header documents each name; unknown names are an error, never silently ignored)
+int laser_hip_set_option(const char *name, int value) {
+  if (!name) return fail(LASER_HIP_E_INVALID, "set_option: null name");
+  const std::string n(name);
+  const bool on = value != 0;
+  if (n == "f32_asm") g_f32_asm = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (n == "f64_mfma") g_ctx.f64_mfma = on;
+  else if (n == "i32_mfma") g_ctx.i32_mfma = on;
+  else if (n == "i64_mfma") g_ctx.i64_mfma = on;
+  else if (n == "conv_implicit") g_ctx.conv_implicit = on;
+  else if (n == "conv_patch") g_conv_patch = on;
+  else if (n == "conv_kslice") g_conv_kslice = on;
+  else if (n == "host_pipeline_2d") g_ctx.host_pipeline_2d = on;
+  else if (n == "zero_copy_poll") g_ctx.zc_poll = on;
+  else if (n == "skinny") g_ctx.skinny = on;
+  else if (n == "small_path") g_small_path = on;
+  else if (n == "split_tail") g_split_tail = on;
+  else if (n == "slice_parallel") g_ctx.slice_parallel = on;
+  else if (n == "slice_parallel_min") g_ctx.slice_parallel_min = value < 2 ? 2 : value;
+  else if (n == "slice_parallel_tiles") g_ctx.slice_parallel_tiles = value < 0 ? 0 : value;
+  else return fail(LASER_HIP_E_INVALID, "set_option: unknown option '%s'", name);
   return LASER_HIP_OK;
 }
-// 1 = int32 GEMM via int8-limb MFMA (default), 0 = VALU kernel (comparison / A-B timing)
-int laser_hip_set_i32_mfma(int on) {
-  g_ctx.i32_mfma = on != 0;
+int laser_hip_get_option(const char *name, int64_t *value) {
+  if (!name || !value) return fail(LASER_HIP_E_INVALID, "get_option: null argument");
+  const std::string n(name);
+  if (n == "f32_asm") *value = g_f32_asm;
+  else if (n == "f64_mfma") *value = g_ctx.f64_mfma;
+  else if (n == "i32_mfma") *value = g_ctx.i32_mfma;
+  else if (n == "i64_mfma") *value = g_ctx.i64_mfma;
+  else if (n == "conv_implicit") *value = g_ctx.conv_implicit;
+  else if (n == "conv_patch") *value = g_conv_patch;
+  else if (n == "conv_kslice") *value = g_conv_kslice;
+  else if (n == "host_pipeline_2d") *value = g_ctx.host_pipeline_2d;
+  else if (n == "zero_copy_poll") *value = g_ctx.zc_poll;
+  else if (n == "skinny") *value = g_ctx.skinny;
+  else if (n == "small_path") *value = g_small_path;
+  else if (n == "split_tail") *value = g_split_tail;
+  else if (n == "slice_parallel") *value = g_ctx.slice_parallel;
+  else if (n == "slice_parallel_min") *value = g_ctx.slice_parallel_min;
+  else if (n == "slice_parallel_tiles") *value = g_ctx.slice_parallel_tiles;
+  // diagnostics of the last launch (read-only)
+  else if (n == "last_f32_config") *value = g_last_f32_cfg;
+  else if (n == "last_f32_asm") *value = g_last_f32_asm;
+  else if (n == "last_split") *value = g_last_split;
+  else return fail(LASER_HIP_E_INVALID, "get_option: unknown option '%s'", name);
   return LASER_HIP_OK;
 }
-// 1 = int64 GEMM via int8-limb MFMA (default), 0 = VALU kernel (comparison / A-B timing)
-int laser_hip_set_i64_mfma(int on) {
-  g_ctx.i64_mfma = on != 0;
-  return LASER_HIP_OK;
-}
-// 1 = implicit GEMM (default), 0 = explicit im2col workspace + batched GEMM (comparison / A-B timing)
-int laser_hip_last_f32_config(void) { return g_last_f32_cfg; }
-int laser_hip_set_conv_patch(int on) {  // A/B knob: B of the implicit conv from an LDS input patch (1) or gathered (0)
-  g_conv_patch = on != 0;
-  return LASER_HIP_OK;
-}
-int laser_hip_set_host_pipeline(int mode) {  // A/B knob: bit 0 = 2-D (row x column panel) host pipeline where it applies (0: row panels
-  g_ctx.host_pipeline_2d = (mode & 1) != 0;  // only); bit 1 CLEAR = the small zero-copy path polls completion flags (set: it synchronises)
-  g_ctx.zc_poll = (mode & 2) == 0;
-  return LASER_HIP_OK;
-}
-int laser_hip_set_f32_asm(int on) {  // 1 (default) = hand-scheduled assembly kernels where they apply, 0 = never, 2 = whenever eligible (tests)
-  g_f32_asm = on;
-  return LASER_HIP_OK;
-}
-int laser_hip_last_f32_asm(void) { return g_last_f32_asm; }
-int laser_hip_set_conv_kslice(int on) {  // A/B knob: laser-order conv tail as parallel kc slices + ordered combine (1) or one launch (0)
-  g_conv_kslice = on != 0;
-  return LASER_HIP_OK;
-}
-int laser_hip_set_slice_parallel(int on) {  // A/B knob: slice-parallel GEMM for few-tile / long-K problems
-  g_ctx.slice_parallel = on != 0;
-  if (on > 100) g_ctx.slice_parallel_tiles = on;  // (tuning: on > 100 sets the tile-count threshold,
-  if (on >= 2 && on <= 100) g_ctx.slice_parallel_min = on;  //  2..100 the minimum slice count)
-  return LASER_HIP_OK;
-}
-int laser_hip_set_split_tail(int on) {  // A/B knob: main + tail launches when the last round of tiles is badly filled
-  g_split_tail = on < 0 ? 0 : on > 2 ? 1 : on;  // 0 never, 1 tail after the main launch (default), 2 tail beside it (A/B arm, measured slower)
-  return LASER_HIP_OK;
-}
-int64_t laser_hip_last_split(void) { return g_last_split; }
 int laser_hip_set_shard_devices(int ndev) {  // host-pointer gemm_strided over ndev GPUs (1 = off, 0 = every visible GPU)
   if (ndev < 0 || ndev > kMaxDevices) return fail(LASER_HIP_E_INVALID, "shard devices outside 0..%d", kMaxDevices);
   g_ctx.shard_devices = ndev;
   return LASER_HIP_OK;
 }
 int laser_hip_get_shard_devices(void) { return g_ctx.shard_devices; }
-int laser_hip_set_small_path(int on) {  // A/B knob: one-wave-per-block kernel for small / batched-tiny problems
-  g_small_path = on != 0;
-  return LASER_HIP_OK;
-}
-int laser_hip_set_skinny(int on) {  // A/B knob: streaming kernel for matrix-vector-like shapes
-  g_ctx.skinny = on != 0;
-  return LASER_HIP_OK;
-}
-int laser_hip_set_transpose_variant(int v) {  // tuning only (scripts/transpose_probe.py)
-  g_transpose_variant = v;
-  return LASER_HIP_OK;
-}
-int laser_hip_set_conv_implicit(int on) {
-  g_ctx.conv_implicit = on != 0;
-  return LASER_HIP_OK;
-}
 const char *laser_hip_f32_config_name(int cfg) { return gemm_f32_config_name(cfg); }
 
 #define LH_DEF_GEMM(SFX, T)                                                                                   \
@@ -1702,13 +1689,11 @@ int laser_hip_copy_strided_b64_dev(void *dst, const int64_t *ds, const void *src
 namespace {
 template <typename T>
 int map_api(int op, bool binary, T *dst, const int64_t *ds, const T *a, const int64_t *as, const T *b, const int64_t *bs,
-            const int64_t *shape, int rank, double alpha, double beta, void *stream) {
+            const int64_t *shape, int rank, T alpha, T beta, void *stream) {
   if (rank < 0 || rank > kMaxRank) return fail(LASER_HIP_E_INVALID, "rank %d outside 0..%d (LASER_MAXRANK)", rank, kMaxRank);
   const bool is_bin = op >= LASER_HIP_MAP_ADD && op <= LASER_HIP_MAP_AXPBY;
-  const bool is_un = op >= LASER_HIP_MAP_COPY && op <= LASER_HIP_MAP_RECIP;
+  const bool is_un = op >= LASER_HIP_MAP_COPY && op <= LASER_HIP_MAP_SQUARE;
   if (binary ? !is_bin : !is_un) return fail(LASER_HIP_E_INVALID, "map op %d is not a %s op", op, binary ? "binary" : "unary");
-  const bool fp_only = (op >= LASER_HIP_MAP_EXP && op <= LASER_HIP_MAP_RECIP) || op == LASER_HIP_MAP_DIV;
-  if (fp_only && !std::is_floating_point<T>::value) return fail(LASER_HIP_E_INVALID, "map op %d is floating-point only", op);
   const int nin = binary ? 2 : (op == LASER_HIP_MAP_FILL ? 0 : 1);
   if (rank > 0 && (!ds || !shape || (nin >= 1 && !as) || (nin >= 2 && !bs))) return fail(LASER_HIP_E_INVALID, "null shape/strides");
   int64_t total = 1;
@@ -1728,12 +1713,12 @@ extern "C" {
 
 #define LH_DEF_MAP(SFX, T)                                                                                              \
   int laser_hip_map_strided_unary_##SFX##_dev(int op, T *dst, const int64_t *ds, const T *a, const int64_t *as,          \
-                                              const int64_t *shape, int rank, double alpha, double beta, void *stream) { \
+                                              const int64_t *shape, int rank, T alpha, T beta, void *stream) {           \
     return map_api<T>(op, false, dst, ds, a, as, nullptr, nullptr, shape, rank, alpha, beta, stream);                    \
   }                                                                                                                     \
   int laser_hip_map_strided_binary_##SFX##_dev(int op, T *dst, const int64_t *ds, const T *a, const int64_t *as,         \
                                                const T *b, const int64_t *bs, const int64_t *shape, int rank,            \
-                                               double alpha, double beta, void *stream) {                               \
+                                               T alpha, T beta, void *stream) {                                         \
     return map_api<T>(op, true, dst, ds, a, as, b, bs, shape, rank, alpha, beta, stream);                                \
   }
 LH_DEF_MAP(f32, float)

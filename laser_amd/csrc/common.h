@@ -155,7 +155,6 @@ extern std::atomic<int> g_conv_kslice;        // laser-order conv tail as parall
 extern std::atomic<int> g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches
 extern std::atomic<int64_t> g_last_split;    // diagnostics: column cut of the last MFMA launch (0 = one launch)
 extern std::atomic<int> g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used
-extern std::atomic<int> g_transpose_variant;  // tuning knob, 0 = production form
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,
                                     int elem_size, hipStream_t s);
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,
@@ -174,7 +173,7 @@ hipError_t launch_copy_strided(T *dst, const int64_t *dstrides, const T *src, co
 // elementwise map over strided rank <= 6 views (map_strided.hip): dst = f(a [, b]); nin = operands read (0: fill)
 template <typename T>
 hipError_t launch_map_strided(int op, int nin, T *dst, const int64_t *dstrides, const T *a, const int64_t *astrides, const T *b,
-                              const int64_t *bstrides, const int64_t *shape, int rank, double alpha, double beta, hipStream_t s);
+                              const int64_t *bstrides, const int64_t *shape, int rank, T alpha, T beta, hipStream_t s);
 template <typename T>
 hipError_t launch_pack_pad(T *dst, int64_t Rpad, int64_t Cpad, const T *src, int64_t R,
                            int64_t Ccols, int64_t rs, int64_t cs, hipStream_t s);

@@ -82,7 +82,6 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ 
   }
 }
 
-std::atomic<int> g_transpose_variant{0};  // tuning knob (laser_hip_set_transpose_variant): tile shape / streaming hints
 
 template <typename T, int TR, int TC, bool NT>
 static hipError_t launch_transpose_v(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s) {
@@ -103,16 +102,7 @@ static hipError_t launch_transpose_t(void *dst, const void *src, int64_t N, int6
     // segments).  scripts/transpose_probe.py (profiles/r01/transpose_probe.log): vs the 64x64 tile
     // +5 % at 16384x8192 and +19 % at 8192^2, equal elsewhere; it runs AT the rate of a plain D2D copy of
     // the same bytes (4.7-5.4 TB/s at these sizes).  Streaming (nontemporal) hints cost 5-20 %; 128x128 loses occupancy.
-    switch (g_transpose_variant) {
-      case 1: return launch_transpose_v<T, 64, 64, false>(dst, src, N, NR, NC, s);
-      case 2: return launch_transpose_v<T, 64, 64, true>(dst, src, N, NR, NC, s);
-      case 3: return launch_transpose_v<T, 64, 128, true>(dst, src, N, NR, NC, s);
-      case 4: return launch_transpose_v<T, 128, 64, false>(dst, src, N, NR, NC, s);
-      case 5: return launch_transpose_v<T, 128, 128, false>(dst, src, N, NR, NC, s);
-      case 6: return launch_transpose_v<T, 32, 64, false>(dst, src, N, NR, NC, s);
-      case 7: return launch_transpose_v<T, 32, 128, false>(dst, src, N, NR, NC, s);
-      default: return launch_transpose_v<T, 64, 128, false>(dst, src, N, NR, NC, s);
-    }
+    return launch_transpose_v<T, 64, 128, false>(dst, src, N, NR, NC, s);
   }
   const int64_t tiles_r = (NR + 63) / 64, tiles_c = (NC + 63) / 64;
   const int64_t blocks = N * tiles_r * tiles_c;

@@ -130,7 +130,7 @@ struct SplitPlan {
   int cfg_main = -1, cfg_tail = -1;
   int64_t n_cut = 0;  // 0: one launch
 };
-std::atomic<int> g_split_tail{1};  // knob (laser_hip_set_split_tail): 0 = never cut, 1 = cut, tail after the main launch, 2 = cut, tail beside it
+std::atomic<int> g_split_tail{1};  // option "split_tail": 0 = never cut, 1 = main launch + tail launch
 std::atomic<int64_t> g_last_split{0};  // diagnostics: column cut of the last MFMA GEMM / conv launch (0: single launch)
 static SplitPlan plan_split(const GemmArgs<float> &a, bool exact, bool need_gen, bool conv, bool bn_multiple_only) {
   SplitPlan p;
@@ -175,40 +175,13 @@ std::atomic<int> g_conv_patch{1}; // implicit conv: B from an LDS input patch wh
 std::atomic<int> g_conv_kslice{1}; // laser-order conv: tail launch as parallel kc slices + ordered combine (0: one workgroup per tail tile)
 std::atomic<int> g_last_f32_cfg{-1}; // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
-// Main + tail.  Default: the tail launch follows the main launch on the caller's stream.  Knob value 2 runs the tail
-// on a side stream BESIDE the main launch (event fork / join, nothing blocks the host) -- the idea being that its few
-// small workgroups fill CUs the main launch would leave idle in its last round.  MEASURED WORSE on every shape tried
-// (C4 conv 0.590 vs 0.553 ms, profiles/r02/conv_c4_v3.log; 5000^3 2.50 vs 2.24 ms): the tail's workgroups take
-// LDS / register slots that delay whole main-launch workgroups, which costs more than the idle CUs did.  Kept only
-// as the A/B arm that shows it.
-struct ForkJoin {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  std::mutex mu;  // the record / wait pairs of one call must not interleave with another host thread's
-};
-static ForkJoin g_fj[64];
+// Main launch, then the tail launch on the same stream.  (Running the tail BESIDE the main launch on a side stream was
+// measured worse on every shape tried -- C4 conv 0.590 vs 0.553 ms, 5000^3 2.50 vs 2.24 ms, profiles/r02/conv_c4_v3.log:
+// the tail's workgroups take LDS / register slots that delay whole main-launch workgroups -- and is not built.)
 template <typename MainFn, typename TailFn>
 static hipError_t launch_main_and_tail(hipStream_t s, MainFn &&main_fn, TailFn &&tail_fn) {
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (g_split_tail != 2 || dev < 0 || dev >= 64) {  // the production form: tail after main, same stream
-    e = main_fn(s);
-    return e != hipSuccess ? e : tail_fn(s);
-  }
-  ForkJoin &fj = g_fj[dev];
-  std::lock_guard<std::mutex> lk(fj.mu);
-  if (!fj.side) {
-    if ((e = hipStreamCreateWithFlags(&fj.side, hipStreamNonBlocking)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&fj.fork, hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&fj.join, hipEventDisableTiming)) != hipSuccess) return e;
-  }
-  if ((e = hipEventRecord(fj.fork, s)) != hipSuccess) return e;
-  if ((e = hipStreamWaitEvent(fj.side, fj.fork, 0)) != hipSuccess) return e;
-  if ((e = tail_fn(fj.side)) != hipSuccess) return e;
-  if ((e = hipEventRecord(fj.join, fj.side)) != hipSuccess) return e;
-  if ((e = main_fn(s)) != hipSuccess) return e;
-  return hipStreamWaitEvent(s, fj.join, 0);
+  const hipError_t e = main_fn(s);
+  return e != hipSuccess ? e : tail_fn(s);
 }
 
 // one launch of configuration `cfg` (falling back to a configuration with the scalar loaders when the operands need them)
@@ -333,7 +306,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   // added in order (gemm.nim:150-158), so the tail runs as images x slices workgroup sets, each ONE chain over its 512 k
   // into a workspace, and the ordered combine pass folds them: same fused multiply-adds, same order => bit-identical.
   const int64_t nsl = (a.K + 511) / 512, ntail = a.N - plan.n_cut;
-  if (exact && g_conv_kslice && g_split_tail == 1 && nsl >= 2 && a.bias == nullptr && a.act == 0 && a.bsC == a.M * a.rsC &&
+  if (exact && g_conv_kslice && g_split_tail && nsl >= 2 && a.bias == nullptr && a.act == 0 && a.bsC == a.M * a.rsC &&
       (int64_t)a.batch * nsl <= 65535) {
     if (hipError_t e = launch_conv_cfg(m, plan.cfg_main, exact, s); e != hipSuccess) return e;
     const int64_t mn = a.M * ntail;

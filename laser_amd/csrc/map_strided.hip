@@ -3,8 +3,9 @@
 //
 // The host forEach is a macro that takes raw pointers (`unsafe_raw_data`) and walks them on the CPU with an odometer
 // over shape / strides; a tensor whose storage lives in HBM must never reach it (the pointer is a device address).
-// What the tensor surface needs from it -- copy, fill, scale, the unary maps of the activation functions, and the
-// binary add / sub / mul / div / max / min / axpy -- is this kernel: dst[idx] = f(a[idx] [, b[idx]]) for every index
+// What tensor initialisation and the GEMM path's call sites need from it (laser/tensor/initialization.nim:42-154: copy,
+// fill, scale, axpy; plus neg / abs / relu / square / add / sub / mul / max / min -- SIMD exp / log are out of scope,
+// SURVEY.md 2b) is this kernel: dst[idx] = f(a[idx] [, b[idx]]) for every index
 // of `shape`, each operand with its own element strides (0 = broadcast), alpha / beta as op parameters.
 // HBM-bound: algorithmic bytes = sizeof(T) * elements * (operands read + 1 written).
 // Same traversal as copy_strided (data_movement.hip): extent-1 dimensions dropped, dimensions contiguous on EVERY
@@ -25,12 +26,10 @@ struct MapArgs {
   int64_t inner, chunks, rows;
   int log2p;
   int op;
-  double alpha, beta;
 };
 
 template <typename T>
 __device__ __forceinline__ T map_op(int op, T a, T b, T alpha, T beta) {
-  constexpr bool F = std::is_floating_point<T>::value;
   switch (op) {
     case LASER_HIP_MAP_COPY: return a;
     case LASER_HIP_MAP_FILL: return alpha;
@@ -57,24 +56,12 @@ __device__ __forceinline__ T map_op(int op, T a, T b, T alpha, T beta) {
     }
     default: break;
   }
-  if constexpr (F) {
-    switch (op) {
-      case LASER_HIP_MAP_EXP: return sizeof(T) == 4 ? (T)expf((float)a) : (T)exp((double)a);
-      case LASER_HIP_MAP_LOG: return sizeof(T) == 4 ? (T)logf((float)a) : (T)log((double)a);
-      case LASER_HIP_MAP_TANH: return sizeof(T) == 4 ? (T)tanhf((float)a) : (T)tanh((double)a);
-      case LASER_HIP_MAP_SIGMOID: return sizeof(T) == 4 ? (T)(1.0f / (1.0f + expf(-(float)a))) : (T)(1.0 / (1.0 + exp(-(double)a)));
-      case LASER_HIP_MAP_SQRT: return sizeof(T) == 4 ? (T)sqrtf((float)a) : (T)sqrt((double)a);
-      case LASER_HIP_MAP_RECIP: return (T)1 / a;
-      case LASER_HIP_MAP_DIV: return a / b;
-      default: break;
-    }
-  }
   return a;
 }
 
 template <typename T, int NIN>
-__global__ void __launch_bounds__(256) map_strided_kernel(T *__restrict__ dst, const T *a, const T *b, const MapArgs m) {
-  const T alpha = (T)m.alpha, beta = (T)m.beta;
+__global__ void __launch_bounds__(256) map_strided_kernel(T *__restrict__ dst, const T *a, const T *b, const MapArgs m, const T alpha,
+                                                          const T beta) {
   const int64_t id = m.sd[m.rank - 1], ia = m.sa[m.rank - 1], ib = m.sb[m.rank - 1];
   auto outer = [&](int64_t row, int64_t &od, int64_t &oa, int64_t &ob) __attribute__((always_inline)) {
     int64_t rem = row;
@@ -120,7 +107,7 @@ __global__ void __launch_bounds__(256) map_strided_kernel(T *__restrict__ dst, c
 
 template <typename T>
 hipError_t launch_map_strided(int op, int nin, T *dst, const int64_t *dstrides, const T *a, const int64_t *astrides, const T *b,
-                              const int64_t *bstrides, const int64_t *shape, int rank, double alpha, double beta, hipStream_t s) {
+                              const int64_t *bstrides, const int64_t *shape, int rank, T alpha, T beta, hipStream_t s) {
   // drop extent-1 dimensions, merge dimension pairs that are contiguous on every operand
   int64_t sh[kMaxRank], sd[kMaxRank], sa[kMaxRank], sb[kMaxRank];
   int r = 0;
@@ -142,8 +129,6 @@ hipError_t launch_map_strided(int op, int nin, T *dst, const int64_t *dstrides, 
   MapArgs m;
   m.rank = r;
   m.op = op;
-  m.alpha = alpha;
-  m.beta = beta;
   m.rows = 1;
   for (int d = 0; d < kMaxRank; d++) {
     m.shape[d] = d < r ? sh[d] : 1;
@@ -166,16 +151,16 @@ hipError_t launch_map_strided(int op, int nin, T *dst, const int64_t *dstrides, 
   }
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (nin == 0)
-    hipLaunchKernelGGL((map_strided_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, s, dst, a, b, m);
+    hipLaunchKernelGGL((map_strided_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, s, dst, a, b, m, alpha, beta);
   else if (nin == 1)
-    hipLaunchKernelGGL((map_strided_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, s, dst, a, b, m);
+    hipLaunchKernelGGL((map_strided_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, s, dst, a, b, m, alpha, beta);
   else
-    hipLaunchKernelGGL((map_strided_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, s, dst, a, b, m);
+    hipLaunchKernelGGL((map_strided_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, s, dst, a, b, m, alpha, beta);
   return hipGetLastError();
 }
 #define LH_INST(T)                                                                                                     \
   template hipError_t launch_map_strided<T>(int, int, T *, const int64_t *, const T *, const int64_t *, const T *,     \
-                                            const int64_t *, const int64_t *, int, double, double, hipStream_t);
+                                            const int64_t *, const int64_t *, int, T, T, hipStream_t);
 LH_INST(float)
 LH_INST(double)
 LH_INST(int32_t)

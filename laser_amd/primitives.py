@@ -95,81 +95,103 @@ def get_f32_config():
     return _f32_config
 
 
+def set_option(name, value):
+    """laser_hip_set_option: every tuning / A-B switch of the library by name (include/laser_hip.h lists them)."""
+    _lib.check(_lib.lib().laser_hip_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    """laser_hip_get_option: an option's value, or a read-only diagnostic of the last launch ("last_f32_config", ...)."""
+    v = C.c_int64()
+    _lib.check(_lib.lib().laser_hip_get_option(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+# named conveniences over set_option / get_option (the tests and probes read better with them)
 def set_f64_mfma(on):
     """True (default): float64 GEMM on the f64 matrix cores; False: VALU kernel."""
-    _lib.check(_lib.lib().laser_hip_set_f64_mfma(1 if on else 0))
+    set_option("f64_mfma", 1 if on else 0)
 
 
 def set_f32_asm(mode):
     """1 (default): eligible float32 problems that fill the chip run the hand-scheduled assembly kernels; 0: never;
     2: whenever eligible, whatever the tile count (tests)."""
-    _lib.check(_lib.lib().laser_hip_set_f32_asm(int(mode)))
+    set_option("f32_asm", int(mode))
 
 
 def last_f32_asm():
-    """0: the last float32 GEMM launch was a compiler-scheduled kernel; 1 / 2: the laser-order / fast assembly kernel on the
-    large tile, 3 / 4: the same on the 128x128 tile."""
-    return int(_lib.lib().laser_hip_last_f32_asm())
+    """0: the last float32 GEMM launch was a compiler-scheduled kernel; else 1 + the index of the assembly kernel
+    (gemm_f32_asm.cpp: 1 / 2 laser-order / one-chain large tile, 3 / 4 the 128x128 tile, 5..8 the same with B transposed,
+    9 / 10 one chain on the 256x128 tile)."""
+    return get_option("last_f32_asm")
 
 
 def set_i32_mfma(on):
     """True (default): int32 GEMM on the int8 matrix cores (limb decomposition); False: VALU kernel."""
-    _lib.check(_lib.lib().laser_hip_set_i32_mfma(1 if on else 0))
+    set_option("i32_mfma", 1 if on else 0)
 
 
 def set_i64_mfma(on):
     """True (default): int64 GEMM on the int8 matrix cores (eight limbs, 36 products); False: VALU kernel."""
-    _lib.check(_lib.lib().laser_hip_set_i64_mfma(1 if on else 0))
+    set_option("i64_mfma", 1 if on else 0)
 
 
 def set_conv_patch(on):
     """True (default): the implicit conv's B operand comes from an LDS-resident input patch where it fits."""
-    _lib.check(_lib.lib().laser_hip_set_conv_patch(1 if on else 0))
+    set_option("conv_patch", 1 if on else 0)
 
 
 def set_conv_kslice(on):
     """True (default): laser-order conv tail launches run Laser's kc slices in parallel + an ordered combine."""
-    _lib.check(_lib.lib().laser_hip_set_conv_kslice(1 if on else 0))
+    set_option("conv_kslice", 1 if on else 0)
 
 
 def set_host_pipeline(mode):
-    """1 (default): large row-major host-pointer calls stream row panels x column panels; 0: row panels only."""
-    _lib.check(_lib.lib().laser_hip_set_host_pipeline(int(mode)))
+    """bit 0 (default 1): large row-major host-pointer calls stream row panels x column panels; bit 1 set: the small
+    zero-copy path synchronises its stream instead of polling completion flags."""
+    set_option("host_pipeline_2d", int(mode) & 1)
+    set_option("zero_copy_poll", 0 if int(mode) & 2 else 1)
 
 
 def set_slice_parallel(on):
-    """True (default): few-tile / long-K float problems run Laser's kc slices in parallel + an ordered combine."""
-    _lib.check(_lib.lib().laser_hip_set_slice_parallel(int(on)))
+    """True (default): few-tile / long-K float problems run Laser's kc slices in parallel + an ordered combine.
+    (tuning: 2..100 sets the minimum slice count, > 100 the tile-count threshold)"""
+    on = int(on)
+    set_option("slice_parallel", 1 if on else 0)
+    if on > 100:
+        set_option("slice_parallel_tiles", on)
+    elif on >= 2:
+        set_option("slice_parallel_min", on)
 
 
 def set_split_tail(on):
     """True (default): fp32 problems whose last round of tiles would be badly filled run as main + tail launches."""
-    _lib.check(_lib.lib().laser_hip_set_split_tail(int(on)))   # 2: tail launch BESIDE the main one (A/B arm, measured slower)
+    set_option("split_tail", 1 if on else 0)
 
 
 def last_split():
     """Column where the last float GEMM / conv launch was cut into main + tail (0: one launch)."""
-    return _lib.lib().laser_hip_last_split()
+    return get_option("last_split")
 
 
 def set_small_path(on):
     """True (default): small / batched-tiny float problems run the one-wave-per-block small-matrix kernel."""
-    _lib.check(_lib.lib().laser_hip_set_small_path(1 if on else 0))
+    set_option("small_path", 1 if on else 0)
 
 
 def set_skinny(on):
     """True (default): M <= 8 or N <= 8 float problems run the streaming (matrix-vector) kernel."""
-    _lib.check(_lib.lib().laser_hip_set_skinny(1 if on else 0))
+    set_option("skinny", 1 if on else 0)
 
 
 def last_f32_config():
     """Index into f32_configs() of the tile configuration the last fp32 GEMM / conv launch used."""
-    return _lib.lib().laser_hip_last_f32_config()
+    return get_option("last_f32_config")
 
 
 def set_conv_implicit(on):
     """True (default): implicit-GEMM convolution; False: explicit im2col workspace + batched GEMM."""
-    _lib.check(_lib.lib().laser_hip_set_conv_implicit(1 if on else 0))
+    set_option("conv_implicit", 1 if on else 0)
 
 
 def f32_configs():

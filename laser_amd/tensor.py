@@ -292,9 +292,8 @@ __all__ = ["trimStorageCache", "Tensor", "HipStorage", "newTensor", "toTensor", 
 # Laser's forEach (laser/strided_iteration/foreach.nim:192-264) walks raw HOST pointers; a Tensor whose storage
 # lives in HBM goes through laser_hip_map_strided_*_dev instead (map_strided.hip): dst[idx] = f(a[idx] [, b[idx]])
 # over strided rank <= 6 views, strides of 0 broadcast.
-MAP_OPS = {"copy": 0, "fill": 1, "neg": 2, "abs": 3, "relu": 4, "scale": 5, "square": 6, "exp": 7, "log": 8, "tanh": 9,
-           "sigmoid": 10, "sqrt": 11, "recip": 12, "add": 32, "sub": 33, "mul": 34, "div": 35, "max": 36, "min": 37,
-           "axpy": 38, "axpby": 39}
+MAP_OPS = {"copy": 0, "fill": 1, "neg": 2, "abs": 3, "relu": 4, "scale": 5, "square": 6, "add": 32, "sub": 33, "mul": 34,
+           "max": 36, "min": 37, "axpy": 38, "axpby": 39}
 _MAP_SFX = {"float32": "f32", "float64": "f64", "int32": "i32", "int64": "i64"}
 
 
@@ -324,6 +323,7 @@ def forEachMap(op, dst, a=None, b=None, alpha=1.0, beta=0.0):
     code = MAP_OPS[op] if isinstance(op, str) else int(op)
     binary = code >= 32
     sfx = _MAP_SFX[dst.dtype.name]
+    ct = _lib.ctype_of(sfx)     # alpha / beta are of the element type (integers exact over the whole range)
     for x in (a, b):
         if x is not None and x.dtype != dst.dtype:
             raise TypeError("operands must share the destination's element type")
@@ -341,9 +341,9 @@ def forEachMap(op, dst, a=None, b=None, alpha=1.0, beta=0.0):
     if binary:
         fn = getattr(L, f"laser_hip_map_strided_binary_{sfx}_dev")
         _lib.check(fn(code, C.c_void_p(dst.unsafe_raw_data()), arr(dst.strides), pa, sa, C.c_void_p(b.unsafe_raw_data()),
-                      arr(_bcast_strides(b, dst.shape)), arr(dst.shape), r, float(alpha), float(beta), _stream()))
+                      arr(_bcast_strides(b, dst.shape)), arr(dst.shape), r, ct(alpha), ct(beta), _stream()))
     else:
         fn = getattr(L, f"laser_hip_map_strided_unary_{sfx}_dev")
-        _lib.check(fn(code, C.c_void_p(dst.unsafe_raw_data()), arr(dst.strides), pa, sa, arr(dst.shape), r, float(alpha),
-                      float(beta), _stream()))
+        _lib.check(fn(code, C.c_void_p(dst.unsafe_raw_data()), arr(dst.strides), pa, sa, arr(dst.shape), r, ct(alpha),
+                      ct(beta), _stream()))
     return dst

@@ -26,6 +26,9 @@ proc laser_hip_init*(device: cint): cint {.lh, importc: "laser_hip_init".}
 proc laser_hip_finalize*(): cint {.lh, importc: "laser_hip_finalize".}
 proc laser_hip_device_count*(): cint {.lh, importc: "laser_hip_device_count".}
 proc laser_hip_set_float_mode*(mode: cint): cint {.lh, importc: "laser_hip_set_float_mode".}   # 0 = Laser order (default), 1 = fast
+# every tuning / A-B switch by name (include/laser_hip.h lists them), and the read-only diagnostics of the last launch
+proc laser_hip_set_option(name: cstring, value: cint): cint {.lh, importc: "laser_hip_set_option".}
+proc laser_hip_get_option(name: cstring, value: ptr int): cint {.lh, importc: "laser_hip_get_option".}
 
 template check(rc: cint) =
   # the reference procs return void and doAssert on precondition violations
@@ -313,22 +316,21 @@ proc copyStrided*[T](dst: DevicePtr[T], dstStrides: openarray[int], src: DeviceP
 # ---- mapStrided: the device twin of forEach / forEachStrided (foreach.nim:192-264) ----------------
 # dst[idx] = f(a[idx]) / f(a[idx], b[idx]) over rank <= 6 (LASER_MAXRANK) strided views, strides in elements, 0 = broadcast.
 type MapOp* = enum
-  mapCopy = 0, mapFill = 1, mapNeg = 2, mapAbs = 3, mapRelu = 4, mapScale = 5, mapSquare = 6, mapExp = 7, mapLog = 8,
-  mapTanh = 9, mapSigmoid = 10, mapSqrt = 11, mapRecip = 12,
-  mapAdd = 32, mapSub = 33, mapMul = 34, mapDiv = 35, mapMax = 36, mapMin = 37, mapAxpy = 38, mapAxpby = 39
+  mapCopy = 0, mapFill = 1, mapNeg = 2, mapAbs = 3, mapRelu = 4, mapScale = 5, mapSquare = 6,
+  mapAdd = 32, mapSub = 33, mapMul = 34, mapMax = 36, mapMin = 37, mapAxpy = 38, mapAxpby = 39
 
-proc laser_hip_map_strided_unary_f32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_f32_dev".}
+proc laser_hip_map_strided_unary_f32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float32, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_f32_dev".}
 proc laser_hip_map_strided_unary_f64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_f64_dev".}
-proc laser_hip_map_strided_unary_i32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_i32_dev".}
-proc laser_hip_map_strided_unary_i64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_i64_dev".}
-proc laser_hip_map_strided_binary_f32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_f32_dev".}
+proc laser_hip_map_strided_unary_i32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: int32, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_i32_dev".}
+proc laser_hip_map_strided_unary_i64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: int64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_unary_i64_dev".}
+proc laser_hip_map_strided_binary_f32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float32, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_f32_dev".}
 proc laser_hip_map_strided_binary_f64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_f64_dev".}
-proc laser_hip_map_strided_binary_i32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_i32_dev".}
-proc laser_hip_map_strided_binary_i64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: float64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_i64_dev".}
+proc laser_hip_map_strided_binary_i32_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: int32, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_i32_dev".}
+proc laser_hip_map_strided_binary_i64_dev(op: cint, dst: pointer, dstStrides: ptr int, a: pointer, aStrides: ptr int, b: pointer, bStrides: ptr int, shape: ptr int, rank: cint, alpha, beta: int64, stream: pointer): cint {.lh, importc: "laser_hip_map_strided_binary_i64_dev".}
 
 proc mapStrided*[T: float32 or float64 or int32 or int64](op: MapOp, dst: DevicePtr[T], dstStrides: openarray[int],
                  a: DevicePtr[T], aStrides: openarray[int], shape: openarray[int],
-                 alpha = 1.0, beta = 0.0, stream: pointer = nil) =
+                 alpha = T(1), beta = T(0), stream: pointer = nil) =
   ## `forEachStrided d in dst, x in a: d = f(x)` on device buffers (fill: `a` may be a nil DevicePtr).
   assert shape.len == dstStrides.len and shape.len == aStrides.len and shape.len <= 6 and ord(op) < 32
   when T is float32:
@@ -342,7 +344,7 @@ proc mapStrided*[T: float32 or float64 or int32 or int64](op: MapOp, dst: Device
 
 proc mapStrided*[T: float32 or float64 or int32 or int64](op: MapOp, dst: DevicePtr[T], dstStrides: openarray[int],
                  a: DevicePtr[T], aStrides: openarray[int], b: DevicePtr[T], bStrides: openarray[int],
-                 shape: openarray[int], alpha = 1.0, beta = 1.0, stream: pointer = nil) =
+                 shape: openarray[int], alpha = T(1), beta = T(1), stream: pointer = nil) =
   ## `forEachStrided d in dst, x in a, y in b: d = f(x, y)` on device buffers.
   assert shape.len == dstStrides.len and shape.len == aStrides.len and shape.len == bStrides.len and shape.len <= 6 and ord(op) >= 32
   when T is float32:
@@ -365,6 +367,9 @@ proc laser_hip_host_free(hostPtr: pointer): cint {.lh, importc: "laser_hip_host_
 proc laser_hip_host_register(hostPtr: pointer, bytes: int): cint {.lh, importc: "laser_hip_host_register".}
 proc laser_hip_host_unregister(hostPtr: pointer): cint {.lh, importc: "laser_hip_host_unregister".}
 
+proc laserHipSetOption*(name: string, value: int) = check laser_hip_set_option(cstring(name), cint(value))
+proc laserHipGetOption*(name: string): int =
+  check laser_hip_get_option(cstring(name), result.addr)
 proc laserHipShardDevices*(ndev: int) = check laser_hip_set_shard_devices(cint(ndev))
 proc laserHipShardDevices*(): int = int(laser_hip_get_shard_devices())
 

@@ -2,7 +2,7 @@
 # full validation of the tree on one MI355X (gpurun) -- whole GPU suite, smoke, bench line, headline profile (+ traffic file on
 # the same tree), C4 conv profile (kernel-trace + PMC), every BASELINE config line
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r02; mkdir -p $O
+O=gpurun_out/r03; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_full.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu_full.log; grep -v "hip_runtime\|nodiscard\|hipError_t\|~~~\|^ *[0-9]* |\|^In file\|^ *from\|note:" $O/pytest_gpu_full.log | tail -12
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2
 timeout 400 python bench.py > $O/bench_full.json 2> $O/bench_full.err; tail -1 $O/bench_full.json | cut -c1-1500; tail -2 $O/bench_full.err

@@ -80,7 +80,7 @@ int main() {
     // forEach's device twin on a strided view: E = relu(C^T - 100), then E += C^T
     auto E = laser::newTensor<float>({2, 2});
     auto Ct = C.transposed();
-    laser::forEachMap(LASER_HIP_MAP_SCALE, E, Ct, 1.0, -100.0);          // [[-42, 39], [-36, 54]]
+    laser::forEachMap(LASER_HIP_MAP_SCALE, E, Ct, 1.0f, -100.0f);          // [[-42, 39], [-36, 54]]
     laser::forEachMap(LASER_HIP_MAP_RELU, E, E);                         // [[0, 39], [0, 54]]
     laser::forEachMap(LASER_HIP_MAP_ADD, E, E, Ct);                      // [[58, 178], [64, 208]]
     const float want_e[4] = {58, 178, 64, 208};

@@ -29,7 +29,7 @@ static double now_us() {
 
 static int measure(int small_on, double *host_us, double *dev_us, double *dev_single_us, double *batched_us, int *bad) {
   const int n = 128;
-  CK(laser_hip_set_small_path(small_on));
+  CK(laser_hip_set_option("small_path", small_on));
   std::vector<float> A(n * n), B(n * n), C(n * n), want(n * n);
   unsigned s = 12345;
   auto rnd = [&]() {
@@ -120,12 +120,12 @@ int main() {
   int bad = 0;
   for (int on = 1; on >= 0; on--)
     if (measure(on, &h[on], &d[on], &ds[on], &b[on], &bad)) return 1;
-  laser_hip_set_small_path(1);
+  laser_hip_set_option("small_path", 1);
   // the host-pointer call again with the zero-copy path synchronising its stream instead of polling completion flags
   double h_sync = 0, d_tmp, ds_tmp, b_tmp;
-  CK(laser_hip_set_host_pipeline(3));
+  CK(laser_hip_set_option("zero_copy_poll", 0));
   if (measure(1, &h_sync, &d_tmp, &ds_tmp, &b_tmp, &bad)) return 1;
-  CK(laser_hip_set_host_pipeline(1));
+  CK(laser_hip_set_option("zero_copy_poll", 1));
   // Laser's own path for this size is single-threaded (M*N*K > 128^3 is false: gemm.nim:141): a plain fmaf triple loop
   // on this host for scale (the oracle's timed single-thread number is in bench_configs.py's output)
   printf("{\"config\": \"C1 fp32 gemm M=N=K=128 from a compiled caller\", \"host_us\": %.2f, \"dev_us\": %.2f, \"dev_single_us\": %.2f, "

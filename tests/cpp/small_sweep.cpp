@@ -39,7 +39,7 @@ int main() {
     const int M = sh[0], N = sh[1], K = sh[2];
     double us[2];
     for (int on = 1; on >= 0; on--) {
-      CK(laser_hip_set_small_path(on));
+      CK(laser_hip_set_option("small_path", on));
       for (int i = 0; i < 50; i++) CK(laser_hip_gemm_strided_f32_dev(M, N, K, 1.0f, dA, K, 1, dB, N, 1, 0.0f, dC, N, 1, st));
       hipStreamSynchronize(st);
       float best = 1e30f;
@@ -56,6 +56,6 @@ int main() {
     }
     printf("{\"shape\": [%d, %d, %d], \"small_us\": %.2f, \"tiled_us\": %.2f, \"ratio\": %.3f}\n", M, N, K, us[1], us[0], us[1] / us[0]);
   }
-  laser_hip_set_small_path(1);
+  laser_hip_set_option("small_path", 1);
   return 0;
 }

@@ -242,9 +242,9 @@ def test_sharded_tile_pin_is_per_call_not_global(la):
         Cs = [torch.zeros((padded, N), device="cuda") for _ in range(2)]
         la.gemm_strided_sharded_dev([0, 0], M, N, K, 1.0, [la.shard_rows(A, 2, g, ppd) for g in range(2)], K, 1, [B, B], N, 1, 0.0, Cs, N,
                                     ppd, la.GATHER_PEER, la.SHARD_PIN_TILE)
-        assert la.lib().laser_hip_last_f32_config() == 2, "the pinned 128x128 tile did not run"
+        assert la.last_f32_config() == 2, "the pinned 128x128 tile did not run"
         la.matmul(A, B)
-        assert la.lib().laser_hip_last_f32_config() == 3, "the caller's forced configuration was clobbered by the pin"
+        assert la.last_f32_config() == 3, "the caller's forced configuration was clobbered by the pin"
     finally:
         la.set_f32_config(-1)
     for g in range(2):
