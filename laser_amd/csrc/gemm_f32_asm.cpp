@@ -185,7 +185,10 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
-  if (e == hipSuccess) g_last_f32_asm = 1 + pick;
+  if (e == hipSuccess) {
+    g_last_f32_asm = 1 + pick;
+    g_last_split = 0;  // one launch
+  }
   return e;
 }
 

@@ -323,7 +323,8 @@ def forEachMap(op, dst, a=None, b=None, alpha=1.0, beta=0.0):
     code = MAP_OPS[op] if isinstance(op, str) else int(op)
     binary = code >= 32
     sfx = _MAP_SFX[dst.dtype.name]
-    ct = _lib.ctype_of(sfx)     # alpha / beta are of the element type (integers exact over the whole range)
+    _ct = _lib.ctype_of(sfx)    # alpha / beta are of the element type (integers exact over the whole range)
+    ct = (lambda v: _ct(int(v))) if sfx[0] == "i" else (lambda v: _ct(float(v)))
     for x in (a, b):
         if x is not None and x.dtype != dst.dtype:
             raise TypeError("operands must share the destination's element type")

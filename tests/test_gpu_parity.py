@@ -791,6 +791,7 @@ def test_split_tail_launch_plans_bit_exact(la, oracle):
     rng = np.random.default_rng(5)
     cases = [(4100, 4100, 600), (256, 100352, 1152), (4224, 4224, 1030), (1000, 9000, 700)]
     took = 0
+    la.set_f32_asm(0)      # the launch plan of the compiler-scheduled kernels is what this test pins
     for (M, N, K) in cases:
         A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
         B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
@@ -813,6 +814,10 @@ def test_split_tail_launch_plans_bit_exact(la, oracle):
         rows = slice(0, min(M, 300))
         want = oracle.matmul(A[rows].cpu().numpy(), B.cpu().numpy())
         assert np.array_equal(la.matmul(A, B)[rows].cpu().numpy(), want), (M, N, K)
+        la.set_f32_asm(1)
+        assert np.array_equal(la.matmul(A, B)[rows].cpu().numpy(), want), (M, N, K, "assembly kernels / library default")
+        la.set_f32_asm(0)
+    la.set_f32_asm(1)
     assert took >= 2, "the planner never cut any of the badly-quantised shapes"
     # batched: the cut is per batch entry
     A = torch.from_numpy(rand(rng, (6, 640, 530), np.float32)).cuda()
