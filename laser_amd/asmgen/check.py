@@ -87,3 +87,49 @@ if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "exact_256x128x32"
     ok = run_case(name, 256, 128 if "128x32" in name else 256, 64, integer=True)
     sys.exit(0 if ok else 1)
+
+
+def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=None, verbose=True):
+    """3x3 / stride 1 convolution kernels: every image through the interpreter, against im2col + the slice-ordered model"""
+    g = K.make(name)
+    g.build()
+    c = g.c
+    rng = np.random.default_rng(seed)
+    oH, oW = H + 2 * pad - 2, W + 2 * pad - 2
+    npix = oH * oW
+    N = n_cut or npix
+    Kd = Cin * 9
+    x = rng.uniform(-0.1, 0.1, (images, Cin, H, W)).astype(np.float32)
+    w = rng.uniform(-0.1, 0.1, (M, Kd)).astype(np.float32)
+    out = np.full((images, M, npix), np.nan, dtype=np.float32)
+    tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
+    table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
+    mem = Memory()
+    # the input is placed with nothing mapped directly before / after it: any access outside the tensor is an error
+    a_, b_, c_, t_ = mem.alloc(w), mem.alloc(x), mem.alloc(out), mem.alloc(table)
+    ka = struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, Kd, 0, npix, M, N, Kd, 0, 0)
+    ka += struct.pack("<IIIIIIII", H, W, oW, pad, pad, Cin, npix, (1 << 32) // oW + 1)
+    ka += struct.pack("<IIQ", 0, 0, Cin * H * W * 4)
+    ka += struct.pack("<Q", M * npix * 4)
+    assert len(ka) == K.KERNARG_SIZE
+    ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    t0 = time.time()
+    for img in range(images):
+        for wg in range(len(table)):
+            Workgroup(g.p, mem, ka_, wg_id=(wg, img), lds_bytes=c.lds_alloc).run(order=order)
+    got = mem.get(c_, np.float32, (images, M, npix))
+    ok = True
+    for img in range(images):
+        xp = np.zeros((Cin, H + 2 * pad, W + 2 * pad), dtype=np.float32)
+        xp[:, pad:pad + H, pad:pad + W] = x[img]
+        Bm = np.stack([xp[ci, kh:kh + oH, kw:kw + oW].reshape(-1) for ci in range(Cin) for kh in range(3) for kw in range(3)])
+        want = reference(w, Bm, 512 if c.exact else 0)
+        ok &= bool(np.array_equal(got[img][:, :N], want[:, :N]))
+        ok &= bool(np.all(np.isnan(got[img][:, N:])))
+        if not ok and verbose:
+            bad = np.argwhere(got[img][:, :N] != want[:, :N])
+            print("  image", img, "first mismatches", bad[:6].tolist(), "count", len(bad))
+            break
+    if verbose:
+        print(f"{name} images={images} Cin={Cin} {H}x{W} M={M} pad={pad} N={N}/{npix}: {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f} s)")
+    return ok

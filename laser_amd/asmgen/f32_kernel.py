@@ -20,7 +20,7 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF
 
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
-                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1):
+                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, conv_pad=True):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
         self.WTM, self.WTN = BM // 2, BN // 2
         self.TM, self.TN = self.WTM // 32, self.WTN // 32
@@ -31,6 +31,12 @@ class Cfg:
         self.STAGE = BK * (BM + BN) * 4
         self.NPA = BM * BK // 4 // 256   # 16-byte pieces of A per thread per tile
         self.NPB = BN * BK // 4 // 256
+        # implicit-GEMM convolution (3x3, stride 1): B is the NCHW image, gathered by the loader as 8-byte pieces (2 output
+        # pixels of one k = (channel, kernel row, kernel column)); conv_pad: the variant for padding 1 (border columns)
+        self.conv, self.conv_pad = conv, conv_pad
+        if conv:
+            assert (BN, BK) == (128, 32) and not b_kcontig
+            self.NPB = 8
         assert self.NPB % 2 == 0 or b_kcontig
         self.KC_TILES = 512 // BK        # gemm_tiling.nim:310: kc = 2048 / sizeof(float32)
         self.bar_gap = bar_gap if bar_gap is not None else (self.NMF - self.GM - 1)
@@ -63,13 +69,20 @@ CONFIGS = {
     "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
     # one chain on the laser-order kernels' tile: halves the tile quantisation of the 256x256 tile (4100^3: 289 tiles of
     # 256x256 are 1.13 rounds of the chip, 561 tiles of 256x128 are 2.19)
+    # implicit-GEMM convolution, 3x3 kernel, stride 1 (benchmarks/convolution/conv2d_im2col.nim): padding 1 / padding 0
+    "conv3x3_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True, conv_pad=True),
+    "conv3x3_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True, conv_pad=True),
+    "conv3x3p0_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True, conv_pad=False),
+    "conv3x3p0_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True, conv_pad=False),
     "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
 }
 
 # kernel argument block (bytes)
 KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 8, 16, 24, 32, 36, 40, 44, 48, 52, 64
-KERNARG_SIZE = 72
+# convolution kernels only: H W oW pH pW Cin Npix magic(oW) | shift(oW) - bsB(bytes, u64) | bsC(bytes, u64)
+KA_CONV0, KA_CONV1, KA_CONV2 = 72, 104, 120
+KERNARG_SIZE = 128
 
 
 class Gen:
@@ -102,7 +115,7 @@ class Gen:
         self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
         # staging pieces
         self.stA = [V(4) for _ in range(c.NPA)]
-        self.stB = [V(4) for _ in range(c.NPB)]
+        self.stB = [V(2) for _ in range(c.NPB)] if c.conv else [V(4) for _ in range(c.NPB)]
         # per-lane LDS addresses, one register per LDS stage: [0] = the stage the tile being multiplied lives in (reads) /
         # the stage being filled (writes), [1] = the next one, [2] = the third; rotated with v_swap_b32 once per K-tile --
         # v_swap is free beside the MFMA stream while any other VALU op costs ~11 cycles of matrix-pipe time
@@ -110,7 +123,20 @@ class Gen:
         self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.WA = [[[V() for _ in range(3)] for _ in range(c.NPA)] for _ in range(2)]   # [MFMA half][piece][stage]
-        if c.b_kcontig:
+        if c.conv:
+            self.WB = [[[V() for _ in range(3)] for _ in range(2)] for _ in range(4)]       # [pair][pixel of the piece][stage]
+            self.vBM, self.vBL, self.vBR = V(), V(), V()   # image offset of the lane's pixel pair (plain / shifted into the image at the left / right border)
+            self.vBoff = [V() for _ in range(8)]
+            scr = S(16, align=4)
+            self.s_scr = scr
+            self.s_koff = [scr[i] for i in range(8)]       # per piece: (c*H*W + kh*W + kw) * 4 of the k it gathers
+            self.s_kw = [scr[8 + i] for i in range(8)]     # per piece: kernel column of that k (border fix-up one tile later)
+            self.s_c0, self.s_r0 = S(), S()                # (channel, kh*3 + kw) of this wave's first k in the tile being loaded
+            self.s_rowm = [S(2) for _ in range(3)]         # lanes whose input row oh + kh - pH exists
+            self.s_mL, self.s_mR = S(2), S(2)              # lanes at the left / right image border
+            self.s_m, self.s_m2 = S(2), S(2)
+            self.s_HW4, self.s_W4, self.s_Cin = S(), S(), S()
+        elif c.b_kcontig:
             self.WB = [[[V() for _ in range(3)] for _ in range(c.NPB)] for _ in range(2)]   # like A: [MFMA half][piece][stage]
         else:
             self.WB = [[[V() for _ in range(3)] for _ in range(4)] for _ in range(c.NPB // 2)]   # [pair][element][stage]
@@ -118,11 +144,12 @@ class Gen:
         self.s_tm = S(2)            # lanes whose 16-byte piece of a k-contiguous operand is real data in the LAST K-tile
         self.s_ktail = S()
         self.vVA = [V() for _ in range(c.NPA)]
-        self.vVB = [V() for _ in range(c.NPB)]
+        self.vVB = [V() for _ in range(c.NPB)] if not c.conv else []
         self.vC = [V() for _ in range(c.TN)]
-        self.srdD = S(4)
-        self.s_dslot = S()
-        self.v_dbg = V()
+        if c.debug:
+            self.srdD = S(4)
+            self.s_dslot = S()
+            self.v_dbg = V()
         self.ndump = 0
         self.dump_names = []
         self.vT = [V(16)]
@@ -311,7 +338,7 @@ class Gen:
         if c.b_kcontig:
             kcontig(self.WB, self.vVB, c.NPB, st[5], c.BK * c.BM * 4)
             e("s_mov_b32", self.s_bstep, c.BK * 4, comment="B (stored transposed) advances BK elements along its rows per K-tile")
-        if not c.b_kcontig:
+        if not c.b_kcontig and not c.conv:
             # B pieces (x-contiguous, 16 B = 4 consecutive x of row k), handled in pairs (k, k+2) -- DESIGN.md 3.2 pair mode
             aa, pp, hh, c0, xq, kb0 = t[0], t[1], t[2], t[3], t[4], t[6]
             BX16 = c.BN // 16
@@ -381,7 +408,23 @@ class Gen:
         e("s_lshl_b32", st[2], self.s_K, 2)
         e("s_add_u32", self.srdA[2], st[0], st[2])
         e("s_mov_b32", self.srdA[3], 0x00020000)
-        if c.b_kcontig:
+        if c.conv:
+            self.conv_setup()
+            if c.debug:
+                self.dump("conv vBM", self.vBM)
+                if c.conv_pad:
+                    self.dump("conv vBL", self.vBL)
+                    self.dump("conv vBR", self.vBR)
+                for kh in range(3):
+                    self.dump(f"conv rowm[{kh}].lo", self.s_rowm[kh][0])
+                    self.dump(f"conv rowm[{kh}].hi", self.s_rowm[kh][1])
+                self.dump("conv c0", self.s_c0)
+                self.dump("conv r0", self.s_r0)
+                self.dump("conv HW4", self.s_HW4)
+                self.dump("conv Cin", self.s_Cin)
+                self.dump("conv WB00", self.WB[0][0][2])
+                self.dump("conv WB31", self.WB[3][1][2])
+        elif c.b_kcontig:
             # B^T panel: base = B + n0 * ldb * 4; bytes = (min(N - n0, BN) - 1) * ldb * 4 + K * 4
             e("s_mul_hi_u32", st[2], self.s_n0, st[5])
             e("s_mul_i32", st[0], self.s_n0, st[5])
@@ -406,10 +449,17 @@ class Gen:
             e("s_lshl_b32", st[2], st[2], 2)
             e("s_add_u32", self.srdB[2], st[0], st[2])
         e("s_mov_b32", self.srdB[3], 0x00020000)
-        # C: the whole matrix, bytes = (M - 1) * ldc * 4 + N * 4
+        # C: the whole matrix (conv: this image's [M][oH*oW] block), bytes = (M - 1) * ldc * 4 + N * 4
         e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
-        e("s_mov_b32", self.srdC[0], C_[0])
-        e("s_and_b32", self.srdC[1], C_[1], 0xffff)
+        if c.conv:
+            e("s_mul_hi_u32", st[2], s(3), self.s_scr[12])
+            e("s_mul_i32", st[0], s(3), self.s_scr[12])
+            e("s_add_u32", self.srdC[0], C_[0], st[0])
+            e("s_addc_u32", self.srdC[1], C_[1], st[2])
+            e("s_and_b32", self.srdC[1], self.srdC[1], 0xffff)
+        else:
+            e("s_mov_b32", self.srdC[0], C_[0])
+            e("s_and_b32", self.srdC[1], C_[1], 0xffff)
         e("s_sub_u32", st[0], self.s_M, 1)
         e("s_mul_i32", st[0], st[0], self.s_ldc4)
         e("s_lshl_b32", st[2], self.s_N, 2)
@@ -427,8 +477,9 @@ class Gen:
                 self.dump(f"srdB[{k_}]", self.srdB[k_])
             self.dump("vVA0", self.vVA[0])
             self.dump("vVA1", self.vVA[1])
-            self.dump("vVB0", self.vVB[0])
-            self.dump("vVB1", self.vVB[1])
+            if not c.conv:
+                self.dump("vVB0", self.vVB[0])
+                self.dump("vVB1", self.vVB[1])
             self.dump("WA0", self.WA[0][0][2])
             self.dump("WA1", self.WA[1][0][2])
             self.dump("WB00", self.WB[0][0][2])
@@ -442,12 +493,21 @@ class Gen:
             self.vmq.clear()
             for k_ in range(4):
                 self.dump(f"stA0[{k_}]", self.stA[0][k_])
-            for k_ in range(4):
+            for k_ in range(2 if c.conv else 4):
                 self.dump(f"stB0[{k_}]", self.stB[0][k_])
+            if c.conv:
+                for i_ in range(8):
+                    self.dump(f"conv koff[{i_}]", self.s_koff[i_])
+                    self.dump(f"conv kw[{i_}]", self.s_kw[i_])
+                    self.dump(f"conv vBoff[{i_}]", self.vBoff[i_])
+                    self.dump(f"conv stB[{i_}][0]", self.stB[i_][0])
+                    self.dump(f"conv stB[{i_}][1]", self.stB[i_][1])
             self.dump("stA_last[3]", self.stA[-1][3])
         for pi in range(c.NPA):
             self.store_A_piece(pi, k=2)     # tile 0 goes to LDS stage 0 = the "third" stage of the write triples
-        if c.b_kcontig:
+        if c.conv:
+            self.run_ops(self.conv_fix_store_ops(2))
+        elif c.b_kcontig:
             for pj in range(c.NPB):
                 self.store_B_kpiece(pj, k=2)
         else:
@@ -487,10 +547,178 @@ class Gen:
             e("v_lshlrev_b32", self.vFoff, 4, v(0))
 
     def issue_loads_all(self):
+        if self.c.conv:      # (B's gathers first, like the loop body: the two queues must carry the same order)
+            self.run_ops([o for grp in self.conv_load_ops() for o in grp])
         for pi in range(self.c.NPA):
             self.load_A_piece(pi)
+        if self.c.conv:
+            return
         for pj in range(self.c.NPB):
             self.load_B_piece(pj)
+
+    # ------------------------------------------------------------------ implicit-GEMM convolution: the B operand
+    # B "matrix" [K = Cin*9][N = oH*oW] of image b is never materialised (conv2d_im2col.nim:62-87 builds it explicitly):
+    # element (k, pixel) = input[c][oh + kh - pH][ow + kw - pW], k = (c*3 + kh)*3 + kw.  One wave-instruction gathers 2
+    # consecutive output pixels per lane (64 lanes = the tile's 128 pixels) of ONE k: the k part of the address is
+    # wave-uniform and rides in the load's SGPR offset, the pixel part is a per-lane constant.  Wave w owns k = 8w .. 8w+7
+    # of every K-tile: pairs (k, k+2) per lane exactly like the GEMM's pair mode.  Padding: rows outside the image get an
+    # offset the bounds check rejects (reads 0); at the left / right border the pair is loaded one pixel further inside
+    # the image (never outside the tensor) and shifted back in registers.
+    CONV_DELTA = (0, 2, 1, 3, 4, 6, 5, 7)      # piece i = 2*pair + j gathers k = 8w + delta: pairs (0,2) (1,3) (4,6) (5,7)
+
+    def conv_setup(self):
+        c, e, t, st, scr = self.c, self.p.emit, self.vt, self.s_t, self.s_scr
+        B_ = self.ka0.sub(2, 2)
+        sH, sW, soW, spH, spW, sCin, sNpix, smagic, sshift = (scr[i] for i in range(9))
+        e("s_load_dwordx8", scr.sub(0, 8), s(0, 2), KA_CONV0)
+        e("s_load_dwordx4", scr.sub(8, 4), s(0, 2), KA_CONV1)
+        e("s_load_dwordx2", scr.sub(12, 2), s(0, 2), KA_CONV2)
+        e("s_waitcnt", lgkmcnt=0)
+        if c.debug:
+            self.dump("wgid_y", s(3))
+            for i in range(14):
+                self.dump(f"scr[{i}] loaded", scr[i])
+        lane, pix, oh, ow = t[0], t[1], t[2], t[3]
+        e("v_and_b32", lane, 63, v(0))
+        e("v_lshl_add_u32", pix, lane, 1, self.s_n0)          # first of this lane's two output pixels
+        e("v_mul_hi_u32", oh, pix, smagic)
+        e("v_lshrrev_b32", oh, sshift, oh)                    # oh = pix / oW
+        e("v_mul_lo_u32", t[4], oh, soW)
+        e("v_sub_u32", ow, pix, t[4])                         # ow = pix % oW  (oW even: both pixels in one output row)
+        e("v_mul_lo_u32", t[4], oh, sW)
+        e("v_add_u32", t[4], t[4], ow)
+        e("v_lshlrev_b32", self.vBM, 2, t[4])                 # (oh*W + ow) * 4, relative to the window origin of pixel (0, 0)
+        e("v_cmp_gt_u32", self.s_m, sNpix, pix)               # pixels beyond the image (ragged last tile) gather nothing
+        if c.debug:
+            self.dump("s_m.lo first", self.s_m[0])
+            self.dump("pix", pix)
+            self.dump("oh", oh)
+            self.dump("ow", ow)
+        for kh in range(3):
+            e("v_add_u32", t[5], kh, oh)
+            e("v_subrev_u32", t[5], spH, t[5])                # input row oh + kh - pH (as unsigned: negative = huge)
+            e("v_cmp_gt_u32", self.s_rowm[kh], sH, t[5])
+            e("s_nop", 1)
+            e("s_and_b64", self.s_rowm[kh], self.s_rowm[kh], self.s_m)
+        if c.conv_pad:
+            e("v_cmp_eq_u32", self.s_mL, 0, ow)                # left border: kw = 0 would start at column -1
+            e("s_sub_u32", st[0], sW, 2)
+            e("v_cmp_eq_u32", self.s_mR, st[0], ow)            # right border: kw = 2 would end at column W
+            e("s_nop", 4)
+            e("v_add_u32", t[5], 4, self.vBM)
+            e("v_cndmask_b32", self.vBL, self.vBM, t[5], self.s_mL)
+            e("v_add_u32", t[5], 0xfffffffc, self.vBM)
+            e("v_cndmask_b32", self.vBR, self.vBM, t[5], self.s_mR)
+        # descriptor: base = B + b * bsB - (pH*W + pW) * 4 (the window origin of output pixel (0, 0), kernel tap (0, 0));
+        # every address a valid lane forms lies inside the image -- the bounds field only has to reject v_oob
+        e("s_mul_hi_u32", st[2], s(3), scr[10])
+        e("s_mul_i32", st[0], s(3), scr[10])
+        e("s_add_u32", st[0], B_[0], st[0])
+        e("s_addc_u32", st[2], B_[1], st[2])
+        e("s_mul_i32", st[3], spH, sW)
+        e("s_add_u32", st[3], st[3], spW)
+        e("s_lshl_b32", st[3], st[3], 2)
+        e("s_sub_u32", self.srdB[0], st[0], st[3])
+        e("s_subb_u32", self.srdB[1], st[2], 0)
+        e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+        e("s_mov_b32", self.srdB[2], 0x7fffffff)
+        e("s_lshl_b32", self.s_W4, sW, 2)
+        e("s_mul_i32", self.s_HW4, self.s_W4, sH)
+        e("s_mov_b32", self.s_Cin, sCin)
+        # LDS write addresses of pair gi, pixel e: x = 2*lane + e, k = 8w + (0, 1, 4, 5)[gi]: L = 2w + (gi & 1), word = (0,0,2,2)[gi]
+        e("s_mov_b32", st[0], c.BK * c.BM * 4)
+        for gi in range(4):
+            e("s_lshl_b32", st[3], self.s_wave, 1)
+            e("s_add_u32", st[3], st[3], gi & 1)
+            for ee in range(2):
+                xx, rr, ss = t[4], t[5], t[6]
+                e("v_lshl_add_u32", xx, lane, 1, ee)
+                self.kq_row(rr, xx, t[7])
+                self.kq_swz(ss, xx, t[7])
+                e("v_xor_b32", ss, st[3], ss)
+                e("v_mul_u32_u24", rr, c.BK * 4, rr)
+                e("v_lshl_add_u32", rr, ss, 4, rr)
+                e("v_add_u32", rr, 4 * (0, 0, 2, 2)[gi], rr)
+                e("v_add_u32", self.WB[gi][ee][2], st[0], rr)
+                e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
+                e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
+        # running k state of this wave: k0 = 8w -> (c0, r0) = (k0 / 9, k0 % 9)
+        e("s_lshl_b32", st[0], self.s_wave, 3)
+        e("s_mul_i32", self.s_c0, st[0], 57)
+        e("s_lshr_b32", self.s_c0, self.s_c0, 9)
+        e("s_mul_i32", st[2], self.s_c0, 9)
+        e("s_sub_u32", self.s_r0, st[0], st[2])
+
+    def conv_load_ops(self):
+        """per piece: [scalar k state ...] [offset select] [load]; then the state moves on by BK.  Returns a list of op groups."""
+        c, st = self.c, self.s_t
+        groups = []
+        for i in range(8):
+            d = self.CONV_DELTA[i]
+            g1 = [("ins", "s_add_u32", (st[0], self.s_r0, d), {}),
+                  ("ins", "s_cmp_ge_u32", (st[0], 9), {}),
+                  ("ins", "s_cselect_b32", (st[2], 9, 0), {}),
+                  ("ins", "s_cselect_b32", (st[3], 1, 0), {}),
+                  ("ins", "s_sub_u32", (st[0], st[0], st[2]), {}),          # r = (r0 + delta) mod 9
+                  ("ins", "s_add_u32", (st[1], self.s_c0, st[3]), {}),      # c
+                  ("ins", "s_mul_i32", (st[2], st[0], 11), {}),
+                  ("ins", "s_lshr_b32", (st[2], st[2], 5), {}),             # kh = r / 3
+                  ("ins", "s_mul_i32", (st[3], st[2], 3), {}),
+                  ("ins", "s_sub_u32", (self.s_kw[i], st[0], st[3]), {})]   # kw = r % 3
+            g2 = [("ins", "s_mul_i32", (st[3], st[1], self.s_HW4), {}),
+                  ("ins", "s_mul_i32", (st[4], st[2], self.s_W4), {}),
+                  ("ins", "s_add_u32", (st[3], st[3], st[4]), {}),
+                  ("ins", "s_lshl_b32", (st[4], self.s_kw[i], 2), {}),
+                  ("ins", "s_add_u32", (self.s_koff[i], st[3], st[4]), {}),  # (c*H*W + kh*W + kw) * 4
+                  ("ins", "s_cmp_eq_u32", (st[2], 0), {}),
+                  ("ins", "s_cselect_b64", (self.s_m, self.s_rowm[0], self.s_rowm[1]), {}),
+                  ("ins", "s_cmp_eq_u32", (st[2], 2), {}),
+                  ("ins", "s_cselect_b64", (self.s_m, self.s_rowm[2], self.s_m), {}),
+                  ("ins", "s_cmp_lt_u32", (st[1], self.s_Cin), {}),
+                  ("ins", "s_cselect_b64", (self.s_m, self.s_m, 0), {})]     # channels beyond Cin (k >= K): nothing
+            g3 = []
+            src = self.vBM
+            if c.conv_pad:
+                g2 += [("ins", "s_cmp_eq_u32", (self.s_kw[i], 0), {}),
+                       ("ins", "s_cselect_b64", (self.s_m2, -1, 0), {})]
+                g3 += [("ins", "v_cndmask_b32", (self.vBoff[i], self.vBM, self.vBL, self.s_m2), {}),
+                       ("ins", "s_cmp_eq_u32", (self.s_kw[i], 2), {}),
+                       ("ins", "s_cselect_b64", (self.s_m2, -1, 0), {}),
+                       ("ins", "v_cndmask_b32", (self.vBoff[i], self.vBoff[i], self.vBR, self.s_m2), {})]
+                src = self.vBoff[i]
+            g3 += [("ins", "v_cndmask_b32", (self.vBoff[i], self.v_oob, src, self.s_m), {}),
+                   ("loadBc", i)]
+            groups += [g1, g2, g3]
+        groups.append([("ins", "s_add_u32", (self.s_r0, self.s_r0, c.BK % 9), {}),
+                       ("ins", "s_add_u32", (self.s_c0, self.s_c0, c.BK // 9), {}),
+                       ("ins", "s_cmp_ge_u32", (self.s_r0, 9), {}),
+                       ("ins", "s_cselect_b32", (st[2], 9, 0), {}),
+                       ("ins", "s_cselect_b32", (st[3], 1, 0), {}),
+                       ("ins", "s_sub_u32", (self.s_r0, self.s_r0, st[2]), {}),
+                       ("ins", "s_add_u32", (self.s_c0, self.s_c0, st[3]), {})])
+        return groups
+
+    def conv_fix_store_ops(self, k):
+        """tile data in the B staging registers -> border fix-up (padding kernels) -> LDS stage index k"""
+        c, out = self.c, []
+        for i in range(8):
+            P = self.stB[i]
+            out.append(("vmwait", ("B", i)))
+            if c.conv_pad:
+                out += [("ins", "s_cmp_eq_u32", (self.s_kw[i], 0), {}),
+                        ("ins", "s_cselect_b64", (self.s_m, self.s_mL, 0), {}),
+                        ("ins", "s_cmp_eq_u32", (self.s_kw[i], 2), {}),
+                        ("ins", "s_cselect_b64", (self.s_m2, self.s_mR, 0), {}),
+                        # left border: loaded (col 0, col 1), wanted (0, col 0); right: loaded (W-2, W-1), wanted (W-1, 0)
+                        ("ins", "v_cndmask_b32", (P[1], P[1], P[0], self.s_m), {}),
+                        ("ins", "v_cndmask_b32", (P[0], P[0], 0, self.s_m), {}),
+                        ("ins", "v_cndmask_b32", (P[0], P[0], P[1], self.s_m2), {}),
+                        ("ins", "v_cndmask_b32", (P[1], P[1], 0, self.s_m2), {})]
+        for gi in range(4):
+            P, Q = self.stB[2 * gi], self.stB[2 * gi + 1]
+            for ee in range(2):
+                out.append(("ldsw", "ds_write2_b32", (self.WB[gi][ee][k], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
+        return out
 
     def load_A_piece(self, pi):
         if "loads" in self.c.ablate:
@@ -508,7 +736,7 @@ class Gen:
         """descriptors move one K-tile along k: base += step, bytes = max(bytes - step, 0)"""
         e = self.p.emit
         ops = []
-        for srd, step in ((self.srdA, self.c.BK * 4), (self.srdB, self.s_bstep)):
+        for srd, step in ((self.srdA, self.c.BK * 4),) + (() if self.c.conv else ((self.srdB, self.s_bstep),)):
             ops += [("s_add_u32", srd[0], srd[0], step), ("s_addc_u32", srd[1], srd[1], 0),
                     ("s_sub_u32", srd[2], srd[2], step), ("s_cselect_b32", srd[2], 0, srd[2])]
         if which is None:
@@ -544,7 +772,7 @@ class Gen:
     def apply_tail_mask(self):
         """the loads issued from here on fetch the last K-tile: pieces beyond K read as 0"""
         e = self.p.emit
-        regs = list(self.vVA) + (list(self.vVB) if self.c.b_kcontig else [])
+        regs = list(self.vVA) + (list(self.vVB) if (self.c.b_kcontig and not self.c.conv) else [])
         for r in regs:
             e("v_cndmask_b32", r, self.v_oob, r, self.s_tm)
 
@@ -611,6 +839,10 @@ class Gen:
             self.load_A_piece(o[1])
         elif kind == "loadB":
             self.load_B_piece(o[1])
+        elif kind == "loadBc":
+            if "loads" not in self.c.ablate:
+                self.p.emit("buffer_load_dwordx2", self.stB[o[1]], self.vBoff[o[1]], self.srdB, self.s_koff[o[1]], offen=True)
+                self.vm_issue(("B", o[1]))
         elif kind == "barrier":
             self.lg_wait(None)
             self.p.emit("s_barrier")
@@ -674,7 +906,9 @@ class Gen:
         for pi in range(c.NPA):
             stg += self.store_A_piece(pi, ops=[], k=wr_k)
             stg.append(("loadA", pi))
-        if c.b_kcontig:
+        if c.conv:
+            pass
+        elif c.b_kcontig:
             for pj in range(c.NPB):
                 stg += self.store_B_kpiece(pj, ops=[], k=wr_k)
                 stg.append(("loadB", pj))
@@ -690,6 +924,29 @@ class Gen:
                 units[-1].append(op)
             else:
                 units.append([op])
+        if c.conv:
+            # B first (its gather was requested a tile ago and is needed soonest: fix-up + store, then the scalar k state,
+            # the offset selects and the 8 gathers of tile t+2), then A's pieces; one unit per gap, VALU work batched per unit
+            fs = self.conv_fix_store_ops(wr_k)
+            cu, cur = [], []
+            for op in fs:
+                if op[0] == "vmwait" and cur:
+                    cu.append(cur)
+                    cur = []
+                if op[0] == "ldsw":
+                    if cur:
+                        cu.append(cur)
+                        cur = []
+                    cu.append([op])
+                else:
+                    cur.append(op)
+            if cur:
+                cu.append(cur)
+            a_units = []
+            for pi in range(c.NPA):
+                a = self.store_A_piece(pi, ops=[], k=wr_k)
+                a_units += [a[:2], [a[2]], [("loadA", pi)]]
+            units = cu + self.conv_load_ops() + a_units
         w0 = max(c.w_start, first_free + (c.TM + c.TN + 2 if fold else 0))
         span = bar - 1 - w0
         step = c.w_step or max(1.0, span / max(1, len(units)))
@@ -978,6 +1235,7 @@ amdhsa.kernels:
       - {{.size: 4, .offset: 52, .value_kind: by_value}}
       - {{.size: 8, .offset: 56, .value_kind: by_value}}
       - {{.size: 8, .offset: 64, .value_kind: global_buffer, .address_space: global}}
+      - {{.size: {KERNARG_SIZE - 72}, .offset: 72, .value_kind: by_value}}
 ...
 \t.end_amdgpu_metadata
 """

@@ -141,7 +141,7 @@ class Workgroup:
             assert x.kind == "s" and x.n == 2
             self._chk_pending(w, x.regs())
             return (int(w.s[x.idx]) & 0xffffffff) | ((int(w.s[x.idx + 1]) & 0xffffffff) << 32)
-        return int(x) & ((1 << 64) - 1) if x >= 0 else (int(x) & ((1 << 64) - 1))
+        return int(x) & ((1 << 64) - 1)
 
     def wr_s64(self, w, x, val):
         val &= (1 << 64) - 1
@@ -326,6 +326,18 @@ class Workgroup:
                  "s_xor_b32": x ^ y, "s_andn2_b32": x & ~y}[op] & 0xffffffff
             sw(A[0], r)
             w.scc = int(r != 0)
+        elif op == "s_subb_u32":
+            x, y = rs(w, A[1]), rs(w, A[2])
+            r = x - y - w.scc
+            sw(A[0], r)
+            w.scc = int(y + w.scc > x)
+        elif op in ("s_and_b64", "s_or_b64", "s_andn2_b64"):
+            x, y = self.rd_s64(w, A[1]), self.rd_s64(w, A[2])
+            r = {"s_and_b64": x & y, "s_or_b64": x | y, "s_andn2_b64": x & ~y}[op] & ((1 << 64) - 1)
+            self.wr_s64(w, A[0], r)
+            w.scc = int(r != 0)
+        elif op == "s_cselect_b64":
+            self.wr_s64(w, A[0], self.rd_s64(w, A[1]) if w.scc else self.rd_s64(w, A[2]))
         elif op in ("s_min_u32", "s_max_u32"):
             x, y = rs(w, A[1]), rs(w, A[2])
             r = min(x, y) if op == "s_min_u32" else max(x, y)
@@ -377,10 +389,10 @@ class Workgroup:
         elif op == "v_mov_b32":
             self.wr_v(w, A[0], rv(w, A[1]))
         elif op in ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mul_lo_u32", "v_mul_u32_u24", "v_and_b32", "v_or_b32", "v_xor_b32",
-                    "v_lshlrev_b32", "v_lshrrev_b32", "v_min_u32", "v_max_u32"):
+                    "v_lshlrev_b32", "v_lshrrev_b32", "v_min_u32", "v_max_u32", "v_mul_hi_u32"):
             x, y = rv(w, A[1]).astype(np.uint64), rv(w, A[2]).astype(np.uint64)
             r = {"v_add_u32": lambda: x + y, "v_sub_u32": lambda: x - y, "v_subrev_u32": lambda: y - x,
-                 "v_mul_lo_u32": lambda: x * y, "v_mul_u32_u24": lambda: (x & 0xffffff) * (y & 0xffffff),
+                 "v_mul_lo_u32": lambda: x * y, "v_mul_hi_u32": lambda: (x * y) >> np.uint64(32), "v_mul_u32_u24": lambda: (x & 0xffffff) * (y & 0xffffff),
                  "v_and_b32": lambda: x & y, "v_or_b32": lambda: x | y, "v_xor_b32": lambda: x ^ y,
                  "v_lshlrev_b32": lambda: y << (x & 31), "v_lshrrev_b32": lambda: y >> (x & 31),
                  "v_min_u32": lambda: np.minimum(x, y), "v_max_u32": lambda: np.maximum(x, y)}[op]()

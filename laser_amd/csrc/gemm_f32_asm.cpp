@@ -29,13 +29,16 @@ struct KernelInfo {
 // [0] laser-order, large tile  [1] one chain, large tile  [2] laser-order, 128x128  [3] one chain, 128x128;
 // [4..7] the same with B passed transposed (unit ROW stride: k-contiguous like A, BASELINE configs[2])
 // [8] / [9]: one chain on the 256x128x32 tile (plain / B transposed): finer tile quantisation for the fast mode
-constexpr int kNumKernels = 10;
+// [10..13]: implicit-GEMM convolution, 3x3 kernel, stride 1: padding 1 (laser-order / one chain), padding 0 (same)
+constexpr int kNumKernels = 14;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32},    {"lh_f32_fast_256x256x16", 256, 256, 16},
     {"lh_f32_exact_128x128x16", 128, 128, 16},    {"lh_f32_fast_128x128x16", 128, 128, 16},
     {"lh_f32_exact_256x128x32_nt", 256, 128, 32}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16},
     {"lh_f32_exact_128x128x16_nt", 128, 128, 16}, {"lh_f32_fast_128x128x16_nt", 128, 128, 16},
-    {"lh_f32_fast_256x128x32", 256, 128, 32},     {"lh_f32_fast_256x128x32_nt", 256, 128, 32}};
+    {"lh_f32_fast_256x128x32", 256, 128, 32},     {"lh_f32_fast_256x128x32_nt", 256, 128, 32},
+    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32},   {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32},
+    {"lh_f32_conv3x3p0_exact_256x128x32", 256, 128, 32}, {"lh_f32_conv3x3p0_fast_256x128x32", 256, 128, 32}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -54,8 +57,12 @@ struct KernArgs {
   uint32_t lda, ldb, ldc, M, N, K;
   uint64_t reserved;
   void *dbg;
+  // convolution kernels only (f32_kernel.py KA_CONV*)
+  uint32_t H, W, oW, pH, pW, Cin, Npix, magic_oW;
+  uint32_t shift_oW, pad_;
+  uint64_t bsB_bytes, bsC_bytes;
 };
-static_assert(sizeof(KernArgs) == 72, "kernel argument block layout (f32_kernel.py KA_*)");
+static_assert(sizeof(KernArgs) == 128, "kernel argument block layout (f32_kernel.py KA_*)");
 
 // blockIdx -> tile: block b runs on XCD b % 8; give every XCD a contiguous chunk of tile ids (bijective for any grid),
 // then walk the tiles in groups of group_m tile rows so the ~32 workgroups resident on an XCD form a compact patch.
@@ -182,6 +189,8 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.K = (uint32_t)a.K;
   ka.reserved = 0;
   ka.dbg = nullptr;
+  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
+  ka.bsB_bytes = ka.bsC_bytes = 0;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
@@ -189,6 +198,88 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
     g_last_f32_asm = 1 + pick;
     g_last_split = 0;  // one launch
   }
+  return e;
+}
+
+
+// Implicit-GEMM convolution (conv2d_im2col.nim:102-166 minus the materialised im2col matrix): output pixels [0, a.N) of every
+// image, a.N a multiple of the 128-pixel tile or the whole image.  GemmArgs as launch_conv_implicit_f32 builds them (A = the
+// filter [M][K], B = the NCHW input, batch = images).  hipErrorNotSupported: not this kernel's class.
+hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
+  if (!g_f32_asm) return hipErrorNotSupported;
+  if (a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.cs_imgs != 0) return hipErrorNotSupported;
+  if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
+  if (a.ckH != 3 || a.ckW != 3 || a.csH != 1 || a.csW != 1) return hipErrorNotSupported;
+  if (!((a.cpH == 1 && a.cpW == 1) || (a.cpH == 0 && a.cpW == 0))) return hipErrorNotSupported;
+  const int64_t oW = a.coW, oH = a.cH + 2 * a.cpH - 2, npix = oH * oW;
+  if (oW != a.cW + 2 * a.cpW - 2 || oW <= 0 || oH <= 0 || (oW & 1) || (a.cW & 1)) return hipErrorNotSupported;  // pixel pairs stay in one row
+  if (a.csA != 1 || a.rsA != a.K || a.csC != 1 || a.rsC != npix || a.K % 36 != 0 || a.K < 36) return hipErrorNotSupported;  // K = Cin * 9, a multiple of 4
+  if (a.N > npix || (a.N != npix && a.N % 128 != 0)) return hipErrorNotSupported;
+  if (a.batch < 1 || a.batch > 65535 || a.M > 0xffff * 256ll) return hipErrorNotSupported;
+  const int64_t Cin = a.K / 9;
+  if ((double)Cin * a.cH * a.cW * 4.0 >= 2.0e9 || (double)a.M * npix * 4.0 >= 2.0e9 || (double)a.rsA * 4.0 * 256 >= 4.0e9) return hipErrorNotSupported;
+  const bool exact = laser_order && a.K > 512;
+  const int pick = (a.cpH == 1 ? 10 : 12) + (exact || a.K <= 512 ? 0 : 1);
+  const KernelInfo &ki = kKernels[pick];
+  const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
+  const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  if (g_f32_asm < 2 && tiles * a.batch < 160) return hipErrorNotSupported;
+  // a 256-row tile that is mostly padding (few output channels) loses to the compiler-scheduled 128 / 64-row tiles
+  if (g_f32_asm < 2 && (double)a.M * (double)a.N < 0.75 * (double)tiles * ki.bm * ki.bn) return hipErrorNotSupported;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(g_mods_mu);
+  DeviceModule *m = nullptr;
+  e = get_module(dev, &m);
+  if (e != hipSuccess) return e;
+  // (one image's tiles are few: plain row-major order of the tile ids keeps an image's pixels together in an XCD's L2)
+  const auto key = std::make_tuple(tiles_m, tiles_n, 1 << 20);
+  auto it = m->tables.find(key);
+  if (it == m->tables.end()) {
+    auto *host = new std::vector<uint32_t>((size_t)tiles);
+    for (int pn = 0, i = 0; pn < tiles_n; pn++)
+      for (int pm = 0; pm < tiles_m; pm++) (*host)[(size_t)i++] = (uint32_t)pm | ((uint32_t)pn << 16);
+    uint32_t *devp = nullptr;
+    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      if (devp) (void)hipFree(devp);
+      delete host;
+      return e;
+    }
+    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
+  }
+  KernArgs ka;
+  ka.A = a.A;
+  ka.B = a.B;
+  ka.C = a.C;
+  ka.table = it->second.first;
+  ka.lda = (uint32_t)a.rsA;
+  ka.ldb = 0;
+  ka.ldc = (uint32_t)npix;
+  ka.M = (uint32_t)a.M;
+  ka.N = (uint32_t)a.N;
+  ka.K = (uint32_t)a.K;
+  ka.reserved = 0;
+  ka.dbg = nullptr;
+  ka.H = (uint32_t)a.cH;
+  ka.W = (uint32_t)a.cW;
+  ka.oW = (uint32_t)oW;
+  ka.pH = (uint32_t)a.cpH;
+  ka.pW = (uint32_t)a.cpW;
+  ka.Cin = (uint32_t)Cin;
+  ka.Npix = (uint32_t)npix;
+  ka.magic_oW = (uint32_t)((1ull << 32) / (uint64_t)oW + 1);   // floor(p / oW) = mulhi(p, magic) for p * oW < 2^32
+  ka.shift_oW = 0;
+  ka.pad_ = 0;
+  ka.bsB_bytes = (uint64_t)a.bsB * 4;
+  ka.bsC_bytes = (uint64_t)a.bsC * 4;
+  if ((double)npix * (double)oW >= 4.0e9) return hipErrorNotSupported;
+  size_t sz = sizeof(ka);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);
+  if (e == hipSuccess) g_last_f32_asm = 1 + pick;
   return e;
 }
 

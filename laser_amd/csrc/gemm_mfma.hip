@@ -295,7 +295,16 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     plan.cfg_main = cfg;
   plan.cfg_main = fix(plan.cfg_main);
   g_last_split = plan.n_cut;
-  if (plan.n_cut <= 0) return launch_conv_cfg(a, plan.cfg_main, exact, s);
+  // the main part (whole 128-pixel tiles, or the whole image) on the hand-scheduled assembly kernel when it is a 3x3 /
+  // stride-1 convolution; hipErrorNotSupported = not its class: the compiler-scheduled loaders below
+  const auto main_launch = [&](const GemmArgs<float> &mm, hipStream_t q) {
+    if (cfg < 0) {
+      const hipError_t e = launch_conv_f32_asm(mm, laser_order, q);
+      if (e != hipErrorNotSupported) return e;
+    }
+    return launch_conv_cfg(mm, plan.cfg_main, exact, q);
+  };
+  if (plan.n_cut <= 0) return main_launch(a, s);
   GemmArgs<float> m = a;  // output pixels [0, n_cut) of every image
   m.N = plan.n_cut; m.Next = plan.n_cut;
   GemmArgs<float> t = a;  // output pixels [n_cut, oH*oW)
@@ -308,7 +317,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   const int64_t nsl = (a.K + 511) / 512, ntail = a.N - plan.n_cut;
   if (exact && g_conv_kslice && g_split_tail && nsl >= 2 && a.bias == nullptr && a.act == 0 && a.bsC == a.M * a.rsC &&
       (int64_t)a.batch * nsl <= 65535) {
-    if (hipError_t e = launch_conv_cfg(m, plan.cfg_main, exact, s); e != hipSuccess) return e;
+    if (hipError_t e = main_launch(m, s); e != hipSuccess) return e;
     const int64_t mn = a.M * ntail;
     float *W = nullptr;
     if (hipError_t e = hipMallocAsync((void **)&W, (size_t)(nsl * a.batch * mn) * sizeof(float), s); e != hipSuccess) return e;
@@ -326,7 +335,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     return e != hipSuccess ? e : e2;
   }
   return launch_main_and_tail(
-      s, [&](hipStream_t q) { return launch_conv_cfg(m, plan.cfg_main, exact, q); },
+      s, [&](hipStream_t q) { return main_launch(m, q); },
       [&](hipStream_t q) { return launch_conv_cfg(t, cfg_tail, exact, q); });
 }
 

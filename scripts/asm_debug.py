@@ -20,24 +20,42 @@ name = sys.argv[1] if len(sys.argv) > 1 else "exact_256x128x32"
 g = K.make(name, debug=True)
 g.build()
 c = g.c
-M, N, Kd = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (c.BM, c.BN, 2 * c.BK)
 rng = np.random.default_rng(0)
-A = rng.uniform(-0.1, 0.1, (M, Kd)).astype(np.float32)
-B = rng.uniform(-0.1, 0.1, (Kd, N)).astype(np.float32)
+NIMG = 1
+if c.conv:   # usage: asm_debug.py conv3x3_... images Cin H W M
+    NIMG, Cin, H, W, M = (int(x) for x in sys.argv[2:7]) if len(sys.argv) > 6 else (2, 8, 12, 16, 40)
+    pad = 1 if c.conv_pad else 0
+    oH, oW = H + 2 * pad - 2, W + 2 * pad - 2
+    N, Kd = oH * oW, Cin * 9
+    A = rng.uniform(-0.1, 0.1, (M, Kd)).astype(np.float32)
+    B = rng.uniform(-0.1, 0.1, (NIMG, Cin, H, W)).astype(np.float32)
+    xp = np.zeros((NIMG, Cin, H + 2 * pad, W + 2 * pad), dtype=np.float64)
+    xp[:, :, pad:pad + H, pad:pad + W] = B
+    want = np.stack([A.astype(np.float64) @ np.stack([xp[b, ci, kh:kh + oH, kw:kw + oW].reshape(-1) for ci in range(Cin) for kh in range(3) for kw in range(3)])
+                     for b in range(NIMG)])
+    conv_args = struct.pack("<IIIIIIII", H, W, oW, pad, pad, Cin, N, (1 << 32) // oW + 1) + struct.pack("<IIQ", 0, 0, Cin * H * W * 4) + struct.pack("<Q", M * N * 4)
+    lds = (Kd, 0, N)
+else:
+    M, N, Kd = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (c.BM, c.BN, 2 * c.BK)
+    A = rng.uniform(-0.1, 0.1, (M, Kd)).astype(np.float32)
+    B = rng.uniform(-0.1, 0.1, (Kd, N)).astype(np.float32)
+    want = (A.astype(np.float64) @ B.astype(np.float64))[None]
+    conv_args = b"\0" * 56
+    lds = (Kd, N, N)
 tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
 table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
 NS = g.ndump
 
 # ---- interpreter ----
 mem = Memory()
-a_, b_, c_, t_ = mem.alloc(A), mem.alloc(B), mem.alloc(np.full((M, N), np.nan, np.float32)), mem.alloc(table)
+a_, b_, c_, t_ = mem.alloc(A), mem.alloc(B), mem.alloc(np.full((NIMG, M, N), np.nan, np.float32)), mem.alloc(table)
 d_ = mem.alloc(np.zeros(NS * 256 + 64, dtype=np.uint32))
-ka_ = mem.alloc(np.frombuffer(struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, Kd, N, N, M, N, Kd, 0, d_), dtype=np.uint8))
-for wg in range(len(table)):
-    Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc).run()
+ka_ = mem.alloc(np.frombuffer(struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, lds[0], lds[1], lds[2], M, N, Kd, 0, d_) + conv_args, dtype=np.uint8))
+for img in range(NIMG):
+    for wg in range(len(table)):
+        Workgroup(g.p, mem, ka_, wg_id=(wg, img), lds_bytes=c.lds_alloc).run()
 sim_dump = mem.get(d_, np.uint32, (NS * 256 + 64,))[:NS * 256].reshape(NS, 256).copy()
-sim_C = mem.get(c_, np.float32, (M, N)).copy()
-want = (A.astype(np.float64) @ B.astype(np.float64))
+sim_C = mem.get(c_, np.float32, (NIMG, M, N)).copy()
 print("interpreter: C max abs err vs fp64", float(np.nanmax(np.abs(sim_C - want))), "nan count", int(np.isnan(sim_C).sum()))
 
 # ---- hardware ----
@@ -60,14 +78,14 @@ mod, fn = C.c_void_p(), C.c_void_p()
 assert hip.hipModuleLoad(C.byref(mod), (sp + ".hsaco").encode()) == 0
 assert hip.hipModuleGetFunction(C.byref(fn), mod, b"lh_dbg") == 0
 dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
-dC = torch.full((M, N), float("nan"), device="cuda")
+dC = torch.full((NIMG, M, N), float("nan"), device="cuda")
 dT = torch.from_numpy(table.astype(np.int32)).cuda()
 dD = torch.zeros(NS * 256 + 64, dtype=torch.int32, device="cuda")
-ka = struct.pack("<QQQQIIIIIIQQ", dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), dT.data_ptr(), Kd, N, N, M, N, Kd, 0, dD.data_ptr())
+ka = struct.pack("<QQQQIIIIIIQQ", dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), dT.data_ptr(), lds[0], lds[1], lds[2], M, N, Kd, 0, dD.data_ptr()) + conv_args
 buf = C.create_string_buffer(ka, len(ka))
 size = C.c_size_t(len(ka))
 extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)
-rc = hip.hipModuleLaunchKernel(fn, len(table), 1, 1, 256, 1, 1, 0, torch.cuda.current_stream().cuda_stream, None, extra)
+rc = hip.hipModuleLaunchKernel(fn, len(table), NIMG, 1, 256, 1, 1, 0, torch.cuda.current_stream().cuda_stream, None, extra)
 assert rc == 0, rc
 torch.cuda.synchronize()
 hw_dump = dD.cpu().numpy().view(np.uint32)[:NS * 256].reshape(NS, 256)
