@@ -156,8 +156,15 @@ def side_configs(budget_s=10.0):
     t_start = time.perf_counter()
 
     def gpu_ms(fn, inner=4, reps=3):
+        # steady state: the clocks ramp up over the first ~20 ms of work after an idle gap (the CPU oracle runs between the
+        # lines); a C4 conv launch measured 470 us right after idle and 405 us fifty launches later
         fn(); fn()
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.03:
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -95,7 +95,8 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     g.build()
     c = g.c
     rng = np.random.default_rng(seed)
-    oH, oW = H + 2 * pad - 2, W + 2 * pad - 2
+    pH, pW = (pad, pad) if isinstance(pad, int) else pad
+    oH, oW = H + 2 * pH - 2, W + 2 * pW - 2
     npix = oH * oW
     N = n_cut or npix
     Kd = Cin * 9
@@ -108,7 +109,7 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     # the input is placed with nothing mapped directly before / after it: any access outside the tensor is an error
     a_, b_, c_, t_ = mem.alloc(w), mem.alloc(x), mem.alloc(out), mem.alloc(table)
     ka = struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, Kd, 0, npix, M, N, Kd, 0, 0)
-    ka += struct.pack("<IIIIIIII", H, W, oW, pad, pad, Cin, npix, (1 << 32) // oW + 1)
+    ka += struct.pack("<IIIIIIII", H, W, oW, pH, pW, Cin, npix, (1 << 32) // oW + 1)
     ka += struct.pack("<IIQ", 0, 0, Cin * H * W * 4)
     ka += struct.pack("<Q", M * npix * 4)
     assert len(ka) == K.KERNARG_SIZE
@@ -120,8 +121,8 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     got = mem.get(c_, np.float32, (images, M, npix))
     ok = True
     for img in range(images):
-        xp = np.zeros((Cin, H + 2 * pad, W + 2 * pad), dtype=np.float32)
-        xp[:, pad:pad + H, pad:pad + W] = x[img]
+        xp = np.zeros((Cin, H + 2 * pH, W + 2 * pW), dtype=np.float32)
+        xp[:, pH:pH + H, pW:pW + W] = x[img]
         Bm = np.stack([xp[ci, kh:kh + oH, kw:kw + oW].reshape(-1) for ci in range(Cin) for kh in range(3) for kw in range(3)])
         want = reference(w, Bm, 512 if c.exact else 0)
         ok &= bool(np.array_equal(got[img][:, :N], want[:, :N]))

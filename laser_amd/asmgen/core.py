@@ -47,7 +47,7 @@ class Sym:
         return self.name
 
 
-VCC, EXEC, OFF = Sym("vcc"), Sym("exec"), Sym("off")
+VCC, EXEC, OFF, M0 = Sym("vcc"), Sym("exec"), Sym("off"), Sym("m0")
 
 
 class Ins:

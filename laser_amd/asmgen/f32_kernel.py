@@ -15,12 +15,12 @@ Shape of the kernel (one workgroup = one BM x BN tile of C, 4 waves = ONE wave p
 Restrictions (the launcher falls back to the compiler-scheduled kernels otherwise): float32, A and C row-major-like
 (unit column stride), B unit column stride (NN) or unit row stride (NT), K a multiple of BK, alpha == 1, beta == 0.
 """
-from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF
+from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 
 
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
-                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, conv_pad=True):
+                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
         self.WTM, self.WTN = BM // 2, BN // 2
         self.TM, self.TN = self.WTM // 32, self.WTN // 32
@@ -31,9 +31,12 @@ class Cfg:
         self.STAGE = BK * (BM + BN) * 4
         self.NPA = BM * BK // 4 // 256   # 16-byte pieces of A per thread per tile
         self.NPB = BN * BK // 4 // 256
-        # implicit-GEMM convolution (3x3, stride 1): B is the NCHW image, gathered by the loader as 8-byte pieces (2 output
-        # pixels of one k = (channel, kernel row, kernel column)); conv_pad: the variant for padding 1 (border columns)
-        self.conv, self.conv_pad = conv, conv_pad
+        # implicit-GEMM convolution (3x3, stride 1, any zero padding): B is the NCHW image; a piece = 2 output pixels per
+        # lane of one k = (channel, kernel row, kernel column), gathered by two dword loads whose per-lane offsets come
+        # from a 10-entry table in LDS (one entry per kernel tap + "nothing"), indexed by the wave-uniform tap
+        self.conv = conv
+        self.TAB_ENTRY, self.TAB_E1 = 256, 2560          # bytes per table entry (64 lanes x 4), offset of the second pixel's table
+        self.LDS0 = 2 * self.TAB_E1 if conv else 0       # the table sits below the stage ring (ds_read_addtid reaches 64 KiB)
         if conv:
             assert (BN, BK) == (128, 32) and not b_kcontig
             self.NPB = 8
@@ -48,7 +51,7 @@ class Cfg:
         self.r_step = r_step
         self.filler, self.filler_every = filler, filler_every   # pricing experiments: one extra instruction of this kind per gap
         self.debug = debug          # dump intermediate state of workgroup 0 to the kernarg's debug buffer (asm_debug.py)
-        self.lds_bytes = 3 * self.STAGE
+        self.lds_bytes = self.LDS0 + 3 * self.STAGE
         assert self.lds_bytes <= 160 * 1024
         self.lds_alloc = self.lds_bytes + (16384 if filler else 0)
         assert self.lds_alloc <= 160 * 1024
@@ -69,11 +72,9 @@ CONFIGS = {
     "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
     # one chain on the laser-order kernels' tile: halves the tile quantisation of the 256x256 tile (4100^3: 289 tiles of
     # 256x256 are 1.13 rounds of the chip, 561 tiles of 256x128 are 2.19)
-    # implicit-GEMM convolution, 3x3 kernel, stride 1 (benchmarks/convolution/conv2d_im2col.nim): padding 1 / padding 0
-    "conv3x3_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True, conv_pad=True),
-    "conv3x3_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True, conv_pad=True),
-    "conv3x3p0_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True, conv_pad=False),
-    "conv3x3p0_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True, conv_pad=False),
+    # implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (benchmarks/convolution/conv2d_im2col.nim)
+    "conv3x3_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True),
+    "conv3x3_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True),
     "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
 }
@@ -125,15 +126,14 @@ class Gen:
         self.WA = [[[V() for _ in range(3)] for _ in range(c.NPA)] for _ in range(2)]   # [MFMA half][piece][stage]
         if c.conv:
             self.WB = [[[V() for _ in range(3)] for _ in range(2)] for _ in range(4)]       # [pair][pixel of the piece][stage]
-            self.vBM, self.vBL, self.vBR = V(), V(), V()   # image offset of the lane's pixel pair (plain / shifted into the image at the left / right border)
-            self.vBoff = [V() for _ in range(8)]
+            self.vB0 = [V() for _ in range(8)]             # per piece: buffer offset of the lane's first / second pixel for the
+            self.vB1 = [V() for _ in range(8)]             # piece's tap (read from the LDS table; 0x80000000 = padding)
             scr = S(16, align=4)
             self.s_scr = scr
             self.s_koff = [scr[i] for i in range(8)]       # per piece: (c*H*W + kh*W + kw) * 4 of the k it gathers
-            self.s_kw = [scr[8 + i] for i in range(8)]     # per piece: kernel column of that k (border fix-up one tile later)
             self.s_c0, self.s_r0 = S(), S()                # (channel, kh*3 + kw) of this wave's first k in the tile being loaded
-            self.s_rowm = [S(2) for _ in range(3)]         # lanes whose input row oh + kh - pH exists
-            self.s_mL, self.s_mR = S(2), S(2)              # lanes at the left / right image border
+            self.s_rowm = [S(2) for _ in range(3)]         # prologue: lanes whose input row oh + kh - pH exists
+            self.s_c0m, self.s_c1m = S(2), S(2)            # prologue: lanes whose first / second pixel's column ow (+1) + kw - pW exists
             self.s_m, self.s_m2 = S(2), S(2)
             self.s_HW4, self.s_W4, self.s_Cin = S(), S(), S()
         elif c.b_kcontig:
@@ -280,9 +280,11 @@ class Gen:
         # fragment reads of group g: (wm0 + lor) * BK * 4 [+ BK*BM*4 + (wn0 + lor) * BK * 4 for B] + 16 * ((2g + hi) ^ kqs)
         e("v_add_u32", t[5], self.s_wm0, lor)
         e("v_mul_u32_u24", t[6], c.BK * 4, t[5])
+        if c.LDS0:
+            e("v_add_u32", t[6], c.LDS0, t[6])
         e("v_add_u32", t[5], self.s_wn0, lor)
         e("v_mul_u32_u24", t[7], c.BK * 4, t[5])
-        e("v_add_u32", t[7], c.BK * c.BM * 4, t[7])
+        e("v_add_u32", t[7], c.LDS0 + c.BK * c.BM * 4, t[7])
         for g in range(c.NG):
             e("v_or_b32", t[5], 2 * g, hi)
             e("v_xor_b32", t[5], t[5], kqs)
@@ -333,7 +335,7 @@ class Gen:
                 e("v_add_u32", Voff[i], st[4], Voff[i - 1])
 
         e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
-        kcontig(self.WA, self.vVA, c.NPA, st[3], 0)
+        kcontig(self.WA, self.vVA, c.NPA, st[3], c.LDS0)
         e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
         if c.b_kcontig:
             kcontig(self.WB, self.vVB, c.NPB, st[5], c.BK * c.BM * 4)
@@ -411,13 +413,10 @@ class Gen:
         if c.conv:
             self.conv_setup()
             if c.debug:
-                self.dump("conv vBM", self.vBM)
-                if c.conv_pad:
-                    self.dump("conv vBL", self.vBL)
-                    self.dump("conv vBR", self.vBR)
                 for kh in range(3):
                     self.dump(f"conv rowm[{kh}].lo", self.s_rowm[kh][0])
-                    self.dump(f"conv rowm[{kh}].hi", self.s_rowm[kh][1])
+                for r_ in range(0, 20, 4):
+                    self.dump_lds(f"tab[{r_ * 256}+4tid]", r_ * 256)
                 self.dump("conv c0", self.s_c0)
                 self.dump("conv r0", self.s_r0)
                 self.dump("conv HW4", self.s_HW4)
@@ -498,15 +497,15 @@ class Gen:
             if c.conv:
                 for i_ in range(8):
                     self.dump(f"conv koff[{i_}]", self.s_koff[i_])
-                    self.dump(f"conv kw[{i_}]", self.s_kw[i_])
-                    self.dump(f"conv vBoff[{i_}]", self.vBoff[i_])
+                    self.dump(f"conv vB0[{i_}]", self.vB0[i_])
+                    self.dump(f"conv vB1[{i_}]", self.vB1[i_])
                     self.dump(f"conv stB[{i_}][0]", self.stB[i_][0])
                     self.dump(f"conv stB[{i_}][1]", self.stB[i_][1])
             self.dump("stA_last[3]", self.stA[-1][3])
         for pi in range(c.NPA):
             self.store_A_piece(pi, k=2)     # tile 0 goes to LDS stage 0 = the "third" stage of the write triples
         if c.conv:
-            self.run_ops(self.conv_fix_store_ops(2))
+            self.run_ops([o for grp in self.conv_store_ops(2) for o in grp])
         elif c.b_kcontig:
             for pj in range(c.NPB):
                 self.store_B_kpiece(pj, k=2)
@@ -517,8 +516,8 @@ class Gen:
             self.lg_wait(None)
             e("s_barrier")
             for k_ in range(0, 8):
-                self.dump_lds(f"lds[{k_ * 1024}+4tid]", k_ * 1024)
-            self.dump_lds("ldsB[0+4tid]", c.BK * c.BM * 4)
+                self.dump_lds(f"lds[{k_ * 1024}+4tid]", c.LDS0 + k_ * 1024)
+            self.dump_lds("ldsB[0+4tid]", c.LDS0 + c.BK * c.BM * 4)
             e("s_barrier")
         self.tail_mask_if(self.s_rem, 2)
         self.issue_loads_all()
@@ -558,12 +557,15 @@ class Gen:
 
     # ------------------------------------------------------------------ implicit-GEMM convolution: the B operand
     # B "matrix" [K = Cin*9][N = oH*oW] of image b is never materialised (conv2d_im2col.nim:62-87 builds it explicitly):
-    # element (k, pixel) = input[c][oh + kh - pH][ow + kw - pW], k = (c*3 + kh)*3 + kw.  One wave-instruction gathers 2
-    # consecutive output pixels per lane (64 lanes = the tile's 128 pixels) of ONE k: the k part of the address is
-    # wave-uniform and rides in the load's SGPR offset, the pixel part is a per-lane constant.  Wave w owns k = 8w .. 8w+7
-    # of every K-tile: pairs (k, k+2) per lane exactly like the GEMM's pair mode.  Padding: rows outside the image get an
-    # offset the bounds check rejects (reads 0); at the left / right border the pair is loaded one pixel further inside
-    # the image (never outside the tensor) and shifted back in registers.
+    # element (k, pixel) = input[c][oh + kh - pH][ow + kw - pW], k = (c*3 + kh)*3 + kw.  One wave-instruction gathers one
+    # output pixel per lane of ONE k: lane l owns pixels n0 + 2l and n0 + 2l + 1 (two dword loads per piece).  The k part
+    # of the address is wave-uniform and rides in the load's SGPR offset; the pixel part is a per-lane constant
+    # (oh*W + ow)*4 -- or, where the tap falls into the zero padding (or beyond the image's pixels / K), the offset
+    # 0x80000000 that the bounds check rejects, so the load returns 0 without touching memory.  Which of the two depends
+    # on the tap (kh, kw), which is wave-uniform but changes every K-tile: the 9 (+1: "nothing") per-lane offset vectors
+    # live in LDS and ds_read_addtid_b32 (address = M0 + 4*lane, no VGPR, no VALU op) fetches the right one -- any VALU op
+    # in the loop costs ~11 cycles of matrix-pipe time (profiles/r03/asm_probe_v4_fillers.jsonl).  Wave w owns
+    # k = 8w .. 8w+7 of every K-tile: pairs (k, k+2) per lane exactly like the GEMM's pair mode.
     CONV_DELTA = (0, 2, 1, 3, 4, 6, 5, 7)      # piece i = 2*pair + j gathers k = 8w + delta: pairs (0,2) (1,3) (4,6) (5,7)
 
     def conv_setup(self):
@@ -574,11 +576,7 @@ class Gen:
         e("s_load_dwordx4", scr.sub(8, 4), s(0, 2), KA_CONV1)
         e("s_load_dwordx2", scr.sub(12, 2), s(0, 2), KA_CONV2)
         e("s_waitcnt", lgkmcnt=0)
-        if c.debug:
-            self.dump("wgid_y", s(3))
-            for i in range(14):
-                self.dump(f"scr[{i}] loaded", scr[i])
-        lane, pix, oh, ow = t[0], t[1], t[2], t[3]
+        lane, pix, oh, ow, base, base4, tab = t[0], t[1], t[2], t[3], t[6], t[7], t[8]
         e("v_and_b32", lane, 63, v(0))
         e("v_lshl_add_u32", pix, lane, 1, self.s_n0)          # first of this lane's two output pixels
         e("v_mul_hi_u32", oh, pix, smagic)
@@ -587,28 +585,41 @@ class Gen:
         e("v_sub_u32", ow, pix, t[4])                         # ow = pix % oW  (oW even: both pixels in one output row)
         e("v_mul_lo_u32", t[4], oh, sW)
         e("v_add_u32", t[4], t[4], ow)
-        e("v_lshlrev_b32", self.vBM, 2, t[4])                 # (oh*W + ow) * 4, relative to the window origin of pixel (0, 0)
+        e("v_lshlrev_b32", base, 2, t[4])                     # (oh*W + ow) * 4, relative to the window origin of pixel (0, 0)
+        e("v_add_u32", base4, 4, base)
+        e("v_lshlrev_b32", tab, 2, lane)
         e("v_cmp_gt_u32", self.s_m, sNpix, pix)               # pixels beyond the image (ragged last tile) gather nothing
-        if c.debug:
-            self.dump("s_m.lo first", self.s_m[0])
-            self.dump("pix", pix)
-            self.dump("oh", oh)
-            self.dump("ow", ow)
         for kh in range(3):
             e("v_add_u32", t[5], kh, oh)
             e("v_subrev_u32", t[5], spH, t[5])                # input row oh + kh - pH (as unsigned: negative = huge)
             e("v_cmp_gt_u32", self.s_rowm[kh], sH, t[5])
             e("s_nop", 1)
             e("s_and_b64", self.s_rowm[kh], self.s_rowm[kh], self.s_m)
-        if c.conv_pad:
-            e("v_cmp_eq_u32", self.s_mL, 0, ow)                # left border: kw = 0 would start at column -1
-            e("s_sub_u32", st[0], sW, 2)
-            e("v_cmp_eq_u32", self.s_mR, st[0], ow)            # right border: kw = 2 would end at column W
-            e("s_nop", 4)
-            e("v_add_u32", t[5], 4, self.vBM)
-            e("v_cndmask_b32", self.vBL, self.vBM, t[5], self.s_mL)
-            e("v_add_u32", t[5], 0xfffffffc, self.vBM)
-            e("v_cndmask_b32", self.vBR, self.vBM, t[5], self.s_mR)
+        # the table is the same for the 4 waves (they own different k of the same 128 pixels): wave 0 writes it
+        skip = self.p.label("notab")
+        e("s_cmp_lg_u32", self.s_wave, 0)
+        e("s_cbranch_scc1", skip)
+        for kw in range(3):
+            e("v_add_u32", t[5], kw, ow)
+            e("v_subrev_u32", t[5], spW, t[5])                # input column of the first pixel, ow + kw - pW
+            e("v_cmp_gt_u32", self.s_c0m, sW, t[5])
+            e("v_add_u32", t[5], 1, t[5])                     # ... of the second pixel
+            e("v_cmp_gt_u32", self.s_c1m, sW, t[5])
+            e("s_nop", 1)
+            for kh in range(3):
+                r = 3 * kh + kw
+                e("s_and_b64", self.s_m, self.s_rowm[kh], self.s_c0m)
+                e("s_and_b64", self.s_m2, self.s_rowm[kh], self.s_c1m)
+                e("s_nop", 0)
+                e("v_cndmask_b32", t[4], self.v_oob, base, self.s_m)
+                e("v_cndmask_b32", t[9], self.v_oob, base4, self.s_m2)
+                e("ds_write_b32", tab, t[4], offset=r * c.TAB_ENTRY)
+                e("ds_write_b32", tab, t[9], offset=c.TAB_E1 + r * c.TAB_ENTRY)
+        e("ds_write_b32", tab, self.v_oob, offset=9 * c.TAB_ENTRY)
+        e("ds_write_b32", tab, self.v_oob, offset=c.TAB_E1 + 9 * c.TAB_ENTRY)
+        self.p.place(skip)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_barrier")
         # descriptor: base = B + b * bsB - (pH*W + pW) * 4 (the window origin of output pixel (0, 0), kernel tap (0, 0));
         # every address a valid lane forms lies inside the image -- the bounds field only has to reject v_oob
         e("s_mul_hi_u32", st[2], s(3), scr[10])
@@ -626,7 +637,7 @@ class Gen:
         e("s_mul_i32", self.s_HW4, self.s_W4, sH)
         e("s_mov_b32", self.s_Cin, sCin)
         # LDS write addresses of pair gi, pixel e: x = 2*lane + e, k = 8w + (0, 1, 4, 5)[gi]: L = 2w + (gi & 1), word = (0,0,2,2)[gi]
-        e("s_mov_b32", st[0], c.BK * c.BM * 4)
+        e("s_mov_b32", st[0], c.LDS0 + c.BK * c.BM * 4)
         for gi in range(4):
             e("s_lshl_b32", st[3], self.s_wave, 1)
             e("s_add_u32", st[3], st[3], gi & 1)
@@ -650,9 +661,10 @@ class Gen:
         e("s_sub_u32", self.s_r0, st[0], st[2])
 
     def conv_load_ops(self):
-        """per piece: [scalar k state ...] [offset select] [load]; then the state moves on by BK.  Returns a list of op groups."""
+        """per piece: [scalar tap state] [SGPR offset, table entry -> M0, the two offset vectors from LDS]; then, for every
+        piece, [the two gathers]; then the state moves on by BK.  Returns a list of op groups (one per MFMA gap)."""
         c, st = self.c, self.s_t
-        groups = []
+        groups, loads = [], []
         for i in range(8):
             d = self.CONV_DELTA[i]
             g1 = [("ins", "s_add_u32", (st[0], self.s_r0, d), {}),
@@ -664,31 +676,21 @@ class Gen:
                   ("ins", "s_mul_i32", (st[2], st[0], 11), {}),
                   ("ins", "s_lshr_b32", (st[2], st[2], 5), {}),             # kh = r / 3
                   ("ins", "s_mul_i32", (st[3], st[2], 3), {}),
-                  ("ins", "s_sub_u32", (self.s_kw[i], st[0], st[3]), {})]   # kw = r % 3
+                  ("ins", "s_sub_u32", (st[5], st[0], st[3]), {})]          # kw = r % 3
             g2 = [("ins", "s_mul_i32", (st[3], st[1], self.s_HW4), {}),
                   ("ins", "s_mul_i32", (st[4], st[2], self.s_W4), {}),
                   ("ins", "s_add_u32", (st[3], st[3], st[4]), {}),
-                  ("ins", "s_lshl_b32", (st[4], self.s_kw[i], 2), {}),
+                  ("ins", "s_lshl_b32", (st[4], st[5], 2), {}),
                   ("ins", "s_add_u32", (self.s_koff[i], st[3], st[4]), {}),  # (c*H*W + kh*W + kw) * 4
-                  ("ins", "s_cmp_eq_u32", (st[2], 0), {}),
-                  ("ins", "s_cselect_b64", (self.s_m, self.s_rowm[0], self.s_rowm[1]), {}),
-                  ("ins", "s_cmp_eq_u32", (st[2], 2), {}),
-                  ("ins", "s_cselect_b64", (self.s_m, self.s_rowm[2], self.s_m), {}),
                   ("ins", "s_cmp_lt_u32", (st[1], self.s_Cin), {}),
-                  ("ins", "s_cselect_b64", (self.s_m, self.s_m, 0), {})]     # channels beyond Cin (k >= K): nothing
-            g3 = []
-            src = self.vBM
-            if c.conv_pad:
-                g2 += [("ins", "s_cmp_eq_u32", (self.s_kw[i], 0), {}),
-                       ("ins", "s_cselect_b64", (self.s_m2, -1, 0), {})]
-                g3 += [("ins", "v_cndmask_b32", (self.vBoff[i], self.vBM, self.vBL, self.s_m2), {}),
-                       ("ins", "s_cmp_eq_u32", (self.s_kw[i], 2), {}),
-                       ("ins", "s_cselect_b64", (self.s_m2, -1, 0), {}),
-                       ("ins", "v_cndmask_b32", (self.vBoff[i], self.vBoff[i], self.vBR, self.s_m2), {})]
-                src = self.vBoff[i]
-            g3 += [("ins", "v_cndmask_b32", (self.vBoff[i], self.v_oob, src, self.s_m), {}),
-                   ("loadBc", i)]
-            groups += [g1, g2, g3]
+                  ("ins", "s_cselect_b32", (st[0], st[0], 9), {}),           # channels beyond Cin (k >= K): the "nothing" entry
+                  ("ins", "s_lshl_b32", (M0, st[0], 8), {}),
+                  ("ins", "s_nop", (0,), {}),                                # (S_MOV to M0 -> LDS add-TID instruction: 1 wait state)
+                  ("ldsr", "ds_read_addtid_b32", (self.vB0[i],), {}, ("T", i)),
+                  ("ldsr", "ds_read_addtid_b32", (self.vB1[i],), {"offset": c.TAB_E1}, ("T", i))]
+            groups += [g1, g2]
+            loads.append([("lgwait", {("T", i)}), ("loadBc", i, 0), ("loadBc", i, 1)])
+        groups += loads
         groups.append([("ins", "s_add_u32", (self.s_r0, self.s_r0, c.BK % 9), {}),
                        ("ins", "s_add_u32", (self.s_c0, self.s_c0, c.BK // 9), {}),
                        ("ins", "s_cmp_ge_u32", (self.s_r0, 9), {}),
@@ -698,26 +700,15 @@ class Gen:
                        ("ins", "s_add_u32", (self.s_c0, self.s_c0, st[3]), {})])
         return groups
 
-    def conv_fix_store_ops(self, k):
-        """tile data in the B staging registers -> border fix-up (padding kernels) -> LDS stage index k"""
-        c, out = self.c, []
-        for i in range(8):
-            P = self.stB[i]
-            out.append(("vmwait", ("B", i)))
-            if c.conv_pad:
-                out += [("ins", "s_cmp_eq_u32", (self.s_kw[i], 0), {}),
-                        ("ins", "s_cselect_b64", (self.s_m, self.s_mL, 0), {}),
-                        ("ins", "s_cmp_eq_u32", (self.s_kw[i], 2), {}),
-                        ("ins", "s_cselect_b64", (self.s_m2, self.s_mR, 0), {}),
-                        # left border: loaded (col 0, col 1), wanted (0, col 0); right: loaded (W-2, W-1), wanted (W-1, 0)
-                        ("ins", "v_cndmask_b32", (P[1], P[1], P[0], self.s_m), {}),
-                        ("ins", "v_cndmask_b32", (P[0], P[0], 0, self.s_m), {}),
-                        ("ins", "v_cndmask_b32", (P[0], P[0], P[1], self.s_m2), {}),
-                        ("ins", "v_cndmask_b32", (P[1], P[1], 0, self.s_m2), {})]
+    def conv_store_ops(self, k):
+        """tile data in the B staging registers -> LDS stage index k; returns op groups"""
+        out = []
         for gi in range(4):
             P, Q = self.stB[2 * gi], self.stB[2 * gi + 1]
             for ee in range(2):
-                out.append(("ldsw", "ds_write2_b32", (self.WB[gi][ee][k], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
+                g = [("vmwait", ("B", 2 * gi + 1, 1))] if ee == 0 else []
+                g.append(("ldsw", "ds_write2_b32", (self.WB[gi][ee][k], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
+                out.append(g)
         return out
 
     def load_A_piece(self, pi):
@@ -841,8 +832,8 @@ class Gen:
             self.load_B_piece(o[1])
         elif kind == "loadBc":
             if "loads" not in self.c.ablate:
-                self.p.emit("buffer_load_dwordx2", self.stB[o[1]], self.vBoff[o[1]], self.srdB, self.s_koff[o[1]], offen=True)
-                self.vm_issue(("B", o[1]))
+                self.p.emit("buffer_load_dword", self.stB[o[1]][o[2]], (self.vB0, self.vB1)[o[2]][o[1]], self.srdB, self.s_koff[o[1]], offen=True)
+                self.vm_issue(("B", o[1], o[2]))
         elif kind == "barrier":
             self.lg_wait(None)
             self.p.emit("s_barrier")
@@ -925,23 +916,9 @@ class Gen:
             else:
                 units.append([op])
         if c.conv:
-            # B first (its gather was requested a tile ago and is needed soonest: fix-up + store, then the scalar k state,
-            # the offset selects and the 8 gathers of tile t+2), then A's pieces; one unit per gap, VALU work batched per unit
-            fs = self.conv_fix_store_ops(wr_k)
-            cu, cur = [], []
-            for op in fs:
-                if op[0] == "vmwait" and cur:
-                    cu.append(cur)
-                    cur = []
-                if op[0] == "ldsw":
-                    if cur:
-                        cu.append(cur)
-                        cur = []
-                    cu.append([op])
-                else:
-                    cur.append(op)
-            if cur:
-                cu.append(cur)
+            # B first (its gathers were requested a tile ago and are needed soonest): stores, then the scalar tap state and
+            # the offset vectors of tile t+2, its 16 gathers, then A's pieces; one unit per gap
+            cu = self.conv_store_ops(wr_k)
             a_units = []
             for pi in range(c.NPA):
                 a = self.store_A_piece(pi, ops=[], k=wr_k)

@@ -86,6 +86,8 @@ class Wave:
         self.s = np.zeros(104, dtype=np.uint64)  # 32-bit values (uint64 storage to make carries easy)
         self.vcc = 0
         self.exec = (1 << 64) - 1
+        self.m0 = 0
+        self.m0_wr = -10   # issue state of the last write of M0
         self.scc = 0
         self.pc = 0
         self.epoch = 0
@@ -129,6 +131,8 @@ class Workgroup:
             self._chk_pending(w, [("s", x.idx)])
             return int(w.s[x.idx]) & 0xffffffff
         if isinstance(x, Sym):
+            if x.name == "m0":
+                return w.m0
             raise SimError(f"32-bit scalar read of {x}")
         if isinstance(x, float):
             return int(np.array([x], dtype=np.float32).view(np.uint32)[0])
@@ -291,6 +295,10 @@ class Workgroup:
         rs, rv = self.rd_s, self.rd_v
 
         def sw(dst, val):
+            if isinstance(dst, Sym):
+                assert dst.name == "m0", dst
+                w.m0, w.m0_wr = int(val) & 0xffffffff, w.state
+                return
             assert dst.kind == "s" and dst.n == 1
             w.s[dst.idx] = int(val) & 0xffffffff
             w.valu_sgpr_wr.pop(dst.idx, None)
@@ -508,6 +516,18 @@ class Workgroup:
                 dst = w.v if A[0].kind == "v" else w.a
                 dst[A[0].idx + d][act] = self.lds[wd[act] + d]
                 w.pending[(A[0].kind, A[0].idx + d)] = op
+            w.lgkm.append(("ldsr", A[0].regs()))
+        elif op == "ds_read_addtid_b32":
+            # LDS address = M0[15:0] + offset + 4 * lane (no address register); S_MOV to M0 -> add-TID LDS op needs one wait state
+            if self.check and w.state - w.m0_wr < 2:
+                raise SimError(f"wave {w.wid} pc {w.pc}: ds_read_addtid right after M0 was written (needs s_nop 0)")
+            addr = (w.m0 & 0xffff) + int(M.get("offset", 0)) + 4 * np.arange(LANES, dtype=np.int64)
+            wd = self._lds_access(w, addr, 1, False, GROUPS_32, 32)
+            assert A[0].n == 1 and A[0].kind == "v"
+            self._chk_waw(w, A[0].regs())
+            act = w.execmask()
+            w.v[A[0].idx][act] = self.lds[wd[act]]
+            w.pending[("v", A[0].idx)] = op
             w.lgkm.append(("ldsr", A[0].regs()))
         elif op in ("ds_write_b32", "ds_write_b64", "ds_write_b128"):
             ndw = {"ds_write_b32": 1, "ds_write_b64": 2, "ds_write_b128": 4}[op]

@@ -29,16 +29,15 @@ struct KernelInfo {
 // [0] laser-order, large tile  [1] one chain, large tile  [2] laser-order, 128x128  [3] one chain, 128x128;
 // [4..7] the same with B passed transposed (unit ROW stride: k-contiguous like A, BASELINE configs[2])
 // [8] / [9]: one chain on the 256x128x32 tile (plain / B transposed): finer tile quantisation for the fast mode
-// [10..13]: implicit-GEMM convolution, 3x3 kernel, stride 1: padding 1 (laser-order / one chain), padding 0 (same)
-constexpr int kNumKernels = 14;
+// [10] / [11]: implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (laser-order / one chain)
+constexpr int kNumKernels = 12;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32},    {"lh_f32_fast_256x256x16", 256, 256, 16},
     {"lh_f32_exact_128x128x16", 128, 128, 16},    {"lh_f32_fast_128x128x16", 128, 128, 16},
     {"lh_f32_exact_256x128x32_nt", 256, 128, 32}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16},
     {"lh_f32_exact_128x128x16_nt", 128, 128, 16}, {"lh_f32_fast_128x128x16_nt", 128, 128, 16},
     {"lh_f32_fast_256x128x32", 256, 128, 32},     {"lh_f32_fast_256x128x32_nt", 256, 128, 32},
-    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32},   {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32},
-    {"lh_f32_conv3x3p0_exact_256x128x32", 256, 128, 32}, {"lh_f32_conv3x3p0_fast_256x128x32", 256, 128, 32}};
+    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32},   {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -210,16 +209,16 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.cs_imgs != 0) return hipErrorNotSupported;
   if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
   if (a.ckH != 3 || a.ckW != 3 || a.csH != 1 || a.csW != 1) return hipErrorNotSupported;
-  if (!((a.cpH == 1 && a.cpW == 1) || (a.cpH == 0 && a.cpW == 0))) return hipErrorNotSupported;
+  if (a.cpH < 0 || a.cpW < 0 || a.cpH > 64 || a.cpW > 64) return hipErrorNotSupported;
   const int64_t oW = a.coW, oH = a.cH + 2 * a.cpH - 2, npix = oH * oW;
-  if (oW != a.cW + 2 * a.cpW - 2 || oW <= 0 || oH <= 0 || (oW & 1) || (a.cW & 1)) return hipErrorNotSupported;  // pixel pairs stay in one row
+  if (oW != a.cW + 2 * a.cpW - 2 || oW <= 0 || oH <= 0 || (oW & 1)) return hipErrorNotSupported;  // a lane's pixel pair stays in one output row
   if (a.csA != 1 || a.rsA != a.K || a.csC != 1 || a.rsC != npix || a.K % 36 != 0 || a.K < 36) return hipErrorNotSupported;  // K = Cin * 9, a multiple of 4
   if (a.N > npix || (a.N != npix && a.N % 128 != 0)) return hipErrorNotSupported;
   if (a.batch < 1 || a.batch > 65535 || a.M > 0xffff * 256ll) return hipErrorNotSupported;
   const int64_t Cin = a.K / 9;
   if ((double)Cin * a.cH * a.cW * 4.0 >= 2.0e9 || (double)a.M * npix * 4.0 >= 2.0e9 || (double)a.rsA * 4.0 * 256 >= 4.0e9) return hipErrorNotSupported;
   const bool exact = laser_order && a.K > 512;
-  const int pick = (a.cpH == 1 ? 10 : 12) + (exact || a.K <= 512 ? 0 : 1);
+  const int pick = 10 + (exact || a.K <= 512 ? 0 : 1);
   const KernelInfo &ki = kKernels[pick];
   const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;

@@ -315,7 +315,8 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   // added in order (gemm.nim:150-158), so the tail runs as images x slices workgroup sets, each ONE chain over its 512 k
   // into a workspace, and the ordered combine pass folds them: same fused multiply-adds, same order => bit-identical.
   const int64_t nsl = (a.K + 511) / 512, ntail = a.N - plan.n_cut;
-  if (exact && g_conv_kslice && g_split_tail && nsl >= 2 && a.bias == nullptr && a.act == 0 && a.bsC == a.M * a.rsC &&
+  // (the one-chain mode has no order to keep: it takes the same faster tail)
+  if ((exact || !laser_order) && g_conv_kslice && g_split_tail && nsl >= 2 && a.bias == nullptr && a.act == 0 && a.bsC == a.M * a.rsC &&
       (int64_t)a.batch * nsl <= 65535) {
     if (hipError_t e = main_launch(m, s); e != hipSuccess) return e;
     const int64_t mn = a.M * ntail;

@@ -22,9 +22,8 @@ g.build()
 c = g.c
 rng = np.random.default_rng(0)
 NIMG = 1
-if c.conv:   # usage: asm_debug.py conv3x3_... images Cin H W M
-    NIMG, Cin, H, W, M = (int(x) for x in sys.argv[2:7]) if len(sys.argv) > 6 else (2, 8, 12, 16, 40)
-    pad = 1 if c.conv_pad else 0
+if c.conv:   # usage: asm_debug.py conv3x3_... images Cin H W M pad
+    NIMG, Cin, H, W, M, pad = (int(x) for x in sys.argv[2:8]) if len(sys.argv) > 7 else (2, 8, 12, 16, 40, 1)
     oH, oW = H + 2 * pad - 2, W + 2 * pad - 2
     N, Kd = oH * oW, Cin * 9
     A = rng.uniform(-0.1, 0.1, (M, Kd)).astype(np.float32)

@@ -2,7 +2,7 @@ import torch, json, sys
 sys.path.insert(0, "/root/repo")
 import laser_amd
 def t(fn, inner=4, reps=5):
-    for _ in range(3): fn()
+    for _ in range(40): fn()
     torch.cuda.synchronize(); ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

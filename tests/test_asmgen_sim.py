@@ -1,0 +1,65 @@
+"""The hand-scheduled fp32 kernels (laser_amd/asmgen/f32_kernel.py) through the CPU interpreter (laser_amd/asmgen/sim.py):
+every generated instruction stream is executed for small problems, wave by wave, and the result is compared BIT FOR BIT
+with the accumulation-order model of SURVEY.md 8 (an fmaf chain per kc = 512 slice from +0, slices added in order --
+gemm.nim:150-158 / gemm_ukernel_generic.nim:56-66).  The interpreter also enforces what the hardware does not forgive:
+registers read while a load into them is still in flight, barriers passed with LDS writes un-waited, cross-wave LDS
+races, the MFMA -> VALU and VALU-SGPR -> VMEM wait states, the M0 -> add-TID wait state, and every access outside an
+operand's span (the operands are placed with nothing mapped around them; row padding is NaN).  No GPU needed."""
+import pytest
+
+from laser_amd.asmgen import check as C
+from laser_amd.asmgen import f32_kernel as K
+
+
+@pytest.mark.parametrize("name", sorted(K.CONFIGS))
+def test_every_config_generates_and_carries_its_queue_state(name):
+    g = K.make(name)
+    g.build()                              # asserts the loop-carried VMEM / LDS queue state and the placement rules
+    text = K.kernel_text(g, "lh_test")
+    assert ".amdhsa_kernel lh_test" in text and "s_endpgm" in text
+    assert g.p._v <= 256 and g.p._a <= 256 and g.p._s <= 100
+    assert g.c.lds_alloc <= 160 * 1024
+
+
+# (name, M, N, K, kwargs): one K-tile, several K-tiles, a kc fold (K > 512), K tails (K % BK != 0), ragged M / N, padded rows
+GEMM_CASES = [
+    ("exact_256x128x32", 70, 90, 64, {}),
+    ("exact_256x128x32", 40, 36, 548, dict(lda=552, ldb=40, ldc=44)),           # fold + K tail + padded rows
+    ("fast_256x256x16", 130, 60, 40, dict(ldb=64)),
+    ("fast_256x128x32", 33, 130, 100, {}),
+    ("exact_128x128x16", 129, 70, 36, {}),
+    ("fast_128x128x16", 20, 140, 20, dict(ldc=144)),
+    ("exact_256x128x32_nt", 50, 40, 68, dict(ldb=72)),
+    ("fast_256x256x16_nt", 30, 270, 24, {}),
+    ("exact_128x128x16_nt", 64, 64, 524, {}),                                   # fold, B transposed
+    ("fast_128x128x16_nt", 140, 30, 12, {}),
+    ("fast_256x128x32_nt", 60, 50, 36, {}),
+]
+
+
+@pytest.mark.parametrize("name,M,N,Kd,kw", GEMM_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}" for c in GEMM_CASES])
+def test_gemm_kernels_bit_exact_in_the_interpreter(name, M, N, Kd, kw):
+    assert C.run_case(name, M, N, Kd, verbose=False, **kw)
+
+
+# (name, images, Cin, H, W, M, pad, n_cut): padding 1 / 0 / asymmetric / 2, the kc fold, ragged last pixel tile, pixel cut
+CONV_CASES = [
+    ("conv3x3_exact_256x128x32", 2, 8, 12, 16, 40, 1, None),
+    ("conv3x3_fast_256x128x32", 1, 4, 10, 12, 24, 0, None),
+    ("conv3x3_exact_256x128x32", 1, 64, 6, 8, 20, 1, None),                     # K = 576: a fold and a K tail
+    ("conv3x3_fast_256x128x32", 1, 20, 14, 20, 16, (0, 1), 128),                # main launch of a main + tail split
+    ("conv3x3_exact_256x128x32", 1, 12, 9, 18, 260, (2, 2), None),              # two row tiles, two pixel tiles (ragged)
+]
+
+
+@pytest.mark.parametrize("name,images,Cin,H,W,M,pad,n_cut", CONV_CASES,
+                         ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}x{c[4]}-pad{c[6]}" for c in CONV_CASES])
+def test_conv_kernels_bit_exact_in_the_interpreter(name, images, Cin, H, W, M, pad, n_cut):
+    assert C.run_conv_case(name, images, Cin, H, W, M, pad, n_cut=n_cut, verbose=False)
+
+
+def test_interpreter_rejects_a_read_of_a_register_still_loading():
+    """the checks are live: dropping the counted waits must be caught, not silently pass"""
+    from laser_amd.asmgen.sim import SimError
+    with pytest.raises((SimError, AssertionError)):
+        C.run_case("exact_256x128x32", 40, 40, 96, verbose=False, over=dict(ablate=("vmwaits",)))
