@@ -38,7 +38,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerate(
     ["lh_f32_exact_256x128x32", "lh_f32_fast_256x256x16", "lh_f32_exact_128x128x16", "lh_f32_fast_128x128x16",
      "lh_f32_exact_256x128x32_nt", "lh_f32_fast_256x256x16_nt", "lh_f32_exact_128x128x16_nt", "lh_f32_fast_128x128x16_nt",
-     "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt"])}
+     "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt", "lh_f32_conv3x3_exact_256x128x32", "lh_f32_conv3x3_fast_256x128x32",
+     "lh_f32_exact_64x64x32", "lh_f32_fast_64x64x32", "lh_f32_exact_64x64x32_nt", "lh_f32_fast_64x64x32_nt"])}
 SIZE = 8192
 
 

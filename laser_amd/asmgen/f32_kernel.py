@@ -72,6 +72,12 @@ CONFIGS = {
     "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
     # one chain on the laser-order kernels' tile: halves the tile quantisation of the 256x256 tile (4100^3: 289 tiles of
     # 256x256 are 1.13 rounds of the chip, 561 tiles of 256x128 are 2.19)
+    # small tiles for problems with few large tiles (1024^3 = 32 tiles of 256x128 on 256 CUs) and for the tile quantisation of
+    # mid-size ones: 2 - 3 workgroups share a CU
+    "exact_64x64x32": dict(BM=64, BN=64, BK=32, exact=True),
+    "fast_64x64x32": dict(BM=64, BN=64, BK=32, exact=False),
+    "exact_64x64x32_nt": dict(BM=64, BN=64, BK=32, exact=True, b_kcontig=True),
+    "fast_64x64x32_nt": dict(BM=64, BN=64, BK=32, exact=False, b_kcontig=True),
     # implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (benchmarks/convolution/conv2d_im2col.nim)
     "conv3x3_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True),
     "conv3x3_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True),
@@ -884,6 +890,8 @@ class Gen:
                 base = first_free
             for k, op in enumerate(ops):
                 at = base + k * c.r_step
+                if not nxt_tile:
+                    at = min(at, max(base, (g + 1) * c.GM - 2))      # (few gaps per group: several reads share a gap)
                 assert nxt_tile or at < (g + 1) * c.GM - 1, "fragment reads must be issued before the group's wait"
                 put(at, op)
             # the group's fragments must have landed before its first MFMA (the next tile's first group: top of the body)
@@ -926,7 +934,7 @@ class Gen:
             units = cu + self.conv_load_ops() + a_units
         w0 = max(c.w_start, first_free + (c.TM + c.TN + 2 if fold else 0))
         span = bar - 1 - w0
-        step = c.w_step or max(1.0, span / max(1, len(units)))
+        step = c.w_step or min(max(1.0, span / max(1, len(units))), span / max(1, len(units) - 1) if len(units) > span else 1e9)
         for k, u in enumerate(units):
             m = int(w0 + k * step)
             assert m < bar, "staging does not fit before the barrier"

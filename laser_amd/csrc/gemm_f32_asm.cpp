@@ -25,19 +25,27 @@ namespace {
 struct KernelInfo {
   const char *symbol;
   int bm, bn, bk;
+  // tile-choice model (fitted to profiles/r03/tile_probe_v1.txt, shape_sweep_v3.jsonl): fraction of the matrix peak a CU reaches on this tile when
+  // its workgroup slots are full / when one workgroup has the CU to itself, and the launch's fixed cost (prologue, first
+  // loads, epilogue of the last round) in microseconds
+  double eff, eff_alone, fixed_us;
 };
 // [0] laser-order, large tile  [1] one chain, large tile  [2] laser-order, 128x128  [3] one chain, 128x128;
 // [4..7] the same with B passed transposed (unit ROW stride: k-contiguous like A, BASELINE configs[2])
 // [8] / [9]: one chain on the 256x128x32 tile (plain / B transposed): finer tile quantisation for the fast mode
 // [10] / [11]: implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (laser-order / one chain)
-constexpr int kNumKernels = 12;
+// [12..15]: 64x64 tiles, three workgroups per CU (laser-order / one chain, plain / B transposed): problems of few tiles
+// (1024^3 = 32 tiles of 256x128 for 256 CUs) and the tile quantisation of mid-size ones (3072^3 = 1.125 rounds of 256x128)
+constexpr int kNumKernels = 16;
 const KernelInfo kKernels[kNumKernels] = {
-    {"lh_f32_exact_256x128x32", 256, 128, 32},    {"lh_f32_fast_256x256x16", 256, 256, 16},
-    {"lh_f32_exact_128x128x16", 128, 128, 16},    {"lh_f32_fast_128x128x16", 128, 128, 16},
-    {"lh_f32_exact_256x128x32_nt", 256, 128, 32}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16},
-    {"lh_f32_exact_128x128x16_nt", 128, 128, 16}, {"lh_f32_fast_128x128x16_nt", 128, 128, 16},
-    {"lh_f32_fast_256x128x32", 256, 128, 32},     {"lh_f32_fast_256x128x32_nt", 256, 128, 32},
-    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32},   {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32}};
+    {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0},
+    {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0},
+    {"lh_f32_exact_256x128x32_nt", 256, 128, 32, 0.965, 0.965, 10.0}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16, 0.98, 0.98, 12.0},
+    {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.91, 6.0},    {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.92, 6.0},
+    {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0},
+    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.9, 0.9, 15.0}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.9, 0.9, 15.0},
+    {"lh_f32_exact_64x64x32", 64, 64, 32, 0.88, 0.78, 3.0},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.895, 0.80, 3.0},
+    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -124,23 +132,26 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0) return hipErrorNotSupported;
   if (a.M > 0xffff * (int64_t)128 || a.N > 0xffff * (int64_t)128) return hipErrorNotSupported;
   const auto tiles_of = [&](const KernelInfo &k) { return ((a.M + k.bm - 1) / k.bm) * ((a.N + k.bn - 1) / k.bn); };
-  // Which tile: time in units of "one 128x128 tile of this K on a fully used CU".  The large tiles run one workgroup per
-  // CU at ~0.96 of the matrix peak; the 128x128 tiles run two per CU (two waves per SIMD) at ~0.9 and need a quarter /
-  // half of the work per workgroup, so they win whenever the large tiles would leave CUs idle or under-fill their last
-  // round (2048^3 = 128 large tiles on 256 CUs, but exactly one round of 256 small ones).
+  // Which tile.  Workgroups that share a CU share its matrix pipes, so whatever the number of workgroup slots a launch of T
+  // tiles takes ceil(T / 256) times one tile's matrix time: the smaller the tile the finer the quantisation, the larger
+  // the tile the closer a CU gets to the peak (the eff columns of kKernels).  3072^3: 288 tiles of 256x128 = 2 rounds for
+  // 1.125 rounds of work, 2304 tiles of 64x64 = exactly 9 rounds.
   int pick = -1;
   double best = 1e300;
   const int mid = (!exact && a.K > 512) ? (nt ? 9 : 8) : -1;   // one chain over a long K: also the 256x128 tile
-  for (int k : {big, mid, small}) {
+  const int tiny = 12 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0);
+  const double cu_flops_per_us = 157.3e6 / 256.0;
+  for (int k : {big, mid, small, tiny}) {
     if (k < 0) continue;
     const KernelInfo &ki_ = kKernels[k];
     const int64_t t = tiles_of(ki_);
-    const double units = (double)ki_.bm * ki_.bn / (128.0 * 128.0);
-    const bool large = k >= 8 || (k & 3) < 2;
-    const double time = (double)((t + 255) / 256) * units / (large ? 0.96 : 0.90);
-    // below ~5/8 of a round the compiler-scheduled small-tile kernels (more workgroups per CU, slice-parallel form) do better
-    if (g_f32_asm < 2 && t < 160) continue;
-    if (time < best) best = time, pick = k;
+    // below ~5/8 of a round of the larger tiles (3/8 of the 64x64 ones) the compiler-scheduled kernels' slice-parallel and
+    // small-problem forms do better
+    if (g_f32_asm < 2 && t < (k == tiny ? 96 : 160)) continue;
+    const int64_t rounds = (t + 255) / 256;
+    const double tile_us = 2.0 * ki_.bm * ki_.bn * (double)a.K / cu_flops_per_us;
+    const double time = (double)rounds * tile_us / (rounds == 1 ? ki_.eff_alone : ki_.eff) + ki_.fixed_us;
+    if (time < 0.99 * best) best = time, pick = k;   // (near ties go to the larger tile: less L2 traffic)
   }
   if (pick < 0) return hipErrorNotSupported;
   const KernelInfo &ki = kKernels[pick];

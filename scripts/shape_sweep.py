@@ -5,7 +5,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import laser_amd
-shapes = [(1024,) * 3, (1536,) * 3, (1920,) * 3, (2048,) * 3, (3072,) * 3, (4096,) * 3, (6144,) * 3, (4100,) * 3, (1000, 3000, 2000), (4095, 4097, 4099),
+shapes = [(512,) * 3, (768,) * 3, (1024,) * 3, (1280,) * 3, (1536,) * 3, (1920,) * 3, (2048,) * 3, (3072,) * 3, (4096,) * 3, (6144,) * 3, (4100,) * 3, (1000, 3000, 2000), (4095, 4097, 4099),
           (2048, 8192, 1024), (8192, 8192, 512)]
 for (M, N, K) in shapes:
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -20,7 +20,7 @@ for (M, N, K) in shapes:
         ref = None
         for asm in (1, 0):
             laser_amd.set_f32_asm(asm)
-            for _ in range(3):
+            for _ in range(max(3, min(400, int(0.03 / max(1e-6, 2.0 * M * N * K / 100e12))))):   # clocks up: ~30 ms of work
                 laser_amd.matmul(A, B, 1, 0, C)
             torch.cuda.synchronize()
             ts = []

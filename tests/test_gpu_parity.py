@@ -661,7 +661,9 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
     took = 0
     shapes = [(4096, 4096, 1024), (2048, 8192, 1568), (8192, 2048, 1056), (4096, 4096, 544), (1000, 900, 2080), (256, 128, 512),
               (300, 260, 32), (2048, 2048, 96), (2048, 2048, 1060), (1920, 1920, 1924), (4100, 4100, 516), (2048, 2048, 20),
-              (1024, 4096, 36), (3000, 2500, 68)]
+              (1024, 4096, 36), (3000, 2500, 68),
+              (1024, 1024, 1028), (1536, 1000, 548), (1000, 3000, 2000), (3072, 3072, 516), (700, 900, 40), (1280, 1280, 1280)]   # 64x64 tiles
+    seen = set()
     for si, (M, N, K) in enumerate(shapes):
         A = rand(rng, (M, K + 8), np.float32)[:, :K]          # leading dimension K + 8
         dAb = torch.from_numpy(np.ascontiguousarray(A.base)).cuda(); dA = dAb[:, :K]
@@ -686,7 +688,9 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 assert la.last_f32_asm() == 0
             finally:
                 la.set_f32_asm(1); la.set_float_mode(0)
-            want = (1, 3, 5, 7) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10)   # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128)
+            # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128; 13..16: 64x64 tiles)
+            want = (1, 3, 5, 7, 13, 15) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10, 14, 16)
+            seen.add(used)
             # (tiny problems are taken by the small-matrix / slice-parallel paths before the tiled kernels are asked)
             assert used in want or (used == 0 and M * N <= 1024 * 1024), (M, N, K, mode, used)
             assert torch.equal(dC, dC2), (M, N, K, mode)
@@ -694,6 +698,8 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
             if mode == 0:
                 assert np.array_equal(dC[:, :N].cpu().numpy(), oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B))), (M, N, K)
         took += 1
+    for family in ({1, 2, 9}, {5, 6, 10}, {3, 4}, {7, 8}, {13, 14}, {15, 16}):      # every kernel family was exercised
+        assert seen & family, (sorted(seen), family)
     # not this kernel's class: alpha / beta, a strided C -> the compiler-scheduled kernels, same results as ever
     M, N, K = 2048, 2048, 1024
     A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
@@ -706,7 +712,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
         w = torch.full((M, 2 * N), 9.0, device="cuda"); la.matmul(A, B, 1, 0, w[:, ::2])
         assert la.last_f32_asm() == 0
         ref = la.matmul(A, B)
-        assert la.last_f32_asm() in (1, 3)
+        assert la.last_f32_asm() in (1, 3, 13)
         odd = la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous())      # K not a multiple of 4: the compiler-scheduled kernels
         assert la.last_f32_asm() == 0
     finally:
