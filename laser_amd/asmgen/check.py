@@ -10,24 +10,23 @@ from . import f32_kernel as K
 from .sim import Memory, Workgroup, fma32
 
 
-def reference(A, B, kc):
+def reference(A, B, kc, alpha=1.0, beta=0.0, C0=None):
+    """C = (..((beta*C0) + alpha*S_0) + alpha*S_1 ..), every product and sum rounded to float32 (gemm_ukernel_generic.nim:53-76)"""
     M, Kd = A.shape
     N = B.shape[1]
-    run = np.zeros((M, N), dtype=np.float32)
+    al = np.float32(alpha)
+    run = np.zeros((M, N), dtype=np.float32) if beta == 0 else (np.float32(beta) * C0.astype(np.float32)).astype(np.float32)
     first = True
     for k0 in range(0, Kd, kc if kc else Kd):
         acc = np.zeros((M, N), dtype=np.float32)
         for k in range(k0, min(Kd, k0 + (kc if kc else Kd))):
             acc = fma32(A[:, k:k + 1] * np.ones((1, N), np.float32), np.ones((M, 1), np.float32) * B[k:k + 1, :], acc)
-        if kc:
-            run = (run + acc).astype(np.float32)
-        else:
-            run = acc
+        run = (run + (al * acc).astype(np.float32)).astype(np.float32)
         first = False
     return run
 
 
-def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True):
+def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0):
     g = K.make(name, **(over or {}))
     g.build()
     c = g.c
@@ -51,11 +50,17 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     Aflat = Af.reshape(-1)[:(M - 1) * lda + Kd].copy()
     Bflat = Bf.reshape(-1)[:(N - 1) * ldb + Kd].copy() if nt else Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
     Cflat = np.full((M - 1) * ldc + N, np.nan, dtype=np.float32)
+    C0 = None
+    if beta != 0:           # C0 in the valid columns, NaN in the row padding
+        C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        full0 = np.full(M * ldc, np.nan, dtype=np.float32).reshape(M, ldc)
+        full0[:, :N] = C0
+        Cflat = full0.reshape(-1)[:(M - 1) * ldc + N].copy()
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Aflat), mem.alloc(Bflat), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 0, 0)
+    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
@@ -66,7 +71,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     Cout = np.full((M, ldc), np.nan, dtype=np.float32).reshape(-1)
     Cout[:len(Cflat)] = mem.get(c_, np.float32, (len(Cflat),))
     Cout = Cout.reshape(M, ldc)[:, :N]
-    want = reference(Af[:, :Kd], Bm, 512 if c.exact else 0)
+    want = reference(Af[:, :Kd], Bm, 512 if c.exact else 0, alpha, beta, C0)
     ok = np.array_equal(Cout, want)
     pad_ok = True
     if ldc > N:
@@ -108,7 +113,7 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     mem = Memory()
     # the input is placed with nothing mapped directly before / after it: any access outside the tensor is an error
     a_, b_, c_, t_ = mem.alloc(w), mem.alloc(x), mem.alloc(out), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, Kd, 0, npix, M, N, Kd, 0, 0)
+    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, Kd, 0, npix, M, N, Kd, 1.0, 0.0, 0)
     ka += struct.pack("<IIIIIIII", H, W, oW, pH, pW, Cin, npix, (1 << 32) // oW + 1)
     ka += struct.pack("<IIQ", 0, 0, Cin * H * W * 4)
     ka += struct.pack("<Q", M * npix * 4)

@@ -108,6 +108,7 @@ class Gen:
         self.ka0 = S(8, align=4)   # A, B, C, TAB pointers
         self.ka1 = S(8, align=4)   # lda ldb ldc M N K - -
         self.s_lda, self.s_ldb, self.s_ldc, self.s_M, self.s_N, self.s_K = (self.ka1[i] for i in range(6))
+        self.s_alpha, self.s_beta = self.ka1[6], self.ka1[7]     # float32 bit patterns
         self.srdA, self.srdB, self.srdC = S(4), S(4), S(4)
         self.s_rem, self.s_cnt = S(), S()
         self.s_bstep = S()
@@ -535,6 +536,8 @@ class Gen:
                 e("v_accvgpr_write_b32", self.acc[b][r], 0)
                 if c.exact:
                     e("v_accvgpr_write_b32", self.run[b][r], 0)
+        if c.exact:
+            self.load_beta_c()
         self.lg_wait(None)
         e("s_barrier")
         self.read_group(0, 0, 0)
@@ -1028,6 +1031,14 @@ class Gen:
             e("v_mfma_f32_32x32x2_f32", self.acc[b], self.fa[slot][i][u], self.fb[slot][n][u], srcc)
             if first:
                 T = self.vT[0]
+                # run += alpha * slice, unfused (gemm_ukernel_generic.nim:68-76); alpha == 1 (every reference caller): 1*x is x,
+                # the multiplies are branched over
+                # the multiplies sit out of line (after s_endpgm) so that the usual case is a branch NOT taken
+                lmul, lback = p.label("amul"), p.label("aback")
+                e("s_cmp_lg_u32", self.s_alpha, 0x3f800000)
+                e("s_cbranch_scc1", lmul)
+                p.place(lback)
+                self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(16)], lback))
                 for r in range(16):
                     tt = self.vt[r % 4]
                     e("v_accvgpr_read_b32", tt, self.run[b][r])
@@ -1082,8 +1093,69 @@ class Gen:
             p.place(L_done)
             return
 
+    def c_addr_setup(self):
+        """vC[n] = byte offset in C of this lane's first element of block column n (row m0 + wm0 + 4*hi, col n0 + wn0 + lo + 32n);
+        columns beyond N get an offset the bounds check always rejects (C is kept under 2 GB by the launcher)"""
+        c, e, t, st = self.c, self.p.emit, self.vt, self.s_t
+        lane, lo, hi = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, v(0))
+        e("v_and_b32", lo, 31, lane)
+        e("v_lshrrev_b32", hi, 5, lane)
+        # row = m0 + wm0 + 4 * hi (+ 32 i + 8 q + rr); col = n0 + wn0 + lo (+ 32 n)
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("v_lshl_add_u32", t[3], hi, 2, st[0])
+        e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], lo)              # col of block n = 0
+        e("v_lshl_add_u32", t[3], t[4], 2, t[3])     # byte offset of (row, col)
+        for n in range(c.TN):
+            e("v_add_u32", t[5], 32 * n, t[4])
+            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
+            e("v_add_u32", t[6], 128 * n, t[3])
+            e("v_mov_b32", t[7], 0x80000000)
+            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+            self.dump(f"vC[{n}]", self.vC[n])
+
+    def c_step(self, i, q, rr):
+        """vC moves on to the next accumulator row: + ldc (rows rr within a quad), + 5*ldc - 0 (next quad: rows 8 apart)"""
+        c = self.c
+        if i == c.TM - 1 and q == 3 and rr == 3:
+            return
+        step = self.s_ldc4 if rr < 3 else self.s_ldc20
+        for n in range(c.TN):
+            self.p.emit("v_add_u32", self.vC[n], step, self.vC[n])
+
+    def load_beta_c(self):
+        """laser-order kernels, beta != 0: the running sum starts as beta * C0 (one rounding; gemm_ukernel_generic.nim:59-66,
+        gemm.nim:158 -- beta applies with the first kc slice only), before the first slice is added.  Loads go through the
+        fragment registers (free until the first fragment read) and are drained inside this block, so the counted waits of the
+        tile loads (computed for the beta == 0 path) stay correct."""
+        c, p = self.c, self.p
+        e = p.emit
+        skip = p.label("nobeta")
+        e("s_and_b32", self.s_t[0], self.s_beta, 0x7fffffff)
+        e("s_cmp_eq_u32", self.s_t[0], 0)
+        e("s_cbranch_scc1", skip)
+        self.c_addr_setup()
+        pool = [r[k] for slot in range(2) for r in (self.fa[slot] + self.fb[slot]) for k in range(4)]
+        per = 4 * c.TN
+        assert len(pool) >= per
+        for i in range(c.TM):
+            for q in range(4):
+                for rr in range(4):
+                    for n in range(c.TN):
+                        e("buffer_load_dword", pool[rr * c.TN + n], self.vC[n], self.srdC, 0, offen=True)
+                    self.c_step(i, q, rr)
+                e("s_waitcnt", vmcnt=0)
+                for rr in range(4):
+                    for n in range(c.TN):
+                        x = pool[rr * c.TN + n]
+                        e("v_mul_f32", x, self.s_beta, x)
+                        e("v_accvgpr_write_b32", self.run[i * c.TN + n][4 * q + rr], x)
+        p.place(skip)
+
     def epilogue(self):
-        """C = run + acc (alpha == 1, beta == 0: gemm_ukernel_generic.nim:53-76), predicated by the descriptor's bounds check"""
+        """C = (beta * C0 + alpha * slice sums in order) -- gemm_ukernel_generic.nim:53-76, predicated by the descriptor's bounds check"""
         c, p = self.c, self.p
         e = p.emit
         t = self.vt
@@ -1103,50 +1175,80 @@ class Gen:
             for k_ in range(4):
                 self.dump(f"srdC[{k_}]", self.srdC[k_])
             self.dump("s_rem", self.s_rem)
-        tid = v(0)
-        lane, lo, hi = t[0], t[1], t[2]
-        e("v_and_b32", lane, 63, tid)
-        e("v_and_b32", lo, 31, lane)
-        e("v_lshrrev_b32", hi, 5, lane)
-        # row = m0 + wm0 + 4 * hi (+ 32 i + 8 q + rr); col = n0 + wn0 + lo (+ 32 n)
-        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
-        e("v_lshl_add_u32", t[3], hi, 2, st[0])
-        e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
-        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
-        e("v_add_u32", t[4], st[1], lo)              # col of block n = 0
-        e("v_lshl_add_u32", t[3], t[4], 2, t[3])     # byte offset of (row, col)
-        for n in range(c.TN):
-            # columns beyond N: an offset the bounds check always rejects (C is kept under 2 GB by the launcher)
-            e("v_add_u32", t[5], 32 * n, t[4])
-            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
-            e("v_add_u32", t[6], 128 * n, t[3])
-            e("v_mov_b32", t[7], 0x80000000)
-            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
-            self.dump(f"vC[{n}]", self.vC[n])
-        for i in range(c.TM):
-            for q in range(4):
+        self.c_addr_setup()
+        if c.exact:
+            # C = run + alpha * (the last slice's sum); run already carries beta * C0 and the earlier slices
+            def rows(i, q):
                 for rr in range(4):
                     r = 4 * q + rr
                     for n in range(c.TN):
                         b = i * c.TN + n
-                        tt = t[(2 * n) % 8]
+                        tt, uu = t[(2 * n) % 8], t[(2 * n + 1) % 8]
                         e("v_accvgpr_read_b32", tt, self.acc[b][r])
-                        if c.exact:
-                            uu = t[(2 * n + 1) % 8]
-                            e("v_accvgpr_read_b32", uu, self.run[b][r])
-                            e("v_add_f32", tt, uu, tt)
+                        e("v_mul_f32", tt, self.s_alpha, tt)
+                        e("v_accvgpr_read_b32", uu, self.run[b][r])
+                        e("v_add_f32", tt, uu, tt)
                         e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
-                    last = (i == c.TM - 1 and q == 3 and rr == 3)
-                    if not last:
-                        step = self.s_ldc4 if rr < 3 else self.s_ldc20
+                    self.c_step(i, q, rr)
+            for i in range(c.TM):
+                for q in range(4):
+                    rows(i, q)
+        else:
+            # one chain: C = beta * C0 + alpha * sum (beta == 0: C0 is never read, gemm_ukernel_generic.nim:59-66)
+            withc, done = p.label("beta"), p.label("stored")
+            e("s_and_b32", st[0], self.s_beta, 0x7fffffff)
+            e("s_cmp_lg_u32", st[0], 0)
+            e("s_cbranch_scc1", withc)
+            for i in range(c.TM):
+                for q in range(4):
+                    for rr in range(4):
+                        r = 4 * q + rr
                         for n in range(c.TN):
-                            e("v_add_u32", self.vC[n], step, self.vC[n])
+                            tt = t[(2 * n) % 8]
+                            e("v_accvgpr_read_b32", tt, self.acc[i * c.TN + n][r])
+                            e("v_mul_f32", tt, self.s_alpha, tt)
+                            e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
+                        self.c_step(i, q, rr)
+            e("s_branch", done)
+            p.place(withc)
+            self.c_addr_setup()
+            P = self.vT[0]
+            for i in range(c.TM):
+                for q in range(4):
+                    for n in range(c.TN):
+                        e("v_mov_b32", t[n], self.vC[n])
+                    for rr in range(4):
+                        for n in range(c.TN):
+                            e("buffer_load_dword", P[rr * c.TN + n], self.vC[n], self.srdC, 0, offen=True)
+                        if rr < 3:
+                            for n in range(c.TN):
+                                e("v_add_u32", self.vC[n], self.s_ldc4, self.vC[n])
+                    for n in range(c.TN):
+                        e("v_mov_b32", self.vC[n], t[n])
+                    e("s_waitcnt", vmcnt=0)
+                    for rr in range(4):
+                        r = 4 * q + rr
+                        for n in range(c.TN):
+                            tt, x = t[4 + n % 4], P[rr * c.TN + n]
+                            e("v_mul_f32", x, self.s_beta, x)
+                            e("v_accvgpr_read_b32", tt, self.acc[i * c.TN + n][r])
+                            e("v_mul_f32", tt, self.s_alpha, tt)
+                            e("v_add_f32", tt, x, tt)
+                            e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
+                        self.c_step(i, q, rr)
+            p.place(done)
         e("s_endpgm")
 
     def build(self):
+        self.outlined = []
         self.prologue()
         self.main_loop()
         self.epilogue()
+        for label, ins, back in self.outlined:
+            self.p.place(label)
+            for i in ins:
+                self.p.emit(*i)
+            self.p.emit("s_branch", back)
         return self.p
 
 

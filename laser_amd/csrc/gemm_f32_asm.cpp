@@ -62,7 +62,7 @@ struct KernArgs {
   float *C;
   const uint32_t *table;
   uint32_t lda, ldb, ldc, M, N, K;
-  uint64_t reserved;
+  float alpha, beta;   // C = beta * C + alpha * A B (beta == 0: C is never read)
   void *dbg;
   // convolution kernels only (f32_kernel.py KA_CONV*)
   uint32_t H, W, oW, pH, pW, Cin, Npix, magic_oW;
@@ -112,7 +112,6 @@ hipError_t get_module(int dev, DeviceModule **out) {
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;
   if (a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
-  if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
   if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
   if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
   // B: row-major-like (unit column stride), or passed transposed (unit row stride: every column is k-contiguous)
@@ -197,7 +196,8 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.M = (uint32_t)a.M;
   ka.N = (uint32_t)a.N;
   ka.K = (uint32_t)a.K;
-  ka.reserved = 0;
+  ka.alpha = a.alpha;
+  ka.beta = a.beta;
   ka.dbg = nullptr;
   ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
   ka.bsB_bytes = ka.bsC_bytes = 0;
@@ -271,7 +271,8 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.M = (uint32_t)a.M;
   ka.N = (uint32_t)a.N;
   ka.K = (uint32_t)a.K;
-  ka.reserved = 0;
+  ka.alpha = 1.0f;
+  ka.beta = 0.0f;
   ka.dbg = nullptr;
   ka.H = (uint32_t)a.cH;
   ka.W = (uint32_t)a.cW;

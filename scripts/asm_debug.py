@@ -49,7 +49,7 @@ NS = g.ndump
 mem = Memory()
 a_, b_, c_, t_ = mem.alloc(A), mem.alloc(B), mem.alloc(np.full((NIMG, M, N), np.nan, np.float32)), mem.alloc(table)
 d_ = mem.alloc(np.zeros(NS * 256 + 64, dtype=np.uint32))
-ka_ = mem.alloc(np.frombuffer(struct.pack("<QQQQIIIIIIQQ", a_, b_, c_, t_, lds[0], lds[1], lds[2], M, N, Kd, 0, d_) + conv_args, dtype=np.uint8))
+ka_ = mem.alloc(np.frombuffer(struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lds[0], lds[1], lds[2], M, N, Kd, 1.0, 0.0, d_) + conv_args, dtype=np.uint8))
 for img in range(NIMG):
     for wg in range(len(table)):
         Workgroup(g.p, mem, ka_, wg_id=(wg, img), lds_bytes=c.lds_alloc).run()
@@ -80,7 +80,7 @@ dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
 dC = torch.full((NIMG, M, N), float("nan"), device="cuda")
 dT = torch.from_numpy(table.astype(np.int32)).cuda()
 dD = torch.zeros(NS * 256 + 64, dtype=torch.int32, device="cuda")
-ka = struct.pack("<QQQQIIIIIIQQ", dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), dT.data_ptr(), lds[0], lds[1], lds[2], M, N, Kd, 0, dD.data_ptr()) + conv_args
+ka = struct.pack("<QQQQIIIIIIffQ", dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), dT.data_ptr(), lds[0], lds[1], lds[2], M, N, Kd, 1.0, 0.0, dD.data_ptr()) + conv_args
 buf = C.create_string_buffer(ka, len(ka))
 size = C.c_size_t(len(ka))
 extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)

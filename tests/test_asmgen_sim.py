@@ -37,6 +37,16 @@ GEMM_CASES = [
 ]
 
 
+# C = beta * C0 + alpha * A B: the running sum starts as beta * C0, every slice is scaled before it is added
+GEMM_CASES += [
+    ("exact_256x128x32", 70, 90, 1060, dict(alpha=0.75, beta=-1.5, ldc=100)),
+    ("exact_64x64x32", 70, 40, 548, dict(alpha=-2.0, beta=1.0)),
+    ("fast_256x256x16", 40, 300, 72, dict(alpha=3.0, beta=0.5)),
+    ("fast_64x64x32_nt", 70, 90, 100, dict(alpha=0.5, beta=0.0)),
+    ("exact_128x128x16_nt", 40, 50, 1028, dict(alpha=1.0, beta=0.25)),
+]
+
+
 @pytest.mark.parametrize("name,M,N,Kd,kw", GEMM_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}" for c in GEMM_CASES])
 def test_gemm_kernels_bit_exact_in_the_interpreter(name, M, N, Kd, kw):
     assert C.run_case(name, M, N, Kd, verbose=False, **kw)

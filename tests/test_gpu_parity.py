@@ -700,15 +700,38 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
         took += 1
     for family in ({1, 2, 9}, {5, 6, 10}, {3, 4}, {7, 8}, {13, 14}, {15, 16}):      # every kernel family was exercised
         assert seen & family, (sorted(seen), family)
-    # not this kernel's class: alpha / beta, a strided C -> the compiler-scheduled kernels, same results as ever
+    # alpha / beta on the assembly kernels (run starts as beta * C0, every slice is scaled before it is added): same bits as the
+    # compiler-scheduled kernels and the oracle, both modes, plain and transposed B, a 64x64-tile shape and a large-tile one
+    for (M, N, K), (al, be) in (((2048, 2048, 1028), (0.5, 0.25)), ((1000, 1100, 520), (-1.25, 1.0)), ((4096, 2048, 64), (3.0, 0.0)),
+                                ((1024, 1024, 1540), (1.0, -0.5))):
+        A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
+        Bt = torch.from_numpy(rand(rng, (N, K), np.float32)).cuda()
+        C0 = torch.from_numpy(rand(rng, (M, N), np.float32)).cuda()
+        for B in (Bt.t().contiguous(), Bt.t()):
+            for mode in (0, 1):
+                la.set_float_mode(mode)
+                try:
+                    la.set_f32_asm(2)
+                    c1 = C0.clone(); la.matmul(A, B, al, be, c1)
+                    assert la.last_f32_asm() != 0
+                    la.set_f32_asm(0)
+                    c2 = C0.clone(); la.matmul(A, B, al, be, c2)
+                finally:
+                    la.set_f32_asm(1); la.set_float_mode(0)
+                assert torch.equal(c1, c2), (M, N, K, al, be, mode)
+                if mode == 0:
+                    want = oracle.matmul(A.cpu().numpy(), np.ascontiguousarray(B.cpu().numpy()), al, be, C0.cpu().numpy().copy())
+                    assert np.array_equal(c1.cpu().numpy(), want), (M, N, K, al, be)
+    # beta == 0 never reads C: NaNs in the output buffer do not reach the result
+    cn = torch.full((2048, 2048), float("nan"), device="cuda")
+    A = torch.from_numpy(rand(rng, (2048, 1024), np.float32)).cuda()
+    B = torch.from_numpy(rand(rng, (1024, 2048), np.float32)).cuda()
+    la.matmul(A, B, 2.0, 0, cn)
+    assert la.last_f32_asm() != 0 and not torch.isnan(cn).any()
+    # not this kernel's class: a strided C, K not a multiple of 4 -> the compiler-scheduled kernels, same results as ever
     M, N, K = 2048, 2048, 1024
-    A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
-    B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
-    C0 = torch.from_numpy(rand(rng, (M, N), np.float32)).cuda()
     try:
         la.set_f32_asm(2)
-        c1 = C0.clone(); la.matmul(A, B, 0.5, 0.25, c1)
-        assert la.last_f32_asm() == 0
         w = torch.full((M, 2 * N), 9.0, device="cuda"); la.matmul(A, B, 1, 0, w[:, ::2])
         assert la.last_f32_asm() == 0
         ref = la.matmul(A, B)
