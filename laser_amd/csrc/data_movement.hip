@@ -98,11 +98,13 @@ static hipError_t launch_transpose_t(void *dst, const void *src, int64_t N, int6
   constexpr int V = 16 / sizeof(T);
   const bool vec = (NR % V == 0) && (NC % V == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
   if (vec) {
-    // production form: 64 source rows x 128 source columns per workgroup (512-B read segments, 256-B write
-    // segments).  scripts/transpose_probe.py (profiles/r01/transpose_probe.log): vs the 64x64 tile
-    // +5 % at 16384x8192 and +19 % at 8192^2, equal elsewhere; it runs AT the rate of a plain D2D copy of
-    // the same bytes (4.7-5.4 TB/s at these sizes).  Streaming (nontemporal) hints cost 5-20 %; 128x128 loses occupancy.
-    return launch_transpose_v<T, 64, 128, false>(dst, src, N, NR, NC, s);
+    // Tile shape by problem size (scripts/probes/transpose_probe.hip, timed from C++ so that no interpreter sits between
+    // launches; profiles/r03/transpose_probe_v1.jsonl): a problem of a few dozen microseconds wants MANY small workgroups
+    // -- 16 source rows x 256 columns (1-KiB read segments, 64-B write segments): 4000 x 2000 f32 5.92 TB/s and 4096^2
+    // 6.37 vs 5.57 / 5.67 with the 64 x 128 tile (a plain copy kernel of the same bytes: 6.3 / 6.7) -- while from ~100 us on
+    // the write segments matter more: 32 x 256 (16384 x 8192: 5.27 vs 5.00; 8192^2: 5.01 vs 5.04; copy kernel 5.7).
+    if (N * NR * NC <= ((int64_t)1 << 24)) return launch_transpose_v<T, 16, 256, false>(dst, src, N, NR, NC, s);
+    return launch_transpose_v<T, 32, 256, false>(dst, src, N, NR, NC, s);
   }
   const int64_t tiles_r = (NR + 63) / 64, tiles_c = (NC + 63) / 64;
   const int64_t blocks = N * tiles_r * tiles_c;

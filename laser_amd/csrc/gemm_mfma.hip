@@ -166,8 +166,12 @@ static SplitPlan plan_split(const GemmArgs<float> &a, bool exact, bool need_gen,
 static int fallback_exact_cfg(const GemmArgs<float> &) { return kCfgWideExact; }
 static int gen_cfg(const GemmArgs<float> &a, bool exact) { return heuristic_cfg(a, exact, true); }
 
-// fp64: two configurations.
-static int heuristic_cfg(const GemmArgs<double> &a, bool, bool = false) { return tiles_of(a, 128, 128) >= 128 ? 0 : 1; }
+
+// fp64: three configurations (rule from profiles/r03/f64_cfg_probe.jsonl).
+static int heuristic_cfg(const GemmArgs<double> &a, bool, bool = false) {
+  if (tiles_of(a, 128, 128) >= 180) return 0;   // (1536^3 = 144 tiles: 44.6 on 64x64 vs 39.9; 1920^3 = 225: 56.0 vs 48.8)
+  return tiles_of(a, 64, 64) <= 256 ? 2 : 1;
+}
 static int fallback_exact_cfg(const GemmArgs<double> &) { return 0; }
 static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 

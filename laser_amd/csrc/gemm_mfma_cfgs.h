@@ -37,10 +37,14 @@
 
 // float64 (v_mfma_f64_16x16x4_f64, 16x16 blocks, 4 k per instruction): the 8-wave 128x128 tile has the
 // same cadence as f32 cfg 0 (8 MFMAs of 64 cycles per k-step); laser-order needs acc 64 + run 64 regs.
+// cfg 2 (64x32): problems of at most one round of 64x64 tiles -- 960^3 (the reference's f64 bench shape,
+// benchmarks/gemm/gemm_bench_float64.nim) 37.0 / 39.0 vs 35.3 / 35.7 TFLOP/s, 1024^3 42.0 / 43.9 vs 40.4 / 40.6
+// (profiles/r03/f64_cfg_probe.jsonl; a 32x32 tile was no better and is not built).
 #define LH_F64_CONFIGS(X)                                        \
   X(0, 128, 128, 16, 2, 4, 3, 2, 2, true, false, true)           \
-  X(1, 64, 64, 16, 2, 2, 2, 2, 2, true, true, true)
-#define LH_F64_NUM_CONFIGS 2
+  X(1, 64, 64, 16, 2, 2, 2, 2, 2, true, true, true)              \
+  X(2, 64, 32, 16, 2, 2, 2, 2, 2, true, true, true)
+#define LH_F64_NUM_CONFIGS 3
 
 namespace laser_hip {
 template <int IDX>
