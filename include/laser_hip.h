@@ -65,10 +65,11 @@ int laser_hip_f32_config_count(void);
 /* ---- options: one entry point for every tuning / A-B switch ------------------------------------------------------------
  * laser_hip_set_option(name, value); unknown names are LASER_HIP_E_INVALID.  Every switch leaves results bit-identical
  * (it selects between implementations of the same arithmetic); defaults in brackets.
- *   "f32_asm"          [1] float32 gemm_strided with unit column strides on A and C, B row-major or passed transposed,
- *                          alpha == 1, beta == 0, K a multiple of 4: the hand-scheduled assembly kernels (one wave per SIMD,
- *                          accumulators in AGPRs; laser_amd/asmgen/) when the problem fills the chip; 0 = never (the
- *                          compiler-scheduled kernels); 2 = whenever eligible, whatever the tile count (tests)
+ *   "f32_asm"          [1] float32 gemm_strided with unit column strides on A and C, B row-major or passed transposed, any
+ *                          alpha / beta, K a multiple of 4 -- and 3x3 / stride-1 convolutions with any zero padding: the
+ *                          hand-scheduled assembly kernels (accumulators in AGPRs; laser_amd/asmgen/) when the problem has at
+ *                          least ~100 tiles of 64x64; 0 = never (the compiler-scheduled kernels); 2 = whenever eligible,
+ *                          whatever the tile count (tests)
  *   "f64_mfma" "i32_mfma" "i64_mfma"  [1] matrix-core kernels (f64 MFMA; int8-limb decomposition for the integers, the
  *                          reference's integer micro-kernels: gemm_ukernel_avx512.nim:40-74); 0 = the VALU kernels
  *   "conv_implicit"    [1] im2col fused into the GEMM's B loader; 0 = explicit im2col workspace + batched GEMM, the
