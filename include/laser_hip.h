@@ -75,6 +75,8 @@ int laser_hip_f32_config_count(void);
  *   "conv_implicit"    [1] im2col fused into the GEMM's B loader; 0 = explicit im2col workspace + batched GEMM, the
  *                          reference's literal structure (conv2d_im2col.nim:126-166)
  *   "conv_patch"       [1] implicit conv reads B from an LDS-resident input patch when it fits; 0 = per-element gather
+ *   "conv_direct"      [1] convolutions with <= 32 output channels and C_in*kH*kW <= 256 (the reference's conv bench shape,
+ *                          conv2d_bench.nim:130-170): the direct HBM-streaming kernel; 0 = the implicit-GEMM kernels
  *   "conv_kslice"      [1] laser-order conv tail as parallel kc slices (gemm.nim:150-158) + ordered combine
  *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only
  *   "zero_copy_poll"   [1] small host-pointer calls poll completion flags in mapped memory; 0 = synchronise the stream
@@ -83,7 +85,7 @@ int laser_hip_f32_config_count(void);
  *   "slice_parallel"   [1] few tiles x long K: kc slices as one batched launch + ordered combine
  *   "slice_parallel_min" / "slice_parallel_tiles"  tuning overrides of that rule (0 = built-in)
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
- *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel)
+ *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
  *   "last_f32_asm"     0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
  *   "last_split"       column where the last float GEMM / conv launch was cut (0 = one launch) */
 int laser_hip_set_option(const char *name, int value);

@@ -1251,6 +1251,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "i64_mfma") g_ctx.i64_mfma = on;
   else if (n == "conv_implicit") g_ctx.conv_implicit = on;
   else if (n == "conv_patch") g_conv_patch = on;
+  else if (n == "conv_direct") g_conv_direct = on;
   else if (n == "conv_kslice") g_conv_kslice = on;
   else if (n == "host_pipeline_2d") g_ctx.host_pipeline_2d = on;
   else if (n == "zero_copy_poll") g_ctx.zc_poll = on;
@@ -1272,6 +1273,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "i64_mfma") *value = g_ctx.i64_mfma;
   else if (n == "conv_implicit") *value = g_ctx.conv_implicit;
   else if (n == "conv_patch") *value = g_conv_patch;
+  else if (n == "conv_direct") *value = g_conv_direct;
   else if (n == "conv_kslice") *value = g_conv_kslice;
   else if (n == "host_pipeline_2d") *value = g_ctx.host_pipeline_2d;
   else if (n == "zero_copy_poll") *value = g_ctx.zc_poll;

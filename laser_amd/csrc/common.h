@@ -152,6 +152,8 @@ hipError_t launch_gemm_i32_mfma(const GemmArgs<int32_t> &args, void *ws, hipStre
 size_t gemm_i64_mfma_workspace_bytes(int64_t M, int64_t N, int64_t K);
 hipError_t launch_gemm_i64_mfma(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 
+extern std::atomic<int> g_conv_direct;        // few output channels x short K: the direct (HBM-streaming) kernel (1, default)
+hipError_t launch_conv_direct_small_f32(const GemmArgs<float> &a, hipStream_t s);
 extern std::atomic<int> g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
 extern std::atomic<int> g_conv_kslice;        // laser-order conv tail as parallel kc slices + ordered combine (1, default)
 extern std::atomic<int> g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches

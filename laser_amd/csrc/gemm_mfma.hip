@@ -286,6 +286,14 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   a.cs_imgs = 0; a.cs_len = 0;
   const bool exact = laser_order && a.K > 512;
   a.kc = exact ? 512 : 0;
+  if (cfg < 0) {  // few output channels, short reduction (the reference's conv bench shape): an HBM stream, not a tile problem
+    const hipError_t e = launch_conv_direct_small_f32(a, s);
+    if (e != hipErrorNotSupported) {
+      g_last_split = 0;
+      g_last_f32_cfg = -3;
+      return e;
+    }
+  }
   // the BK=32 laser-order kernel has no registers left for the gather state (it would spill): same tile at BK=16
   auto fix = [&](int c) {
     if (exact && !kCfgsF32[c].exact) c = kCfgWideExact;

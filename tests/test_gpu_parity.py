@@ -1123,3 +1123,40 @@ def test_batched_small_matrices_bit_exact(la, oracle):
     C = torch.zeros((10, 40, 30), device="cuda")
     la.gemm_strided_batched(10, 40, 30, 50, 1.0, A, 50, 1, 2000, B, 30, 1, 0, 0.0, C, 30, 1, 1200)
     assert np.array_equal(C[7].cpu().numpy(), oracle.matmul(A[7].cpu().numpy(), B.cpu().numpy()))
+
+
+def test_conv_direct_small_channels_bit_exact(la, oracle):
+    """Few output channels x short reduction (the reference's own conv bench geometry, conv2d_bench.nim:130-170): the direct
+    HBM-streaming kernel -- same bits as the implicit-GEMM kernels (option conv_direct = 0) and as the oracle, for padding,
+    strides, non-square filters and ragged pixel counts; the class boundary (33 channels, K = 288) falls through."""
+    import torch
+    rng = np.random.default_rng(77)
+    cases = [((16, 3, 224, 224), (20, 3, 3, 3), (0, 0), (1, 1)), ((2, 4, 17, 19), (7, 4, 5, 3), (2, 1), (2, 1)),
+             ((3, 8, 30, 30), (32, 8, 3, 3), (1, 1), (1, 1)), ((1, 1, 9, 300), (3, 1, 1, 7), (0, 3), (1, 2)),
+             ((2, 28, 12, 12), (16, 28, 3, 3), (1, 1), (1, 1))]
+    for ishape, kshape, pad, st in cases:
+        x = rng.uniform(-1, 1, ishape).astype(np.float32)
+        w = rng.uniform(-1, 1, kshape).astype(np.float32)
+        dx, dw = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+        outs = {}
+        for mode in (0, 1):
+            la.set_float_mode(mode)
+            for direct in (1, 0):
+                la.set_option("conv_direct", direct)
+                try:
+                    o = torch.full(oshape, float("nan"), device="cuda")
+                    la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, pad, st, None)
+                    assert (la.get_option("last_f32_config") == -3) == (direct == 1), (ishape, kshape, direct)
+                    outs[(mode, direct)] = o
+                finally:
+                    la.set_option("conv_direct", 1); la.set_float_mode(0)
+        assert torch.equal(outs[(0, 1)], outs[(0, 0)]) and torch.equal(outs[(1, 1)], outs[(1, 0)]), (ishape, kshape)
+        assert np.array_equal(outs[(0, 1)].cpu().numpy(), oracle.conv2d_im2col(x, w, pad, st)), (ishape, kshape)
+    for ishape, kshape in (((1, 8, 20, 20), (33, 8, 3, 3)), ((1, 32, 20, 20), (8, 32, 3, 3))):     # outside the class
+        dx = torch.from_numpy(rng.uniform(-1, 1, ishape).astype(np.float32)).cuda()
+        dw = torch.from_numpy(rng.uniform(-1, 1, kshape).astype(np.float32)).cuda()
+        oshape = la.conv2d_out_shape(ishape, kshape, (1, 1), (1, 1))
+        o = torch.zeros(oshape, device="cuda")
+        la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, (1, 1), (1, 1), None)
+        assert la.get_option("last_f32_config") != -3
