@@ -12,7 +12,7 @@
 // Arithmetic: per output element the ascending-k fused multiply-add chain from +0, k = (c*kH + kh)*kW + kw
 // (conv2d_im2col.nim:62-87 order), zero-padding taps multiplied in as zeros -- exactly what the matrix cores compute on the
 // implicit-GEMM path for K <= kc = 512 (one slice: laser-order and one-chain modes coincide), so the results are
-// bit-identical to it and to the oracle (a v_fma_f32 chain == the f32 MFMA's chain, as in gemm_skinny.hip).
+// bit-identical to it and to the CPU restatement the tests use (a v_fma_f32 chain == the f32 MFMA's chain, as in gemm_skinny.hip).
 #include "common.h"
 
 namespace laser_hip {
