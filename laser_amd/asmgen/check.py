@@ -139,3 +139,49 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     if verbose:
         print(f"{name} images={images} Cin={Cin} {H}x{W} M={M} pad={pad} N={N}/{npix}: {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f} s)")
     return ok
+
+
+def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True):
+    """float64 kernels (f64_kernel.py) through the interpreter.  Operands are small integers, for which every product and
+    partial sum is exact in float64 (the interpreter's f64 MFMA is mul + add, not an exact fma): this checks every address,
+    layout, wait and hazard of the program; the accumulation ORDER with rounding is checked on hardware against the
+    compiler-scheduled kernels and the CPU restatement."""
+    from . import f64_kernel as K64
+    g = K64.make(name, **(over or {}))
+    g.build()
+    c = g.c
+    rng = np.random.default_rng(seed)
+    lda, ldb, ldc = lda or Kd, ldb or N, ldc or N
+    Af = np.full((M, lda), np.nan)
+    Bf = np.full((Kd, ldb), np.nan)
+    Am = rng.integers(-4, 5, (M, Kd)).astype(np.float64)
+    Bm = rng.integers(-4, 5, (Kd, N)).astype(np.float64)
+    Af[:, :Kd] = Am
+    Bf[:, :N] = Bm
+    Aflat = Af.reshape(-1)[:(M - 1) * lda + Kd].copy()
+    Bflat = Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
+    Cflat = np.full((M - 1) * ldc + N, np.nan)
+    tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
+    table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
+    mem = Memory()
+    a_, b_, c_, t_ = mem.alloc(Aflat), mem.alloc(Bflat), mem.alloc(Cflat), mem.alloc(table)
+    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + b"\0" * 56
+    ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    t0 = time.time()
+    stats = None
+    for wg in range(len(table)):
+        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc)
+        w.run(order=order)
+        stats = w.waves[0].stats
+    full = np.full(M * ldc, np.nan)
+    full[:len(Cflat)] = mem.get(c_, np.float64, (len(Cflat),))
+    full = full.reshape(M, ldc)
+    want = Am @ Bm
+    ok = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(np.isnan(full[:, N:][:-1]))))
+    if verbose:
+        print(f"f64 {name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, "
+              f"bank-conflict cycles {stats['bank_conflict_cycles']}, {stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
+        if not ok:
+            bad = np.argwhere(full[:, :N] != want)
+            print("  first mismatches:", bad[:8].tolist(), full[tuple(bad[0])] if len(bad) else None, want[tuple(bad[0])] if len(bad) else None, "count", len(bad))
+    return ok

@@ -20,17 +20,24 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
-                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False):
+                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32"):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
+        self.dtype = dtype
+        f64 = dtype == "f64"
+        # f32: v_mfma_f32_32x32x2 (32x32 blocks, 2 k per instruction, one 16-byte fragment read feeds 4 k-steps);
+        # f64: v_mfma_f64_16x16x4 (16x16 blocks, 4 k per instruction, one 16-byte read feeds 2 k-steps): 8 k per group either way
+        self.MB, self.KSTEP, self.KREAD, self.ACCR, self.ESZ = (16, 4, 2, 8, 8) if f64 else (32, 2, 4, 16, 4)
+        self.KC = 256 if f64 else 512    # gemm_tiling.nim:310: kc = 2048 / sizeof(T)
+        self.RS = 144 if f64 else BK * 4  # bytes of one panel row in LDS (f64: 128 + 16 of padding: conflict-free b128 reads)
         self.WTM, self.WTN = BM // 2, BN // 2
-        self.TM, self.TN = self.WTM // 32, self.WTN // 32
+        self.TM, self.TN = self.WTM // self.MB, self.WTN // self.MB
         self.NB = self.TM * self.TN
-        self.NG = BK // 8            # fragment groups (4 k-steps each) per K-tile
-        self.NMF = self.NB * (BK // 2)  # MFMAs per K-tile per wave
+        self.NG = BK // 8            # fragment groups (8 k each) per K-tile
+        self.NMF = self.NB * (BK // self.KSTEP)  # MFMAs per K-tile per wave
         self.GM = self.NMF // self.NG   # MFMAs per group
-        self.STAGE = BK * (BM + BN) * 4
-        self.NPA = BM * BK // 4 // 256   # 16-byte pieces of A per thread per tile
-        self.NPB = BN * BK // 4 // 256
+        self.STAGE = (BM + BN) * self.RS
+        self.NPA = BM * BK * self.ESZ // 16 // 256   # 16-byte pieces of A per thread per tile
+        self.NPB = BN * BK * self.ESZ // 16 // 256
         # implicit-GEMM convolution (3x3, stride 1, any zero padding): B is the NCHW image; a piece = 2 output pixels per
         # lane of one k = (channel, kernel row, kernel column), gathered by two dword loads whose per-lane offsets come
         # from a 10-entry table in LDS (one entry per kernel tap + "nothing"), indexed by the wave-uniform tap
@@ -41,7 +48,7 @@ class Cfg:
             assert (BN, BK) == (128, 32) and not b_kcontig
             self.NPB = 8
         assert self.NPB % 2 == 0 or b_kcontig
-        self.KC_TILES = 512 // BK        # gemm_tiling.nim:310: kc = 2048 / sizeof(float32)
+        self.KC_TILES = self.KC // BK
         self.bar_gap = bar_gap if bar_gap is not None else (self.NMF - self.GM - 1)
         self.w_start, self.w_step = w_start, w_step
         self.trace = trace
@@ -116,8 +123,8 @@ class Gen:
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
         # accumulators
-        self.acc = [p.aalloc(16) for _ in range(c.NB)]
-        self.run = [p.aalloc(16) for _ in range(c.NB)] if c.exact else None
+        self.acc = [p.aalloc(c.ACCR) for _ in range(c.NB)]
+        self.run = [p.aalloc(c.ACCR) for _ in range(c.NB)] if c.exact else None
         # fragments: 2 slots
         self.fa = [[V(4) for _ in range(c.TM)] for _ in range(2)]
         self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
@@ -532,7 +539,7 @@ class Gen:
         self.tail_mask_if(self.s_rem, 3)        # the first loop body loads tile 2
         # accumulators start at +0
         for b in range(c.NB):
-            for r in range(16):
+            for r in range(c.ACCR):
                 e("v_accvgpr_write_b32", self.acc[b][r], 0)
                 if c.exact:
                     e("v_accvgpr_write_b32", self.run[b][r], 0)
@@ -855,7 +862,7 @@ class Gen:
         """fragment reads of group g (4 k-steps) into register slot `slot`; stage 0: the tile being multiplied, 1: the next tile"""
         c = self.c
         ops = []
-        blk = 32 * c.BK * 4
+        blk = c.MB * c.RS
         for i in range(c.TM):
             ops.append(("ldsr", "ds_read_b128", (self.fa[slot][i], self.RA[g][stage]), {"offset": i * blk}, ("R", slot)))
         for n in range(c.TN):
@@ -864,6 +871,56 @@ class Gen:
 
     def read_group(self, g, stage, slot):
         self.run_ops(self.read_group_ops(g, stage, slot))
+
+    def staging_ops(self, wr_k):
+        """LDS stores of tile t+1 (from registers), each followed by the HBM load of tile t+2 into the drained registers"""
+        c = self.c
+        stg = []
+        for pi in range(c.NPA):
+            stg += self.store_A_piece(pi, ops=[], k=wr_k)
+            stg.append(("loadA", pi))
+        if c.conv:
+            pass
+        elif c.b_kcontig:
+            for pj in range(c.NPB):
+                stg += self.store_B_kpiece(pj, ops=[], k=wr_k)
+                stg.append(("loadB", pj))
+        else:
+            for gi in range(c.NPB // 2):
+                stg += self.store_B_pair(gi, ops=[], k=wr_k)
+                stg.append(("loadB", 2 * gi))
+                stg.append(("loadB", 2 * gi + 1))
+        return stg
+
+    # ------------------------------------------------------------------ the matrix instruction and the slice fold
+    def emit_mfma(self, b, slot, i, n, u, srcc):
+        self.p.emit("v_mfma_f32_32x32x2_f32", self.acc[b], self.fa[slot][i][u], self.fb[slot][n][u], srcc)
+
+    def fold_before(self, b):
+        # Laser's pc loop (gemm.nim:150-158): the finished slice sum leaves the accumulator (16 reads in the shadow of
+        # the previous MFMA), this MFMA starts the next chain from a literal +0, and run += slice follows it -- all
+        # 64 VALU operations of a block in ONE gap: beside the f32 MFMA stream the first VALU instruction of a gap
+        # costs ~11 cycles of matrix-pipe time and every further one ~4 (profiles/r03/asm_probe_v4_fillers.jsonl), so
+        # VALU work is batched, never spread.  (Moving the sums AGPR -> LDS -> VGPR instead, which needs no VALU
+        # moves, measured slower: profiles/r03/asm_probe_v8.jsonl "exact_lds".)
+        T = self.vT[0]
+        for r in range(16):
+            self.p.emit("v_accvgpr_read_b32", T[r], self.acc[b][r])
+
+    def fold_after(self, b):
+        p, e, T = self.p, self.p.emit, self.vT[0]
+        # run += alpha * slice, unfused (gemm_ukernel_generic.nim:68-76); alpha == 1 (every reference caller): 1*x is x;
+        # the multiplies sit out of line (after s_endpgm) so that the usual case is a branch NOT taken
+        lmul, lback = p.label("amul"), p.label("aback")
+        e("s_cmp_lg_u32", self.s_alpha, 0x3f800000)
+        e("s_cbranch_scc1", lmul)
+        p.place(lback)
+        self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(16)], lback))
+        for r in range(16):
+            tt = self.vt[r % 4]
+            e("v_accvgpr_read_b32", tt, self.run[b][r])
+            e("v_add_f32", tt, tt, T[r])
+            e("v_accvgpr_write_b32", self.run[b][r], tt)
 
     # ------------------------------------------------------------------ one K-tile
     def tile_body(self, fold, stage=None):
@@ -881,6 +938,8 @@ class Gen:
         first_free = 0
         if fold:
             first_free = c.NB + 1           # gaps 0..NB-1 carry the slice fold
+            if bar - 1 - (first_free + c.TM + c.TN + 2) < 2:      # very few gaps per tile: the barrier as late as the prefetch allows
+                bar = max(bar, c.NMF - 3)
         # fragment reads: group g+1 (or group 0 of the next tile) during group g
         for g in range(c.NG):
             nxt_tile = (g + 1 == c.NG)
@@ -904,21 +963,7 @@ class Gen:
         # register of a triple: [0] / [1] = this tile's / the next tile's stage when the triples rotate; with one body per
         # stage, reads of stage k use index k and writes index (k + 2) % 3 (the triples were initialised for stage 0)
         wr_k = ((stage + 1) % 3 + 2) % 3
-        stg = []
-        for pi in range(c.NPA):
-            stg += self.store_A_piece(pi, ops=[], k=wr_k)
-            stg.append(("loadA", pi))
-        if c.conv:
-            pass
-        elif c.b_kcontig:
-            for pj in range(c.NPB):
-                stg += self.store_B_kpiece(pj, ops=[], k=wr_k)
-                stg.append(("loadB", pj))
-        else:
-            for gi in range(c.NPB // 2):
-                stg += self.store_B_pair(gi, ops=[], k=wr_k)
-                stg.append(("loadB", 2 * gi))
-                stg.append(("loadB", 2 * gi + 1))
+        stg = self.staging_ops(wr_k)
         # waits ride with the op that follows them
         units = []
         for op in stg:
@@ -936,6 +981,8 @@ class Gen:
                 a_units += [a[:2], [a[2]], [("loadA", pi)]]
             units = cu + self.conv_load_ops() + a_units
         w0 = max(c.w_start, first_free + (c.TM + c.TN + 2 if fold else 0))
+        if fold and bar - 1 - w0 < 2:         # very few gaps (16 MFMAs per tile): staging shares the gaps of the fragment reads
+            w0 = first_free
         span = bar - 1 - w0
         step = c.w_step or min(max(1.0, span / max(1, len(units))), span / max(1, len(units) - 1) if len(units) > span else 1e9)
         for k, u in enumerate(units):
@@ -950,7 +997,7 @@ class Gen:
             put(tail + k, ("ins", o[0], o[1:], {}))
 
         # MFMA order: k-step-major -- NB independent accumulators between two uses of one
-        order = [(g, u, b) for g in range(c.NG) for u in range(4) for b in range(c.NB)]
+        order = [(g, u, b) for g in range(c.NG) for u in range(c.KREAD) for b in range(c.NB)]
 
         if c.filler:
             nvm = 0
@@ -1017,33 +1064,11 @@ class Gen:
             srcc = self.acc[b]
             first = fold and g == 0 and u == 0
             if first:
-                # Laser's pc loop (gemm.nim:150-158): the finished slice sum leaves the accumulator (16 reads in the shadow of
-                # the previous MFMA), this MFMA starts the next chain from a literal +0, and run += slice follows it -- all
-                # 64 VALU operations of a block in ONE gap: beside the f32 MFMA stream the first VALU instruction of a gap
-                # costs ~11 cycles of matrix-pipe time and every further one ~4 (profiles/r03/asm_probe_v4_fillers.jsonl), so
-                # VALU work is batched, never spread.  (Moving the sums AGPR -> LDS -> VGPR instead, which needs no VALU
-                # moves, measured slower: profiles/r03/asm_probe_v8.jsonl "exact_lds".)
-                T = self.vT[0]
-                for r in range(16):
-                    e("v_accvgpr_read_b32", T[r], self.acc[b][r])
-            if first:
+                self.fold_before(b)
                 srcc = 0
-            e("v_mfma_f32_32x32x2_f32", self.acc[b], self.fa[slot][i][u], self.fb[slot][n][u], srcc)
+            self.emit_mfma(b, slot, i, n, u, srcc)
             if first:
-                T = self.vT[0]
-                # run += alpha * slice, unfused (gemm_ukernel_generic.nim:68-76); alpha == 1 (every reference caller): 1*x is x,
-                # the multiplies are branched over
-                # the multiplies sit out of line (after s_endpgm) so that the usual case is a branch NOT taken
-                lmul, lback = p.label("amul"), p.label("aback")
-                e("s_cmp_lg_u32", self.s_alpha, 0x3f800000)
-                e("s_cbranch_scc1", lmul)
-                p.place(lback)
-                self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(16)], lback))
-                for r in range(16):
-                    tt = self.vt[r % 4]
-                    e("v_accvgpr_read_b32", tt, self.run[b][r])
-                    e("v_add_f32", tt, tt, T[r])
-                    e("v_accvgpr_write_b32", self.run[b][r], tt)
+                self.fold_after(b)
             for op in gaps[m]:
                 self.run_op(op)
         assert len(order) == c.NMF

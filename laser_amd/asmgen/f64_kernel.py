@@ -1,0 +1,404 @@
+"""float64 GEMM kernels for gfx950, hand-scheduled: the f32 generator's program structure (f32_kernel.Gen: 3-stage LDS ring,
+one barrier per K-tile, one body per stage, counted waits, accumulators in AGPRs, laser-order fold every kc) with the f64
+matrix instruction and its own LDS image.
+
+  v_mfma_f64_16x16x4_f64   16x16 block, 4 k per instruction (64 cycles per SIMD on MI355X), lane l feeds A[l % 16][l / 16] and
+                           B[l / 16][l % 16] and holds D[l / 16 + 4 * d][l % 16], d = 0..3: 8 accumulator registers per block
+  kc = 256                 gemm_tiling.nim:310 (2048 bytes / sizeof(float64)): the running sum is folded every 16 K-tiles of 16
+
+LDS image (per stage: A panel rows 0..BM-1, then the B panel rows = columns of the tile): a row holds BK = 16 doubles as 8
+chunks of 16 bytes, chunk 4*(k / 8) + k % 4 holding k and k + 4 -- the two k-steps lane group q = k % 4 needs from one
+ds_read_b128 -- and is 144 bytes long: with 9 chunks per row the 16 rows a 16-lane group reads fall into 16 different
+4-bank groups, so the fragment reads are conflict-free without a swizzle, and every store is ONE ds_write2_b64:
+  A piece (16 bytes = k0, k0 + 1 of one row)      -> chunks c and c + 1 of that row:           offsets 0, +16 bytes
+  B piece (16 bytes = columns x0, x0 + 1 of one k) -> the same chunk of rows x0 and x0 + 1:     offsets 0, +144 bytes
+Operands: A row-major (k-contiguous), B row-major (x-contiguous), C row-major; K a multiple of 2; alpha = 1, beta = 0 (the
+launcher sends everything else to the compiler-scheduled kernels)."""
+from .core import v, a, s, VCC
+from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
+
+CONFIGS = {
+    # one wave per SIMD: 2 x 2 waves of 64x64 = 16 blocks = 128 accumulator registers (+ 128 for the running sum)
+    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True),
+    "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False),
+    # problems of few tiles (the reference's f64 bench shape, 960^3 = 225 tiles): 2 x 2 waves of 32x32, several workgroups per CU
+    "exact_64x64x16": dict(BM=64, BN=64, BK=16, exact=True),
+    "fast_64x64x16": dict(BM=64, BN=64, BK=16, exact=False),
+}
+
+
+class Gen64(Gen):
+    # ------------------------------------------------------------------ registers
+    def alloc(self):
+        c, p = self.c, self.p
+        S, V = p.salloc, p.valloc
+        self.ka0 = S(8, align=4)
+        self.ka1 = S(8, align=4)
+        self.s_lda, self.s_ldb, self.s_ldc, self.s_M, self.s_N, self.s_K = (self.ka1[i] for i in range(6))
+        self.s_alpha, self.s_beta = self.ka1[6], self.ka1[7]
+        self.srdA, self.srdB, self.srdC = S(4), S(4), S(4)
+        self.s_rem, self.s_cnt = S(), S()
+        self.s_bstep = S()
+        self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
+        self.s_t = [S() for _ in range(6)]
+        self.s_ldc4, self.s_ldc20 = S(), S()      # here: ldc * 8 bytes, 4 * ldc * 8 (the next accumulator row of a lane)
+        self.acc = [p.aalloc(8) for _ in range(c.NB)]
+        self.run = [p.aalloc(8) for _ in range(c.NB)] if c.exact else None
+        self.fa = [[V(4) for _ in range(c.TM)] for _ in range(2)]
+        self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
+        self.stA = [V(4) for _ in range(c.NPA)]
+        self.stB = [V(4) for _ in range(c.NPB)]
+        self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
+        self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
+        self.WA = [[V() for _ in range(3)] for _ in range(c.NPA)]   # [piece][stage]
+        self.WB = [[V() for _ in range(3)] for _ in range(c.NPB)]
+        self.v_oob = V()
+        self.s_tm = S(2)
+        self.s_ktail = S()
+        self.vVA = [V() for _ in range(c.NPA)]
+        self.vVB = [V() for _ in range(c.NPB)]
+        self.vC = [V() for _ in range(c.TN)]
+        if c.debug:
+            self.srdD = S(4)
+            self.s_dslot = S()
+            self.v_dbg = V()
+        self.ndump = 0
+        self.dump_names = []
+        self.vT = [V(16, align=2)]
+        blk = V(12, align=4)
+        self.vt = [blk[i] for i in range(10)]
+        self.vF, self.vFaddr, self.vFoff = blk.sub(4, 4), blk[10], blk[11]
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self):
+        c, p = self.c, self.p
+        e = p.emit
+        t, st = self.vt, self.s_t
+        RS = c.RS
+        p.note(f"f64 {c.name}: {c.BM}x{c.BN}x{c.BK} tile, 4 waves, wave tile {c.WTM}x{c.WTN}, "
+               f"{'laser-order (kc = 256 slices)' if c.exact else 'one accumulation chain'}")
+        e("s_load_dwordx8", self.ka0, s(0, 2), KA_A)
+        e("s_load_dwordx8", self.ka1, s(0, 2), KA_LDA)
+        e("s_lshl_b32", st[0], s(2), 2)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16")
+        if c.debug:
+            e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_and_b32", self.srdD[1], self.srdD[1], 0xffff)
+            e("s_mov_b32", self.srdD[2], 0x10000000)
+            e("s_mov_b32", self.srdD[3], 0x00020000)
+            e("v_lshlrev_b32", self.v_dbg, 2, v(0))
+            self.dump("tid", v(0))
+        tid = v(0)
+        lane, r16, q = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, tid)
+        e("v_lshrrev_b32", t[5], 6, tid)
+        e("s_nop", 1, comment="VALU write -> v_readfirstlane of the same VGPR needs wait states")
+        e("v_readfirstlane_b32", self.s_wave, t[5])
+        e("s_nop", 3)
+        e("v_and_b32", r16, 15, lane)
+        e("v_lshrrev_b32", q, 4, lane)
+        e("s_lshr_b32", st[2], self.s_wave, 1)
+        e("s_mul_i32", self.s_wm0, st[2], c.WTM)
+        e("s_and_b32", st[2], self.s_wave, 1)
+        e("s_mul_i32", self.s_wn0, st[2], c.WTN)
+        # fragment reads of group g: (wm0 + r16) * RS [+ BM * RS + (wn0 + r16) * RS for B] + (4g + q) * 16
+        e("v_add_u32", t[5], self.s_wm0, r16)
+        e("v_mul_u32_u24", t[6], RS, t[5])
+        e("v_add_u32", t[5], self.s_wn0, r16)
+        e("v_mul_u32_u24", t[7], RS, t[5])
+        e("v_add_u32", t[7], c.BM * RS, t[7])
+        for g in range(c.NG):
+            e("v_lshl_add_u32", t[5], q, 4, 64 * g)
+            for R, row in ((self.RA, t[6]), (self.RB, t[7])):
+                e("v_add_u32", R[g][0], t[5], row)
+                e("v_add_u32", R[g][1], c.STAGE, R[g][0])
+                e("v_add_u32", R[g][2], 2 * c.STAGE, R[g][0])
+        # K tail (K a multiple of 2): A pieces of the last K-tile beyond K read as 0
+        pc, xr = t[0], t[1]
+        e("v_and_b32", pc, 7, tid)
+        e("v_lshrrev_b32", xr, 3, tid)
+        e("s_and_b32", self.s_ktail, self.s_K, c.BK - 1)
+        e("v_lshlrev_b32", t[5], 1, pc)
+        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
+        e("v_mov_b32", self.v_oob, 0x80000000)
+        e("s_nop", 4)
+        # A pieces: piece column pc = tid % 8 (k0 = 2 pc), row xr = tid / 8 (+ 32 per piece)
+        #   LDS: row * RS + (4 * (pc >> 2) + 2 * (pc & 1)) * 16 + ((pc >> 1) & 1) * 8
+        e("v_lshrrev_b32", t[5], 2, pc)
+        e("v_lshlrev_b32", t[5], 6, t[5])                    # (pc >> 2) * 64
+        e("v_and_b32", t[6], 1, pc)
+        e("v_lshl_add_u32", t[5], t[6], 5, t[5])             # + (pc & 1) * 32
+        e("v_bfe_u32", t[6], pc, 1, 1)
+        e("v_lshl_add_u32", t[5], t[6], 3, t[5])             # + ((pc >> 1) & 1) * 8
+        e("v_mul_u32_u24", t[6], RS, xr)
+        e("v_add_u32", t[5], t[5], t[6])
+        for i in range(c.NPA):
+            e("v_add_u32", self.WA[i][2], 32 * RS * i, t[5])
+            e("v_add_u32", self.WA[i][0], c.STAGE, self.WA[i][2])
+            e("v_add_u32", self.WA[i][1], 2 * c.STAGE, self.WA[i][2])
+        e("s_lshl_b32", st[3], self.s_lda, 3, comment="lda * 8 bytes")
+        e("v_mul_lo_u32", t[7], xr, st[3])
+        e("v_lshl_add_u32", self.vVA[0], pc, 4, t[7])
+        e("s_lshl_b32", st[4], st[3], 5)                     # 32 rows
+        for i in range(1, c.NPA):
+            e("v_add_u32", self.vVA[i], st[4], self.vVA[i - 1])
+        # B pieces: x pair px = tid % (BN / 2), row k = tid / (BN / 2) (+ KS per piece, KS = 512 / BN)
+        #   LDS: BM * RS + 2 px * RS + (4 * (k >> 3) + (k & 3)) * 16 + ((k >> 2) & 1) * 8; k = k0 + KS * j with k0 < KS
+        HB = c.BN // 2
+        KS = 256 // HB
+        px, k0 = t[0], t[1]
+        e("v_and_b32", px, HB - 1, tid)
+        e("v_lshrrev_b32", k0, HB.bit_length() - 1, tid)
+        e("v_and_b32", t[5], 3, k0)
+        e("v_lshlrev_b32", t[5], 4, t[5])                    # (k0 & 3) * 16
+        e("v_bfe_u32", t[6], k0, 2, 1)
+        e("v_lshl_add_u32", t[5], t[6], 3, t[5])             # + ((k0 >> 2) & 1) * 8      (k0 < 8)
+        e("v_mul_u32_u24", t[6], 2 * RS, px)
+        e("v_add_u32", t[5], t[5], t[6])
+        e("v_add_u32", t[5], c.BM * RS, t[5])
+        for j in range(c.NPB):
+            kk = KS * j
+            cst = 64 * (kk >> 3) + 16 * (kk & 3) + 8 * ((kk >> 2) & 1)
+            assert (kk & 3) == 0 or KS >= 8, "k0 and KS * j must not share bits"
+            e("v_add_u32", self.WB[j][2], cst, t[5])
+            e("v_add_u32", self.WB[j][0], c.STAGE, self.WB[j][2])
+            e("v_add_u32", self.WB[j][1], 2 * c.STAGE, self.WB[j][2])
+        e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
+        e("v_mul_lo_u32", t[7], k0, st[5])
+        e("v_lshl_add_u32", self.vVB[0], px, 4, t[7])
+        e("s_mul_i32", st[4], st[5], KS)
+        for j in range(1, c.NPB):
+            e("v_add_u32", self.vVB[j], st[4], self.vVB[j - 1])
+        e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
+        # ---- tile coordinates, descriptors ----
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_and_b32", st[0], st[1], 0xffff)
+        e("s_lshr_b32", st[1], st[1], 16)
+        e("s_mul_i32", self.s_m0, st[0], c.BM)
+        e("s_mul_i32", self.s_n0, st[1], c.BN)
+        A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
+        # A panel: base = A + m0 * lda * 8; bytes = (min(M - m0, BM) - 1) * lda * 8 + K * 8
+        e("s_mul_hi_u32", st[2], self.s_m0, st[3])
+        e("s_mul_i32", st[0], self.s_m0, st[3])
+        e("s_add_u32", self.srdA[0], A_[0], st[0])
+        e("s_addc_u32", self.srdA[1], A_[1], st[2])
+        e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_M, self.s_m0)
+        e("s_min_u32", st[0], st[0], c.BM)
+        e("s_sub_u32", st[0], st[0], 1)
+        e("s_mul_i32", st[0], st[0], st[3])
+        e("s_lshl_b32", st[2], self.s_K, 3)
+        e("s_add_u32", self.srdA[2], st[0], st[2])
+        e("s_mov_b32", self.srdA[3], 0x00020000)
+        # B panel: base = B + n0 * 8; bytes = (K - 1) * ldb * 8 + (N - n0) * 8
+        e("s_lshl_b32", st[0], self.s_n0, 3)
+        e("s_add_u32", self.srdB[0], B_[0], st[0])
+        e("s_addc_u32", self.srdB[1], B_[1], 0)
+        e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_K, 1)
+        e("s_mul_i32", st[0], st[0], st[5])
+        e("s_sub_u32", st[2], self.s_N, self.s_n0)
+        e("s_lshl_b32", st[2], st[2], 3)
+        e("s_add_u32", self.srdB[2], st[0], st[2])
+        e("s_mov_b32", self.srdB[3], 0x00020000)
+        # C: the whole matrix, bytes = (M - 1) * ldc * 8 + N * 8
+        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 3)
+        e("s_mov_b32", self.srdC[0], C_[0])
+        e("s_and_b32", self.srdC[1], C_[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_M, 1)
+        e("s_mul_i32", st[0], st[0], self.s_ldc4)
+        e("s_lshl_b32", st[2], self.s_N, 3)
+        e("s_add_u32", self.srdC[2], st[0], st[2])
+        e("s_mov_b32", self.srdC[3], 0x00020000)
+        e("s_lshl_b32", self.s_ldc20, self.s_ldc4, 2)
+        e("s_add_u32", self.s_rem, self.s_K, c.BK - 1)
+        e("s_lshr_b32", self.s_rem, self.s_rem, (c.BK).bit_length() - 1)
+        # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
+        self.tail_mask_if(self.s_rem, 1)
+        self.issue_loads_all()
+        self.advance_srds()
+        if c.debug:
+            e("s_waitcnt", vmcnt=0)
+            self.vmq.clear()
+            for k_ in range(4):
+                self.dump(f"stA0[{k_}]", self.stA[0][k_])
+            for k_ in range(4):
+                self.dump(f"stB0[{k_}]", self.stB[0][k_])
+        for pi in range(c.NPA):
+            self.store_A_piece(pi, k=2)
+        for pj in range(c.NPB):
+            self.store_B_piece(pj, k=2)
+        if c.debug:
+            self.lg_wait(None)
+            e("s_barrier")
+            for k_ in range(0, 4):
+                self.dump_lds(f"lds[{k_ * 1024}+4tid]", k_ * 1024)
+            self.dump_lds("ldsB[0+4tid]", c.BM * RS)
+            e("s_barrier")
+        self.tail_mask_if(self.s_rem, 2)
+        self.issue_loads_all()
+        self.advance_srds()
+        self.tail_mask_if(self.s_rem, 3)
+        for b in range(c.NB):
+            for r in range(8):
+                e("v_accvgpr_write_b32", self.acc[b][r], 0)
+                if c.exact:
+                    e("v_accvgpr_write_b32", self.run[b][r], 0)
+        self.lg_wait(None)
+        e("s_barrier")
+        self.read_group(0, 0, 0)
+        if c.debug:
+            self.lg_wait(None)
+            for k_ in range(4):
+                self.dump(f"fa[0][0][{k_}]", self.fa[0][0][k_])
+            for k_ in range(4):
+                self.dump(f"fb[0][0][{k_}]", self.fb[0][0][k_])
+            for _ in range(c.TM + c.TN):
+                self.lg_issue(("R", 0))
+
+    def issue_loads_all(self):
+        for pi in range(self.c.NPA):
+            self.load_A_piece(pi)
+        for pj in range(self.c.NPB):
+            self.load_B_piece(pj)
+
+    def advance_srds(self, which=None):
+        e = self.p.emit
+        ops = []
+        for srd, step in ((self.srdA, self.c.BK * 8), (self.srdB, self.s_bstep)):
+            ops += [("s_add_u32", srd[0], srd[0], step), ("s_addc_u32", srd[1], srd[1], 0),
+                    ("s_sub_u32", srd[2], srd[2], step), ("s_cselect_b32", srd[2], 0, srd[2])]
+        if which is None:
+            for o in ops:
+                e(*o)
+        return ops
+
+    def apply_tail_mask(self):
+        for r in self.vVA:
+            self.p.emit("v_cndmask_b32", r, self.v_oob, r, self.s_tm)
+
+    # ------------------------------------------------------------------ LDS stores: one ds_write2_b64 per piece
+    def store_A_piece(self, pi, ops=None, k=0):
+        r = self.stA[pi]
+        out = [("vmwait", ("A", pi)),
+               ("ldsw", "ds_write2_b64", (self.WA[pi][k], r.sub(0, 2), r.sub(2, 2)), {"offset0": 0, "offset1": 2})]
+        if ops is None:
+            self.run_ops(out)
+        return out
+
+    def store_B_piece(self, pj, ops=None, k=0):
+        r = self.stB[pj]
+        out = [("vmwait", ("B", pj)),
+               ("ldsw", "ds_write2_b64", (self.WB[pj][k], r.sub(0, 2), r.sub(2, 2)), {"offset0": 0, "offset1": self.c.RS // 8})]
+        if ops is None:
+            self.run_ops(out)
+        return out
+
+    def staging_ops(self, wr_k):
+        c, stg = self.c, []
+        for pi in range(c.NPA):
+            stg += self.store_A_piece(pi, ops=[], k=wr_k)
+            stg.append(("loadA", pi))
+        for pj in range(c.NPB):
+            stg += self.store_B_piece(pj, ops=[], k=wr_k)
+            stg.append(("loadB", pj))
+        return stg
+
+    # ------------------------------------------------------------------ matrix instruction, slice fold
+    def emit_mfma(self, b, slot, i, n, u, srcc):
+        self.p.emit("v_mfma_f64_16x16x4_f64", self.acc[b], self.fa[slot][i].sub(2 * u, 2), self.fb[slot][n].sub(2 * u, 2), srcc)
+
+    def fold_before(self, b):
+        T = self.vT[0]
+        for r in range(8):
+            self.p.emit("v_accvgpr_read_b32", T[r], self.acc[b][r])
+
+    def fold_after(self, b):
+        e, T = self.p.emit, self.vT[0]
+        for d in range(4):
+            tt = T.sub(8 + 2 * (d % 2), 2)
+            e("v_accvgpr_read_b32", tt[0], self.run[b][2 * d])
+            e("v_accvgpr_read_b32", tt[1], self.run[b][2 * d + 1])
+            e("v_add_f64", tt, tt, T.sub(2 * d, 2))
+            e("v_accvgpr_write_b32", self.run[b][2 * d], tt[0])
+            e("v_accvgpr_write_b32", self.run[b][2 * d + 1], tt[1])
+
+    # ------------------------------------------------------------------ epilogue
+    def c_addr_setup(self):
+        """vC[n] = byte offset in C of D[q][r16] of block column n: row m0 + wm0 + q (+ 4 per accumulator element, + 16 per
+        block row), col n0 + wn0 + r16 + 16n"""
+        c, e, t, st = self.c, self.p.emit, self.vt, self.s_t
+        lane, r16, q = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, v(0))
+        e("v_and_b32", r16, 15, lane)
+        e("v_lshrrev_b32", q, 4, lane)
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("v_add_u32", t[3], st[0], q)
+        e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], r16)
+        e("v_lshl_add_u32", t[3], t[4], 3, t[3])
+        for n in range(c.TN):
+            e("v_add_u32", t[5], 16 * n, t[4])
+            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
+            e("v_add_u32", t[6], 128 * n, t[3])
+            e("v_mov_b32", t[7], 0x80000000)
+            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+
+    def load_beta_c(self):
+        pass
+
+    def epilogue(self):
+        """C = run + acc (alpha = 1, beta = 0: gemm_ukernel_generic.nim:53-76), predicated by the descriptor's bounds check"""
+        c, p = self.c, self.p
+        e, t = p.emit, self.vt
+        e("s_nop", 15)
+        e("s_nop", 7)
+        e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        self.vmq.clear()
+        self.lgq.clear()
+        if c.debug:
+            for k_ in range(4):
+                self.dump(f"acc[0][{k_}]", self.acc[0][k_])
+        self.c_addr_setup()
+        T = self.vT[0]
+        for i in range(c.TM):
+            for d in range(4):
+                for n in range(c.TN):
+                    b = i * c.TN + n
+                    tt, uu = T.sub(4 * (n % 2), 2), T.sub(4 * (n % 2) + 2, 2)
+                    e("v_accvgpr_read_b32", tt[0], self.acc[b][2 * d])
+                    e("v_accvgpr_read_b32", tt[1], self.acc[b][2 * d + 1])
+                    if c.exact:
+                        e("v_accvgpr_read_b32", uu[0], self.run[b][2 * d])
+                        e("v_accvgpr_read_b32", uu[1], self.run[b][2 * d + 1])
+                        e("v_add_f64", tt, uu, tt)
+                    e("buffer_store_dwordx2", tt, self.vC[n], self.srdC, 0, offen=True)
+                if not (i == c.TM - 1 and d == 3):
+                    for n in range(c.TN):
+                        e("v_add_u32", self.vC[n], self.s_ldc20, self.vC[n])
+        e("s_endpgm")
+
+
+def make(name, **over):
+    kw = dict(CONFIGS[name])
+    kw.update(over)
+    return Gen64(Cfg(name, dtype="f64", **kw))
+
+
+if __name__ == "__main__":
+    import argparse
+    import os
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for name in CONFIGS:
+        g = make(name)
+        g.build()
+        sym = "lh_f64_" + name
+        with open(os.path.join(args.out, sym + ".s"), "w") as f:
+            f.write(kernel_text(g, sym))
+        print(sym, len(g.p.ins), "instructions")

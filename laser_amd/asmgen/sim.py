@@ -503,6 +503,73 @@ class Workgroup:
                 w.mfma_wr[(D.kind, D.idx + r)] = w.state
             w.n_mfma += 1
             w.stats["mfma"] += 1
+        elif op == "v_mfma_f64_16x16x4_f64":
+            # D[i][j] += sum over k = 0..3 (ascending, fused) of A[i][k] * B[k][j]; lane l holds A[l % 16][l / 16], B[l / 16][l % 16],
+            # and D[l / 16 + 4 * d][l % 16] for d = 0..3 (two registers each).  The products and sums are done in float64
+            # WITHOUT an exact fused multiply-add model: the f64 tests use integer-valued operands, for which every product
+            # and partial sum is exact (fma == mul + add); the accumulation ORDER is validated on hardware.
+            cost = 16
+            D, SA, SB, SC = A
+            assert D.n == 8 and SA.n == 2 and SB.n == 2
+            if self.check:
+                for r_ in list(SA.regs()) + list(SB.regs()):
+                    if r_ in w.valu_wr_state and w.state - w.valu_wr_state[r_] < 2:
+                        raise SimError(f"wave {w.wid} pc {w.pc}: MFMA reads {r_} right after a VALU wrote it")
+
+            def rd64(R):
+                arr_ = w.v if R.kind == "v" else w.a
+                self._chk_pending(w, R.regs())
+                lo = arr_[R.idx].astype(np.uint64)
+                hi = arr_[R.idx + 1].astype(np.uint64)
+                return (lo | (hi << np.uint64(32))).view(np.float64)
+            av, bv = rd64(SA), rd64(SB)
+            lanes = np.arange(LANES)
+            Ct = np.zeros((16, 16), dtype=np.float64)
+            if isinstance(SC, Reg):
+                assert SC.n == 8
+                if self.check:
+                    for kk in SC.regs():
+                        if kk in w.mfma_wr and w.state - w.mfma_wr[kk] < 16 and not (SC.kind == D.kind and SC.idx == D.idx):
+                            raise SimError(f"wave {w.wid} pc {w.pc}: MFMA srcC overlaps a different in-flight MFMA result")
+                        if kk in w.valu_wr_state and w.state - w.valu_wr_state[kk] < 3:
+                            raise SimError(f"wave {w.wid} pc {w.pc}: MFMA srcC {SC} read {w.state - w.valu_wr_state[kk]} states after a VALU wrote it")
+                for d in range(4):
+                    Ct[(lanes >> 4) + 4 * d, lanes & 15] = rd64(SC.sub(2 * d, 2))
+            else:
+                assert int(SC) == 0
+            for kk in range(4):
+                arow = av[16 * kk:16 * kk + 16]
+                bcol = bv[16 * kk:16 * kk + 16]
+                with np.errstate(all="ignore"):
+                    Ct = arow[:, None] * bcol[None, :] + Ct
+            arr = w.v if D.kind == "v" else w.a
+            self._chk_waw(w, D.regs())
+            for d in range(4):
+                bits = Ct[(lanes >> 4) + 4 * d, lanes & 15].copy().view(np.uint64)
+                arr[D.idx + 2 * d] = (bits & np.uint64(0xffffffff)).astype(U32)
+                arr[D.idx + 2 * d + 1] = (bits >> np.uint64(32)).astype(U32)
+                w.mfma_wr[(D.kind, D.idx + 2 * d)] = w.state
+                w.mfma_wr[(D.kind, D.idx + 2 * d + 1)] = w.state
+            w.n_mfma += 1
+            w.stats["mfma"] += 1
+        elif op in ("v_add_f64", "v_mul_f64"):
+            assert A[0].n == 2
+
+            def rd64v(X):
+                if isinstance(X, Reg) and X.kind == "v":
+                    assert X.n == 2
+                    lo, hi = rv(w, X[0]).astype(np.uint64), rv(w, X[1]).astype(np.uint64)
+                    return (lo | (hi << np.uint64(32))).view(np.float64)
+                if isinstance(X, Reg) and X.kind == "s":
+                    assert X.n == 2
+                    return np.full(LANES, np.array([self.rd_s64(w, X)], dtype=np.uint64).view(np.float64)[0])
+                raise SimError(f"f64 operand {X}")
+            x, y = rd64v(A[1]), rd64v(A[2])
+            with np.errstate(all="ignore"):
+                r = (x + y) if op == "v_add_f64" else (x * y)
+            bits = r.view(np.uint64)
+            self.wr_v(w, A[0][0], (bits & np.uint64(0xffffffff)).astype(U32))
+            self.wr_v(w, A[0][1], (bits >> np.uint64(32)).astype(U32))
         # ------------------------------------------------------------ LDS
         elif op in ("ds_read_b128", "ds_read_b64", "ds_read_b32"):
             ndw = {"ds_read_b128": 4, "ds_read_b64": 2, "ds_read_b32": 1}[op]
@@ -538,6 +605,17 @@ class Workgroup:
             act = w.execmask()
             for d in range(ndw):
                 self.lds[wd[act] + d] = rv(w, A[1][d])[act]
+            w.lgkm.append(("ldsw", []))
+        elif op == "ds_write2_b64":
+            base = rv(w, A[0]).astype(np.int64)
+            act = w.execmask()
+            for which, data in ((0, A[1]), (1, A[2])):
+                assert data.n == 2
+                addr = base + 8 * int(M.get(f"offset{which}", 0))
+                wd = self._lds_access(w, addr, 2, True, GROUPS_16, 32)
+                for d in range(2):
+                    self.lds[wd[act] + d] = rv(w, data[d])[act]
+            w.stats["lds_ops"] -= 1
             w.lgkm.append(("ldsw", []))
         elif op == "ds_write2_b32":
             base = rv(w, A[0]).astype(np.int64)

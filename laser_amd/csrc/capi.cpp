@@ -347,13 +347,21 @@ hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s) {
     const hipError_t e = launch_gemm_small<float>(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
-  if (f32_cfg_now() < 0) {
+  // Up to ~150 tiles of 64x64 the slice-parallel form (kc slices as one batched launch + ordered combine) fills the chip
+  // better than any single launch; above that the hand-scheduled assembly kernels come first (their 64x64 tile covers the
+  // few-tile x long-K problems the slice-parallel form was built for: 1024^2 x 8192 = 256 tiles).
+  const bool few_tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64) <= 150;
+  g_last_f32_asm = 0;
+  if (f32_cfg_now() < 0 && few_tiles) {
     const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
-  g_last_f32_asm = 0;
-  if (f32_cfg_now() < 0) {  // large row-major-like products: the hand-scheduled assembly kernels (one wave per SIMD)
+  if (f32_cfg_now() < 0) {
     const hipError_t e = launch_gemm_f32_asm(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+    if (e != hipErrorNotSupported) return e;
+  }
+  if (f32_cfg_now() < 0 && !few_tiles) {
+    const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
   return launch_gemm_f32(a, f32_cfg_now(), g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
@@ -368,8 +376,18 @@ hipError_t run_gemm_core<double>(const GemmArgs<double> &a, hipStream_t s) {
   if (g_ctx.f64_mfma) {
     const hipError_t es = launch_gemm_small<double>(a, laser, 256, s);
     if (es != hipErrorNotSupported) return es;
-    const hipError_t e = gemm_slice_parallel<double>(a, 256, s);
-    if (e != hipErrorNotSupported) return e;
+    const bool few_tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64) <= 150;   // (same rule as float32)
+    g_last_f64_asm = 0;
+    if (few_tiles) {
+      const hipError_t e = gemm_slice_parallel<double>(a, 256, s);
+      if (e != hipErrorNotSupported) return e;
+    }
+    const hipError_t ea = launch_gemm_f64_asm(a, laser, s);   // the hand-scheduled assembly kernels (laser_amd/asmgen/f64_kernel.py)
+    if (ea != hipErrorNotSupported) return ea;
+    if (!few_tiles) {
+      const hipError_t e = gemm_slice_parallel<double>(a, 256, s);
+      if (e != hipErrorNotSupported) return e;
+    }
     return launch_gemm_f64(a, laser, s);
   }  // v_mfma_f64_16x16x4_f64: a k-ordered fma chain
   return launch_gemm_valu<double>(a, laser, s);
@@ -1246,6 +1264,7 @@ int laser_hip_set_option(const char *name, int value) {
   const std::string n(name);
   const bool on = value != 0;
   if (n == "f32_asm") g_f32_asm = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (n == "f64_asm") g_f64_asm = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "f64_mfma") g_ctx.f64_mfma = on;
   else if (n == "i32_mfma") g_ctx.i32_mfma = on;
   else if (n == "i64_mfma") g_ctx.i64_mfma = on;
@@ -1268,6 +1287,8 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   if (!name || !value) return fail(LASER_HIP_E_INVALID, "get_option: null argument");
   const std::string n(name);
   if (n == "f32_asm") *value = g_f32_asm;
+  else if (n == "f64_asm") *value = g_f64_asm;
+  else if (n == "last_f64_asm") *value = g_last_f64_asm;
   else if (n == "f64_mfma") *value = g_ctx.f64_mfma;
   else if (n == "i32_mfma") *value = g_ctx.i32_mfma;
   else if (n == "i64_mfma") *value = g_ctx.i64_mfma;

@@ -17,6 +17,8 @@
 
 namespace laser_hip {
 
+std::atomic<int> g_f64_asm{1};       // float64: same meaning as g_f32_asm
+std::atomic<int> g_last_f64_asm{0};  // diagnostics: 0 = compiler-scheduled kernel; 1 + index into kKernels otherwise
 std::atomic<int> g_f32_asm{1};       // 1 (default): eligible problems run on the hand-scheduled kernels
 std::atomic<int> g_last_f32_asm{0};  // diagnostics: 0 = compiler-scheduled kernel; 1 + index into kKernels otherwise
 
@@ -36,7 +38,8 @@ struct KernelInfo {
 // [10] / [11]: implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (laser-order / one chain)
 // [12..15]: 64x64 tiles, three workgroups per CU (laser-order / one chain, plain / B transposed): problems of few tiles
 // (1024^3 = 32 tiles of 256x128 for 256 CUs) and the tile quantisation of mid-size ones (3072^3 = 1.125 rounds of 256x128)
-constexpr int kNumKernels = 16;
+// [16..19]: float64 (v_mfma_f64_16x16x4_f64; laser_amd/asmgen/f64_kernel.py): 128x128x16 laser-order / one chain, 64x64x16 same
+constexpr int kNumKernels = 20;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0},
@@ -45,7 +48,9 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0},
     {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.9, 0.9, 15.0}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.9, 0.9, 15.0},
     {"lh_f32_exact_64x64x32", 64, 64, 32, 0.88, 0.78, 3.0},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.895, 0.80, 3.0},
-    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0}};
+    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0},
+    {"lh_f64_exact_128x128x16", 128, 128, 16, 0.92, 0.92, 8.0},       {"lh_f64_fast_128x128x16", 128, 128, 16, 0.93, 0.93, 8.0},
+    {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -58,8 +63,8 @@ DeviceModule g_mods[kMaxDev];
 std::mutex g_mods_mu;
 
 struct KernArgs {
-  const float *A, *B;
-  float *C;
+  const void *A, *B;   // float or double
+  void *C;
   const uint32_t *table;
   uint32_t lda, ldb, ldc, M, N, K;
   float alpha, beta;   // C = beta * C + alpha * A B (beta == 0: C is never read)
@@ -211,6 +216,73 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   return e;
 }
 
+
+// float64 twin of launch_gemm_f32_asm (kernels of laser_amd/asmgen/f64_kernel.py): row-major A, B, C, alpha = 1, beta = 0, K even.
+hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipStream_t s) {
+  if (!g_f64_asm) return hipErrorNotSupported;
+  if (a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if (a.alpha != 1.0 || a.beta != 0.0) return hipErrorNotSupported;
+  if (a.csA != 1 || a.csB != 1 || a.csC != 1) return hipErrorNotSupported;
+  if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
+  if (a.rsA < a.K || a.rsB < a.N || a.rsC < a.N || a.K < 2 || a.K % 2 != 0) return hipErrorNotSupported;   // 16-byte pieces = 2 k
+  if ((double)a.rsA * 8.0 * 128 >= 4.0e9 || (double)a.K * (double)a.rsB * 8.0 >= 4.0e9) return hipErrorNotSupported;
+  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 8.0 > 2147483648.0) return hipErrorNotSupported;
+  if (a.M > 0xffff * (int64_t)64 || a.N > 0xffff * (int64_t)64) return hipErrorNotSupported;
+  const bool exact = laser_order && a.K > 256;   // kc = 256 doubles (gemm_tiling.nim:310)
+  const int big = exact ? 16 : 17, tiny = exact ? 18 : 19;
+  int pick = -1;
+  double best = 1e300;
+  const double cu_flops_per_us = 78.6e6 / 256.0;
+  for (int k : {big, tiny}) {
+    const KernelInfo &ki_ = kKernels[k];
+    const int64_t t = ((a.M + ki_.bm - 1) / ki_.bm) * ((a.N + ki_.bn - 1) / ki_.bn);
+    if (g_f64_asm < 2 && t < (k == tiny ? 96 : 160)) continue;
+    const int64_t rounds = (t + 255) / 256;
+    const double tile_us = 2.0 * ki_.bm * ki_.bn * (double)a.K / cu_flops_per_us;
+    const double time = (double)rounds * tile_us / (rounds == 1 ? ki_.eff_alone : ki_.eff) + ki_.fixed_us;
+    if (time < 0.99 * best) best = time, pick = k;
+  }
+  if (pick < 0) return hipErrorNotSupported;
+  const KernelInfo &ki = kKernels[pick];
+  const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(g_mods_mu);
+  DeviceModule *m = nullptr;
+  e = get_module(dev, &m);
+  if (e != hipSuccess) return e;
+  const int group_m = 8;
+  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
+  auto it = m->tables.find(key);
+  if (it == m->tables.end()) {
+    auto *host = new std::vector<uint32_t>();
+    make_table(tiles_m, tiles_n, group_m, *host);
+    uint32_t *devp = nullptr;
+    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      if (devp) (void)hipFree(devp);
+      delete host;
+      return e;
+    }
+    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
+  }
+  KernArgs ka;
+  ka.A = a.A; ka.B = a.B; ka.C = a.C;
+  ka.table = it->second.first;
+  ka.lda = (uint32_t)a.rsA; ka.ldb = (uint32_t)a.rsB; ka.ldc = (uint32_t)a.rsC;
+  ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)a.K;
+  ka.alpha = 1.0f; ka.beta = 0.0f;
+  ka.dbg = nullptr;
+  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
+  ka.bsB_bytes = ka.bsC_bytes = 0;
+  size_t sz = sizeof(ka);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)(tiles_m * (int64_t)tiles_n), 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  if (e == hipSuccess) g_last_f64_asm = 1 + pick;
+  return e;
+}
 
 // Implicit-GEMM convolution (conv2d_im2col.nim:102-166 minus the materialised im2col matrix): output pixels [0, a.N) of every
 // image, a.N a multiple of the 128-pixel tile or the whole image.  GemmArgs as launch_conv_implicit_f32 builds them (A = the

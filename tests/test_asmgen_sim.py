@@ -68,6 +68,29 @@ def test_conv_kernels_bit_exact_in_the_interpreter(name, images, Cin, H, W, M, p
     assert C.run_conv_case(name, images, Cin, H, W, M, pad, n_cut=n_cut, verbose=False)
 
 
+# float64 kernels (f64_kernel.py): integer-valued operands (exact in f64: the interpreter's f64 MFMA is mul + add)
+F64_CASES = [
+    ("fast_64x64x16", 70, 90, 48, {}),
+    ("exact_64x64x16", 40, 30, 530, dict(lda=532)),                   # kc = 256 folds + K tail
+    ("fast_128x128x16", 33, 50, 22, dict(lda=24, ldb=52, ldc=54)),
+    ("exact_128x128x16", 130, 70, 290, {}),
+]
+
+
+@pytest.mark.parametrize("name,M,N,Kd,kw", F64_CASES, ids=[f"f64-{c[0]}-{c[1]}x{c[2]}x{c[3]}" for c in F64_CASES])
+def test_f64_kernels_exact_in_the_interpreter(name, M, N, Kd, kw):
+    assert C.run_case64(name, M, N, Kd, verbose=False, **kw)
+
+
+def test_f64_configs_generate():
+    from laser_amd.asmgen import f64_kernel as K64
+    for name in K64.CONFIGS:
+        g = K64.make(name)
+        g.build()
+        assert g.p._v <= 256 and g.p._a <= 256 and g.c.lds_alloc <= 160 * 1024
+        assert "v_mfma_f64_16x16x4_f64" in K64.kernel_text(g, "lh_test64")
+
+
 def test_interpreter_rejects_a_read_of_a_register_still_loading():
     """the checks are live: dropping the counted waits must be caught, not silently pass"""
     from laser_amd.asmgen.sim import SimError

@@ -678,6 +678,9 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
         for mode in (0, 1):
             la.set_float_mode(mode)
             try:
+                # (one-chain mode: the slice-parallel form sums kc slices -- a different, equally valid rounding -- so the
+                # comparison of the two kernel families keeps it out of the way)
+                la.set_option("slice_parallel", 0 if mode == 1 else 1)
                 la.set_f32_asm(2)
                 dC = wide.clone()
                 la.matmul(dA, dB, 1, 0, dC[:, :N])
@@ -687,7 +690,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 la.matmul(dA, dB, 1, 0, dC2[:, :N])
                 assert la.last_f32_asm() == 0
             finally:
-                la.set_f32_asm(1); la.set_float_mode(0)
+                la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1)
             # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128; 13..16: 64x64 tiles)
             want = (1, 3, 5, 7, 13, 15) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10, 14, 16)
             seen.add(used)
@@ -1160,3 +1163,51 @@ def test_conv_direct_small_channels_bit_exact(la, oracle):
         o = torch.zeros(oshape, device="cuda")
         la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, (1, 1), (1, 1), None)
         assert la.get_option("last_f32_config") != -3
+
+
+def test_f64_asm_kernels_bit_exact(la, oracle):
+    """The hand-scheduled float64 kernels (laser_amd/asmgen/f64_kernel.py; option f64_asm): same bits as the compiler-scheduled
+    f64 MFMA kernels (f64_asm = 0) in both accumulation modes and as the oracle in laser-order mode -- kc = 256 folds, a fold
+    tile as the last tile, K tails (K even), ragged M / N, padded leading dimensions; ineligible calls fall through."""
+    import torch
+    rng = np.random.default_rng(123)
+    shapes = [(960, 960, 960), (1024, 768, 256), (300, 260, 34), (2048, 2048, 530), (1000, 900, 1030), (2176, 2304, 272),
+              (128, 128, 16), (4096, 4096, 64), (1920, 1920, 514)]
+    seen = set()
+    for (M, N, K) in shapes:
+        A = rand(rng, (M, K + 6), np.float64)[:, :K]
+        B = rand(rng, (K, N + 10), np.float64)[:, :N]
+        dAb = torch.from_numpy(np.ascontiguousarray(A.base)).cuda(); dA = dAb[:, :K]
+        dBb = torch.from_numpy(np.ascontiguousarray(B.base)).cuda(); dB = dBb[:, :N]
+        wide = torch.full((M, N + 14), 7.0, device="cuda", dtype=torch.float64)
+        for mode in (0, 1):
+            la.set_float_mode(mode)
+            try:
+                la.set_option("slice_parallel", 0 if mode == 1 else 1)     # (see the float32 test)
+                la.set_option("f64_asm", 2)
+                dC = wide.clone()
+                la.matmul(dA, dB, 1, 0, dC[:, :N])
+                used = la.get_option("last_f64_asm")
+                la.set_option("f64_asm", 0)
+                dC2 = wide.clone()
+                la.matmul(dA, dB, 1, 0, dC2[:, :N])
+                assert la.get_option("last_f64_asm") == 0
+            finally:
+                la.set_option("f64_asm", 1); la.set_float_mode(0); la.set_option("slice_parallel", 1)
+            seen.add(used)
+            assert used in ((17, 19) if (mode == 0 and K > 256) else (18, 20)) or (used == 0 and M * N <= 512 * 512), (M, N, K, mode, used)
+            assert torch.equal(dC, dC2), (M, N, K, mode)
+            assert (dC[:, N:] == 7.0).all(), "wrote outside C"
+            if mode == 0:
+                assert np.array_equal(dC[:, :N].cpu().numpy(), oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B))), (M, N, K)
+    assert {17, 19} <= seen and (seen & {18, 20}), sorted(seen)
+    A = torch.from_numpy(rand(rng, (1024, 1023), np.float64)).cuda()
+    B = torch.from_numpy(rand(rng, (1023, 1024), np.float64)).cuda()
+    la.set_option("f64_asm", 2)
+    try:
+        la.matmul(A, B)
+        assert la.get_option("last_f64_asm") == 0                       # K odd
+        la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous(), 0.5, 0.0)
+        assert la.get_option("last_f64_asm") == 0                       # alpha != 1
+    finally:
+        la.set_option("f64_asm", 1)
