@@ -71,6 +71,7 @@ int laser_hip_f32_config_count(void);
  *                          least ~100 tiles of 64x64; 0 = never (the compiler-scheduled kernels); 2 = whenever eligible,
  *                          whatever the tile count (tests)
  *   "f64_asm"          [1] float64 twin of "f32_asm" (row-major operands, alpha == 1, beta == 0, K even; laser_amd/asmgen/f64_kernel.py)
+ *   "i32_asm"          [1] int32 limb GEMM with alpha == 1, beta == 0, K <= 8192: the hand-scheduled kernel (laser_amd/asmgen/i8_kernel.py)
  *   "f64_mfma" "i32_mfma" "i64_mfma"  [1] matrix-core kernels (f64 MFMA; int8-limb decomposition for the integers, the
  *                          reference's integer micro-kernels: gemm_ukernel_avx512.nim:40-74); 0 = the VALU kernels
  *   "conv_implicit"    [1] im2col fused into the GEMM's B loader; 0 = explicit im2col workspace + batched GEMM, the
@@ -87,7 +88,7 @@ int laser_hip_f32_config_count(void);
  *   "slice_parallel_min" / "slice_parallel_tiles"  tuning overrides of that rule (0 = built-in)
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
- *   "last_f32_asm" / "last_f64_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
+ *   "last_f32_asm" / "last_f64_asm" / "last_i32_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
  *   "last_split"       column where the last float GEMM / conv launch was cut (0 = one launch) */
 int laser_hip_set_option(const char *name, int value);
 int laser_hip_get_option(const char *name, int64_t *value);

@@ -185,3 +185,66 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
             bad = np.argwhere(full[:, :N] != want)
             print("  first mismatches:", bad[:8].tolist(), full[tuple(bad[0])] if len(bad) else None, want[tuple(bad[0])] if len(bad) else None, "count", len(bad))
     return ok
+
+
+def pack_limb_tiles(X):
+    """host model of the packing pass (limb_planes.h, tile-major form): int32 matrix X[x][k] -> for every 128-row tile and 32-k tile a
+    16-KiB block [plane p][k half h][row r][16 bytes] of balanced base-256 digits; rows / k zero-padded to multiples of 128 / 32"""
+    x, k = X.shape
+    xp, kp = (x + 127) // 128 * 128, (k + 31) // 32 * 32
+    P = np.zeros((xp, kp), dtype=np.uint32)
+    P[:x, :k] = X.astype(np.int64).astype(np.uint32)
+    d = ((P.astype(np.uint64) + 0x00808080) & 0xffffffff).astype(np.uint32) ^ np.uint32(0x00808080)
+    out = np.zeros((xp // 128, kp // 32, 4, 2, 128, 16), dtype=np.uint8)
+    for pl in range(4):
+        digit = ((d >> np.uint32(8 * pl)) & np.uint32(0xff)).astype(np.uint8)          # [xp][kp]
+        out[:, :, pl] = digit.reshape(xp // 128, 128, kp // 32, 2, 16).transpose(0, 2, 3, 1, 4)
+    return out.reshape(-1), xp, kp
+
+
+def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_range=True):
+    """int32 GEMM kernel (i8_kernel.py) through the interpreter: C = A B mod 2^32 with full-range int32 operands"""
+    from . import i8_kernel as KI
+    g = KI.make()
+    g.build()
+    c = g.c
+    rng = np.random.default_rng(seed)
+    lo, hi = (-2**31, 2**31) if full_range else (-100, 101)
+    A = rng.integers(lo, hi, (M, Kd), dtype=np.int64).astype(np.int32)
+    B = rng.integers(lo, hi, (Kd, N), dtype=np.int64).astype(np.int32)
+    ldc = ldc or N
+    Ap, Mp, Kp = pack_limb_tiles(A)
+    Bp, Np_, _ = pack_limb_tiles(B.T.copy())
+    KT = Kp // 32
+    Cflat = np.full((M - 1) * ldc + N, 0x7bad7bad, dtype=np.uint32)
+    tm, tn = Mp // 128, Np_ // 128
+    table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
+    mem = Memory()
+    a_, b_, c_, t_ = mem.alloc(Ap), mem.alloc(Bp), mem.alloc(Cflat), mem.alloc(table)
+    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, 1.0, 0.0, 0) + b"\0" * 56
+    ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    t0 = time.time()
+    stats = None
+    for wg in range(len(table)):
+        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc)
+        w.run(order=order)
+        stats = w.waves[0].stats
+    full = np.full(M * ldc, 0x7bad7bad, dtype=np.uint32)
+    full[:len(Cflat)] = mem.get(c_, np.uint32, (len(Cflat),))
+    full = full.reshape(M, ldc)
+    want = ((A.astype(np.int64).astype(object) @ B.astype(np.int64).astype(object)) % (1 << 32)).astype(np.uint64).astype(np.uint32) \
+        if M * N * Kd <= 200000 else None
+    if want is None:
+        acc = np.zeros((M, N), dtype=np.uint64)
+        Au, Bu = A.astype(np.int64).astype(np.uint64) & np.uint64(0xffffffff), B.astype(np.int64).astype(np.uint64) & np.uint64(0xffffffff)
+        for k in range(Kd):      # products mod 2^64 then mod 2^32: exact for the low 32 bits
+            acc = (acc + (Au[:, k:k + 1] * Bu[k:k + 1, :])) & np.uint64(0xffffffff)
+        want = acc.astype(np.uint32)
+    ok = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(full[:, N:][:-1] == 0x7bad7bad)))
+    if verbose:
+        print(f"i32 M={M} N={N} K={Kd} ldc={ldc}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, bank-conflict cycles "
+              f"{stats['bank_conflict_cycles']}, {stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
+        if not ok:
+            bad = np.argwhere(full[:, :N] != want)
+            print("  first mismatches:", bad[:8].tolist(), hex(int(full[tuple(bad[0])])), hex(int(want[tuple(bad[0])])), "count", len(bad))
+    return ok

@@ -1,0 +1,292 @@
+"""int32 GEMM on the int8 matrix cores, hand-scheduled: the limb-product kernel of gemm_i32_mfma.hip (arithmetic mod 2^32 over
+balanced base-256 digits: 10 products of int8 planes per 32x32x32 block, four accumulator groups, one per power of 256) on the
+generator's program structure -- one wave per SIMD, every accumulator in AGPRs (4 groups x 4 blocks x 16 = all 256), 3-stage
+LDS ring with one barrier per K-tile, counted waits.
+
+  v_mfma_i32_32x32x32_i8   32x32 block, 32 k per instruction; lane (lo = l % 32, hi = l / 32) feeds A[lo][16 hi .. 16 hi + 15] and
+                           B[16 hi .. 16 hi + 15][lo] (16 bytes = 4 registers each); D as the f32 32x32 instruction.
+
+Operands are the digit planes written by the packing pass (limb_planes.h, tile-major form): for every 128-row tile and 32-k
+tile one contiguous 16-KiB block [plane p][k half h][row r][16 bytes] -- so the global->LDS stage is a lane-linear copy (thread t
+moves bytes 16 t + 4096 i, fully coalesced, one ds_write_b128 each, no address arithmetic) and a fragment read is 32 consecutive
+16-byte chunks per half wave (conflict-free).  Workgroup tile 128x128, 2 x 2 waves of 64x64 (2 x 2 blocks); a K-tile is one
+k-step: 40 MFMAs.  The fragments of tile t+1 (16 ds_read_b128) are read after the barrier of tile t into the other of two
+register sets, so the loop is unrolled x6 (3 LDS stages x 2 fragment sets).  alpha = 1, beta = 0, K <= 8192 (no fold of the
+accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything else stays on the compiler-scheduled kernel."""
+from .core import v, a, s, VCC
+from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
+
+# the 10 limb products with p + q <= 3, ordered so that neighbours hit different accumulator groups
+PRODUCTS = ((3, 0), (0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (2, 0), (2, 1))
+BLOCK = 16384      # bytes of one operand's (row tile, k tile) block
+PLANE = 4096
+
+
+class GenI8(Gen):
+    def alloc(self):
+        c, p = self.c, self.p
+        S, V = p.salloc, p.valloc
+        self.ka0 = S(8, align=4)
+        self.ka1 = S(8, align=4)
+        self.s_lda, self.s_ldb, self.s_ldc, self.s_M, self.s_N, self.s_K = (self.ka1[i] for i in range(6))
+        self.srdA, self.srdB, self.srdC = S(4), S(4), S(4)
+        self.s_rem = S()
+        self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
+        self.s_t = [S() for _ in range(6)]
+        self.s_ldc4, self.s_ldc20 = S(), S()
+        self.acc = [[p.aalloc(16) for _ in range(4)] for _ in range(4)]        # [power of 256][block = 2 i + n]
+        self.fa = [[[V(4) for _ in range(4)] for _ in range(2)] for _ in range(2)]   # [set][i][plane]
+        self.fb = [[[V(4) for _ in range(4)] for _ in range(2)] for _ in range(2)]   # [set][n][plane]
+        self.stA = [V(4) for _ in range(4)]
+        self.stB = [V(4) for _ in range(4)]
+        self.vW = [V() for _ in range(3)]
+        self.RA = [V() for _ in range(3)]
+        self.RB = [V() for _ in range(3)]
+        self.vV = [V() for _ in range(4)]
+        self.vC = [V() for _ in range(2)]
+        if c.debug:
+            self.srdD = S(4)
+            self.s_dslot = S()
+            self.v_dbg = V()
+        self.ndump = 0
+        self.dump_names = []
+        blk = V(12, align=4)
+        self.vt = [blk[i] for i in range(10)]
+
+    # ------------------------------------------------------------------ prologue
+    def prologue(self):
+        c, p = self.c, self.p
+        e, t, st = p.emit, self.vt, self.s_t
+        p.note("int32 GEMM via int8 limb planes: 128x128 tile, 4 waves of 64x64, 40 MFMAs (10 limb products x 4 blocks) per 32-k tile")
+        e("s_load_dwordx8", self.ka0, s(0, 2), KA_A)
+        e("s_load_dwordx8", self.ka1, s(0, 2), KA_LDA)
+        e("s_lshl_b32", st[0], s(2), 2)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16")
+        if c.debug:
+            e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_and_b32", self.srdD[1], self.srdD[1], 0xffff)
+            e("s_mov_b32", self.srdD[2], 0x10000000)
+            e("s_mov_b32", self.srdD[3], 0x00020000)
+            e("v_lshlrev_b32", self.v_dbg, 2, v(0))
+        tid = v(0)
+        lane, lo, hi = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, tid)
+        e("v_lshrrev_b32", t[5], 6, tid)
+        e("s_nop", 1, comment="VALU write -> v_readfirstlane of the same VGPR needs wait states")
+        e("v_readfirstlane_b32", self.s_wave, t[5])
+        e("s_nop", 3)
+        e("v_and_b32", lo, 31, lane)
+        e("v_lshrrev_b32", hi, 5, lane)
+        e("s_lshr_b32", st[2], self.s_wave, 1)
+        e("s_lshl_b32", self.s_wm0, st[2], 6)
+        e("s_and_b32", st[2], self.s_wave, 1)
+        e("s_lshl_b32", self.s_wn0, st[2], 6)
+        # fragment reads: stage * STAGE [+ BLOCK for B] + plane * 4096 + hi * 2048 + (w?0 + 32 blk + lo) * 16
+        e("v_lshlrev_b32", t[5], 11, hi)
+        e("v_add_u32", t[6], self.s_wm0, lo)
+        e("v_lshl_add_u32", t[6], t[6], 4, t[5])
+        e("v_add_u32", t[7], self.s_wn0, lo)
+        e("v_lshl_add_u32", t[7], t[7], 4, t[5])
+        e("v_add_u32", t[7], BLOCK, t[7])
+        for k in range(3):
+            e("v_add_u32", self.RA[k], k * c.STAGE, t[6])
+            e("v_add_u32", self.RB[k], k * c.STAGE, t[7])
+        e("v_lshlrev_b32", t[5], 4, tid)
+        for k in range(3):
+            e("v_add_u32", self.vW[k], k * c.STAGE, t[5])
+        for i in range(4):
+            e("v_add_u32", self.vV[i], PLANE * i, t[5])
+        # ---- tile coordinates, descriptors ----
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_and_b32", st[0], st[1], 0xffff)
+        e("s_lshr_b32", st[1], st[1], 16)
+        e("s_lshl_b32", self.s_m0, st[0], 7)
+        e("s_lshl_b32", self.s_n0, st[1], 7)
+        A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
+        e("s_lshl_b32", st[3], self.s_lda, 14, comment="bytes of one row tile's panel: k tiles * 16 KiB")
+        for srd, base, pid in ((self.srdA, A_, st[0]), (self.srdB, B_, st[1])):
+            e("s_mul_hi_u32", st[4], pid, st[3])
+            e("s_mul_i32", st[2], pid, st[3])
+            e("s_add_u32", srd[0], base[0], st[2])
+            e("s_addc_u32", srd[1], base[1], st[4])
+            e("s_and_b32", srd[1], srd[1], 0xffff)
+            e("s_mov_b32", srd[2], st[3])
+            e("s_mov_b32", srd[3], 0x00020000)
+        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
+        e("s_mov_b32", self.srdC[0], C_[0])
+        e("s_and_b32", self.srdC[1], C_[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_M, 1)
+        e("s_mul_i32", st[0], st[0], self.s_ldc4)
+        e("s_lshl_b32", st[2], self.s_N, 2)
+        e("s_add_u32", self.srdC[2], st[0], st[2])
+        e("s_mov_b32", self.srdC[3], 0x00020000)
+        e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
+        e("s_mov_b32", self.s_rem, self.s_lda)
+        # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers, fragments of tile 0 -> set 0 ----
+        self.issue_loads_all()
+        self.advance_srds()
+        self.run_ops(self.store_ops(0))
+        self.issue_loads_all()
+        self.advance_srds()
+        for sgrp in range(4):
+            for b in range(4):
+                for r in range(16):
+                    e("v_accvgpr_write_b32", self.acc[sgrp][b][r], 0)
+        self.lg_wait(None)
+        e("s_barrier")
+        self.run_ops(self.read_ops(0, 0))
+
+    def issue_loads_all(self):
+        for i in range(4):
+            self.run_op(("loadA", i))
+        for i in range(4):
+            self.run_op(("loadB", i))
+
+    def load_A_piece(self, pi):
+        self.p.emit("buffer_load_dwordx4", self.stA[pi], self.vV[pi], self.srdA, 0, offen=True)
+        self.vm_issue(("A", pi))
+
+    def load_B_piece(self, pj):
+        self.p.emit("buffer_load_dwordx4", self.stB[pj], self.vV[pj], self.srdB, 0, offen=True)
+        self.vm_issue(("B", pj))
+
+    def advance_srds(self, which=None):
+        ops = []
+        for srd in (self.srdA, self.srdB):
+            ops += [("s_add_u32", srd[0], srd[0], BLOCK), ("s_addc_u32", srd[1], srd[1], 0),
+                    ("s_sub_u32", srd[2], srd[2], BLOCK), ("s_cselect_b32", srd[2], 0, srd[2])]
+        if which is None:
+            for o in ops:
+                self.p.emit(*o)
+        return ops
+
+    def store_ops(self, k):
+        """staging registers -> LDS stage k: a lane-linear copy"""
+        out = []
+        for i in range(4):
+            out += [("vmwait", ("A", i)), ("ldsw", "ds_write_b128", (self.vW[k], self.stA[i]), {"offset": PLANE * i})]
+        for i in range(4):
+            out += [("vmwait", ("B", i)), ("ldsw", "ds_write_b128", (self.vW[k], self.stB[i]), {"offset": BLOCK + PLANE * i})]
+        return out
+
+    def read_ops(self, k, fs):
+        """the 16 fragments of the tile in LDS stage k -> register set fs, in the order the MFMAs want them"""
+        ops = []
+        for i in range(2):
+            for n in range(2):
+                if n == 0:
+                    for pl in range(4):
+                        ops.append(("ldsr", "ds_read_b128", (self.fa[fs][i][pl], self.RA[k]), {"offset": PLANE * pl + 512 * i}, ("R", 0)))
+                if i == 0:
+                    for pl in range(4):
+                        ops.append(("ldsr", "ds_read_b128", (self.fb[fs][n][pl], self.RB[k]), {"offset": PLANE * pl + 512 * n}, ("R", 0)))
+        return ops
+
+    # ------------------------------------------------------------------ one K-tile: 40 MFMAs
+    def tile_body(self, stage, fs):
+        c, e = self.c, self.p.emit
+        NMF = 40
+        gaps = {m: [] for m in range(-1, NMF)}
+        nstage = (stage + 1) % 3
+        # LDS stores of tile t+1 (staging registers -> stage t+1), each followed by the load of tile t+2 into the drained registers
+        st = self.store_ops(nstage)
+        units = []
+        for i in range(8):
+            units.append([st[2 * i], st[2 * i + 1]])
+            units.append([("loadA", i) if i < 4 else ("loadB", i - 4)])
+        bar = c.bar_gap
+        for k, u in enumerate(units):
+            gaps[1 + k * (bar - 2) // len(units)] += u
+        gaps[bar].append(("barrier",))
+        for k, o in enumerate(self.advance_srds(which="ops")):
+            gaps[min(bar + 1 + k, NMF - 1)].append(("ins", o[0], o[1:], {}))
+        # the 16 fragment reads of tile t+1 follow the barrier one per gap: all issued >= 8 gaps before the tile ends, so the
+        # wait at the top of the next body finds them done
+        rd = self.read_ops(nstage, 1 - fs)
+        for k, o in enumerate(rd):
+            gaps[min(bar + 1 + k * c.r_step, NMF - 2)].append(o)
+        self.lg_wait({("R", 0)})
+        m = 0
+        for i in range(2):
+            for (pa, qb) in PRODUCTS:
+                for n in range(2):
+                    acc = self.acc[pa + qb][2 * i + n]
+                    e("v_mfma_i32_32x32x32_i8", acc, self.fa[fs][i][pa], self.fb[fs][n][qb], acc)
+                    for op in gaps[m]:
+                        self.run_op(op)
+                    m += 1
+        assert m == NMF
+
+    def main_loop(self):
+        c, p = self.c, self.p
+        e = p.emit
+        state0 = (list(self.vmq), list(self.lgq))
+        L_done = p.label("done")
+        B = [p.label(f"tile_{k}") for k in range(6)]
+        e("raw", ".p2align 6")
+        for k in range(6):
+            p.place(B[k])
+            self.tile_body(k % 3, k % 2)
+            assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs"
+            e("s_sub_u32", self.s_rem, self.s_rem, 1)
+            e("s_cmp_eq_u32", self.s_rem, 0)
+            e("s_cbranch_scc1", L_done)
+            if k == 5:
+                e("s_branch", B[0])
+        p.place(L_done)
+
+    # ------------------------------------------------------------------ epilogue: G0 + (G1 << 8) + (G2 << 16) + (G3 << 24)
+    def epilogue(self):
+        c, p = self.c, self.p
+        e, t = p.emit, self.vt
+        e("s_nop", 15)
+        e("s_nop", 7)
+        e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        self.vmq.clear()
+        self.lgq.clear()
+        self.c_addr_setup()
+        for i in range(2):
+            for q in range(4):
+                for rr in range(4):
+                    r = 4 * q + rr
+                    for n in range(2):
+                        b = 2 * i + n
+                        x = [t[4 * n + j] for j in range(4)]
+                        for j in range(4):
+                            e("v_accvgpr_read_b32", x[j], self.acc[j][b][r])
+                        e("v_lshl_add_u32", x[0], x[1], 8, x[0])
+                        e("v_lshl_add_u32", x[0], x[2], 16, x[0])
+                        e("v_lshl_add_u32", x[0], x[3], 24, x[0])
+                        e("buffer_store_dword", x[0], self.vC[n], self.srdC, 0, offen=True)
+                    self.c_step(i, q, rr)
+        e("s_endpgm")
+
+
+def make(name="i32_128x128x32", **over):
+    kw = dict(BM=128, BN=128, BK=32, exact=False, bar_gap=20)   # (scripts/i8_probe.py: 9 / 12 / 16 / 20 -> 275 / 279 / 283 / 286 Tint-op/s)
+    kw.update(over)
+    c = Cfg(name, **kw)
+    c.dtype = "i8"
+    c.TM = c.TN = 2
+    c.NB, c.NMF, c.STAGE, c.NPA, c.NPB = 4, 40, 2 * BLOCK, 4, 4
+    c.lds_bytes = c.lds_alloc = 3 * c.STAGE
+    return GenI8(c)
+
+
+CONFIGS = {"i32_128x128x32": {}}
+
+if __name__ == "__main__":
+    import argparse
+    import os
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    g = make()
+    g.build()
+    sym = "lh_i32_128x128x32"
+    with open(os.path.join(args.out, sym + ".s"), "w") as f:
+        f.write(kernel_text(g, sym))
+    print(sym, len(g.p.ins), "instructions")

@@ -503,6 +503,43 @@ class Workgroup:
                 w.mfma_wr[(D.kind, D.idx + r)] = w.state
             w.n_mfma += 1
             w.stats["mfma"] += 1
+        elif op == "v_mfma_i32_32x32x32_i8":
+            # D[i][j] += sum over 32 k of int8 A[i][k] * int8 B[k][j] (int32, wrapping); lane (lo, hi) holds A[lo][16 hi + 0..15]
+            # and B[16 hi + 0..15][lo] as 4 registers each; D as the f32 32x32 instruction
+            cost = 8
+            D, SA, SB, SC = A
+            assert D.n == 16 and SA.n == 4 and SB.n == 4 and isinstance(SC, Reg) and SC.n == 16
+            if self.check:
+                for kk in SC.regs():
+                    if kk in w.mfma_wr and w.state - w.mfma_wr[kk] < 8 and not (SC.kind == D.kind and SC.idx == D.idx):
+                        raise SimError(f"wave {w.wid} pc {w.pc}: MFMA srcC overlaps a different in-flight MFMA result")
+                    if kk in w.valu_wr_state and w.state - w.valu_wr_state[kk] < 3:
+                        raise SimError(f"wave {w.wid} pc {w.pc}: MFMA srcC {SC} read right after a VALU wrote it")
+
+            def bytes_of(R):
+                self._chk_pending(w, R.regs())
+                arr_ = w.v if R.kind == "v" else w.a
+                words = np.stack([arr_[R.idx + d] for d in range(4)], axis=1).astype(np.uint32)   # [lane][4]
+                return words.view(np.int8).reshape(LANES, 16).astype(np.int64)                     # [lane][16 k]
+            ab, bb = bytes_of(SA), bytes_of(SB)
+            lanes = np.arange(LANES)
+            Amat = np.zeros((32, 32), dtype=np.int64)
+            Bmat = np.zeros((32, 32), dtype=np.int64)
+            for l in range(LANES):
+                Amat[l & 31, 16 * (l >> 5):16 * (l >> 5) + 16] = ab[l]
+                Bmat[16 * (l >> 5):16 * (l >> 5) + 16, l & 31] = bb[l]
+            arr = w.a if SC.kind == "a" else w.v
+            Ct = np.zeros((32, 32), dtype=np.int64)
+            for r in range(16):
+                Ct[(r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5), lanes & 31] = arr[SC.idx + r].astype(np.int64)
+            Ct = (Ct + Amat @ Bmat) & 0xffffffff
+            arr = w.v if D.kind == "v" else w.a
+            self._chk_waw(w, D.regs())
+            for r in range(16):
+                arr[D.idx + r] = Ct[(r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5), lanes & 31].astype(U32)
+                w.mfma_wr[(D.kind, D.idx + r)] = w.state
+            w.n_mfma += 1
+            w.stats["mfma"] += 1
         elif op == "v_mfma_f64_16x16x4_f64":
             # D[i][j] += sum over k = 0..3 (ascending, fused) of A[i][k] * B[k][j]; lane l holds A[l % 16][l / 16], B[l / 16][l % 16],
             # and D[l / 16 + 4 * d][l % 16] for d = 0..3 (two registers each).  The products and sums are done in float64

@@ -405,7 +405,9 @@ hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
     void *ws = nullptr;
     hipError_t e = hipMallocAsync(&ws, gemm_i32_mfma_workspace_bytes(a.M, a.N, a.K), s);
     if (e != hipSuccess) return e;
-    e = launch_gemm_i32_mfma(a, ws, s);
+    g_last_i32_asm = 0;
+    e = launch_gemm_i32_asm(a, ws, s);      // the hand-scheduled kernel (laser_amd/asmgen/i8_kernel.py) when eligible
+    if (e == hipErrorNotSupported) e = launch_gemm_i32_mfma(a, ws, s);
     hipError_t e2 = hipFreeAsync(ws, s);
     return e != hipSuccess ? e : e2;
   }
@@ -1265,6 +1267,7 @@ int laser_hip_set_option(const char *name, int value) {
   const bool on = value != 0;
   if (n == "f32_asm") g_f32_asm = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "f64_asm") g_f64_asm = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (n == "i32_asm") g_i32_asm = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "f64_mfma") g_ctx.f64_mfma = on;
   else if (n == "i32_mfma") g_ctx.i32_mfma = on;
   else if (n == "i64_mfma") g_ctx.i64_mfma = on;
@@ -1289,6 +1292,8 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   if (n == "f32_asm") *value = g_f32_asm;
   else if (n == "f64_asm") *value = g_f64_asm;
   else if (n == "last_f64_asm") *value = g_last_f64_asm;
+  else if (n == "i32_asm") *value = g_i32_asm;
+  else if (n == "last_i32_asm") *value = g_last_i32_asm;
   else if (n == "f64_mfma") *value = g_ctx.f64_mfma;
   else if (n == "i32_mfma") *value = g_ctx.i32_mfma;
   else if (n == "i64_mfma") *value = g_ctx.i64_mfma;

@@ -13,10 +13,13 @@
 #include <vector>
 
 #include "common.h"
+#include "limb_planes.h"
 #include "f32_asm_blob.h"  // generated: lh_f32_asm_hsaco[], lh_f32_asm_hsaco_len
 
 namespace laser_hip {
 
+std::atomic<int> g_i32_asm{1};       // int32 limb GEMM: the hand-scheduled kernel when eligible (0 = the compiler-scheduled one)
+std::atomic<int> g_last_i32_asm{0};
 std::atomic<int> g_f64_asm{1};       // float64: same meaning as g_f32_asm
 std::atomic<int> g_last_f64_asm{0};  // diagnostics: 0 = compiler-scheduled kernel; 1 + index into kKernels otherwise
 std::atomic<int> g_f32_asm{1};       // 1 (default): eligible problems run on the hand-scheduled kernels
@@ -39,7 +42,8 @@ struct KernelInfo {
 // [12..15]: 64x64 tiles, three workgroups per CU (laser-order / one chain, plain / B transposed): problems of few tiles
 // (1024^3 = 32 tiles of 256x128 for 256 CUs) and the tile quantisation of mid-size ones (3072^3 = 1.125 rounds of 256x128)
 // [16..19]: float64 (v_mfma_f64_16x16x4_f64; laser_amd/asmgen/f64_kernel.py): 128x128x16 laser-order / one chain, 64x64x16 same
-constexpr int kNumKernels = 20;
+// [20]: int32 via int8 limb planes (laser_amd/asmgen/i8_kernel.py)
+constexpr int kNumKernels = 21;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0},
@@ -50,7 +54,8 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_64x64x32", 64, 64, 32, 0.88, 0.78, 3.0},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.895, 0.80, 3.0},
     {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0},
     {"lh_f64_exact_128x128x16", 128, 128, 16, 0.92, 0.92, 8.0},       {"lh_f64_fast_128x128x16", 128, 128, 16, 0.93, 0.93, 8.0},
-    {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0}};
+    {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0},
+    {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -216,6 +221,62 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   return e;
 }
 
+
+// int32 GEMM mod 2^32 on the int8 matrix cores (gemm_i32_mfma.hip's arithmetic; kernel of laser_amd/asmgen/i8_kernel.py): the
+// packing pass writes tile-major digit planes into `ws` (>= 4 * (rup(M,128) + rup(N,128)) * rup(K,32) bytes), then one launch.
+// alpha = 1, beta = 0, unit column stride on C, K <= 8192 (the accumulator groups are never folded).
+hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t s) {
+  if (!g_i32_asm) return hipErrorNotSupported;
+  if (a.batch != 1 || a.alpha != 1 || a.beta != 0 || a.csC != 1 || a.rsC < a.N) return hipErrorNotSupported;
+  if (a.M < 1 || a.N < 1 || a.K < 1 || a.K > 8192) return hipErrorNotSupported;
+  const int64_t Mpad = (a.M + 127) / 128 * 128, Npad = (a.N + 127) / 128 * 128, Kpad = (a.K + 31) / 32 * 32;
+  const int64_t tiles = (Mpad / 128) * (Npad / 128);
+  if (g_i32_asm < 2 && tiles < 128) return hipErrorNotSupported;      // few tiles: the 8-wave compiler kernel's two workgroups per CU
+  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0 || Mpad > 0xffff * 128ll || Npad > 0xffff * 128ll)
+    return hipErrorNotSupported;
+  int8_t *Ap = (int8_t *)ws, *Bp = Ap + 4 * Mpad * Kpad;
+  hipError_t e = launch_limb_planes<int32_t>(Ap, a.A, a.M, a.K, a.rsA, a.csA, Mpad, Kpad, s, 1);
+  if (e != hipSuccess) return e;
+  e = launch_limb_planes<int32_t>(Bp, a.B, a.N, a.K, a.csB, a.rsB, Npad, Kpad, s, 1);
+  if (e != hipSuccess) return e;
+  int dev = 0;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(g_mods_mu);
+  DeviceModule *m = nullptr;
+  e = get_module(dev, &m);
+  if (e != hipSuccess) return e;
+  const int tiles_m = (int)(Mpad / 128), tiles_n = (int)(Npad / 128), group_m = 8;
+  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
+  auto it = m->tables.find(key);
+  if (it == m->tables.end()) {
+    auto *host = new std::vector<uint32_t>();
+    make_table(tiles_m, tiles_n, group_m, *host);
+    uint32_t *devp = nullptr;
+    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      if (devp) (void)hipFree(devp);
+      delete host;
+      return e;
+    }
+    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
+  }
+  KernArgs ka;
+  ka.A = Ap; ka.B = Bp; ka.C = a.C;
+  ka.table = it->second.first;
+  ka.lda = (uint32_t)(Kpad / 32); ka.ldb = 0; ka.ldc = (uint32_t)a.rsC;
+  ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)Kpad;
+  ka.alpha = 1.0f; ka.beta = 0.0f;
+  ka.dbg = nullptr;
+  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
+  ka.bsB_bytes = ka.bsC_bytes = 0;
+  size_t sz = sizeof(ka);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(m->fn[20], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  if (e == hipSuccess) g_last_i32_asm = 21;
+  return e;
+}
 
 // float64 twin of launch_gemm_f32_asm (kernels of laser_amd/asmgen/f64_kernel.py): row-major A, B, C, alpha = 1, beta = 0, K even.
 hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipStream_t s) {

@@ -39,7 +39,7 @@ struct LimbDigits<int64_t> {
 template <typename T>
 __global__ void __launch_bounds__(LP_THREADS) limb_planes_tiled_kernel(int8_t *__restrict__ planes, const T *__restrict__ src, int64_t X,
                                                                       int64_t K, int64_t sx, int64_t sk, int64_t Xpad, int64_t Kpad,
-                                                                      int x_fast, int tiles_k) {
+                                                                      int x_fast, int tiles_k, int tile_major) {
   constexpr int NW = (int)sizeof(T) / 4;  // 32-bit words per element = groups of four planes
   // [x][k] tile, rows padded by 4 elements (16 / 32 bytes): the phase-2 reads of 8 lanes walk one row, the next row starts
   // 16+ bytes further round the banks
@@ -79,21 +79,28 @@ __global__ void __launch_bounds__(LP_THREADS) limb_planes_tiled_kernel(int8_t *_
   }
   typedef __attribute__((ext_vector_type(4))) int lp_i32x4;
   const int64_t plane = Xpad * Kpad;
+  // tile_major (the hand-scheduled int32 kernel, laser_amd/asmgen/i8_kernel.py; Xpad % 128 == 0, Kpad % 32 == 0): for every
+  // 128-row tile and 32-k tile one contiguous block [plane][k half][row][16 bytes] -- the global -> LDS stage of the GEMM is then a
+  // lane-linear copy and a fragment read is 32 consecutive chunks
+  const int64_t tbase = ((x >> 7) * (Kpad >> 5) + (kq >> 1)) * (int64_t)(4 * NW * 4096) + (kq & 1) * 2048 + (x & 127) * 16;
 #pragma unroll
   for (int p = 0; p < 4 * NW; p++) {
     const lp_i32x4 q = {(int)out[p][0], (int)out[p][1], (int)out[p][2], (int)out[p][3]};
-    *reinterpret_cast<lp_i32x4 *>(planes + p * plane + x * Kpad + kq * 16) = q;
+    if (tile_major)
+      *reinterpret_cast<lp_i32x4 *>(planes + tbase + p * 4096) = q;
+    else
+      *reinterpret_cast<lp_i32x4 *>(planes + p * plane + x * Kpad + kq * 16) = q;
   }
 }
 
 template <typename T>
 inline hipError_t launch_limb_planes(int8_t *dst, const T *src, int64_t X, int64_t K, int64_t sx, int64_t sk, int64_t Xpad, int64_t Kpad,
-                                     hipStream_t s) {
+                                     hipStream_t s, int tile_major = 0) {
   const int64_t tiles_x = (Xpad + LP_TX - 1) / LP_TX, tiles_k = (Kpad + LP_TK - 1) / LP_TK;
   if (tiles_x * tiles_k > 0x7fffffffll) return hipErrorInvalidValue;
   const int x_fast = (sx < 0 ? -sx : sx) < (sk < 0 ? -sk : sk);
   hipLaunchKernelGGL(limb_planes_tiled_kernel<T>, dim3((unsigned)(tiles_x * tiles_k)), dim3(LP_THREADS), 0, s, dst, src, X, K, sx, sk, Xpad,
-                     Kpad, x_fast, (int)tiles_k);
+                     Kpad, x_fast, (int)tiles_k, tile_major);
   return hipGetLastError();
 }
 

@@ -91,6 +91,13 @@ def test_f64_configs_generate():
         assert "v_mfma_f64_16x16x4_f64" in K64.kernel_text(g, "lh_test64")
 
 
+@pytest.mark.parametrize("M,N,Kd,ldc", [(128, 128, 224, None), (70, 200, 100, 204), (130, 129, 33, None)])
+def test_i32_limb_kernel_exact_in_the_interpreter(M, N, Kd, ldc):
+    """int32 GEMM mod 2^32 on int8 digit planes (i8_kernel.py), full-range operands, against exact integer arithmetic; the host
+    model of the packing pass (check.pack_limb_tiles) is what limb_planes.h implements on the device"""
+    assert C.run_case_i32(M, N, Kd, ldc=ldc, verbose=False)
+
+
 def test_interpreter_rejects_a_read_of_a_register_still_loading():
     """the checks are live: dropping the counted waits must be caught, not silently pass"""
     from laser_amd.asmgen.sim import SimError

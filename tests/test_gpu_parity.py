@@ -1211,3 +1211,53 @@ def test_f64_asm_kernels_bit_exact(la, oracle):
         assert la.get_option("last_f64_asm") == 0                       # alpha != 1
     finally:
         la.set_option("f64_asm", 1)
+
+
+def test_i32_asm_kernel_bit_exact(la, oracle):
+    """The hand-scheduled int32 limb kernel (laser_amd/asmgen/i8_kernel.py; option i32_asm): == the compiler-scheduled limb kernel
+    (i32_asm = 0) == the oracle, full-range operands (wrap-around mod 2^32), ragged M / N / K, strided and transposed operand views,
+    a padded C; K > 8192, alpha / beta and a strided C fall through to the compiler-scheduled kernel."""
+    import torch
+    rng = np.random.default_rng(91)
+    info = np.iinfo(np.int32)
+    for (M, N, K) in [(128, 128, 256), (130, 257, 100), (1000, 900, 1030), (2048, 2048, 512), (513, 129, 8192), (300, 200, 40)]:
+        A = rng.integers(info.min, info.max, (M, K), dtype=np.int32)
+        B = rng.integers(info.min, info.max, (K, N), dtype=np.int32)
+        want = oracle.matmul(A, B)
+        for dA, dB in ((torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()),
+                       (torch.from_numpy(np.asfortranarray(A)).cuda(), torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t())):
+            outs = {}
+            for asm in (2, 0):
+                la.set_option("i32_asm", asm)
+                try:
+                    wide = torch.full((M, N + 9), 77, dtype=torch.int32, device="cuda")
+                    la.matmul(dA, dB, 1, 0, wide[:, :N])
+                    assert (la.get_option("last_i32_asm") != 0) == (asm == 2), (M, N, K, asm)
+                    outs[asm] = wide
+                finally:
+                    la.set_option("i32_asm", 1)
+            assert torch.equal(outs[2], outs[0]), (M, N, K)
+            assert (outs[2][:, N:] == 77).all(), "wrote outside C"
+            assert np.array_equal(outs[2][:, :N].cpu().numpy(), want), (M, N, K)
+    # extreme digits
+    for val in (info.min, info.max, -1, 0x7f7f7f7f, -0x7f7f7f80, 0x00808080, 128, -129):
+        A = np.full((128, 160), val, dtype=np.int32)
+        B = rng.integers(info.min, info.max, (160, 128), dtype=np.int32)
+        la.set_option("i32_asm", 2)
+        try:
+            got = la.matmul(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda())
+            assert la.get_option("last_i32_asm") != 0
+        finally:
+            la.set_option("i32_asm", 1)
+        assert np.array_equal(got.cpu().numpy(), oracle.matmul(A, B)), val
+    # not this kernel's class
+    A = torch.from_numpy(rng.integers(info.min, info.max, (256, 8200), dtype=np.int32)).cuda()
+    B = torch.from_numpy(rng.integers(info.min, info.max, (8200, 256), dtype=np.int32)).cuda()
+    la.set_option("i32_asm", 2)
+    try:
+        la.matmul(A, B)
+        assert la.get_option("last_i32_asm") == 0          # K > 8192
+        la.matmul(A[:, :512].contiguous(), B[:512].contiguous(), 3, 0)
+        assert la.get_option("last_i32_asm") == 0          # alpha != 1
+    finally:
+        la.set_option("i32_asm", 1)
