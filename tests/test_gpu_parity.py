@@ -1261,3 +1261,64 @@ def test_i32_asm_kernel_bit_exact(la, oracle):
         assert la.get_option("last_i32_asm") == 0          # alpha != 1
     finally:
         la.set_option("i32_asm", 1)
+
+
+def test_asm_kernels_fuzz_strides_offsets(la, oracle):
+    """Randomised operand geometry on the hand-scheduled kernels (f32 plain / transposed B with alpha, beta; f64; int32): leading
+    dimensions of any parity, base pointers at any element offset (element alignment only), ragged M / N, K tails -- against the
+    compiler-scheduled kernels (bit-identical, nothing outside the M x N view of C touched) and, in laser-order mode, the oracle."""
+    import torch
+    rng = np.random.default_rng(2024)
+
+    def host_buf(rows, ld, off, dtype):
+        n = rows * ld + off + 8
+        if dtype == np.int32:
+            return rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+        return rng.uniform(-1, 1, n).astype(dtype)
+
+    def views(host, rows, cols, ld, off):
+        dev = torch.from_numpy(host).cuda()
+        return dev, dev[off:off + rows * ld].view(rows, ld)[:, :cols], host[off:off + rows * ld].reshape(rows, ld)[:, :cols]
+
+    for case in range(36):
+        kind = ("f32", "f32nt", "f64", "i32")[case % 4]
+        M, N = int(rng.integers(300, 1500)), int(rng.integers(300, 1500))
+        K = int(rng.integers(1, 300)) * (4 if kind.startswith("f32") else 2 if kind == "f64" else 1)
+        if kind == "i32":
+            K = max(K, 32)         # (smaller int32 problems go to the VALU kernel)
+        dt = {"f32": np.float32, "f32nt": np.float32, "f64": np.float64, "i32": np.int32}[kind]
+        lda, offa = K + int(rng.integers(0, 9)), int(rng.integers(0, 7))
+        _, dA, hA = views(host_buf(M, lda, offa, dt), M, K, lda, offa)
+        if kind == "f32nt":
+            ldb, offb = K + int(rng.integers(0, 9)), int(rng.integers(0, 7))
+            _, dBt, hBt = views(host_buf(N, ldb, offb, dt), N, K, ldb, offb)
+            dB, hB = dBt.t(), hBt.T
+        else:
+            ldb, offb = N + int(rng.integers(0, 9)), int(rng.integers(0, 7))
+            _, dB, hB = views(host_buf(K, ldb, offb, dt), K, N, ldb, offb)
+        ldc, offc = N + int(rng.integers(0, 9)), int(rng.integers(0, 7))
+        hC0 = host_buf(M, ldc, offc, dt)
+        al, be = ((1, 0), (0.5, 0), (1, 1), (-1.5, 0.75))[int(rng.integers(0, 4))] if kind.startswith("f32") else (1, 0)
+        opt = {"f32": "f32_asm", "f32nt": "f32_asm", "f64": "f64_asm", "i32": "i32_asm"}[kind]
+        for mode in ((0, 1) if kind != "i32" else (0,)):
+            outs = {}
+            for asm in (2, 0):
+                la.set_float_mode(mode)
+                la.set_option(opt, asm)
+                la.set_option("slice_parallel", 0)      # (few-tile shapes would take the slice-parallel form before either kernel family)
+                try:
+                    buf, dC, _ = views(hC0.copy(), M, N, ldc, offc)
+                    la.matmul(dA, dB, al, be, dC)
+                    outs[asm] = (buf, la.get_option("last_" + opt))
+                finally:
+                    la.set_option(opt, 1); la.set_option("slice_parallel", 1); la.set_float_mode(0)
+            assert outs[2][1] != 0 and outs[0][1] == 0, (kind, M, N, K, outs[2][1], outs[0][1])
+            assert torch.equal(outs[2][0], outs[0][0]), (kind, M, N, K, mode, al, be)      # whole buffer: the view AND its surroundings
+            got = outs[2][0].cpu().numpy()
+            inside = np.zeros(got.shape, dtype=bool)
+            inside[offc:offc + M * ldc].reshape(M, ldc)[:, :N] = True
+            assert np.array_equal(got[~inside], hC0[~inside]), (kind, M, N, K, "wrote outside C")
+            if mode == 0:
+                c0 = hC0[offc:offc + M * ldc].reshape(M, ldc)[:, :N].copy()
+                want = oracle.matmul(np.ascontiguousarray(hA), np.ascontiguousarray(hB), al, be, c0)
+                assert np.array_equal(got[offc:offc + M * ldc].reshape(M, ldc)[:, :N], want), (kind, M, N, K, al, be)
