@@ -66,7 +66,7 @@ int laser_hip_f32_config_count(void);
  * laser_hip_set_option(name, value); unknown names are LASER_HIP_E_INVALID.  Every switch leaves results bit-identical
  * (it selects between implementations of the same arithmetic); defaults in brackets.
  *   "f32_asm"          [1] float32 gemm_strided with unit column strides on A and C, B row-major or passed transposed, any
- *                          alpha / beta, K a multiple of 4 -- and 3x3 / stride-1 convolutions with any zero padding: the
+ *                          alpha / beta, any K -- and 3x3 / stride-1 convolutions with any zero padding: the
  *                          hand-scheduled assembly kernels (accumulators in AGPRs; laser_amd/asmgen/) when the problem has at
  *                          least ~100 tiles of 64x64; 0 = never (the compiler-scheduled kernels); 2 = whenever eligible,
  *                          whatever the tile count (tests)

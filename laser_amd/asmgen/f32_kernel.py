@@ -157,6 +157,7 @@ class Gen:
         self.v_oob = V()            # 0x80000000: a buffer offset the bounds check always rejects (reads as 0)
         self.s_tm = S(2)            # lanes whose 16-byte piece of a k-contiguous operand is real data in the LAST K-tile
         self.s_ktail = S()
+        self.s_em = [S(2) for _ in range(4)]   # K % 4 != 0: lanes whose element j of their piece is real data in the last K-tile
         self.vVA = [V() for _ in range(c.NPA)]
         self.vVB = [V() for _ in range(c.NPB)] if not c.conv else []
         self.vC = [V() for _ in range(c.TN)]
@@ -321,6 +322,11 @@ class Gen:
         e("s_and_b32", self.s_ktail, self.s_K, c.BK - 1)
         e("v_lshlrev_b32", t[5], 2, kq)
         e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
+        # K % 4 != 0: the piece that straddles K is loaded whole (its tail belongs to the next row, or reads 0 past the panel) and
+        # its elements beyond K are zeroed in the staging registers before they are stored (mask_last_pieces)
+        for j in range(4):
+            e("v_add_u32", t[6], j, t[5])
+            e("v_cmp_gt_u32", self.s_em[j], self.s_ktail, t[6])
         e("v_mov_b32", self.v_oob, 0x80000000)
         e("s_nop", 4)
 
@@ -500,6 +506,7 @@ class Gen:
             self.dump("RB0", self.RB[0][0])
         self.tail_mask_if(self.s_rem, 1)        # a single K-tile: tile 0 is the last one
         self.issue_loads_all()
+        self.mask_last_pieces_if(self.s_rem, 1)
         self.advance_srds()
         if c.debug:
             e("s_waitcnt", vmcnt=0)
@@ -535,6 +542,7 @@ class Gen:
             e("s_barrier")
         self.tail_mask_if(self.s_rem, 2)
         self.issue_loads_all()
+        self.mask_last_pieces_if(self.s_rem, 2)
         self.advance_srds()
         self.tail_mask_if(self.s_rem, 3)        # the first loop body loads tile 2
         # accumulators start at +0
@@ -782,6 +790,24 @@ class Gen:
         regs = list(self.vVA) + (list(self.vVB) if (self.c.b_kcontig and not self.c.conv) else [])
         for r in regs:
             e("v_cndmask_b32", r, self.v_oob, r, self.s_tm)
+
+    def mask_last_pieces_if(self, sreg, value):
+        """K % 4 != 0 and `sreg` == value: the staging registers hold the last K-tile (requested one step earlier): wait for it and
+        zero the elements beyond K.  ~NPA * 4 v_cndmask once per workgroup; the counted waits that follow are then satisfied early."""
+        c, e = self.c, self.p.emit
+        if c.conv:
+            return
+        skip = self.p.label("nok4")
+        e("s_and_b32", self.s_t[0], self.s_K, 3)
+        e("s_cmp_eq_u32", self.s_t[0], 0)
+        e("s_cbranch_scc1", skip)
+        e("s_cmp_lg_u32", sreg, value)
+        e("s_cbranch_scc1", skip)
+        e("s_waitcnt", vmcnt=0)
+        for r in list(self.stA) + (list(self.stB) if c.b_kcontig else []):
+            for j in range(4):
+                e("v_cndmask_b32", r[j], 0, r[j], self.s_em[j])
+        self.p.place(skip)
 
     def tail_mask_if(self, sreg, value):
         """apply_tail_mask when K has a tail and `sreg` == value (uniform branch around ~12 VALU instructions, once per workgroup)"""
@@ -1095,6 +1121,7 @@ class Gen:
                 e("s_cmp_eq_u32", self.s_rem, 0)
                 e("s_cbranch_scc1", L_done)
                 self.tail_mask_if(self.s_rem, 3)    # the next body loads the last K-tile
+                self.mask_last_pieces_if(self.s_rem, 2)   # the next body stores it (K % 4 != 0: zero what lies beyond K)
                 if c.exact:
                     e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
                     e("s_cmp_eq_u32", self.s_cnt, 0)

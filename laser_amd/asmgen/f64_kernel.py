@@ -275,6 +275,9 @@ class Gen64(Gen):
                 e(*o)
         return ops
 
+    def mask_last_pieces_if(self, sreg, value):
+        pass      # (K is even: the 16-byte pieces of 2 doubles are all-or-nothing)
+
     def apply_tail_mask(self):
         for r in self.vVA:
             self.p.emit("v_cndmask_b32", r, self.v_oob, r, self.s_tm)

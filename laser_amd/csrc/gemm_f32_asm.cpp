@@ -129,8 +129,8 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (!nt && a.csB != 1) return hipErrorNotSupported;
   const int64_t ldb = nt ? a.csB : a.rsB;
   if (a.rsA < a.K || ldb < (nt ? a.K : a.N) || a.rsC < a.N) return hipErrorNotSupported;
-  // a ragged last K-tile is zero-filled piece-wise (16 bytes = 4 k): K must be a multiple of 4
-  if (a.K < 4 || a.K % 4 != 0) return hipErrorNotSupported;
+  // (a ragged last K-tile is zero-filled piece-wise -- 16 bytes = 4 k -- and, when K % 4 != 0, element-wise in the staging registers)
+  if (a.K < 1) return hipErrorNotSupported;
   // laser-order results need the kc = 512 slices only when K > 512; one chain otherwise (the laser-order kernels are
   // plain single-chain kernels then: their fold tile is never reached)
   const bool exact = laser_order && a.K > 512;

@@ -37,6 +37,14 @@ GEMM_CASES = [
 ]
 
 
+# K not a multiple of 4: the piece that straddles K is zeroed element-wise in the staging registers (row padding is NaN here)
+GEMM_CASES += [
+    ("exact_256x128x32", 70, 90, 1030, dict(lda=1033, ldb=93, ldc=95)),
+    ("fast_64x64x32_nt", 70, 90, 99, dict(lda=102, ldb=104)),
+    ("exact_128x128x16_nt", 40, 50, 1031, dict(lda=1034, ldb=1036)),
+    ("fast_256x256x16", 33, 270, 17, dict(lda=20)),
+    ("exact_64x64x32", 70, 90, 6, dict(lda=9)),
+]
 # C = beta * C0 + alpha * A B: the running sum starts as beta * C0, every slice is scaled before it is added
 GEMM_CASES += [
     ("exact_256x128x32", 70, 90, 1060, dict(alpha=0.75, beta=-1.5, ldc=100)),

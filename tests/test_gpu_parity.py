@@ -731,7 +731,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
     B = torch.from_numpy(rand(rng, (1024, 2048), np.float32)).cuda()
     la.matmul(A, B, 2.0, 0, cn)
     assert la.last_f32_asm() != 0 and not torch.isnan(cn).any()
-    # not this kernel's class: a strided C, K not a multiple of 4 -> the compiler-scheduled kernels, same results as ever
+    # not this kernel's class: a strided C -> the compiler-scheduled kernels, same results as ever
     M, N, K = 2048, 2048, 1024
     try:
         la.set_f32_asm(2)
@@ -739,8 +739,11 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
         assert la.last_f32_asm() == 0
         ref = la.matmul(A, B)
         assert la.last_f32_asm() in (1, 3, 13)
-        odd = la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous())      # K not a multiple of 4: the compiler-scheduled kernels
-        assert la.last_f32_asm() == 0
+        odd = la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous())      # K not a multiple of 4: element-wise tail mask
+        assert la.last_f32_asm() != 0
+        la.set_f32_asm(0)
+        assert torch.equal(odd, la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous()))
+        la.set_f32_asm(2)
     finally:
         la.set_f32_asm(1)
     assert torch.equal(w[:, ::2], ref) and (w[:, 1::2] == 9.0).all()
@@ -1283,7 +1286,7 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
     for case in range(36):
         kind = ("f32", "f32nt", "f64", "i32")[case % 4]
         M, N = int(rng.integers(300, 1500)), int(rng.integers(300, 1500))
-        K = int(rng.integers(1, 300)) * (4 if kind.startswith("f32") else 2 if kind == "f64" else 1)
+        K = int(rng.integers(1, 1200)) if kind.startswith("f32") else int(rng.integers(1, 300)) * (2 if kind == "f64" else 1)
         if kind == "i32":
             K = max(K, 32)         # (smaller int32 problems go to the VALU kernel)
         dt = {"f32": np.float32, "f32nt": np.float32, "f64": np.float64, "i32": np.int32}[kind]
