@@ -39,7 +39,9 @@ ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerat
     ["lh_f32_exact_256x128x32", "lh_f32_fast_256x256x16", "lh_f32_exact_128x128x16", "lh_f32_fast_128x128x16",
      "lh_f32_exact_256x128x32_nt", "lh_f32_fast_256x256x16_nt", "lh_f32_exact_128x128x16_nt", "lh_f32_fast_128x128x16_nt",
      "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt", "lh_f32_conv3x3_exact_256x128x32", "lh_f32_conv3x3_fast_256x128x32",
-     "lh_f32_exact_64x64x32", "lh_f32_fast_64x64x32", "lh_f32_exact_64x64x32_nt", "lh_f32_fast_64x64x32_nt"])}
+     "lh_f32_exact_64x64x32", "lh_f32_fast_64x64x32", "lh_f32_exact_64x64x32_nt", "lh_f32_fast_64x64x32_nt",
+     "lh_f64_exact_128x128x16", "lh_f64_fast_128x128x16", "lh_f64_exact_64x64x16", "lh_f64_fast_64x64x16", "lh_i32_128x128x32",
+     "lh_f32_conv3x3_exact_128x128x32", "lh_f32_conv3x3_fast_128x128x32", "lh_f32_conv3x3_exact_64x128x32", "lh_f32_conv3x3_fast_64x128x32"])}
 SIZE = 8192
 
 

@@ -88,6 +88,11 @@ CONFIGS = {
     # implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (benchmarks/convolution/conv2d_im2col.nim)
     "conv3x3_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True),
     "conv3x3_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True),
+    # fewer output channels: 128 / 64 rows of the same pixel tile (the B side -- the gather -- is unchanged)
+    "conv3x3_exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True, conv=True),
+    "conv3x3_fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False, conv=True),
+    "conv3x3_exact_64x128x32": dict(BM=64, BN=128, BK=32, exact=True, conv=True),
+    "conv3x3_fast_64x128x32": dict(BM=64, BN=128, BK=32, exact=False, conv=True),
     "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
 }

@@ -43,19 +43,22 @@ struct KernelInfo {
 // (1024^3 = 32 tiles of 256x128 for 256 CUs) and the tile quantisation of mid-size ones (3072^3 = 1.125 rounds of 256x128)
 // [16..19]: float64 (v_mfma_f64_16x16x4_f64; laser_amd/asmgen/f64_kernel.py): 128x128x16 laser-order / one chain, 64x64x16 same
 // [20]: int32 via int8 limb planes (laser_amd/asmgen/i8_kernel.py)
-constexpr int kNumKernels = 21;
+// [21..24]: convolution with fewer output channels: 128x128x32 (laser-order / one chain), 64x128x32 (same)
+constexpr int kNumKernels = 25;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0},
     {"lh_f32_exact_256x128x32_nt", 256, 128, 32, 0.965, 0.965, 10.0}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16, 0.98, 0.98, 12.0},
     {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.91, 6.0},    {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.92, 6.0},
     {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0},
-    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.9, 0.9, 15.0}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.9, 0.9, 15.0},
+    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0},
     {"lh_f32_exact_64x64x32", 64, 64, 32, 0.88, 0.78, 3.0},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.895, 0.80, 3.0},
     {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0},
     {"lh_f64_exact_128x128x16", 128, 128, 16, 0.92, 0.92, 8.0},       {"lh_f64_fast_128x128x16", 128, 128, 16, 0.93, 0.93, 8.0},
     {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0},
-    {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0}};
+    {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0},
+    {"lh_f32_conv3x3_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0}, {"lh_f32_conv3x3_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0},
+    {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -358,11 +361,19 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (oW != a.cW + 2 * a.cpW - 2 || oW <= 0 || oH <= 0 || (oW & 1)) return hipErrorNotSupported;  // a lane's pixel pair stays in one output row
   if (a.csA != 1 || a.rsA != a.K || a.csC != 1 || a.rsC != npix || a.K % 36 != 0 || a.K < 36) return hipErrorNotSupported;  // K = Cin * 9, a multiple of 4
   if (a.N > npix || (a.N != npix && a.N % 128 != 0)) return hipErrorNotSupported;
-  if (a.batch < 1 || a.batch > 65535 || a.M > 0xffff * 256ll) return hipErrorNotSupported;
+  if (a.batch < 1 || a.batch > 65535 || a.M > 0xffff * 64ll) return hipErrorNotSupported;
   const int64_t Cin = a.K / 9;
   if ((double)Cin * a.cH * a.cW * 4.0 >= 2.0e9 || (double)a.M * npix * 4.0 >= 2.0e9 || (double)a.rsA * 4.0 * 256 >= 4.0e9) return hipErrorNotSupported;
   const bool exact = laser_order && a.K > 512;
-  const int pick = 10 + (exact || a.K <= 512 ? 0 : 1);
+  // rows of the tile by the number of output channels: the smallest padded row count, weighted by what each tile reaches
+  int pick = -1;
+  double best_cost = 1e300;
+  for (int base : {10, 21, 23}) {
+    const KernelInfo &kc = kKernels[base];
+    const double cost = (double)((a.M + kc.bm - 1) / kc.bm * kc.bm) / kc.eff;
+    if (cost < 0.99 * best_cost) best_cost = cost, pick = base;
+  }
+  pick += (exact || a.K <= 512 ? 0 : 1);
   const KernelInfo &ki = kKernels[pick];
   const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;

@@ -11,7 +11,7 @@ def t(fn, inner=4, reps=5):
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / inner)
     return sorted(ts)[len(ts) // 2]
 g = torch.Generator(device="cuda").manual_seed(1)
-for (ishape, kshape, pad) in [((32, 128, 56, 56), (256, 128, 3, 3), (1, 1)), ((32, 128, 56, 56), (256, 128, 3, 3), (0, 0)), ((64, 64, 56, 56), (64, 64, 3, 3), (1, 1)), ((16, 256, 28, 28), (512, 256, 3, 3), (1, 1)), ((16, 3, 224, 224), (20, 3, 3, 3), (0, 0))]:
+for (ishape, kshape, pad) in [((32, 128, 56, 56), (256, 128, 3, 3), (1, 1)), ((32, 128, 56, 56), (256, 128, 3, 3), (0, 0)), ((64, 64, 56, 56), (64, 64, 3, 3), (1, 1)), ((16, 256, 28, 28), (512, 256, 3, 3), (1, 1)), ((32, 128, 28, 28), (128, 128, 3, 3), (1, 1)), ((16, 3, 224, 224), (20, 3, 3, 3), (0, 0))]:
     st = (1, 1)
     x = torch.rand(ishape, generator=g, device="cuda"); w = torch.rand(kshape, generator=g, device="cuda")
     oshape = laser_amd.conv2d_out_shape(ishape, kshape, pad, st); o = torch.zeros(oshape, device="cuda")
