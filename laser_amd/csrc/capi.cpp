@@ -1221,6 +1221,7 @@ int laser_hip_finalize(void) {
     D.zc_sz = 0;
     D.device = -1;
   }
+  asm_kernels_release();
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_ctx.device >= 0) (void)hipSetDevice(g_ctx.device);
   for (auto &kv : g_panels) (void)hipFree(kv.second.ptr);

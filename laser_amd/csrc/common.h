@@ -123,6 +123,7 @@ hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipSt
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &args, bool laser_order, hipStream_t s);
 // implicit-GEMM convolution on the same framework (3x3 kernel, stride 1, padding 0 or 1): output pixels [0, args.N) of every image
 hipError_t launch_conv_f32_asm(const GemmArgs<float> &args, bool laser_order, hipStream_t s);
+void asm_kernels_release();   // unload the assembly kernels' code objects (laser_hip_finalize)
 hipError_t launch_gemm_f64_asm(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
 extern std::atomic<int> g_f64_asm, g_last_f64_asm;
 hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);

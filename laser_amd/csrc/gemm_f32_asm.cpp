@@ -121,6 +121,27 @@ hipError_t get_module(int dev, DeviceModule **out) {
 
 }  // namespace
 
+// laser_hip_finalize: unload the code objects and free the tile tables of every device that used them
+void asm_kernels_release() {
+  std::lock_guard<std::mutex> lk(g_mods_mu);
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  for (int d = 0; d < kMaxDev; d++) {
+    DeviceModule &m = g_mods[d];
+    if (!m.mod) continue;
+    (void)hipSetDevice(d);
+    (void)hipDeviceSynchronize();   // (a table's host copy backs an async upload; kernels may still read the device copy)
+    for (auto &kv : m.tables) {
+      (void)hipFree(kv.second.first);
+      delete kv.second.second;
+    }
+    m.tables.clear();
+    (void)hipModuleUnload(m.mod);
+    m.mod = nullptr;
+  }
+  if (cur >= 0) (void)hipSetDevice(cur);
+}
+
 // hipErrorNotSupported: not this kernel's class of problem -- the caller takes the compiler-scheduled kernels
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;

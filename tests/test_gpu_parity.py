@@ -1325,3 +1325,20 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
                 c0 = hC0[offc:offc + M * ldc].reshape(M, ldc)[:, :N].copy()
                 want = oracle.matmul(np.ascontiguousarray(hA), np.ascontiguousarray(hB), al, be, c0)
                 assert np.array_equal(got[offc:offc + M * ldc].reshape(M, ldc)[:, :N], want), (kind, M, N, K, al, be)
+
+
+def test_finalize_unloads_and_the_library_comes_back(la, oracle):
+    """laser_hip_finalize releases the per-device state -- scratch, streams, the assembly kernels' code objects and tile tables --
+    and the next call re-initialises lazily: same results before and after."""
+    import torch
+    rng = np.random.default_rng(5150)
+    A = torch.from_numpy(rand(rng, (1024, 516), np.float32)).cuda()
+    B = torch.from_numpy(rand(rng, (516, 1024), np.float32)).cuda()
+    first = la.matmul(A, B)
+    assert la.last_f32_asm() != 0
+    torch.cuda.synchronize()
+    assert la._lib.lib().laser_hip_finalize() == 0
+    second = la.matmul(A, B)
+    assert la.last_f32_asm() != 0
+    assert torch.equal(first, second)
+    assert np.array_equal(second.cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
