@@ -26,7 +26,9 @@ def reference(A, B, kc, alpha=1.0, beta=0.0, C0=None):
     return run
 
 
-def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0):
+def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
+             batch=1):
+    """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart"""
     g = K.make(name, **(over or {}))
     g.build()
     c = g.c
@@ -35,56 +37,66 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     nt = c.b_kcontig
     if nt:
         ldb = ldb if (ldb and ldb >= Kd) else Kd
-    Af = np.zeros((M, lda), dtype=np.float32)
-    Bf = np.zeros((N, ldb), dtype=np.float32) if nt else np.zeros((Kd, ldb), dtype=np.float32)
-    Bm = rng.integers(-3, 4, (Kd, N)).astype(np.float32) if integer else rng.uniform(-0.1, 0.1, (Kd, N)).astype(np.float32)
-    Af[:, :Kd] = rng.integers(-3, 4, (M, Kd)) if integer else rng.uniform(-0.1, 0.1, (M, Kd))
-    Af[:, Kd:] = np.nan       # whatever lies between the rows must never reach the result
-    if nt:
-        Bf[:, :Kd] = Bm.T
-        Bf[:, Kd:] = np.nan
-    else:
-        Bf[:, :N] = Bm
-        Bf[:, N:] = np.nan
-    # trim the allocations to exactly the operand spans: any read past them is a simulator error
-    Aflat = Af.reshape(-1)[:(M - 1) * lda + Kd].copy()
-    Bflat = Bf.reshape(-1)[:(N - 1) * ldb + Kd].copy() if nt else Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
-    Cflat = np.full((M - 1) * ldc + N, np.nan, dtype=np.float32)
-    C0 = None
-    if beta != 0:           # C0 in the valid columns, NaN in the row padding
-        C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
-        full0 = np.full(M * ldc, np.nan, dtype=np.float32).reshape(M, ldc)
-        full0[:, :N] = C0
-        Cflat = full0.reshape(-1)[:(M - 1) * ldc + N].copy()
+    LA = (M - 1) * lda + Kd
+    LB = (N - 1) * ldb + Kd if nt else (Kd - 1) * ldb + N
+    LC = (M - 1) * ldc + N
+    Aall, Ball, Call = np.zeros(batch * LA, np.float32), np.zeros(batch * LB, np.float32), np.full(batch * LC, np.nan, dtype=np.float32)
+    As, Bs, C0s = [], [], []
+    for b in range(batch):
+        Af = np.zeros((M, lda), dtype=np.float32)
+        Bf = np.zeros((N, ldb), dtype=np.float32) if nt else np.zeros((Kd, ldb), dtype=np.float32)
+        Bm = rng.integers(-3, 4, (Kd, N)).astype(np.float32) if integer else rng.uniform(-0.1, 0.1, (Kd, N)).astype(np.float32)
+        Af[:, :Kd] = rng.integers(-3, 4, (M, Kd)) if integer else rng.uniform(-0.1, 0.1, (M, Kd))
+        Af[:, Kd:] = np.nan       # whatever lies between the rows must never reach the result
+        if nt:
+            Bf[:, :Kd] = Bm.T
+            Bf[:, Kd:] = np.nan
+        else:
+            Bf[:, :N] = Bm
+            Bf[:, N:] = np.nan
+        # trim the allocations to exactly the operand spans: any read past them is a simulator error
+        Aall[b * LA:(b + 1) * LA] = Af.reshape(-1)[:LA]
+        Ball[b * LB:(b + 1) * LB] = Bf.reshape(-1)[:LB]
+        C0 = None
+        if beta != 0:           # C0 in the valid columns, NaN in the row padding
+            C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+            full0 = np.full(M * ldc, np.nan, dtype=np.float32).reshape(M, ldc)
+            full0[:, :N] = C0
+            Call[b * LC:(b + 1) * LC] = full0.reshape(-1)[:LC]
+        As.append(Af[:, :Kd].copy()); Bs.append(Bm); C0s.append(C0)
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
-    a_, b_, c_, t_ = mem.alloc(Aflat), mem.alloc(Bflat), mem.alloc(Cflat), mem.alloc(table)
+    a_, b_, c_, t_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call), mem.alloc(table)
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
+    ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4)
+    assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
-    for wg in range(len(table)):
-        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc)
-        w.run(order=order)
-        stats = w.waves[0].stats
-    Cout = np.full((M, ldc), np.nan, dtype=np.float32).reshape(-1)
-    Cout[:len(Cflat)] = mem.get(c_, np.float32, (len(Cflat),))
-    Cout = Cout.reshape(M, ldc)[:, :N]
-    want = reference(Af[:, :Kd], Bm, 512 if c.exact else 0, alpha, beta, C0)
-    ok = np.array_equal(Cout, want)
-    pad_ok = True
-    if ldc > N:
+    for bi in range(batch):
+        for wg in range(len(table)):
+            w = Workgroup(g.p, mem, ka_, wg_id=(wg, bi), lds_bytes=c.lds_alloc)
+            w.run(order=order)
+            stats = w.waves[0].stats
+    got = mem.get(c_, np.float32, (batch * LC,))
+    ok = pad_ok = True
+    for b in range(batch):
         full = np.full(M * ldc, np.nan, dtype=np.float32)
-        full[:len(Cflat)] = mem.get(c_, np.float32, (len(Cflat),))
-        pad_ok = bool(np.all(np.isnan(full.reshape(M, ldc)[:, N:][:-1])))
+        full[:LC] = got[b * LC:(b + 1) * LC]
+        Cout = full.reshape(M, ldc)[:, :N]
+        want = reference(As[b], Bs[b], 512 if c.exact else 0, alpha, beta, C0s[b])
+        ok &= bool(np.array_equal(Cout, want))
+        if ldc > N:
+            pad_ok &= bool(np.all(np.isnan(full.reshape(M, ldc)[:, N:][:-1])))
+        if not ok and verbose:
+            bad = np.argwhere(Cout != want)
+            print("  batch", b, "first mismatches:", bad[:8].tolist(), Cout[tuple(bad[0])], want[tuple(bad[0])], "count", len(bad))
+            break
     if verbose:
-        print(f"{name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc} int={integer}: "
+        print(f"{name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc} int={integer} batch={batch}: "
               f"{'OK' if ok and pad_ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, bank-conflict cycles {stats['bank_conflict_cycles']}, "
               f"{stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
-        if not ok:
-            bad = np.argwhere(Cout != want)
-            print("  first mismatches:", bad[:8].tolist(), Cout[tuple(bad[0])], want[tuple(bad[0])], "count", len(bad))
     return ok and pad_ok
 
 

@@ -101,6 +101,7 @@ CONFIGS = {
 KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 8, 16, 24, 32, 36, 40, 44, 48, 52, 64
 # convolution kernels only: H W oW pH pW Cin Npix magic(oW) | shift(oW) - bsB(bytes, u64) | bsC(bytes, u64)
 KA_CONV0, KA_CONV1, KA_CONV2 = 72, 104, 120
+KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's share the convolution kernels' slots at 112 / 120
 KERNARG_SIZE = 128
 
 
@@ -163,6 +164,8 @@ class Gen:
         self.s_tm = S(2)            # lanes whose 16-byte piece of a k-contiguous operand is real data in the LAST K-tile
         self.s_ktail = S()
         self.s_em = [S(2) for _ in range(4)]   # K % 4 != 0: lanes whose element j of their piece is real data in the last K-tile
+        if not c.conv:
+            self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
         self.vVA = [V() for _ in range(c.NPA)]
         self.vVB = [V() for _ in range(c.NPB)] if not c.conv else []
         self.vC = [V() for _ in range(c.TN)]
@@ -269,6 +272,19 @@ class Gen:
         e("s_lshl_b32", st[0], s(2), 2)
         e("s_waitcnt", lgkmcnt=0)
         e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16 (XCD-aware raster made by the host)")
+        if not c.conv:
+            # batched problems (gemm_strided_batched; the kc slices of the slice-parallel form): workgroup id y = batch index,
+            # operand b at base + b * batch stride (bytes, 64-bit; 0 for plain launches)
+            e("s_load_dwordx2", self.s_bsA, s(0, 2), KA_BSA)
+            e("s_load_dwordx4", self.s_bsBC, s(0, 2), KA_CONV1 + 8)
+            e("s_waitcnt", lgkmcnt=0)
+            for ptr, bs in ((self.ka0.sub(0, 2), self.s_bsA), (self.ka0.sub(2, 2), self.s_bsBC.sub(0, 2)), (self.ka0.sub(4, 2), self.s_bsBC.sub(2, 2))):
+                e("s_mul_i32", st[2], s(3), bs[0])
+                e("s_mul_hi_u32", st[3], s(3), bs[0])
+                e("s_mul_i32", st[4], s(3), bs[1])
+                e("s_add_u32", st[3], st[3], st[4])
+                e("s_add_u32", ptr[0], ptr[0], st[2])
+                e("s_addc_u32", ptr[1], ptr[1], st[3])
         if c.debug:
             e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
             e("s_waitcnt", lgkmcnt=0)

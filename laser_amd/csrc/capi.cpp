@@ -220,6 +220,10 @@ void view_span(int64_t R, int64_t C, int64_t rs, int64_t cs, int64_t *lo, int64_
 }
 
 hipError_t launch_tiled(const GemmArgs<float> &a, hipStream_t s) {
+  if (f32_cfg_now() < 0) {   // (batched: the hand-scheduled kernels take the batch index as grid y)
+    const hipError_t e = launch_gemm_f32_asm(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   return launch_gemm_f32(a, f32_cfg_now(), g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 hipError_t launch_tiled(const GemmArgs<double> &a, hipStream_t s) {

@@ -145,7 +145,8 @@ void asm_kernels_release() {
 // hipErrorNotSupported: not this kernel's class of problem -- the caller takes the compiler-scheduled kernels
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;
-  if (a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if (a.batch < 1 || a.batch > 65535 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if (a.batch > 1 && (a.bsA < 0 || a.bsB < 0 || a.bsC < 0)) return hipErrorNotSupported;
   if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
   if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
   // B: row-major-like (unit column stride), or passed transposed (unit row stride: every column is k-contiguous)
@@ -164,7 +165,9 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if ((nt ? (double)ldb * 4.0 * 256 : (double)a.K * (double)ldb * 4.0) >= 4.0e9) return hipErrorNotSupported;
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0) return hipErrorNotSupported;
   if (a.M > 0xffff * (int64_t)128 || a.N > 0xffff * (int64_t)128) return hipErrorNotSupported;
-  const auto tiles_of = [&](const KernelInfo &k) { return ((a.M + k.bm - 1) / k.bm) * ((a.N + k.bn - 1) / k.bn); };
+  // (batched problems -- gemm_strided_batched, the kc slices of the slice-parallel form -- are grid y: every tile count below is
+  // per launch)
+  const auto tiles_of = [&](const KernelInfo &k) { return ((a.M + k.bm - 1) / k.bm) * ((a.N + k.bn - 1) / k.bn) * (int64_t)a.batch; };
   // Which tile.  Workgroups that share a CU share its matrix pipes, so whatever the number of workgroup slots a launch of T
   // tiles takes ceil(T / 256) times one tile's matrix time: the smaller the tile the finer the quantisation, the larger
   // the tile the closer a CU gets to the peak (the eff columns of kKernels).  3072^3: 288 tiles of 256x128 = 2 rounds for
@@ -234,10 +237,15 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.beta = a.beta;
   ka.dbg = nullptr;
   ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
-  ka.bsB_bytes = ka.bsC_bytes = 0;
+  // batch strides in bytes (f32_kernel.py KA_BSA = the H, W slots; B's and C's in the convolution kernels' slots)
+  const uint64_t bsA_bytes = a.batch > 1 ? (uint64_t)a.bsA * 4 : 0;
+  ka.H = (uint32_t)bsA_bytes;
+  ka.W = (uint32_t)(bsA_bytes >> 32);
+  ka.bsB_bytes = a.batch > 1 ? (uint64_t)a.bsB * 4 : 0;
+  ka.bsC_bytes = a.batch > 1 ? (uint64_t)a.bsC * 4 : 0;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);
   if (e == hipSuccess) {
     g_last_f32_asm = 1 + pick;
     g_last_split = 0;  // one launch

@@ -1342,3 +1342,44 @@ def test_finalize_unloads_and_the_library_comes_back(la, oracle):
     assert la.last_f32_asm() != 0
     assert torch.equal(first, second)
     assert np.array_equal(second.cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
+
+
+def test_f32_asm_batched_and_slice_parallel(la, oracle):
+    """Batches on the assembly kernels (grid y = batch index; shared operands by stride 0) and the slice-parallel form running
+    its kc slices on them: bit-identical to the compiler-scheduled kernels, batches and slices against the oracle."""
+    import torch
+    rng = np.random.default_rng(606)
+    b, M, N, K = 5, 520, 640, 1030
+    A = torch.from_numpy(rand(rng, (b, M, K), np.float32)).cuda()
+    B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()               # shared by every batch entry (stride 0)
+    outs = {}
+    for mode in (0, 1):
+        for asm in (2, 0):
+            la.set_float_mode(mode); la.set_f32_asm(asm)
+            try:
+                C = torch.full((b, M, N + 3), 5.0, device="cuda")
+                la.gemm_strided_batched(b, M, N, K, 1.0, A, K, 1, M * K, B, N, 1, 0, 0.0, C, N + 3, 1, M * (N + 3))
+                assert (la.last_f32_asm() != 0) == (asm == 2)
+                outs[(mode, asm)] = C
+            finally:
+                la.set_f32_asm(1); la.set_float_mode(0)
+        assert torch.equal(outs[(mode, 2)], outs[(mode, 0)]), mode
+    got = outs[(0, 2)].cpu().numpy()
+    assert (got[:, :, N:] == 5.0).all()
+    for i in range(b):
+        assert np.array_equal(got[i, :, :N], oracle.matmul(A[i].cpu().numpy(), B.cpu().numpy())), i
+    # few tiles x long K: the slice-parallel form; its batched launch of kc slices now runs on the assembly kernels
+    M, N, K = 640, 640, 4096 + 36
+    A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
+    B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
+    res = {}
+    for asm in (1, 0):
+        la.set_f32_asm(asm)
+        try:
+            res[asm] = la.matmul(A, B)
+            used = la.last_f32_asm()
+        finally:
+            la.set_f32_asm(1)
+        assert (used != 0) == (asm == 1), (asm, used)
+    assert torch.equal(res[1], res[0])
+    assert np.array_equal(res[1].cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
