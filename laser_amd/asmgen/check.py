@@ -153,31 +153,42 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     return ok
 
 
-def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True):
-    """float64 kernels (f64_kernel.py) through the interpreter.  Operands are small integers, for which every product and
-    partial sum is exact in float64 (the interpreter's f64 MFMA is mul + add, not an exact fma): this checks every address,
-    layout, wait and hazard of the program; the accumulation ORDER with rounding is checked on hardware against the
+def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True, alpha=1.0, beta=0.0):
+    """float64 kernels (f64_kernel.py) through the interpreter.  Operands are small integers (alpha, beta dyadic), for which every
+    product and partial sum is exact in float64 (the interpreter's f64 MFMA is mul + add, not an exact fma): this checks every
+    address, layout, wait and hazard of the program; the accumulation ORDER with rounding is checked on hardware against the
     compiler-scheduled kernels and the CPU restatement."""
     from . import f64_kernel as K64
     g = K64.make(name, **(over or {}))
     g.build()
     c = g.c
+    nt = c.b_kcontig
     rng = np.random.default_rng(seed)
-    lda, ldb, ldc = lda or Kd, ldb or N, ldc or N
+    lda, ldc = lda or Kd, ldc or N
+    ldb = (ldb if (ldb and ldb >= Kd) else Kd) if nt else (ldb or N)
     Af = np.full((M, lda), np.nan)
-    Bf = np.full((Kd, ldb), np.nan)
     Am = rng.integers(-4, 5, (M, Kd)).astype(np.float64)
     Bm = rng.integers(-4, 5, (Kd, N)).astype(np.float64)
     Af[:, :Kd] = Am
-    Bf[:, :N] = Bm
+    if nt:
+        Bf = np.full((N, ldb), np.nan)
+        Bf[:, :Kd] = Bm.T
+        Bflat = Bf.reshape(-1)[:(N - 1) * ldb + Kd].copy()
+    else:
+        Bf = np.full((Kd, ldb), np.nan)
+        Bf[:, :N] = Bm
+        Bflat = Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
     Aflat = Af.reshape(-1)[:(M - 1) * lda + Kd].copy()
-    Bflat = Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
-    Cflat = np.full((M - 1) * ldc + N, np.nan)
+    C0 = rng.integers(-8, 9, (M, N)).astype(np.float64)
+    full0 = np.full((M, ldc), np.nan)
+    if beta != 0:
+        full0[:, :N] = C0
+    Cflat = full0.reshape(-1)[:(M - 1) * ldc + N].copy()
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Aflat), mem.alloc(Bflat), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + b"\0" * 56
+    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta) + b"\0" * 40
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
@@ -188,10 +199,10 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     full = np.full(M * ldc, np.nan)
     full[:len(Cflat)] = mem.get(c_, np.float64, (len(Cflat),))
     full = full.reshape(M, ldc)
-    want = Am @ Bm
+    want = alpha * (Am @ Bm) + (beta * C0 if beta != 0 else 0.0)
     ok = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(np.isnan(full[:, N:][:-1]))))
     if verbose:
-        print(f"f64 {name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, "
+        print(f"f64 {name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc} alpha={alpha} beta={beta}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, "
               f"bank-conflict cycles {stats['bank_conflict_cycles']}, {stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
         if not ok:
             bad = np.argwhere(full[:, :N] != want)

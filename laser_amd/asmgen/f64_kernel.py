@@ -12,8 +12,8 @@ ds_read_b128 -- and is 144 bytes long: with 9 chunks per row the 16 rows a 16-la
 4-bank groups, so the fragment reads are conflict-free without a swizzle, and every store is ONE ds_write2_b64:
   A piece (16 bytes = k0, k0 + 1 of one row)      -> chunks c and c + 1 of that row:           offsets 0, +16 bytes
   B piece (16 bytes = columns x0, x0 + 1 of one k) -> the same chunk of rows x0 and x0 + 1:     offsets 0, +144 bytes
-Operands: A row-major (k-contiguous), B row-major (x-contiguous), C row-major; K a multiple of 2; alpha = 1, beta = 0 (the
-launcher sends everything else to the compiler-scheduled kernels)."""
+Operands: A row-major (k-contiguous), B row-major (x-contiguous) or passed transposed (`_nt`: k-contiguous, stored like A), C
+row-major; K a multiple of 2; any alpha / beta (float64 in the kernel arguments)."""
 from .core import v, a, s, VCC
 from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
 
@@ -24,7 +24,13 @@ CONFIGS = {
     # problems of few tiles (the reference's f64 bench shape, 960^3 = 225 tiles): 2 x 2 waves of 32x32, several workgroups per CU
     "exact_64x64x16": dict(BM=64, BN=64, BK=16, exact=True),
     "fast_64x64x16": dict(BM=64, BN=64, BK=16, exact=False),
+    # B passed transposed (rowStrideB == 1: k-contiguous like A)
+    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True),
+    "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
+    "exact_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=True, b_kcontig=True),
+    "fast_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=False, b_kcontig=True),
 }
+KA_ALPHA64 = 72      # alpha, beta as float64 (the f32 kernels' float fields at 56 / 60 are unused here)
 
 
 class Gen64(Gen):
@@ -41,6 +47,9 @@ class Gen64(Gen):
         self.s_bstep = S()
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
+        self.s_ab = S(4, align=4)                 # alpha (2 registers), beta (2 registers): float64
+        self.s_al, self.s_be = self.s_ab.sub(0, 2), self.s_ab.sub(2, 2)
+        self.s_a1, self.s_b0 = S(), S()           # 0 when alpha == 1.0 / when beta == +-0.0
         self.s_ldc4, self.s_ldc20 = S(), S()      # here: ldc * 8 bytes, 4 * ldc * 8 (the next accumulator row of a lane)
         self.acc = [p.aalloc(8) for _ in range(c.NB)]
         self.run = [p.aalloc(8) for _ in range(c.NB)] if c.exact else None
@@ -82,6 +91,12 @@ class Gen64(Gen):
         e("s_lshl_b32", st[0], s(2), 2)
         e("s_waitcnt", lgkmcnt=0)
         e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16")
+        e("s_load_dwordx4", self.s_ab, s(0, 2), KA_ALPHA64)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_xor_b32", st[2], self.s_al[1], 0x3ff00000)
+        e("s_or_b32", self.s_a1, st[2], self.s_al[0])
+        e("s_and_b32", st[2], self.s_be[1], 0x7fffffff)
+        e("s_or_b32", self.s_b0, st[2], self.s_be[0])
         if c.debug:
             e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
             e("s_waitcnt", lgkmcnt=0)
@@ -144,34 +159,49 @@ class Gen64(Gen):
         e("s_lshl_b32", st[4], st[3], 5)                     # 32 rows
         for i in range(1, c.NPA):
             e("v_add_u32", self.vVA[i], st[4], self.vVA[i - 1])
-        # B pieces: x pair px = tid % (BN / 2), row k = tid / (BN / 2) (+ KS per piece, KS = 512 / BN)
-        #   LDS: BM * RS + 2 px * RS + (4 * (k >> 3) + (k & 3)) * 16 + ((k >> 2) & 1) * 8; k = k0 + KS * j with k0 < KS
-        HB = c.BN // 2
-        KS = 256 // HB
-        px, k0 = t[0], t[1]
-        e("v_and_b32", px, HB - 1, tid)
-        e("v_lshrrev_b32", k0, HB.bit_length() - 1, tid)
-        e("v_and_b32", t[5], 3, k0)
-        e("v_lshlrev_b32", t[5], 4, t[5])                    # (k0 & 3) * 16
-        e("v_bfe_u32", t[6], k0, 2, 1)
-        e("v_lshl_add_u32", t[5], t[6], 3, t[5])             # + ((k0 >> 2) & 1) * 8      (k0 < 8)
-        e("v_mul_u32_u24", t[6], 2 * RS, px)
-        e("v_add_u32", t[5], t[5], t[6])
-        e("v_add_u32", t[5], c.BM * RS, t[5])
-        for j in range(c.NPB):
-            kk = KS * j
-            cst = 64 * (kk >> 3) + 16 * (kk & 3) + 8 * ((kk >> 2) & 1)
-            assert (kk & 3) == 0 or KS >= 8, "k0 and KS * j must not share bits"
-            e("v_add_u32", self.WB[j][2], cst, t[5])
-            e("v_add_u32", self.WB[j][0], c.STAGE, self.WB[j][2])
-            e("v_add_u32", self.WB[j][1], 2 * c.STAGE, self.WB[j][2])
-        e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
-        e("v_mul_lo_u32", t[7], k0, st[5])
-        e("v_lshl_add_u32", self.vVB[0], px, 4, t[7])
-        e("s_mul_i32", st[4], st[5], KS)
-        for j in range(1, c.NPB):
-            e("v_add_u32", self.vVB[j], st[4], self.vVB[j - 1])
-        e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
+        if c.b_kcontig:
+            # B passed transposed: its pieces are (column x, k0 .. k0 + 1) -- the A layout with the B panel's offsets
+            e("v_add_u32", t[5], c.BM * RS, t[5])
+            for j in range(c.NPB):
+                e("v_add_u32", self.WB[j][2], 32 * RS * j, t[5])
+                e("v_add_u32", self.WB[j][0], c.STAGE, self.WB[j][2])
+                e("v_add_u32", self.WB[j][1], 2 * c.STAGE, self.WB[j][2])
+            e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
+            e("v_mul_lo_u32", t[7], xr, st[5])
+            e("v_lshl_add_u32", self.vVB[0], pc, 4, t[7])
+            e("s_lshl_b32", st[4], st[5], 5)
+            for j in range(1, c.NPB):
+                e("v_add_u32", self.vVB[j], st[4], self.vVB[j - 1])
+            e("s_mov_b32", self.s_bstep, c.BK * 8)
+        else:
+            # B pieces: x pair px = tid % (BN / 2), row k = tid / (BN / 2) (+ KS per piece, KS = 512 / BN)
+            #   LDS: BM * RS + 2 px * RS + (4 * (k >> 3) + (k & 3)) * 16 + ((k >> 2) & 1) * 8; k = k0 + KS * j with k0 < KS
+            HB = c.BN // 2
+            KS = 256 // HB
+            px, k0 = t[0], t[1]
+            e("v_and_b32", px, HB - 1, tid)
+            e("v_lshrrev_b32", k0, HB.bit_length() - 1, tid)
+            e("v_and_b32", t[5], 3, k0)
+            e("v_lshlrev_b32", t[5], 4, t[5])                    # (k0 & 3) * 16
+            e("v_bfe_u32", t[6], k0, 2, 1)
+            e("v_lshl_add_u32", t[5], t[6], 3, t[5])             # + ((k0 >> 2) & 1) * 8      (k0 < 8)
+            e("v_mul_u32_u24", t[6], 2 * RS, px)
+            e("v_add_u32", t[5], t[5], t[6])
+            e("v_add_u32", t[5], c.BM * RS, t[5])
+            for j in range(c.NPB):
+                kk = KS * j
+                cst = 64 * (kk >> 3) + 16 * (kk & 3) + 8 * ((kk >> 2) & 1)
+                assert (kk & 3) == 0 or KS >= 8, "k0 and KS * j must not share bits"
+                e("v_add_u32", self.WB[j][2], cst, t[5])
+                e("v_add_u32", self.WB[j][0], c.STAGE, self.WB[j][2])
+                e("v_add_u32", self.WB[j][1], 2 * c.STAGE, self.WB[j][2])
+            e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
+            e("v_mul_lo_u32", t[7], k0, st[5])
+            e("v_lshl_add_u32", self.vVB[0], px, 4, t[7])
+            e("s_mul_i32", st[4], st[5], KS)
+            for j in range(1, c.NPB):
+                e("v_add_u32", self.vVB[j], st[4], self.vVB[j - 1])
+            e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
         # ---- tile coordinates, descriptors ----
         e("s_waitcnt", lgkmcnt=0)
         e("s_and_b32", st[0], st[1], 0xffff)
@@ -192,16 +222,30 @@ class Gen64(Gen):
         e("s_lshl_b32", st[2], self.s_K, 3)
         e("s_add_u32", self.srdA[2], st[0], st[2])
         e("s_mov_b32", self.srdA[3], 0x00020000)
-        # B panel: base = B + n0 * 8; bytes = (K - 1) * ldb * 8 + (N - n0) * 8
-        e("s_lshl_b32", st[0], self.s_n0, 3)
-        e("s_add_u32", self.srdB[0], B_[0], st[0])
-        e("s_addc_u32", self.srdB[1], B_[1], 0)
-        e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
-        e("s_sub_u32", st[0], self.s_K, 1)
-        e("s_mul_i32", st[0], st[0], st[5])
-        e("s_sub_u32", st[2], self.s_N, self.s_n0)
-        e("s_lshl_b32", st[2], st[2], 3)
-        e("s_add_u32", self.srdB[2], st[0], st[2])
+        if c.b_kcontig:
+            # B^T panel: base = B + n0 * ldb * 8; bytes = (min(N - n0, BN) - 1) * ldb * 8 + K * 8
+            e("s_mul_hi_u32", st[2], self.s_n0, st[5])
+            e("s_mul_i32", st[0], self.s_n0, st[5])
+            e("s_add_u32", self.srdB[0], B_[0], st[0])
+            e("s_addc_u32", self.srdB[1], B_[1], st[2])
+            e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+            e("s_sub_u32", st[0], self.s_N, self.s_n0)
+            e("s_min_u32", st[0], st[0], c.BN)
+            e("s_sub_u32", st[0], st[0], 1)
+            e("s_mul_i32", st[0], st[0], st[5])
+            e("s_lshl_b32", st[2], self.s_K, 3)
+            e("s_add_u32", self.srdB[2], st[0], st[2])
+        else:
+            # B panel: base = B + n0 * 8; bytes = (K - 1) * ldb * 8 + (N - n0) * 8
+            e("s_lshl_b32", st[0], self.s_n0, 3)
+            e("s_add_u32", self.srdB[0], B_[0], st[0])
+            e("s_addc_u32", self.srdB[1], B_[1], 0)
+            e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+            e("s_sub_u32", st[0], self.s_K, 1)
+            e("s_mul_i32", st[0], st[0], st[5])
+            e("s_sub_u32", st[2], self.s_N, self.s_n0)
+            e("s_lshl_b32", st[2], st[2], 3)
+            e("s_add_u32", self.srdB[2], st[0], st[2])
         e("s_mov_b32", self.srdB[3], 0x00020000)
         # C: the whole matrix, bytes = (M - 1) * ldc * 8 + N * 8
         e("s_lshl_b32", self.s_ldc4, self.s_ldc, 3)
@@ -246,6 +290,8 @@ class Gen64(Gen):
                 e("v_accvgpr_write_b32", self.acc[b][r], 0)
                 if c.exact:
                     e("v_accvgpr_write_b32", self.run[b][r], 0)
+        if c.exact:
+            self.load_beta_c()
         self.lg_wait(None)
         e("s_barrier")
         self.read_group(0, 0, 0)
@@ -267,7 +313,7 @@ class Gen64(Gen):
     def advance_srds(self, which=None):
         e = self.p.emit
         ops = []
-        for srd, step in ((self.srdA, self.c.BK * 8), (self.srdB, self.s_bstep)):
+        for srd, step in ((self.srdA, self.c.BK * 8), (self.srdB, self.c.BK * 8 if self.c.b_kcontig else self.s_bstep)):
             ops += [("s_add_u32", srd[0], srd[0], step), ("s_addc_u32", srd[1], srd[1], 0),
                     ("s_sub_u32", srd[2], srd[2], step), ("s_cselect_b32", srd[2], 0, srd[2])]
         if which is None:
@@ -279,7 +325,7 @@ class Gen64(Gen):
         pass      # (K is even: the 16-byte pieces of 2 doubles are all-or-nothing)
 
     def apply_tail_mask(self):
-        for r in self.vVA:
+        for r in list(self.vVA) + (list(self.vVB) if self.c.b_kcontig else []):
             self.p.emit("v_cndmask_b32", r, self.v_oob, r, self.s_tm)
 
     # ------------------------------------------------------------------ LDS stores: one ds_write2_b64 per piece
@@ -294,7 +340,8 @@ class Gen64(Gen):
     def store_B_piece(self, pj, ops=None, k=0):
         r = self.stB[pj]
         out = [("vmwait", ("B", pj)),
-               ("ldsw", "ds_write2_b64", (self.WB[pj][k], r.sub(0, 2), r.sub(2, 2)), {"offset0": 0, "offset1": self.c.RS // 8})]
+               ("ldsw", "ds_write2_b64", (self.WB[pj][k], r.sub(0, 2), r.sub(2, 2)),
+                {"offset0": 0, "offset1": 2 if self.c.b_kcontig else self.c.RS // 8})]
         if ops is None:
             self.run_ops(out)
         return out
@@ -319,7 +366,13 @@ class Gen64(Gen):
             self.p.emit("v_accvgpr_read_b32", T[r], self.acc[b][r])
 
     def fold_after(self, b):
-        e, T = self.p.emit, self.vT[0]
+        p, e, T = self.p, self.p.emit, self.vT[0]
+        # run += alpha * slice, unfused; alpha == 1: the multiplies (out of line) are a branch not taken
+        lmul, lback = p.label("amul"), p.label("aback")
+        e("s_cmp_lg_u32", self.s_a1, 0)
+        e("s_cbranch_scc1", lmul)
+        p.place(lback)
+        self.outlined.append((lmul, [("v_mul_f64", T.sub(2 * d, 2), self.s_al, T.sub(2 * d, 2)) for d in range(4)], lback))
         for d in range(4):
             tt = T.sub(8 + 2 * (d % 2), 2)
             e("v_accvgpr_read_b32", tt[0], self.run[b][2 * d])
@@ -350,13 +403,43 @@ class Gen64(Gen):
             e("v_mov_b32", t[7], 0x80000000)
             e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
 
+    def c_walk(self, fn):
+        """visit this lane's accumulator elements in C order: fn(i, d, n) with vC[n] addressing D[q + 4d][r16] of block (i, n)"""
+        c = self.c
+        for i in range(c.TM):
+            for d in range(4):
+                fn(i, d)
+                if not (i == c.TM - 1 and d == 3):
+                    for n in range(c.TN):
+                        self.p.emit("v_add_u32", self.vC[n], self.s_ldc20, self.vC[n])
+
     def load_beta_c(self):
-        pass
+        """laser-order kernels, beta != 0: the running sum starts as beta * C0 (one rounding), loaded through the idle fragment
+        registers and drained here, so the loop's counted waits (computed for beta == 0) stay correct"""
+        c, p = self.c, self.p
+        e = p.emit
+        skip = p.label("nobeta")
+        e("s_cmp_eq_u32", self.s_b0, 0)
+        e("s_cbranch_scc1", skip)
+        self.c_addr_setup()
+        pool = [r.sub(2 * h, 2) for slot in range(2) for r in (self.fa[slot] + self.fb[slot]) for h in range(2)]
+        assert len(pool) >= c.TN
+
+        def row(i, d):
+            for n in range(c.TN):
+                e("buffer_load_dwordx2", pool[n], self.vC[n], self.srdC, 0, offen=True)
+            e("s_waitcnt", vmcnt=0)
+            for n in range(c.TN):
+                e("v_mul_f64", pool[n], self.s_be, pool[n])
+                e("v_accvgpr_write_b32", self.run[i * c.TN + n][2 * d], pool[n][0])
+                e("v_accvgpr_write_b32", self.run[i * c.TN + n][2 * d + 1], pool[n][1])
+        self.c_walk(row)
+        p.place(skip)
 
     def epilogue(self):
-        """C = run + acc (alpha = 1, beta = 0: gemm_ukernel_generic.nim:53-76), predicated by the descriptor's bounds check"""
+        """C = beta * C0 + alpha * (slice sums in order) -- gemm_ukernel_generic.nim:53-76 -- predicated by the descriptor's bounds check"""
         c, p = self.c, self.p
-        e, t = p.emit, self.vt
+        e = p.emit
         e("s_nop", 15)
         e("s_nop", 7)
         e("s_waitcnt", vmcnt=0, lgkmcnt=0)
@@ -367,21 +450,50 @@ class Gen64(Gen):
                 self.dump(f"acc[0][{k_}]", self.acc[0][k_])
         self.c_addr_setup()
         T = self.vT[0]
-        for i in range(c.TM):
-            for d in range(4):
+
+        def read_acc(tt, b, d):
+            e("v_accvgpr_read_b32", tt[0], self.acc[b][2 * d])
+            e("v_accvgpr_read_b32", tt[1], self.acc[b][2 * d + 1])
+            e("v_mul_f64", tt, self.s_al, tt)                     # (1.0 * x is x)
+
+        if c.exact:
+            def row(i, d):
                 for n in range(c.TN):
                     b = i * c.TN + n
                     tt, uu = T.sub(4 * (n % 2), 2), T.sub(4 * (n % 2) + 2, 2)
-                    e("v_accvgpr_read_b32", tt[0], self.acc[b][2 * d])
-                    e("v_accvgpr_read_b32", tt[1], self.acc[b][2 * d + 1])
-                    if c.exact:
-                        e("v_accvgpr_read_b32", uu[0], self.run[b][2 * d])
-                        e("v_accvgpr_read_b32", uu[1], self.run[b][2 * d + 1])
-                        e("v_add_f64", tt, uu, tt)
+                    read_acc(tt, b, d)
+                    e("v_accvgpr_read_b32", uu[0], self.run[b][2 * d])
+                    e("v_accvgpr_read_b32", uu[1], self.run[b][2 * d + 1])
+                    e("v_add_f64", tt, uu, tt)
                     e("buffer_store_dwordx2", tt, self.vC[n], self.srdC, 0, offen=True)
-                if not (i == c.TM - 1 and d == 3):
-                    for n in range(c.TN):
-                        e("v_add_u32", self.vC[n], self.s_ldc20, self.vC[n])
+            self.c_walk(row)
+        else:
+            withc, done = p.label("beta"), p.label("stored")
+            e("s_cmp_lg_u32", self.s_b0, 0)
+            e("s_cbranch_scc1", withc)
+
+            def row0(i, d):
+                for n in range(c.TN):
+                    tt = T.sub(4 * (n % 2), 2)
+                    read_acc(tt, i * c.TN + n, d)
+                    e("buffer_store_dwordx2", tt, self.vC[n], self.srdC, 0, offen=True)
+            self.c_walk(row0)
+            e("s_branch", done)
+            p.place(withc)
+            self.c_addr_setup()
+
+            def row1(i, d):
+                for n in range(c.TN):
+                    e("buffer_load_dwordx2", T.sub(8 + 2 * n, 2), self.vC[n], self.srdC, 0, offen=True)
+                e("s_waitcnt", vmcnt=0)
+                for n in range(c.TN):
+                    tt, x = T.sub(2 * n, 2), T.sub(8 + 2 * n, 2)
+                    e("v_mul_f64", x, self.s_be, x)
+                    read_acc(tt, i * c.TN + n, d)
+                    e("v_add_f64", tt, x, tt)
+                    e("buffer_store_dwordx2", tt, self.vC[n], self.srdC, 0, offen=True)
+            self.c_walk(row1)
+            p.place(done)
         e("s_endpgm")
 
 

@@ -12,6 +12,7 @@
 #include <tuple>
 #include <vector>
 
+#include <cstring>
 #include "common.h"
 #include "limb_planes.h"
 #include "f32_asm_blob.h"  // generated: lh_f32_asm_hsaco[], lh_f32_asm_hsaco_len
@@ -44,7 +45,8 @@ struct KernelInfo {
 // [16..19]: float64 (v_mfma_f64_16x16x4_f64; laser_amd/asmgen/f64_kernel.py): 128x128x16 laser-order / one chain, 64x64x16 same
 // [20]: int32 via int8 limb planes (laser_amd/asmgen/i8_kernel.py)
 // [21..24]: convolution with fewer output channels: 128x128x32 (laser-order / one chain), 64x128x32 (same)
-constexpr int kNumKernels = 25;
+// [25..28]: float64 with B passed transposed: 128x128x16 (laser-order / one chain), 64x64x16 (same)
+constexpr int kNumKernels = 29;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0},
@@ -58,7 +60,9 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0},
     {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0},
     {"lh_f32_conv3x3_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0}, {"lh_f32_conv3x3_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0},
-    {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0}};
+    {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},
+    {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.92, 0.92, 8.0},     {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.93, 0.93, 8.0},
+    {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -310,19 +314,22 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   return e;
 }
 
-// float64 twin of launch_gemm_f32_asm (kernels of laser_amd/asmgen/f64_kernel.py): row-major A, B, C, alpha = 1, beta = 0, K even.
+// float64 twin of launch_gemm_f32_asm (kernels of laser_amd/asmgen/f64_kernel.py): row-major A and C, B row-major or passed
+// transposed, any alpha / beta, K even.
 hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipStream_t s) {
   if (!g_f64_asm) return hipErrorNotSupported;
   if (a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
-  if (a.alpha != 1.0 || a.beta != 0.0) return hipErrorNotSupported;
-  if (a.csA != 1 || a.csB != 1 || a.csC != 1) return hipErrorNotSupported;
+  if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
+  const bool nt = a.csB != 1 && a.rsB == 1;
+  if (!nt && a.csB != 1) return hipErrorNotSupported;
+  const int64_t ldb = nt ? a.csB : a.rsB;
   if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
-  if (a.rsA < a.K || a.rsB < a.N || a.rsC < a.N || a.K < 2 || a.K % 2 != 0) return hipErrorNotSupported;   // 16-byte pieces = 2 k
-  if ((double)a.rsA * 8.0 * 128 >= 4.0e9 || (double)a.K * (double)a.rsB * 8.0 >= 4.0e9) return hipErrorNotSupported;
+  if (a.rsA < a.K || ldb < (nt ? a.K : a.N) || a.rsC < a.N || a.K < 2 || a.K % 2 != 0) return hipErrorNotSupported;   // 16-byte pieces = 2 k
+  if ((double)a.rsA * 8.0 * 128 >= 4.0e9 || (nt ? (double)ldb * 8.0 * 128 : (double)a.K * (double)ldb * 8.0) >= 4.0e9) return hipErrorNotSupported;
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 8.0 > 2147483648.0) return hipErrorNotSupported;
   if (a.M > 0xffff * (int64_t)64 || a.N > 0xffff * (int64_t)64) return hipErrorNotSupported;
   const bool exact = laser_order && a.K > 256;   // kc = 256 doubles (gemm_tiling.nim:310)
-  const int big = exact ? 16 : 17, tiny = exact ? 18 : 19;
+  const int big = (nt ? 25 : 16) + (exact ? 0 : 1), tiny = (nt ? 27 : 18) + (exact ? 0 : 1);
   int pick = -1;
   double best = 1e300;
   const double cu_flops_per_us = 78.6e6 / 256.0;
@@ -364,12 +371,19 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   KernArgs ka;
   ka.A = a.A; ka.B = a.B; ka.C = a.C;
   ka.table = it->second.first;
-  ka.lda = (uint32_t)a.rsA; ka.ldb = (uint32_t)a.rsB; ka.ldc = (uint32_t)a.rsC;
+  ka.lda = (uint32_t)a.rsA; ka.ldb = (uint32_t)ldb; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)a.K;
   ka.alpha = 1.0f; ka.beta = 0.0f;
   ka.dbg = nullptr;
   ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
   ka.bsB_bytes = ka.bsC_bytes = 0;
+  // alpha, beta as float64 in the H..pH slots (f64_kernel.py KA_ALPHA64)
+  uint64_t ab[2];
+  static_assert(sizeof(double) == 8, "");
+  std::memcpy(&ab[0], &a.alpha, 8);
+  std::memcpy(&ab[1], &a.beta, 8);
+  ka.H = (uint32_t)ab[0]; ka.W = (uint32_t)(ab[0] >> 32);
+  ka.oW = (uint32_t)ab[1]; ka.pH = (uint32_t)(ab[1] >> 32);
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m->fn[pick], (unsigned)(tiles_m * (int64_t)tiles_n), 1, 1, 256, 1, 1, 0, s, nullptr, extra);

@@ -1210,8 +1210,10 @@ def test_f64_asm_kernels_bit_exact(la, oracle):
     try:
         la.matmul(A, B)
         assert la.get_option("last_f64_asm") == 0                       # K odd
-        la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous(), 0.5, 0.0)
-        assert la.get_option("last_f64_asm") == 0                       # alpha != 1
+        c1 = la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous(), 0.5, 0.0)
+        assert la.get_option("last_f64_asm") != 0                       # alpha / beta run on the assembly kernels too
+        la.set_option("f64_asm", 0)
+        assert torch.equal(c1, la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous(), 0.5, 0.0))
     finally:
         la.set_option("f64_asm", 1)
 
@@ -1283,16 +1285,16 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
         dev = torch.from_numpy(host).cuda()
         return dev, dev[off:off + rows * ld].view(rows, ld)[:, :cols], host[off:off + rows * ld].reshape(rows, ld)[:, :cols]
 
-    for case in range(36):
-        kind = ("f32", "f32nt", "f64", "i32")[case % 4]
+    for case in range(40):
+        kind = ("f32", "f32nt", "f64", "i32", "f64nt")[case % 5]
         M, N = int(rng.integers(300, 1500)), int(rng.integers(300, 1500))
-        K = int(rng.integers(1, 1200)) if kind.startswith("f32") else int(rng.integers(1, 300)) * (2 if kind == "f64" else 1)
+        K = int(rng.integers(1, 1200)) if kind.startswith("f32") else int(rng.integers(1, 300)) * (2 if kind.startswith("f64") else 1)
         if kind == "i32":
             K = max(K, 32)         # (smaller int32 problems go to the VALU kernel)
-        dt = {"f32": np.float32, "f32nt": np.float32, "f64": np.float64, "i32": np.int32}[kind]
+        dt = {"f32": np.float32, "f32nt": np.float32, "f64": np.float64, "i32": np.int32, "f64nt": np.float64}[kind]
         lda, offa = K + int(rng.integers(0, 9)), int(rng.integers(0, 7))
         _, dA, hA = views(host_buf(M, lda, offa, dt), M, K, lda, offa)
-        if kind == "f32nt":
+        if kind.endswith("nt"):
             ldb, offb = K + int(rng.integers(0, 9)), int(rng.integers(0, 7))
             _, dBt, hBt = views(host_buf(N, ldb, offb, dt), N, K, ldb, offb)
             dB, hB = dBt.t(), hBt.T
@@ -1301,8 +1303,8 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
             _, dB, hB = views(host_buf(K, ldb, offb, dt), K, N, ldb, offb)
         ldc, offc = N + int(rng.integers(0, 9)), int(rng.integers(0, 7))
         hC0 = host_buf(M, ldc, offc, dt)
-        al, be = ((1, 0), (0.5, 0), (1, 1), (-1.5, 0.75))[int(rng.integers(0, 4))] if kind.startswith("f32") else (1, 0)
-        opt = {"f32": "f32_asm", "f32nt": "f32_asm", "f64": "f64_asm", "i32": "i32_asm"}[kind]
+        al, be = ((1, 0), (0.5, 0), (1, 1), (-1.5, 0.75))[int(rng.integers(0, 4))] if kind != "i32" else (1, 0)
+        opt = {"f32": "f32_asm", "f32nt": "f32_asm", "f64": "f64_asm", "i32": "i32_asm", "f64nt": "f64_asm"}[kind]
         for mode in ((0, 1) if kind != "i32" else (0,)):
             outs = {}
             for asm in (2, 0):
