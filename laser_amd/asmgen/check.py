@@ -225,7 +225,7 @@ def pack_limb_tiles(X):
     return out.reshape(-1), xp, kp
 
 
-def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_range=True):
+def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_range=True, alpha=1, beta=0):
     """int32 GEMM kernel (i8_kernel.py) through the interpreter: C = A B mod 2^32 with full-range int32 operands"""
     from . import i8_kernel as KI
     g = KI.make()
@@ -240,11 +240,16 @@ def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_rang
     Bp, Np_, _ = pack_limb_tiles(B.T.copy())
     KT = Kp // 32
     Cflat = np.full((M - 1) * ldc + N, 0x7bad7bad, dtype=np.uint32)
+    C0 = rng.integers(0, 2**32, (M, N), dtype=np.uint64).astype(np.uint32)
+    if beta != 0:
+        full0 = np.full((M, ldc), 0x7bad7bad, dtype=np.uint32)
+        full0[:, :N] = C0
+        Cflat = full0.reshape(-1)[:(M - 1) * ldc + N].copy()
     tm, tn = Mp // 128, Np_ // 128
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Ap), mem.alloc(Bp), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, 1.0, 0.0, 0) + b"\0" * 56
+    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, alpha, beta, 0) + b"\0" * 56
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
@@ -263,6 +268,8 @@ def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_rang
         for k in range(Kd):      # products mod 2^64 then mod 2^32: exact for the low 32 bits
             acc = (acc + (Au[:, k:k + 1] * Bu[k:k + 1, :])) & np.uint64(0xffffffff)
         want = acc.astype(np.uint32)
+    want = ((want.astype(np.uint64) * np.uint64(alpha & 0xffffffff) + (C0.astype(np.uint64) * np.uint64(beta & 0xffffffff) if beta != 0 else np.uint64(0)))
+            & np.uint64(0xffffffff)).astype(np.uint32)
     ok = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(full[:, N:][:-1] == 0x7bad7bad)))
     if verbose:
         print(f"i32 M={M} N={N} K={Kd} ldc={ldc}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, bank-conflict cycles "

@@ -11,8 +11,8 @@ tile one contiguous 16-KiB block [plane p][k half h][row r][16 bytes] -- so the 
 moves bytes 16 t + 4096 i, fully coalesced, one ds_write_b128 each, no address arithmetic) and a fragment read is 32 consecutive
 16-byte chunks per half wave (conflict-free).  Workgroup tile 128x128, 2 x 2 waves of 64x64 (2 x 2 blocks); a K-tile is one
 k-step: 40 MFMAs.  The fragments of tile t+1 (16 ds_read_b128) are read after the barrier of tile t into the other of two
-register sets, so the loop is unrolled x6 (3 LDS stages x 2 fragment sets).  alpha = 1, beta = 0, K <= 8192 (no fold of the
-accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything else stays on the compiler-scheduled kernel."""
+register sets, so the loop is unrolled x6 (3 LDS stages x 2 fragment sets).  Any int32 alpha / beta (wrapping), K <= 8192 (no
+fold of the accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything else stays on the compiler-scheduled kernel."""
 from .core import v, a, s, VCC
 from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
 
@@ -29,6 +29,7 @@ class GenI8(Gen):
         self.ka0 = S(8, align=4)
         self.ka1 = S(8, align=4)
         self.s_lda, self.s_ldb, self.s_ldc, self.s_M, self.s_N, self.s_K = (self.ka1[i] for i in range(6))
+        self.s_alpha, self.s_beta = self.ka1[6], self.ka1[7]        # int32 (the float slots of the f32 kernels)
         self.srdA, self.srdB, self.srdC = S(4), S(4), S(4)
         self.s_rem = S()
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
@@ -246,21 +247,41 @@ class GenI8(Gen):
         e("s_waitcnt", vmcnt=0, lgkmcnt=0)
         self.vmq.clear()
         self.lgq.clear()
-        self.c_addr_setup()
-        for i in range(2):
-            for q in range(4):
-                for rr in range(4):
-                    r = 4 * q + rr
-                    for n in range(2):
-                        b = 2 * i + n
-                        x = [t[4 * n + j] for j in range(4)]
-                        for j in range(4):
-                            e("v_accvgpr_read_b32", x[j], self.acc[j][b][r])
-                        e("v_lshl_add_u32", x[0], x[1], 8, x[0])
-                        e("v_lshl_add_u32", x[0], x[2], 16, x[0])
-                        e("v_lshl_add_u32", x[0], x[3], 24, x[0])
-                        e("buffer_store_dword", x[0], self.vC[n], self.srdC, 0, offen=True)
-                    self.c_step(i, q, rr)
+        # C = beta * C0 + alpha * sum, all mod 2^32 (gemm_ukernel_generic.nim:53-76); beta == 0 never reads C
+        withc, done = p.label("beta"), p.label("stored")
+        e("s_cmp_lg_u32", self.s_beta, 0)
+        e("s_cbranch_scc1", withc)
+        for with_beta in (False, True):
+            if with_beta:
+                p.place(withc)
+            self.c_addr_setup()
+            for i in range(2):
+                for q in range(4):
+                    for rr in range(4):
+                        r = 4 * q + rr
+                        if with_beta:
+                            for n in range(2):
+                                e("buffer_load_dword", t[8 + n], self.vC[n], self.srdC, 0, offen=True)
+                        for n in range(2):
+                            b = 2 * i + n
+                            x = [t[4 * n + j] for j in range(4)]
+                            for j in range(4):
+                                e("v_accvgpr_read_b32", x[j], self.acc[j][b][r])
+                            e("v_lshl_add_u32", x[0], x[1], 8, x[0])
+                            e("v_lshl_add_u32", x[0], x[2], 16, x[0])
+                            e("v_lshl_add_u32", x[0], x[3], 24, x[0])
+                            e("v_mul_lo_u32", x[0], x[0], self.s_alpha)
+                        if with_beta:
+                            e("s_waitcnt", vmcnt=0)
+                            for n in range(2):
+                                e("v_mul_lo_u32", t[8 + n], t[8 + n], self.s_beta)
+                                e("v_add_u32", t[4 * n], t[4 * n], t[8 + n])
+                        for n in range(2):
+                            e("buffer_store_dword", t[4 * n], self.vC[n], self.srdC, 0, offen=True)
+                        self.c_step(i, q, rr)
+            if not with_beta:
+                e("s_branch", done)
+        p.place(done)
         e("s_endpgm")
 
 

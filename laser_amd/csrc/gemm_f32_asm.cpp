@@ -260,10 +260,10 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
 
 // int32 GEMM mod 2^32 on the int8 matrix cores (gemm_i32_mfma.hip's arithmetic; kernel of laser_amd/asmgen/i8_kernel.py): the
 // packing pass writes tile-major digit planes into `ws` (>= 4 * (rup(M,128) + rup(N,128)) * rup(K,32) bytes), then one launch.
-// alpha = 1, beta = 0, unit column stride on C, K <= 8192 (the accumulator groups are never folded).
+// Any int32 alpha / beta, unit column stride on C, K <= 8192 (the accumulator groups are never folded).
 hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t s) {
   if (!g_i32_asm) return hipErrorNotSupported;
-  if (a.batch != 1 || a.alpha != 1 || a.beta != 0 || a.csC != 1 || a.rsC < a.N) return hipErrorNotSupported;
+  if (a.batch != 1 || a.csC != 1 || a.rsC < a.N) return hipErrorNotSupported;
   if (a.M < 1 || a.N < 1 || a.K < 1 || a.K > 8192) return hipErrorNotSupported;
   const int64_t Mpad = (a.M + 127) / 128 * 128, Npad = (a.N + 127) / 128 * 128, Kpad = (a.K + 31) / 32 * 32;
   const int64_t tiles = (Mpad / 128) * (Npad / 128);
@@ -303,7 +303,9 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   ka.table = it->second.first;
   ka.lda = (uint32_t)(Kpad / 32); ka.ldb = 0; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)Kpad;
-  ka.alpha = 1.0f; ka.beta = 0.0f;
+  static_assert(sizeof(float) == sizeof(int32_t), "");
+  std::memcpy(&ka.alpha, &a.alpha, 4);   // int32 alpha / beta travel in the float slots (i8_kernel.py)
+  std::memcpy(&ka.beta, &a.beta, 4);
   ka.dbg = nullptr;
   ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
   ka.bsB_bytes = ka.bsC_bytes = 0;

@@ -1262,8 +1262,12 @@ def test_i32_asm_kernel_bit_exact(la, oracle):
     try:
         la.matmul(A, B)
         assert la.get_option("last_i32_asm") == 0          # K > 8192
-        la.matmul(A[:, :512].contiguous(), B[:512].contiguous(), 3, 0)
-        assert la.get_option("last_i32_asm") == 0          # alpha != 1
+        c1 = torch.full((256, 256), 11, dtype=torch.int32, device="cuda"); c2 = c1.clone()
+        la.matmul(A[:, :512].contiguous(), B[:512].contiguous(), -3, 7, c1)
+        assert la.get_option("last_i32_asm") != 0          # alpha / beta (wrapping) run on the assembly kernel too
+        la.set_option("i32_asm", 0)
+        la.matmul(A[:, :512].contiguous(), B[:512].contiguous(), -3, 7, c2)
+        assert torch.equal(c1, c2)
     finally:
         la.set_option("i32_asm", 1)
 
@@ -1303,7 +1307,7 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
             _, dB, hB = views(host_buf(K, ldb, offb, dt), K, N, ldb, offb)
         ldc, offc = N + int(rng.integers(0, 9)), int(rng.integers(0, 7))
         hC0 = host_buf(M, ldc, offc, dt)
-        al, be = ((1, 0), (0.5, 0), (1, 1), (-1.5, 0.75))[int(rng.integers(0, 4))] if kind != "i32" else (1, 0)
+        al, be = ((1, 0), (0.5, 0), (1, 1), (-1.5, 0.75))[int(rng.integers(0, 4))] if kind != "i32" else ((1, 0), (-3, 7), (2**31 - 1, 1))[int(rng.integers(0, 3))]
         opt = {"f32": "f32_asm", "f32nt": "f32_asm", "f64": "f64_asm", "i32": "i32_asm", "f64nt": "f64_asm"}[kind]
         for mode in ((0, 1) if kind != "i32" else (0,)):
             outs = {}
