@@ -210,19 +210,67 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     return ok
 
 
-def pack_limb_tiles(X):
-    """host model of the packing pass (limb_planes.h, tile-major form): int32 matrix X[x][k] -> for every 128-row tile and 32-k tile a
-    16-KiB block [plane p][k half h][row r][16 bytes] of balanced base-256 digits; rows / k zero-padded to multiples of 128 / 32"""
+def pack_limb_tiles(X, np_=4):
+    """host model of the packing pass (limb_planes.h, tile-major form): int32 / int64 matrix X[x][k] -> for every TR-row tile (128 for
+    int32, 64 for int64) and 32-k tile a 16-KiB block [plane p][k half h][row r][16 bytes] of balanced base-256 digits; rows / k
+    zero-padded to multiples of TR / 32"""
+    tr = 128 if np_ == 4 else 64
     x, k = X.shape
-    xp, kp = (x + 127) // 128 * 128, (k + 31) // 32 * 32
-    P = np.zeros((xp, kp), dtype=np.uint32)
-    P[:x, :k] = X.astype(np.int64).astype(np.uint32)
-    d = ((P.astype(np.uint64) + 0x00808080) & 0xffffffff).astype(np.uint32) ^ np.uint32(0x00808080)
-    out = np.zeros((xp // 128, kp // 32, 4, 2, 128, 16), dtype=np.uint8)
-    for pl in range(4):
-        digit = ((d >> np.uint32(8 * pl)) & np.uint32(0xff)).astype(np.uint8)          # [xp][kp]
-        out[:, :, pl] = digit.reshape(xp // 128, 128, kp // 32, 2, 16).transpose(0, 2, 3, 1, 4)
+    xp, kp = (x + tr - 1) // tr * tr, (k + 31) // 32 * 32
+    P = np.zeros((xp, kp), dtype=np.uint64)
+    mask = np.uint64((1 << (8 * np_)) - 1)
+    P[:x, :k] = X.astype(np.int64).view(np.uint64) & mask
+    bias = np.uint64(int("80" * (np_ - 1), 16))
+    d = ((P + bias) & mask) ^ bias
+    out = np.zeros((xp // tr, kp // 32, np_, 2, tr, 16), dtype=np.uint8)
+    for pl in range(np_):
+        digit = ((d >> np.uint64(8 * pl)) & np.uint64(0xff)).astype(np.uint8)          # [xp][kp]
+        out[:, :, pl] = digit.reshape(xp // tr, tr, kp // 32, 2, 16).transpose(0, 2, 3, 1, 4)
     return out.reshape(-1), xp, kp
+
+
+def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True):
+    """int64 GEMM kernel (i8_kernel.py, "i64_64x64x32") through the interpreter: C = A B mod 2^64 with full-range int64 operands"""
+    from . import i8_kernel as KI
+    g = KI.make("i64_64x64x32")
+    g.build()
+    c = g.c
+    rng = np.random.default_rng(seed)
+    A = rng.integers(-2**63, 2**63 - 1, (M, Kd), dtype=np.int64)
+    B = rng.integers(-2**63, 2**63 - 1, (Kd, N), dtype=np.int64)
+    ldc = ldc or N
+    Ap, Mp, Kp = pack_limb_tiles(A, 8)
+    Bp, Np_, _ = pack_limb_tiles(B.T.copy(), 8)
+    KT = Kp // 32
+    Cflat = np.full((M - 1) * ldc + N, 0x7bad7bad7bad7bad, dtype=np.uint64)
+    tm, tn = Mp // 64, Np_ // 64
+    table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
+    mem = Memory()
+    a_, b_, c_, t_ = mem.alloc(Ap), mem.alloc(Bp), mem.alloc(Cflat), mem.alloc(table)
+    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, 1, 0, 0) + b"\0" * 56
+    ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
+    t0 = time.time()
+    stats = None
+    for wg in range(len(table)):
+        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc)
+        w.run(order=order)
+        stats = w.waves[0].stats
+    full = np.full(M * ldc, 0x7bad7bad7bad7bad, dtype=np.uint64)
+    full[:len(Cflat)] = mem.get(c_, np.uint64, (len(Cflat),))
+    full = full.reshape(M, ldc)
+    Au, Bu = A.view(np.uint64), B.view(np.uint64)
+    want = np.zeros((M, N), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for k in range(Kd):
+            want += Au[:, k:k + 1] * Bu[k:k + 1, :]          # uint64 arithmetic wraps mod 2^64
+    ok = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(full[:, N:][:-1] == 0x7bad7bad7bad7bad)))
+    if verbose:
+        print(f"i64 M={M} N={N} K={Kd} ldc={ldc}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, bank-conflict cycles "
+              f"{stats['bank_conflict_cycles']}, {stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
+        if not ok:
+            bad = np.argwhere(full[:, :N] != want)
+            print("  first mismatches:", bad[:8].tolist(), hex(int(full[tuple(bad[0])])), hex(int(want[tuple(bad[0])])), "count", len(bad))
+    return ok
 
 
 def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_range=True, alpha=1, beta=0):

@@ -1,4 +1,4 @@
-"""int32 GEMM on the int8 matrix cores, hand-scheduled: the limb-product kernel of gemm_i32_mfma.hip (arithmetic mod 2^32 over
+"""int32 / int64 GEMM on the int8 matrix cores, hand-scheduled: the limb-product kernel of gemm_i32_mfma.hip (arithmetic mod 2^32 over
 balanced base-256 digits: 10 products of int8 planes per 32x32x32 block, four accumulator groups, one per power of 256) on the
 generator's program structure -- one wave per SIMD, every accumulator in AGPRs (4 groups x 4 blocks x 16 = all 256), 3-stage
 LDS ring with one barrier per K-tile, counted waits.
@@ -12,14 +12,28 @@ moves bytes 16 t + 4096 i, fully coalesced, one ds_write_b128 each, no address a
 16-byte chunks per half wave (conflict-free).  Workgroup tile 128x128, 2 x 2 waves of 64x64 (2 x 2 blocks); a K-tile is one
 k-step: 40 MFMAs.  The fragments of tile t+1 (16 ds_read_b128) are read after the barrier of tile t into the other of two
 register sets, so the loop is unrolled x6 (3 LDS stages x 2 fragment sets).  Any int32 alpha / beta (wrapping), K <= 8192 (no
-fold of the accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything else stays on the compiler-scheduled kernel."""
+fold of the accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything else stays on the compiler-scheduled kernel.
+
+int64 (`make("i64_64x64x32")`): eight planes, 36 products, eight accumulator groups = 128 AGPRs per 32x32 block, so a wave owns ONE
+block and the workgroup tile is 64x64 (blocks of [8 planes][2 halves][64 rows][16 bytes] = the same 16 KiB); the epilogue sums
+sext(G_s) << 8s in 64-bit (add-with-carry for s <= 3, shifted adds into the high word above); alpha = 1, beta = 0."""
 from .core import v, a, s, VCC
 from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
 
-# the 10 limb products with p + q <= 3, ordered so that neighbours hit different accumulator groups
-PRODUCTS = ((3, 0), (0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (2, 0), (2, 1))
-BLOCK = 16384      # bytes of one operand's (row tile, k tile) block
-PLANE = 4096
+BLOCK = 16384      # bytes of one operand's (row tile, k tile) block: planes x 2 k halves x tile rows x 16 (int32: 4 x 2 x 128, int64: 8 x 2 x 64)
+
+
+def products(np_):
+    """the limb products (p, q) with p + q < np_ (what survives mod 256^np_), ordered so that consecutive MFMAs hit different
+    accumulator groups s = p + q whenever another group still has products left"""
+    left = {sg: [(p_, sg - p_) for p_ in range(sg + 1)] for sg in range(np_)}
+    out, last = [], -1
+    while any(left.values()):
+        cands = sorted((sg for sg in left if left[sg] and sg != last), key=lambda sg: -len(left[sg])) or [sg for sg in left if left[sg]]
+        sg = cands[0]
+        out.append(left[sg].pop())
+        last = sg
+    return tuple(out)
 
 
 class GenI8(Gen):
@@ -35,16 +49,16 @@ class GenI8(Gen):
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
-        self.acc = [[p.aalloc(16) for _ in range(4)] for _ in range(4)]        # [power of 256][block = 2 i + n]
-        self.fa = [[[V(4) for _ in range(4)] for _ in range(2)] for _ in range(2)]   # [set][i][plane]
-        self.fb = [[[V(4) for _ in range(4)] for _ in range(2)] for _ in range(2)]   # [set][n][plane]
+        self.acc = [[p.aalloc(16) for _ in range(c.WB * c.WB)] for _ in range(c.NP)]        # [power of 256][block = WB * i + n]
+        self.fa = [[[V(4) for _ in range(c.NP)] for _ in range(c.WB)] for _ in range(2)]   # [set][i][plane]
+        self.fb = [[[V(4) for _ in range(c.NP)] for _ in range(c.WB)] for _ in range(2)]   # [set][n][plane]
         self.stA = [V(4) for _ in range(4)]
         self.stB = [V(4) for _ in range(4)]
         self.vW = [V() for _ in range(3)]
         self.RA = [V() for _ in range(3)]
         self.RB = [V() for _ in range(3)]
         self.vV = [V() for _ in range(4)]
-        self.vC = [V() for _ in range(2)]
+        self.vC = [V() for _ in range(c.WB)]
         if c.debug:
             self.srdD = S(4)
             self.s_dslot = S()
@@ -81,11 +95,11 @@ class GenI8(Gen):
         e("v_and_b32", lo, 31, lane)
         e("v_lshrrev_b32", hi, 5, lane)
         e("s_lshr_b32", st[2], self.s_wave, 1)
-        e("s_lshl_b32", self.s_wm0, st[2], 6)
+        e("s_mul_i32", self.s_wm0, st[2], 32 * c.WB)
         e("s_and_b32", st[2], self.s_wave, 1)
-        e("s_lshl_b32", self.s_wn0, st[2], 6)
-        # fragment reads: stage * STAGE [+ BLOCK for B] + plane * 4096 + hi * 2048 + (w?0 + 32 blk + lo) * 16
-        e("v_lshlrev_b32", t[5], 11, hi)
+        e("s_mul_i32", self.s_wn0, st[2], 32 * c.WB)
+        # fragment reads: stage * STAGE [+ BLOCK for B] + plane * PLANE + hi * (PLANE / 2) + (w?0 + 32 blk + lo) * 16
+        e("v_mul_u32_u24", t[5], c.PLANE // 2, hi)
         e("v_add_u32", t[6], self.s_wm0, lo)
         e("v_lshl_add_u32", t[6], t[6], 4, t[5])
         e("v_add_u32", t[7], self.s_wn0, lo)
@@ -98,13 +112,13 @@ class GenI8(Gen):
         for k in range(3):
             e("v_add_u32", self.vW[k], k * c.STAGE, t[5])
         for i in range(4):
-            e("v_add_u32", self.vV[i], PLANE * i, t[5])
+            e("v_add_u32", self.vV[i], 4096 * i, t[5])
         # ---- tile coordinates, descriptors ----
         e("s_waitcnt", lgkmcnt=0)
         e("s_and_b32", st[0], st[1], 0xffff)
         e("s_lshr_b32", st[1], st[1], 16)
-        e("s_lshl_b32", self.s_m0, st[0], 7)
-        e("s_lshl_b32", self.s_n0, st[1], 7)
+        e("s_mul_i32", self.s_m0, st[0], c.BM)
+        e("s_mul_i32", self.s_n0, st[1], c.BN)
         A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
         e("s_lshl_b32", st[3], self.s_lda, 14, comment="bytes of one row tile's panel: k tiles * 16 KiB")
         for srd, base, pid in ((self.srdA, A_, st[0]), (self.srdB, B_, st[1])):
@@ -115,12 +129,12 @@ class GenI8(Gen):
             e("s_and_b32", srd[1], srd[1], 0xffff)
             e("s_mov_b32", srd[2], st[3])
             e("s_mov_b32", srd[3], 0x00020000)
-        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
+        e("s_lshl_b32", self.s_ldc4, self.s_ldc, c.ESH)
         e("s_mov_b32", self.srdC[0], C_[0])
         e("s_and_b32", self.srdC[1], C_[1], 0xffff)
         e("s_sub_u32", st[0], self.s_M, 1)
         e("s_mul_i32", st[0], st[0], self.s_ldc4)
-        e("s_lshl_b32", st[2], self.s_N, 2)
+        e("s_lshl_b32", st[2], self.s_N, c.ESH)
         e("s_add_u32", self.srdC[2], st[0], st[2])
         e("s_mov_b32", self.srdC[3], 0x00020000)
         e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
@@ -131,8 +145,8 @@ class GenI8(Gen):
         self.run_ops(self.store_ops(0))
         self.issue_loads_all()
         self.advance_srds()
-        for sgrp in range(4):
-            for b in range(4):
+        for sgrp in range(c.NP):
+            for b in range(c.WB * c.WB):
                 for r in range(16):
                     e("v_accvgpr_write_b32", self.acc[sgrp][b][r], 0)
         self.lg_wait(None)
@@ -167,28 +181,28 @@ class GenI8(Gen):
         """staging registers -> LDS stage k: a lane-linear copy"""
         out = []
         for i in range(4):
-            out += [("vmwait", ("A", i)), ("ldsw", "ds_write_b128", (self.vW[k], self.stA[i]), {"offset": PLANE * i})]
+            out += [("vmwait", ("A", i)), ("ldsw", "ds_write_b128", (self.vW[k], self.stA[i]), {"offset": 4096 * i})]
         for i in range(4):
-            out += [("vmwait", ("B", i)), ("ldsw", "ds_write_b128", (self.vW[k], self.stB[i]), {"offset": BLOCK + PLANE * i})]
+            out += [("vmwait", ("B", i)), ("ldsw", "ds_write_b128", (self.vW[k], self.stB[i]), {"offset": BLOCK + 4096 * i})]
         return out
 
     def read_ops(self, k, fs):
         """the 16 fragments of the tile in LDS stage k -> register set fs, in the order the MFMAs want them"""
-        ops = []
-        for i in range(2):
-            for n in range(2):
+        c, ops = self.c, []
+        for i in range(c.WB):
+            for n in range(c.WB):
                 if n == 0:
-                    for pl in range(4):
-                        ops.append(("ldsr", "ds_read_b128", (self.fa[fs][i][pl], self.RA[k]), {"offset": PLANE * pl + 512 * i}, ("R", 0)))
+                    for pl in range(c.NP):
+                        ops.append(("ldsr", "ds_read_b128", (self.fa[fs][i][pl], self.RA[k]), {"offset": c.PLANE * pl + 512 * i}, ("R", 0)))
                 if i == 0:
-                    for pl in range(4):
-                        ops.append(("ldsr", "ds_read_b128", (self.fb[fs][n][pl], self.RB[k]), {"offset": PLANE * pl + 512 * n}, ("R", 0)))
+                    for pl in range(c.NP):
+                        ops.append(("ldsr", "ds_read_b128", (self.fb[fs][n][pl], self.RB[k]), {"offset": c.PLANE * pl + 512 * n}, ("R", 0)))
         return ops
 
     # ------------------------------------------------------------------ one K-tile: 40 MFMAs
     def tile_body(self, stage, fs):
         c, e = self.c, self.p.emit
-        NMF = 40
+        NMF = c.NMF
         gaps = {m: [] for m in range(-1, NMF)}
         nstage = (stage + 1) % 3
         # LDS stores of tile t+1 (staging registers -> stage t+1), each followed by the load of tile t+2 into the drained registers
@@ -210,10 +224,10 @@ class GenI8(Gen):
             gaps[min(bar + 1 + k * c.r_step, NMF - 2)].append(o)
         self.lg_wait({("R", 0)})
         m = 0
-        for i in range(2):
-            for (pa, qb) in PRODUCTS:
-                for n in range(2):
-                    acc = self.acc[pa + qb][2 * i + n]
+        for i in range(c.WB):
+            for (pa, qb) in c.PRODUCTS:
+                for n in range(c.WB):
+                    acc = self.acc[pa + qb][c.WB * i + n]
                     e("v_mfma_i32_32x32x32_i8", acc, self.fa[fs][i][pa], self.fb[fs][n][qb], acc)
                     for op in gaps[m]:
                         self.run_op(op)
@@ -240,6 +254,8 @@ class GenI8(Gen):
 
     # ------------------------------------------------------------------ epilogue: G0 + (G1 << 8) + (G2 << 16) + (G3 << 24)
     def epilogue(self):
+        if self.c.NP == 8:
+            return self.epilogue64()
         c, p = self.c, self.p
         e, t = p.emit, self.vt
         e("s_nop", 15)
@@ -285,18 +301,79 @@ class GenI8(Gen):
         e("s_endpgm")
 
 
+    def c_addr_setup(self):
+        if self.c.NP == 4:
+            return Gen.c_addr_setup(self)
+        # int64 elements: byte offset of (row m0 + wm0 + 4 hi, col n0 + wn0 + lo) with 8-byte elements
+        c, e, t, st = self.c, self.p.emit, self.vt, self.s_t
+        lane, lo, hi = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, v(0))
+        e("v_and_b32", lo, 31, lane)
+        e("v_lshrrev_b32", hi, 5, lane)
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("v_lshl_add_u32", t[3], hi, 2, st[0])
+        e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], lo)
+        e("v_lshl_add_u32", t[3], t[4], 3, t[3])
+        for n in range(c.WB):
+            e("v_add_u32", t[5], 32 * n, t[4])
+            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
+            e("v_add_u32", t[6], 256 * n, t[3])
+            e("v_mov_b32", t[7], 0x80000000)
+            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+
+    def epilogue64(self):
+        """C = sum over s of sext(G_s) << 8s (mod 2^64): 64-bit adds with carry for s <= 3, shifted adds into the high word above"""
+        c, p = self.c, self.p
+        e, t = p.emit, self.vt
+        e("s_nop", 15)
+        e("s_nop", 7)
+        e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        self.vmq.clear()
+        self.lgq.clear()
+        self.c_addr_setup()
+        lo, hi, g, x = t[0], t[1], t[2], t[3]
+        res = t[4:6]
+        for q in range(4):
+            for rr in range(4):
+                r = 4 * q + rr
+                e("v_accvgpr_read_b32", lo, self.acc[0][0][r])
+                e("v_ashrrev_i32", hi, 31, lo)
+                for sg in range(1, 4):
+                    e("v_accvgpr_read_b32", g, self.acc[sg][0][r])
+                    e("v_lshlrev_b32", x, 8 * sg, g)
+                    e("v_ashrrev_i32", g, 32 - 8 * sg, g)
+                    e("v_add_co_u32", lo, VCC, lo, x)
+                    e("v_addc_co_u32", hi, VCC, hi, g, VCC)
+                for sg in range(4, 8):
+                    e("v_accvgpr_read_b32", g, self.acc[sg][0][r])
+                    e("v_lshl_add_u32", hi, g, 8 * (sg - 4), hi)
+                e("v_mov_b32", res[0], lo)
+                e("v_mov_b32", res[1], hi)
+                e("buffer_store_dwordx2", v(res[0].idx, 2), self.vC[0], self.srdC, 0, offen=True)
+                self.c_step(0, q, rr)
+        e("s_endpgm")
+
+
 def make(name="i32_128x128x32", **over):
-    kw = dict(BM=128, BN=128, BK=32, exact=False, bar_gap=20)   # (scripts/i8_probe.py: 9 / 12 / 16 / 20 -> 275 / 279 / 283 / 286 Tint-op/s)
+    i64 = name.startswith("i64")
+    kw = dict(BM=64 if i64 else 128, BN=64 if i64 else 128, BK=32, exact=False, bar_gap=18 if i64 else 20)   # (scripts/i8_probe.py: barrier 9 / 12 / 16 / 20 -> 275 / 279 / 283 / 286 Tint-op/s, int32)
     kw.update(over)
     c = Cfg(name, **kw)
     c.dtype = "i8"
-    c.TM = c.TN = 2
-    c.NB, c.NMF, c.STAGE, c.NPA, c.NPB = 4, 40, 2 * BLOCK, 4, 4
+    c.NP = 8 if i64 else 4                     # digit planes = bytes of the element
+    c.WB = 1 if i64 else 2                     # 32x32 blocks per wave in each direction
+    c.PRODUCTS = products(c.NP)
+    c.PLANE = BLOCK // c.NP                    # bytes of one plane of a block: 2 k halves x tile rows x 16
+    c.ESH = 3 if i64 else 2                    # log2(bytes of an element of C)
+    c.TM = c.TN = c.WB
+    c.NB, c.NMF, c.STAGE, c.NPA, c.NPB = c.WB * c.WB, c.WB * c.WB * len(c.PRODUCTS), 2 * BLOCK, 4, 4
     c.lds_bytes = c.lds_alloc = 3 * c.STAGE
     return GenI8(c)
 
 
-CONFIGS = {"i32_128x128x32": {}}
+CONFIGS = {"i32_128x128x32": {}, "i64_64x64x32": {}}
 
 if __name__ == "__main__":
     import argparse
@@ -305,9 +382,10 @@ if __name__ == "__main__":
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    g = make()
-    g.build()
-    sym = "lh_i32_128x128x32"
-    with open(os.path.join(args.out, sym + ".s"), "w") as f:
-        f.write(kernel_text(g, sym))
-    print(sym, len(g.p.ins), "instructions")
+    for name in CONFIGS:
+        g = make(name)
+        g.build()
+        sym = "lh_" + name
+        with open(os.path.join(args.out, sym + ".s"), "w") as f:
+            f.write(kernel_text(g, sym))
+        print(sym, len(g.p.ins), "instructions")

@@ -413,6 +413,25 @@ class Workgroup:
                  "v_bfe_u32": lambda: (x >> (y & 31)) & ((np.uint64(1) << (z & 31)) - np.uint64(1)),
                  "v_add3_u32": lambda: x + y + z, "v_xad_u32": lambda: (x ^ y) + z}[op]()
             self.wr_v(w, A[0], (r & 0xffffffff).astype(U32))
+        elif op == "v_ashrrev_i32":
+            x = rv(w, A[1]).astype(np.int64) & 31
+            y = rv(w, A[2]).astype(np.uint32).view(np.int32).astype(np.int64)
+            self.wr_v(w, A[0], ((y >> x) & 0xffffffff).astype(U32))
+        elif op in ("v_add_co_u32", "v_addc_co_u32"):
+            # D, carry-out (vcc or an SGPR pair), S0, S1 [, carry-in]
+            x, y = rv(w, A[2]).astype(np.uint64), rv(w, A[3]).astype(np.uint64)
+            cin = np.zeros(LANES, dtype=np.uint64)
+            if op == "v_addc_co_u32":
+                mk = self.rd_s64(w, A[4])
+                cin = np.array([(mk >> l) & 1 for l in range(LANES)], dtype=np.uint64)
+            r = x + y + cin
+            cout = 0
+            act = w.execmask()
+            for l in range(LANES):
+                if act[l] and int(r[l]) >> 32:
+                    cout |= 1 << l
+            self.wr_v(w, A[0], (r & np.uint64(0xffffffff)).astype(U32))
+            self.wr_s64(w, A[1], cout)
         elif op == "v_readfirstlane_b32":
             k_ = (A[1].kind, A[1].idx)
             if self.check and k_ in w.valu_wr_state and w.state - w.valu_wr_state[k_] < 3:

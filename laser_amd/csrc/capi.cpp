@@ -429,7 +429,9 @@ hipError_t run_gemm<int64_t>(const GemmArgs<int64_t> &a, hipStream_t s) {
     void *ws = nullptr;
     hipError_t e = hipMallocAsync(&ws, gemm_i64_mfma_workspace_bytes(a.M, a.N, a.K), s);
     if (e != hipSuccess) return e;
-    e = launch_gemm_i64_mfma(a, ws, s);
+    g_last_i32_asm = 0;
+    e = launch_gemm_i64_asm(a, ws, s);      // the hand-scheduled kernel (i8_kernel.py "i64_64x64x32") when eligible
+    if (e == hipErrorNotSupported) e = launch_gemm_i64_mfma(a, ws, s);
     hipError_t e2 = hipFreeAsync(ws, s);
     return e != hipSuccess ? e : e2;
   }

@@ -127,6 +127,7 @@ void asm_kernels_release();   // unload the assembly kernels' code objects (lase
 hipError_t launch_gemm_f64_asm(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
 extern std::atomic<int> g_f64_asm, g_last_f64_asm;
 hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
+hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 extern std::atomic<int> g_i32_asm, g_last_i32_asm;
 extern std::atomic<int> g_f32_asm;       // 1 default; 0 = never; 2 = whenever the kernel can (no tile-count rule: tests)
 extern std::atomic<int> g_last_f32_asm;  // 0 = the last f32 GEMM launch was a compiler-scheduled kernel, 1 / 2 = laser-order / fast assembly kernel

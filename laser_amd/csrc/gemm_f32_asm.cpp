@@ -19,7 +19,7 @@
 
 namespace laser_hip {
 
-std::atomic<int> g_i32_asm{1};       // int32 limb GEMM: the hand-scheduled kernel when eligible (0 = the compiler-scheduled one)
+std::atomic<int> g_i32_asm{1};       // int32 / int64 limb GEMMs: the hand-scheduled kernels when eligible (0 = the compiler-scheduled ones)
 std::atomic<int> g_last_i32_asm{0};
 std::atomic<int> g_f64_asm{1};       // float64: same meaning as g_f32_asm
 std::atomic<int> g_last_f64_asm{0};  // diagnostics: 0 = compiler-scheduled kernel; 1 + index into kKernels otherwise
@@ -46,7 +46,8 @@ struct KernelInfo {
 // [20]: int32 via int8 limb planes (laser_amd/asmgen/i8_kernel.py)
 // [21..24]: convolution with fewer output channels: 128x128x32 (laser-order / one chain), 64x128x32 (same)
 // [25..28]: float64 with B passed transposed: 128x128x16 (laser-order / one chain), 64x64x16 (same)
-constexpr int kNumKernels = 29;
+// [29]: int64 via eight int8 limb planes (i8_kernel.py "i64_64x64x32")
+constexpr int kNumKernels = 30;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0},
@@ -62,7 +63,8 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_conv3x3_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0}, {"lh_f32_conv3x3_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0},
     {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},
     {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.92, 0.92, 8.0},     {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.93, 0.93, 8.0},
-    {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0}};
+    {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0},
+    {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0}};
 
 struct DeviceModule {
   hipModule_t mod = nullptr;
@@ -271,9 +273,9 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0 || Mpad > 0xffff * 128ll || Npad > 0xffff * 128ll)
     return hipErrorNotSupported;
   int8_t *Ap = (int8_t *)ws, *Bp = Ap + 4 * Mpad * Kpad;
-  hipError_t e = launch_limb_planes<int32_t>(Ap, a.A, a.M, a.K, a.rsA, a.csA, Mpad, Kpad, s, 1);
+  hipError_t e = launch_limb_planes<int32_t>(Ap, a.A, a.M, a.K, a.rsA, a.csA, Mpad, Kpad, s, 128);
   if (e != hipSuccess) return e;
-  e = launch_limb_planes<int32_t>(Bp, a.B, a.N, a.K, a.csB, a.rsB, Npad, Kpad, s, 1);
+  e = launch_limb_planes<int32_t>(Bp, a.B, a.N, a.K, a.csB, a.rsB, Npad, Kpad, s, 128);
   if (e != hipSuccess) return e;
   int dev = 0;
   e = hipGetDevice(&dev);
@@ -313,6 +315,61 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m->fn[20], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
   if (e == hipSuccess) g_last_i32_asm = 21;
+  return e;
+}
+
+// int64 GEMM mod 2^64 (gemm_i64_mfma.hip's arithmetic; kernel "i64_64x64x32" of laser_amd/asmgen/i8_kernel.py): eight tile-major
+// digit planes in `ws` (>= 8 * (rup(M,64) + rup(N,64)) * rup(K,32) bytes), one launch.  alpha = 1, beta = 0, K <= 8192.
+hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t s) {
+  if (!g_i32_asm) return hipErrorNotSupported;
+  if (a.batch != 1 || a.alpha != 1 || a.beta != 0 || a.csC != 1 || a.rsC < a.N) return hipErrorNotSupported;
+  if (a.M < 1 || a.N < 1 || a.K < 1 || a.K > 8192) return hipErrorNotSupported;
+  const int64_t Mpad = (a.M + 63) / 64 * 64, Npad = (a.N + 63) / 64 * 64, Kpad = (a.K + 31) / 32 * 32;
+  const int64_t tiles = (Mpad / 64) * (Npad / 64);
+  if (g_i32_asm < 2 && tiles < 128) return hipErrorNotSupported;
+  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 8.0 > 2147483648.0 || Mpad > 0xffff * 64ll || Npad > 0xffff * 64ll)
+    return hipErrorNotSupported;
+  int8_t *Ap = (int8_t *)ws, *Bp = Ap + 8 * Mpad * Kpad;
+  hipError_t e = launch_limb_planes<int64_t>(Ap, a.A, a.M, a.K, a.rsA, a.csA, Mpad, Kpad, s, 64);
+  if (e != hipSuccess) return e;
+  e = launch_limb_planes<int64_t>(Bp, a.B, a.N, a.K, a.csB, a.rsB, Npad, Kpad, s, 64);
+  if (e != hipSuccess) return e;
+  int dev = 0;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(g_mods_mu);
+  DeviceModule *m = nullptr;
+  e = get_module(dev, &m);
+  if (e != hipSuccess) return e;
+  const int tiles_m = (int)(Mpad / 64), tiles_n = (int)(Npad / 64), group_m = 8;
+  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
+  auto it = m->tables.find(key);
+  if (it == m->tables.end()) {
+    auto *host = new std::vector<uint32_t>();
+    make_table(tiles_m, tiles_n, group_m, *host);
+    uint32_t *devp = nullptr;
+    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      if (devp) (void)hipFree(devp);
+      delete host;
+      return e;
+    }
+    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
+  }
+  KernArgs ka;
+  ka.A = Ap; ka.B = Bp; ka.C = a.C;
+  ka.table = it->second.first;
+  ka.lda = (uint32_t)(Kpad / 32); ka.ldb = 0; ka.ldc = (uint32_t)a.rsC;
+  ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)Kpad;
+  ka.alpha = 0.0f; ka.beta = 0.0f;
+  ka.dbg = nullptr;
+  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
+  ka.bsB_bytes = ka.bsC_bytes = 0;
+  size_t sz = sizeof(ka);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(m->fn[29], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  if (e == hipSuccess) g_last_i32_asm = 30;
   return e;
 }
 

@@ -79,15 +79,16 @@ __global__ void __launch_bounds__(LP_THREADS) limb_planes_tiled_kernel(int8_t *_
   }
   typedef __attribute__((ext_vector_type(4))) int lp_i32x4;
   const int64_t plane = Xpad * Kpad;
-  // tile_major (the hand-scheduled int32 kernel, laser_amd/asmgen/i8_kernel.py; Xpad % 128 == 0, Kpad % 32 == 0): for every
-  // 128-row tile and 32-k tile one contiguous block [plane][k half][row][16 bytes] -- the global -> LDS stage of the GEMM is then a
-  // lane-linear copy and a fragment read is 32 consecutive chunks
-  const int64_t tbase = ((x >> 7) * (Kpad >> 5) + (kq >> 1)) * (int64_t)(4 * NW * 4096) + (kq & 1) * 2048 + (x & 127) * 16;
+  // tile_major = TR > 0 (the hand-scheduled kernels of laser_amd/asmgen/i8_kernel.py: TR = 128 rows for int32, 64 for int64;
+  // Xpad % TR == 0, Kpad % 32 == 0): for every TR-row tile and 32-k tile one contiguous 16-KiB block [plane][k half][row][16
+  // bytes] -- the global -> LDS stage of the GEMM is then a lane-linear copy and a fragment read is 32 consecutive chunks
+  const int TR = tile_major > 0 ? tile_major : 1;
+  const int64_t tbase = ((x / TR) * (Kpad >> 5) + (kq >> 1)) * (int64_t)(4 * NW * 2 * TR * 16) + (kq & 1) * (TR * 16) + (x % TR) * 16;
 #pragma unroll
   for (int p = 0; p < 4 * NW; p++) {
     const lp_i32x4 q = {(int)out[p][0], (int)out[p][1], (int)out[p][2], (int)out[p][3]};
     if (tile_major)
-      *reinterpret_cast<lp_i32x4 *>(planes + tbase + p * 4096) = q;
+      *reinterpret_cast<lp_i32x4 *>(planes + tbase + (int64_t)p * (2 * TR * 16)) = q;
     else
       *reinterpret_cast<lp_i32x4 *>(planes + p * plane + x * Kpad + kq * 16) = q;
   }

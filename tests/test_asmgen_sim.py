@@ -106,6 +106,12 @@ def test_i32_limb_kernel_exact_in_the_interpreter(M, N, Kd, ldc):
     assert C.run_case_i32(M, N, Kd, ldc=ldc, verbose=False)
 
 
+@pytest.mark.parametrize("M,N,Kd,ldc", [(64, 64, 64, None), (70, 90, 100, 93)])
+def test_i64_limb_kernel_exact_in_the_interpreter(M, N, Kd, ldc):
+    """int64 GEMM mod 2^64 on eight int8 digit planes (36 limb products, 64-bit recombination with carries), full-range operands"""
+    assert C.run_case_i64(M, N, Kd, ldc=ldc, verbose=False)
+
+
 def test_interpreter_rejects_a_read_of_a_register_still_loading():
     """the checks are live: dropping the counted waits must be caught, not silently pass"""
     from laser_amd.asmgen.sim import SimError

@@ -1389,3 +1389,41 @@ def test_f32_asm_batched_and_slice_parallel(la, oracle):
         assert (used != 0) == (asm == 1), (asm, used)
     assert torch.equal(res[1], res[0])
     assert np.array_equal(res[1].cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
+
+
+def test_i64_asm_kernel_bit_exact(la, oracle):
+    """The hand-scheduled int64 limb kernel (i8_kernel.py "i64_64x64x32"; option i32_asm covers both integer kernels): == the
+    compiler-scheduled limb kernel == the oracle, full-range operands (wrap-around mod 2^64), ragged shapes, strided views; K > 8192
+    and alpha / beta fall through."""
+    import torch
+    rng = np.random.default_rng(92)
+    info = np.iinfo(np.int64)
+    for (M, N, K) in [(128, 128, 256), (130, 257, 100), (1000, 900, 530), (1024, 1024, 512), (300, 200, 8192)]:
+        A = rng.integers(info.min, info.max, (M, K), dtype=np.int64)
+        B = rng.integers(info.min, info.max, (K, N), dtype=np.int64)
+        want = oracle.matmul(A, B)
+        for dA, dB in ((torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()),
+                       (torch.from_numpy(np.asfortranarray(A)).cuda(), torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t())):
+            outs = {}
+            for asm in (2, 0):
+                la.set_option("i32_asm", asm)
+                try:
+                    wide = torch.full((M, N + 5), 77, dtype=torch.int64, device="cuda")
+                    la.matmul(dA, dB, 1, 0, wide[:, :N])
+                    assert (la.get_option("last_i32_asm") != 0) == (asm == 2), (M, N, K, asm)
+                    outs[asm] = wide
+                finally:
+                    la.set_option("i32_asm", 1)
+            assert torch.equal(outs[2], outs[0]), (M, N, K)
+            assert (outs[2][:, N:] == 77).all(), "wrote outside C"
+            assert np.array_equal(outs[2][:, :N].cpu().numpy(), want), (M, N, K)
+    A = torch.from_numpy(rng.integers(info.min, info.max, (256, 8200), dtype=np.int64)).cuda()
+    B = torch.from_numpy(rng.integers(info.min, info.max, (8200, 256), dtype=np.int64)).cuda()
+    la.set_option("i32_asm", 2)
+    try:
+        la.matmul(A, B)
+        assert la.get_option("last_i32_asm") == 0          # K > 8192
+        la.matmul(A[:, :512].contiguous(), B[:512].contiguous(), 3, 0)
+        assert la.get_option("last_i32_asm") == 0          # alpha != 1
+    finally:
+        la.set_option("i32_asm", 1)
