@@ -125,6 +125,35 @@ hipError_t get_module(int dev, DeviceModule **out) {
   return hipSuccess;
 }
 
+// Device copy of the tile table for a (tiles_m x tiles_n) grid, cached per device until laser_hip_finalize: group_m > 0 = the
+// XCD-aware grouped raster of make_table, group_m == 0 = plain order (pid_n-major; the convolution's few tiles per image).
+// The upload is stream-ordered ahead of the launch; the host copy stays alive with the cache entry.
+hipError_t tile_table(DeviceModule *m, int tiles_m, int tiles_n, int group_m, hipStream_t s, const uint32_t **out) {
+  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
+  auto it = m->tables.find(key);
+  if (it == m->tables.end()) {
+    auto *host = new std::vector<uint32_t>();
+    if (group_m > 0) {
+      make_table(tiles_m, tiles_n, group_m, *host);
+    } else {
+      host->reserve((size_t)tiles_m * tiles_n);
+      for (int pn = 0; pn < tiles_n; pn++)
+        for (int pm = 0; pm < tiles_m; pm++) host->push_back((uint32_t)pm | ((uint32_t)pn << 16));
+    }
+    uint32_t *devp = nullptr;
+    hipError_t e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      if (devp) (void)hipFree(devp);
+      delete host;
+      return e;
+    }
+    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
+  }
+  *out = it->second.first;
+  return hipSuccess;
+}
+
 }  // namespace
 
 // laser_hip_finalize: unload the code objects and free the tile tables of every device that used them
@@ -208,31 +237,14 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int group_m = (ki.bm >= 2 * ki.bn) ? 4 : 8;
-  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
-  auto it = m->tables.find(key);
-  if (it == m->tables.end()) {
-    auto *host = new std::vector<uint32_t>();
-    make_table(tiles_m, tiles_n, group_m, *host);
-    uint32_t *devp = nullptr;
-    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
-    if (e != hipSuccess) {
-      delete host;
-      return e;
-    }
-    // stream-ordered ahead of the launch; the host copy stays alive with the cache entry
-    e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) {
-      (void)hipFree(devp);
-      delete host;
-      return e;
-    }
-    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
-  }
+  const uint32_t *table = nullptr;
+  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
+  if (e != hipSuccess) return e;
   KernArgs ka;
   ka.A = a.A;
   ka.B = a.B;
   ka.C = a.C;
-  ka.table = it->second.first;
+  ka.table = table;
   ka.lda = (uint32_t)a.rsA;
   ka.ldb = (uint32_t)ldb;
   ka.ldc = (uint32_t)a.rsC;
@@ -285,24 +297,12 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int tiles_m = (int)(Mpad / 128), tiles_n = (int)(Npad / 128), group_m = 8;
-  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
-  auto it = m->tables.find(key);
-  if (it == m->tables.end()) {
-    auto *host = new std::vector<uint32_t>();
-    make_table(tiles_m, tiles_n, group_m, *host);
-    uint32_t *devp = nullptr;
-    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) {
-      if (devp) (void)hipFree(devp);
-      delete host;
-      return e;
-    }
-    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
-  }
+  const uint32_t *table = nullptr;
+  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
+  if (e != hipSuccess) return e;
   KernArgs ka;
   ka.A = Ap; ka.B = Bp; ka.C = a.C;
-  ka.table = it->second.first;
+  ka.table = table;
   ka.lda = (uint32_t)(Kpad / 32); ka.ldb = 0; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)Kpad;
   static_assert(sizeof(float) == sizeof(int32_t), "");
@@ -342,24 +342,12 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int tiles_m = (int)(Mpad / 64), tiles_n = (int)(Npad / 64), group_m = 8;
-  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
-  auto it = m->tables.find(key);
-  if (it == m->tables.end()) {
-    auto *host = new std::vector<uint32_t>();
-    make_table(tiles_m, tiles_n, group_m, *host);
-    uint32_t *devp = nullptr;
-    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) {
-      if (devp) (void)hipFree(devp);
-      delete host;
-      return e;
-    }
-    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
-  }
+  const uint32_t *table = nullptr;
+  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
+  if (e != hipSuccess) return e;
   KernArgs ka;
   ka.A = Ap; ka.B = Bp; ka.C = a.C;
-  ka.table = it->second.first;
+  ka.table = table;
   ka.lda = (uint32_t)(Kpad / 32); ka.ldb = 0; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)Kpad;
   ka.alpha = 0.0f; ka.beta = 0.0f;
@@ -412,24 +400,12 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int group_m = 8;
-  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
-  auto it = m->tables.find(key);
-  if (it == m->tables.end()) {
-    auto *host = new std::vector<uint32_t>();
-    make_table(tiles_m, tiles_n, group_m, *host);
-    uint32_t *devp = nullptr;
-    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) {
-      if (devp) (void)hipFree(devp);
-      delete host;
-      return e;
-    }
-    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
-  }
+  const uint32_t *table = nullptr;
+  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
+  if (e != hipSuccess) return e;
   KernArgs ka;
   ka.A = a.A; ka.B = a.B; ka.C = a.C;
-  ka.table = it->second.first;
+  ka.table = table;
   ka.lda = (uint32_t)a.rsA; ka.ldb = (uint32_t)ldb; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)a.K;
   ka.alpha = 1.0f; ka.beta = 0.0f;
@@ -489,28 +465,15 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
-  // (one image's tiles are few: plain row-major order of the tile ids keeps an image's pixels together in an XCD's L2)
-  const auto key = std::make_tuple(tiles_m, tiles_n, 1 << 20);
-  auto it = m->tables.find(key);
-  if (it == m->tables.end()) {
-    auto *host = new std::vector<uint32_t>((size_t)tiles);
-    for (int pn = 0, i = 0; pn < tiles_n; pn++)
-      for (int pm = 0; pm < tiles_m; pm++) (*host)[(size_t)i++] = (uint32_t)pm | ((uint32_t)pn << 16);
-    uint32_t *devp = nullptr;
-    e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) {
-      if (devp) (void)hipFree(devp);
-      delete host;
-      return e;
-    }
-    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
-  }
+  // (one image's tiles are few: plain order of the tile ids keeps an image's pixels together in an XCD's L2)
+  const uint32_t *table = nullptr;
+  e = tile_table(m, tiles_m, tiles_n, 0, s, &table);
+  if (e != hipSuccess) return e;
   KernArgs ka;
   ka.A = a.A;
   ka.B = a.B;
   ka.C = a.C;
-  ka.table = it->second.first;
+  ka.table = table;
   ka.lda = (uint32_t)a.rsA;
   ka.ldb = 0;
   ka.ldc = (uint32_t)npix;
