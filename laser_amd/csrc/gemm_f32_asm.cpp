@@ -183,7 +183,9 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (a.batch < 1 || a.batch > 65535 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
   if (a.batch > 1 && (a.bsA < 0 || a.bsB < 0 || a.bsC < 0)) return hipErrorNotSupported;
   if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
-  if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
+  // (tile-padded pre-pack images -- Mext / Next / Kext beyond M / N / K, gemm_prepacked.nim:63-292 -- are plain padded row-major
+  // copies: the kernels bound every access by M, N, K themselves and never need the padding)
+  if (a.Mext < a.M || a.Next < a.N || a.Kext < a.K) return hipErrorNotSupported;
   // B: row-major-like (unit column stride), or passed transposed (unit row stride: every column is k-contiguous)
   const bool nt = a.csB != 1 && a.rsB == 1;
   if (!nt && a.csB != 1) return hipErrorNotSupported;
@@ -370,7 +372,9 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   const bool nt = a.csB != 1 && a.rsB == 1;
   if (!nt && a.csB != 1) return hipErrorNotSupported;
   const int64_t ldb = nt ? a.csB : a.rsB;
-  if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorNotSupported;
+  // (tile-padded pre-pack images -- Mext / Next / Kext beyond M / N / K, gemm_prepacked.nim:63-292 -- are plain padded row-major
+  // copies: the kernels bound every access by M, N, K themselves and never need the padding)
+  if (a.Mext < a.M || a.Next < a.N || a.Kext < a.K) return hipErrorNotSupported;
   if (a.rsA < a.K || ldb < (nt ? a.K : a.N) || a.rsC < a.N || a.K < 2 || a.K % 2 != 0) return hipErrorNotSupported;   // 16-byte pieces = 2 k
   if ((double)a.rsA * 8.0 * 128 >= 4.0e9 || (nt ? (double)ldb * 8.0 * 128 : (double)a.K * (double)ldb * 8.0) >= 4.0e9) return hipErrorNotSupported;
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 8.0 > 2147483648.0) return hipErrorNotSupported;

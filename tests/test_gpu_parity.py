@@ -395,6 +395,24 @@ def test_prepacked_ragged_shapes(la, oracle):
         la.gemm_prepack_release(pb)
 
 
+def test_prepacked_large_runs_on_the_assembly_kernels(la, oracle):
+    """gemm_prepack* + gemm_packed at a size the hand-scheduled kernels take: the tile-padded panel images are plain padded
+    row-major copies, so the packed call runs on the same kernels as gemm_strided, with the same bits."""
+    rng = np.random.default_rng(171)
+    M, N, K = 1030, 1100, 1540
+    A = rand(rng, (M, K), np.float32)
+    B = rand(rng, (K, N), np.float32)
+    pa = la.aligned_host_buffer(la.gemm_prepackA_mem_required(np.float32, M, N, K))
+    pb = la.aligned_host_buffer(la.gemm_prepackB_mem_required(np.float32, M, N, K))
+    la.gemm_prepackA(pa, M, N, K, A, K, 1)
+    la.gemm_prepackB(pb, M, N, K, B, N, 1)
+    C = np.zeros((M, N), dtype=np.float32)
+    la.gemm_packed(M, N, K, 1, pa, pb, 0, C, N, 1)
+    assert la.last_f32_asm() != 0
+    assert np.array_equal(C, oracle.matmul(A, B))
+    la.gemm_prepack_release(pa); la.gemm_prepack_release(pb)
+
+
 def test_transposes(la, oracle):
     import torch
     rng = np.random.default_rng(18)
