@@ -27,7 +27,7 @@ def reference(A, B, kc, alpha=1.0, beta=0.0, C0=None):
 
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
-             batch=1):
+             batch=1, bias=None, act=0):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart"""
     g = K.make(name, **(over or {}))
     g.build()
@@ -68,8 +68,18 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call), mem.alloc(table)
+    # fused epilogue: bias = "row" (1 x N, row stride 0), "col" (M x 1, column stride 0) or "full" (M x N, padded rows); act 1 = relu
+    bias_ptr, rsb, csb, Bias = 0, 0, 0, None
+    if bias:
+        if bias == "row":
+            Bias = rng.uniform(-1, 1, (1, N)).astype(np.float32); rsb, csb = 0, 1
+        elif bias == "col":
+            Bias = rng.uniform(-1, 1, (M, 1)).astype(np.float32); rsb, csb = 1, 0
+        else:
+            Bias = rng.uniform(-1, 1, (M, N)).astype(np.float32); rsb, csb = N, 1
+        bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
-    ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4)
+    ka += struct.pack("<Q", LA * 4) + struct.pack("<QIII", bias_ptr, rsb, csb, act) + b"\0" * 12 + struct.pack("<QQ", LB * 4, LC * 4)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
@@ -86,6 +96,10 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         full[:LC] = got[b * LC:(b + 1) * LC]
         Cout = full.reshape(M, ldc)[:, :N]
         want = reference(As[b], Bs[b], 512 if c.exact else 0, alpha, beta, C0s[b])
+        if Bias is not None:
+            want = (want + np.broadcast_to(Bias, (M, N))).astype(np.float32)
+        if act == 1:
+            want = np.where(want > 0, want, np.float32(0)).astype(np.float32)
         ok &= bool(np.array_equal(Cout, want))
         if ldc > N:
             pad_ok &= bool(np.all(np.isnan(full.reshape(M, ldc)[:, N:][:-1])))

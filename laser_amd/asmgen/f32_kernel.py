@@ -101,6 +101,7 @@ CONFIGS = {
 KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 8, 16, 24, 32, 36, 40, 44, 48, 52, 64
 # convolution kernels only: H W oW pH pW Cin Npix magic(oW) | shift(oW) - bsB(bytes, u64) | bsC(bytes, u64)
 KA_CONV0, KA_CONV1, KA_CONV2 = 72, 104, 120
+KA_BIAS, KA_EPI = 80, 88   # GEMM kernels: bias pointer (u64; 0 = none); rowStrideBias, colStrideBias (elements), activation (0 none / 1 relu), -
 KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's share the convolution kernels' slots at 112 / 120
 KERNARG_SIZE = 128
 
@@ -166,6 +167,8 @@ class Gen:
         self.s_em = [S(2) for _ in range(4)]   # K % 4 != 0: lanes whose element j of their piece is real data in the last K-tile
         if not c.conv:
             self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
+            self.srdBias = S(4)                                      # fused epilogue: the bias view (base, -, bytes, flags)
+            self.s_epi = S(4, align=4)                               # rowStrideBias, colStrideBias (elements), activation, -
         self.vVA = [V() for _ in range(c.NPA)]
         self.vVB = [V() for _ in range(c.NPB)] if not c.conv else []
         self.vC = [V() for _ in range(c.TN)]
@@ -277,6 +280,8 @@ class Gen:
             # operand b at base + b * batch stride (bytes, 64-bit; 0 for plain launches)
             e("s_load_dwordx2", self.s_bsA, s(0, 2), KA_BSA)
             e("s_load_dwordx4", self.s_bsBC, s(0, 2), KA_CONV1 + 8)
+            e("s_load_dwordx2", self.srdBias.sub(0, 2), s(0, 2), KA_BIAS)
+            e("s_load_dwordx4", self.s_epi, s(0, 2), KA_EPI)
             e("s_waitcnt", lgkmcnt=0)
             for ptr, bs in ((self.ka0.sub(0, 2), self.s_bsA), (self.ka0.sub(2, 2), self.s_bsBC.sub(0, 2)), (self.ka0.sub(4, 2), self.s_bsBC.sub(2, 2))):
                 e("s_mul_i32", st[2], s(3), bs[0])
@@ -1227,6 +1232,99 @@ class Gen:
                         e("v_accvgpr_write_b32", self.run[i * c.TN + n][4 * q + rr], x)
         p.place(skip)
 
+    def fused_epilogue(self):
+        """bias pointer != 0 or activation != 0: C = act((run | 0) + alpha * sum + bias), the bias added with one more rounding after
+        the last slice, relu = max(x, 0) (the reference plans this fusion: README.md:238-242, TODOs gemm.nim:196); a path of its own so
+        that the plain epilogue carries none of it.  One-chain kernels: beta == 0 only (the launcher guarantees it).  Ends the program."""
+        c, p = self.c, self.p
+        e, t, st = p.emit, self.vt, self.s_t
+        plain = p.label("plain")
+        e("s_or_b32", st[0], self.srdBias[0], self.srdBias[1])
+        e("s_or_b32", st[1], st[0], self.s_epi[2])
+        e("s_cmp_eq_u32", st[1], 0)
+        e("s_cbranch_scc1", plain)
+        # bias descriptor: a null pointer gets a zero-size buffer (every load returns 0: x + 0 is x)
+        e("s_and_b32", self.srdBias[1], self.srdBias[1], 0xffff)
+        # bytes of the bias view: ((M - 1) * rowStride + (N - 1) * colStride + 1) * 4 -- rows / columns of a ragged tile beyond it read 0
+        e("s_sub_u32", st[2], self.s_M, 1)
+        e("s_mul_i32", st[2], st[2], self.s_epi[0])
+        e("s_sub_u32", st[3], self.s_N, 1)
+        e("s_mul_i32", st[3], st[3], self.s_epi[1])
+        e("s_add_u32", st[2], st[2], st[3])
+        e("s_add_u32", st[2], st[2], 1)
+        e("s_lshl_b32", st[2], st[2], 2)
+        e("s_cmp_eq_u32", st[0], 0)
+        e("s_cselect_b32", self.srdBias[2], 0, st[2])
+        e("s_mov_b32", self.srdBias[3], 0x00020000)
+        e("s_lshl_b32", st[2], self.s_epi[0], 2)          # rowStrideBias * 4
+        e("s_mul_i32", st[3], st[2], 5)
+        self.c_addr_setup()
+        # bias offsets of this lane's first element of block column n: (row * rsBias + col * csBias) * 4, rows / cols as in c_addr_setup
+        lane, lo, hi = t[0], t[1], t[2]
+        vB = [self.vT[0][12 + n] if n < 4 else None for n in range(c.TN)]
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("v_lshl_add_u32", t[3], hi, 2, st[0])
+        e("v_mul_lo_u32", t[3], t[3], st[2])
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], lo)
+        e("s_lshl_b32", st[4], self.s_epi[1], 2)          # colStrideBias * 4
+        e("v_mul_lo_u32", t[4], t[4], st[4])
+        e("v_add_u32", t[3], t[3], t[4])
+        e("s_lshl_b32", st[4], st[4], 5)                  # 32 columns further
+        for n in range(c.TN):
+            if n == 0:
+                e("v_mov_b32", vB[0], t[3])
+            else:
+                e("v_add_u32", vB[n], st[4], vB[n - 1])
+        P = self.vT[0]
+        norelu = None
+        for i in range(c.TM):
+            for q in range(4):
+                # this lane's 4 rows x TN block columns of the quad: bias loads first (one wait), then the arithmetic
+                per = c.TN
+                for rr in range(4):
+                    for n in range(c.TN):
+                        if rr * per + n < 12:
+                            e("buffer_load_dword", P[rr * per + n], vB[n], self.srdBias, 0, offen=True)
+                    if rr < 3:
+                        for n in range(c.TN):
+                            e("v_add_u32", vB[n], st[2], vB[n])
+                assert 4 * per <= 12 or c.TN == 4
+                if c.TN == 4:      # 16 values per quad do not fit beside the offsets: the last row in a second batch
+                    pass
+                e("s_waitcnt", vmcnt=0)
+                for rr in range(4):
+                    r = 4 * q + rr
+                    if c.TN == 4 and rr == 3:
+                        for n in range(c.TN):
+                            e("buffer_load_dword", P[n], vB[n], self.srdBias, 0, offen=True)
+                        e("s_waitcnt", vmcnt=0)
+                    for n in range(c.TN):
+                        b = i * c.TN + n
+                        tt, uu = t[(2 * n) % 8], t[(2 * n + 1) % 8]
+                        bias = P[n] if (c.TN == 4 and rr == 3) else P[rr * per + n]
+                        e("v_accvgpr_read_b32", tt, self.acc[b][r])
+                        e("v_mul_f32", tt, self.s_alpha, tt)
+                        if c.exact:
+                            e("v_accvgpr_read_b32", uu, self.run[b][r])
+                            e("v_add_f32", tt, uu, tt)
+                        e("v_add_f32", tt, bias, tt)
+                    skip = p.label("norelu")
+                    e("s_cmp_lg_u32", self.s_epi[2], 1)
+                    e("s_cbranch_scc1", skip)
+                    for n in range(c.TN):
+                        e("v_max_f32", t[(2 * n) % 8], 0, t[(2 * n) % 8])
+                    p.place(skip)
+                    for n in range(c.TN):
+                        e("buffer_store_dword", t[(2 * n) % 8], self.vC[n], self.srdC, 0, offen=True)
+                    self.c_step(i, q, rr)
+                # bias offsets: on to the next quad (rows 8 apart: + 5 rows from the last row of this one)
+                if not (i == c.TM - 1 and q == 3):
+                    for n in range(c.TN):
+                        e("v_add_u32", vB[n], st[3], vB[n])
+        e("s_endpgm")
+        p.place(plain)
+
     def epilogue(self):
         """C = (beta * C0 + alpha * slice sums in order) -- gemm_ukernel_generic.nim:53-76, predicated by the descriptor's bounds check"""
         c, p = self.c, self.p
@@ -1248,6 +1346,8 @@ class Gen:
             for k_ in range(4):
                 self.dump(f"srdC[{k_}]", self.srdC[k_])
             self.dump("s_rem", self.s_rem)
+        if not c.conv:
+            self.fused_epilogue()
         self.c_addr_setup()
         if c.exact:
             # C = run + alpha * (the last slice's sum); run already carries beta * C0 and the earlier slices

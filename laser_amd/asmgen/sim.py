@@ -450,10 +450,10 @@ class Workgroup:
         elif op == "v_accvgpr_write_b32":
             assert A[0].kind == "a"
             self.wr_v(w, A[0], rv(w, A[1]))
-        elif op in ("v_add_f32", "v_mul_f32", "v_sub_f32"):
+        elif op in ("v_add_f32", "v_mul_f32", "v_sub_f32", "v_max_f32"):
             x, y = f32(rv(w, A[1])), f32(rv(w, A[2]))
             with np.errstate(all="ignore"):
-                r = {"v_add_f32": x + y, "v_mul_f32": x * y, "v_sub_f32": x - y}[op]
+                r = {"v_add_f32": x + y, "v_mul_f32": x * y, "v_sub_f32": x - y, "v_max_f32": np.fmax(x, y)}[op]
             self.wr_v(w, A[0], u32(r.astype(np.float32)))
         elif op == "v_pk_add_f32":
             assert A[0].n == 2 and A[1].n == 2 and A[2].n == 2

@@ -180,8 +180,15 @@ void asm_kernels_release() {
 // hipErrorNotSupported: not this kernel's class of problem -- the caller takes the compiler-scheduled kernels
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;
-  if (a.batch < 1 || a.batch > 65535 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if (a.batch < 1 || a.batch > 65535 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
   if (a.batch > 1 && (a.bsA < 0 || a.bsB < 0 || a.bsC < 0)) return hipErrorNotSupported;
+  // fused epilogue (laser_hip_gemm_strided_ex_*): bias views with non-negative element strides, no activation or relu; tanh /
+  // sigmoid stay on the compiler-scheduled kernels (their library bodies are what the bit-exact tests pin)
+  const bool fused = a.bias != nullptr || a.act != 0;
+  if (a.act != 0 && a.act != 1) return hipErrorNotSupported;
+  if (a.bias != nullptr && (a.rsBias < 0 || a.csBias < 0 || a.rsBias > 0x3fffffff || a.csBias > 0x3fffffff || (a.batch > 1 && a.bsBias != 0) ||
+                            ((double)(a.M - 1) * a.rsBias + (double)(a.N - 1) * a.csBias + 1.0) * 4.0 >= 2147483648.0))
+    return hipErrorNotSupported;
   if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
   // (tile-padded pre-pack images -- Mext / Next / Kext beyond M / N / K, gemm_prepacked.nim:63-292 -- are plain padded row-major
   // copies: the kernels bound every access by M, N, K themselves and never need the padding)
@@ -227,6 +234,9 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
     if (time < 0.99 * best) best = time, pick = k;   // (near ties go to the larger tile: less L2 traffic)
   }
   if (pick < 0) return hipErrorNotSupported;
+  // the one-chain kernels' fused epilogue has no C read: beta != 0 with a bias / activation only on the laser-order kernels
+  const bool lo_kernel = pick == 0 || pick == 2 || pick == 4 || pick == 6 || pick == 12 || pick == 14;
+  if (fused && !lo_kernel && a.beta != 0.0f) return hipErrorNotSupported;
   const KernelInfo &ki = kKernels[pick];
   const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
@@ -263,6 +273,13 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.W = (uint32_t)(bsA_bytes >> 32);
   ka.bsB_bytes = a.batch > 1 ? (uint64_t)a.bsB * 4 : 0;
   ka.bsC_bytes = a.batch > 1 ? (uint64_t)a.bsC * 4 : 0;
+  // fused epilogue (f32_kernel.py KA_BIAS / KA_EPI = the oW .. Npix slots): bias pointer, its element strides, the activation
+  const uint64_t bias_bits = (uint64_t)reinterpret_cast<uintptr_t>(a.bias);
+  ka.oW = (uint32_t)bias_bits;
+  ka.pH = (uint32_t)(bias_bits >> 32);
+  ka.pW = a.bias ? (uint32_t)a.rsBias : 0;
+  ka.Cin = a.bias ? (uint32_t)a.csBias : 0;
+  ka.Npix = (uint32_t)a.act;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);

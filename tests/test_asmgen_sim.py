@@ -45,6 +45,13 @@ GEMM_CASES += [
     ("fast_256x256x16", 33, 270, 17, dict(lda=20)),
     ("exact_64x64x32", 70, 90, 6, dict(lda=9)),
 ]
+# fused epilogue: C = act(beta * C0 + alpha * A B + bias): bias as a row / a column / a full view, relu
+GEMM_CASES += [
+    ("exact_256x128x32", 70, 90, 548, dict(bias="row", act=1, ldc=94)),
+    ("fast_256x256x16", 70, 300, 40, dict(bias="col", act=1)),
+    ("exact_64x64x32", 70, 90, 100, dict(bias="full", act=0, alpha=0.5, beta=2.0)),
+    ("fast_128x128x16_nt", 140, 150, 36, dict(act=1)),
+]
 # C = beta * C0 + alpha * A B: the running sum starts as beta * C0, every slice is scaled before it is added
 GEMM_CASES += [
     ("exact_256x128x32", 70, 90, 1060, dict(alpha=0.75, beta=-1.5, ldc=100)),

@@ -1445,3 +1445,47 @@ def test_i64_asm_kernel_bit_exact(la, oracle):
         assert la.get_option("last_i32_asm") == 0          # alpha != 1
     finally:
         la.set_option("i32_asm", 1)
+
+
+def test_fused_epilogue_on_the_assembly_kernels(la, oracle):
+    """act(alpha*A*B + beta*C + bias) at sizes the hand-scheduled kernels take: bias row / column / full views and relu run in
+    their epilogue (same bits as the compiler-scheduled EPI kernels and as the oracle); tanh / sigmoid, and beta != 0 on the
+    one-chain kernels, fall through."""
+    import torch
+    rng = np.random.default_rng(404)
+    for (M, N, K) in [(1024, 1100, 1030), (2048, 2048, 260), (300, 5000, 516)]:
+        A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
+        B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
+        C0 = torch.from_numpy(rand(rng, (M, N), np.float32)).cuda()
+        biases = {"col": torch.from_numpy(rand(rng, (1, N), np.float32)).cuda(), "row": torch.from_numpy(rand(rng, (M, 1), np.float32)).cuda(),
+                  "full": torch.from_numpy(rand(rng, (M, N), np.float32)).cuda(), "none": None}
+        for mode in (0, 1):
+            for bname, bias in biases.items():
+                for act in (None, "relu"):
+                    if bias is None and act is None:
+                        continue
+                    al, be = (0.75, -0.5) if mode == 0 else (0.75, 0.0)
+                    outs = {}
+                    for asm in (2, 0):
+                        la.set_float_mode(mode); la.set_f32_asm(asm); la.set_option("slice_parallel", 0)
+                        try:
+                            outs[asm] = la.matmul(A, B, alpha=al, beta=be, out=C0.clone(), bias=bias, activation=act)
+                            used = la.last_f32_asm()
+                        finally:
+                            la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1)
+                        assert (used != 0) == (asm == 2), (M, N, K, mode, bname, act, used)
+                    assert torch.equal(outs[2], outs[0]), (M, N, K, mode, bname, act)
+                    if mode == 0:
+                        base = oracle.matmul(A.cpu().numpy(), B.cpu().numpy(), alpha=np.float32(al), beta=np.float32(be), C_=C0.cpu().numpy().copy(),
+                                             isa=oracle.fused_isa(np.float32))
+                        want = oracle.apply_epilogue(base, None if bias is None else bias.cpu().numpy(), act)
+                        assert np.array_equal(outs[2].cpu().numpy(), want), (M, N, K, bname, act)
+    la.set_f32_asm(2)
+    try:
+        la.matmul(A, B, activation="tanh")
+        assert la.last_f32_asm() == 0
+        la.set_float_mode(1)
+        la.matmul(A, B, alpha=1.0, beta=1.0, out=C0.clone(), activation="relu")       # one-chain kernel + beta: the compiler-scheduled kernels
+        assert la.last_f32_asm() == 0 or K <= 512
+    finally:
+        la.set_f32_asm(1); la.set_float_mode(0)
