@@ -79,7 +79,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
             Bias = rng.uniform(-1, 1, (M, N)).astype(np.float32); rsb, csb = N, 1
         bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
-    ka += struct.pack("<Q", LA * 4) + struct.pack("<QIII", bias_ptr, rsb, csb, act) + b"\0" * 12 + struct.pack("<QQ", LB * 4, LC * 4)
+    ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, 0)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
@@ -120,7 +120,7 @@ if __name__ == "__main__":
     sys.exit(0 if ok else 1)
 
 
-def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=None, verbose=True):
+def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=None, verbose=True, bias=False, act=0):
     """3x3 / stride 1 convolution kernels: every image through the interpreter, against im2col + the slice-ordered model"""
     g = K.make(name)
     g.build()
@@ -139,10 +139,13 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     mem = Memory()
     # the input is placed with nothing mapped directly before / after it: any access outside the tensor is an error
     a_, b_, c_, t_ = mem.alloc(w), mem.alloc(x), mem.alloc(out), mem.alloc(table)
+    Bias = rng.uniform(-1, 1, M).astype(np.float32) if bias else None
+    bias_ptr = mem.alloc(Bias) if bias else 0
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, Kd, 0, npix, M, N, Kd, 1.0, 0.0, 0)
     ka += struct.pack("<IIIIIIII", H, W, oW, pH, pW, Cin, npix, (1 << 32) // oW + 1)
     ka += struct.pack("<IIQ", 0, 0, Cin * H * W * 4)
     ka += struct.pack("<Q", M * npix * 4)
+    ka += struct.pack("<QIIII", bias_ptr, 1, 0, act, 0)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
@@ -156,6 +159,10 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
         xp[:, pH:pH + H, pW:pW + W] = x[img]
         Bm = np.stack([xp[ci, kh:kh + oH, kw:kw + oW].reshape(-1) for ci in range(Cin) for kh in range(3) for kw in range(3)])
         want = reference(w, Bm, 512 if c.exact else 0)
+        if Bias is not None:
+            want = (want + Bias[:, None]).astype(np.float32)
+        if act == 1:
+            want = np.where(want > 0, want, np.float32(0)).astype(np.float32)
         ok &= bool(np.array_equal(got[img][:, :N], want[:, :N]))
         ok &= bool(np.all(np.isnan(got[img][:, N:])))
         if not ok and verbose:
@@ -202,7 +209,7 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Aflat), mem.alloc(Bflat), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta) + b"\0" * 40
+    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta) + b"\0" * 64
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
@@ -261,7 +268,7 @@ def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True):
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Ap), mem.alloc(Bp), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, 1, 0, 0) + b"\0" * 56
+    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, 1, 0, 0) + b"\0" * 80
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
@@ -311,7 +318,7 @@ def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_rang
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Ap), mem.alloc(Bp), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, alpha, beta, 0) + b"\0" * 56
+    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, alpha, beta, 0) + b"\0" * 80
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None

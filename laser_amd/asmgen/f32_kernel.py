@@ -101,9 +101,9 @@ CONFIGS = {
 KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 8, 16, 24, 32, 36, 40, 44, 48, 52, 64
 # convolution kernels only: H W oW pH pW Cin Npix magic(oW) | shift(oW) - bsB(bytes, u64) | bsC(bytes, u64)
 KA_CONV0, KA_CONV1, KA_CONV2 = 72, 104, 120
-KA_BIAS, KA_EPI = 80, 88   # GEMM kernels: bias pointer (u64; 0 = none); rowStrideBias, colStrideBias (elements), activation (0 none / 1 relu), -
+KA_BIAS, KA_EPI = 128, 136   # fused epilogue: bias pointer (u64; 0 = none); rowStrideBias, colStrideBias (elements), activation (0 none / 1 relu), -
 KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's share the convolution kernels' slots at 112 / 120
-KERNARG_SIZE = 128
+KERNARG_SIZE = 152
 
 
 class Gen:
@@ -167,6 +167,9 @@ class Gen:
         self.s_em = [S(2) for _ in range(4)]   # K % 4 != 0: lanes whose element j of their piece is real data in the last K-tile
         if not c.conv:
             self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
+        if c.conv:     # (the convolution kernels are out of SGPRs: the tap state is dead by the epilogue)
+            self.srdBias, self.s_epi = self.s_scr.sub(0, 4), self.s_scr.sub(4, 4)
+        else:
             self.srdBias = S(4)                                      # fused epilogue: the bias view (base, -, bytes, flags)
             self.s_epi = S(4, align=4)                               # rowStrideBias, colStrideBias (elements), activation, -
         self.vVA = [V() for _ in range(c.NPA)]
@@ -280,8 +283,6 @@ class Gen:
             # operand b at base + b * batch stride (bytes, 64-bit; 0 for plain launches)
             e("s_load_dwordx2", self.s_bsA, s(0, 2), KA_BSA)
             e("s_load_dwordx4", self.s_bsBC, s(0, 2), KA_CONV1 + 8)
-            e("s_load_dwordx2", self.srdBias.sub(0, 2), s(0, 2), KA_BIAS)
-            e("s_load_dwordx4", self.s_epi, s(0, 2), KA_EPI)
             e("s_waitcnt", lgkmcnt=0)
             for ptr, bs in ((self.ka0.sub(0, 2), self.s_bsA), (self.ka0.sub(2, 2), self.s_bsBC.sub(0, 2)), (self.ka0.sub(4, 2), self.s_bsBC.sub(2, 2))):
                 e("s_mul_i32", st[2], s(3), bs[0])
@@ -1239,6 +1240,9 @@ class Gen:
         c, p = self.c, self.p
         e, t, st = p.emit, self.vt, self.s_t
         plain = p.label("plain")
+        e("s_load_dwordx2", self.srdBias.sub(0, 2), s(0, 2), KA_BIAS)
+        e("s_load_dwordx4", self.s_epi, s(0, 2), KA_EPI)
+        e("s_waitcnt", lgkmcnt=0)
         e("s_or_b32", st[0], self.srdBias[0], self.srdBias[1])
         e("s_or_b32", st[1], st[0], self.s_epi[2])
         e("s_cmp_eq_u32", st[1], 0)
@@ -1346,8 +1350,7 @@ class Gen:
             for k_ in range(4):
                 self.dump(f"srdC[{k_}]", self.srdC[k_])
             self.dump("s_rem", self.s_rem)
-        if not c.conv:
-            self.fused_epilogue()
+        self.fused_epilogue()
         self.c_addr_setup()
         if c.exact:
             # C = run + alpha * (the last slice's sum); run already carries beta * C0 and the earlier slices

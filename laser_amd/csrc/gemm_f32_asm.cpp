@@ -87,8 +87,11 @@ struct KernArgs {
   uint32_t H, W, oW, pH, pW, Cin, Npix, magic_oW;
   uint32_t shift_oW, pad_;
   uint64_t bsB_bytes, bsC_bytes;
+  // fused epilogue of the f32 kernels (f32_kernel.py KA_BIAS / KA_EPI): bias view + activation; zero = plain epilogue
+  const void *bias = nullptr;
+  uint32_t rsBias = 0, csBias = 0, act = 0, pad2_ = 0;
 };
-static_assert(sizeof(KernArgs) == 128, "kernel argument block layout (f32_kernel.py KA_*)");
+static_assert(sizeof(KernArgs) == 152, "kernel argument block layout (f32_kernel.py KA_*)");
 
 // blockIdx -> tile: block b runs on XCD b % 8; give every XCD a contiguous chunk of tile ids (bijective for any grid),
 // then walk the tiles in groups of group_m tile rows so the ~32 workgroups resident on an XCD form a compact patch.
@@ -273,13 +276,10 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.W = (uint32_t)(bsA_bytes >> 32);
   ka.bsB_bytes = a.batch > 1 ? (uint64_t)a.bsB * 4 : 0;
   ka.bsC_bytes = a.batch > 1 ? (uint64_t)a.bsC * 4 : 0;
-  // fused epilogue (f32_kernel.py KA_BIAS / KA_EPI = the oW .. Npix slots): bias pointer, its element strides, the activation
-  const uint64_t bias_bits = (uint64_t)reinterpret_cast<uintptr_t>(a.bias);
-  ka.oW = (uint32_t)bias_bits;
-  ka.pH = (uint32_t)(bias_bits >> 32);
-  ka.pW = a.bias ? (uint32_t)a.rsBias : 0;
-  ka.Cin = a.bias ? (uint32_t)a.csBias : 0;
-  ka.Npix = (uint32_t)a.act;
+  ka.bias = a.bias;
+  ka.rsBias = a.bias ? (uint32_t)a.rsBias : 0;
+  ka.csBias = a.bias ? (uint32_t)a.csBias : 0;
+  ka.act = (uint32_t)a.act;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);
@@ -452,8 +452,13 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
 // filter [M][K], B = the NCHW input, batch = images).  hipErrorNotSupported: not this kernel's class.
 hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;
-  if (a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.cs_imgs != 0) return hipErrorNotSupported;
+  if (a.col0 != 0 || a.cs_imgs != 0) return hipErrorNotSupported;
   if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
+  // fused epilogue (laser_hip_conv2d_im2col_ex_f32: per-channel bias, relu) as in the GEMM kernels; tanh / sigmoid: the compiler kernels
+  if (a.act != 0 && a.act != 1) return hipErrorNotSupported;
+  if (a.bias != nullptr && (a.rsBias < 0 || a.csBias < 0 || a.bsBias != 0 || a.rsBias > 0x3fffffff || a.csBias > 0x3fffffff ||
+                            ((double)(a.M - 1) * a.rsBias + (double)(a.N - 1) * a.csBias + 1.0) * 4.0 >= 2147483648.0))
+    return hipErrorNotSupported;
   if (a.ckH != 3 || a.ckW != 3 || a.csH != 1 || a.csW != 1) return hipErrorNotSupported;
   if (a.cpH < 0 || a.cpW < 0 || a.cpH > 64 || a.cpW > 64) return hipErrorNotSupported;
   const int64_t oW = a.coW, oH = a.cH + 2 * a.cpH - 2, npix = oH * oW;
@@ -516,6 +521,10 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.pad_ = 0;
   ka.bsB_bytes = (uint64_t)a.bsB * 4;
   ka.bsC_bytes = (uint64_t)a.bsC * 4;
+  ka.bias = a.bias;
+  ka.rsBias = a.bias ? (uint32_t)a.rsBias : 0;
+  ka.csBias = a.bias ? (uint32_t)a.csBias : 0;
+  ka.act = (uint32_t)a.act;
   if ((double)npix * (double)oW >= 4.0e9) return hipErrorNotSupported;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

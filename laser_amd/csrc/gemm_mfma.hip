@@ -284,6 +284,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   a.dbg = 0;
   a.col0 = 0;
   a.cs_imgs = 0; a.cs_len = 0;
+  g_last_f32_asm = 0;
   const bool exact = laser_order && a.K > 512;
   a.kc = exact ? 512 : 0;
   if (cfg < 0) {  // few output channels, short reduction (the reference's conv bench shape): an HBM stream, not a tile problem

@@ -32,14 +32,14 @@ if c.conv:   # usage: asm_debug.py conv3x3_... images Cin H W M pad
     xp[:, :, pad:pad + H, pad:pad + W] = B
     want = np.stack([A.astype(np.float64) @ np.stack([xp[b, ci, kh:kh + oH, kw:kw + oW].reshape(-1) for ci in range(Cin) for kh in range(3) for kw in range(3)])
                      for b in range(NIMG)])
-    conv_args = struct.pack("<IIIIIIII", H, W, oW, pad, pad, Cin, N, (1 << 32) // oW + 1) + struct.pack("<IIQ", 0, 0, Cin * H * W * 4) + struct.pack("<Q", M * N * 4)
+    conv_args = struct.pack("<IIIIIIII", H, W, oW, pad, pad, Cin, N, (1 << 32) // oW + 1) + struct.pack("<IIQ", 0, 0, Cin * H * W * 4) + struct.pack("<Q", M * N * 4) + b"\0" * 24
     lds = (Kd, 0, N)
 else:
     M, N, Kd = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (c.BM, c.BN, 2 * c.BK)
     A = rng.uniform(-0.1, 0.1, (M, Kd)).astype(np.float32)
     B = rng.uniform(-0.1, 0.1, (Kd, N)).astype(np.float32)
     want = (A.astype(np.float64) @ B.astype(np.float64))[None]
-    conv_args = b"\0" * 56
+    conv_args = b"\0" * 80
     lds = (Kd, N, N)
 tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
 table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)

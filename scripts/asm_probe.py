@@ -89,7 +89,7 @@ def main():
         key = (tm, tn, gm)
         if key not in tables:
             tables[key] = torch.tensor(make_table(tm, tn, gm), dtype=torch.int32, device="cuda")
-        ka = struct.pack("<QQQQIIIIIIffQ", A.data_ptr(), B.data_ptr(), Cm.data_ptr(), tables[key].data_ptr(), K_, N_, N_, M_, N_, K_, 1.0, 0.0, 0) + b"\0" * 56
+        ka = struct.pack("<QQQQIIIIIIffQ", A.data_ptr(), B.data_ptr(), Cm.data_ptr(), tables[key].data_ptr(), K_, N_, N_, M_, N_, K_, 1.0, 0.0, 0) + b"\0" * 80
         buf = C.create_string_buffer(ka, len(ka))
         size = C.c_size_t(len(ka))
         extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)

@@ -32,7 +32,7 @@ for var in variants:
     mod, fn = C.c_void_p(), C.c_void_p()
     assert hip.hipModuleLoad(C.byref(mod), (sp + ".hsaco").encode()) == 0
     assert hip.hipModuleGetFunction(C.byref(fn), mod, b"lh_probe") == 0
-    ka = struct.pack("<QQQQIIIIIIffQ", Ap.data_ptr(), Bp.data_ptr(), Cm.data_ptr(), table.data_ptr(), kt, 0, n, n, n, kt * 32, 1.0, 0.0, 0) + b"\0" * 56
+    ka = struct.pack("<QQQQIIIIIIffQ", Ap.data_ptr(), Bp.data_ptr(), Cm.data_ptr(), table.data_ptr(), kt, 0, n, n, n, kt * 32, 1.0, 0.0, 0) + b"\0" * 80
     buf = C.create_string_buffer(ka, len(ka)); size = C.c_size_t(len(ka))
     extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)
     built.append((var, fn, buf, size, extra))

@@ -83,6 +83,11 @@ def test_conv_kernels_bit_exact_in_the_interpreter(name, images, Cin, H, W, M, p
     assert C.run_conv_case(name, images, Cin, H, W, M, pad, n_cut=n_cut, verbose=False)
 
 
+def test_conv_kernels_fused_bias_relu_in_the_interpreter():
+    assert C.run_conv_case("conv3x3_exact_256x128x32", 2, 8, 12, 16, 40, 1, bias=True, act=1, verbose=False)
+    assert C.run_conv_case("conv3x3_fast_64x128x32", 1, 64, 6, 8, 70, (0, 1), bias=True, act=0, verbose=False)
+
+
 # float64 kernels (f64_kernel.py): integer-valued operands (exact in f64: the interpreter's f64 MFMA is mul + add)
 F64_CASES = [
     ("fast_64x64x16", 70, 90, 48, {}),

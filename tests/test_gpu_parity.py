@@ -1489,3 +1489,34 @@ def test_fused_epilogue_on_the_assembly_kernels(la, oracle):
         assert la.last_f32_asm() == 0 or K <= 512
     finally:
         la.set_f32_asm(1); la.set_float_mode(0)
+
+
+def test_fused_conv_epilogue_on_the_assembly_kernels(la, oracle):
+    """conv + per-channel bias + relu (laser_hip_conv2d_im2col_ex_f32) with the main launch on the hand-scheduled convolution
+    kernels: same bits as the compiler-scheduled kernels and as the oracle, every image; 256-, 128- and 64-row tiles."""
+    import torch
+    rng = np.random.default_rng(505)
+    for ishape, kshape, pad in [((4, 128, 56, 56), (256, 128, 3, 3), (1, 1)), ((8, 64, 28, 28), (128, 64, 3, 3), (1, 1)),
+                                ((6, 32, 30, 30), (64, 32, 3, 3), (0, 0))]:
+        st = (1, 1)
+        x = rng.uniform(-1, 1, ishape).astype(np.float32)
+        w = rng.uniform(-1, 1, kshape).astype(np.float32)
+        b = rng.uniform(-1, 1, kshape[0]).astype(np.float32)
+        dx, dw, db = (torch.from_numpy(v_).cuda() for v_ in (x, w, b))
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+        ref = oracle.conv2d_im2col(x, w, pad, st, isa=oracle.fused_isa(np.float32))
+        for act in (None, "relu"):
+            outs = {}
+            for asm in (2, 0):
+                la.set_f32_asm(asm)
+                try:
+                    o = torch.full(oshape, float("nan"), device="cuda")
+                    la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, pad, st, None, bias=db, activation=act)
+                    used = la.last_f32_asm()
+                finally:
+                    la.set_f32_asm(1)
+                assert (used != 0) == (asm == 2), (ishape, kshape, act, used)
+                outs[asm] = o
+            assert torch.equal(outs[2], outs[0]), (ishape, kshape, act)
+            want = oracle.apply_epilogue(ref.reshape(ishape[0], kshape[0], -1), b.reshape(1, -1, 1), act).reshape(oshape)
+            assert np.array_equal(outs[2].cpu().numpy(), want), (ishape, kshape, act)
