@@ -1157,7 +1157,8 @@ def test_conv_direct_small_channels_bit_exact(la, oracle):
     rng = np.random.default_rng(77)
     cases = [((16, 3, 224, 224), (20, 3, 3, 3), (0, 0), (1, 1)), ((2, 4, 17, 19), (7, 4, 5, 3), (2, 1), (2, 1)),
              ((3, 8, 30, 30), (32, 8, 3, 3), (1, 1), (1, 1)), ((1, 1, 9, 300), (3, 1, 1, 7), (0, 3), (1, 2)),
-             ((2, 28, 12, 12), (16, 28, 3, 3), (1, 1), (1, 1))]
+             ((2, 28, 12, 12), (16, 28, 3, 3), (1, 1), (1, 1)), ((2, 12, 11, 13), (5, 12, 3, 3), (1, 1), (1, 1)),
+             ((1, 13, 40, 37), (31, 13, 3, 3), (0, 0), (1, 1)), ((1, 2, 70, 70), (9, 2, 4, 4), (3, 3), (3, 2))]
     for ishape, kshape, pad, st in cases:
         x = rng.uniform(-1, 1, ishape).astype(np.float32)
         w = rng.uniform(-1, 1, kshape).astype(np.float32)
