@@ -18,7 +18,7 @@ def main():
         print("| kernel | calls | avg ms | min ms | max ms | % |")
         print("|---|---|---|---|---|---|")
         for r in csv.DictReader(open(f)):
-            if pat in r["Name"] or "lh_f32" in r["Name"]:
+            if pat in r["Name"] or "lh_" in r["Name"]:
                 name = r["Name"].split("(")[0].replace("void ", "")
                 print(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | {float(r['MinNs'])/1e6:.4f} | "
                       f"{float(r['MaxNs'])/1e6:.4f} | {r['Percentage']} |")
@@ -28,7 +28,7 @@ def main():
         dur = defaultdict(dict)
         meta = {}
         for r in csv.DictReader(open(f)):
-            if pat not in r["Kernel_Name"] and "lh_f32" not in r["Kernel_Name"]:
+            if pat not in r["Kernel_Name"] and "lh_" not in r["Kernel_Name"]:
                 continue
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[name][r["Counter_Name"]].append((r["Dispatch_Id"], float(r["Counter_Value"])))
