@@ -174,11 +174,11 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     return ok
 
 
-def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True, alpha=1.0, beta=0.0):
+def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True, alpha=1.0, beta=0.0, batch=1):
     """float64 kernels (f64_kernel.py) through the interpreter.  Operands are small integers (alpha, beta dyadic), for which every
     product and partial sum is exact in float64 (the interpreter's f64 MFMA is mul + add, not an exact fma): this checks every
     address, layout, wait and hazard of the program; the accumulation ORDER with rounding is checked on hardware against the
-    compiler-scheduled kernels and the CPU restatement."""
+    compiler-scheduled kernels and the CPU restatement.  batch > 1: workgroup id y = batch index, operands `batch` spans apart."""
     from . import f64_kernel as K64
     g = K64.make(name, **(over or {}))
     g.build()
@@ -187,47 +187,60 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     rng = np.random.default_rng(seed)
     lda, ldc = lda or Kd, ldc or N
     ldb = (ldb if (ldb and ldb >= Kd) else Kd) if nt else (ldb or N)
-    Af = np.full((M, lda), np.nan)
-    Am = rng.integers(-4, 5, (M, Kd)).astype(np.float64)
-    Bm = rng.integers(-4, 5, (Kd, N)).astype(np.float64)
-    Af[:, :Kd] = Am
-    if nt:
-        Bf = np.full((N, ldb), np.nan)
-        Bf[:, :Kd] = Bm.T
-        Bflat = Bf.reshape(-1)[:(N - 1) * ldb + Kd].copy()
-    else:
-        Bf = np.full((Kd, ldb), np.nan)
-        Bf[:, :N] = Bm
-        Bflat = Bf.reshape(-1)[:(Kd - 1) * ldb + N].copy()
-    Aflat = Af.reshape(-1)[:(M - 1) * lda + Kd].copy()
-    C0 = rng.integers(-8, 9, (M, N)).astype(np.float64)
-    full0 = np.full((M, ldc), np.nan)
-    if beta != 0:
-        full0[:, :N] = C0
-    Cflat = full0.reshape(-1)[:(M - 1) * ldc + N].copy()
+    LA, LC = (M - 1) * lda + Kd + 3, (M - 1) * ldc + N + 5          # spans between batches: a few elements of slack
+    LB = ((N - 1) * ldb + Kd if nt else (Kd - 1) * ldb + N) + 7
+    Aall, Ball, Call = np.full(batch * LA, np.nan), np.full(batch * LB, np.nan), np.full(batch * LC, np.nan)
+    Am = rng.integers(-4, 5, (batch, M, Kd)).astype(np.float64)
+    Bm = rng.integers(-4, 5, (batch, Kd, N)).astype(np.float64)
+    C0 = rng.integers(-8, 9, (batch, M, N)).astype(np.float64)
+    for b in range(batch):
+        Af = np.full((M, lda), np.nan)
+        Af[:, :Kd] = Am[b]
+        if nt:
+            Bf = np.full((N, ldb), np.nan)
+            Bf[:, :Kd] = Bm[b].T
+            Bflat = Bf.reshape(-1)[:(N - 1) * ldb + Kd]
+        else:
+            Bf = np.full((Kd, ldb), np.nan)
+            Bf[:, :N] = Bm[b]
+            Bflat = Bf.reshape(-1)[:(Kd - 1) * ldb + N]
+        Aall[b * LA:b * LA + LA - 3] = Af.reshape(-1)[:(M - 1) * lda + Kd]
+        Ball[b * LB:b * LB + LB - 7] = Bflat
+        full0 = np.full((M, ldc), np.nan)
+        if beta != 0:
+            full0[:, :N] = C0[b]
+        Call[b * LC:b * LC + LC - 5] = full0.reshape(-1)[:(M - 1) * ldc + N]
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
-    a_, b_, c_, t_ = mem.alloc(Aflat), mem.alloc(Bflat), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta) + b"\0" * 64
+    a_, b_, c_, t_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call), mem.alloc(table)
+    bs = (LA * 8, LB * 8, LC * 8) if batch > 1 else (0, 0, 0)
+    ka = (struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, t_, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta)
+          + struct.pack("<Q", bs[0]) + b"\0" * 16 + struct.pack("<QQ", bs[1], bs[2]) + b"\0" * 24)
+    assert len(ka) == 152
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
-    for wg in range(len(table)):
-        w = Workgroup(g.p, mem, ka_, wg_id=(wg, 0), lds_bytes=c.lds_alloc)
-        w.run(order=order)
-        stats = w.waves[0].stats
-    full = np.full(M * ldc, np.nan)
-    full[:len(Cflat)] = mem.get(c_, np.float64, (len(Cflat),))
-    full = full.reshape(M, ldc)
-    want = alpha * (Am @ Bm) + (beta * C0 if beta != 0 else 0.0)
-    ok = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(np.isnan(full[:, N:][:-1]))))
-    if verbose:
-        print(f"f64 {name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc} alpha={alpha} beta={beta}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, "
-              f"bank-conflict cycles {stats['bank_conflict_cycles']}, {stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
-        if not ok:
+    for bi in range(batch):
+        for wg in range(len(table)):
+            w = Workgroup(g.p, mem, ka_, wg_id=(wg, bi), lds_bytes=c.lds_alloc)
+            w.run(order=order)
+            stats = w.waves[0].stats
+    got = mem.get(c_, np.float64, (batch * LC,))
+    ok = True
+    for b in range(batch):
+        full = np.full(M * ldc, np.nan)
+        full[:LC - 5] = got[b * LC:b * LC + LC - 5]
+        full = full.reshape(M, ldc)
+        want = alpha * (Am[b] @ Bm[b]) + (beta * C0[b] if beta != 0 else 0.0)
+        okb = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(np.isnan(full[:, N:][:-1])))) and bool(np.all(np.isnan(got[b * LC + LC - 5:(b + 1) * LC])))
+        if not okb and verbose:
             bad = np.argwhere(full[:, :N] != want)
-            print("  first mismatches:", bad[:8].tolist(), full[tuple(bad[0])] if len(bad) else None, want[tuple(bad[0])] if len(bad) else None, "count", len(bad))
+            print("  batch", b, "first mismatches:", bad[:8].tolist(), full[tuple(bad[0])] if len(bad) else None, want[tuple(bad[0])] if len(bad) else None, "count", len(bad))
+        ok = ok and okb
+    if verbose:
+        print(f"f64 {name} M={M} N={N} K={Kd} lda={lda} ldb={ldb} ldc={ldc} alpha={alpha} beta={beta} batch={batch}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, "
+              f"bank-conflict cycles {stats['bank_conflict_cycles']}, {stats['ins']} instr/wave, {stats['mfma']} mfma/wave)")
     return ok
 
 
@@ -250,7 +263,7 @@ def pack_limb_tiles(X, np_=4):
     return out.reshape(-1), xp, kp
 
 
-def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True):
+def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, alpha=1, beta=0):
     """int64 GEMM kernel (i8_kernel.py, "i64_64x64x32") through the interpreter: C = A B mod 2^64 with full-range int64 operands"""
     from . import i8_kernel as KI
     g = KI.make("i64_64x64x32")
@@ -264,11 +277,15 @@ def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True):
     Bp, Np_, _ = pack_limb_tiles(B.T.copy(), 8)
     KT = Kp // 32
     Cflat = np.full((M - 1) * ldc + N, 0x7bad7bad7bad7bad, dtype=np.uint64)
+    C0 = rng.integers(0, 2**64, (M, N), dtype=np.uint64)
+    if beta != 0:
+        for r in range(M):
+            Cflat[r * ldc:r * ldc + N] = C0[r]
     tm, tn = Mp // 64, Np_ // 64
     table = np.array([pm | (pn << 16) for pn in range(tn) for pm in range(tm)], dtype=np.uint32)
     mem = Memory()
     a_, b_, c_, t_ = mem.alloc(Ap), mem.alloc(Bp), mem.alloc(Cflat), mem.alloc(table)
-    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, 1, 0, 0) + b"\0" * 80
+    ka = struct.pack("<QQQQIIIIIIiiQ", a_, b_, c_, t_, KT, 0, ldc, M, N, Kp, 1, 0, 0) + struct.pack("<qq", alpha, beta) + b"\0" * 64
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = None
@@ -284,6 +301,9 @@ def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True):
     with np.errstate(over="ignore"):
         for k in range(Kd):
             want += Au[:, k:k + 1] * Bu[k:k + 1, :]          # uint64 arithmetic wraps mod 2^64
+        want = want * np.uint64(alpha % 2**64)
+        if beta != 0:
+            want = want + C0 * np.uint64(beta % 2**64)
     ok = np.array_equal(full[:, :N], want) and (ldc == N or bool(np.all(full[:, N:][:-1] == 0x7bad7bad7bad7bad)))
     if verbose:
         print(f"i64 M={M} N={N} K={Kd} ldc={ldc}: {'OK' if ok else 'MISMATCH'}  ({time.time() - t0:.1f} s, bank-conflict cycles "

@@ -15,7 +15,7 @@ ds_read_b128 -- and is 144 bytes long: with 9 chunks per row the 16 rows a 16-la
 Operands: A row-major (k-contiguous), B row-major (x-contiguous) or passed transposed (`_nt`: k-contiguous, stored like A), C
 row-major; K a multiple of 2; any alpha / beta (float64 in the kernel arguments)."""
 from .core import v, a, s, VCC
-from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
+from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_CONV1  # noqa: F401
 
 CONFIGS = {
     # one wave per SIMD: 2 x 2 waves of 64x64 = 16 blocks = 128 accumulator registers (+ 128 for the running sum)
@@ -31,6 +31,7 @@ CONFIGS = {
     "fast_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=False, b_kcontig=True),
 }
 KA_ALPHA64 = 72      # alpha, beta as float64 (the f32 kernels' float fields at 56 / 60 are unused here)
+KA_BSA64 = 88        # batch stride of A in bytes (u64); B's and C's at 112 / 120 as in the f32 kernels
 
 
 class Gen64(Gen):
@@ -50,6 +51,7 @@ class Gen64(Gen):
         self.s_ab = S(4, align=4)                 # alpha (2 registers), beta (2 registers): float64
         self.s_al, self.s_be = self.s_ab.sub(0, 2), self.s_ab.sub(2, 2)
         self.s_a1, self.s_b0 = S(), S()           # 0 when alpha == 1.0 / when beta == +-0.0
+        self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
         self.s_ldc4, self.s_ldc20 = S(), S()      # here: ldc * 8 bytes, 4 * ldc * 8 (the next accumulator row of a lane)
         self.acc = [p.aalloc(8) for _ in range(c.NB)]
         self.run = [p.aalloc(8) for _ in range(c.NB)] if c.exact else None
@@ -92,7 +94,18 @@ class Gen64(Gen):
         e("s_waitcnt", lgkmcnt=0)
         e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16")
         e("s_load_dwordx4", self.s_ab, s(0, 2), KA_ALPHA64)
+        # batched problems (gemm_strided_batched; the kc slices of the slice-parallel form): workgroup id y = batch index, operand b at
+        # base + b * batch stride (bytes, 64-bit; 0 for plain launches) -- as in the f32 kernels
+        e("s_load_dwordx2", self.s_bsA, s(0, 2), KA_BSA64)
+        e("s_load_dwordx4", self.s_bsBC, s(0, 2), KA_CONV1 + 8)
         e("s_waitcnt", lgkmcnt=0)
+        for ptr, bs in ((self.ka0.sub(0, 2), self.s_bsA), (self.ka0.sub(2, 2), self.s_bsBC.sub(0, 2)), (self.ka0.sub(4, 2), self.s_bsBC.sub(2, 2))):
+            e("s_mul_i32", st[2], s(3), bs[0])
+            e("s_mul_hi_u32", st[3], s(3), bs[0])
+            e("s_mul_i32", st[4], s(3), bs[1])
+            e("s_add_u32", st[3], st[3], st[4])
+            e("s_add_u32", ptr[0], ptr[0], st[2])
+            e("s_addc_u32", ptr[1], ptr[1], st[3])
         e("s_xor_b32", st[2], self.s_al[1], 0x3ff00000)
         e("s_or_b32", self.s_a1, st[2], self.s_al[0])
         e("s_and_b32", st[2], self.s_be[1], 0x7fffffff)

@@ -16,9 +16,11 @@ fold of the accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything els
 
 int64 (`make("i64_64x64x32")`): eight planes, 36 products, eight accumulator groups = 128 AGPRs per 32x32 block, so a wave owns ONE
 block and the workgroup tile is 64x64 (blocks of [8 planes][2 halves][64 rows][16 bytes] = the same 16 KiB); the epilogue sums
-sext(G_s) << 8s in 64-bit (add-with-carry for s <= 3, shifted adds into the high word above); alpha = 1, beta = 0."""
+sext(G_s) << 8s in 64-bit (add-with-carry for s <= 3, shifted adds into the high word above), then alpha * (...) + beta * C0 wrapping."""
 from .core import v, a, s, VCC
 from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
+
+KA_ALPHA64 = 72   # int64 alpha, beta (16 bytes): the slot of the f64 kernels' doubles
 
 BLOCK = 16384      # bytes of one operand's (row tile, k tile) block: planes x 2 k halves x tile rows x 16 (int32: 4 x 2 x 128, int64: 8 x 2 x 64)
 
@@ -49,6 +51,7 @@ class GenI8(Gen):
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
+        self.s_ab64 = S(4, align=4) if c.NP == 8 else None      # int64 alpha (lo, hi), beta (lo, hi): loaded by the epilogue
         self.acc = [[p.aalloc(16) for _ in range(c.WB * c.WB)] for _ in range(c.NP)]        # [power of 256][block = WB * i + n]
         self.fa = [[[V(4) for _ in range(c.NP)] for _ in range(c.WB)] for _ in range(2)]   # [set][i][plane]
         self.fb = [[[V(4) for _ in range(c.NP)] for _ in range(c.WB)] for _ in range(2)]   # [set][n][plane]
@@ -324,35 +327,78 @@ class GenI8(Gen):
             e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
 
     def epilogue64(self):
-        """C = sum over s of sext(G_s) << 8s (mod 2^64): 64-bit adds with carry for s <= 3, shifted adds into the high word above"""
+        """C = beta * C0 + alpha * sum over s of sext(G_s) << 8s (mod 2^64; gemm_ukernel_generic.nim:53-76): 64-bit adds with carry
+        for s <= 3, shifted adds into the high word above; alpha / beta are int64 at kernel-argument offset 72 / 80 (the doubles'
+        slots of the f64 kernels).  Three bodies: alpha == 1 and beta == 0 (no multiplies), beta == 0 (never reads C), general."""
         c, p = self.c, self.p
-        e, t = p.emit, self.vt
+        e, t, st = p.emit, self.vt, self.s_t
         e("s_nop", 15)
         e("s_nop", 7)
         e("s_waitcnt", vmcnt=0, lgkmcnt=0)
         self.vmq.clear()
         self.lgq.clear()
-        self.c_addr_setup()
+        ab = self.s_ab64
+        e("s_load_dwordx4", ab, s(0, 2), KA_ALPHA64)
+        e("s_waitcnt", lgkmcnt=0)
+        L_mul, L_beta, L_done = p.label("alpha"), p.label("beta64"), p.label("stored64")
+        e("s_xor_b32", st[2], ab[0], 1)
+        e("s_or_b32", st[2], st[2], ab[1])
+        e("s_or_b32", st[3], ab[2], ab[3])
+        e("s_or_b32", st[2], st[2], st[3])
+        e("s_cmp_lg_u32", st[2], 0)
+        e("s_cbranch_scc1", L_mul)
         lo, hi, g, x = t[0], t[1], t[2], t[3]
         res = t[4:6]
-        for q in range(4):
-            for rr in range(4):
-                r = 4 * q + rr
-                e("v_accvgpr_read_b32", lo, self.acc[0][0][r])
-                e("v_ashrrev_i32", hi, 31, lo)
-                for sg in range(1, 4):
-                    e("v_accvgpr_read_b32", g, self.acc[sg][0][r])
-                    e("v_lshlrev_b32", x, 8 * sg, g)
-                    e("v_ashrrev_i32", g, 32 - 8 * sg, g)
-                    e("v_add_co_u32", lo, VCC, lo, x)
-                    e("v_addc_co_u32", hi, VCC, hi, g, VCC)
-                for sg in range(4, 8):
-                    e("v_accvgpr_read_b32", g, self.acc[sg][0][r])
-                    e("v_lshl_add_u32", hi, g, 8 * (sg - 4), hi)
-                e("v_mov_b32", res[0], lo)
-                e("v_mov_b32", res[1], hi)
-                e("buffer_store_dwordx2", v(res[0].idx, 2), self.vC[0], self.srdC, 0, offen=True)
-                self.c_step(0, q, rr)
+        cc = t[6:8]
+        for mode in ("plain", "alpha", "beta"):
+            if mode == "alpha":
+                p.place(L_mul)
+                e("s_cmp_lg_u32", st[3], 0)
+                e("s_cbranch_scc1", L_beta)
+            elif mode == "beta":
+                p.place(L_beta)
+            self.c_addr_setup()
+            for q in range(4):
+                for rr in range(4):
+                    r = 4 * q + rr
+                    if mode == "beta":
+                        e("buffer_load_dwordx2", v(cc[0].idx, 2), self.vC[0], self.srdC, 0, offen=True)
+                    e("v_accvgpr_read_b32", lo, self.acc[0][0][r])
+                    e("v_ashrrev_i32", hi, 31, lo)
+                    for sg in range(1, 4):
+                        e("v_accvgpr_read_b32", g, self.acc[sg][0][r])
+                        e("v_lshlrev_b32", x, 8 * sg, g)
+                        e("v_ashrrev_i32", g, 32 - 8 * sg, g)
+                        e("v_add_co_u32", lo, VCC, lo, x)
+                        e("v_addc_co_u32", hi, VCC, hi, g, VCC)
+                    for sg in range(4, 8):
+                        e("v_accvgpr_read_b32", g, self.acc[sg][0][r])
+                        e("v_lshl_add_u32", hi, g, 8 * (sg - 4), hi)
+                    if mode != "plain":
+                        # (lo, hi) *= alpha mod 2^64: hi' = mulhi(lo, a_lo) + lo * a_hi + hi * a_lo
+                        e("v_mul_hi_u32", x, lo, ab[0])
+                        e("v_mul_lo_u32", g, lo, ab[1])
+                        e("v_add_u32", x, x, g)
+                        e("v_mul_lo_u32", g, hi, ab[0])
+                        e("v_add_u32", hi, x, g)
+                        e("v_mul_lo_u32", lo, lo, ab[0])
+                    if mode == "beta":
+                        e("s_waitcnt", vmcnt=0)
+                        e("v_mul_hi_u32", x, cc[0], ab[2])
+                        e("v_mul_lo_u32", g, cc[0], ab[3])
+                        e("v_add_u32", x, x, g)
+                        e("v_mul_lo_u32", g, cc[1], ab[2])
+                        e("v_add_u32", x, x, g)
+                        e("v_mul_lo_u32", g, cc[0], ab[2])
+                        e("v_add_co_u32", lo, VCC, lo, g)
+                        e("v_addc_co_u32", hi, VCC, hi, x, VCC)
+                    e("v_mov_b32", res[0], lo)
+                    e("v_mov_b32", res[1], hi)
+                    e("buffer_store_dwordx2", v(res[0].idx, 2), self.vC[0], self.srdC, 0, offen=True)
+                    self.c_step(0, q, rr)
+            if mode != "beta":
+                e("s_branch", L_done)
+        p.place(L_done)
         e("s_endpgm")
 
 

@@ -227,6 +227,10 @@ hipError_t launch_tiled(const GemmArgs<float> &a, hipStream_t s) {
   return launch_gemm_f32(a, f32_cfg_now(), g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 hipError_t launch_tiled(const GemmArgs<double> &a, hipStream_t s) {
+  if (g_ctx.f64_mfma) {
+    const hipError_t e = launch_gemm_f64_asm(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+    if (e != hipErrorNotSupported) return e;
+  }
   return launch_gemm_f64(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
 }
 

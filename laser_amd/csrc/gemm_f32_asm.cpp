@@ -12,6 +12,7 @@
 #include <tuple>
 #include <vector>
 
+#include <cstddef>
 #include <cstring>
 #include "common.h"
 #include "limb_planes.h"
@@ -228,6 +229,8 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
     if (k < 0) continue;
     const KernelInfo &ki_ = kKernels[k];
     const int64_t t = tiles_of(ki_);
+    // the tile table packs (tile row, tile column) into 16 bits each
+    if ((a.M + ki_.bm - 1) / ki_.bm > 0xffff || (a.N + ki_.bn - 1) / ki_.bn > 0xffff) continue;
     // below ~5/8 of a round of the larger tiles (3/8 of the 64x64 ones) the compiler-scheduled kernels' slice-parallel and
     // small-problem forms do better
     if (g_f32_asm < 2 && t < (k == tiny ? 96 : 160)) continue;
@@ -338,10 +341,10 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
 }
 
 // int64 GEMM mod 2^64 (gemm_i64_mfma.hip's arithmetic; kernel "i64_64x64x32" of laser_amd/asmgen/i8_kernel.py): eight tile-major
-// digit planes in `ws` (>= 8 * (rup(M,64) + rup(N,64)) * rup(K,32) bytes), one launch.  alpha = 1, beta = 0, K <= 8192.
+// digit planes in `ws` (>= 8 * (rup(M,64) + rup(N,64)) * rup(K,32) bytes), one launch.  Any int64 alpha / beta (wrapping), K <= 8192.
 hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t s) {
   if (!g_i32_asm) return hipErrorNotSupported;
-  if (a.batch != 1 || a.alpha != 1 || a.beta != 0 || a.csC != 1 || a.rsC < a.N) return hipErrorNotSupported;
+  if (a.batch != 1 || a.csC != 1 || a.rsC < a.N) return hipErrorNotSupported;
   if (a.M < 1 || a.N < 1 || a.K < 1 || a.K > 8192) return hipErrorNotSupported;
   const int64_t Mpad = (a.M + 63) / 64 * 64, Npad = (a.N + 63) / 64 * 64, Kpad = (a.K + 31) / 32 * 32;
   const int64_t tiles = (Mpad / 64) * (Npad / 64);
@@ -372,6 +375,10 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t
   ka.alpha = 0.0f; ka.beta = 0.0f;
   ka.dbg = nullptr;
   ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
+  // int64 alpha / beta in the H, W / oW, pH slots (i8_kernel.py KA_ALPHA64 = 72: where the f64 kernels take their doubles)
+  static_assert(offsetof(KernArgs, H) == 72 && offsetof(KernArgs, oW) == 80, "KA_ALPHA64");
+  std::memcpy(&ka.H, &a.alpha, 8);
+  std::memcpy(&ka.oW, &a.beta, 8);
   ka.bsB_bytes = ka.bsC_bytes = 0;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -381,10 +388,11 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t
 }
 
 // float64 twin of launch_gemm_f32_asm (kernels of laser_amd/asmgen/f64_kernel.py): row-major A and C, B row-major or passed
-// transposed, any alpha / beta, K even.
+// transposed, any alpha / beta, K even, batches as grid y.
 hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipStream_t s) {
   if (!g_f64_asm) return hipErrorNotSupported;
-  if (a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if (a.batch < 1 || a.batch > 65535 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if (a.batch > 1 && (a.bsA < 0 || a.bsB < 0 || a.bsC < 0)) return hipErrorNotSupported;
   if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
   const bool nt = a.csB != 1 && a.rsB == 1;
   if (!nt && a.csB != 1) return hipErrorNotSupported;
@@ -403,7 +411,7 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   const double cu_flops_per_us = 78.6e6 / 256.0;
   for (int k : {big, tiny}) {
     const KernelInfo &ki_ = kKernels[k];
-    const int64_t t = ((a.M + ki_.bm - 1) / ki_.bm) * ((a.N + ki_.bn - 1) / ki_.bn);
+    const int64_t t = ((a.M + ki_.bm - 1) / ki_.bm) * ((a.N + ki_.bn - 1) / ki_.bn) * (int64_t)a.batch;   // (batches are grid y)
     if (g_f64_asm < 2 && t < (k == tiny ? 96 : 160)) continue;
     const int64_t rounds = (t + 255) / 256;
     const double tile_us = 2.0 * ki_.bm * ki_.bn * (double)a.K / cu_flops_per_us;
@@ -440,9 +448,15 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   std::memcpy(&ab[1], &a.beta, 8);
   ka.H = (uint32_t)ab[0]; ka.W = (uint32_t)(ab[0] >> 32);
   ka.oW = (uint32_t)ab[1]; ka.pH = (uint32_t)(ab[1] >> 32);
+  // batch strides in bytes (f64_kernel.py KA_BSA64 = 88: the pW, Cin slots; B's and C's where the f32 kernels take theirs)
+  static_assert(offsetof(KernArgs, pW) == 88, "KA_BSA64");
+  const uint64_t bsA_bytes = a.batch > 1 ? (uint64_t)a.bsA * 8 : 0;
+  ka.pW = (uint32_t)bsA_bytes; ka.Cin = (uint32_t)(bsA_bytes >> 32);
+  ka.bsB_bytes = a.batch > 1 ? (uint64_t)a.bsB * 8 : 0;
+  ka.bsC_bytes = a.batch > 1 ? (uint64_t)a.bsC * 8 : 0;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)(tiles_m * (int64_t)tiles_n), 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)(tiles_m * (int64_t)tiles_n), (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);
   if (e == hipSuccess) g_last_f64_asm = 1 + pick;
   return e;
 }
@@ -481,6 +495,7 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   const KernelInfo &ki = kKernels[pick];
   const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
+  if (tiles_m > 0xffff || tiles_n > 0xffff) return hipErrorNotSupported;   // 16-bit tile coordinates in the table
   if (g_f32_asm < 2 && tiles * a.batch < 160) return hipErrorNotSupported;
   // a 256-row tile that is mostly padding (few output channels) loses to the compiler-scheduled 128 / 64-row tiles
   if (g_f32_asm < 2 && (double)a.M * (double)a.N < 0.75 * (double)tiles * ki.bm * ki.bn) return hipErrorNotSupported;

@@ -17,6 +17,7 @@ passed down is the address of the array's first element; strides are in elements
 computes: every function forwards to the HIP library and raises LaserHipError on failure.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -462,15 +463,15 @@ def conv2d_im2col(output, oshape, input_, ishape, kernel, kshape, padding, strid
         raise ValueError("oshape does not match conv2d_out_shape(ishape, kshape, padding, strides)")
     if oshape[1] != kshape[0]:
         raise ValueError("oshape.c != kshape.c_out")  # conv2d_im2col.nim:109
-    _f32_dense("output", output, int(np.prod(oshape)))
-    _f32_dense("input", input_, int(np.prod(ishape)))
-    _f32_dense("kernel", kernel, int(np.prod(kshape)))
+    _f32_dense("output", output, math.prod(oshape))
+    _f32_dense("input", input_, math.prod(ishape))
+    _f32_dense("kernel", kernel, math.prod(kshape))
     _f32_dense("pworkspace", pworkspace, im2col_workspace_size(ishape, kshape, padding, strides))   # ONE image's worth (the reference's contract)
     _f32_dense("bias", bias, kshape[0])
     args = [_ptr(output), _ptr(input_), *ishape, _ptr(kernel), *kshape, *padding, *strides, _ptr(pworkspace)]
     act = _activation_code(activation)
     if bias is not None or act:
-        if bias is not None and int(np.prod(tuple(bias.shape))) != kshape[0]:
+        if bias is not None and math.prod(bias.shape) != kshape[0]:
             raise ValueError("bias must hold c_out values")
         args += [_ptr(bias), act]
         if _same_side(output, input_, kernel, pworkspace, bias):

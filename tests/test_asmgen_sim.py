@@ -94,6 +94,8 @@ F64_CASES = [
     ("exact_64x64x16", 40, 30, 530, dict(lda=532)),                   # kc = 256 folds + K tail
     ("fast_128x128x16", 33, 50, 22, dict(lda=24, ldb=52, ldc=54)),
     ("exact_128x128x16", 130, 70, 290, {}),
+    ("exact_64x64x16", 70, 80, 300, dict(lda=310, ldc=90, batch=3, alpha=2.0, beta=0.5)),   # grid y = batch index
+    ("fast_64x64x16_nt", 64, 70, 32, dict(batch=2)),
 ]
 
 
@@ -122,6 +124,12 @@ def test_i32_limb_kernel_exact_in_the_interpreter(M, N, Kd, ldc):
 def test_i64_limb_kernel_exact_in_the_interpreter(M, N, Kd, ldc):
     """int64 GEMM mod 2^64 on eight int8 digit planes (36 limb products, 64-bit recombination with carries), full-range operands"""
     assert C.run_case_i64(M, N, Kd, ldc=ldc, verbose=False)
+
+
+@pytest.mark.parametrize("alpha,beta", [(-3, 0), (0x123456789abcdef, -0x7654321fedcba987), (1, 5)])
+def test_i64_limb_kernel_alpha_beta_in_the_interpreter(alpha, beta):
+    """C = alpha * A B + beta * C0 mod 2^64 in the int64 kernel's epilogue (three bodies: plain, alpha only, alpha and beta)"""
+    assert C.run_case_i64(70, 50, 40, ldc=61, alpha=alpha, beta=beta, seed=4, verbose=False)
 
 
 def test_interpreter_rejects_a_read_of_a_register_still_loading():

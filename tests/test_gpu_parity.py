@@ -1369,6 +1369,26 @@ def test_finalize_unloads_and_the_library_comes_back(la, oracle):
     assert np.array_equal(second.cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
 
 
+def test_f32_asm_more_than_65535_tile_rows(la, oracle):
+    """A tall matrix with more 64-row tiles than the tile table's 16-bit coordinates hold (M = 4.2 M rows, one 64-column tile):
+    the launcher must leave the 64x64 kernels out of the choice.  Rows on both sides of the 65536 * 64 wrap point, the first
+    and the last rows against the oracle (a row of C depends on its row of A only)."""
+    import torch
+    M, N, K = 4_200_000, 64, 8
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.rand((M, K), generator=g, device="cuda") - 0.5
+    B = torch.rand((K, N), generator=g, device="cuda") - 0.5
+    C = torch.full((M, N), float("nan"), device="cuda")
+    la.gemm_strided(M, N, K, 1.0, A, K, 1, B, N, 1, 0.0, C, N, 1)
+    assert la.last_f32_asm() in (3, 4, 7, 8), la.last_f32_asm()      # the 128x128 kernels: 32813 tile rows
+    Bh = B.cpu().numpy()
+    wrap = 65536 * 64
+    for r0, r1 in ((0, 200), (wrap - 200, wrap + 200), (wrap + 5000, wrap + 5100), (M - 150, M)):
+        want = oracle.matmul(A[r0:r1].cpu().numpy(), Bh)
+        assert np.array_equal(C[r0:r1].cpu().numpy(), want), (r0, r1)
+    assert not bool(torch.isnan(C).any())
+
+
 def test_f32_asm_batched_and_slice_parallel(la, oracle):
     """Batches on the assembly kernels (grid y = batch index; shared operands by stride 0) and the slice-parallel form running
     its kc slices on them: bit-identical to the compiler-scheduled kernels, batches and slices against the oracle."""
@@ -1410,10 +1430,50 @@ def test_f32_asm_batched_and_slice_parallel(la, oracle):
     assert np.array_equal(res[1].cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
 
 
+def test_f64_asm_batched_and_slice_parallel(la, oracle):
+    """float64 twin of the test above: batches as grid y on the hand-scheduled f64 kernels and the slice-parallel form's kc = 256
+    slices on them -- bit-identical to the compiler-scheduled kernels, batches and slices against the oracle."""
+    import torch
+    rng = np.random.default_rng(607)
+    b, M, N, K = 4, 400, 520, 530
+    A = torch.from_numpy(rand(rng, (b, M, K), np.float64)).cuda()
+    B = torch.from_numpy(rand(rng, (K, N), np.float64)).cuda()               # shared by every batch entry (stride 0)
+    outs = {}
+    for mode in (0, 1):
+        for asm in (2, 0):
+            la.set_float_mode(mode); la.set_option("f64_asm", asm)
+            try:
+                C = torch.full((b, M, N + 3), 5.0, device="cuda", dtype=torch.float64)
+                la.gemm_strided_batched(b, M, N, K, 1.0, A, K, 1, M * K, B, N, 1, 0, 0.0, C, N + 3, 1, M * (N + 3))
+                assert (la.get_option("last_f64_asm") != 0) == (asm == 2), (mode, asm)
+                outs[(mode, asm)] = C
+            finally:
+                la.set_option("f64_asm", 1); la.set_float_mode(0)
+        assert torch.equal(outs[(mode, 2)], outs[(mode, 0)]), mode
+    got = outs[(0, 2)].cpu().numpy()
+    assert (got[:, :, N:] == 5.0).all()
+    for i in range(b):
+        assert np.array_equal(got[i, :, :N], oracle.matmul(A[i].cpu().numpy(), B.cpu().numpy())), i
+    M, N, K = 512, 512, 2048 + 36                                            # 64 tiles x 9 slices
+    A = torch.from_numpy(rand(rng, (M, K), np.float64)).cuda()
+    B = torch.from_numpy(rand(rng, (K, N), np.float64)).cuda()
+    res = {}
+    for asm in (1, 0):
+        la.set_option("f64_asm", asm)
+        try:
+            res[asm] = la.matmul(A, B)
+            used = la.get_option("last_f64_asm")
+        finally:
+            la.set_option("f64_asm", 1)
+        assert (used != 0) == (asm == 1), (asm, used)
+    assert torch.equal(res[1], res[0])
+    assert np.array_equal(res[1].cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
+
+
 def test_i64_asm_kernel_bit_exact(la, oracle):
     """The hand-scheduled int64 limb kernel (i8_kernel.py "i64_64x64x32"; option i32_asm covers both integer kernels): == the
-    compiler-scheduled limb kernel == the oracle, full-range operands (wrap-around mod 2^64), ragged shapes, strided views; K > 8192
-    and alpha / beta fall through."""
+    compiler-scheduled limb kernel == the oracle, full-range operands (wrap-around mod 2^64), ragged shapes, strided views, any
+    alpha / beta; K > 8192 falls through."""
     import torch
     rng = np.random.default_rng(92)
     info = np.iinfo(np.int64)
@@ -1442,10 +1502,28 @@ def test_i64_asm_kernel_bit_exact(la, oracle):
     try:
         la.matmul(A, B)
         assert la.get_option("last_i32_asm") == 0          # K > 8192
-        la.matmul(A[:, :512].contiguous(), B[:512].contiguous(), 3, 0)
-        assert la.get_option("last_i32_asm") == 0          # alpha != 1
     finally:
         la.set_option("i32_asm", 1)
+    # alpha / beta (wrapping mod 2^64) in the kernel's epilogue: == the compiler-scheduled kernel == the oracle; beta == 0 never reads C
+    for (M, N, K, alpha, beta) in [(256, 256, 128, -3, 0), (300, 200, 96, 0x123456789abcdef, -0x7654321fedcba987), (128, 1000, 64, 1, 5),
+                                   (130, 130, 200, int(info.min), int(info.max))]:
+        A = rng.integers(info.min, info.max, (M, K), dtype=np.int64)
+        B = rng.integers(info.min, info.max, (K, N), dtype=np.int64)
+        C0 = rng.integers(info.min, info.max, (M, N), dtype=np.int64)
+        want = oracle.matmul(A, B, alpha, beta, C0.copy())
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        outs = {}
+        for asm in (2, 0):
+            la.set_option("i32_asm", asm)
+            try:
+                C = torch.from_numpy(C0).cuda()
+                la.matmul(dA, dB, alpha, beta, C)
+                assert (la.get_option("last_i32_asm") != 0) == (asm == 2), (M, N, K, asm)
+                outs[asm] = C
+            finally:
+                la.set_option("i32_asm", 1)
+        assert torch.equal(outs[2], outs[0]), (M, N, K, alpha, beta)
+        assert np.array_equal(outs[2].cpu().numpy(), want), (M, N, K, alpha, beta)
 
 
 def test_fused_epilogue_on_the_assembly_kernels(la, oracle):
