@@ -212,7 +212,8 @@ template <int CH>
 hipError_t launch_mfma_ch(const ConvSmallArgs &g, int batch, hipStream_t s) {
   const int kpad = (g.K + 2 * CH - 1) / (2 * CH) * (2 * CH);
   const size_t lds = (size_t)kpad * (32 * sizeof(float) + sizeof(int2));
-  // three workgroups per CU in one round (about 124 registers, four waves each), split evenly over the images
+  // three workgroups per CU in one round (about 124 registers, four waves each), split evenly over the images (two per CU:
+  // the same time without padding, 43 vs 37 us with the per-tap bounds tests of the padded form)
   const int64_t wgs_needed = (g.npix + 127) / 128, wgs_target = (256 * 3 + batch - 1) / batch;
   const dim3 grid((unsigned)std::max<int64_t>(1, std::min(wgs_needed, wgs_target)), (unsigned)batch);
   if (g.pH == 0 && g.pW == 0) hipLaunchKernelGGL((conv_direct_mfma_kernel<false, CH>), grid, dim3(256), lds, s, g, kpad);

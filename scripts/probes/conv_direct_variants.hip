@@ -48,6 +48,17 @@ __global__ void __launch_bounds__(256) k(const Args g, int kpad) {
   };
   float xa[CH], xb[CH];
   issue(xa);
+  if (V == 7) {   // three register sets: the loads run two steps ahead of the arithmetic
+    float xc[CH];
+    issue(xb);
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s += 3) {
+      issue(xc); compute(xa); if (s + 1 >= nsteps) break;
+      issue(xa); compute(xb); if (s + 2 >= nsteps) break;
+      issue(xb); compute(xc);
+    }
+    return;
+  }
   if (V == 6) {
     float prev[16]; int ppix = g.npix;   // nothing to store yet
     auto compute6 = [&](const float (&x)[CH]) {
@@ -88,9 +99,9 @@ int main() {
   float *img, *filt, *out; hipMalloc(&img, 4L * batch * C * H * W); hipMalloc(&filt, 4L * M * K); hipMalloc(&out, 4L * batch * M * npix + 4096);
   hipMemset(img, 0, 4L * batch * C * H * W); hipMemset(filt, 0, 4L * M * K);
   Args a{filt, img, out, (long)C * H * W, (long)M * npix, npix, M, K, H, W, 3, 3, oW, npix};
-  for (int wgs : {48, 64, 80, 128}) {
-    printf("{\"wgs_per_image\": %d, \"V0_full_us\": %.1f, \"V1_nostore_us\": %.1f, \"V2_noload_us\": %.1f, \"V3_mfma_only_us\": %.1f, \"V5_store_only_us\": %.1f, \"V6_interleaved_stores_us\": %.1f}\n", wgs,
-           run<0>(a, batch, wgs), run<1>(a, batch, wgs), run<2>(a, batch, wgs), run<3>(a, batch, wgs), run<5>(a, batch, wgs), run<6>(a, batch, wgs));
+  for (int wgs : {8, 16, 24}) {
+    printf("{\"wgs_per_image\": %d, \"V0_full_us\": %.1f, \"V1_nostore_us\": %.1f, \"V2_noload_us\": %.1f, \"V3_mfma_only_us\": %.1f, \"V5_store_only_us\": %.1f, \"V6_interleaved_stores_us\": %.1f, \"V7_three_sets_us\": %.1f}\n", wgs,
+           run<0>(a, batch, wgs), run<1>(a, batch, wgs), run<2>(a, batch, wgs), run<3>(a, batch, wgs), run<5>(a, batch, wgs), run<6>(a, batch, wgs), run<7>(a, batch, wgs));
   }
   // padded planes: rsC a multiple of 32 floats -> every 128-byte store is line-aligned
   { Args b = a; b.rsC = (npix + 31) / 32 * 32; b.bsC = (long)M * b.rsC; float *o2; hipMalloc(&o2, 4L * batch * b.bsC + 4096); b.out = o2;
