@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised convolution parity (GPU box): random geometry (incl. W % 4 == 0 shapes that take the LDS input-patch
 loader and others that take the per-element gather), bias + relu epilogue on some, device path, vs the oracle.
-usage: fuzz_conv.py [cases] [seed]"""
+usage: fuzz_conv.py [cases] [seed] [small]     small: every case in the direct kernels' class (<= 32 output channels, C*kH*kW <= 256)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,6 +11,8 @@ from oracle import oracle
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fails = 0
+small = len(sys.argv) > 3 and sys.argv[3] == "small"
+direct = 0
 isa = oracle.fused_isa(np.float32)
 for it in range(cases):
     kH, kW = int(rng.integers(1, 8)), int(rng.integers(1, 8))
@@ -26,6 +28,10 @@ for it in range(cases):
         kH = kW = 3; pH = pW = int(rng.integers(0, 2)); sH = sW = 1
         H = W = int(rng.choice([28, 30, 54, 56, 58]))
         n, C, Co = int(rng.integers(8, 33)), int(rng.choice([32, 57, 64, 100, 128])), int(rng.choice([128, 192, 256]))
+    if small:
+        Co = int(rng.integers(1, 33))
+        C = int(rng.integers(1, max(2, min(70, 256 // (kH * kW) + 1))))
+        if rng.random() < 0.3: H, W = int(rng.integers(max(kH, 40), 120)), int(rng.integers(max(kW, 40), 120))   # several groups per wave
     ishape, kshape, pad, st = (n, C, H, W), (Co, C, kH, kW), (pH, pW), (sH, sW)
     x = rng.uniform(-1, 1, ishape).astype(np.float32); w = rng.uniform(-1, 1, kshape).astype(np.float32)
     oshape = laser_amd.conv2d_out_shape(ishape, kshape, pad, st)
@@ -43,11 +49,12 @@ for it in range(cases):
     laser_amd.set_conv_patch(bool(rng.random() < 0.8)); laser_amd.set_conv_kslice(bool(rng.random() < 0.8))
     laser_amd.conv2d_im2col(dout, oshape, torch.from_numpy(x).cuda(), ishape, torch.from_numpy(w).cuda(), kshape, pad, st, None,
                             bias=None if b is None else torch.from_numpy(b).cuda(), activation="relu" if use_epi else None)
+    direct += laser_amd.get_option("last_f32_config") == -3
     got = dout.cpu().numpy()
     ok = np.allclose(got, want, rtol=1e-5, atol=1e-5) if shortcut_is_wrong else np.array_equal(got, want)
     if not ok:
         fails += 1
         print("FAIL", dict(it=it, ishape=ishape, kshape=kshape, pad=pad, st=st, epi=use_epi, maxabs=float(np.nanmax(np.abs(got - want)))), flush=True)
 laser_amd.set_conv_patch(True); laser_amd.set_conv_kslice(True)
-print(f"fuzz_conv: {cases} cases, {fails} failures")
+print(f"fuzz_conv: {cases} cases, {fails} failures, {direct} on the direct small-channel kernels")
 sys.exit(1 if fails else 0)
