@@ -1292,7 +1292,7 @@ def test_i32_asm_kernel_bit_exact(la, oracle):
 
 
 def test_asm_kernels_fuzz_strides_offsets(la, oracle):
-    """Randomised operand geometry on the hand-scheduled kernels (f32 plain / transposed B with alpha, beta; f64; int32): leading
+    """Randomised operand geometry on the hand-scheduled kernels (f32 plain / transposed B, f64, int32, int64; alpha, beta): leading
     dimensions of any parity, base pointers at any element offset (element alignment only), ragged M / N, K tails -- against the
     compiler-scheduled kernels (bit-identical, nothing outside the M x N view of C touched) and, in laser-order mode, the oracle."""
     import torch
@@ -1302,19 +1302,21 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
         n = rows * ld + off + 8
         if dtype == np.int32:
             return rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+        if dtype == np.int64:
+            return rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
         return rng.uniform(-1, 1, n).astype(dtype)
 
     def views(host, rows, cols, ld, off):
         dev = torch.from_numpy(host).cuda()
         return dev, dev[off:off + rows * ld].view(rows, ld)[:, :cols], host[off:off + rows * ld].reshape(rows, ld)[:, :cols]
 
-    for case in range(40):
-        kind = ("f32", "f32nt", "f64", "i32", "f64nt")[case % 5]
+    for case in range(48):
+        kind = ("f32", "f32nt", "f64", "i32", "f64nt", "i64")[case % 6]
         M, N = int(rng.integers(300, 1500)), int(rng.integers(300, 1500))
         K = int(rng.integers(1, 1200)) if kind.startswith("f32") else int(rng.integers(1, 300)) * (2 if kind.startswith("f64") else 1)
-        if kind == "i32":
-            K = max(K, 32)         # (smaller int32 problems go to the VALU kernel)
-        dt = {"f32": np.float32, "f32nt": np.float32, "f64": np.float64, "i32": np.int32, "f64nt": np.float64}[kind]
+        if kind in ("i32", "i64"):
+            K = max(K, 32)         # (smaller integer problems go to the VALU kernel)
+        dt = {"f32": np.float32, "f32nt": np.float32, "f64": np.float64, "i32": np.int32, "f64nt": np.float64, "i64": np.int64}[kind]
         lda, offa = K + int(rng.integers(0, 9)), int(rng.integers(0, 7))
         _, dA, hA = views(host_buf(M, lda, offa, dt), M, K, lda, offa)
         if kind.endswith("nt"):
@@ -1326,9 +1328,14 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
             _, dB, hB = views(host_buf(K, ldb, offb, dt), K, N, ldb, offb)
         ldc, offc = N + int(rng.integers(0, 9)), int(rng.integers(0, 7))
         hC0 = host_buf(M, ldc, offc, dt)
-        al, be = ((1, 0), (0.5, 0), (1, 1), (-1.5, 0.75))[int(rng.integers(0, 4))] if kind != "i32" else ((1, 0), (-3, 7), (2**31 - 1, 1))[int(rng.integers(0, 3))]
-        opt = {"f32": "f32_asm", "f32nt": "f32_asm", "f64": "f64_asm", "i32": "i32_asm", "f64nt": "f64_asm"}[kind]
-        for mode in ((0, 1) if kind != "i32" else (0,)):
+        if kind == "i32":
+            al, be = ((1, 0), (-3, 7), (2**31 - 1, 1))[int(rng.integers(0, 3))]
+        elif kind == "i64":
+            al, be = ((1, 0), (-3, 0), (2**63 - 1, -5), (1, 1))[int(rng.integers(0, 4))]
+        else:
+            al, be = ((1, 0), (0.5, 0), (1, 1), (-1.5, 0.75))[int(rng.integers(0, 4))]
+        opt = {"f32": "f32_asm", "f32nt": "f32_asm", "f64": "f64_asm", "i32": "i32_asm", "f64nt": "f64_asm", "i64": "i32_asm"}[kind]
+        for mode in ((0, 1) if kind not in ("i32", "i64") else (0,)):
             outs = {}
             for asm in (2, 0):
                 la.set_float_mode(mode)
