@@ -83,13 +83,15 @@ int laser_hip_f32_config_count(void);
  *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only
  *   "zero_copy_poll"   [1] small host-pointer calls poll completion flags in mapped memory; 0 = synchronise the stream
  *   "skinny"           [1] M <= 8 or N <= 8: the streaming kernel        "small_path" [1] the one-wave-per-block kernel
- *   "split_tail"       [1] main + tail launches when the last round of tiles would be badly filled
+ *   "split_tail"       [1] main + tail launches when the last round of tiles would be badly filled (also: whole rounds on top +
+ *                      the slice-parallel form for the rows of the last round, with "slice_parallel")
  *   "slice_parallel"   [1] few tiles x long K: kc slices as one batched launch + ordered combine
  *   "slice_parallel_min" / "slice_parallel_tiles"  tuning overrides of that rule (0 = built-in)
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
  *   "last_f32_asm" / "last_f64_asm" / "last_i32_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
- *   "last_split"       column where the last float GEMM / conv launch was cut (0 = one launch) */
+ *   "last_split"       column where the last float GEMM / conv launch was cut (0 = one launch); negative: -(first row of the
+ *                      K-sliced bottom part) of a problem cut along M into whole rounds + the rest */
 int laser_hip_set_option(const char *name, int value);
 int laser_hip_get_option(const char *name, int64_t *value);
 const char *laser_hip_f32_config_name(int cfg);
