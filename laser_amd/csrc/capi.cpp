@@ -458,6 +458,30 @@ hipError_t run_gemm_core<double>(const GemmArgs<double> &a, hipStream_t s) {
   }  // v_mfma_f64_16x16x4_f64: a k-ordered fma chain
   return launch_gemm_valu<double>(a, laser, s);
 }
+// Integer K beyond the hand-scheduled limb kernels' 8192 (their accumulator groups are never folded): arithmetic mod 2^n is
+// associative, so C = alpha * sum_chunks(A_c B_c) + beta * C0 is computed chunk by chunk -- the first with (alpha, beta), the
+// rest with (alpha, 1) -- bit for bit the single product.  hipErrorNotSupported (nothing launched): not the kernels' class.
+template <typename T, typename FA, typename FC>
+hipError_t int_gemm_k_chunks(const GemmArgs<T> &a, void *ws, hipStream_t s, FA asm_launch, FC compiler_launch) {
+  constexpr int64_t kChunk = 8192;
+  hipError_t e = hipErrorNotSupported;
+  for (int64_t k0 = 0; k0 < a.K; k0 += kChunk) {
+    GemmArgs<T> c = a;
+    c.K = std::min(kChunk, a.K - k0);
+    c.Kext = c.K;
+    c.A = a.A + k0 * a.csA;
+    c.B = a.B + k0 * a.rsB;
+    if (k0 > 0) c.beta = (T)1;
+    e = asm_launch(c, ws, s);
+    if (e == hipErrorNotSupported) {
+      if (k0 == 0) return e;
+      e = compiler_launch(c, ws, s);
+    }
+    if (e != hipSuccess) return e;
+  }
+  return e;
+}
+
 template <>
 hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
   // Large single problems go to the int8 matrix cores (limb decomposition, gemm_i32_mfma.hip); the
@@ -472,7 +496,8 @@ hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
     hipError_t e = hipMallocAsync(&ws, gemm_i32_mfma_workspace_bytes(a.M, a.N, a.K), s);
     if (e != hipSuccess) return e;
     g_last_i32_asm = 0;
-    e = launch_gemm_i32_asm(a, ws, s);      // the hand-scheduled kernel (laser_amd/asmgen/i8_kernel.py) when eligible
+    // the hand-scheduled kernel (laser_amd/asmgen/i8_kernel.py) when eligible, K > 8192 in chunks
+    e = a.K > 8192 ? int_gemm_k_chunks<int32_t>(a, ws, s, launch_gemm_i32_asm, launch_gemm_i32_mfma) : launch_gemm_i32_asm(a, ws, s);
     if (e == hipErrorNotSupported) e = launch_gemm_i32_mfma(a, ws, s);
     hipError_t e2 = hipFreeAsync(ws, s);
     return e != hipSuccess ? e : e2;
@@ -492,7 +517,8 @@ hipError_t run_gemm<int64_t>(const GemmArgs<int64_t> &a, hipStream_t s) {
     hipError_t e = hipMallocAsync(&ws, gemm_i64_mfma_workspace_bytes(a.M, a.N, a.K), s);
     if (e != hipSuccess) return e;
     g_last_i32_asm = 0;
-    e = launch_gemm_i64_asm(a, ws, s);      // the hand-scheduled kernel (i8_kernel.py "i64_64x64x32") when eligible
+    // the hand-scheduled kernel (i8_kernel.py "i64_64x64x32") when eligible, K > 8192 in chunks
+    e = a.K > 8192 ? int_gemm_k_chunks<int64_t>(a, ws, s, launch_gemm_i64_asm, launch_gemm_i64_mfma) : launch_gemm_i64_asm(a, ws, s);
     if (e == hipErrorNotSupported) e = launch_gemm_i64_mfma(a, ws, s);
     hipError_t e2 = hipFreeAsync(ws, s);
     return e != hipSuccess ? e : e2;

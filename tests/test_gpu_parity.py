@@ -1240,7 +1240,7 @@ def test_f64_asm_kernels_bit_exact(la, oracle):
 def test_i32_asm_kernel_bit_exact(la, oracle):
     """The hand-scheduled int32 limb kernel (laser_amd/asmgen/i8_kernel.py; option i32_asm): == the compiler-scheduled limb kernel
     (i32_asm = 0) == the oracle, full-range operands (wrap-around mod 2^32), ragged M / N / K, strided and transposed operand views,
-    a padded C; K > 8192, alpha / beta and a strided C fall through to the compiler-scheduled kernel."""
+    a padded C, any alpha / beta, K > 8192 in chunks; a strided C falls through to the compiler-scheduled kernel."""
     import torch
     rng = np.random.default_rng(91)
     info = np.iinfo(np.int32)
@@ -1279,8 +1279,16 @@ def test_i32_asm_kernel_bit_exact(la, oracle):
     B = torch.from_numpy(rng.integers(info.min, info.max, (8200, 256), dtype=np.int32)).cuda()
     la.set_option("i32_asm", 2)
     try:
-        la.matmul(A, B)
-        assert la.get_option("last_i32_asm") == 0          # K > 8192
+        # K > 8192: chunks of 8192 k on the assembly kernel, the first with (alpha, beta), the rest with (alpha, 1) -- arithmetic
+        # mod 2^32 is associative, so this is the single product bit for bit
+        k1 = torch.full((256, 256), 5, dtype=torch.int32, device="cuda"); k0 = k1.clone()
+        la.matmul(A, B, -3, 7, k1)
+        assert la.get_option("last_i32_asm") != 0
+        la.set_option("i32_asm", 0)
+        la.matmul(A, B, -3, 7, k0)
+        assert la.get_option("last_i32_asm") == 0 and torch.equal(k1, k0)
+        assert np.array_equal(k1.cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy(), -3, 7, np.full((256, 256), 5, np.int32)))
+        la.set_option("i32_asm", 2)
         c1 = torch.full((256, 256), 11, dtype=torch.int32, device="cuda"); c2 = c1.clone()
         la.matmul(A[:, :512].contiguous(), B[:512].contiguous(), -3, 7, c1)
         assert la.get_option("last_i32_asm") != 0          # alpha / beta (wrapping) run on the assembly kernel too
@@ -1510,7 +1518,7 @@ def test_f64_asm_batched_and_slice_parallel(la, oracle):
 def test_i64_asm_kernel_bit_exact(la, oracle):
     """The hand-scheduled int64 limb kernel (i8_kernel.py "i64_64x64x32"; option i32_asm covers both integer kernels): == the
     compiler-scheduled limb kernel == the oracle, full-range operands (wrap-around mod 2^64), ragged shapes, strided views, any
-    alpha / beta; K > 8192 falls through."""
+    alpha / beta, K > 8192 in chunks."""
     import torch
     rng = np.random.default_rng(92)
     info = np.iinfo(np.int64)
@@ -1537,8 +1545,13 @@ def test_i64_asm_kernel_bit_exact(la, oracle):
     B = torch.from_numpy(rng.integers(info.min, info.max, (8200, 256), dtype=np.int64)).cuda()
     la.set_option("i32_asm", 2)
     try:
-        la.matmul(A, B)
-        assert la.get_option("last_i32_asm") == 0          # K > 8192
+        k1 = torch.full((256, 256), 5, dtype=torch.int64, device="cuda"); k0 = k1.clone()     # K > 8192: chunks, as for int32
+        la.matmul(A, B, 2**62 + 3, -9, k1)
+        assert la.get_option("last_i32_asm") != 0
+        la.set_option("i32_asm", 0)
+        la.matmul(A, B, 2**62 + 3, -9, k0)
+        assert la.get_option("last_i32_asm") == 0 and torch.equal(k1, k0)
+        assert np.array_equal(k1.cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy(), 2**62 + 3, -9, np.full((256, 256), 5, np.int64)))
     finally:
         la.set_option("i32_asm", 1)
     # alpha / beta (wrapping mod 2^64) in the kernel's epilogue: == the compiler-scheduled kernel == the oracle; beta == 0 never reads C
