@@ -27,7 +27,9 @@
  *     sums added into beta*C in ascending order -- bit-identical to Laser on an FMA host
  *     (gemm_ukernel_generator.nim:245-248, gemm.nim:150-158, gemm_tiling.nim:309-310).
  *     LASER_HIP_F32_FAST keeps one chain across all of K (within 1e-5 relative, not bit-equal
- *     for K > 512).  f64 follows the same rule with kc = 256.
+ *     for K > 512; launch plans that split K -- few tiles x long K, the rows of a badly filled
+ *     last round -- add kc-slice chains in order instead: the same bound).  f64 follows the same
+ *     rule with kc = 256.
  */
 #ifndef LASER_HIP_H
 #define LASER_HIP_H
