@@ -146,7 +146,10 @@ hipError_t tile_table(DeviceModule *m, int tiles_m, int tiles_n, int group_m, hi
     }
     uint32_t *devp = nullptr;
     hipError_t e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    // blocking, once per tile grid: the table is cached for every later call, which may run on ANOTHER stream -- an upload
+    // ordered only on this call's stream could still be in flight when that stream launches against it
+    (void)s;
+    if (e == hipSuccess) e = hipMemcpy(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       if (devp) (void)hipFree(devp);
       delete host;
