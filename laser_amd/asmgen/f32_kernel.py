@@ -20,9 +20,14 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
-                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32"):
+                 b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32",
+                 persistent=None):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
         self.dtype = dtype
+        # persistent: the workgroup loops over unit runs handed out by the in-kernel scheduler (sched_next): whole tiles, and -- where
+        # the launcher cuts tiles along K at slice boundaries -- head slices stored to a workspace / tail runs that fold them in
+        # order.  The convolution kernels (out of SGPRs, never split) run exactly one tile per workgroup.
+        self.persistent = (not conv and not debug) if persistent is None else persistent
         f64 = dtype == "f64"
         # f32: v_mfma_f32_32x32x2 (32x32 blocks, 2 k per instruction, one 16-byte fragment read feeds 4 k-steps);
         # f64: v_mfma_f64_16x16x4 (16x16 blocks, 4 k per instruction, one 16-byte read feeds 2 k-steps): 8 k per group either way
@@ -103,7 +108,24 @@ KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 
 KA_CONV0, KA_CONV1, KA_CONV2 = 72, 104, 120
 KA_BIAS, KA_EPI = 128, 136   # fused epilogue: bias pointer (u64; 0 = none); rowStrideBias, colStrideBias (elements), activation (0 none / 1 relu), -
 KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's share the convolution kernels' slots at 112 / 120
-KERNARG_SIZE = 152
+# scheduler block (every kernel): the workgroup -> tile map is arithmetic on these (gemm.nim:160-176 partitions by arithmetic too);
+# a divisor d travels as magic(d) = floor(2^32 / d) + 1 (0 for d == 1): x / d = mulhi(x, magic) while x * d < 2^32 (launcher)
+#   +0 tiles_m  +4 tiles_n  +8 group_m  +12 rows of the last group  +16 magic(group_m * tiles_n)  +20 magic(group_m)
+#   +24 magic(rows of the last group)  +28 xcd_q (workgroups / 8; 0 = no XCD remap)
+#   +32 xcd_r (workgroups % 8)  +36 P (K slices per tile)  +40 magic(P)  +44 units_q  +48 units_r (units = workgroups * q + r)
+#   +52 slice length (elements of K)  +56 workspace slots per workgroup  +60 workgroups
+#   +64 workspace (u64)  +72 flags (u64)
+KA_SCHED = 152
+KA_SCHED2 = KA_SCHED + 32
+KA_WS = KA_SCHED + 64
+KERNARG_SIZE = 232
+MODE_FULL, MODE_HEAD, MODE_TAIL = 0, 1, 2
+
+
+def magic_u32(d):
+    """host side of the kernels' division: floor(2^32 / d) + 1, 0 for d == 1"""
+    assert d >= 1
+    return 0 if d == 1 else ((1 << 32) // d + 1) & 0xffffffff
 
 
 class Gen:
@@ -129,6 +151,7 @@ class Gen:
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
+        self.alloc_sched()
         # accumulators
         self.acc = [p.aalloc(c.ACCR) for _ in range(c.NB)]
         self.run = [p.aalloc(c.ACCR) for _ in range(c.NB)] if c.exact else None
@@ -157,6 +180,7 @@ class Gen:
             self.s_c0m, self.s_c1m = S(2), S(2)            # prologue: lanes whose first / second pixel's column ow (+1) + kw - pW exists
             self.s_m, self.s_m2 = S(2), S(2)
             self.s_HW4, self.s_W4, self.s_Cin = S(), S(), S()
+            self.s_sc = scr.sub(0, 8)                      # (the scheduler constants are dead before conv_setup loads the geometry)
         elif c.b_kcontig:
             self.WB = [[[V() for _ in range(3)] for _ in range(c.NPB)] for _ in range(2)]   # like A: [MFMA half][piece][stage]
         else:
@@ -186,6 +210,23 @@ class Gen:
         self.vt = [blk[i] for i in range(10)]
         # filler experiments (timing only): dummy data / address registers that alias temporaries the loop does not use
         self.vF, self.vFaddr, self.vFoff = blk.sub(4, 4), blk[10], blk[11]
+
+    def alloc_sched(self):
+        """scheduler state: persistent kernels walk units [s_u, s_uend) of the launch's unit sequence (unit = one K slice of one
+        tile, tile-major); a run = consecutive units of ONE tile: k in [s_kb, s_kb + s_Keff), in one of three modes"""
+        c, S = self.c, self.p.salloc
+        self.s_sc = None
+        if c.persistent:
+            self.s_sc = S(8, align=4)                      # scheduler constants, (re)loaded where they are used
+            self.s_u, self.s_uend, self.s_vid = S(), S(), S()
+            self.s_kb, self.s_Keff, self.s_mode = S(), S(), S()
+            self.s_tile, self.s_pe, self.s_slot = S(), S(), S()   # linear tile index; slices of the run; workspace slot of a head run
+            self.s_wsf = S(4, align=4)                     # workspace pointer, flags pointer
+        else:
+            self.s_Keff = self.s_K
+            self.s_tile = None
+            if not c.conv:
+                self.s_sc = S(8, align=4)
 
     # ------------------------------------------------------------------ queue models -> counted waits
     def vm_issue(self, tag):
@@ -265,8 +306,143 @@ class Gen:
         e("s_waitcnt", lgkmcnt=0)
         self.dump(name, self.vt[8])
 
+    # ------------------------------------------------------------------ workgroup -> tile: arithmetic, no table
+    def udiv(self, dst, x, magic):
+        """dst = x / d for the divisor whose magic number (magic_u32) is in SGPR `magic`; dst != x"""
+        e = self.p.emit
+        e("s_mul_hi_u32", dst, x, magic)
+        e("s_cmp_eq_u32", magic, 0)
+        e("s_cselect_b32", dst, x, dst)
+
+    def xcd_remap(self, dst, wg, xq, xr, tmp):
+        """hardware sends workgroup g to XCD g % 8: give every XCD one contiguous chunk of ids (bijective for any grid size), so
+        that the workgroups resident on an XCD work on neighbouring tiles and share operand panels in that XCD's L2.
+        dst = (g % 8) * xq + min(g % 8, xr) + g / 8 with xq = G / 8, xr = G % 8; xq == 0: dst = g"""
+        e = self.p.emit
+        e("s_and_b32", tmp, wg, 7)
+        e("s_mul_i32", dst, tmp, xq)
+        e("s_min_u32", tmp, tmp, xr)
+        e("s_add_u32", dst, dst, tmp)
+        e("s_lshr_b32", tmp, wg, 3)
+        e("s_add_u32", dst, dst, tmp)
+        e("s_cmp_eq_u32", xq, 0)
+        e("s_cselect_b32", dst, wg, dst)
+
+    def tile_coords(self, tile, sc, pm, pn, tmp):
+        """grouped raster (the ic / jr partition of gemm.nim:160-176 as arithmetic): tiles are walked in groups of group_m tile rows,
+        column by column inside a group.  sc = the 8 SGPRs loaded from KA_SCHED; pm, pn, tmp[0..2]: distinct SGPRs, not `tile`"""
+        e = self.p.emit
+        tiles_m, tiles_n, gm, gsz_last, mg_width, mg_gm, mg_last = (sc[i] for i in range(7))
+        e("s_mul_i32", tmp[0], gm, tiles_n)                   # width = tiles of a full group
+        self.udiv(tmp[1], tile, mg_width)                     # group
+        e("s_mul_i32", tmp[0], tmp[1], tmp[0])
+        e("s_sub_u32", tmp[0], tile, tmp[0])                  # rem = index inside the group
+        e("s_mul_i32", tmp[1], tmp[1], gm)                    # first tile row of the group
+        e("s_sub_u32", tmp[2], tiles_m, tmp[1])
+        e("s_cmp_lt_u32", tmp[2], gm)                         # the last group may have fewer rows
+        e("s_cselect_b32", tmp[2], gsz_last, gm)              # gsz
+        e("s_cselect_b32", pm, mg_last, mg_gm)                # its magic
+        self.udiv(pn, tmp[0], pm)                             # pid_n = rem / gsz
+        e("s_mul_i32", tmp[2], pn, tmp[2])
+        e("s_sub_u32", tmp[0], tmp[0], tmp[2])                # rem % gsz
+        e("s_add_u32", pm, tmp[1], tmp[0])                    # pid_m
+
+    # ------------------------------------------------------------------ scheduler of the persistent kernels
+    def sched_init(self):
+        """units [s_u, s_uend) of this workgroup: virtual id v (XCD remap) -> v * units_q + min(v, units_r), one more unit for v < units_r"""
+        e, st, sc = self.p.emit, self.s_t, self.s_sc
+        e("s_load_dword", st[5], s(0, 2), KA_SCHED + 28)
+        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
+        e("s_load_dwordx4", self.s_wsf, s(0, 2), KA_WS)
+        e("s_waitcnt", lgkmcnt=0)
+        xr, units_q, units_r = sc[0], sc[3], sc[4]
+        self.xcd_remap(self.s_vid, s(2), st[5], xr, st[0])
+        e("s_mul_i32", self.s_u, self.s_vid, units_q)
+        e("s_min_u32", st[0], self.s_vid, units_r)
+        e("s_add_u32", self.s_u, self.s_u, st[0])
+        e("s_cmp_lt_u32", self.s_vid, units_r)
+        e("s_cselect_b32", st[0], 1, 0)
+        e("s_add_u32", self.s_uend, self.s_u, units_q)
+        e("s_add_u32", self.s_uend, self.s_uend, st[0])
+
+    def sched_next(self, L_exit):
+        """the next run: consecutive units of one tile.  Unit u = tile * P + p.  p == 0: slices [0, n), n = min(P, units left): the
+        whole tile (FULL) or its first slices (TAIL: this workgroup finishes the tile -- the later slices come from the workspace,
+        where the workgroups that own them put them as HEAD runs: laser-order one slice per run, since every slice sum is added on its
+        own, gemm.nim:150-158; one chain: all of the workgroup's slices of that tile as one partial sum)."""
+        c, e, st, sc = self.c, self.p.emit, self.s_t, self.s_sc
+        e("s_cmp_ge_u32", self.s_u, self.s_uend)
+        e("s_cbranch_scc1", L_exit)
+        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
+        e("s_waitcnt", lgkmcnt=0)
+        P, mg_P, units_q, units_r, slen, hmax = sc[1], sc[2], sc[3], sc[4], sc[5], sc[6]
+        p_, left = st[0], st[1]
+        self.udiv(self.s_tile, self.s_u, mg_P)
+        e("s_mul_i32", p_, self.s_tile, P)
+        e("s_sub_u32", p_, self.s_u, p_)                          # p
+        e("s_sub_u32", left, self.s_uend, self.s_u)
+        head, join = self.p.label("head"), self.p.label("run")
+        e("s_cmp_lg_u32", p_, 0)
+        e("s_cbranch_scc1", head)
+        e("s_min_u32", self.s_pe, P, left)
+        e("s_cmp_eq_u32", self.s_pe, P)
+        e("s_cselect_b32", self.s_mode, MODE_FULL, MODE_TAIL)
+        e("s_mov_b32", self.s_kb, 0)
+        e("s_branch", join)
+        self.p.place(head)
+        if c.exact:
+            e("s_mov_b32", self.s_pe, 1)
+        else:
+            e("s_sub_u32", self.s_pe, P, p_)
+            e("s_min_u32", self.s_pe, self.s_pe, left)
+        e("s_mov_b32", self.s_mode, MODE_HEAD)
+        e("s_mul_i32", self.s_kb, p_, slen)
+        # workspace slot: vid * hmax + (index of this head run in the workgroup: laser-order u - first unit, one chain 0)
+        e("s_mul_i32", self.s_slot, self.s_vid, hmax)
+        if c.exact:
+            e("s_mul_i32", st[2], self.s_vid, units_q)
+            e("s_min_u32", st[3], self.s_vid, units_r)
+            e("s_add_u32", st[2], st[2], st[3])
+            e("s_sub_u32", st[2], self.s_u, st[2])
+            e("s_add_u32", self.s_slot, self.s_slot, st[2])
+        self.p.place(join)
+        e("s_add_u32", st[2], p_, self.s_pe)
+        e("s_mul_i32", st[2], st[2], slen)
+        e("s_min_u32", st[2], st[2], self.s_K)                    # end of the run along K
+        e("s_sub_u32", self.s_Keff, st[2], self.s_kb)
+        e("s_add_u32", self.s_u, self.s_u, self.s_pe)
+
     # ------------------------------------------------------------------ prologue
     def prologue(self):
+        """once per workgroup: kernel arguments, lane decode, LDS addresses; then (persistent kernels: per run) the tile, its
+        descriptors and the first two K-tiles"""
+        c, p = self.c, self.p
+        e = p.emit
+        st = self.s_t
+        self.once()
+        self.L_run, self.L_exit = p.label("next_run"), p.label("exit")
+        if c.persistent:
+            self.sched_init()
+            p.place(self.L_run)
+            e("s_barrier", comment="every wave is done with the previous run's LDS tiles")
+            self.sched_next(self.L_exit)
+            tile = self.s_tile
+            e("s_load_dwordx8", self.s_sc, s(0, 2), KA_SCHED)
+            e("s_waitcnt", lgkmcnt=0)
+        else:
+            e("s_load_dwordx8", self.s_sc, s(0, 2), KA_SCHED)
+            e("s_load_dword", st[5], s(0, 2), KA_SCHED2)
+            e("s_waitcnt", lgkmcnt=0)
+            self.xcd_remap(st[4], s(2), self.s_sc[7], st[5], st[0])
+            tile = st[4]
+        self.tile_coords(tile, self.s_sc, st[0], st[1], (st[2], st[3], st[5]))
+        self.dump("pid_m", st[0])
+        self.dump("pid_n", st[1])
+        e("s_mul_i32", self.s_m0, st[0], c.BM)
+        e("s_mul_i32", self.s_n0, st[1], c.BN)
+        self.run_setup()
+
+    def once(self):
         c, p = self.c, self.p
         e = p.emit
         t = self.vt
@@ -275,9 +451,6 @@ class Gen:
                f"{'laser-order (kc = 512 slices)' if c.exact else 'one accumulation chain'}")
         e("s_load_dwordx8", self.ka0, s(0, 2), KA_A)
         e("s_load_dwordx8", self.ka1, s(0, 2), KA_LDA)
-        e("s_lshl_b32", st[0], s(2), 2)
-        e("s_waitcnt", lgkmcnt=0)
-        e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16 (XCD-aware raster made by the host)")
         if not c.conv:
             # batched problems (gemm_strided_batched; the kc slices of the slice-parallel form): workgroup id y = batch index,
             # operand b at base + b * batch stride (bytes, 64-bit; 0 for plain launches)
@@ -291,6 +464,7 @@ class Gen:
                 e("s_add_u32", st[3], st[3], st[4])
                 e("s_add_u32", ptr[0], ptr[0], st[2])
                 e("s_addc_u32", ptr[1], ptr[1], st[3])
+        e("s_waitcnt", lgkmcnt=0)
         if c.debug:
             e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
             e("s_waitcnt", lgkmcnt=0)
@@ -302,7 +476,6 @@ class Gen:
             self.dump("wgid_x", s(2))
             self.dump("lda", self.s_lda)
             self.dump("K", self.s_K)
-            self.dump("tile_word", st[1])
         # ---- lane decode (independent of the tile) ----
         tid = v(0)
         lane, lo, hi, lor, kqs = t[0], t[1], t[2], t[3], t[4]
@@ -338,26 +511,14 @@ class Gen:
         # k-contiguous operand (A always; B when it is passed transposed): a 16-byte piece = 4 consecutive k of row x,
         # kq = tid % (BK/4), x = tid / (BK/4) (+ XS per piece)
         nkq = c.BK // 4
-        XS = 256 // nkq
         kq, x, row, sw = t[0], t[1], t[2], t[3]
         e("v_and_b32", kq, nkq - 1, tid)
         e("v_lshrrev_b32", x, nkq.bit_length() - 1, tid)
         self.kq_row(row, x, t[5])
         self.kq_swz(sw, x, t[5])
-        # K tail: pieces of the last K-tile that lie beyond K get an offset the bounds check rejects (they read as 0, like
-        # Laser's zero-padded panels, gemm_packing.nim:46-55); K is a multiple of 4 (launcher), so pieces are all-or-nothing
-        e("s_and_b32", self.s_ktail, self.s_K, c.BK - 1)
-        e("v_lshlrev_b32", t[5], 2, kq)
-        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
-        # K % 4 != 0: the piece that straddles K is loaded whole (its tail belongs to the next row, or reads 0 past the panel) and
-        # its elements beyond K are zeroed in the staging registers before they are stored (mask_last_pieces)
-        for j in range(4):
-            e("v_add_u32", t[6], j, t[5])
-            e("v_cmp_gt_u32", self.s_em[j], self.s_ktail, t[6])
         e("v_mov_b32", self.v_oob, 0x80000000)
-        e("s_nop", 4)
 
-        def kcontig(W, Voff, NP, ld_bytes, lds_off):
+        def kcontig_lds(W, NP, lds_off):
             e("v_lshrrev_b32", t[5], 1, kq)          # kq / 2
             e("v_lshlrev_b32", t[5], 1, t[5])        # 2 * (kq / 2)
             e("v_and_b32", t[6], 1, kq)              # kq % 2
@@ -374,18 +535,11 @@ class Gen:
                         e("v_add_u32", W[cc][pi][2], 4096 * pi, W[cc][0][2])
                     e("v_add_u32", W[cc][pi][0], c.STAGE, W[cc][pi][2])
                     e("v_add_u32", W[cc][pi][1], 2 * c.STAGE, W[cc][pi][2])
-            # global offsets of the pieces: V_i = (x + i*XS) * ld * 4 + kq * 16
-            e("v_mul_lo_u32", t[7], x, ld_bytes)
-            e("v_lshl_add_u32", Voff[0], kq, 4, t[7])
-            e("s_mul_i32", st[4], ld_bytes, XS)
-            for i in range(1, NP):
-                e("v_add_u32", Voff[i], st[4], Voff[i - 1])
 
-        e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
-        kcontig(self.WA, self.vVA, c.NPA, st[3], c.LDS0)
+        kcontig_lds(self.WA, c.NPA, c.LDS0)
         e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
         if c.b_kcontig:
-            kcontig(self.WB, self.vVB, c.NPB, st[5], c.BK * c.BM * 4)
+            kcontig_lds(self.WB, c.NPB, c.BK * c.BM * 4)
             e("s_mov_b32", self.s_bstep, c.BK * 4, comment="B (stored transposed) advances BK elements along its rows per K-tile")
         if not c.b_kcontig and not c.conv:
             # B pieces (x-contiguous, 16 B = 4 consecutive x of row k), handled in pairs (k, k+2) -- DESIGN.md 3.2 pair mode
@@ -425,8 +579,6 @@ class Gen:
                 e("v_lshlrev_b32", t[9], 2, t[9])                # 4 * word
                 for ee in range(4):
                     xx, rr, ss = t[0], t[1], t[2]  # aa / pp / hh are dead from here on
-                    if gi == 0 and ee == 0:
-                        pass
                     e("v_lshl_add_u32", xx, xq, 2, ee)           # x = 4xq + e
                     self.kq_row(rr, xx, t[5])
                     self.kq_swz(ss, xx, t[5])
@@ -436,25 +588,63 @@ class Gen:
                     e("v_add3_u32", self.WB[gi][ee][2], rr, t[9], st[0])
                     e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
                     e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
-        # ---- tile coordinates, descriptors ----
-        e("s_waitcnt", lgkmcnt=0)
-        e("s_and_b32", st[0], st[1], 0xffff)
-        e("s_lshr_b32", st[1], st[1], 16)
-        e("s_mul_i32", self.s_m0, st[0], c.BM)
-        e("s_mul_i32", self.s_n0, st[1], c.BN)
+
+    def kcontig_goff(self, Voff, NP, ld_bytes):
+        """global offsets of the 16-byte pieces of a k-contiguous operand: V_i = (x + i*XS) * ld * 4 + kq * 16 (per run: the K tail
+        of a run overwrites them with the out-of-bounds offset)"""
+        c, e, t, st = self.c, self.p.emit, self.vt, self.s_t
+        nkq = c.BK // 4
+        XS = 256 // nkq
+        e("v_and_b32", t[0], nkq - 1, v(0))
+        e("v_lshrrev_b32", t[1], nkq.bit_length() - 1, v(0))
+        e("v_mul_lo_u32", t[7], t[1], ld_bytes)
+        e("v_lshl_add_u32", Voff[0], t[0], 4, t[7])
+        e("s_mul_i32", st[4], ld_bytes, XS)
+        for i in range(1, NP):
+            e("v_add_u32", Voff[i], st[4], Voff[i - 1])
+
+    def run_setup(self):
+        """one run = k in [kb, kb + Keff) of tile (m0, n0): K-tail masks, piece offsets, descriptors, the first two K-tiles"""
+        c, p = self.c, self.p
+        e = p.emit
+        t = self.vt
+        st = self.s_t
+        Keff = self.s_Keff
+        # K tail: pieces of the last K-tile that lie beyond K get an offset the bounds check rejects (they read as 0, like
+        # Laser's zero-padded panels, gemm_packing.nim:46-55)
+        nkq = c.BK // 4
+        e("s_and_b32", self.s_ktail, Keff, c.BK - 1)
+        e("v_and_b32", t[5], nkq - 1, v(0))
+        e("v_lshlrev_b32", t[5], 2, t[5])
+        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
+        # K % 4 != 0: the piece that straddles K is loaded whole (its tail belongs to the next row, or reads 0 past the panel) and
+        # its elements beyond K are zeroed in the staging registers before they are stored (mask_last_pieces)
+        for j in range(4):
+            e("v_add_u32", t[6], j, t[5])
+            e("v_cmp_gt_u32", self.s_em[j], self.s_ktail, t[6])
+        e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
+        self.kcontig_goff(self.vVA, c.NPA, st[3])
+        e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
+        if c.b_kcontig:
+            self.kcontig_goff(self.vVB, c.NPB, st[5])
+        e("s_nop", 4)
+        # ---- descriptors ----
         A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
-        # A panel: base = A + m0 * lda * 4; bytes = (min(M - m0, BM) - 1) * lda * 4 + K * 4
-        e("s_lshl_b32", st[3], self.s_lda, 2)
+        # A panel: base = A + m0 * lda * 4 + kb * 4; bytes = (min(M - m0, BM) - 1) * lda * 4 + Keff * 4
         e("s_mul_hi_u32", st[2], self.s_m0, st[3])
         e("s_mul_i32", st[0], self.s_m0, st[3])
         e("s_add_u32", self.srdA[0], A_[0], st[0])
         e("s_addc_u32", self.srdA[1], A_[1], st[2])
+        if c.persistent:
+            e("s_lshl_b32", st[0], self.s_kb, 2)
+            e("s_add_u32", self.srdA[0], self.srdA[0], st[0])
+            e("s_addc_u32", self.srdA[1], self.srdA[1], 0)
         e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
         e("s_sub_u32", st[0], self.s_M, self.s_m0)
         e("s_min_u32", st[0], st[0], c.BM)
         e("s_sub_u32", st[0], st[0], 1)
         e("s_mul_i32", st[0], st[0], st[3])
-        e("s_lshl_b32", st[2], self.s_K, 2)
+        e("s_lshl_b32", st[2], Keff, 2)
         e("s_add_u32", self.srdA[2], st[0], st[2])
         e("s_mov_b32", self.srdA[3], 0x00020000)
         if c.conv:
@@ -471,49 +661,43 @@ class Gen:
                 self.dump("conv WB00", self.WB[0][0][2])
                 self.dump("conv WB31", self.WB[3][1][2])
         elif c.b_kcontig:
-            # B^T panel: base = B + n0 * ldb * 4; bytes = (min(N - n0, BN) - 1) * ldb * 4 + K * 4
+            # B^T panel: base = B + n0 * ldb * 4 + kb * 4; bytes = (min(N - n0, BN) - 1) * ldb * 4 + Keff * 4
             e("s_mul_hi_u32", st[2], self.s_n0, st[5])
             e("s_mul_i32", st[0], self.s_n0, st[5])
             e("s_add_u32", self.srdB[0], B_[0], st[0])
             e("s_addc_u32", self.srdB[1], B_[1], st[2])
+            if c.persistent:
+                e("s_lshl_b32", st[0], self.s_kb, 2)
+                e("s_add_u32", self.srdB[0], self.srdB[0], st[0])
+                e("s_addc_u32", self.srdB[1], self.srdB[1], 0)
             e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
             e("s_sub_u32", st[0], self.s_N, self.s_n0)
             e("s_min_u32", st[0], st[0], c.BN)
             e("s_sub_u32", st[0], st[0], 1)
             e("s_mul_i32", st[0], st[0], st[5])
-            e("s_lshl_b32", st[2], self.s_K, 2)
+            e("s_lshl_b32", st[2], Keff, 2)
             e("s_add_u32", self.srdB[2], st[0], st[2])
         else:
-            # B panel: base = B + n0 * 4; bytes = (K - 1) * ldb * 4 + (N - n0) * 4
+            # B panel: base = B + n0 * 4 + kb * ldb * 4; bytes = (Keff - 1) * ldb * 4 + (N - n0) * 4
             e("s_lshl_b32", st[0], self.s_n0, 2)
             e("s_add_u32", self.srdB[0], B_[0], st[0])
             e("s_addc_u32", self.srdB[1], B_[1], 0)
+            if c.persistent:
+                e("s_mul_hi_u32", st[2], self.s_kb, st[5])
+                e("s_mul_i32", st[0], self.s_kb, st[5])
+                e("s_add_u32", self.srdB[0], self.srdB[0], st[0])
+                e("s_addc_u32", self.srdB[1], self.srdB[1], st[2])
             e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
-            e("s_sub_u32", st[0], self.s_K, 1)
+            e("s_sub_u32", st[0], Keff, 1)
             e("s_mul_i32", st[0], st[0], st[5])
             e("s_sub_u32", st[2], self.s_N, self.s_n0)
             e("s_lshl_b32", st[2], st[2], 2)
             e("s_add_u32", self.srdB[2], st[0], st[2])
         e("s_mov_b32", self.srdB[3], 0x00020000)
         # C: the whole matrix (conv: this image's [M][oH*oW] block), bytes = (M - 1) * ldc * 4 + N * 4
-        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
-        if c.conv:
-            e("s_mul_hi_u32", st[2], s(3), self.s_scr[12])
-            e("s_mul_i32", st[0], s(3), self.s_scr[12])
-            e("s_add_u32", self.srdC[0], C_[0], st[0])
-            e("s_addc_u32", self.srdC[1], C_[1], st[2])
-            e("s_and_b32", self.srdC[1], self.srdC[1], 0xffff)
-        else:
-            e("s_mov_b32", self.srdC[0], C_[0])
-            e("s_and_b32", self.srdC[1], C_[1], 0xffff)
-        e("s_sub_u32", st[0], self.s_M, 1)
-        e("s_mul_i32", st[0], st[0], self.s_ldc4)
-        e("s_lshl_b32", st[2], self.s_N, 2)
-        e("s_add_u32", self.srdC[2], st[0], st[2])
-        e("s_mov_b32", self.srdC[3], 0x00020000)
-        e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
+        self.c_descriptor()
         # number of K-tiles
-        e("s_add_u32", self.s_rem, self.s_K, c.BK - 1)
+        e("s_add_u32", self.s_rem, Keff, c.BK - 1)
         e("s_lshr_b32", self.s_rem, self.s_rem, (c.BK).bit_length() - 1)
         # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
         if c.debug:
@@ -595,6 +779,27 @@ class Gen:
             e("v_lshlrev_b32", self.vFaddr, 4, v(0))
             e("v_add_u32", self.vFaddr, c.lds_bytes, self.vFaddr, comment="filler experiments: 16 B per lane past the kernel's LDS")
             e("v_lshlrev_b32", self.vFoff, 4, v(0))
+
+    def c_descriptor(self):
+        """srdC = the whole C matrix (conv: this image's [M][oH*oW] block): bytes = (M - 1) * ldc * 4 + N * 4"""
+        c, e, st = self.c, self.p.emit, self.s_t
+        C_ = self.ka0.sub(4, 2)
+        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
+        if c.conv:
+            e("s_mul_hi_u32", st[2], s(3), self.s_scr[12])
+            e("s_mul_i32", st[0], s(3), self.s_scr[12])
+            e("s_add_u32", self.srdC[0], C_[0], st[0])
+            e("s_addc_u32", self.srdC[1], C_[1], st[2])
+            e("s_and_b32", self.srdC[1], self.srdC[1], 0xffff)
+        else:
+            e("s_mov_b32", self.srdC[0], C_[0])
+            e("s_and_b32", self.srdC[1], C_[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_M, 1)
+        e("s_mul_i32", st[0], st[0], self.s_ldc4)
+        e("s_lshl_b32", st[2], self.s_N, 2)
+        e("s_add_u32", self.srdC[2], st[0], st[2])
+        e("s_mov_b32", self.srdC[3], 0x00020000)
+        e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
 
     def issue_loads_all(self):
         if self.c.conv:      # (B's gathers first, like the loop body: the two queues must carry the same order)
@@ -825,7 +1030,7 @@ class Gen:
         if c.conv:
             return
         skip = self.p.label("nok4")
-        e("s_and_b32", self.s_t[0], self.s_K, 3)
+        e("s_and_b32", self.s_t[0], self.s_Keff, 3)
         e("s_cmp_eq_u32", self.s_t[0], 0)
         e("s_cbranch_scc1", skip)
         e("s_cmp_lg_u32", sreg, value)
@@ -1215,6 +1420,9 @@ class Gen:
         e("s_and_b32", self.s_t[0], self.s_beta, 0x7fffffff)
         e("s_cmp_eq_u32", self.s_t[0], 0)
         e("s_cbranch_scc1", skip)
+        if c.persistent:       # a head run's slice sums go to the workspace raw: beta * C0 belongs to the run that finishes the tile
+            e("s_cmp_eq_u32", self.s_mode, MODE_HEAD)
+            e("s_cbranch_scc1", skip)
         self.c_addr_setup()
         pool = [r[k] for slot in range(2) for r in (self.fa[slot] + self.fb[slot]) for k in range(4)]
         per = 4 * c.TN
@@ -1326,7 +1534,7 @@ class Gen:
                 if not (i == c.TM - 1 and q == 3):
                     for n in range(c.TN):
                         e("v_add_u32", vB[n], st[3], vB[n])
-        e("s_endpgm")
+        self.end_run()
         p.place(plain)
 
     def epilogue(self):
@@ -1350,6 +1558,7 @@ class Gen:
             for k_ in range(4):
                 self.dump(f"srdC[{k_}]", self.srdC[k_])
             self.dump("s_rem", self.s_rem)
+        self.mode_dispatch()
         self.fused_epilogue()
         self.c_addr_setup()
         if c.exact:
@@ -1413,10 +1622,185 @@ class Gen:
                             e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
                         self.c_step(i, q, rr)
             p.place(done)
-        e("s_endpgm")
+        self.end_run()
+
+    # ------------------------------------------------------------------ runs that share a tile: workspace, flags, ordered fix-up
+    def end_run(self):
+        if self.c.persistent:
+            self.p.emit("s_branch", self.L_run)
+        else:
+            self.p.emit("s_endpgm")
+
+    def tile_bytes(self):
+        c = self.c
+        return c.NB * c.ACCR * 256 * 4
+
+    def ws_descriptors(self, slot):
+        """srdA = flags[slot] (one dword: of the workgroup's 256 byte offsets 4 * tid only thread 0's is in range), srdB = workspace
+        slot `slot`: one tile in register order -- dword (b * ACCR + r) * 256 + tid = accumulator register r of block b of thread tid.
+        Clobbers s_t[4], s_t[5]."""
+        e, st, wsf = self.p.emit, self.s_t, self.s_wsf
+        e("s_lshl_b32", st[5], slot, 2)
+        e("s_add_u32", self.srdA[0], wsf[2], st[5])
+        e("s_addc_u32", self.srdA[1], wsf[3], 0)
+        e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
+        e("s_mov_b32", self.srdA[2], 4)
+        e("s_mov_b32", self.srdA[3], 0x00020000)
+        e("s_mul_hi_u32", st[4], slot, self.tile_bytes())
+        e("s_mul_i32", st[5], slot, self.tile_bytes())
+        e("s_add_u32", self.srdB[0], wsf[0], st[5])
+        e("s_addc_u32", self.srdB[1], wsf[1], st[4])
+        e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
+        e("s_mov_b32", self.srdB[2], self.tile_bytes())
+        e("s_mov_b32", self.srdB[3], 0x00020000)
+
+    def ws_walk(self, fn):
+        """fn(b, r, soffset SGPR, immediate offset) for every accumulator register in workspace order; soffset = s_t[5]"""
+        c, e, st = self.c, self.p.emit, self.s_t
+        e("s_mov_b32", st[5], 0)
+        n = 0
+        for b in range(c.NB):
+            for r in range(c.ACCR):
+                fn(b, r, st[5], (n % 4) * 1024)
+                n += 1
+                if n % 4 == 0 and n < c.NB * c.ACCR:
+                    e("s_add_u32", st[5], st[5], 4096)
+
+    def head_store(self):
+        """HEAD run: the raw slice sum (one chain: the partial sum of the run's slices) goes to the workspace slot, then the flag is
+        released at agent scope (the sequence hipcc emits for a release store on gfx950: write back L2, wait, store sc1) with the
+        number of slices the partial covers.  The workgroup that owns slice 0 of the tile adds the partials in ascending k."""
+        c, e, t = self.c, self.p.emit, self.vt
+        self.ws_descriptors(self.s_slot)
+        e("v_lshlrev_b32", t[8], 2, v(0))
+        self.ws_walk(lambda b, r, so, imm: e("buffer_store_dword", self.acc[b][r], t[8], self.srdB, so, offen=True, offset=imm, sc1=True))
+        e("s_waitcnt", vmcnt=0)
+        e("buffer_wbl2", sc1=True)
+        e("s_waitcnt", vmcnt=0)
+        e("s_barrier")
+        e("v_mov_b32", t[9], self.s_pe)
+        e("buffer_store_dword", t[9], t[8], self.srdA, 0, offen=True, sc1=True)
+        e("s_waitcnt", vmcnt=0)
+        self.end_run()
+
+    def fold_all(self):
+        """run += alpha * acc for every block (the slice fold of the K loop, outside it)"""
+        for b in range(self.c.NB):
+            self.fold_block(b)
+
+    def fold_block(self, b):
+        e, T = self.p.emit, self.vT[0]
+        for r in range(16):
+            e("v_accvgpr_read_b32", T[r], self.acc[b][r])
+        for r in range(16):
+            e("v_mul_f32", T[r], self.s_alpha, T[r])      # (1.0 * x is x: no branch here, the fix-up is not the hot loop)
+        for r in range(16):
+            tt = self.vt[r % 4]
+            e("v_accvgpr_read_b32", tt, self.run[b][r])
+            e("v_add_f32", tt, tt, T[r])
+            e("v_accvgpr_write_b32", self.run[b][r], tt)
+
+    def acc_add_block(self, b):
+        """acc[b] += the partial in vT"""
+        e, T = self.p.emit, self.vT[0]
+        for r in range(16):
+            tt = self.vt[r % 4]
+            e("v_accvgpr_read_b32", tt, self.acc[b][r])
+            e("v_add_f32", tt, tt, T[r])
+            e("v_accvgpr_write_b32", self.acc[b][r], tt)
+
+    def load_partial(self, t_off):
+        """laser-order: the accumulators become the next slice sum (the fold before the next partial / the epilogue adds it);
+        one chain: acc += partial"""
+        c, e, T, st = self.c, self.p.emit, self.vT[0], self.s_t
+        if c.exact:
+            self.ws_walk(lambda b, r, so, imm: e("buffer_load_dword", self.acc[b][r], t_off, self.srdB, so, offen=True, offset=imm, sc1=True))
+            e("s_waitcnt", vmcnt=0)
+            return
+        e("s_mov_b32", st[5], 0)
+        n = 0
+        for b in range(c.NB):
+            for r in range(c.ACCR):
+                e("buffer_load_dword", T[r], t_off, self.srdB, st[5], offen=True, offset=(n % 4) * 1024, sc1=True)
+                n += 1
+                if n % 4 == 0:
+                    e("s_add_u32", st[5], st[5], 4096)
+            e("s_waitcnt", vmcnt=0)
+            self.acc_add_block(b)
+
+    def tail_fixup(self, L_back):
+        """TAIL run: this workgroup computed slices [0, pe) of its tile; slices pe .. P-1 lie in the workspace, put there by the
+        workgroups after it in unit order (their HEAD runs, the first thing they do).  They are added in ascending slice order:
+        laser-order C = (..((beta C0 + a S_0) + a S_1) ..) exactly as the sequential loop does it (gemm.nim:150-158)."""
+        c, p = self.c, self.p
+        e, t, st, sc = p.emit, self.vt, self.s_t, self.s_sc
+        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
+        e("s_waitcnt", lgkmcnt=0)
+        P, units_q, units_r, hmax = sc[1], sc[3], sc[4], sc[6]
+        w, j, remw, slot, fv = st[0], st[1], st[2], st[3], st[4]
+
+        def len_w():
+            e("s_cmp_lt_u32", w, units_r)
+            e("s_cselect_b32", remw, 1, 0)
+            e("s_add_u32", remw, remw, units_q)
+        e("s_add_u32", w, self.s_vid, 1)
+        e("s_mov_b32", j, 0)
+        len_w()
+        e("v_lshlrev_b32", t[8], 2, v(0))
+        loop, spin, got, same = p.label("fix"), p.label("spin"), p.label("got"), p.label("samew")
+        p.place(loop)
+        if c.exact:
+            self.fold_all()
+        e("s_mul_i32", slot, w, hmax)
+        e("s_add_u32", slot, slot, j)
+        self.ws_descriptors(slot)
+        p.place(spin)
+        e("buffer_load_dword", t[9], OFF, self.srdA, 0, sc1=True)
+        e("s_waitcnt", vmcnt=0)
+        e("v_readfirstlane_b32", fv, t[9])
+        e("s_cmp_lg_u32", fv, 0)
+        e("s_cbranch_scc1", got)
+        e("s_sleep", 8)
+        e("s_branch", spin)
+        p.place(got)
+        e("buffer_inv", sc1=True)
+        self.load_partial(t[8])
+        e("s_barrier", comment="every wave has seen the flag: it can be cleared for the next launch")
+        e("v_mov_b32", t[9], 0)
+        e("buffer_store_dword", t[9], t[8], self.srdA, 0, offen=True, sc1=True)
+        e("s_waitcnt", vmcnt=0)
+        e("s_add_u32", self.s_pe, self.s_pe, fv)
+        e("s_sub_u32", remw, remw, fv)
+        e("s_add_u32", j, j, 1)
+        e("s_cmp_lg_u32", remw, 0)
+        e("s_cbranch_scc1", same)
+        e("s_add_u32", w, w, 1)
+        e("s_mov_b32", j, 0)
+        len_w()
+        p.place(same)
+        e("s_cmp_lt_u32", self.s_pe, P)
+        e("s_cbranch_scc1", loop)
+        e("s_branch", L_back)
+
+    def mode_dispatch(self):
+        """persistent kernels, after the K loop: HEAD runs store their partial and go on; TAIL runs collect the other workgroups'
+        partials, then take the ordinary epilogue"""
+        c, p = self.c, self.p
+        if not c.persistent:
+            return
+        e = p.emit
+        L_head, L_tail, L_epi = p.label("head_store"), p.label("tail_fixup"), p.label("epi")
+        e("s_cmp_eq_u32", self.s_mode, MODE_HEAD)
+        e("s_cbranch_scc1", L_head)
+        e("s_cmp_eq_u32", self.s_mode, MODE_TAIL)
+        e("s_cbranch_scc1", L_tail)
+        p.place(L_epi)
+        self.outlined_blocks.append((L_head, self.head_store))
+        self.outlined_blocks.append((L_tail, lambda: self.tail_fixup(L_epi)))
 
     def build(self):
         self.outlined = []
+        self.outlined_blocks = []
         self.prologue()
         self.main_loop()
         self.epilogue()
@@ -1425,6 +1809,12 @@ class Gen:
             for i in ins:
                 self.p.emit(*i)
             self.p.emit("s_branch", back)
+        for label, fn in self.outlined_blocks:
+            self.p.place(label)
+            fn()
+        if self.c.persistent:
+            self.p.place(self.L_exit)
+            self.p.emit("s_endpgm")
         return self.p
 
 

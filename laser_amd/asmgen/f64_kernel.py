@@ -15,7 +15,7 @@ ds_read_b128 -- and is 144 bytes long: with 9 chunks per row the 16 rows a 16-la
 Operands: A row-major (k-contiguous), B row-major (x-contiguous) or passed transposed (`_nt`: k-contiguous, stored like A), C
 row-major; K a multiple of 2; any alpha / beta (float64 in the kernel arguments)."""
 from .core import v, a, s, VCC
-from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_CONV1  # noqa: F401
+from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_CONV1, MODE_HEAD  # noqa: F401
 
 CONFIGS = {
     # one wave per SIMD: 2 x 2 waves of 64x64 = 16 blocks = 128 accumulator registers (+ 128 for the running sum)
@@ -53,6 +53,7 @@ class Gen64(Gen):
         self.s_a1, self.s_b0 = S(), S()           # 0 when alpha == 1.0 / when beta == +-0.0
         self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
         self.s_ldc4, self.s_ldc20 = S(), S()      # here: ldc * 8 bytes, 4 * ldc * 8 (the next accumulator row of a lane)
+        self.alloc_sched()
         self.acc = [p.aalloc(8) for _ in range(c.NB)]
         self.run = [p.aalloc(8) for _ in range(c.NB)] if c.exact else None
         self.fa = [[V(4) for _ in range(c.TM)] for _ in range(2)]
@@ -80,8 +81,8 @@ class Gen64(Gen):
         self.vt = [blk[i] for i in range(10)]
         self.vF, self.vFaddr, self.vFoff = blk.sub(4, 4), blk[10], blk[11]
 
-    # ------------------------------------------------------------------ prologue
-    def prologue(self):
+    # ------------------------------------------------------------------ prologue (f32_kernel.Gen.prologue: once, scheduler, run_setup)
+    def once(self):
         c, p = self.c, self.p
         e = p.emit
         t, st = self.vt, self.s_t
@@ -90,9 +91,6 @@ class Gen64(Gen):
                f"{'laser-order (kc = 256 slices)' if c.exact else 'one accumulation chain'}")
         e("s_load_dwordx8", self.ka0, s(0, 2), KA_A)
         e("s_load_dwordx8", self.ka1, s(0, 2), KA_LDA)
-        e("s_lshl_b32", st[0], s(2), 2)
-        e("s_waitcnt", lgkmcnt=0)
-        e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16")
         e("s_load_dwordx4", self.s_ab, s(0, 2), KA_ALPHA64)
         # batched problems (gemm_strided_batched; the kc slices of the slice-parallel form): workgroup id y = batch index, operand b at
         # base + b * batch stride (bytes, 64-bit; 0 for plain launches) -- as in the f32 kernels
@@ -143,15 +141,10 @@ class Gen64(Gen):
                 e("v_add_u32", R[g][0], t[5], row)
                 e("v_add_u32", R[g][1], c.STAGE, R[g][0])
                 e("v_add_u32", R[g][2], 2 * c.STAGE, R[g][0])
-        # K tail (K a multiple of 2): A pieces of the last K-tile beyond K read as 0
         pc, xr = t[0], t[1]
         e("v_and_b32", pc, 7, tid)
         e("v_lshrrev_b32", xr, 3, tid)
-        e("s_and_b32", self.s_ktail, self.s_K, c.BK - 1)
-        e("v_lshlrev_b32", t[5], 1, pc)
-        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
         e("v_mov_b32", self.v_oob, 0x80000000)
-        e("s_nop", 4)
         # A pieces: piece column pc = tid % 8 (k0 = 2 pc), row xr = tid / 8 (+ 32 per piece)
         #   LDS: row * RS + (4 * (pc >> 2) + 2 * (pc & 1)) * 16 + ((pc >> 1) & 1) * 8
         e("v_lshrrev_b32", t[5], 2, pc)
@@ -166,12 +159,7 @@ class Gen64(Gen):
             e("v_add_u32", self.WA[i][2], 32 * RS * i, t[5])
             e("v_add_u32", self.WA[i][0], c.STAGE, self.WA[i][2])
             e("v_add_u32", self.WA[i][1], 2 * c.STAGE, self.WA[i][2])
-        e("s_lshl_b32", st[3], self.s_lda, 3, comment="lda * 8 bytes")
-        e("v_mul_lo_u32", t[7], xr, st[3])
-        e("v_lshl_add_u32", self.vVA[0], pc, 4, t[7])
-        e("s_lshl_b32", st[4], st[3], 5)                     # 32 rows
-        for i in range(1, c.NPA):
-            e("v_add_u32", self.vVA[i], st[4], self.vVA[i - 1])
+        e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
         if c.b_kcontig:
             # B passed transposed: its pieces are (column x, k0 .. k0 + 1) -- the A layout with the B panel's offsets
             e("v_add_u32", t[5], c.BM * RS, t[5])
@@ -179,12 +167,6 @@ class Gen64(Gen):
                 e("v_add_u32", self.WB[j][2], 32 * RS * j, t[5])
                 e("v_add_u32", self.WB[j][0], c.STAGE, self.WB[j][2])
                 e("v_add_u32", self.WB[j][1], 2 * c.STAGE, self.WB[j][2])
-            e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
-            e("v_mul_lo_u32", t[7], xr, st[5])
-            e("v_lshl_add_u32", self.vVB[0], pc, 4, t[7])
-            e("s_lshl_b32", st[4], st[5], 5)
-            for j in range(1, c.NPB):
-                e("v_add_u32", self.vVB[j], st[4], self.vVB[j - 1])
             e("s_mov_b32", self.s_bstep, c.BK * 8)
         else:
             # B pieces: x pair px = tid % (BN / 2), row k = tid / (BN / 2) (+ KS per piece, KS = 512 / BN)
@@ -208,69 +190,97 @@ class Gen64(Gen):
                 e("v_add_u32", self.WB[j][2], cst, t[5])
                 e("v_add_u32", self.WB[j][0], c.STAGE, self.WB[j][2])
                 e("v_add_u32", self.WB[j][1], 2 * c.STAGE, self.WB[j][2])
-            e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
             e("v_mul_lo_u32", t[7], k0, st[5])
             e("v_lshl_add_u32", self.vVB[0], px, 4, t[7])
             e("s_mul_i32", st[4], st[5], KS)
             for j in range(1, c.NPB):
                 e("v_add_u32", self.vVB[j], st[4], self.vVB[j - 1])
             e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
-        # ---- tile coordinates, descriptors ----
-        e("s_waitcnt", lgkmcnt=0)
-        e("s_and_b32", st[0], st[1], 0xffff)
-        e("s_lshr_b32", st[1], st[1], 16)
-        e("s_mul_i32", self.s_m0, st[0], c.BM)
-        e("s_mul_i32", self.s_n0, st[1], c.BN)
-        A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
-        # A panel: base = A + m0 * lda * 8; bytes = (min(M - m0, BM) - 1) * lda * 8 + K * 8
+
+    def kcontig_goff64(self, Voff, NP, ld_bytes):
+        """global offsets of a k-contiguous operand's pieces: (xr + 32 i) * ld * 8 + pc * 16, pc = tid % 8, xr = tid / 8 (per run: the K
+        tail of a run overwrites them with the out-of-bounds offset)"""
+        e, t, st = self.p.emit, self.vt, self.s_t
+        e("v_and_b32", t[0], 7, v(0))
+        e("v_lshrrev_b32", t[1], 3, v(0))
+        e("v_mul_lo_u32", t[7], t[1], ld_bytes)
+        e("v_lshl_add_u32", Voff[0], t[0], 4, t[7])
+        e("s_lshl_b32", st[4], ld_bytes, 5)                  # 32 rows
+        for i in range(1, NP):
+            e("v_add_u32", Voff[i], st[4], Voff[i - 1])
+
+    def run_setup(self):
+        """one run = k in [kb, kb + Keff) of tile (m0, n0)"""
+        c, p = self.c, self.p
+        e = p.emit
+        t, st = self.vt, self.s_t
+        RS = c.RS
+        Keff = self.s_Keff
+        # K tail (Keff a multiple of 2): A pieces of the last K-tile beyond K read as 0
+        e("s_and_b32", self.s_ktail, Keff, c.BK - 1)
+        e("v_and_b32", t[5], 7, v(0))
+        e("v_lshlrev_b32", t[5], 1, t[5])
+        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
+        e("s_lshl_b32", st[3], self.s_lda, 3, comment="lda * 8 bytes")
+        self.kcontig_goff64(self.vVA, c.NPA, st[3])
+        e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
+        if c.b_kcontig:
+            self.kcontig_goff64(self.vVB, c.NPB, st[5])
+        e("s_nop", 4)
+        A_, B_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2)
+        # A panel: base = A + m0 * lda * 8 + kb * 8; bytes = (min(M - m0, BM) - 1) * lda * 8 + Keff * 8
         e("s_mul_hi_u32", st[2], self.s_m0, st[3])
         e("s_mul_i32", st[0], self.s_m0, st[3])
         e("s_add_u32", self.srdA[0], A_[0], st[0])
         e("s_addc_u32", self.srdA[1], A_[1], st[2])
+        if c.persistent:
+            e("s_lshl_b32", st[0], self.s_kb, 3)
+            e("s_add_u32", self.srdA[0], self.srdA[0], st[0])
+            e("s_addc_u32", self.srdA[1], self.srdA[1], 0)
         e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
         e("s_sub_u32", st[0], self.s_M, self.s_m0)
         e("s_min_u32", st[0], st[0], c.BM)
         e("s_sub_u32", st[0], st[0], 1)
         e("s_mul_i32", st[0], st[0], st[3])
-        e("s_lshl_b32", st[2], self.s_K, 3)
+        e("s_lshl_b32", st[2], Keff, 3)
         e("s_add_u32", self.srdA[2], st[0], st[2])
         e("s_mov_b32", self.srdA[3], 0x00020000)
         if c.b_kcontig:
-            # B^T panel: base = B + n0 * ldb * 8; bytes = (min(N - n0, BN) - 1) * ldb * 8 + K * 8
+            # B^T panel: base = B + n0 * ldb * 8 + kb * 8; bytes = (min(N - n0, BN) - 1) * ldb * 8 + Keff * 8
             e("s_mul_hi_u32", st[2], self.s_n0, st[5])
             e("s_mul_i32", st[0], self.s_n0, st[5])
             e("s_add_u32", self.srdB[0], B_[0], st[0])
             e("s_addc_u32", self.srdB[1], B_[1], st[2])
+            if c.persistent:
+                e("s_lshl_b32", st[0], self.s_kb, 3)
+                e("s_add_u32", self.srdB[0], self.srdB[0], st[0])
+                e("s_addc_u32", self.srdB[1], self.srdB[1], 0)
             e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
             e("s_sub_u32", st[0], self.s_N, self.s_n0)
             e("s_min_u32", st[0], st[0], c.BN)
             e("s_sub_u32", st[0], st[0], 1)
             e("s_mul_i32", st[0], st[0], st[5])
-            e("s_lshl_b32", st[2], self.s_K, 3)
+            e("s_lshl_b32", st[2], Keff, 3)
             e("s_add_u32", self.srdB[2], st[0], st[2])
         else:
-            # B panel: base = B + n0 * 8; bytes = (K - 1) * ldb * 8 + (N - n0) * 8
+            # B panel: base = B + n0 * 8 + kb * ldb * 8; bytes = (Keff - 1) * ldb * 8 + (N - n0) * 8
             e("s_lshl_b32", st[0], self.s_n0, 3)
             e("s_add_u32", self.srdB[0], B_[0], st[0])
             e("s_addc_u32", self.srdB[1], B_[1], 0)
+            if c.persistent:
+                e("s_mul_hi_u32", st[2], self.s_kb, st[5])
+                e("s_mul_i32", st[0], self.s_kb, st[5])
+                e("s_add_u32", self.srdB[0], self.srdB[0], st[0])
+                e("s_addc_u32", self.srdB[1], self.srdB[1], st[2])
             e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
-            e("s_sub_u32", st[0], self.s_K, 1)
+            e("s_sub_u32", st[0], Keff, 1)
             e("s_mul_i32", st[0], st[0], st[5])
             e("s_sub_u32", st[2], self.s_N, self.s_n0)
             e("s_lshl_b32", st[2], st[2], 3)
             e("s_add_u32", self.srdB[2], st[0], st[2])
         e("s_mov_b32", self.srdB[3], 0x00020000)
-        # C: the whole matrix, bytes = (M - 1) * ldc * 8 + N * 8
-        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 3)
-        e("s_mov_b32", self.srdC[0], C_[0])
-        e("s_and_b32", self.srdC[1], C_[1], 0xffff)
-        e("s_sub_u32", st[0], self.s_M, 1)
-        e("s_mul_i32", st[0], st[0], self.s_ldc4)
-        e("s_lshl_b32", st[2], self.s_N, 3)
-        e("s_add_u32", self.srdC[2], st[0], st[2])
-        e("s_mov_b32", self.srdC[3], 0x00020000)
-        e("s_lshl_b32", self.s_ldc20, self.s_ldc4, 2)
-        e("s_add_u32", self.s_rem, self.s_K, c.BK - 1)
+        self.c_descriptor()
+        e("s_add_u32", self.s_rem, Keff, c.BK - 1)
         e("s_lshr_b32", self.s_rem, self.s_rem, (c.BK).bit_length() - 1)
         # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
         self.tail_mask_if(self.s_rem, 1)
@@ -316,6 +326,20 @@ class Gen64(Gen):
                 self.dump(f"fb[0][0][{k_}]", self.fb[0][0][k_])
             for _ in range(c.TM + c.TN):
                 self.lg_issue(("R", 0))
+
+    def c_descriptor(self):
+        """srdC = the whole matrix: bytes = (M - 1) * ldc * 8 + N * 8"""
+        e, st = self.p.emit, self.s_t
+        C_ = self.ka0.sub(4, 2)
+        e("s_lshl_b32", self.s_ldc4, self.s_ldc, 3)
+        e("s_mov_b32", self.srdC[0], C_[0])
+        e("s_and_b32", self.srdC[1], C_[1], 0xffff)
+        e("s_sub_u32", st[0], self.s_M, 1)
+        e("s_mul_i32", st[0], st[0], self.s_ldc4)
+        e("s_lshl_b32", st[2], self.s_N, 3)
+        e("s_add_u32", self.srdC[2], st[0], st[2])
+        e("s_mov_b32", self.srdC[3], 0x00020000)
+        e("s_lshl_b32", self.s_ldc20, self.s_ldc4, 2)
 
     def issue_loads_all(self):
         for pi in range(self.c.NPA):
@@ -394,6 +418,30 @@ class Gen64(Gen):
             e("v_accvgpr_write_b32", self.run[b][2 * d], tt[0])
             e("v_accvgpr_write_b32", self.run[b][2 * d + 1], tt[1])
 
+    def fold_block(self, b):
+        e, T = self.p.emit, self.vT[0]
+        for r in range(8):
+            e("v_accvgpr_read_b32", T[r], self.acc[b][r])
+        for d in range(4):
+            e("v_mul_f64", T.sub(2 * d, 2), self.s_al, T.sub(2 * d, 2))      # (1.0 * x is x)
+        for d in range(4):
+            tt = T.sub(8 + 2 * (d % 2), 2)
+            e("v_accvgpr_read_b32", tt[0], self.run[b][2 * d])
+            e("v_accvgpr_read_b32", tt[1], self.run[b][2 * d + 1])
+            e("v_add_f64", tt, tt, T.sub(2 * d, 2))
+            e("v_accvgpr_write_b32", self.run[b][2 * d], tt[0])
+            e("v_accvgpr_write_b32", self.run[b][2 * d + 1], tt[1])
+
+    def acc_add_block(self, b):
+        e, T = self.p.emit, self.vT[0]
+        for d in range(4):
+            tt = T.sub(8 + 2 * (d % 2), 2)
+            e("v_accvgpr_read_b32", tt[0], self.acc[b][2 * d])
+            e("v_accvgpr_read_b32", tt[1], self.acc[b][2 * d + 1])
+            e("v_add_f64", tt, tt, T.sub(2 * d, 2))
+            e("v_accvgpr_write_b32", self.acc[b][2 * d], tt[0])
+            e("v_accvgpr_write_b32", self.acc[b][2 * d + 1], tt[1])
+
     # ------------------------------------------------------------------ epilogue
     def c_addr_setup(self):
         """vC[n] = byte offset in C of D[q][r16] of block column n: row m0 + wm0 + q (+ 4 per accumulator element, + 16 per
@@ -434,6 +482,9 @@ class Gen64(Gen):
         skip = p.label("nobeta")
         e("s_cmp_eq_u32", self.s_b0, 0)
         e("s_cbranch_scc1", skip)
+        if c.persistent:       # (a head run's slice sums go to the workspace raw)
+            e("s_cmp_eq_u32", self.s_mode, MODE_HEAD)
+            e("s_cbranch_scc1", skip)
         self.c_addr_setup()
         pool = [r.sub(2 * h, 2) for slot in range(2) for r in (self.fa[slot] + self.fb[slot]) for h in range(2)]
         assert len(pool) >= c.TN
@@ -461,6 +512,7 @@ class Gen64(Gen):
         if c.debug:
             for k_ in range(4):
                 self.dump(f"acc[0][{k_}]", self.acc[0][k_])
+        self.mode_dispatch()
         self.c_addr_setup()
         T = self.vT[0]
 
@@ -507,7 +559,7 @@ class Gen64(Gen):
                     e("buffer_store_dwordx2", tt, self.vC[n], self.srdC, 0, offen=True)
             self.c_walk(row1)
             p.place(done)
-        e("s_endpgm")
+        self.end_run()
 
 
 def make(name, **over):

@@ -18,7 +18,7 @@ int64 (`make("i64_64x64x32")`): eight planes, 36 products, eight accumulator gro
 block and the workgroup tile is 64x64 (blocks of [8 planes][2 halves][64 rows][16 bytes] = the same 16 KiB); the epilogue sums
 sext(G_s) << 8s in 64-bit (add-with-carry for s <= 3, shifted adds into the high word above), then alpha * (...) + beta * C0 wrapping."""
 from .core import v, a, s, VCC
-from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG  # noqa: F401
+from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_SCHED, KA_SCHED2  # noqa: F401
 
 KA_ALPHA64 = 72   # int64 alpha, beta (16 bytes): the slot of the f64 kernels' doubles
 
@@ -51,6 +51,7 @@ class GenI8(Gen):
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
+        self.s_sc = S(8, align=4)                                # tile map constants (f32_kernel.py KA_SCHED)
         self.s_ab64 = S(4, align=4) if c.NP == 8 else None      # int64 alpha (lo, hi), beta (lo, hi): loaded by the epilogue
         self.acc = [[p.aalloc(16) for _ in range(c.WB * c.WB)] for _ in range(c.NP)]        # [power of 256][block = WB * i + n]
         self.fa = [[[V(4) for _ in range(c.NP)] for _ in range(c.WB)] for _ in range(2)]   # [set][i][plane]
@@ -78,9 +79,8 @@ class GenI8(Gen):
         p.note("int32 GEMM via int8 limb planes: 128x128 tile, 4 waves of 64x64, 40 MFMAs (10 limb products x 4 blocks) per 32-k tile")
         e("s_load_dwordx8", self.ka0, s(0, 2), KA_A)
         e("s_load_dwordx8", self.ka1, s(0, 2), KA_LDA)
-        e("s_lshl_b32", st[0], s(2), 2)
-        e("s_waitcnt", lgkmcnt=0)
-        e("s_load_dword", st[1], self.ka0.sub(6, 2), st[0], comment="tile table: pid_m | pid_n << 16")
+        e("s_load_dwordx8", self.s_sc, s(0, 2), KA_SCHED)
+        e("s_load_dword", st[5], s(0, 2), KA_SCHED2)
         if c.debug:
             e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
             e("s_waitcnt", lgkmcnt=0)
@@ -118,8 +118,8 @@ class GenI8(Gen):
             e("v_add_u32", self.vV[i], 4096 * i, t[5])
         # ---- tile coordinates, descriptors ----
         e("s_waitcnt", lgkmcnt=0)
-        e("s_and_b32", st[0], st[1], 0xffff)
-        e("s_lshr_b32", st[1], st[1], 16)
+        self.xcd_remap(st[4], s(2), self.s_sc[7], st[5], st[0])
+        self.tile_coords(st[4], self.s_sc, st[0], st[1], (st[2], st[3], st[5]))
         e("s_mul_i32", self.s_m0, st[0], c.BM)
         e("s_mul_i32", self.s_n0, st[1], c.BN)
         A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
@@ -406,7 +406,7 @@ def make(name="i32_128x128x32", **over):
     i64 = name.startswith("i64")
     kw = dict(BM=64 if i64 else 128, BN=64 if i64 else 128, BK=32, exact=False, bar_gap=18 if i64 else 20)   # (scripts/i8_probe.py: barrier 9 / 12 / 16 / 20 -> 275 / 279 / 283 / 286 Tint-op/s, int32)
     kw.update(over)
-    c = Cfg(name, **kw)
+    c = Cfg(name, persistent=False, **kw)       # one tile per workgroup (the limb kernels are never cut along K)
     c.dtype = "i8"
     c.NP = 8 if i64 else 4                     # digit planes = bytes of the element
     c.WB = 1 if i64 else 2                     # 32x32 blocks per wave in each direction

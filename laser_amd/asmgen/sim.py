@@ -369,6 +369,14 @@ class Workgroup:
             return "end"
         elif op == "s_nop":
             cost = int(A[0]) + 1
+        elif op == "s_sleep":
+            # only ever executed inside a spin on a flag another workgroup sets: the interpreter runs workgroups one after the
+            # other (producers first), so a flag that is not set yet never will be
+            raise SimError(f"wave {w.wid} pc {w.pc}: spinning on a flag that no earlier workgroup has set (wrong run order, or a lost release)")
+        elif op == "buffer_wbl2":
+            w.vm.append([])
+        elif op == "buffer_inv":
+            pass
         elif op == "s_barrier":
             if self.check and any(kind == "ldsw" for kind, _ in w.lgkm):
                 raise SimError(f"wave {w.wid} pc {w.pc}: s_barrier crossed with LDS writes not waited for")
@@ -692,8 +700,12 @@ class Workgroup:
                     raise SimError(f"wave {w.wid} pc {w.pc}: VMEM reads s{r_[1]} {w.state - w.valu_sgpr_wr[r_[1]]} states after a VALU wrote it")
             base, nrec = self._srd(w, srd)
             so = rs(w, soff)
-            assert M.get("offen"), "offen addressing only"
-            vo = rv(w, voff).astype(np.int64) + int(M.get("offset", 0))
+            if isinstance(voff, Sym):
+                assert voff.name == "off" and not M.get("offen"), "off: no per-lane offset"
+                vo = np.zeros(LANES, dtype=np.int64) + int(M.get("offset", 0))
+            else:
+                assert M.get("offen"), "offen addressing only"
+                vo = rv(w, voff).astype(np.int64) + int(M.get("offset", 0))
             act = w.execmask()
             assert data.n == ndw
             if op.startswith("buffer_load"):
