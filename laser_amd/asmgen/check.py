@@ -40,7 +40,7 @@ def plan_units(tiles, Kd, G, exact, kc, BK, split=True):
     U = tiles * P
     assert 1 <= G <= U
     q, r = U // G, U % G
-    hmax = max(1, min(P - 1, q + 1)) if exact else 1
+    hmax = max(1, min(P - 1, q + (1 if r else 0))) if exact else 1
     return P, slen, q, r, hmax
 
 
@@ -51,7 +51,7 @@ def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, hmax=1, ws=0, flags=0
     if q is None:
         q, r = tm * tn * P // G, tm * tn * P % G
     return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), (G // 8) if xcd else 0,
-                       (G % 8) if xcd else 0, P, K.magic_u32(P), q, r, slen, hmax, G, ws, flags)
+                       (G % 8) if xcd else 0, P, K.magic_u32(P), q, r, slen, hmax, K.magic_u32(G), ws, flags)
 
 
 def virtual_id(g, G, xcd):

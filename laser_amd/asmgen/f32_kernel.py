@@ -112,8 +112,9 @@ KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's s
 # a divisor d travels as magic(d) = floor(2^32 / d) + 1 (0 for d == 1): x / d = mulhi(x, magic) while x * d < 2^32 (launcher)
 #   +0 tiles_m  +4 tiles_n  +8 group_m  +12 rows of the last group  +16 magic(group_m * tiles_n)  +20 magic(group_m)
 #   +24 magic(rows of the last group)  +28 xcd_q (workgroups / 8; 0 = no XCD remap)
-#   +32 xcd_r (workgroups % 8)  +36 P (K slices per tile)  +40 magic(P)  +44 units_q  +48 units_r (units = workgroups * q + r)
-#   +52 slice length (elements of K)  +56 workspace slots per workgroup  +60 workgroups
+#   +32 xcd_r (workgroups % 8)  +36 P (K slices per tile)  +40 magic(P)  +44 units_q  +48 units_r (units = workgroups * q + r:
+#       workgroup v starts at unit v * q + floor(v * r / workgroups) -- the r longer ranges are spread evenly over the ids)
+#   +52 slice length (elements of K)  +56 workspace slots per workgroup  +60 magic(workgroups)
 #   +64 workspace (u64)  +72 flags (u64)
 KA_SCHED = 152
 KA_SCHED2 = KA_SCHED + 32
@@ -348,22 +349,25 @@ class Gen:
         e("s_add_u32", pm, tmp[1], tmp[0])                    # pid_m
 
     # ------------------------------------------------------------------ scheduler of the persistent kernels
+    def unit_start(self, dst, vid, tmp):
+        """first unit of workgroup `vid`: vid * units_q + floor(vid * units_r / workgroups) (s_sc holds the KA_SCHED2 block)"""
+        e, sc = self.p.emit, self.s_sc
+        e("s_mul_i32", tmp, vid, sc[4])
+        self.udiv(dst, tmp, sc[7])
+        e("s_mul_i32", tmp, vid, sc[3])
+        e("s_add_u32", dst, dst, tmp)
+
     def sched_init(self):
-        """units [s_u, s_uend) of this workgroup: virtual id v (XCD remap) -> v * units_q + min(v, units_r), one more unit for v < units_r"""
+        """units [s_u, s_uend) of this workgroup, by its virtual id (XCD remap)"""
         e, st, sc = self.p.emit, self.s_t, self.s_sc
         e("s_load_dword", st[5], s(0, 2), KA_SCHED + 28)
         e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
         e("s_load_dwordx4", self.s_wsf, s(0, 2), KA_WS)
         e("s_waitcnt", lgkmcnt=0)
-        xr, units_q, units_r = sc[0], sc[3], sc[4]
-        self.xcd_remap(self.s_vid, s(2), st[5], xr, st[0])
-        e("s_mul_i32", self.s_u, self.s_vid, units_q)
-        e("s_min_u32", st[0], self.s_vid, units_r)
-        e("s_add_u32", self.s_u, self.s_u, st[0])
-        e("s_cmp_lt_u32", self.s_vid, units_r)
-        e("s_cselect_b32", st[0], 1, 0)
-        e("s_add_u32", self.s_uend, self.s_u, units_q)
-        e("s_add_u32", self.s_uend, self.s_uend, st[0])
+        self.xcd_remap(self.s_vid, s(2), st[5], sc[0], st[0])
+        self.unit_start(self.s_u, self.s_vid, st[0])
+        e("s_add_u32", st[1], self.s_vid, 1)
+        self.unit_start(self.s_uend, st[1], st[0])
 
     def sched_next(self, L_exit):
         """the next run: consecutive units of one tile.  Unit u = tile * P + p.  p == 0: slices [0, n), n = min(P, units left): the
@@ -400,9 +404,7 @@ class Gen:
         # workspace slot: vid * hmax + (index of this head run in the workgroup: laser-order u - first unit, one chain 0)
         e("s_mul_i32", self.s_slot, self.s_vid, hmax)
         if c.exact:
-            e("s_mul_i32", st[2], self.s_vid, units_q)
-            e("s_min_u32", st[3], self.s_vid, units_r)
-            e("s_add_u32", st[2], st[2], st[3])
+            self.unit_start(st[2], self.s_vid, st[3])
             e("s_sub_u32", st[2], self.s_u, st[2])
             e("s_add_u32", self.s_slot, self.s_slot, st[2])
         self.p.place(join)
@@ -1736,13 +1738,14 @@ class Gen:
         e, t, st, sc = p.emit, self.vt, self.s_t, self.s_sc
         e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
         e("s_waitcnt", lgkmcnt=0)
-        P, units_q, units_r, hmax = sc[1], sc[3], sc[4], sc[6]
+        P, hmax = sc[1], sc[6]
         w, j, remw, slot, fv = st[0], st[1], st[2], st[3], st[4]
 
-        def len_w():
-            e("s_cmp_lt_u32", w, units_r)
-            e("s_cselect_b32", remw, 1, 0)
-            e("s_add_u32", remw, remw, units_q)
+        def len_w():      # units of workgroup w
+            self.unit_start(st[3], w, st[5])
+            e("s_add_u32", st[4], w, 1)
+            self.unit_start(remw, st[4], st[5])
+            e("s_sub_u32", remw, remw, st[3])
         e("s_add_u32", w, self.s_vid, 1)
         e("s_mov_b32", j, 0)
         len_w()
@@ -1754,12 +1757,20 @@ class Gen:
         e("s_mul_i32", slot, w, hmax)
         e("s_add_u32", slot, slot, j)
         self.ws_descriptors(slot)
+        lost, cleared = p.label("lost"), p.label("cleared")
+        e("s_mov_b32", st[5], 0)
         p.place(spin)
         e("buffer_load_dword", t[9], OFF, self.srdA, 0, sc1=True)
         e("s_waitcnt", vmcnt=0)
         e("v_readfirstlane_b32", fv, t[9])
         e("s_cmp_lg_u32", fv, 0)
         e("s_cbranch_scc1", got)
+        # a legitimate wait is shorter than the launch (the partial is the first thing its producer computes); after ~2 s of polling
+        # the workgroup reports to the error word in front of the flags (launcher: option "asm_fixup_timeouts") and goes on -- a wrong
+        # result that is flagged, not a hung GPU
+        e("s_add_u32", st[5], st[5], 1)
+        e("s_cmp_lt_u32", st[5], 1 << 21)
+        e("s_cbranch_scc0", lost)
         e("s_sleep", 8)
         e("s_branch", spin)
         p.place(got)
@@ -1780,6 +1791,14 @@ class Gen:
         p.place(same)
         e("s_cmp_lt_u32", self.s_pe, P)
         e("s_cbranch_scc1", loop)
+        e("s_branch", L_back)
+        p.place(lost)
+        e("s_sub_u32", self.srdA[0], self.s_wsf[2], 4)
+        e("s_subb_u32", self.srdA[1], self.s_wsf[3], 0)
+        e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
+        e("v_mov_b32", t[9], 1)
+        e("buffer_store_dword", t[9], t[8], self.srdA, 0, offen=True, sc1=True)
+        e("s_waitcnt", vmcnt=0)
         e("s_branch", L_back)
 
     def mode_dispatch(self):

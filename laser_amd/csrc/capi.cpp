@@ -241,7 +241,7 @@ hipError_t launch_tiled(const GemmArgs<double> &a, hipStream_t s) {
 // alpha / beta arithmetic => bit-identical to the sequential kernel, with ceil(K / kc) times the workgroups.
 // Returns hipErrorNotSupported when the shape does not call for it.
 template <typename T>
-hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s, bool force = false) {
+hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s) {
   if (!g_ctx.slice_parallel || a.batch != 1 || a.bias != nullptr || a.act != 0) return hipErrorNotSupported;
   if (a.M <= 0 || a.N <= 0 || a.K <= kc) return hipErrorNotSupported;
   const int64_t tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
@@ -254,7 +254,6 @@ hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s, bool
   int64_t need = tiles64 <= 150 ? 2 : tiles64 <= 400 ? 5 : tiles64 <= 600 ? 6 : (int64_t)1 << 40;
   if (a.K % kc != 0 && need < 3) need = 3;  // a ragged last slice is a launch of its own: 768^3 (512 + 256) loses
   if (g_ctx.slice_parallel_tiles > 0) need = tiles64 <= g_ctx.slice_parallel_tiles.load() ? (int64_t)g_ctx.slice_parallel_min.load() : (int64_t)1 << 40;  // tuning override
-  if (force) need = 2;  // the caller has priced it (run_gemm_round_split: the badly filled last round of a larger problem)
   if (nsl < need || nsl > 65535 || ws_bytes > 1.5e9) return hipErrorNotSupported;
   T *W = nullptr;
   hipError_t e = hipMallocAsync((void **)&W, (size_t)ws_bytes, s);
@@ -290,52 +289,6 @@ template <>
 hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s);
 template <>
 hipError_t run_gemm_core<double>(const GemmArgs<double> &a, hipStream_t s);
-
-// Tile quantisation on 1..8-round problems (1536^3 = 576 tiles of 64x64 = 2.25 rounds of 256 CUs: the third round runs 64
-// tiles on a quarter of the chip for a whole tile time).  Rows of C are independent, and Laser's kc slices are independent
-// chains whose sums are added in order (gemm.nim:150-158), so the problem is cut along M: the top part -- whole rounds of
-// tiles -- is one ordinary launch, the bottom part -- the tiles of the badly filled last round -- goes through the
-// slice-parallel form (ceil(K / kc) times the workgroups, each 1 / ceil(K / kc) as long, then the ordered combine).  Same
-// chains, same order of the slice sums: bit-identical to the single launch in laser-order mode (one-chain mode: the bottom
-// rows get the kc-sliced order, as every slice-parallel launch does).  Plain (unfused, unbatched, not pre-packed) problems.
-template <typename T>
-hipError_t run_gemm_round_split(const GemmArgs<T> &a, int kc, bool *taken, hipStream_t s) {
-  *taken = false;
-  if (!g_split_tail || !g_ctx.slice_parallel || a.batch != 1 || a.bias != nullptr || a.act != 0 || a.col0 != 0) return hipSuccess;
-  if (a.Mext != a.M || a.Next != a.N || a.Kext != a.K || a.K < 2 * (int64_t)kc) return hipSuccess;
-  const int64_t tm = (a.M + 63) / 64, tn = (a.N + 63) / 64, t64 = tm * tn;
-  if (t64 <= 256 || tn >= 256) return hipSuccess;   // one round: the few-tile rules; a tile row as long as a round: no cut along M helps
-  const auto rounds = [](int64_t t) { return (double)((t + 255) / 256); };
-  // the single launch, in units of one 64x64 tile's matrix time (the assembly launchers' candidates and efficiencies)
-  constexpr double e64 = 0.88, e128 = 0.93, e256 = 0.96;
-  const int64_t t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128), t256 = ((a.M + 255) / 256) * ((a.N + 127) / 128);
-  double single = rounds(t64) / e64;
-  if (t128 >= 160) single = std::min(single, 4.0 * rounds(t128) / e128);
-  if (t256 >= 160 && sizeof(T) == 4) single = std::min(single, 8.0 * rounds(t256) / e256);
-  const int64_t top_rows = (t64 / 256) * 256 / tn;   // tile rows of the whole rounds
-  if (top_rows <= 0 || top_rows >= tm) return hipSuccess;
-  const int64_t nsl = (a.K + kc - 1) / kc, bot_tiles = (tm - top_rows) * tn;
-  const double tile_us = 2.0 * 64 * 64 * (double)a.K / ((sizeof(T) == 4 ? 157.3e6 : 78.6e6) / 256.0);
-  // bottom: rounds of slice-sized tiles + 10 % (a ragged last slice); fixed: three more kernel boundaries and the combine
-  // pass, 15 us measured (profiles/r03/round_split_v1.jsonl: 1536^3 f32 gains nothing, 1536^2 x 4096 12 %, f64 9-13 %).
-  // (The two parts side by side on two streams, forked and joined by events, lost 15-20 %: round_split_v2.jsonl.)
-  const double split = rounds(top_rows * tn) / e64 + 1.1 * rounds(bot_tiles * nsl) / (double)nsl / e64 + 15.0 / tile_us;
-  if (split >= 0.95 * single) return hipSuccess;
-  const int64_t M1 = top_rows * 64;
-  GemmArgs<T> b = a;   // rows [M1, M): before the top part, so that a refusal leaves nothing half done
-  b.M = a.M - M1; b.Mext = b.M;
-  b.A = a.A + M1 * a.rsA;
-  b.C = a.C + M1 * a.rsC;
-  hipError_t e = gemm_slice_parallel<T>(b, kc, s, true);
-  if (e == hipErrorNotSupported) return hipSuccess;
-  *taken = true;
-  if (e != hipSuccess) return e;
-  GemmArgs<T> m = a;
-  m.M = M1; m.Mext = M1;
-  e = launch_tiled(m, s);
-  g_last_split = -M1;
-  return e;
-}
 
 // Ragged-by-a-few problems (4100^3, 4095 x 4097 x 4099): 1..8 rows / columns past a multiple of 64 cost a whole extra row /
 // column of tiles (4100 = 16 x 256 + 4: 17 tile rows for 16.02 tile rows of work).  Elements of C are independent and the
@@ -411,11 +364,8 @@ hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s) {
     const hipError_t e = gemm_slice_parallel<float>(a, 512, s);
     if (e != hipErrorNotSupported) return e;
   }
-  if (f32_cfg_now() < 0 && !few_tiles) {   // a badly filled last round: whole rounds on top + the K-sliced rest
-    bool taken;
-    const hipError_t e = run_gemm_round_split<float>(a, 512, &taken, s);
-    if (taken) return e;
-  }
+  // (a badly filled last round of tiles is the assembly launcher's business: its persistent plan hands the chip's workgroup slots
+  // equal numbers of kc slices and finishes a cut tile with an in-kernel ordered fix-up -- gemm_f32_asm.cpp plan_launch)
   if (f32_cfg_now() < 0) {
     const hipError_t e = launch_gemm_f32_asm(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
     if (e != hipErrorNotSupported) return e;
@@ -442,11 +392,6 @@ hipError_t run_gemm_core<double>(const GemmArgs<double> &a, hipStream_t s) {
     if (few_tiles) {
       const hipError_t e = gemm_slice_parallel<double>(a, 256, s);
       if (e != hipErrorNotSupported) return e;
-    }
-    if (!few_tiles) {
-      bool taken;
-      const hipError_t e = run_gemm_round_split<double>(a, 256, &taken, s);
-      if (taken) return e;
     }
     const hipError_t ea = launch_gemm_f64_asm(a, laser, s);   // the hand-scheduled assembly kernels (laser_amd/asmgen/f64_kernel.py)
     if (ea != hipErrorNotSupported) return ea;
@@ -1375,6 +1320,10 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "skinny") g_ctx.skinny = on;
   else if (n == "small_path") g_small_path = on;
   else if (n == "split_tail") g_split_tail = on;
+  else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (n == "asm_kernel") g_asm_kernel = value < 0 ? -1 : value;
+  else if (n == "asm_wgs") g_asm_wgs = value < 0 ? 0 : value;
+  else if (n == "asm_slice") g_asm_slice = value < 0 ? 0 : value;
   else if (n == "slice_parallel") g_ctx.slice_parallel = on;
   else if (n == "slice_parallel_min") g_ctx.slice_parallel_min = value < 2 ? 2 : value;
   else if (n == "slice_parallel_tiles") g_ctx.slice_parallel_tiles = value < 0 ? 0 : value;
@@ -1401,6 +1350,13 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "skinny") *value = g_ctx.skinny;
   else if (n == "small_path") *value = g_small_path;
   else if (n == "split_tail") *value = g_split_tail;
+  else if (n == "asm_plan") *value = g_asm_plan;
+  else if (n == "asm_kernel") *value = g_asm_kernel;
+  else if (n == "asm_wgs") *value = g_asm_wgs;
+  else if (n == "asm_slice") *value = g_asm_slice;
+  else if (n == "last_asm_wgs") *value = g_last_asm_wgs;
+  else if (n == "last_asm_slices") *value = g_last_asm_slices;
+  else if (n == "asm_fixup_timeouts") *value = asm_fixup_timeouts();
   else if (n == "slice_parallel") *value = g_ctx.slice_parallel;
   else if (n == "slice_parallel_min") *value = g_ctx.slice_parallel_min;
   else if (n == "slice_parallel_tiles") *value = g_ctx.slice_parallel_tiles;

@@ -118,17 +118,20 @@ inline bool conv_patch_geom(int BK, int BN, int W, int oW, int kH, int kW, int s
 
 hipError_t launch_gemm_f32(const GemmArgs<float> &args, int cfg, bool laser_order, hipStream_t s);
 hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
-// float32, unit column strides, alpha == 1, beta == 0, K a multiple of the K-tile, enough tiles to fill the chip: the
-// hand-scheduled assembly kernels (gemm_f32_asm.cpp, laser_amd/asmgen/); hipErrorNotSupported = not that class, use launch_gemm_f32
+// float32, unit column strides on A and C, B row-major-like or passed transposed, any alpha / beta / K, enough tiles to fill the
+// chip: the hand-scheduled assembly kernels (gemm_f32_asm.cpp, laser_amd/asmgen/); hipErrorNotSupported = not that class, use launch_gemm_f32
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &args, bool laser_order, hipStream_t s);
 // implicit-GEMM convolution on the same framework (3x3 kernel, stride 1, padding 0 or 1): output pixels [0, args.N) of every image
 hipError_t launch_conv_f32_asm(const GemmArgs<float> &args, bool laser_order, hipStream_t s);
+int64_t asm_fixup_timeouts();  // diagnostics: fix-ups of cut launches that gave up waiting (0 in a correct run; synchronises the device)
 void asm_kernels_release();   // unload the assembly kernels' code objects (laser_hip_finalize)
 hipError_t launch_gemm_f64_asm(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
 extern std::atomic<int> g_f64_asm, g_last_f64_asm;
 hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
 hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 extern std::atomic<int> g_i32_asm, g_last_i32_asm;
+extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
+extern std::atomic<int> g_last_asm_wgs, g_last_asm_slices;                  // diagnostics: workgroups / K slices per tile of the last assembly launch
 extern std::atomic<int> g_f32_asm;       // 1 default; 0 = never; 2 = whenever the kernel can (no tile-count rule: tests)
 extern std::atomic<int> g_last_f32_asm;  // 0 = the last f32 GEMM launch was a compiler-scheduled kernel, 1 / 2 = laser-order / fast assembly kernel
 // args.B = NCHW input, args.bsB = C*H*W, args.c* = geometry, N = oH*oW, K = C*kH*kW; A = filter

@@ -2,8 +2,9 @@
 // laser_amd/asmgen/f32_kernel.py, assembled at build time, carried in this library as a code object and loaded with
 // hipModuleLoadData).  One workgroup = one tile of C, 4 waves = one wave per SIMD with the accumulators in AGPRs -- the
 // register-level design of the reference's generated micro-kernels (gemm_ukernel_generator.nim:140-250) with the loop
-// nest of gemm.nim:109-176 around it.  The workgroup -> tile map (the ic / jr partition of gemm.nim:160-176) is a
-// table made here: XCD-aware, grouped raster, so neighbouring workgroups of an XCD share operand panels in its L2.
+// nest of gemm.nim:109-176 around it.  The workgroup -> tile map (the ic / jr partition of gemm.nim:160-176) is arithmetic in the
+// kernel on a few numbers made here (XCD-aware chunking of the workgroup ids, grouped raster: neighbouring workgroups of an XCD
+// share operand panels in its L2), and a launch may be persistent: fewer workgroups than tiles, tiles cut at K-slice boundaries.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -27,6 +28,12 @@ std::atomic<int> g_last_f64_asm{0};  // diagnostics: 0 = compiler-scheduled kern
 std::atomic<int> g_f32_asm{1};       // 1 (default): eligible problems run on the hand-scheduled kernels
 std::atomic<int> g_last_f32_asm{0};  // diagnostics: 0 = compiler-scheduled kernel; 1 + index into kKernels otherwise
 
+std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model decides; 1 = one tile per workgroup only; 2 = the persistent plan whenever legal
+std::atomic<int> g_asm_kernel{-1};    // option "asm_kernel": force an index of kKernels (tuning sweeps); -1 = the model decides
+std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persistent launch (0 = every slot of the chip)
+std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
+std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
+
 namespace {
 
 struct KernelInfo {
@@ -36,6 +43,7 @@ struct KernelInfo {
   // its workgroup slots are full / when one workgroup has the CU to itself, and the launch's fixed cost (prologue, first
   // loads, epilogue of the last round) in microseconds
   double eff, eff_alone, fixed_us;
+  int occ;   // workgroups of this kernel a CU holds (registers / LDS)
 };
 // [0] laser-order, large tile  [1] one chain, large tile  [2] laser-order, 128x128  [3] one chain, 128x128;
 // [4..7] the same with B passed transposed (unit ROW stride: k-contiguous like A, BASELINE configs[2])
@@ -50,37 +58,56 @@ struct KernelInfo {
 // [29]: int64 via eight int8 limb planes (i8_kernel.py "i64_64x64x32")
 constexpr int kNumKernels = 30;
 const KernelInfo kKernels[kNumKernels] = {
-    {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0},
-    {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0},
-    {"lh_f32_exact_256x128x32_nt", 256, 128, 32, 0.965, 0.965, 10.0}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16, 0.98, 0.98, 12.0},
-    {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.91, 6.0},    {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.92, 6.0},
-    {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0},
-    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0},
-    {"lh_f32_exact_64x64x32", 64, 64, 32, 0.88, 0.78, 3.0},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.895, 0.80, 3.0},
-    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0},
-    {"lh_f64_exact_128x128x16", 128, 128, 16, 0.92, 0.92, 8.0},       {"lh_f64_fast_128x128x16", 128, 128, 16, 0.93, 0.93, 8.0},
-    {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0},
-    {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0},
-    {"lh_f32_conv3x3_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0}, {"lh_f32_conv3x3_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0},
-    {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0},
-    {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.92, 0.92, 8.0},     {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.93, 0.93, 8.0},
-    {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0},
-    {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0}};
+    {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0, 1},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0, 1},
+    {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0, 2},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0, 2},
+    {"lh_f32_exact_256x128x32_nt", 256, 128, 32, 0.965, 0.965, 10.0, 1}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16, 0.98, 0.98, 12.0, 1},
+    {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.91, 6.0, 2},    {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.92, 6.0, 2},
+    {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0, 1},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0, 1},
+    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1},
+    {"lh_f32_exact_64x64x32", 64, 64, 32, 0.88, 0.78, 3.0, 3},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.895, 0.80, 3.0, 3},
+    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0, 3},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0, 3},
+    {"lh_f64_exact_128x128x16", 128, 128, 16, 0.92, 0.92, 8.0, 1},       {"lh_f64_fast_128x128x16", 128, 128, 16, 0.93, 0.93, 8.0, 1},
+    {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0, 2},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0, 2},
+    {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0, 1},
+    {"lh_f32_conv3x3_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1}, {"lh_f32_conv3x3_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1},
+    {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},
+    {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.92, 0.92, 8.0, 1},     {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.93, 0.93, 8.0, 1},
+    {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0, 2},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0, 2},
+    {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0, 1}};
+constexpr int kCUs = 256;
 
+// Workspace of the cut launches of ONE stream on one device: partial tiles + their flags (all flags are zero between launches: the
+// workgroup that consumes a partial clears its flag).  Launches on a stream run in order, so they can share it.
+struct StreamWs {
+  void *ws = nullptr;
+  size_t ws_bytes = 0;
+  uint32_t *flags = nullptr;
+  size_t nflags = 0;
+};
 struct DeviceModule {
+  std::mutex mu;     // module load + this device's workspace map; never held across a launch
   hipModule_t mod = nullptr;
   hipFunction_t fn[kNumKernels] = {};
-  // tile tables by (tiles_m, tiles_n, group_m); entries live until the process ends
-  std::map<std::tuple<int, int, int>, std::pair<uint32_t *, std::vector<uint32_t> *>> tables;
+  std::map<hipStream_t, StreamWs> ws;
 };
 constexpr int kMaxDev = 16;
 DeviceModule g_mods[kMaxDev];
-std::mutex g_mods_mu;
+constexpr size_t kWsMaxBytes = (size_t)512 << 20;
+constexpr size_t kWsMaxStreams = 64;
+
+// the scheduler block of the kernel arguments (f32_kernel.py KA_SCHED): the workgroup -> tile map is arithmetic in the kernel
+// (XCD-aware chunking of the workgroup ids + grouped raster: the ic / jr partition of gemm.nim:160-176), no table
+struct SchedArgs {
+  uint32_t tiles_m, tiles_n, group_m, gsz_last, mg_width, mg_gm, mg_last, xcd_q;
+  uint32_t xcd_r, P, mg_P, units_q, units_r, slice_len, hmax, mg_G;
+  uint64_t ws, flags;
+};
+static_assert(sizeof(SchedArgs) == 80, "f32_kernel.py KA_SCHED");
 
 struct KernArgs {
   const void *A, *B;   // float or double
   void *C;
-  const uint32_t *table;
+  const uint32_t *unused_;
   uint32_t lda, ldb, ldc, M, N, K;
   float alpha, beta;   // C = beta * C + alpha * A B (beta == 0: C is never read)
   void *dbg;
@@ -91,30 +118,36 @@ struct KernArgs {
   // fused epilogue of the f32 kernels (f32_kernel.py KA_BIAS / KA_EPI): bias view + activation; zero = plain epilogue
   const void *bias = nullptr;
   uint32_t rsBias = 0, csBias = 0, act = 0, pad2_ = 0;
+  SchedArgs sch;
 };
-static_assert(sizeof(KernArgs) == 152, "kernel argument block layout (f32_kernel.py KA_*)");
+static_assert(sizeof(KernArgs) == 232 && offsetof(KernArgs, sch) == 152, "kernel argument block layout (f32_kernel.py KA_*)");
 
-// blockIdx -> tile: block b runs on XCD b % 8; give every XCD a contiguous chunk of tile ids (bijective for any grid),
-// then walk the tiles in groups of group_m tile rows so the ~32 workgroups resident on an XCD form a compact patch.
-void make_table(int tiles_m, int tiles_n, int group_m, std::vector<uint32_t> &out) {
-  const int nwg = tiles_m * tiles_n;
-  out.resize((size_t)nwg);
-  for (int bid = 0; bid < nwg; bid++) {
-    const int xcd = bid % 8, loc = bid / 8, q = nwg / 8, r = nwg % 8;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int width = group_m * tiles_n;
-    const int group = wgid / width;
-    const int first_m = group * group_m;
-    const int gsz = std::min(tiles_m - first_m, group_m);
-    const int pid_m = first_m + (wgid % width) % gsz;
-    const int pid_n = (wgid % width) / gsz;
-    out[(size_t)bid] = (uint32_t)pid_m | ((uint32_t)pid_n << 16);
-  }
+// x / d in the kernels = mulhi(x, magic(d)) with magic(d) = floor(2^32 / d) + 1 (0 for d == 1): exact while x * d < 2^32
+inline uint32_t magic_u32(uint64_t d) { return d <= 1 ? 0u : (uint32_t)(((uint64_t)1 << 32) / d + 1); }
+
+// Tile map + unit arithmetic of a launch of G workgroups over tiles_m x tiles_n tiles, each cut into P slices of slice_len
+// elements of K (P == 1: no cut).  false: a quotient of the in-kernel arithmetic would leave the range of its magic number.
+bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, int64_t G, int64_t P, int64_t slice_len, int64_t hmax,
+                const StreamWs *w, bool xcd) {
+  const int64_t T = tiles_m * tiles_n, U = T * P;
+  if (group_m <= 0 || group_m > tiles_m) group_m = (int)tiles_m;   // one group: tile rows fastest (the convolution's order)
+  const int64_t width = (int64_t)group_m * tiles_n, gsz_last = tiles_m % group_m ? tiles_m % group_m : group_m;
+  if ((double)T * (double)width >= 4.0e9 || (double)U * (double)P >= 4.0e9 || G < 1 || G > U) return false;
+  const int64_t q = U / G, r = U % G;
+  if ((double)G * (double)r * (double)G >= 4.0e9 || tiles_m > 0x7fffffff || tiles_n > 0x7fffffff || U > 0x7fffffff) return false;
+  sc.tiles_m = (uint32_t)tiles_m; sc.tiles_n = (uint32_t)tiles_n; sc.group_m = (uint32_t)group_m; sc.gsz_last = (uint32_t)gsz_last;
+  sc.mg_width = magic_u32((uint64_t)width); sc.mg_gm = magic_u32((uint64_t)group_m); sc.mg_last = magic_u32((uint64_t)gsz_last);
+  sc.xcd_q = xcd && G >= 8 ? (uint32_t)(G / 8) : 0; sc.xcd_r = xcd && G >= 8 ? (uint32_t)(G % 8) : 0;
+  sc.P = (uint32_t)P; sc.mg_P = magic_u32((uint64_t)P); sc.units_q = (uint32_t)q; sc.units_r = (uint32_t)r;
+  sc.slice_len = (uint32_t)slice_len; sc.hmax = (uint32_t)hmax; sc.mg_G = magic_u32((uint64_t)G);
+  sc.ws = w ? (uint64_t)(uintptr_t)w->ws : 0; sc.flags = w ? (uint64_t)(uintptr_t)(w->flags + 1) : 0;   // (flags[0] = the error word)
+  return true;
 }
 
 hipError_t get_module(int dev, DeviceModule **out) {
   if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
   DeviceModule &m = g_mods[dev];
+  std::lock_guard<std::mutex> lk(m.mu);
   if (!m.mod) {
     hipError_t e = hipModuleLoadData(&m.mod, lh_f32_asm_hsaco);
     if (e != hipSuccess) return e;
@@ -129,55 +162,169 @@ hipError_t get_module(int dev, DeviceModule **out) {
   return hipSuccess;
 }
 
-// Device copy of the tile table for a (tiles_m x tiles_n) grid, cached per device until laser_hip_finalize: group_m > 0 = the
-// XCD-aware grouped raster of make_table, group_m == 0 = plain order (pid_n-major; the convolution's few tiles per image).
-// The upload is stream-ordered ahead of the launch; the host copy stays alive with the cache entry.
-hipError_t tile_table(DeviceModule *m, int tiles_m, int tiles_n, int group_m, hipStream_t s, const uint32_t **out) {
-  const auto key = std::make_tuple(tiles_m, tiles_n, group_m);
-  auto it = m->tables.find(key);
-  if (it == m->tables.end()) {
-    auto *host = new std::vector<uint32_t>();
-    if (group_m > 0) {
-      make_table(tiles_m, tiles_n, group_m, *host);
-    } else {
-      host->reserve((size_t)tiles_m * tiles_n);
-      for (int pn = 0; pn < tiles_n; pn++)
-        for (int pm = 0; pm < tiles_m; pm++) host->push_back((uint32_t)pm | ((uint32_t)pn << 16));
-    }
-    uint32_t *devp = nullptr;
-    hipError_t e = hipMalloc((void **)&devp, host->size() * sizeof(uint32_t));
-    // blocking, once per tile grid: the table is cached for every later call, which may run on ANOTHER stream -- an upload
-    // ordered only on this call's stream could still be in flight when that stream launches against it
-    (void)s;
-    if (e == hipSuccess) e = hipMemcpy(devp, host->data(), host->size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-      if (devp) (void)hipFree(devp);
-      delete host;
-      return e;
-    }
-    it = m->tables.emplace(key, std::make_pair(devp, host)).first;
+// The stream's workspace, grown when needed (rare: a blocking free + allocation + clear; never while the stream is being
+// captured -- hipErrorNotSupported then, and the caller takes the plan that needs no workspace).
+hipError_t get_ws(DeviceModule *m, hipStream_t s, size_t ws_bytes, size_t nflags, StreamWs *out) {
+  if (ws_bytes > kWsMaxBytes) return hipErrorNotSupported;
+  std::lock_guard<std::mutex> lk(m->mu);
+  auto it = m->ws.find(s);
+  if (it != m->ws.end() && it->second.ws_bytes >= ws_bytes && it->second.nflags >= nflags) {
+    *out = it->second;
+    return hipSuccess;
   }
-  *out = it->second.first;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return hipErrorNotSupported;
+  if (it == m->ws.end() && m->ws.size() >= kWsMaxStreams) return hipErrorNotSupported;
+  StreamWs w = it != m->ws.end() ? it->second : StreamWs();
+  hipError_t e = hipSuccess;
+  if (w.ws_bytes < ws_bytes) {
+    if (w.ws) (void)hipFree(w.ws);      // (hipFree waits for the device: no kernel still reads the old buffer)
+    w.ws = nullptr; w.ws_bytes = 0;
+    const size_t want = std::max(ws_bytes, (size_t)32 << 20);
+    e = hipMalloc(&w.ws, want);
+    if (e == hipSuccess) w.ws_bytes = want;
+  }
+  if (e == hipSuccess && w.nflags < nflags) {
+    if (w.flags) (void)hipFree(w.flags);
+    w.flags = nullptr; w.nflags = 0;
+    const size_t want = std::max(nflags, (size_t)1 << 16);
+    e = hipMalloc((void **)&w.flags, want * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(w.flags, 0, want * sizeof(uint32_t));
+    if (e == hipSuccess) w.nflags = want;
+  }
+  m->ws[s] = w;
+  if (e != hipSuccess) return e;
+  *out = w;
   return hipSuccess;
+}
+
+// One launch of the tiled problem described by (tiles, K): which plan.
+//   plain:      one tile per workgroup, the hardware hands tiles to CUs as they free up: ceil(T / slots) rounds.
+//   persistent: G = every slot of the chip (or fewer), each workgroup walks an equal share of the T * P units (unit = one K slice of
+//               one tile; laser-order: slice = kc, the unit Laser's own pc loop restarts its chain at, gemm.nim:150-158; one chain: a
+//               slice length chosen here); a tile that straddles two workgroups is finished by the owner of its slice 0 (in-kernel
+//               ordered fix-up: laser-order results are the SAME bits as the sequential loop's).
+struct Plan {
+  bool persistent = false;
+  int64_t G = 0, P = 1, slice_len = 0, hmax = 1;
+  double time_us = 1e300;
+};
+
+Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, bool exact, int kc, double cu_flops_per_us, bool may_cut) {
+  Plan best;
+  const double tile_us = 2.0 * ki.bm * ki.bn * (double)K / cu_flops_per_us;
+  {
+    const int64_t t = tiles * batch, rounds = (t + kCUs - 1) / kCUs;
+    best.G = tiles;
+    best.slice_len = (K + ki.bk - 1) / ki.bk * ki.bk;
+    best.time_us = (double)rounds * tile_us / (rounds == 1 ? ki.eff_alone : ki.eff) + ki.fixed_us;
+  }
+  if (g_asm_plan == 1 || !may_cut || batch != 1 || !g_split_tail) return best;
+  const int64_t slots = g_asm_wgs > 0 ? std::min<int64_t>(g_asm_wgs, 4096) : (int64_t)kCUs * ki.occ;
+  const int64_t kt = (K + ki.bk - 1) / ki.bk;
+  // candidate cuts: laser-order: the kc slices; one chain: 1..16 slices of equal numbers of K-tiles (or the forced length)
+  int64_t cuts[18];
+  int ncuts = 0;
+  if (exact) {
+    cuts[ncuts++] = kc;
+  } else if (g_asm_slice > 0) {
+    cuts[ncuts++] = (int64_t)g_asm_slice * ki.bk;
+  } else {
+    for (int64_t p = 1; p <= 16 && p <= kt; p++) {
+      const int64_t len = (kt + p - 1) / p * ki.bk;
+      if (len >= 4 * ki.bk || p == 1) cuts[ncuts++] = len;
+    }
+  }
+  for (int i = 0; i < ncuts; i++) {
+    const int64_t len = cuts[i], P = (K + len - 1) / len, U = tiles * P, G = std::min(slots, U);
+    const bool cut = U % G != 0 || (U / G) % P != 0;      // some tile straddles two workgroups
+    if (!cut && G >= tiles && g_asm_plan != 2) continue;  // one whole tile per workgroup: that is the plain launch
+    // many tiles per workgroup: the workgroups of an XCD drift apart in the tile order and lose their shared panels -- the plain
+    // launch keeps them on neighbouring tiles
+    if ((double)U / (double)G / (double)P > 4.0 && g_asm_plan != 2) continue;
+    const int64_t q = U / G, r = U % G;
+    // the busiest CU: its workgroups' units back to back (the r longer ranges are spread evenly over the workgroup ids)
+    const int64_t wg_per_cu = (G + kCUs - 1) / kCUs;
+    const double units_cu = (double)(q * wg_per_cu) + (r ? std::min((double)wg_per_cu, std::ceil((double)r / kCUs)) : 0.0);
+    const double unit_us = tile_us * (double)std::min(len, K) / (double)K;
+    const double eff = G >= (int64_t)kCUs * ki.occ ? ki.eff : ki.eff_alone + (ki.eff - ki.eff_alone) * std::min(1.0, (double)(wg_per_cu - 1) / std::max(1, ki.occ - 1));
+    // every run restarts the pipeline (first loads, epilogue: hidden behind the CU's other workgroups when there are any); a cut
+    // tile costs a partial store + load and the flag round trip; laser-order head slices are one run each
+    const double runs = (double)(q / P) + (cut ? (exact ? 0.5 * (double)(P - 1) + 1.0 : 2.0) : 0.0);
+    const double t_us = units_cu * unit_us / eff + ki.fixed_us + 2.0 * runs / ki.occ + (cut ? 3.0 : 0.0);
+    if (t_us < 0.97 * best.time_us || (g_asm_plan == 2 && (!best.persistent || t_us < best.time_us))) {
+      best.persistent = true;
+      best.G = G; best.P = P; best.slice_len = len;
+      best.hmax = exact ? std::max<int64_t>(1, std::min(P - 1, q + (r ? 1 : 0))) : 1;
+      best.time_us = t_us;
+    }
+  }
+  return best;
+}
+
+// Fill the scheduler block for `plan` and launch.  The workspace is taken only by launches that cut tiles.
+hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernArgs &ka, int tiles_m, int tiles_n, int group_m, int64_t batch,
+                          size_t tile_bytes, hipStream_t s) {
+  Plan plan = plan_in;
+  StreamWs w;
+  const int64_t U = (int64_t)tiles_m * tiles_n * plan.P;
+  const bool cuts = plan.persistent && (U % plan.G != 0 || (U / plan.G) % plan.P != 0);
+  if (cuts) {
+    const hipError_t e = get_ws(m, s, (size_t)plan.G * plan.hmax * tile_bytes, (size_t)plan.G * plan.hmax + 1, &w);
+    if (e == hipErrorNotSupported) return e;
+    if (e != hipSuccess) return e;
+  }
+  if (!fill_sched(ka.sch, tiles_m, tiles_n, group_m, plan.G, plan.P, plan.slice_len, plan.hmax, cuts ? &w : nullptr, group_m > 0)) return hipErrorNotSupported;
+  size_t sz = sizeof(ka);
+  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  const hipError_t e = hipModuleLaunchKernel(m->fn[kern], (unsigned)plan.G, (unsigned)batch, 1, 256, 1, 1, 0, s, nullptr, extra);
+  if (e == hipSuccess) {
+    g_last_asm_wgs = (int)plan.G;
+    g_last_asm_slices = (int)plan.P;
+  }
+  return e;
+}
+
+void zero_conv_fields(KernArgs &ka) {
+  ka.unused_ = nullptr;
+  ka.dbg = nullptr;
+  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
+  ka.bsB_bytes = ka.bsC_bytes = 0;
 }
 
 }  // namespace
 
-// laser_hip_finalize: unload the code objects and free the tile tables of every device that used them
+// diagnostics (option "asm_fixup_timeouts", synchronises the device): fix-ups on the current device that gave up waiting for a partial
+// (asmgen/f32_kernel.py tail_fixup) -- never in a correct run
+int64_t asm_fixup_timeouts() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -1;
+  DeviceModule &m = g_mods[dev];
+  std::lock_guard<std::mutex> lk(m.mu);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  int64_t n = 0;
+  for (auto &kv : m.ws) {
+    uint32_t wv = 0;
+    if (kv.second.flags && hipMemcpy(&wv, kv.second.flags, 4, hipMemcpyDeviceToHost) == hipSuccess) n += wv;
+  }
+  return n;
+}
+
+// laser_hip_finalize: unload the code objects and free the workspaces of every device that used them
 void asm_kernels_release() {
-  std::lock_guard<std::mutex> lk(g_mods_mu);
   int cur = -1;
   (void)hipGetDevice(&cur);
   for (int d = 0; d < kMaxDev; d++) {
     DeviceModule &m = g_mods[d];
+    std::lock_guard<std::mutex> lk(m.mu);
     if (!m.mod) continue;
     (void)hipSetDevice(d);
-    (void)hipDeviceSynchronize();   // (a table's host copy backs an async upload; kernels may still read the device copy)
-    for (auto &kv : m.tables) {
-      (void)hipFree(kv.second.first);
-      delete kv.second.second;
+    (void)hipDeviceSynchronize();
+    for (auto &kv : m.ws) {
+      if (kv.second.ws) (void)hipFree(kv.second.ws);
+      if (kv.second.flags) (void)hipFree(kv.second.flags);
     }
-    m.tables.clear();
+    m.ws.clear();
     (void)hipModuleUnload(m.mod);
     m.mod = nullptr;
   }
@@ -206,7 +353,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   const int64_t ldb = nt ? a.csB : a.rsB;
   if (a.rsA < a.K || ldb < (nt ? a.K : a.N) || a.rsC < a.N) return hipErrorNotSupported;
   // (a ragged last K-tile is zero-filled piece-wise -- 16 bytes = 4 k -- and, when K % 4 != 0, element-wise in the staging registers)
-  if (a.K < 1) return hipErrorNotSupported;
+  if (a.K < 1 || a.M < 1 || a.N < 1) return hipErrorNotSupported;
   // laser-order results need the kc = 512 slices only when K > 512; one chain otherwise (the laser-order kernels are
   // plain single-chain kernels then: their fold tile is never reached)
   const bool exact = laser_order && a.K > 512;
@@ -215,57 +362,47 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if ((double)a.rsA * 4.0 * 256 >= 4.0e9) return hipErrorNotSupported;
   if ((nt ? (double)ldb * 4.0 * 256 : (double)a.K * (double)ldb * 4.0) >= 4.0e9) return hipErrorNotSupported;
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0) return hipErrorNotSupported;
-  if (a.M > 0xffff * (int64_t)128 || a.N > 0xffff * (int64_t)128) return hipErrorNotSupported;
   // (batched problems -- gemm_strided_batched, the kc slices of the slice-parallel form -- are grid y: every tile count below is
   // per launch)
-  const auto tiles_of = [&](const KernelInfo &k) { return ((a.M + k.bm - 1) / k.bm) * ((a.N + k.bn - 1) / k.bn) * (int64_t)a.batch; };
-  // Which tile.  Workgroups that share a CU share its matrix pipes, so whatever the number of workgroup slots a launch of T
-  // tiles takes ceil(T / 256) times one tile's matrix time: the smaller the tile the finer the quantisation, the larger
-  // the tile the closer a CU gets to the peak (the eff columns of kKernels).  3072^3: 288 tiles of 256x128 = 2 rounds for
-  // 1.125 rounds of work, 2304 tiles of 64x64 = exactly 9 rounds.
+  // Which tile and which plan.  Workgroups that share a CU share its matrix pipes, so whatever the number of workgroup slots a
+  // plain launch of T tiles takes ceil(T / 256) times one tile's matrix time: the smaller the tile the finer the quantisation, the
+  // larger the tile the closer a CU gets to the peak (the eff columns of kKernels); the persistent plan (plan_launch) cuts the
+  // quantisation to one K slice.  3072^3: 288 tiles of 256x128 = 2 rounds for 1.125 rounds of work, or 6.75 slices per CU.
   int pick = -1;
-  double best = 1e300;
+  Plan plan;
   const int mid = (!exact && a.K > 512) ? (nt ? 9 : 8) : -1;   // one chain over a long K: also the 256x128 tile
   const int tiny = 12 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0);
   const double cu_flops_per_us = 157.3e6 / 256.0;
+  // the one-chain kernels' fused epilogue has no C read: beta != 0 with a bias / activation only on the laser-order kernels
+  const auto lo_kernel = [](int k) { return k == 0 || k == 2 || k == 4 || k == 6 || k == 12 || k == 14; };
   for (int k : {big, mid, small, tiny}) {
-    if (k < 0) continue;
+    if (k < 0 || (g_asm_kernel >= 0 && k != g_asm_kernel)) continue;
+    if (fused && !lo_kernel(k) && a.beta != 0.0f) continue;
     const KernelInfo &ki_ = kKernels[k];
-    const int64_t t = tiles_of(ki_);
-    // the tile table packs (tile row, tile column) into 16 bits each
-    if ((a.M + ki_.bm - 1) / ki_.bm > 0xffff || (a.N + ki_.bn - 1) / ki_.bn > 0xffff) continue;
+    const int64_t tm = (a.M + ki_.bm - 1) / ki_.bm, tn = (a.N + ki_.bn - 1) / ki_.bn, t = tm * tn;
+    if ((double)t * 8.0 * (double)tn >= 4.0e9) continue;    // the in-kernel tile arithmetic's range (fill_sched)
     // below ~5/8 of a round of the larger tiles (3/8 of the 64x64 ones) the compiler-scheduled kernels' slice-parallel and
     // small-problem forms do better
-    if (g_f32_asm < 2 && t < (k == tiny ? 96 : 160)) continue;
-    const int64_t rounds = (t + 255) / 256;
-    const double tile_us = 2.0 * ki_.bm * ki_.bn * (double)a.K / cu_flops_per_us;
-    const double time = (double)rounds * tile_us / (rounds == 1 ? ki_.eff_alone : ki_.eff) + ki_.fixed_us;
-    if (time < 0.99 * best) best = time, pick = k;   // (near ties go to the larger tile: less L2 traffic)
+    if (g_f32_asm < 2 && t * a.batch < (k == tiny ? 96 : 160)) continue;
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 512, cu_flops_per_us, true);
+    if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;   // (near ties go to the larger tile: less L2 traffic)
   }
   if (pick < 0) return hipErrorNotSupported;
-  // the one-chain kernels' fused epilogue has no C read: beta != 0 with a bias / activation only on the laser-order kernels
-  const bool lo_kernel = pick == 0 || pick == 2 || pick == 4 || pick == 6 || pick == 12 || pick == 14;
-  if (fused && !lo_kernel && a.beta != 0.0f) return hipErrorNotSupported;
   const KernelInfo &ki = kKernels[pick];
   const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
-  const int64_t tiles = (int64_t)tiles_m * tiles_n;
 
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lk(g_mods_mu);
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int group_m = (ki.bm >= 2 * ki.bn) ? 4 : 8;
-  const uint32_t *table = nullptr;
-  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
-  if (e != hipSuccess) return e;
   KernArgs ka;
+  zero_conv_fields(ka);
   ka.A = a.A;
   ka.B = a.B;
   ka.C = a.C;
-  ka.table = table;
   ka.lda = (uint32_t)a.rsA;
   ka.ldb = (uint32_t)ldb;
   ka.ldc = (uint32_t)a.rsC;
@@ -274,8 +411,6 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.K = (uint32_t)a.K;
   ka.alpha = a.alpha;
   ka.beta = a.beta;
-  ka.dbg = nullptr;
-  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
   // batch strides in bytes (f32_kernel.py KA_BSA = the H, W slots; B's and C's in the convolution kernels' slots)
   const uint64_t bsA_bytes = a.batch > 1 ? (uint64_t)a.bsA * 4 : 0;
   ka.H = (uint32_t)bsA_bytes;
@@ -286,9 +421,11 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.rsBias = a.bias ? (uint32_t)a.rsBias : 0;
   ka.csBias = a.bias ? (uint32_t)a.csBias : 0;
   ka.act = (uint32_t)a.act;
-  size_t sz = sizeof(ka);
-  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);
+  e = launch_planned(m, pick, plan, ka, tiles_m, tiles_n, group_m, a.batch, (size_t)ki.bm * ki.bn * 4, s);
+  if (e == hipErrorNotSupported && plan.persistent) {   // no workspace (a stream being captured, ...): one tile per workgroup
+    Plan plain = plan_launch(ki, (int64_t)tiles_m * tiles_n, a.K, a.batch, exact, 512, cu_flops_per_us, false);
+    e = launch_planned(m, pick, plain, ka, tiles_m, tiles_n, group_m, a.batch, (size_t)ki.bm * ki.bn * 4, s);
+  }
   if (e == hipSuccess) {
     g_last_f32_asm = 1 + pick;
     g_last_split = 0;  // one launch
@@ -307,7 +444,7 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   const int64_t Mpad = (a.M + 127) / 128 * 128, Npad = (a.N + 127) / 128 * 128, Kpad = (a.K + 31) / 32 * 32;
   const int64_t tiles = (Mpad / 128) * (Npad / 128);
   if (g_i32_asm < 2 && tiles < 128) return hipErrorNotSupported;      // few tiles: the 8-wave compiler kernel's two workgroups per CU
-  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0 || Mpad > 0xffff * 128ll || Npad > 0xffff * 128ll)
+  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0 || (double)tiles * 8.0 * (double)(Npad / 128) >= 4.0e9)
     return hipErrorNotSupported;
   int8_t *Ap = (int8_t *)ws, *Bp = Ap + 4 * Mpad * Kpad;
   hipError_t e = launch_limb_planes<int32_t>(Ap, a.A, a.M, a.K, a.rsA, a.csA, Mpad, Kpad, s, 128);
@@ -317,28 +454,21 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   int dev = 0;
   e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lk(g_mods_mu);
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int tiles_m = (int)(Mpad / 128), tiles_n = (int)(Npad / 128), group_m = 8;
-  const uint32_t *table = nullptr;
-  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
-  if (e != hipSuccess) return e;
   KernArgs ka;
+  zero_conv_fields(ka);
   ka.A = Ap; ka.B = Bp; ka.C = a.C;
-  ka.table = table;
   ka.lda = (uint32_t)(Kpad / 32); ka.ldb = 0; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)Kpad;
   static_assert(sizeof(float) == sizeof(int32_t), "");
   std::memcpy(&ka.alpha, &a.alpha, 4);   // int32 alpha / beta travel in the float slots (i8_kernel.py)
   std::memcpy(&ka.beta, &a.beta, 4);
-  ka.dbg = nullptr;
-  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
-  ka.bsB_bytes = ka.bsC_bytes = 0;
-  size_t sz = sizeof(ka);
-  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(m->fn[20], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  Plan plain;      // one tile per workgroup (the limb kernels are never cut along K: integer sums need no order, K <= 8192 per launch)
+  plain.G = tiles;
+  e = launch_planned(m, 20, plain, ka, tiles_m, tiles_n, group_m, 1, 0, s);
   if (e == hipSuccess) g_last_i32_asm = 21;
   return e;
 }
@@ -352,7 +482,7 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t
   const int64_t Mpad = (a.M + 63) / 64 * 64, Npad = (a.N + 63) / 64 * 64, Kpad = (a.K + 31) / 32 * 32;
   const int64_t tiles = (Mpad / 64) * (Npad / 64);
   if (g_i32_asm < 2 && tiles < 128) return hipErrorNotSupported;
-  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 8.0 > 2147483648.0 || Mpad > 0xffff * 64ll || Npad > 0xffff * 64ll)
+  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 8.0 > 2147483648.0 || (double)tiles * 8.0 * (double)(Npad / 64) >= 4.0e9)
     return hipErrorNotSupported;
   int8_t *Ap = (int8_t *)ws, *Bp = Ap + 8 * Mpad * Kpad;
   hipError_t e = launch_limb_planes<int64_t>(Ap, a.A, a.M, a.K, a.rsA, a.csA, Mpad, Kpad, s, 64);
@@ -362,30 +492,23 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t
   int dev = 0;
   e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lk(g_mods_mu);
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int tiles_m = (int)(Mpad / 64), tiles_n = (int)(Npad / 64), group_m = 8;
-  const uint32_t *table = nullptr;
-  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
-  if (e != hipSuccess) return e;
   KernArgs ka;
+  zero_conv_fields(ka);
   ka.A = Ap; ka.B = Bp; ka.C = a.C;
-  ka.table = table;
   ka.lda = (uint32_t)(Kpad / 32); ka.ldb = 0; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)Kpad;
   ka.alpha = 0.0f; ka.beta = 0.0f;
-  ka.dbg = nullptr;
-  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
   // int64 alpha / beta in the H, W / oW, pH slots (i8_kernel.py KA_ALPHA64 = 72: where the f64 kernels take their doubles)
   static_assert(offsetof(KernArgs, H) == 72 && offsetof(KernArgs, oW) == 80, "KA_ALPHA64");
   std::memcpy(&ka.H, &a.alpha, 8);
   std::memcpy(&ka.oW, &a.beta, 8);
-  ka.bsB_bytes = ka.bsC_bytes = 0;
-  size_t sz = sizeof(ka);
-  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(m->fn[29], (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, nullptr, extra);
+  Plan plain;
+  plain.G = tiles;
+  e = launch_planned(m, 29, plain, ka, tiles_m, tiles_n, group_m, 1, 0, s);
   if (e == hipSuccess) g_last_i32_asm = 30;
   return e;
 }
@@ -406,20 +529,19 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   if (a.rsA < a.K || ldb < (nt ? a.K : a.N) || a.rsC < a.N || a.K < 2 || a.K % 2 != 0) return hipErrorNotSupported;   // 16-byte pieces = 2 k
   if ((double)a.rsA * 8.0 * 128 >= 4.0e9 || (nt ? (double)ldb * 8.0 * 128 : (double)a.K * (double)ldb * 8.0) >= 4.0e9) return hipErrorNotSupported;
   if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 8.0 > 2147483648.0) return hipErrorNotSupported;
-  if (a.M > 0xffff * (int64_t)64 || a.N > 0xffff * (int64_t)64) return hipErrorNotSupported;
   const bool exact = laser_order && a.K > 256;   // kc = 256 doubles (gemm_tiling.nim:310)
   const int big = (nt ? 25 : 16) + (exact ? 0 : 1), tiny = (nt ? 27 : 18) + (exact ? 0 : 1);
   int pick = -1;
-  double best = 1e300;
+  Plan plan;
   const double cu_flops_per_us = 78.6e6 / 256.0;
   for (int k : {big, tiny}) {
+    if (g_asm_kernel >= 0 && k != g_asm_kernel) continue;
     const KernelInfo &ki_ = kKernels[k];
-    const int64_t t = ((a.M + ki_.bm - 1) / ki_.bm) * ((a.N + ki_.bn - 1) / ki_.bn) * (int64_t)a.batch;   // (batches are grid y)
-    if (g_f64_asm < 2 && t < (k == tiny ? 96 : 160)) continue;
-    const int64_t rounds = (t + 255) / 256;
-    const double tile_us = 2.0 * ki_.bm * ki_.bn * (double)a.K / cu_flops_per_us;
-    const double time = (double)rounds * tile_us / (rounds == 1 ? ki_.eff_alone : ki_.eff) + ki_.fixed_us;
-    if (time < 0.99 * best) best = time, pick = k;
+    const int64_t tm = (a.M + ki_.bm - 1) / ki_.bm, tn = (a.N + ki_.bn - 1) / ki_.bn, t = tm * tn;   // (batches are grid y)
+    if ((double)t * 8.0 * (double)tn >= 4.0e9) continue;
+    if (g_f64_asm < 2 && t * a.batch < (k == tiny ? 96 : 160)) continue;
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 256, cu_flops_per_us, true);
+    if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;
   }
   if (pick < 0) return hipErrorNotSupported;
   const KernelInfo &ki = kKernels[pick];
@@ -427,23 +549,16 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lk(g_mods_mu);
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
   const int group_m = 8;
-  const uint32_t *table = nullptr;
-  e = tile_table(m, tiles_m, tiles_n, group_m, s, &table);
-  if (e != hipSuccess) return e;
   KernArgs ka;
+  zero_conv_fields(ka);
   ka.A = a.A; ka.B = a.B; ka.C = a.C;
-  ka.table = table;
   ka.lda = (uint32_t)a.rsA; ka.ldb = (uint32_t)ldb; ka.ldc = (uint32_t)a.rsC;
   ka.M = (uint32_t)a.M; ka.N = (uint32_t)a.N; ka.K = (uint32_t)a.K;
   ka.alpha = 1.0f; ka.beta = 0.0f;
-  ka.dbg = nullptr;
-  ka.H = ka.W = ka.oW = ka.pH = ka.pW = ka.Cin = ka.Npix = ka.magic_oW = ka.shift_oW = ka.pad_ = 0;
-  ka.bsB_bytes = ka.bsC_bytes = 0;
   // alpha, beta as float64 in the H..pH slots (f64_kernel.py KA_ALPHA64)
   uint64_t ab[2];
   static_assert(sizeof(double) == 8, "");
@@ -457,9 +572,11 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   ka.pW = (uint32_t)bsA_bytes; ka.Cin = (uint32_t)(bsA_bytes >> 32);
   ka.bsB_bytes = a.batch > 1 ? (uint64_t)a.bsB * 8 : 0;
   ka.bsC_bytes = a.batch > 1 ? (uint64_t)a.bsC * 8 : 0;
-  size_t sz = sizeof(ka);
-  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)(tiles_m * (int64_t)tiles_n), (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);
+  e = launch_planned(m, pick, plan, ka, tiles_m, tiles_n, group_m, a.batch, (size_t)ki.bm * ki.bn * 8, s);
+  if (e == hipErrorNotSupported && plan.persistent) {
+    Plan plain = plan_launch(ki, (int64_t)tiles_m * tiles_n, a.K, a.batch, exact, 256, cu_flops_per_us, false);
+    e = launch_planned(m, pick, plain, ka, tiles_m, tiles_n, group_m, a.batch, (size_t)ki.bm * ki.bn * 8, s);
+  }
   if (e == hipSuccess) g_last_f64_asm = 1 + pick;
   return e;
 }
@@ -498,26 +615,24 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   const KernelInfo &ki = kKernels[pick];
   const int tiles_m = (int)((a.M + ki.bm - 1) / ki.bm), tiles_n = (int)((a.N + ki.bn - 1) / ki.bn);
   const int64_t tiles = (int64_t)tiles_m * tiles_n;
-  if (tiles_m > 0xffff || tiles_n > 0xffff) return hipErrorNotSupported;   // 16-bit tile coordinates in the table
+  if ((double)tiles * (double)tiles >= 4.0e9) return hipErrorNotSupported;   // the in-kernel tile arithmetic's range (fill_sched)
   if (g_f32_asm < 2 && tiles * a.batch < 160) return hipErrorNotSupported;
   // a 256-row tile that is mostly padding (few output channels) loses to the compiler-scheduled 128 / 64-row tiles
   if (g_f32_asm < 2 && (double)a.M * (double)a.N < 0.75 * (double)tiles * ki.bm * ki.bn) return hipErrorNotSupported;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> lk(g_mods_mu);
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
-  // (one image's tiles are few: plain order of the tile ids keeps an image's pixels together in an XCD's L2)
-  const uint32_t *table = nullptr;
-  e = tile_table(m, tiles_m, tiles_n, 0, s, &table);
-  if (e != hipSuccess) return e;
+  // (one image's tiles are few: plain order of the tile ids -- tile rows fastest, no XCD remap -- keeps an image's pixels together
+  // in an XCD's L2)
+  const int group_m = 0;
   KernArgs ka;
+  zero_conv_fields(ka);
   ka.A = a.A;
   ka.B = a.B;
   ka.C = a.C;
-  ka.table = table;
   ka.lda = (uint32_t)a.rsA;
   ka.ldb = 0;
   ka.ldc = (uint32_t)npix;
@@ -526,7 +641,6 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.K = (uint32_t)a.K;
   ka.alpha = 1.0f;
   ka.beta = 0.0f;
-  ka.dbg = nullptr;
   ka.H = (uint32_t)a.cH;
   ka.W = (uint32_t)a.cW;
   ka.oW = (uint32_t)oW;
@@ -544,9 +658,9 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.csBias = a.bias ? (uint32_t)a.csBias : 0;
   ka.act = (uint32_t)a.act;
   if ((double)npix * (double)oW >= 4.0e9) return hipErrorNotSupported;
-  size_t sz = sizeof(ka);
-  void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(m->fn[pick], (unsigned)tiles, (unsigned)a.batch, 1, 256, 1, 1, 0, s, nullptr, extra);
+  Plan plain;
+  plain.G = tiles;
+  e = launch_planned(m, pick, plain, ka, tiles_m, tiles_n, group_m, a.batch, 0, s);
   if (e == hipSuccess) g_last_f32_asm = 1 + pick;
   return e;
 }

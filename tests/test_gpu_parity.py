@@ -1445,34 +1445,34 @@ def test_f32_asm_batched_and_slice_parallel(la, oracle):
     assert np.array_equal(res[1].cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy()))
 
 
-def test_round_split_whole_rounds_plus_k_sliced_rest(la, oracle):
-    """A badly filled last round of tiles (576 / 600 tiles of 64x64 = 2.25 / 2.34 rounds of 256 CUs): the problem is cut along M
-    into whole rounds (one ordinary launch) and the rows of the last round (slice-parallel form: kc slices as one batched launch
-    + ordered combine).  Same chains, same order of the slice sums: bit-identical to the single launch (split_tail = 0) and
-    to the oracle, ragged M / N / K included."""
+def test_badly_filled_last_round_persistent_plan_bit_identical(la, oracle):
+    """A badly filled last round of tiles (576 / 600 tiles of 64x64 = 2.25 / 2.34 rounds of 256 CUs): the assembly launcher's
+    persistent plan gives every workgroup slot an equal share of kc slices and finishes cut tiles with the in-kernel ordered
+    fix-up.  Same chains, same order of the slice sums (gemm.nim:150-158): bit-identical to the one-tile-per-workgroup launch
+    (asm_plan = 1) and to the oracle, ragged M / N / K and alpha / beta included."""
     import torch
     rng = np.random.default_rng(808)
-    for dtype, (M, N, K), cut in ((np.float64, (1536, 1536, 1536), 1344), (np.float32, (1536, 1536, 4096), 1344),
-                                  (np.float32, (1540, 1530, 4100), 1344), (np.float64, (1790, 1795, 1800), 1728)):   # (3 columns past 28 tiles are peeled off first)
+    for dtype, (M, N, K) in ((np.float64, (1536, 1536, 1536)), (np.float32, (1536, 1536, 4096)),
+                             (np.float32, (1540, 1530, 4100)), (np.float64, (1790, 1795, 1800))):
         A = torch.from_numpy(rand(rng, (M, K), dtype)).cuda()
         B = torch.from_numpy(rand(rng, (K, N), dtype)).cuda()
         outs = {}
-        for split in (1, 0):
-            la.set_option("split_tail", split)
+        for plan in (2, 1):
+            la.set_option("asm_plan", plan)
             try:
-                C = torch.from_numpy(rand(rng, (M, N), dtype)).cuda() if split else outs["c0"].clone()
-                if split: outs["c0"] = C.clone()
+                C = torch.from_numpy(rand(rng, (M, N), dtype)).cuda() if plan == 2 else outs["c0"].clone()
+                if plan == 2: outs["c0"] = C.clone()
                 la.matmul(A, B, 0.5, 0.25, C)
-                ls = la.get_option("last_split")
-                assert (ls < 0) == (split == 1), (M, N, K, split, ls)
-                if split and cut is not None:
-                    assert ls == -cut, (M, N, K, ls)
-                outs[split] = C
+                used = la.last_f32_asm() if dtype == np.float32 else la.get_option("last_f64_asm")
+                assert used != 0, (M, N, K, plan)
+                if plan == 2:
+                    assert la.get_option("last_asm_slices") > 1, (M, N, K)
+                outs[plan] = C
             finally:
-                la.set_option("split_tail", 1)
-        assert torch.equal(outs[1], outs[0]), (M, N, K)
+                la.set_option("asm_plan", 0)
+        assert torch.equal(outs[2], outs[1]), (M, N, K)
         want = oracle.matmul(A.cpu().numpy(), B.cpu().numpy(), 0.5, 0.25, outs["c0"].cpu().numpy())
-        assert np.array_equal(outs[1].cpu().numpy(), want), (M, N, K)
+        assert np.array_equal(outs[2].cpu().numpy(), want), (M, N, K)
 
 
 def test_f64_asm_batched_and_slice_parallel(la, oracle):

@@ -1,0 +1,239 @@
+"""GPU tests of the assembly kernels' launch plans (laser_amd/csrc/gemm_f32_asm.cpp plan_launch, asmgen/f32_kernel.py sched_next):
+the workgroup -> tile map is arithmetic in the kernel (no table, no lock, nothing to upload), launches may be persistent (fewer
+workgroups than tiles) and may cut tiles at K-slice boundaries, the owner of a tile's slice 0 adding the other workgroups' slice sums
+in ascending order.  Laser-order results must be the SAME bits whatever the plan (gemm.nim:150-158: slices are independent chains,
+their sums are added in order) and equal to the oracle; one-chain results stay within 1e-5 mean relative error
+(gemm_bench_float32.nim:365-367).  Also: concurrent launches from several host threads and streams, and a launch captured into a
+HIP graph and replayed."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import laser_amd
+    laser_amd.lib()
+    laser_amd.set_float_mode(0)
+    laser_amd.set_f32_config(-1)
+    yield laser_amd
+    for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("asm_slice", 0), ("f32_asm", 1), ("f64_asm", 1)):
+        laser_amd.set_option(k, v)
+    laser_amd.set_float_mode(0)
+
+
+def _rnd(rng, shape, dtype=np.float32):
+    return rng.uniform(-0.1, 0.1, shape).astype(dtype)
+
+
+def _mre(got, want):
+    return float(np.mean(np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-30)))
+
+
+# kernel index (gemm_f32_asm.cpp kKernels) -> tile; laser-order kernels only here
+LASER_KERNELS = {0: (256, 128), 2: (128, 128), 12: (64, 64)}
+LASER_KERNELS_NT = {4: (256, 128), 6: (128, 128), 14: (64, 64)}
+
+
+@pytest.mark.parametrize("nt", [False, True])
+def test_laser_order_bit_identical_for_every_plan_and_workgroup_count(la, oracle, nt):
+    """every laser-order kernel, forced; plain launch vs persistent launches of 7 .. 768 workgroups (cuts in every position: ranges
+    shorter than a tile, longer than a tile, ending inside the first / last slice), ragged M / N / K, alpha / beta"""
+    import torch
+    rng = np.random.default_rng(4242 + nt)
+    la.set_option("f32_asm", 2)
+    try:
+        for kern, (bm, bn) in (LASER_KERNELS_NT if nt else LASER_KERNELS).items():
+            M, N, K = 3 * bm + 17, 5 * bn - 9, 2048 + 100 + 3
+            A = torch.from_numpy(_rnd(rng, (M, K))).cuda()
+            Bh = _rnd(rng, (K, N))
+            B = torch.from_numpy(np.ascontiguousarray(Bh.T)).cuda().t() if nt else torch.from_numpy(Bh).cuda()
+            C0 = torch.from_numpy(_rnd(rng, (M, N))).cuda()
+            want = oracle.matmul(A.cpu().numpy(), Bh, 0.5, -0.25, C0.cpu().numpy())
+            la.set_option("asm_kernel", kern)
+            for plan, wgs in ((1, 0), (2, 0), (2, 7), (2, 15), (2, 16), (2, 100), (2, 256), (2, 333)):
+                la.set_option("asm_plan", plan)
+                la.set_option("asm_wgs", wgs)
+                C = C0.clone()
+                la.matmul(A, B, 0.5, -0.25, C)
+                assert la.last_f32_asm() == kern + 1, (kern, plan, wgs, la.last_f32_asm())
+                if plan == 2:
+                    assert la.get_option("last_asm_slices") == 5, (kern, la.get_option("last_asm_slices"))
+                    if wgs:
+                        assert la.get_option("last_asm_wgs") == wgs
+                assert np.array_equal(C.cpu().numpy(), want), (kern, plan, wgs)
+    finally:
+        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f32_asm", 1)):
+            la.set_option(k, v)
+
+
+def test_one_chain_cut_launches_within_tolerance_and_deterministic(la, oracle):
+    """FAST mode: a cut launch adds partial sums (another rounding order than the single chain, by design): <= 1e-5 mean relative
+    error against the float64 product, and the same bits on every repetition (the fix-up order is fixed, not first-come)"""
+    import torch
+    rng = np.random.default_rng(99)
+    la.set_float_mode(1)
+    la.set_option("f32_asm", 2)
+    try:
+        for kern, (bm, bn) in {1: (256, 256), 8: (256, 128), 3: (128, 128), 13: (64, 64)}.items():
+            M, N, K = 2 * bm + 40, 3 * bn - 8, 1500
+            Ah, Bh = _rnd(rng, (M, K)), _rnd(rng, (K, N))
+            A, B = torch.from_numpy(Ah).cuda(), torch.from_numpy(Bh).cuda()
+            want = Ah.astype(np.float64) @ Bh.astype(np.float64)
+            la.set_option("asm_kernel", kern)
+            for wgs, sl in ((0, 0), (11, 4), (50, 7), (256, 0)):
+                la.set_option("asm_plan", 2)
+                la.set_option("asm_wgs", wgs)
+                la.set_option("asm_slice", sl)
+                outs = []
+                for _ in range(2):
+                    C = torch.full((M, N), float("nan"), device="cuda")
+                    la.matmul(A, B, 1, 0, C)
+                    assert la.last_f32_asm() == kern + 1, (kern, la.last_f32_asm())
+                    outs.append(C.cpu().numpy())
+                assert np.array_equal(outs[0], outs[1]), (kern, wgs, sl)
+                assert _mre(outs[0], want) <= 1e-5, (kern, wgs, sl, _mre(outs[0], want))
+    finally:
+        la.set_float_mode(0)
+        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("asm_slice", 0), ("f32_asm", 1)):
+            la.set_option(k, v)
+
+
+def test_f64_plans_bit_identical(la, oracle):
+    """float64 kernels (kc = 256): every plan against the oracle, laser-order"""
+    import torch
+    rng = np.random.default_rng(5)
+    la.set_option("f64_asm", 2)
+    try:
+        for kern, (bm, bn), nt in ((16, (128, 128), False), (18, (64, 64), False), (27, (64, 64), True)):
+            M, N, K = 3 * bm + 10, 2 * bn + 30, 1024 + 130
+            Ah, Bh = _rnd(rng, (M, K), np.float64), _rnd(rng, (K, N), np.float64)
+            A = torch.from_numpy(Ah).cuda()
+            B = torch.from_numpy(np.ascontiguousarray(Bh.T)).cuda().t() if nt else torch.from_numpy(Bh).cuda()
+            C0 = torch.from_numpy(_rnd(rng, (M, N), np.float64)).cuda()
+            want = oracle.matmul(Ah, Bh, -1.5, 0.5, C0.cpu().numpy())
+            la.set_option("asm_kernel", kern)
+            for plan, wgs in ((1, 0), (2, 0), (2, 9), (2, 64), (2, 256)):
+                la.set_option("asm_plan", plan)
+                la.set_option("asm_wgs", wgs)
+                C = C0.clone()
+                la.matmul(A, B, -1.5, 0.5, C)
+                assert la.get_option("last_f64_asm") == kern + 1, (kern, plan, wgs, la.get_option("last_f64_asm"))
+                assert np.array_equal(C.cpu().numpy(), want), (kern, plan, wgs)
+    finally:
+        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f64_asm", 1)):
+            la.set_option(k, v)
+
+
+def test_default_plan_mid_sizes_bit_exact(la, oracle):
+    """the shapes the persistent plan was built for, default options: whichever plan the model takes, the oracle's bits"""
+    import torch
+    rng = np.random.default_rng(17)
+    for (M, N, K) in ((1920, 1920, 1920), (1536, 1536, 1536), (1024, 1024, 1024), (1000, 3000, 2000), (3072, 3072, 1030)):
+        Ah, Bh = _rnd(rng, (M, K)), _rnd(rng, (K, N))
+        C = la.matmul(torch.from_numpy(Ah).cuda(), torch.from_numpy(Bh).cuda())
+        assert la.last_f32_asm() != 0, (M, N, K)
+        assert np.array_equal(C.cpu().numpy(), oracle.matmul(Ah, Bh)), (M, N, K, la.last_f32_asm(), la.get_option("last_asm_wgs"))
+
+
+def test_concurrent_launches_two_threads_two_streams(la, oracle):
+    """distinct shapes launched at the same time from 2 host threads x 2 streams each (plain and cut plans mixed): the launcher
+    holds no lock across a launch, keeps one workspace per stream, and has nothing to upload -- every result bit-exact"""
+    import torch
+    rng = np.random.default_rng(2024)
+    shapes = [(1100, 900, 1600), (700, 1300, 2100), (1536, 1536, 1100), (520, 2050, 1030)]
+    probs = []
+    for (M, N, K) in shapes:
+        Ah, Bh = _rnd(rng, (M, K)), _rnd(rng, (K, N))
+        probs.append((torch.from_numpy(Ah).cuda(), torch.from_numpy(Bh).cuda(), oracle.matmul(Ah, Bh)))
+    torch.cuda.synchronize()
+    la.set_option("f32_asm", 2)
+    errors = []
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            outs = []
+            for rep in range(6):
+                for si, st in enumerate(streams):
+                    A, B, want = probs[(2 * tid + si + rep) % len(probs)]
+                    with torch.cuda.stream(st):
+                        la.set_option("asm_plan", 2 if (rep + si) % 2 else 0)     # (a process-wide knob: any mix is legal)
+                        outs.append((la.matmul(A, B), want))
+            for st in streams:
+                st.synchronize()
+            for C, want in outs:
+                if not np.array_equal(C.cpu().numpy(), want):
+                    errors.append(f"thread {tid}: mismatch")
+        except Exception as exc:      # noqa: BLE001
+            errors.append(f"thread {tid}: {type(exc).__name__}: {exc}")
+
+    try:
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        la.set_option("asm_plan", 0)
+        la.set_option("f32_asm", 1)
+    assert not errors, errors
+
+
+def test_dev_entry_point_captured_into_a_graph_and_replayed(la, oracle):
+    """a _dev call is pure stream work: captured into a HIP graph (no allocation, no copy, no synchronisation inside the call) and
+    replayed with new operand contents -- both the plain plan and, once the stream's workspace exists, a cut plan"""
+    import torch
+    rng = np.random.default_rng(31)
+    M, N, K = 1536, 1536, 1100
+    A = torch.from_numpy(_rnd(rng, (M, K))).cuda()
+    B = torch.from_numpy(_rnd(rng, (K, N))).cuda()
+    C = torch.zeros((M, N), device="cuda")
+    la.set_option("f32_asm", 2)
+    try:
+        for plan in (1, 2):
+            la.set_option("asm_plan", plan)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                la.matmul(A, B, 1, 0, C)          # warm: module load, (plan 2) this stream's workspace
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                la.matmul(A, B, 1, 0, C)
+            assert la.last_f32_asm() != 0
+            for rep in range(3):
+                Ah = _rnd(rng, (M, K))
+                A.copy_(torch.from_numpy(Ah))
+                C.fill_(float("nan"))
+                g.replay()
+                torch.cuda.synchronize()
+                assert np.array_equal(C.cpu().numpy(), oracle.matmul(Ah, B.cpu().numpy())), (plan, rep)
+    finally:
+        la.set_option("asm_plan", 0)
+        la.set_option("f32_asm", 1)
+
+
+def test_full_size_c3_transposed_b_dense_c_every_element(la, oracle):
+    """BASELINE configs[2] in the exact operand form bench.py times: A dense, B passed transposed (rowStrideB = 1), C dense,
+    4096^3 -> the `_nt` assembly kernels; every element against the oracle"""
+    import torch
+    rng = np.random.default_rng(6)
+    n = 4096
+    Ah, Bt = _rnd(rng, (n, n)), _rnd(rng, (n, n))           # Bt = B^T stored row-major
+    A, B = torch.from_numpy(Ah).cuda(), torch.from_numpy(Bt).cuda().t()
+    C = torch.zeros((n, n), device="cuda")
+    la.matmul(A, B, 1, 0, C)
+    assert la.last_f32_asm() in (5, 7, 15), la.last_f32_asm()
+    assert np.array_equal(C.cpu().numpy(), oracle.matmul(Ah, np.ascontiguousarray(Bt.T)))
+
+
+def test_no_fix_up_ever_gave_up_waiting(la):
+    """(last in this file) the error word in front of every stream's flags: a fix-up that polled for ~2 s without seeing its partial
+    would have counted itself here -- a lost release or a scheduling order the design does not allow"""
+    assert la.get_option("asm_fixup_timeouts") == 0
