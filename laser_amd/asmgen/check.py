@@ -28,7 +28,7 @@ def reference(A, B, kc, alpha=1.0, beta=0.0, C0=None):
 
 def plan_units(tiles, Kd, G, exact, kc, BK, split=True):
     """host model of the launcher's unit arithmetic (gemm_f32_asm.cpp: plan_launch): P slices per tile, slice length, units per
-    workgroup, workspace slots per workgroup"""
+    workgroup"""
     if not split:
         P, slen = 1, (Kd + BK - 1) // BK * BK
     elif exact:
@@ -39,19 +39,17 @@ def plan_units(tiles, Kd, G, exact, kc, BK, split=True):
         P = (Kd + slen - 1) // slen
     U = tiles * P
     assert 1 <= G <= U
-    q, r = U // G, U % G
-    hmax = max(1, min(P - 1, q + (1 if r else 0))) if exact else 1
-    return P, slen, q, r, hmax
+    return P, slen, U // G, U % G
 
 
-def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, hmax=1, ws=0, flags=0, group_m=None, xcd=False):
+def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, noseed=0, ws=0, flags=0, group_m=None, xcd=False):
     """the scheduler block of the kernel arguments (f32_kernel.py KA_SCHED); group_m None = one group: tile rows fastest"""
     gm = group_m or tm
     gsz_last = tm % gm or gm
     if q is None:
         q, r = tm * tn * P // G, tm * tn * P % G
     return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), (G // 8) if xcd else 0,
-                       (G % 8) if xcd else 0, P, K.magic_u32(P), q, r, slen, hmax, K.magic_u32(G), ws, flags)
+                       (G % 8) if xcd else 0, P, K.magic_u32(P), q, r, slen, noseed, K.magic_u32(G), ws, flags)
 
 
 def virtual_id(g, G, xcd):
@@ -59,11 +57,11 @@ def virtual_id(g, G, xcd):
 
 
 def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
-    """every workgroup of a launch, one after the other: descending virtual id, so that the HEAD partials a TAIL run waits for (they
-    come from the workgroups after it in unit order) are already in the workspace; returns the last workgroup's wave-0 statistics"""
+    """every workgroup of a launch, one after the other: ascending virtual id, so that the running sum a workgroup receives (from the
+    workgroup before it in unit order) is already in the workspace; returns the last workgroup's wave-0 statistics"""
     stats = None
     for bi in range(batch):
-        for g in sorted(range(G), key=lambda g_: -virtual_id(g_, G, xcd)):
+        for g in sorted(range(G), key=lambda g_: virtual_id(g_, G, xcd)):
             w = Workgroup(prog, mem, ka_, wg_id=(g, bi), lds_bytes=lds_bytes)
             w.run(order=order)
             stats = w.waves[0].stats
@@ -71,7 +69,7 @@ def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
 
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
-             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None):
+             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart.
     G: workgroups of the (persistent) launch, default one per tile; split: cut tiles along K at slice boundaries (laser-order: kc;
     one chain: `split` K-tiles per slice) so that the G workgroups get equal numbers of units"""
@@ -112,11 +110,11 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         As.append(Af[:, :Kd].copy()); Bs.append(Bm); C0s.append(C0)
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     G = G or tm * tn
-    P, slen, uq, ur, hmax = plan_units(tm * tn, Kd, G, c.exact, 512, c.BK, split)
+    P, slen, uq, ur = plan_units(tm * tn, Kd, G, c.exact, 512, c.BK, split)
     mem = Memory()
     a_, b_, c_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call)
-    ws_ = mem.alloc(np.full(G * hmax * g.tile_bytes() // 4, np.nan, dtype=np.float32))
-    fl_ = mem.alloc(np.zeros(G * hmax, dtype=np.uint32))
+    ws_ = mem.alloc(np.full(G * g.tile_bytes() // 4, np.nan, dtype=np.float32))
+    fl_ = mem.alloc(np.zeros(G, dtype=np.uint32))
     # fused epilogue: bias = "row" (1 x N, row stride 0), "col" (M x 1, column stride 0) or "full" (M x N, padded rows); act 1 = relu
     bias_ptr, rsb, csb, Bias = 0, 0, 0, None
     if bias:
@@ -129,13 +127,13 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
     ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, 0)
-    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, hmax, ws_, fl_, group_m, xcd)
+    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd)
-    if np.any(mem.get(fl_, np.uint32, (G * hmax,))):
-        raise AssertionError("a workspace flag was left set: the next launch would take a stale partial")
+    if np.any(mem.get(fl_, np.uint32, (G,))):
+        raise AssertionError("a workspace flag was left set: the next launch would take a stale sum")
     got = mem.get(c_, np.float32, (batch * LC,))
     ok = pad_ok = True
     for b in range(batch):
@@ -224,7 +222,7 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
 
 
 def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True, alpha=1.0, beta=0.0, batch=1,
-               G=None, split=False, group_m=None, xcd=False):
+               G=None, split=False, group_m=None, xcd=False, noseed=0):
     """float64 kernels (f64_kernel.py) through the interpreter.  Operands are small integers (alpha, beta dyadic), for which every
     product and partial sum is exact in float64 (the interpreter's f64 MFMA is mul + add, not an exact fma): this checks every
     address, layout, wait and hazard of the program; the accumulation ORDER with rounding is checked on hardware against the
@@ -262,20 +260,20 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
         Call[b * LC:b * LC + LC - 5] = full0.reshape(-1)[:(M - 1) * ldc + N]
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     G = G or tm * tn
-    P, slen, uq, ur, hmax = plan_units(tm * tn, Kd, G, c.exact, 256, c.BK, split)
+    P, slen, uq, ur = plan_units(tm * tn, Kd, G, c.exact, 256, c.BK, split)
     mem = Memory()
     a_, b_, c_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call)
-    ws_ = mem.alloc(np.full(G * hmax * g.tile_bytes() // 8, np.nan))
-    fl_ = mem.alloc(np.zeros(G * hmax, dtype=np.uint32))
+    ws_ = mem.alloc(np.full(G * g.tile_bytes() // 8, np.nan))
+    fl_ = mem.alloc(np.zeros(G, dtype=np.uint32))
     bs = (LA * 8, LB * 8, LC * 8) if batch > 1 else (0, 0, 0)
     ka = (struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta)
           + struct.pack("<Q", bs[0]) + b"\0" * 16 + struct.pack("<QQ", bs[1], bs[2]) + b"\0" * 24)
-    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, hmax, ws_, fl_, group_m, xcd)
+    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd)
-    if np.any(mem.get(fl_, np.uint32, (G * hmax,))):
+    if np.any(mem.get(fl_, np.uint32, (G,))):
         raise AssertionError("a workspace flag was left set")
     got = mem.get(c_, np.float64, (batch * LC,))
     ok = True

@@ -114,13 +114,14 @@ KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's s
 #   +24 magic(rows of the last group)  +28 xcd_q (workgroups / 8; 0 = no XCD remap)
 #   +32 xcd_r (workgroups % 8)  +36 P (K slices per tile)  +40 magic(P)  +44 units_q  +48 units_r (units = workgroups * q + r:
 #       workgroup v starts at unit v * q + floor(v * r / workgroups) -- the r longer ranges are spread evenly over the ids)
-#   +52 slice length (elements of K)  +56 workspace slots per workgroup  +60 magic(workgroups)
+#   +52 slice length (elements of K)  +56 bit 0: never take a received sum early (tests: forces the two-run receive path)  +60 magic(workgroups)
 #   +64 workspace (u64)  +72 flags (u64)
 KA_SCHED = 152
 KA_SCHED2 = KA_SCHED + 32
 KA_WS = KA_SCHED + 64
 KERNARG_SIZE = 232
-MODE_FULL, MODE_HEAD, MODE_TAIL = 0, 1, 2
+MODE_NORMAL, MODE_ACC, MODE_CONT = 0, 1, 2     # run_setup: running sum from beta * C0 / left alone (not used by the run) / kept (a received sum)
+END_EPI, END_SEND, END_RECV = 0, 1, 2          # after the K loop: store C / send the running sum on / receive the predecessor's
 
 
 def magic_u32(d):
@@ -213,16 +214,17 @@ class Gen:
         self.vF, self.vFaddr, self.vFoff = blk.sub(4, 4), blk[10], blk[11]
 
     def alloc_sched(self):
-        """scheduler state: persistent kernels walk units [s_u, s_uend) of the launch's unit sequence (unit = one K slice of one
-        tile, tile-major); a run = consecutive units of ONE tile: k in [s_kb, s_kb + s_Keff), in one of three modes"""
+        """scheduler state.  A persistent workgroup owns units [u0, u1) of the launch's unit sequence (unit = one K slice of one tile,
+        tile-major): u0 = t0 * P + p0, u1 = t1 * P + pe.  It runs, in this order: the FIRST slices [0, pe) of tile t1 (their running sum
+        is sent on to the next workgroup), its whole tiles, and last the END piece [p0, P) of tile t0, which continues the running sum
+        received from the previous workgroup -- by then long since sent (sched_next)."""
         c, S = self.c, self.p.salloc
         self.s_sc = None
         if c.persistent:
             self.s_sc = S(8, align=4)                      # scheduler constants, (re)loaded where they are used
-            self.s_u, self.s_uend, self.s_vid = S(), S(), S()
-            self.s_kb, self.s_Keff, self.s_mode = S(), S(), S()
-            self.s_tile, self.s_pe, self.s_slot = S(), S(), S()   # linear tile index; slices of the run; workspace slot of a head run
-            self.s_wsf = S(4, align=4)                     # workspace pointer, flags pointer
+            self.s_vid, self.s_t0, self.s_p0, self.s_t1, self.s_pe, self.s_tcur, self.s_phase = (S() for _ in range(7))
+            self.s_kb, self.s_Keff, self.s_mode, self.s_tile = S(), S(), S(), S()
+            self.s_end, self.s_fin, self.s_pz = S(), S(), S()
         else:
             self.s_Keff = self.s_K
             self.s_tile = None
@@ -358,61 +360,125 @@ class Gen:
         e("s_add_u32", dst, dst, tmp)
 
     def sched_init(self):
-        """units [s_u, s_uend) of this workgroup, by its virtual id (XCD remap)"""
+        """[u0, u1) of this workgroup by its virtual id (XCD remap) -> (t0, p0), (t1, pe)"""
         e, st, sc = self.p.emit, self.s_t, self.s_sc
         e("s_load_dword", st[5], s(0, 2), KA_SCHED + 28)
         e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
-        e("s_load_dwordx4", self.s_wsf, s(0, 2), KA_WS)
         e("s_waitcnt", lgkmcnt=0)
+        P, mg_P = sc[1], sc[2]
         self.xcd_remap(self.s_vid, s(2), st[5], sc[0], st[0])
-        self.unit_start(self.s_u, self.s_vid, st[0])
+        self.unit_start(st[2], self.s_vid, st[0])
         e("s_add_u32", st[1], self.s_vid, 1)
-        self.unit_start(self.s_uend, st[1], st[0])
+        self.unit_start(st[3], st[1], st[0])
+        self.udiv(self.s_t0, st[2], mg_P)
+        e("s_mul_i32", st[0], self.s_t0, P)
+        e("s_sub_u32", self.s_p0, st[2], st[0])
+        self.udiv(self.s_t1, st[3], mg_P)
+        e("s_mul_i32", st[0], self.s_t1, P)
+        e("s_sub_u32", self.s_pe, st[3], st[0])
+        e("s_cmp_lg_u32", self.s_p0, 0)
+        e("s_cselect_b32", st[0], 1, 0)
+        e("s_add_u32", self.s_tcur, self.s_t0, st[0])      # first whole tile
+        e("s_mov_b32", self.s_phase, 0)
 
-    def sched_next(self, L_exit):
-        """the next run: consecutive units of one tile.  Unit u = tile * P + p.  p == 0: slices [0, n), n = min(P, units left): the
-        whole tile (FULL) or its first slices (TAIL: this workgroup finishes the tile -- the later slices come from the workspace,
-        where the workgroups that own them put them as HEAD runs: laser-order one slice per run, since every slice sum is added on its
-        own, gemm.nim:150-158; one chain: all of the workgroup's slices of that tile as one partial sum)."""
-        c, e, st, sc = self.c, self.p.emit, self.s_t, self.s_sc
-        e("s_cmp_ge_u32", self.s_u, self.s_uend)
-        e("s_cbranch_scc1", L_exit)
+    def sched_next(self, L_exit, L_recv):
+        """the next run of this workgroup (falls through with s_tile, s_kb, s_Keff, s_mode, s_end set; L_exit when there is none).
+        phase 0: slices [0, pe) of tile t1, running sum SENT to workgroup vid + 1 (slot vid) -- first, so that the receiver, which
+                 needs it last, never waits;
+        phase 1: whole tiles t0 (+1 if p0 > 0) .. t1 - 1;
+        phase 2: the piece [p0, pz) of tile t0 (pz = P, or pe when the whole range lies inside one tile): continues the sum RECEIVED
+                 from workgroup vid - 1.  Laser-order: if the sum has already arrived it becomes the running sum and the piece is one
+                 run; else the piece's first slice is computed while the sender still works (run A: a chain from +0 needs nothing),
+                 the sum is received after it, and the remaining slices follow as run B on top of it (mode CONT) -- every slice sum
+                 is added in ascending order either way (gemm.nim:150-158).  One chain: one run, the received partial sum added last."""
+        c, p = self.c, self.p
+        e, st, sc, t = p.emit, self.s_t, self.s_sc, self.vt
+        L_ph1, L_ph2, L_go, L_more = p.label("ph1"), p.label("ph2"), p.label("go"), p.label("whole")
         e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
         e("s_waitcnt", lgkmcnt=0)
-        P, mg_P, units_q, units_r, slen, hmax = sc[1], sc[2], sc[3], sc[4], sc[5], sc[6]
-        p_, left = st[0], st[1]
-        self.udiv(self.s_tile, self.s_u, mg_P)
-        e("s_mul_i32", p_, self.s_tile, P)
-        e("s_sub_u32", p_, self.s_u, p_)                          # p
-        e("s_sub_u32", left, self.s_uend, self.s_u)
-        head, join = self.p.label("head"), self.p.label("run")
-        e("s_cmp_lg_u32", p_, 0)
-        e("s_cbranch_scc1", head)
-        e("s_min_u32", self.s_pe, P, left)
-        e("s_cmp_eq_u32", self.s_pe, P)
-        e("s_cselect_b32", self.s_mode, MODE_FULL, MODE_TAIL)
+        P, slen = sc[1], sc[5]
+        ke = st[0]
+        # ---- phase 0: the first slices of the tile the range ends in
+        e("s_cmp_lg_u32", self.s_phase, 0)
+        e("s_cbranch_scc1", L_ph1)
+        e("s_mov_b32", self.s_phase, 1)
+        e("s_cmp_eq_u32", self.s_pe, 0)
+        e("s_cbranch_scc1", L_ph1)
+        e("s_cmp_lg_u32", self.s_t0, self.s_t1)
+        e("s_cselect_b32", st[1], 1, 0)
+        e("s_cmp_eq_u32", self.s_p0, 0)
+        e("s_cselect_b32", st[2], 1, 0)
+        e("s_or_b32", st[1], st[1], st[2])                  # t0 != t1 or p0 == 0: slice 0 of tile t1 is ours
+        e("s_cmp_eq_u32", st[1], 0)
+        e("s_cbranch_scc1", L_ph1)
+        e("s_mov_b32", self.s_tile, self.s_t1)
         e("s_mov_b32", self.s_kb, 0)
-        e("s_branch", join)
-        self.p.place(head)
+        e("s_mul_i32", ke, self.s_pe, slen)
+        e("s_mov_b32", self.s_mode, MODE_NORMAL)
+        e("s_mov_b32", self.s_end, END_SEND)
+        e("s_branch", L_go)
+        # ---- phase 1: whole tiles
+        p.place(L_ph1)
+        e("s_cmp_lg_u32", self.s_phase, 1)
+        e("s_cbranch_scc1", L_ph2)
+        e("s_cmp_lt_u32", self.s_tcur, self.s_t1)
+        e("s_cbranch_scc1", L_more)
+        e("s_mov_b32", self.s_phase, 2)
+        e("s_branch", L_ph2)
+        p.place(L_more)
+        e("s_mov_b32", self.s_tile, self.s_tcur)
+        e("s_add_u32", self.s_tcur, self.s_tcur, 1)
+        e("s_mov_b32", self.s_kb, 0)
+        e("s_mov_b32", ke, self.s_K)
+        e("s_mov_b32", self.s_mode, MODE_NORMAL)
+        e("s_mov_b32", self.s_end, END_EPI)
+        e("s_branch", L_go)
+        # ---- phase 2: the piece that continues the previous workgroup's running sum
+        p.place(L_ph2)
+        e("s_cmp_lg_u32", self.s_phase, 2)
+        e("s_cbranch_scc1", L_exit)
+        e("s_mov_b32", self.s_phase, 4)
+        e("s_cmp_eq_u32", self.s_p0, 0)
+        e("s_cbranch_scc1", L_exit)
+        e("s_mov_b32", self.s_tile, self.s_t0)
+        e("s_cmp_eq_u32", self.s_t0, self.s_t1)
+        e("s_cselect_b32", self.s_pz, self.s_pe, P)
+        e("s_cmp_eq_u32", self.s_pz, P)
+        e("s_cselect_b32", self.s_fin, END_EPI, END_SEND)
+        e("s_mul_i32", self.s_kb, self.s_p0, slen)
         if c.exact:
-            e("s_mov_b32", self.s_pe, 1)
+            L_late = p.label("late")
+            # has the sum arrived?  (one look at the flag; sc[6] bit 0: tests force the two-run path)
+            e("s_bitcmp1_b32", sc[6], 0)
+            e("s_cbranch_scc1", L_late)
+            e("s_sub_u32", st[3], self.s_vid, 1)
+            self.ws_descriptors(st[3])
+            e("buffer_load_dword", t[9], OFF, self.srdA, 0, sc1=True)
+            e("s_waitcnt", vmcnt=0)
+            e("v_readfirstlane_b32", st[4], t[9])
+            e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_cmp_eq_u32", st[4], 0)
+            e("s_cbranch_scc1", L_late)
+            e("s_mov_b32", self.s_phase, 5)                  # the receive block comes back to the run set-up
+            e("s_mul_i32", ke, self.s_pz, slen)
+            e("s_min_u32", ke, ke, self.s_K)
+            e("s_sub_u32", self.s_Keff, ke, self.s_kb)
+            e("s_mov_b32", self.s_mode, MODE_CONT)
+            e("s_mov_b32", self.s_end, self.s_fin)
+            e("s_branch", L_recv)
+            p.place(L_late)
+            e("s_add_u32", ke, self.s_p0, 1)
+            e("s_mul_i32", ke, ke, slen)
+            e("s_mov_b32", self.s_mode, MODE_ACC)
+            e("s_mov_b32", self.s_end, END_RECV)
         else:
-            e("s_sub_u32", self.s_pe, P, p_)
-            e("s_min_u32", self.s_pe, self.s_pe, left)
-        e("s_mov_b32", self.s_mode, MODE_HEAD)
-        e("s_mul_i32", self.s_kb, p_, slen)
-        # workspace slot: vid * hmax + (index of this head run in the workgroup: laser-order u - first unit, one chain 0)
-        e("s_mul_i32", self.s_slot, self.s_vid, hmax)
-        if c.exact:
-            self.unit_start(st[2], self.s_vid, st[3])
-            e("s_sub_u32", st[2], self.s_u, st[2])
-            e("s_add_u32", self.s_slot, self.s_slot, st[2])
-        self.p.place(join)
-        e("s_add_u32", st[2], p_, self.s_pe)
-        e("s_mul_i32", st[2], st[2], slen)
-        e("s_min_u32", st[2], st[2], self.s_K)                    # end of the run along K
-        e("s_sub_u32", self.s_Keff, st[2], self.s_kb)
-        e("s_add_u32", self.s_u, self.s_u, self.s_pe)
+            e("s_mul_i32", ke, self.s_pz, slen)
+            e("s_mov_b32", self.s_mode, MODE_NORMAL)
+            e("s_mov_b32", self.s_end, END_RECV)
+        p.place(L_go)
+        e("s_min_u32", ke, ke, self.s_K)
+        e("s_sub_u32", self.s_Keff, ke, self.s_kb)
 
     # ------------------------------------------------------------------ prologue
     def prologue(self):
@@ -423,11 +489,13 @@ class Gen:
         st = self.s_t
         self.once()
         self.L_run, self.L_exit = p.label("next_run"), p.label("exit")
+        self.L_setup, self.L_recv = p.label("setup"), p.label("recv")
         if c.persistent:
             self.sched_init()
             p.place(self.L_run)
+            self.sched_next(self.L_exit, self.L_recv)
+            p.place(self.L_setup)
             e("s_barrier", comment="every wave is done with the previous run's LDS tiles")
-            self.sched_next(self.L_exit)
             tile = self.s_tile
             e("s_load_dwordx8", self.s_sc, s(0, 2), KA_SCHED)
             e("s_waitcnt", lgkmcnt=0)
@@ -758,14 +826,7 @@ class Gen:
         self.mask_last_pieces_if(self.s_rem, 2)
         self.advance_srds()
         self.tail_mask_if(self.s_rem, 3)        # the first loop body loads tile 2
-        # accumulators start at +0
-        for b in range(c.NB):
-            for r in range(c.ACCR):
-                e("v_accvgpr_write_b32", self.acc[b][r], 0)
-                if c.exact:
-                    e("v_accvgpr_write_b32", self.run[b][r], 0)
-        if c.exact:
-            self.load_beta_c()
+        self.init_accumulators()
         self.lg_wait(None)
         e("s_barrier")
         self.read_group(0, 0, 0)
@@ -781,6 +842,26 @@ class Gen:
             e("v_lshlrev_b32", self.vFaddr, 4, v(0))
             e("v_add_u32", self.vFaddr, c.lds_bytes, self.vFaddr, comment="filler experiments: 16 B per lane past the kernel's LDS")
             e("v_lshlrev_b32", self.vFoff, 4, v(0))
+
+    def init_accumulators(self):
+        """the chain starts at +0; laser-order: the running sum starts as beta * C0 -- unless this run continues a received sum
+        (MODE_CONT) or does not use it (MODE_ACC: a piece's first slice, computed before the sum is received)"""
+        c, p = self.c, self.p
+        e = p.emit
+        for b in range(c.NB):
+            for r in range(c.ACCR):
+                e("v_accvgpr_write_b32", self.acc[b][r], 0)
+        if not c.exact:
+            return
+        keep = p.label("keeprun")
+        if c.persistent:
+            e("s_cmp_lg_u32", self.s_mode, MODE_NORMAL)
+            e("s_cbranch_scc1", keep)
+        for b in range(c.NB):
+            for r in range(c.ACCR):
+                e("v_accvgpr_write_b32", self.run[b][r], 0)
+        self.load_beta_c()
+        p.place(keep)
 
     def c_descriptor(self):
         """srdC = the whole C matrix (conv: this image's [M][oH*oW] block): bytes = (M - 1) * ldc * 4 + N * 4"""
@@ -1422,9 +1503,6 @@ class Gen:
         e("s_and_b32", self.s_t[0], self.s_beta, 0x7fffffff)
         e("s_cmp_eq_u32", self.s_t[0], 0)
         e("s_cbranch_scc1", skip)
-        if c.persistent:       # a head run's slice sums go to the workspace raw: beta * C0 belongs to the run that finishes the tile
-            e("s_cmp_eq_u32", self.s_mode, MODE_HEAD)
-            e("s_cbranch_scc1", skip)
         self.c_addr_setup()
         pool = [r[k] for slot in range(2) for r in (self.fa[slot] + self.fb[slot]) for k in range(4)]
         per = 4 * c.TN
@@ -1639,19 +1717,21 @@ class Gen:
 
     def ws_descriptors(self, slot):
         """srdA = flags[slot] (one dword: of the workgroup's 256 byte offsets 4 * tid only thread 0's is in range), srdB = workspace
-        slot `slot`: one tile in register order -- dword (b * ACCR + r) * 256 + tid = accumulator register r of block b of thread tid.
-        Clobbers s_t[4], s_t[5]."""
-        e, st, wsf = self.p.emit, self.s_t, self.s_wsf
+        slot `slot`: one tile in register order -- dword (b * ACCR + r) * 256 + tid = register r of block b of thread tid.
+        Clobbers s_t[4], s_t[5]; `slot` must not be one of them."""
+        e, st = self.p.emit, self.s_t
+        e("s_load_dwordx4", self.srdB, s(0, 2), KA_WS)
+        e("s_waitcnt", lgkmcnt=0)
         e("s_lshl_b32", st[5], slot, 2)
-        e("s_add_u32", self.srdA[0], wsf[2], st[5])
-        e("s_addc_u32", self.srdA[1], wsf[3], 0)
+        e("s_add_u32", self.srdA[0], self.srdB[2], st[5])
+        e("s_addc_u32", self.srdA[1], self.srdB[3], 0)
         e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
         e("s_mov_b32", self.srdA[2], 4)
         e("s_mov_b32", self.srdA[3], 0x00020000)
         e("s_mul_hi_u32", st[4], slot, self.tile_bytes())
         e("s_mul_i32", st[5], slot, self.tile_bytes())
-        e("s_add_u32", self.srdB[0], wsf[0], st[5])
-        e("s_addc_u32", self.srdB[1], wsf[1], st[4])
+        e("s_add_u32", self.srdB[0], self.srdB[0], st[5])
+        e("s_addc_u32", self.srdB[1], self.srdB[1], st[4])
         e("s_and_b32", self.srdB[1], self.srdB[1], 0xffff)
         e("s_mov_b32", self.srdB[2], self.tile_bytes())
         e("s_mov_b32", self.srdB[3], 0x00020000)
@@ -1668,22 +1748,27 @@ class Gen:
                 if n % 4 == 0 and n < c.NB * c.ACCR:
                     e("s_add_u32", st[5], st[5], 4096)
 
-    def head_store(self):
-        """HEAD run: the raw slice sum (one chain: the partial sum of the run's slices) goes to the workspace slot, then the flag is
-        released at agent scope (the sequence hipcc emits for a release store on gfx950: write back L2, wait, store sc1) with the
-        number of slices the partial covers.  The workgroup that owns slice 0 of the tile adds the partials in ascending k."""
+    def send_block(self):
+        """SEND: the running sum of this tile's first slices (beta * C0 included; one chain: the partial chain sum) goes to workspace slot
+        `vid`, then flag `vid` is set; workgroup vid + 1 continues the tile from it.
+        Visibility across XCDs (each has its own L2): every access to the workspace and the flags carries sc1 = agent scope -- the
+        stores write through, the loads do not hit a stale line -- and the flag is stored after the sum's stores have completed
+        (s_waitcnt vmcnt(0) on every wave, then the barrier).  The whole-L2 write-back + invalidate pair hipcc emits around a
+        release / acquire (buffer_wbl2 sc1 / buffer_inv sc1) protects accesses WITHOUT scope bits; here it only threw the other
+        workgroups' operand panels out of the L2: cut launches ran at half speed with it (profiles/r04/plan_sweep_f32_mid_a.jsonl)."""
         c, e, t = self.c, self.p.emit, self.vt
-        self.ws_descriptors(self.s_slot)
+        if c.exact:
+            self.fold_all()
+        self.ws_descriptors(self.s_vid)
         e("v_lshlrev_b32", t[8], 2, v(0))
-        self.ws_walk(lambda b, r, so, imm: e("buffer_store_dword", self.acc[b][r], t[8], self.srdB, so, offen=True, offset=imm, sc1=True))
-        e("s_waitcnt", vmcnt=0)
-        e("buffer_wbl2", sc1=True)
+        src = self.run if c.exact else self.acc
+        self.ws_walk(lambda b, r, so, imm: e("buffer_store_dword", src[b][r], t[8], self.srdB, so, offen=True, offset=imm, sc1=True))
         e("s_waitcnt", vmcnt=0)
         e("s_barrier")
-        e("v_mov_b32", t[9], self.s_pe)
+        e("v_mov_b32", t[9], 1)
         e("buffer_store_dword", t[9], t[8], self.srdA, 0, offen=True, sc1=True)
         e("s_waitcnt", vmcnt=0)
-        self.end_run()
+        e("s_branch", self.L_run)
 
     def fold_all(self):
         """run += alpha * acc for every block (the slice fold of the K loop, outside it)"""
@@ -1695,7 +1780,7 @@ class Gen:
         for r in range(16):
             e("v_accvgpr_read_b32", T[r], self.acc[b][r])
         for r in range(16):
-            e("v_mul_f32", T[r], self.s_alpha, T[r])      # (1.0 * x is x: no branch here, the fix-up is not the hot loop)
+            e("v_mul_f32", T[r], self.s_alpha, T[r])      # (1.0 * x is x: no branch here, the hand-over is not the hot loop)
         for r in range(16):
             tt = self.vt[r % 4]
             e("v_accvgpr_read_b32", tt, self.run[b][r])
@@ -1711,12 +1796,11 @@ class Gen:
             e("v_add_f32", tt, tt, T[r])
             e("v_accvgpr_write_b32", self.acc[b][r], tt)
 
-    def load_partial(self, t_off):
-        """laser-order: the accumulators become the next slice sum (the fold before the next partial / the epilogue adds it);
-        one chain: acc += partial"""
+    def load_received(self, t_off):
+        """laser-order: the received sum becomes the running sum; one chain: acc += received partial"""
         c, e, T, st = self.c, self.p.emit, self.vT[0], self.s_t
         if c.exact:
-            self.ws_walk(lambda b, r, so, imm: e("buffer_load_dword", self.acc[b][r], t_off, self.srdB, so, offen=True, offset=imm, sc1=True))
+            self.ws_walk(lambda b, r, so, imm: e("buffer_load_dword", self.run[b][r], t_off, self.srdB, so, offen=True, offset=imm, sc1=True))
             e("s_waitcnt", vmcnt=0)
             return
         e("s_mov_b32", st[5], 0)
@@ -1730,34 +1814,17 @@ class Gen:
             e("s_waitcnt", vmcnt=0)
             self.acc_add_block(b)
 
-    def tail_fixup(self, L_back):
-        """TAIL run: this workgroup computed slices [0, pe) of its tile; slices pe .. P-1 lie in the workspace, put there by the
-        workgroups after it in unit order (their HEAD runs, the first thing they do).  They are added in ascending slice order:
-        laser-order C = (..((beta C0 + a S_0) + a S_1) ..) exactly as the sequential loop does it (gemm.nim:150-158)."""
+    def recv_block(self, L_epi, L_send):
+        """RECEIVE: wait for flag vid - 1 (set by the previous workgroup after the first thing it did), take the sum from slot vid - 1,
+        clear the flag for the next launch; then: the run set-up (the sum arrived before the piece started: phase 5), or run B on top
+        of it (laser-order, more slices left), or the end of the tile (store C / send the sum on)."""
         c, p = self.c, self.p
         e, t, st, sc = p.emit, self.vt, self.s_t, self.s_sc
-        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
-        e("s_waitcnt", lgkmcnt=0)
-        P, hmax = sc[1], sc[6]
-        w, j, remw, slot, fv = st[0], st[1], st[2], st[3], st[4]
-
-        def len_w():      # units of workgroup w
-            self.unit_start(st[3], w, st[5])
-            e("s_add_u32", st[4], w, 1)
-            self.unit_start(remw, st[4], st[5])
-            e("s_sub_u32", remw, remw, st[3])
-        e("s_add_u32", w, self.s_vid, 1)
-        e("s_mov_b32", j, 0)
-        len_w()
-        e("v_lshlrev_b32", t[8], 2, v(0))
-        loop, spin, got, same = p.label("fix"), p.label("spin"), p.label("got"), p.label("samew")
-        p.place(loop)
-        if c.exact:
-            self.fold_all()
-        e("s_mul_i32", slot, w, hmax)
-        e("s_add_u32", slot, slot, j)
+        slot, fv = st[3], st[2]
+        spin, got, lost, after = p.label("spin"), p.label("got"), p.label("lost"), p.label("after")
+        e("s_sub_u32", slot, self.s_vid, 1)
         self.ws_descriptors(slot)
-        lost, cleared = p.label("lost"), p.label("cleared")
+        e("v_lshlrev_b32", t[8], 2, v(0))
         e("s_mov_b32", st[5], 0)
         p.place(spin)
         e("buffer_load_dword", t[9], OFF, self.srdA, 0, sc1=True)
@@ -1765,57 +1832,72 @@ class Gen:
         e("v_readfirstlane_b32", fv, t[9])
         e("s_cmp_lg_u32", fv, 0)
         e("s_cbranch_scc1", got)
-        # a legitimate wait is shorter than the launch (the partial is the first thing its producer computes); after ~2 s of polling
-        # the workgroup reports to the error word in front of the flags (launcher: option "asm_fixup_timeouts") and goes on -- a wrong
-        # result that is flagged, not a hung GPU
+        # a legitimate wait is short (the sum is the first thing its sender computes); after ~2 s of polling the workgroup reports
+        # to the error word in front of the flags (launcher: option "asm_fixup_timeouts") and goes on -- a wrong result that is
+        # flagged, not a hung GPU
         e("s_add_u32", st[5], st[5], 1)
         e("s_cmp_lt_u32", st[5], 1 << 21)
         e("s_cbranch_scc0", lost)
         e("s_sleep", 8)
         e("s_branch", spin)
+        p.place(lost)
+        e("s_load_dwordx2", self.s_sc.sub(0, 2), s(0, 2), KA_WS + 8)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_sub_u32", self.srdC[0], sc[0], 4)
+        e("s_subb_u32", self.srdC[1], sc[1], 0)
+        e("s_and_b32", self.srdC[1], self.srdC[1], 0xffff)
+        e("s_mov_b32", self.srdC[2], 4)
+        e("s_mov_b32", self.srdC[3], 0x00020000)
+        e("v_mov_b32", t[9], 1)
+        e("buffer_store_dword", t[9], t[8], self.srdC, 0, offen=True, sc1=True)
+        e("s_waitcnt", vmcnt=0)
         p.place(got)
-        e("buffer_inv", sc1=True)
-        self.load_partial(t[8])
+        self.load_received(t[8])
         e("s_barrier", comment="every wave has seen the flag: it can be cleared for the next launch")
         e("v_mov_b32", t[9], 0)
         e("buffer_store_dword", t[9], t[8], self.srdA, 0, offen=True, sc1=True)
         e("s_waitcnt", vmcnt=0)
-        e("s_add_u32", self.s_pe, self.s_pe, fv)
-        e("s_sub_u32", remw, remw, fv)
-        e("s_add_u32", j, j, 1)
-        e("s_cmp_lg_u32", remw, 0)
-        e("s_cbranch_scc1", same)
-        e("s_add_u32", w, w, 1)
-        e("s_mov_b32", j, 0)
-        len_w()
-        p.place(same)
-        e("s_cmp_lt_u32", self.s_pe, P)
-        e("s_cbranch_scc1", loop)
-        e("s_branch", L_back)
-        p.place(lost)
-        e("s_sub_u32", self.srdA[0], self.s_wsf[2], 4)
-        e("s_subb_u32", self.srdA[1], self.s_wsf[3], 0)
-        e("s_and_b32", self.srdA[1], self.srdA[1], 0xffff)
-        e("v_mov_b32", t[9], 1)
-        e("buffer_store_dword", t[9], t[8], self.srdA, 0, offen=True, sc1=True)
-        e("s_waitcnt", vmcnt=0)
-        e("s_branch", L_back)
+        if c.exact:
+            e("s_cmp_lg_u32", self.s_phase, 5)
+            e("s_cbranch_scc1", after)
+            e("s_mov_b32", self.s_phase, 4)
+            e("s_branch", self.L_setup)
+            p.place(after)
+            # after run A: slices p0 + 1 .. pz - 1 left?
+            last = p.label("lastslice")
+            e("s_add_u32", st[0], self.s_p0, 1)
+            e("s_cmp_ge_u32", st[0], self.s_pz)
+            e("s_cbranch_scc1", last)
+            self.fold_all()
+            e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_add_u32", st[0], self.s_p0, 1)
+            e("s_mul_i32", self.s_kb, st[0], sc[5])
+            e("s_mul_i32", st[0], self.s_pz, sc[5])
+            e("s_min_u32", st[0], st[0], self.s_K)
+            e("s_sub_u32", self.s_Keff, st[0], self.s_kb)
+            e("s_mov_b32", self.s_mode, MODE_CONT)
+            e("s_mov_b32", self.s_end, self.s_fin)
+            e("s_branch", self.L_setup)
+            p.place(last)
+        e("s_cmp_eq_u32", self.s_fin, END_EPI)
+        e("s_cbranch_scc1", L_epi)
+        e("s_branch", L_send)
 
     def mode_dispatch(self):
-        """persistent kernels, after the K loop: HEAD runs store their partial and go on; TAIL runs collect the other workgroups'
-        partials, then take the ordinary epilogue"""
+        """persistent kernels, after the K loop: store C (the ordinary epilogue), send the running sum on, or receive"""
         c, p = self.c, self.p
         if not c.persistent:
             return
         e = p.emit
-        L_head, L_tail, L_epi = p.label("head_store"), p.label("tail_fixup"), p.label("epi")
-        e("s_cmp_eq_u32", self.s_mode, MODE_HEAD)
-        e("s_cbranch_scc1", L_head)
-        e("s_cmp_eq_u32", self.s_mode, MODE_TAIL)
-        e("s_cbranch_scc1", L_tail)
+        L_send, L_epi = p.label("send"), p.label("epi")
+        e("s_cmp_eq_u32", self.s_end, END_SEND)
+        e("s_cbranch_scc1", L_send)
+        e("s_cmp_eq_u32", self.s_end, END_RECV)
+        e("s_cbranch_scc1", self.L_recv)
         p.place(L_epi)
-        self.outlined_blocks.append((L_head, self.head_store))
-        self.outlined_blocks.append((L_tail, lambda: self.tail_fixup(L_epi)))
+        self.outlined_blocks.append((L_send, self.send_block))
+        self.outlined_blocks.append((self.L_recv, lambda: self.recv_block(L_epi, L_send)))
 
     def build(self):
         self.outlined = []

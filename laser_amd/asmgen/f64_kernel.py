@@ -15,7 +15,7 @@ ds_read_b128 -- and is 144 bytes long: with 9 chunks per row the 16 rows a 16-la
 Operands: A row-major (k-contiguous), B row-major (x-contiguous) or passed transposed (`_nt`: k-contiguous, stored like A), C
 row-major; K a multiple of 2; any alpha / beta (float64 in the kernel arguments)."""
 from .core import v, a, s, VCC
-from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_CONV1, MODE_HEAD  # noqa: F401
+from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_CONV1  # noqa: F401
 
 CONFIGS = {
     # one wave per SIMD: 2 x 2 waves of 64x64 = 16 blocks = 128 accumulator registers (+ 128 for the running sum)
@@ -308,13 +308,7 @@ class Gen64(Gen):
         self.issue_loads_all()
         self.advance_srds()
         self.tail_mask_if(self.s_rem, 3)
-        for b in range(c.NB):
-            for r in range(8):
-                e("v_accvgpr_write_b32", self.acc[b][r], 0)
-                if c.exact:
-                    e("v_accvgpr_write_b32", self.run[b][r], 0)
-        if c.exact:
-            self.load_beta_c()
+        self.init_accumulators()
         self.lg_wait(None)
         e("s_barrier")
         self.read_group(0, 0, 0)
@@ -482,9 +476,6 @@ class Gen64(Gen):
         skip = p.label("nobeta")
         e("s_cmp_eq_u32", self.s_b0, 0)
         e("s_cbranch_scc1", skip)
-        if c.persistent:       # (a head run's slice sums go to the workspace raw)
-            e("s_cmp_eq_u32", self.s_mode, MODE_HEAD)
-            e("s_cbranch_scc1", skip)
         self.c_addr_setup()
         pool = [r.sub(2 * h, 2) for slot in range(2) for r in (self.fa[slot] + self.fb[slot]) for h in range(2)]
         assert len(pool) >= c.TN

@@ -357,6 +357,8 @@ class Workgroup:
                 x, y = to_i32(x), to_i32(y)
             rel = op.split("_")[2]
             w.scc = int({"eq": x == y, "lg": x != y, "lt": x < y, "le": x <= y, "gt": x > y, "ge": x >= y}[rel])
+        elif op == "s_bitcmp1_b32":
+            w.scc = (rs(w, A[0]) >> (rs(w, A[1]) & 31)) & 1
         elif op == "s_cselect_b32":
             sw(A[0], rs(w, A[1]) if w.scc else rs(w, A[2]))
         elif op in ("s_cbranch_scc0", "s_cbranch_scc1", "s_branch"):

@@ -32,6 +32,7 @@ std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model
 std::atomic<int> g_asm_kernel{-1};    // option "asm_kernel": force an index of kKernels (tuning sweeps); -1 = the model decides
 std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persistent launch (0 = every slot of the chip)
 std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
+std::atomic<int> g_asm_noseed{0};     // option "asm_noseed": 1 = a piece never takes its received sum early (tests: forces the two-run receive path)
 std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
 
 namespace {
@@ -99,7 +100,7 @@ constexpr size_t kWsMaxStreams = 64;
 // (XCD-aware chunking of the workgroup ids + grouped raster: the ic / jr partition of gemm.nim:160-176), no table
 struct SchedArgs {
   uint32_t tiles_m, tiles_n, group_m, gsz_last, mg_width, mg_gm, mg_last, xcd_q;
-  uint32_t xcd_r, P, mg_P, units_q, units_r, slice_len, hmax, mg_G;
+  uint32_t xcd_r, P, mg_P, units_q, units_r, slice_len, flags_bits, mg_G;
   uint64_t ws, flags;
 };
 static_assert(sizeof(SchedArgs) == 80, "f32_kernel.py KA_SCHED");
@@ -127,7 +128,7 @@ inline uint32_t magic_u32(uint64_t d) { return d <= 1 ? 0u : (uint32_t)(((uint64
 
 // Tile map + unit arithmetic of a launch of G workgroups over tiles_m x tiles_n tiles, each cut into P slices of slice_len
 // elements of K (P == 1: no cut).  false: a quotient of the in-kernel arithmetic would leave the range of its magic number.
-bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, int64_t G, int64_t P, int64_t slice_len, int64_t hmax,
+bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, int64_t G, int64_t P, int64_t slice_len,
                 const StreamWs *w, bool xcd) {
   const int64_t T = tiles_m * tiles_n, U = T * P;
   if (group_m <= 0 || group_m > tiles_m) group_m = (int)tiles_m;   // one group: tile rows fastest (the convolution's order)
@@ -139,7 +140,7 @@ bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, in
   sc.mg_width = magic_u32((uint64_t)width); sc.mg_gm = magic_u32((uint64_t)group_m); sc.mg_last = magic_u32((uint64_t)gsz_last);
   sc.xcd_q = xcd && G >= 8 ? (uint32_t)(G / 8) : 0; sc.xcd_r = xcd && G >= 8 ? (uint32_t)(G % 8) : 0;
   sc.P = (uint32_t)P; sc.mg_P = magic_u32((uint64_t)P); sc.units_q = (uint32_t)q; sc.units_r = (uint32_t)r;
-  sc.slice_len = (uint32_t)slice_len; sc.hmax = (uint32_t)hmax; sc.mg_G = magic_u32((uint64_t)G);
+  sc.slice_len = (uint32_t)slice_len; sc.flags_bits = g_asm_noseed ? 1u : 0u; sc.mg_G = magic_u32((uint64_t)G);
   sc.ws = w ? (uint64_t)(uintptr_t)w->ws : 0; sc.flags = w ? (uint64_t)(uintptr_t)(w->flags + 1) : 0;   // (flags[0] = the error word)
   return true;
 }
@@ -202,11 +203,12 @@ hipError_t get_ws(DeviceModule *m, hipStream_t s, size_t ws_bytes, size_t nflags
 //   plain:      one tile per workgroup, the hardware hands tiles to CUs as they free up: ceil(T / slots) rounds.
 //   persistent: G = every slot of the chip (or fewer), each workgroup walks an equal share of the T * P units (unit = one K slice of
 //               one tile; laser-order: slice = kc, the unit Laser's own pc loop restarts its chain at, gemm.nim:150-158; one chain: a
-//               slice length chosen here); a tile that straddles two workgroups is finished by the owner of its slice 0 (in-kernel
-//               ordered fix-up: laser-order results are the SAME bits as the sequential loop's).
+//               slice length chosen here).  A tile that straddles two workgroups is started by the owner of its slice 0, which sends
+//               the running sum on through the workspace (one tile-sized hand-over per cut, whatever P); the next workgroup
+//               continues it, in order: laser-order results are the SAME bits as the sequential loop's (asmgen/f32_kernel.py sched_next).
 struct Plan {
   bool persistent = false;
-  int64_t G = 0, P = 1, slice_len = 0, hmax = 1;
+  int64_t G = 0, P = 1, slice_len = 0;
   double time_us = 1e300;
 };
 
@@ -243,19 +245,21 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     // launch keeps them on neighbouring tiles
     if ((double)U / (double)G / (double)P > 4.0 && g_asm_plan != 2) continue;
     const int64_t q = U / G, r = U % G;
+    // ranges shorter than a tile minus one slice: a workgroup would wait for the sum of a predecessor that is still computing it
+    // (hand-over chains); such problems are few-tile x long-K: the slice-parallel form / the plain launch serve them
+    if (q < P - 1 && g_asm_plan != 2) continue;
     // the busiest CU: its workgroups' units back to back (the r longer ranges are spread evenly over the workgroup ids)
     const int64_t wg_per_cu = (G + kCUs - 1) / kCUs;
     const double units_cu = (double)(q * wg_per_cu) + (r ? std::min((double)wg_per_cu, std::ceil((double)r / kCUs)) : 0.0);
     const double unit_us = tile_us * (double)std::min(len, K) / (double)K;
     const double eff = G >= (int64_t)kCUs * ki.occ ? ki.eff : ki.eff_alone + (ki.eff - ki.eff_alone) * std::min(1.0, (double)(wg_per_cu - 1) / std::max(1, ki.occ - 1));
     // every run restarts the pipeline (first loads, epilogue: hidden behind the CU's other workgroups when there are any); a cut
-    // tile costs a partial store + load and the flag round trip; laser-order head slices are one run each
-    const double runs = (double)(q / P) + (cut ? (exact ? 0.5 * (double)(P - 1) + 1.0 : 2.0) : 0.0);
+    // tile costs two more runs (its two parts), a tile-sized store + load and the flag round trip
+    const double runs = (double)(q / P) + (cut ? 2.0 : 0.0);
     const double t_us = units_cu * unit_us / eff + ki.fixed_us + 2.0 * runs / ki.occ + (cut ? 3.0 : 0.0);
     if (t_us < 0.97 * best.time_us || (g_asm_plan == 2 && (!best.persistent || t_us < best.time_us))) {
       best.persistent = true;
       best.G = G; best.P = P; best.slice_len = len;
-      best.hmax = exact ? std::max<int64_t>(1, std::min(P - 1, q + (r ? 1 : 0))) : 1;
       best.time_us = t_us;
     }
   }
@@ -270,11 +274,11 @@ hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernAr
   const int64_t U = (int64_t)tiles_m * tiles_n * plan.P;
   const bool cuts = plan.persistent && (U % plan.G != 0 || (U / plan.G) % plan.P != 0);
   if (cuts) {
-    const hipError_t e = get_ws(m, s, (size_t)plan.G * plan.hmax * tile_bytes, (size_t)plan.G * plan.hmax + 1, &w);
+    const hipError_t e = get_ws(m, s, (size_t)plan.G * tile_bytes, (size_t)plan.G + 1, &w);   // one slot per sender; flags[0] = the error word
     if (e == hipErrorNotSupported) return e;
     if (e != hipSuccess) return e;
   }
-  if (!fill_sched(ka.sch, tiles_m, tiles_n, group_m, plan.G, plan.P, plan.slice_len, plan.hmax, cuts ? &w : nullptr, group_m > 0)) return hipErrorNotSupported;
+  if (!fill_sched(ka.sch, tiles_m, tiles_n, group_m, plan.G, plan.P, plan.slice_len, cuts ? &w : nullptr, group_m > 0)) return hipErrorNotSupported;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   const hipError_t e = hipModuleLaunchKernel(m->fn[kern], (unsigned)plan.G, (unsigned)batch, 1, 256, 1, 1, 0, s, nullptr, extra);
@@ -294,8 +298,8 @@ void zero_conv_fields(KernArgs &ka) {
 
 }  // namespace
 
-// diagnostics (option "asm_fixup_timeouts", synchronises the device): fix-ups on the current device that gave up waiting for a partial
-// (asmgen/f32_kernel.py tail_fixup) -- never in a correct run
+// diagnostics (option "asm_fixup_timeouts", synchronises the device): workgroups on the current device that gave up waiting for a
+// running sum (asmgen/f32_kernel.py recv_block) -- never in a correct run
 int64_t asm_fixup_timeouts() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -1;
@@ -384,7 +388,8 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
     // below ~5/8 of a round of the larger tiles (3/8 of the 64x64 ones) the compiler-scheduled kernels' slice-parallel and
     // small-problem forms do better
     if (g_f32_asm < 2 && t * a.batch < (k == tiny ? 96 : 160)) continue;
-    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 512, cu_flops_per_us, true);
+    // (laser-order with K <= kc is ONE chain that must stay one chain: cuts only at kc boundaries, or anywhere in one-chain mode)
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 512, cu_flops_per_us, exact || !laser_order);
     if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;   // (near ties go to the larger tile: less L2 traffic)
   }
   if (pick < 0) return hipErrorNotSupported;
@@ -540,7 +545,7 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
     const int64_t tm = (a.M + ki_.bm - 1) / ki_.bm, tn = (a.N + ki_.bn - 1) / ki_.bn, t = tm * tn;   // (batches are grid y)
     if ((double)t * 8.0 * (double)tn >= 4.0e9) continue;
     if (g_f64_asm < 2 && t * a.batch < (k == tiny ? 96 : 160)) continue;
-    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 256, cu_flops_per_us, true);
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 256, cu_flops_per_us, exact || !laser_order);
     if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;
   }
   if (pick < 0) return hipErrorNotSupported;

@@ -68,10 +68,12 @@ def test_gemm_kernels_bit_exact_in_the_interpreter(name, M, N, Kd, kw):
 
 
 # Persistent launches (fewer workgroups than tiles) and tiles cut along K at slice boundaries (f32_kernel.py sched_next): G workgroups
-# share tiles x P units; a workgroup whose range starts inside a tile puts those slice sums into the workspace (HEAD runs), the
-# workgroup that owns the tile's slice 0 adds them in ascending order after its own (TAIL run).  Laser-order kernels must stay
-# BIT-identical to the sequential slice order (gemm.nim:150-158) for any G; one-chain kernels are checked on integer-valued
-# operands (their split changes the rounding order, not the sum).  xcd: the workgroup-id remap; group_m: grouped raster.
+# share tiles x P units.  A tile that straddles two workgroups is started by the one that owns its slice 0 -- first thing it does --
+# which SENDS the running sum (beta * C0 included) through the workspace; the next workgroup does the tile's remaining slices last,
+# on top of the RECEIVED sum: taken at the start of the piece if it has arrived (one run), else after the piece's first slice (two
+# runs: noseed=1 forces that path).  Laser-order kernels must stay BIT-identical to the sequential slice order (gemm.nim:150-158)
+# for any G; one-chain kernels are checked on integer-valued operands (their cut changes the rounding order, not the sum).
+# xcd: the workgroup-id remap; group_m: grouped raster.
 SPLIT_CASES = [
     ("exact_64x64x32", 70, 40, 1100, dict(G=4, split=True, alpha=-2.0, beta=1.0)),
     ("exact_64x64x32", 70, 90, 1100, dict(G=5, split=True)),
@@ -81,6 +83,13 @@ SPLIT_CASES = [
     ("exact_64x64x32", 130, 70, 1540, dict(G=16, split=True, bias="row", act=1, xcd=True, group_m=2)),   # fused epilogue after the fix-up
     ("exact_128x128x16_nt", 140, 130, 1031, dict(G=9, split=True, lda=1034, ldb=1036)),
     ("exact_256x128x32", 300, 140, 1060, dict(G=5, split=True, alpha=0.75, beta=-1.5, ldc=150, group_m=1)),
+    ("exact_64x64x32", 70, 40, 1100, dict(G=4, split=True, alpha=-2.0, beta=1.0, noseed=1)),
+    ("exact_64x64x32", 70, 90, 1100, dict(G=2, split=True, noseed=1)),
+    ("exact_64x64x32", 70, 40, 2100, dict(G=9, split=True, noseed=1, beta=0.5)),              # ranges inside one tile: receive, then send on
+    ("exact_64x64x32", 70, 40, 2100, dict(G=9, split=True)),
+    ("exact_64x64x32_nt", 130, 70, 1030, dict(G=11, split=True, lda=1033, ldb=1036, ldc=75, alpha=0.75, beta=-1.5, group_m=2, xcd=True, noseed=1)),
+    ("exact_128x128x16", 140, 130, 1100, dict(G=7, split=True, noseed=1, bias="col", act=1)),
+    ("fast_64x64x32", 70, 40, 600, dict(G=9, split=2, integer=True, beta=2.0)),                # one chain, ranges inside one tile
     ("fast_64x64x32", 70, 90, 300, dict(G=5, split=2, alpha=0.5, beta=2.0, integer=True)),
     ("fast_64x64x32_nt", 70, 90, 301, dict(G=7, split=3, integer=True, lda=304, ldb=305, ldc=93)),
     ("fast_128x128x16", 140, 130, 200, dict(G=6, split=3, integer=True, beta=2.0, alpha=3.0)),
@@ -88,7 +97,7 @@ SPLIT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("name,M,N,Kd,kw", SPLIT_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-G{c[4]['G']}" for c in SPLIT_CASES])
+@pytest.mark.parametrize("name,M,N,Kd,kw", SPLIT_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-G{c[4]['G']}{'-late' if c[4].get('noseed') else ''}" for c in SPLIT_CASES])
 def test_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, kw):
     assert C.run_case(name, M, N, Kd, verbose=False, **kw)
 
@@ -99,14 +108,14 @@ def test_one_chain_split_matches_within_rounding():
     assert C.run_case("fast_64x64x32", 70, 90, 300, G=5, split=2, verbose=False, tol=1e-5)
 
 
-def test_interpreter_reports_a_tail_run_that_precedes_its_head_runs():
-    """the interpreter runs workgroups one after the other: a TAIL run simulated BEFORE the workgroup that produces its partials must
-    be reported (spin on a flag nobody has set), not hang -- this is also what a lost release would look like"""
+def test_interpreter_reports_a_receive_that_precedes_its_send():
+    """the interpreter runs workgroups one after the other: a workgroup simulated BEFORE the one that sends it its running sum must be
+    reported (spin on a flag nobody has set), not hang -- this is also what a lost flag store would look like"""
     from laser_amd.asmgen import check
     from laser_amd.asmgen.sim import SimError
     real = check.virtual_id
     try:
-        check.virtual_id = lambda g, G, xcd: -g          # ascending order: consumers first
+        check.virtual_id = lambda g, G, xcd: -g          # descending order: receivers first
         with pytest.raises(SimError):
             check.run_case("exact_64x64x32", 70, 40, 1100, G=4, split=True, verbose=False)
     finally:
@@ -118,10 +127,12 @@ F64_SPLIT_CASES = [
     ("fast_64x64x16_nt", 70, 80, 150, dict(G=6, split=2, alpha=2.0, beta=0.5)),
     ("fast_128x128x16", 130, 70, 86, dict(G=3, split=2)),
     ("exact_128x128x16", 130, 140, 520, dict(G=5, split=True, alpha=-1.0, beta=2.0)),
+    ("exact_64x64x16", 70, 80, 530, dict(lda=532, G=7, split=True, alpha=2.0, beta=0.5, noseed=1)),
+    ("exact_64x64x16_nt", 70, 40, 1040, dict(G=9, split=True, noseed=1, beta=-1.0)),
 ]
 
 
-@pytest.mark.parametrize("name,M,N,Kd,kw", F64_SPLIT_CASES, ids=[f"f64-{c[0]}-{c[1]}x{c[2]}x{c[3]}-G{c[4]['G']}" for c in F64_SPLIT_CASES])
+@pytest.mark.parametrize("name,M,N,Kd,kw", F64_SPLIT_CASES, ids=[f"f64-{c[0]}-{c[1]}x{c[2]}x{c[3]}-G{c[4]['G']}{'-late' if c[4].get('noseed') else ''}" for c in F64_SPLIT_CASES])
 def test_f64_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, kw):
     assert C.run_case64(name, M, N, Kd, verbose=False, **kw)
 

@@ -699,6 +699,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 # (one-chain mode: the slice-parallel form sums kc slices -- a different, equally valid rounding -- so the
                 # comparison of the two kernel families keeps it out of the way)
                 la.set_option("slice_parallel", 0 if mode == 1 else 1)
+                la.set_option("asm_plan", 1 if mode == 1 else 0)    # (likewise the assembly launcher's K cuts in one-chain mode)
                 la.set_f32_asm(2)
                 dC = wide.clone()
                 la.matmul(dA, dB, 1, 0, dC[:, :N])
@@ -708,7 +709,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 la.matmul(dA, dB, 1, 0, dC2[:, :N])
                 assert la.last_f32_asm() == 0
             finally:
-                la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1)
+                la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1); la.set_option("asm_plan", 0)
             # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128; 13..16: 64x64 tiles)
             want = (1, 3, 5, 7, 13, 15) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10, 14, 16)
             seen.add(used)

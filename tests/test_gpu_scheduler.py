@@ -1,7 +1,7 @@
 """GPU tests of the assembly kernels' launch plans (laser_amd/csrc/gemm_f32_asm.cpp plan_launch, asmgen/f32_kernel.py sched_next):
 the workgroup -> tile map is arithmetic in the kernel (no table, no lock, nothing to upload), launches may be persistent (fewer
-workgroups than tiles) and may cut tiles at K-slice boundaries, the owner of a tile's slice 0 adding the other workgroups' slice sums
-in ascending order.  Laser-order results must be the SAME bits whatever the plan (gemm.nim:150-158: slices are independent chains,
+workgroups than tiles) and may cut tiles at K-slice boundaries, the owner of a tile's slice 0 handing its running sum on to the
+workgroup that owns the rest.  Laser-order results must be the SAME bits whatever the plan (gemm.nim:150-158: slices are independent chains,
 their sums are added in order) and equal to the oracle; one-chain results stay within 1e-5 mean relative error
 (gemm_bench_float32.nim:365-367).  Also: concurrent launches from several host threads and streams, and a launch captured into a
 HIP graph and replayed."""
@@ -21,7 +21,9 @@ def la():
     laser_amd.lib()
     laser_amd.set_float_mode(0)
     laser_amd.set_f32_config(-1)
+    laser_amd.set_option("slice_parallel", 0)      # (few-tile x long-K problems: keep them on the tiled launcher under test)
     yield laser_amd
+    laser_amd.set_option("slice_parallel", 1)
     for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("asm_slice", 0), ("f32_asm", 1), ("f64_asm", 1)):
         laser_amd.set_option(k, v)
     laser_amd.set_float_mode(0)
@@ -56,19 +58,21 @@ def test_laser_order_bit_identical_for_every_plan_and_workgroup_count(la, oracle
             C0 = torch.from_numpy(_rnd(rng, (M, N))).cuda()
             want = oracle.matmul(A.cpu().numpy(), Bh, 0.5, -0.25, C0.cpu().numpy())
             la.set_option("asm_kernel", kern)
-            for plan, wgs in ((1, 0), (2, 0), (2, 7), (2, 15), (2, 16), (2, 100), (2, 256), (2, 333)):
+            for plan, wgs, late in ((1, 0, 0), (2, 0, 0), (2, 7, 0), (2, 7, 1), (2, 15, 1), (2, 16, 0), (2, 100, 0), (2, 100, 1), (2, 256, 0), (2, 333, 1)):
                 la.set_option("asm_plan", plan)
                 la.set_option("asm_wgs", wgs)
+                la.set_option("asm_noseed", late)        # 1: a piece never takes its received sum early (the two-run receive path)
                 C = C0.clone()
                 la.matmul(A, B, 0.5, -0.25, C)
                 assert la.last_f32_asm() == kern + 1, (kern, plan, wgs, la.last_f32_asm())
                 if plan == 2:
                     assert la.get_option("last_asm_slices") == 5, (kern, la.get_option("last_asm_slices"))
                     if wgs:
-                        assert la.get_option("last_asm_wgs") == wgs
+                        units = 5 * ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+                        assert la.get_option("last_asm_wgs") == min(wgs, units)
                 assert np.array_equal(C.cpu().numpy(), want), (kern, plan, wgs)
     finally:
-        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f32_asm", 1)):
+        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f32_asm", 1), ("asm_noseed", 0)):
             la.set_option(k, v)
 
 
@@ -118,15 +122,16 @@ def test_f64_plans_bit_identical(la, oracle):
             C0 = torch.from_numpy(_rnd(rng, (M, N), np.float64)).cuda()
             want = oracle.matmul(Ah, Bh, -1.5, 0.5, C0.cpu().numpy())
             la.set_option("asm_kernel", kern)
-            for plan, wgs in ((1, 0), (2, 0), (2, 9), (2, 64), (2, 256)):
+            for plan, wgs, late in ((1, 0, 0), (2, 0, 0), (2, 9, 1), (2, 64, 0), (2, 64, 1), (2, 256, 0)):
                 la.set_option("asm_plan", plan)
                 la.set_option("asm_wgs", wgs)
+                la.set_option("asm_noseed", late)
                 C = C0.clone()
                 la.matmul(A, B, -1.5, 0.5, C)
                 assert la.get_option("last_f64_asm") == kern + 1, (kern, plan, wgs, la.get_option("last_f64_asm"))
                 assert np.array_equal(C.cpu().numpy(), want), (kern, plan, wgs)
     finally:
-        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f64_asm", 1)):
+        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f64_asm", 1), ("asm_noseed", 0)):
             la.set_option(k, v)
 
 
