@@ -42,12 +42,17 @@ def plan_units(tiles, Kd, G, exact, kc, BK, split=True):
     return P, slen, U // G, U % G
 
 
-def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, noseed=0, ws=0, flags=0, group_m=None, xcd=False):
-    """the scheduler block of the kernel arguments (f32_kernel.py KA_SCHED); group_m None = one group: tile rows fastest"""
+def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, noseed=0, ws=0, flags=0, group_m=None, xcd=False, two_level=False):
+    """the scheduler block of the kernel arguments (f32_kernel.py KA_SCHED); group_m None = one group: tile rows fastest;
+    two_level: XCD x owns whole tiles, its G / 8 workgroups share them (launches that cut tiles)"""
     gm = group_m or tm
     gsz_last = tm % gm or gm
     if q is None:
         q, r = tm * tn * P // G, tm * tn * P % G
+    if two_level:
+        assert G % 8 == 0
+        return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), G // 8,
+                           0, P, K.magic_u32(P), tm * tn, 0, slen, noseed | 2, K.magic_u32(G // 8), ws, flags)
     return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), (G // 8) if xcd else 0,
                        (G % 8) if xcd else 0, P, K.magic_u32(P), q, r, slen, noseed, K.magic_u32(G), ws, flags)
 
@@ -69,7 +74,7 @@ def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
 
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
-             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0):
+             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart.
     G: workgroups of the (persistent) launch, default one per tile; split: cut tiles along K at slice boundaries (laser-order: kc;
     one chain: `split` K-tiles per slice) so that the G workgroups get equal numbers of units"""
@@ -127,11 +132,11 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
     ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, 0)
-    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd)
+    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
-    stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd)
+    stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd or two_level)
     if np.any(mem.get(fl_, np.uint32, (G,))):
         raise AssertionError("a workspace flag was left set: the next launch would take a stale sum")
     got = mem.get(c_, np.float32, (batch * LC,))
@@ -222,7 +227,7 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
 
 
 def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True, alpha=1.0, beta=0.0, batch=1,
-               G=None, split=False, group_m=None, xcd=False, noseed=0):
+               G=None, split=False, group_m=None, xcd=False, noseed=0, two_level=False):
     """float64 kernels (f64_kernel.py) through the interpreter.  Operands are small integers (alpha, beta dyadic), for which every
     product and partial sum is exact in float64 (the interpreter's f64 MFMA is mul + add, not an exact fma): this checks every
     address, layout, wait and hazard of the program; the accumulation ORDER with rounding is checked on hardware against the
@@ -268,11 +273,11 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     bs = (LA * 8, LB * 8, LC * 8) if batch > 1 else (0, 0, 0)
     ka = (struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta)
           + struct.pack("<Q", bs[0]) + b"\0" * 16 + struct.pack("<QQ", bs[1], bs[2]) + b"\0" * 24)
-    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd)
+    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
-    stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd)
+    stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd or two_level)
     if np.any(mem.get(fl_, np.uint32, (G,))):
         raise AssertionError("a workspace flag was left set")
     got = mem.get(c_, np.float64, (batch * LC,))

@@ -65,7 +65,9 @@ class Cfg:
         self.debug = debug          # dump intermediate state of workgroup 0 to the kernarg's debug buffer (asm_debug.py)
         self.lds_bytes = self.LDS0 + 3 * self.STAGE
         assert self.lds_bytes <= 160 * 1024
-        self.lds_alloc = self.lds_bytes + (16384 if filler else 0)
+        # persistent laser-order kernels: 16 bytes past the stage ring where the four waves agree on what they saw in a flag
+        self.VOTE = self.lds_bytes
+        self.lds_alloc = self.lds_bytes + (16384 if filler else 0) + (16 if (self.persistent and exact) else 0)
         assert self.lds_alloc <= 160 * 1024
 
 
@@ -114,7 +116,12 @@ KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's s
 #   +24 magic(rows of the last group)  +28 xcd_q (workgroups / 8; 0 = no XCD remap)
 #   +32 xcd_r (workgroups % 8)  +36 P (K slices per tile)  +40 magic(P)  +44 units_q  +48 units_r (units = workgroups * q + r:
 #       workgroup v starts at unit v * q + floor(v * r / workgroups) -- the r longer ranges are spread evenly over the ids)
-#   +52 slice length (elements of K)  +56 bit 0: never take a received sum early (tests: forces the two-run receive path)  +60 magic(workgroups)
+#   +52 slice length (elements of K)  +56 bit 0: never take a received sum early (tests: forces the two-run receive path);
+#       bit 1: two-level ranges (launches that cut tiles; workgroups a multiple of 8): XCD x = workgroup id % 8 owns the WHOLE tiles
+#       [T x / 8, T (x + 1) / 8) and its workgroups (local index l = id / 8) share those tiles' units evenly -- a tile is only ever
+#       cut between workgroups id and id + 8: the hardware starts the sender before the receiver, so a receiver never waits for a
+#       workgroup that is not running yet, whatever else shares the GPU.  Then +44 = T (tiles) and +60 = magic(workgroups / 8)
+#   +60 magic(workgroups)
 #   +64 workspace (u64)  +72 flags (u64)
 KA_SCHED = 152
 KA_SCHED2 = KA_SCHED + 32
@@ -360,22 +367,55 @@ class Gen:
         e("s_add_u32", dst, dst, tmp)
 
     def sched_init(self):
-        """[u0, u1) of this workgroup by its virtual id (XCD remap) -> (t0, p0), (t1, pe)"""
-        e, st, sc = self.p.emit, self.s_t, self.s_sc
+        """[u0, u1) of this workgroup -> (t0, p0), (t1, pe)"""
+        c, p = self.c, self.p
+        e, st, sc = p.emit, self.s_t, self.s_sc
+        L_two, L_have = p.label("twolevel"), p.label("haverange")
         e("s_load_dword", st[5], s(0, 2), KA_SCHED + 28)
         e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
         e("s_waitcnt", lgkmcnt=0)
         P, mg_P = sc[1], sc[2]
+        u0, u1 = st[2], st[3]
+        e("s_bitcmp1_b32", sc[6], 1)
+        e("s_cbranch_scc1", L_two)
+        # one level: virtual id (XCD remap) -> equal shares of all units
         self.xcd_remap(self.s_vid, s(2), st[5], sc[0], st[0])
-        self.unit_start(st[2], self.s_vid, st[0])
+        self.unit_start(u0, self.s_vid, st[0])
         e("s_add_u32", st[1], self.s_vid, 1)
-        self.unit_start(st[3], st[1], st[0])
-        self.udiv(self.s_t0, st[2], mg_P)
+        self.unit_start(u1, st[1], st[0])
+        e("s_branch", L_have)
+        # two levels: XCD x = id % 8 owns whole tiles; local index l = id / 8 shares that XCD's units (st[5] = workgroups / 8)
+        p.place(L_two)
+        Gq, T, mg = st[5], sc[3], sc[7]
+        e("s_and_b32", st[0], s(2), 7)                      # x
+        e("s_lshr_b32", st[1], s(2), 3)                     # l
+        e("s_mul_i32", self.s_vid, st[0], Gq)
+        e("s_add_u32", self.s_vid, self.s_vid, st[1])       # slot id: x * Gq + l
+        e("s_mul_i32", st[4], T, st[0])
+        e("s_lshr_b32", st[4], st[4], 3)                    # first tile of the XCD
+        e("s_add_u32", st[0], st[0], 1)
+        e("s_mul_i32", st[0], T, st[0])
+        e("s_lshr_b32", st[0], st[0], 3)
+        e("s_sub_u32", st[0], st[0], st[4])                 # its number of tiles
+        e("s_mul_i32", st[0], st[0], P)                     # Ux = its units
+        e("s_mul_i32", st[4], st[4], P)                     # its first unit
+        self.udiv(self.s_t0, st[0], mg)                     # qx = Ux / Gq            (s_t0, s_t1, s_pe: free until set below)
+        e("s_mul_i32", self.s_t1, self.s_t0, Gq)
+        e("s_sub_u32", self.s_t1, st[0], self.s_t1)         # rx
+        for dst, off in ((u0, 0), (u1, 1)):
+            e("s_add_u32", st[0], st[1], off)               # l (+ 1)
+            e("s_mul_i32", self.s_pe, st[0], self.s_t1)
+            self.udiv(dst, self.s_pe, mg)                   # floor(l * rx / Gq)
+            e("s_mul_i32", st[0], st[0], self.s_t0)
+            e("s_add_u32", dst, dst, st[0])
+            e("s_add_u32", dst, dst, st[4])
+        p.place(L_have)
+        self.udiv(self.s_t0, u0, mg_P)
         e("s_mul_i32", st[0], self.s_t0, P)
-        e("s_sub_u32", self.s_p0, st[2], st[0])
-        self.udiv(self.s_t1, st[3], mg_P)
+        e("s_sub_u32", self.s_p0, u0, st[0])
+        self.udiv(self.s_t1, u1, mg_P)
         e("s_mul_i32", st[0], self.s_t1, P)
-        e("s_sub_u32", self.s_pe, st[3], st[0])
+        e("s_sub_u32", self.s_pe, u1, st[0])
         e("s_cmp_lg_u32", self.s_p0, 0)
         e("s_cselect_b32", st[0], 1, 0)
         e("s_add_u32", self.s_tcur, self.s_t0, st[0])      # first whole tile
@@ -455,7 +495,22 @@ class Gen:
             self.ws_descriptors(st[3])
             e("buffer_load_dword", t[9], OFF, self.srdA, 0, sc1=True)
             e("s_waitcnt", vmcnt=0)
-            e("v_readfirstlane_b32", st[4], t[9])
+            # the four waves must take the same path (each has looked at the flag at its own time): every wave posts what it saw,
+            # the sum counts as arrived only if all four saw it
+            e("s_lshl_b32", st[4], self.s_wave, 2)
+            e("s_add_u32", st[4], st[4], c.VOTE)
+            e("v_mov_b32", t[8], st[4])
+            e("ds_write_b32", t[8], t[9])
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_barrier")
+            e("v_mov_b32", t[8], c.VOTE)
+            e("ds_read_b128", v(t[4].idx, 4), t[8])
+            e("s_waitcnt", lgkmcnt=0)
+            e("v_min_u32", t[4], t[4], t[5])
+            e("v_min_u32", t[6], t[6], t[7])
+            e("v_min_u32", t[4], t[4], t[6])
+            e("s_nop", 1)
+            e("v_readfirstlane_b32", st[4], t[4])
             e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
             e("s_waitcnt", lgkmcnt=0)
             e("s_cmp_eq_u32", st[4], 0)

@@ -127,20 +127,24 @@ static_assert(sizeof(KernArgs) == 232 && offsetof(KernArgs, sch) == 152, "kernel
 inline uint32_t magic_u32(uint64_t d) { return d <= 1 ? 0u : (uint32_t)(((uint64_t)1 << 32) / d + 1); }
 
 // Tile map + unit arithmetic of a launch of G workgroups over tiles_m x tiles_n tiles, each cut into P slices of slice_len
-// elements of K (P == 1: no cut).  false: a quotient of the in-kernel arithmetic would leave the range of its magic number.
+// elements of K (P == 1: no cut).  two_level (launches that cut tiles, G a multiple of 8): XCD x = workgroup id % 8 owns the whole
+// tiles [T x / 8, T (x + 1) / 8) and its G / 8 workgroups share them -- a cut tile's sender is always started before its receiver
+// (asmgen/f32_kernel.py KA_SCHED).  false: a quotient of the in-kernel arithmetic would leave the range of its magic number.
 bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, int64_t G, int64_t P, int64_t slice_len,
-                const StreamWs *w, bool xcd) {
+                const StreamWs *w, bool xcd, bool two_level) {
   const int64_t T = tiles_m * tiles_n, U = T * P;
   if (group_m <= 0 || group_m > tiles_m) group_m = (int)tiles_m;   // one group: tile rows fastest (the convolution's order)
   const int64_t width = (int64_t)group_m * tiles_n, gsz_last = tiles_m % group_m ? tiles_m % group_m : group_m;
   if ((double)T * (double)width >= 4.0e9 || (double)U * (double)P >= 4.0e9 || G < 1 || G > U) return false;
   const int64_t q = U / G, r = U % G;
-  if ((double)G * (double)r * (double)G >= 4.0e9 || tiles_m > 0x7fffffff || tiles_n > 0x7fffffff || U > 0x7fffffff) return false;
+  if ((double)G * (double)r * (double)G >= 4.0e9 || tiles_m > 0x7fffffff || tiles_n > 0x7fffffff || U > 0x7fffffff || T >= ((int64_t)1 << 28)) return false;
+  if (two_level && (G % 8 != 0 || T < 8 || (double)(U / 8 + P) * (double)(G / 8) >= 4.0e9)) return false;
   sc.tiles_m = (uint32_t)tiles_m; sc.tiles_n = (uint32_t)tiles_n; sc.group_m = (uint32_t)group_m; sc.gsz_last = (uint32_t)gsz_last;
   sc.mg_width = magic_u32((uint64_t)width); sc.mg_gm = magic_u32((uint64_t)group_m); sc.mg_last = magic_u32((uint64_t)gsz_last);
-  sc.xcd_q = xcd && G >= 8 ? (uint32_t)(G / 8) : 0; sc.xcd_r = xcd && G >= 8 ? (uint32_t)(G % 8) : 0;
-  sc.P = (uint32_t)P; sc.mg_P = magic_u32((uint64_t)P); sc.units_q = (uint32_t)q; sc.units_r = (uint32_t)r;
-  sc.slice_len = (uint32_t)slice_len; sc.flags_bits = g_asm_noseed ? 1u : 0u; sc.mg_G = magic_u32((uint64_t)G);
+  sc.xcd_q = (xcd || two_level) && G >= 8 ? (uint32_t)(G / 8) : 0; sc.xcd_r = (xcd || two_level) && G >= 8 ? (uint32_t)(G % 8) : 0;
+  sc.P = (uint32_t)P; sc.mg_P = magic_u32((uint64_t)P); sc.units_q = (uint32_t)(two_level ? T : q); sc.units_r = (uint32_t)(two_level ? 0 : r);
+  sc.slice_len = (uint32_t)slice_len; sc.flags_bits = (g_asm_noseed ? 1u : 0u) | (two_level ? 2u : 0u);
+  sc.mg_G = magic_u32((uint64_t)(two_level ? G / 8 : G));
   sc.ws = w ? (uint64_t)(uintptr_t)w->ws : 0; sc.flags = w ? (uint64_t)(uintptr_t)(w->flags + 1) : 0;   // (flags[0] = the error word)
   return true;
 }
@@ -238,8 +242,12 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     }
   }
   for (int i = 0; i < ncuts; i++) {
-    const int64_t len = cuts[i], P = (K + len - 1) / len, U = tiles * P, G = std::min(slots, U);
-    const bool cut = U % G != 0 || (U / G) % P != 0;      // some tile straddles two workgroups
+    const int64_t len = cuts[i], P = (K + len - 1) / len, U = tiles * P;
+    int64_t G = std::min(slots, U);
+    if (G >= 8) G -= G % 8;                               // (launches that cut tiles: 8 XCDs x G / 8 workgroups, fill_sched)
+    // some tile straddles two workgroups (an XCD's share of the tiles may be one more or less than T / 8: then its units do not
+    // divide evenly even where U / G does)
+    const bool cut = U % G != 0 || (U / G) % P != 0 || (G >= 8 && tiles % 8 != 0);
     if (!cut && G >= tiles && g_asm_plan != 2) continue;  // one whole tile per workgroup: that is the plain launch
     // many tiles per workgroup: the workgroups of an XCD drift apart in the tile order and lose their shared panels -- the plain
     // launch keeps them on neighbouring tiles
@@ -271,14 +279,17 @@ hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernAr
                           size_t tile_bytes, hipStream_t s) {
   Plan plan = plan_in;
   StreamWs w;
-  const int64_t U = (int64_t)tiles_m * tiles_n * plan.P;
-  const bool cuts = plan.persistent && (U % plan.G != 0 || (U / plan.G) % plan.P != 0);
+  const int64_t T = (int64_t)tiles_m * tiles_n, U = T * plan.P;
+  const bool cuts = plan.persistent && (U % plan.G != 0 || (U / plan.G) % plan.P != 0 || (plan.G >= 8 && T % 8 != 0));
+  const bool two_level = cuts && plan.G >= 8 && plan.G % 8 == 0 && T >= 8;
+  if (cuts && plan.G >= 8 && !two_level) return hipErrorNotSupported;
   if (cuts) {
     const hipError_t e = get_ws(m, s, (size_t)plan.G * tile_bytes, (size_t)plan.G + 1, &w);   // one slot per sender; flags[0] = the error word
     if (e == hipErrorNotSupported) return e;
     if (e != hipSuccess) return e;
   }
-  if (!fill_sched(ka.sch, tiles_m, tiles_n, group_m, plan.G, plan.P, plan.slice_len, cuts ? &w : nullptr, group_m > 0)) return hipErrorNotSupported;
+  if (!fill_sched(ka.sch, tiles_m, tiles_n, group_m, plan.G, plan.P, plan.slice_len, cuts ? &w : nullptr, group_m > 0 && (!cuts || two_level), two_level))
+    return hipErrorNotSupported;
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   const hipError_t e = hipModuleLaunchKernel(m->fn[kern], (unsigned)plan.G, (unsigned)batch, 1, 256, 1, 1, 0, s, nullptr, extra);

@@ -90,6 +90,11 @@ SPLIT_CASES = [
     ("exact_64x64x32_nt", 130, 70, 1030, dict(G=11, split=True, lda=1033, ldb=1036, ldc=75, alpha=0.75, beta=-1.5, group_m=2, xcd=True, noseed=1)),
     ("exact_128x128x16", 140, 130, 1100, dict(G=7, split=True, noseed=1, bias="col", act=1)),
     ("fast_64x64x32", 70, 40, 600, dict(G=9, split=2, integer=True, beta=2.0)),                # one chain, ranges inside one tile
+    # two-level ranges (what the launcher uses for every cut launch): XCD x = id % 8 owns whole tiles, its G / 8 workgroups share them
+    ("exact_64x64x32", 130, 200, 1100, dict(G=16, split=True, two_level=True, group_m=2, beta=0.5)),
+    ("exact_64x64x32", 130, 200, 1100, dict(G=16, split=True, two_level=True, group_m=2, beta=0.5, noseed=1)),
+    ("exact_64x64x32", 130, 70, 1100, dict(G=8, split=True, two_level=True, noseed=1)),
+    ("fast_64x64x32", 130, 200, 300, dict(G=24, split=2, integer=True, two_level=True)),
     ("fast_64x64x32", 70, 90, 300, dict(G=5, split=2, alpha=0.5, beta=2.0, integer=True)),
     ("fast_64x64x32_nt", 70, 90, 301, dict(G=7, split=3, integer=True, lda=304, ldb=305, ldc=93)),
     ("fast_128x128x16", 140, 130, 200, dict(G=6, split=3, integer=True, beta=2.0, alpha=3.0)),
@@ -97,7 +102,7 @@ SPLIT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("name,M,N,Kd,kw", SPLIT_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-G{c[4]['G']}{'-late' if c[4].get('noseed') else ''}" for c in SPLIT_CASES])
+@pytest.mark.parametrize("name,M,N,Kd,kw", SPLIT_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-G{c[4]['G']}{'-late' if c[4].get('noseed') else ''}{'-2lvl' if c[4].get('two_level') else ''}" for c in SPLIT_CASES])
 def test_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, kw):
     assert C.run_case(name, M, N, Kd, verbose=False, **kw)
 

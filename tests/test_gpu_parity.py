@@ -1350,12 +1350,13 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
                 la.set_float_mode(mode)
                 la.set_option(opt, asm)
                 la.set_option("slice_parallel", 0)      # (few-tile shapes would take the slice-parallel form before either kernel family)
+                la.set_option("asm_plan", 1 if mode == 1 else 0)   # (one-chain mode: a cut launch adds partial sums -- another valid rounding)
                 try:
                     buf, dC, _ = views(hC0.copy(), M, N, ldc, offc)
                     la.matmul(dA, dB, al, be, dC)
                     outs[asm] = (buf, la.get_option("last_" + opt))
                 finally:
-                    la.set_option(opt, 1); la.set_option("slice_parallel", 1); la.set_float_mode(0)
+                    la.set_option(opt, 1); la.set_option("slice_parallel", 1); la.set_float_mode(0); la.set_option("asm_plan", 0)
             assert outs[2][1] != 0 and outs[0][1] == 0, (kind, M, N, K, outs[2][1], outs[0][1])
             assert torch.equal(outs[2][0], outs[0][0]), (kind, M, N, K, mode, al, be)      # whole buffer: the view AND its surroundings
             got = outs[2][0].cpu().numpy()
@@ -1386,9 +1387,10 @@ def test_finalize_unloads_and_the_library_comes_back(la, oracle):
 
 
 def test_f32_asm_more_than_65535_tile_rows(la, oracle):
-    """A tall matrix with more 64-row tiles than the tile table's 16-bit coordinates hold (M = 4.2 M rows, one 64-column tile):
-    the launcher must leave the 64x64 kernels out of the choice.  Rows on both sides of the 65536 * 64 wrap point, the first
-    and the last rows against the oracle (a row of C depends on its row of A only)."""
+    """A tall matrix with more 64-row tiles than 16 bits count (M = 4.2 M rows, one 64-column tile): the tile coordinates are
+    32-bit arithmetic in the kernel (round 3's table packed them into 16 bits each and the launcher had to avoid the 64x64
+    kernels here).  Rows on both sides of the 65536 * 64 point, the first and the last rows against the oracle (a row of C
+    depends on its row of A only)."""
     import torch
     M, N, K = 4_200_000, 64, 8
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -1396,7 +1398,7 @@ def test_f32_asm_more_than_65535_tile_rows(la, oracle):
     B = torch.rand((K, N), generator=g, device="cuda") - 0.5
     C = torch.full((M, N), float("nan"), device="cuda")
     la.gemm_strided(M, N, K, 1.0, A, K, 1, B, N, 1, 0.0, C, N, 1)
-    assert la.last_f32_asm() in (3, 4, 7, 8), la.last_f32_asm()      # the 128x128 kernels: 32813 tile rows
+    assert la.last_f32_asm() != 0, la.last_f32_asm()                 # whichever tile the model takes: 65625 tile rows of 64 are fine now
     Bh = B.cpu().numpy()
     wrap = 65536 * 64
     for r0, r1 in ((0, 200), (wrap - 200, wrap + 200), (wrap + 5000, wrap + 5100), (M - 150, M)):
@@ -1597,12 +1599,12 @@ def test_fused_epilogue_on_the_assembly_kernels(la, oracle):
                     al, be = (0.75, -0.5) if mode == 0 else (0.75, 0.0)
                     outs = {}
                     for asm in (2, 0):
-                        la.set_float_mode(mode); la.set_f32_asm(asm); la.set_option("slice_parallel", 0)
+                        la.set_float_mode(mode); la.set_f32_asm(asm); la.set_option("slice_parallel", 0); la.set_option("asm_plan", 1 if mode == 1 else 0)
                         try:
                             outs[asm] = la.matmul(A, B, alpha=al, beta=be, out=C0.clone(), bias=bias, activation=act)
                             used = la.last_f32_asm()
                         finally:
-                            la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1)
+                            la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1); la.set_option("asm_plan", 0)
                         assert (used != 0) == (asm == 2), (M, N, K, mode, bname, act, used)
                     assert torch.equal(outs[2], outs[0]), (M, N, K, mode, bname, act)
                     if mode == 0:
