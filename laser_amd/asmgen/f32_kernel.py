@@ -419,7 +419,8 @@ class Gen:
         e("s_cmp_lg_u32", self.s_p0, 0)
         e("s_cselect_b32", st[0], 1, 0)
         e("s_add_u32", self.s_tcur, self.s_t0, st[0])      # first whole tile
-        e("s_mov_b32", self.s_phase, 0)
+        e("s_cmp_eq_u32", u0, u1)
+        e("s_cselect_b32", self.s_phase, 4, 0)             # (an empty range -- more workgroups than an XCD has units -- has nothing to do)
 
     def sched_next(self, L_exit, L_recv):
         """the next run of this workgroup (falls through with s_tile, s_kb, s_Keff, s_mode, s_end set; L_exit when there is none).

@@ -138,7 +138,7 @@ bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, in
   if ((double)T * (double)width >= 4.0e9 || (double)U * (double)P >= 4.0e9 || G < 1 || G > U) return false;
   const int64_t q = U / G, r = U % G;
   if ((double)G * (double)r * (double)G >= 4.0e9 || tiles_m > 0x7fffffff || tiles_n > 0x7fffffff || U > 0x7fffffff || T >= ((int64_t)1 << 28)) return false;
-  if (two_level && (G % 8 != 0 || T < 8 || (double)(U / 8 + P) * (double)(G / 8) >= 4.0e9)) return false;
+  if (two_level && (G % 8 != 0 || T < 8 || (T / 8) * P < G / 8 || (double)(U / 8 + P) * (double)(G / 8) >= 4.0e9)) return false;
   sc.tiles_m = (uint32_t)tiles_m; sc.tiles_n = (uint32_t)tiles_n; sc.group_m = (uint32_t)group_m; sc.gsz_last = (uint32_t)gsz_last;
   sc.mg_width = magic_u32((uint64_t)width); sc.mg_gm = magic_u32((uint64_t)group_m); sc.mg_last = magic_u32((uint64_t)gsz_last);
   sc.xcd_q = (xcd || two_level) && G >= 8 ? (uint32_t)(G / 8) : 0; sc.xcd_r = (xcd || two_level) && G >= 8 ? (uint32_t)(G % 8) : 0;
@@ -244,7 +244,10 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
   for (int i = 0; i < ncuts; i++) {
     const int64_t len = cuts[i], P = (K + len - 1) / len, U = tiles * P;
     int64_t G = std::min(slots, U);
-    if (G >= 8) G -= G % 8;                               // (launches that cut tiles: 8 XCDs x G / 8 workgroups, fill_sched)
+    if (G >= 8) {                                         // launches that cut tiles: 8 XCDs x G / 8 workgroups (fill_sched), and no
+      if (tiles < 8) continue;                            // more workgroups on an XCD than the XCD with the fewest tiles has units
+      G = 8 * std::min(G / 8, (tiles / 8) * P);
+    }
     // some tile straddles two workgroups (an XCD's share of the tiles may be one more or less than T / 8: then its units do not
     // divide evenly even where U / G does)
     const bool cut = U % G != 0 || (U / G) % P != 0 || (G >= 8 && tiles % 8 != 0);

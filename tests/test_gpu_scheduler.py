@@ -70,7 +70,9 @@ def test_laser_order_bit_identical_for_every_plan_and_workgroup_count(la, oracle
                     if wgs:
                         units = 5 * ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
                         want_wgs = min(wgs, units)
-                        assert la.get_option("last_asm_wgs") == (want_wgs - want_wgs % 8 if want_wgs >= 8 else want_wgs)   # (8 XCDs x G / 8)
+                        if want_wgs >= 8:      # 8 XCDs x G / 8 workgroups, no more per XCD than its units
+                            want_wgs = 8 * min(want_wgs // 8, (units // 5 // 8) * 5)
+                        assert la.get_option("last_asm_wgs") == want_wgs
                 assert np.array_equal(C.cpu().numpy(), want), (kern, plan, wgs)
     finally:
         for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f32_asm", 1), ("asm_noseed", 0)):
