@@ -194,7 +194,10 @@ hipError_t get_ws(DeviceModule *m, hipStream_t s, size_t ws_bytes, size_t nflags
     w.flags = nullptr; w.nflags = 0;
     const size_t want = std::max(nflags, (size_t)1 << 16);
     e = hipMalloc((void **)&w.flags, want * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(w.flags, 0, want * sizeof(uint32_t));
+    // cleared ON THE LAUNCH STREAM: a null-stream hipMemset may still be pending when it returns, and a non-blocking stream's
+    // kernel is not ordered behind it -- the clear would then wipe flags the running launch has set (seen: a receiver timing out
+    // on the first cut launch of a fresh stream, profiles/r04/README.md)
+    if (e == hipSuccess) e = hipMemsetAsync(w.flags, 0, want * sizeof(uint32_t), s);
     if (e == hipSuccess) w.nflags = want;
   }
   m->ws[s] = w;
@@ -256,19 +259,23 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     // launch keeps them on neighbouring tiles
     if ((double)U / (double)G / (double)P > 4.0 && g_asm_plan != 2) continue;
     const int64_t q = U / G, r = U % G;
-    // ranges shorter than a tile minus one slice: a workgroup would wait for the sum of a predecessor that is still computing it
-    // (hand-over chains); such problems are few-tile x long-K: the slice-parallel form / the plain launch serve them
-    if (q < P - 1 && g_asm_plan != 2) continue;
-    // the busiest CU: its workgroups' units back to back (the r longer ranges are spread evenly over the workgroup ids)
+    // ranges much shorter than a tile: a workgroup waits for the sum of a predecessor that is still computing it (hand-over
+    // chains); such problems are few-tile x long-K: the slice-parallel form / the plain launch serve them
+    if (q < P - 2 && g_asm_plan != 2) continue;
+    // the busiest CU: its workgroups' units back to back (the r longer ranges are spread evenly over the workgroup ids), at the
+    // average unit length (the last slice of a tile is shorter)
     const int64_t wg_per_cu = (G + kCUs - 1) / kCUs;
-    const double units_cu = (double)(q * wg_per_cu) + (r ? std::min((double)wg_per_cu, std::ceil((double)r / kCUs)) : 0.0);
-    const double unit_us = tile_us * (double)std::min(len, K) / (double)K;
-    const double eff = G >= (int64_t)kCUs * ki.occ ? ki.eff : ki.eff_alone + (ki.eff - ki.eff_alone) * std::min(1.0, (double)(wg_per_cu - 1) / std::max(1, ki.occ - 1));
-    // every run restarts the pipeline (first loads, epilogue: hidden behind the CU's other workgroups when there are any); a cut
-    // tile costs two more runs (its two parts), a tile-sized store + load and the flag round trip
-    const double runs = (double)(q / P) + (cut ? 2.0 : 0.0);
-    const double t_us = units_cu * unit_us / eff + ki.fixed_us + 2.0 * runs / ki.occ + (cut ? 3.0 : 0.0);
-    if (t_us < 0.97 * best.time_us || (g_asm_plan == 2 && (!best.persistent || t_us < best.time_us))) {
+    const double extras = r ? std::min((double)wg_per_cu, std::ceil((double)r * (double)wg_per_cu / (double)G)) : 0.0;
+    const double units_cu = (double)(q * wg_per_cu) + extras;
+    const double unit_us = tile_us / (double)P;
+    double eff = G >= (int64_t)kCUs * ki.occ ? ki.eff - (ki.occ >= 3 ? 0.02 : 0.0)
+                                             : ki.eff_alone + (ki.eff - ki.eff_alone) * std::min(1.0, (double)(wg_per_cu - 1) / std::max(1, ki.occ - 1));
+    // fitted to profiles/r04/plan_sweep_*_f.jsonl: a launch that cuts tiles pays ~8 us (the two extra runs of a cut tile, its
+    // hand-over through the workspace) whatever its length -- all workgroups pay it at the same time, so the CU's other workgroups
+    // do not hide it -- and ranges under 3/4 of a tile run into hand-over chains (+25 %)
+    double t_us = units_cu * unit_us / eff + ki.fixed_us + (cut ? 8.0 : 0.0);
+    if (cut && (double)U / (double)G / (double)P < 0.75) t_us *= 1.25;
+    if (t_us < 0.96 * best.time_us || (g_asm_plan == 2 && (!best.persistent || t_us < best.time_us))) {
       best.persistent = true;
       best.G = G; best.P = P; best.slice_len = len;
       best.time_us = t_us;
