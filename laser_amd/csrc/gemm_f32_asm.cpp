@@ -229,6 +229,7 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     best.time_us = (double)rounds * tile_us / (rounds == 1 ? ki.eff_alone : ki.eff) + ki.fixed_us;
   }
   if (g_asm_plan == 1 || !may_cut || batch != 1 || !g_split_tail) return best;
+  Plan pers;
   const int64_t slots = g_asm_wgs > 0 ? std::min<int64_t>(g_asm_wgs, 4096) : (int64_t)kCUs * ki.occ;
   const int64_t kt = (K + ki.bk - 1) / ki.bk;
   // candidate cuts: laser-order: the kc slices; one chain: 1..16 slices of equal numbers of K-tiles (or the forced length)
@@ -275,12 +276,13 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     // do not hide it -- and ranges under 3/4 of a tile run into hand-over chains (+25 %)
     double t_us = units_cu * unit_us / eff + ki.fixed_us + (cut ? 8.0 : 0.0);
     if (cut && (double)U / (double)G / (double)P < 0.75) t_us *= 1.25;
-    if (t_us < 0.96 * best.time_us || (g_asm_plan == 2 && (!best.persistent || t_us < best.time_us))) {
-      best.persistent = true;
-      best.G = G; best.P = P; best.slice_len = len;
-      best.time_us = t_us;
+    if (t_us < pers.time_us) {       // the best cut; it replaces the plain launch only with a margin (below)
+      pers.persistent = true;
+      pers.G = G; pers.P = P; pers.slice_len = len;
+      pers.time_us = t_us;
     }
   }
+  if (pers.persistent && (pers.time_us < 0.96 * best.time_us || g_asm_plan == 2)) return pers;
   return best;
 }
 
