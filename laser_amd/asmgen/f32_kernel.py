@@ -102,6 +102,12 @@ CONFIGS = {
     "conv3x3_fast_64x128x32": dict(BM=64, BN=128, BK=32, exact=False, conv=True),
     "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
+    # one round of 128x128 tiles (129 .. 256 of them: 1920^3, 2048^3): a workgroup has its CU to itself, and the 16-deep K-tile of
+    # the two-per-CU kernels (32 MFMAs between barriers) leaves its latencies uncovered; 32 deep = 64 MFMAs per barrier, 96 KiB of LDS
+    "exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True),
+    "fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False),
+    "exact_128x128x32_nt": dict(BM=128, BN=128, BK=32, exact=True, b_kcontig=True),
+    "fast_128x128x32_nt": dict(BM=128, BN=128, BK=32, exact=False, b_kcontig=True),
 }
 
 # kernel argument block (bytes)

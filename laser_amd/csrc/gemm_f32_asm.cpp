@@ -57,7 +57,9 @@ struct KernelInfo {
 // [21..24]: convolution with fewer output channels: 128x128x32 (laser-order / one chain), 64x128x32 (same)
 // [25..28]: float64 with B passed transposed: 128x128x16 (laser-order / one chain), 64x64x16 (same)
 // [29]: int64 via eight int8 limb planes (i8_kernel.py "i64_64x64x32")
-constexpr int kNumKernels = 30;
+// [30..33]: 128x128 tiles with a 32-deep K-tile, one workgroup per CU (laser-order / one chain, plain / B transposed): one round of
+// 129 .. 256 tiles, where a workgroup has its CU to itself
+constexpr int kNumKernels = 34;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0, 1},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0, 1},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0, 2},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0, 2},
@@ -74,7 +76,9 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},
     {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.92, 0.92, 8.0, 1},     {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.93, 0.93, 8.0, 1},
     {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0, 2},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0, 2},
-    {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0, 1}};
+    {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0, 1},
+    {"lh_f32_exact_128x128x32", 128, 128, 32, 0.92, 0.90, 7.0, 1},       {"lh_f32_fast_128x128x32", 128, 128, 32, 0.93, 0.91, 7.0, 1},
+    {"lh_f32_exact_128x128x32_nt", 128, 128, 32, 0.92, 0.90, 7.0, 1},    {"lh_f32_fast_128x128x32_nt", 128, 128, 32, 0.93, 0.91, 7.0, 1}};
 constexpr int kCUs = 256;
 
 // Workspace of the cut launches of ONE stream on one device: partial tiles + their flags (all flags are zero between launches: the
@@ -399,10 +403,11 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   Plan plan;
   const int mid = (!exact && a.K > 512) ? (nt ? 9 : 8) : -1;   // one chain over a long K: also the 256x128 tile
   const int tiny = 12 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0);
+  const int deep = 30 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0);    // 128x128 with the 32-deep K-tile: one workgroup per CU
   const double cu_flops_per_us = 157.3e6 / 256.0;
   // the one-chain kernels' fused epilogue has no C read: beta != 0 with a bias / activation only on the laser-order kernels
-  const auto lo_kernel = [](int k) { return k == 0 || k == 2 || k == 4 || k == 6 || k == 12 || k == 14; };
-  for (int k : {big, mid, small, tiny}) {
+  const auto lo_kernel = [](int k) { return k == 0 || k == 2 || k == 4 || k == 6 || k == 12 || k == 14 || k == 30 || k == 32; };
+  for (int k : {big, mid, small, deep, tiny}) {
     if (k < 0 || (g_asm_kernel >= 0 && k != g_asm_kernel)) continue;
     if (fused && !lo_kernel(k) && a.beta != 0.0f) continue;
     const KernelInfo &ki_ = kKernels[k];

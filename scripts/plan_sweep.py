@@ -29,8 +29,8 @@ PEAK = 78.6 if f64 else 157.3
 dt = torch.float64 if f64 else torch.float32
 fn = L.laser_hip_gemm_strided_f64_dev if f64 else L.laser_hip_gemm_strided_f32_dev
 ct = ctypes.c_double if f64 else ctypes.c_float
-CANDS = {0: ({16: "128x128", 18: "64x64"} if f64 else {0: "256x128", 2: "128x128", 12: "64x64"}),
-         1: ({17: "128x128", 19: "64x64"} if f64 else {1: "256x256", 8: "256x128", 3: "128x128", 13: "64x64"})}
+CANDS = {0: ({16: "128x128", 18: "64x64"} if f64 else {0: "256x128", 2: "128x128", 30: "128x128x32", 12: "64x64"}),
+         1: ({17: "128x128", 19: "64x64"} if f64 else {1: "256x256", 8: "256x128", 3: "128x128", 31: "128x128x32", 13: "64x64"})}
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 laser_amd.set_option("f64_asm" if f64 else "f32_asm", 2)
 
