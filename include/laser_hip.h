@@ -52,6 +52,11 @@ int laser_hip_init(int device);
 int laser_hip_finalize(void);
 const char *laser_hip_last_error(void);
 const char *laser_hip_version(void);
+/* Incremented whenever an exported prototype, an option name or an operation code changes incompatibly (round 3 changed the
+ * alpha / beta types of map_strided and collapsed the setters into laser_hip_set_option: 2; round 4 only added names: still 2).
+ * A caller built against another header should refuse to run. */
+#define LASER_HIP_ABI_VERSION 2
+int laser_hip_abi_version(void);
 int laser_hip_device_count(void);
 /* Name of the GPU architecture in use, e.g. "gfx950" (replaces the reference's cpuinfo ISA
  * dispatch, gemm.nim:228-247). */
@@ -65,15 +70,18 @@ int laser_hip_get_float_mode(void);
 int laser_hip_set_f32_config(int cfg);
 int laser_hip_f32_config_count(void);
 /* ---- options: one entry point for every tuning / A-B switch ------------------------------------------------------------
- * laser_hip_set_option(name, value); unknown names are LASER_HIP_E_INVALID.  Every switch leaves results bit-identical
- * (it selects between implementations of the same arithmetic); defaults in brackets.
- *   "f32_asm"          [1] float32 gemm_strided with unit column strides on A and C, B row-major or passed transposed, any
- *                          alpha / beta, any K -- and 3x3 / stride-1 convolutions with any zero padding: the
- *                          hand-scheduled assembly kernels (accumulators in AGPRs; laser_amd/asmgen/) when the problem has at
- *                          least ~100 tiles of 64x64; 0 = never (the compiler-scheduled kernels); 2 = whenever eligible,
- *                          whatever the tile count (tests)
- *   "f64_asm"          [1] float64 twin of "f32_asm" (row-major operands, alpha == 1, beta == 0, K even; laser_amd/asmgen/f64_kernel.py)
- *   "i32_asm"          [1] int32 limb GEMM with alpha == 1, beta == 0, K <= 8192: the hand-scheduled kernel (laser_amd/asmgen/i8_kernel.py)
+ * laser_hip_set_option(name, value); unknown names are LASER_HIP_E_INVALID.  In LASER_ORDER float mode (the default) every switch
+ * leaves results bit-identical (it selects between implementations of the same arithmetic); in FAST mode the switches that change how
+ * K is cut ("split_tail", "slice_parallel", "asm_plan" / "asm_slice" / "asm_wgs") change the rounding order of the sums, within the
+ * 1e-5 mean relative error of that mode.  Defaults in brackets.
+ *   "f32_asm"          [1] float32 gemm_strided with any element strides on A, B and C (MatrixView, gemm_utils.nim:36-60), any alpha /
+ *                          beta, any K -- and 3x3 / stride-1 convolutions with any zero padding: the hand-scheduled assembly
+ *                          kernels (accumulators in AGPRs; laser_amd/asmgen/) when the problem has at least ~100 tiles of 64x64;
+ *                          0 = never (the compiler-scheduled kernels); 2 = whenever eligible, whatever the tile count (tests)
+ *   "f64_asm"          [1] float64 twin of "f32_asm" (unit column strides on A and C, B row-major-like or passed transposed, any
+ *                          alpha / beta, K even; laser_amd/asmgen/f64_kernel.py)
+ *   "i32_asm"          [1] int32 / int64 limb GEMMs, any alpha / beta: the hand-scheduled kernels (laser_amd/asmgen/i8_kernel.py;
+ *                          K > 8192 in chunks)
  *   "f64_mfma" "i32_mfma" "i64_mfma"  [1] matrix-core kernels (f64 MFMA; int8-limb decomposition for the integers, the
  *                          reference's integer micro-kernels: gemm_ukernel_avx512.nim:40-74); 0 = the VALU kernels
  *   "conv_implicit"    [1] im2col fused into the GEMM's B loader; 0 = explicit im2col workspace + batched GEMM, the
@@ -85,15 +93,23 @@ int laser_hip_f32_config_count(void);
  *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only
  *   "zero_copy_poll"   [1] small host-pointer calls poll completion flags in mapped memory; 0 = synchronise the stream
  *   "skinny"           [1] M <= 8 or N <= 8: the streaming kernel        "small_path" [1] the one-wave-per-block kernel
- *   "split_tail"       [1] main + tail launches when the last round of tiles would be badly filled (also: whole rounds on top +
- *                      the slice-parallel form for the rows of the last round, with "slice_parallel")
+ *   "split_tail"       [1] launch plans that cut a problem: main + tail launches of the compiler-scheduled kernels, peeled rows /
+ *                          columns of ragged-by-a-few shapes, and the assembly kernels' persistent plan (below); 0 = one plain launch
  *   "slice_parallel"   [1] few tiles x long K: kc slices as one batched launch + ordered combine
  *   "slice_parallel_min" / "slice_parallel_tiles"  tuning overrides of that rule (0 = built-in)
+ *   "asm_plan"         [0] launch plan of the assembly GEMM kernels: 0 = the launcher's model decides; 1 = one tile per workgroup;
+ *                          2 = the persistent plan whenever legal: every workgroup slot of the chip gets an equal share of K-slice
+ *                          units (laser-order: kc slices), a tile that straddles two workgroups is handed over in-kernel, in slice
+ *                          order (gemm.nim:150-158) -- laser-order results are the same bits under every plan
+ *   "asm_kernel" [-1] / "asm_wgs" [0] / "asm_slice" [0] / "asm_noseed" [0]  tuning / test overrides of that plan: force an assembly
+ *                          kernel index, the number of workgroups, the K-tiles per slice of a one-chain cut, the two-run receive path
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
  *   "last_f32_asm" / "last_f64_asm" / "last_i32_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
- *   "last_split"       column where the last float GEMM / conv launch was cut (0 = one launch); negative: -(first row of the
- *                      K-sliced bottom part) of a problem cut along M into whole rounds + the rest */
+ *   "last_asm_wgs" / "last_asm_slices"  workgroups and K slices per tile of the last assembly launch (slices 1 = tiles never cut)
+ *   "asm_fixup_timeouts"  workgroups of cut launches on the current device that gave up waiting for a hand-over (0 in a correct
+ *                      run; reading it synchronises the device)
+ *   "last_split"       column where the last compiler-scheduled float GEMM / conv launch was cut into main + tail (0 = one launch) */
 int laser_hip_set_option(const char *name, int value);
 int laser_hip_get_option(const char *name, int64_t *value);
 const char *laser_hip_f32_config_name(int cfg);

@@ -5,6 +5,8 @@ There is NO fallback: if the shared library is missing or the GPU is not a gfx95
 import ctypes as C
 import os
 
+ABI_VERSION = 2   # include/laser_hip.h LASER_HIP_ABI_VERSION this mirror was written against
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblaser_hip.so")
 
@@ -37,6 +39,8 @@ def lib():
     L.laser_hip_init.argtypes = [ci]
     L.laser_hip_last_error.restype = C.c_char_p
     L.laser_hip_version.restype = C.c_char_p
+    if L.laser_hip_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"liblaser_hip.so has ABI {L.laser_hip_abi_version()}, this mirror was written against {ABI_VERSION} (rebuild: make -C laser_amd/csrc)")
     L.laser_hip_arch.restype = C.c_char_p
     L.laser_hip_set_float_mode.argtypes = [ci]
     L.laser_hip_set_f32_config.argtypes = [ci]
@@ -120,7 +124,7 @@ def ctype_of(sfx):
 
 # Every symbol include/laser_hip.h declares (tests check the .so exports each of them).
 def declared_symbols():
-    names = ["laser_hip_init", "laser_hip_finalize", "laser_hip_last_error", "laser_hip_version",
+    names = ["laser_hip_init", "laser_hip_finalize", "laser_hip_last_error", "laser_hip_version", "laser_hip_abi_version",
              "laser_hip_device_count", "laser_hip_arch", "laser_hip_set_float_mode",
              "laser_hip_get_float_mode", "laser_hip_set_f32_config", "laser_hip_f32_config_count",
              "laser_hip_f32_config_name", "laser_hip_set_option", "laser_hip_get_option", "laser_hip_gemm_prepack_release",

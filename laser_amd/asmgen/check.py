@@ -74,7 +74,7 @@ def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
 
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
-             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False):
+             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False, csc=1):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart.
     G: workgroups of the (persistent) launch, default one per tile; split: cut tiles along K at slice boundaries (laser-order: kc;
     one chain: `split` K-tiles per slice) so that the G workgroups get equal numbers of units"""
@@ -88,7 +88,8 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         ldb = ldb if (ldb and ldb >= Kd) else Kd
     LA = (M - 1) * lda + Kd
     LB = (N - 1) * ldb + Kd if nt else (Kd - 1) * ldb + N
-    LC = (M - 1) * ldc + N
+    ldc = max(ldc, (N - 1) * csc + 1)
+    LC = (M - 1) * ldc + (N - 1) * csc + 1                  # C[i][j] at i * ldc + j * csc (a strided view, gemm_utils.nim:36-60)
     Aall, Ball, Call = np.zeros(batch * LA, np.float32), np.zeros(batch * LB, np.float32), np.full(batch * LC, np.nan, dtype=np.float32)
     As, Bs, C0s = [], [], []
     for b in range(batch):
@@ -110,7 +111,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         if beta != 0:           # C0 in the valid columns, NaN in the row padding
             C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
             full0 = np.full(M * ldc, np.nan, dtype=np.float32).reshape(M, ldc)
-            full0[:, :N] = C0
+            full0[:, :(N - 1) * csc + 1:csc] = C0
             Call[b * LC:(b + 1) * LC] = full0.reshape(-1)[:LC]
         As.append(Af[:, :Kd].copy()); Bs.append(Bm); C0s.append(C0)
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
@@ -131,7 +132,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
             Bias = rng.uniform(-1, 1, (M, N)).astype(np.float32); rsb, csb = N, 1
         bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
-    ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, 0)
+    ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, csc if csc != 1 else 0)
     ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
@@ -144,7 +145,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     for b in range(batch):
         full = np.full(M * ldc, np.nan, dtype=np.float32)
         full[:LC] = got[b * LC:(b + 1) * LC]
-        Cout = full.reshape(M, ldc)[:, :N]
+        Cout = full.reshape(M, ldc)[:, :(N - 1) * csc + 1:csc]
         want = reference(As[b], Bs[b], 512 if c.exact else 0, alpha, beta, C0s[b])
         if Bias is not None:
             want = (want + np.broadcast_to(Bias, (M, N))).astype(np.float32)
@@ -155,8 +156,12 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         else:       # (a cut one-chain launch adds partial sums: another rounding order than the single chain, by design)
             err = float(np.max(np.abs(Cout.astype(np.float64) - want.astype(np.float64))))
             ok &= 0.0 < err <= tol
-        if ldc > N:
+        if ldc > N and csc == 1:
             pad_ok &= bool(np.all(np.isnan(full.reshape(M, ldc)[:, N:][:-1])))
+        if csc > 1 and beta == 0:          # the elements between the columns of the view are never written
+            gaps = np.ones(ldc, dtype=bool)
+            gaps[:(N - 1) * csc + 1:csc] = False
+            pad_ok &= bool(np.all(np.isnan(full.reshape(M, ldc)[:-1][:, gaps])))
         if not ok and verbose:
             bad = np.argwhere(Cout != want)
             print("  batch", b, "first mismatches:", bad[:8].tolist(), Cout[tuple(bad[0])], want[tuple(bad[0])], "count", len(bad))

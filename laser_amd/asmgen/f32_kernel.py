@@ -114,7 +114,7 @@ CONFIGS = {
 KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 8, 16, 24, 32, 36, 40, 44, 48, 52, 64
 # convolution kernels only: H W oW pH pW Cin Npix magic(oW) | shift(oW) - bsB(bytes, u64) | bsC(bytes, u64)
 KA_CONV0, KA_CONV1, KA_CONV2 = 72, 104, 120
-KA_BIAS, KA_EPI = 128, 136   # fused epilogue: bias pointer (u64; 0 = none); rowStrideBias, colStrideBias (elements), activation (0 none / 1 relu), -
+KA_BIAS, KA_EPI = 128, 136   # fused epilogue: bias pointer (u64; 0 = none); rowStrideBias, colStrideBias (elements), activation (0 none / 1 relu); GEMM kernels: column stride of C in elements (0 = 1)
 KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's share the convolution kernels' slots at 112 / 120
 # scheduler block (every kernel): the workgroup -> tile map is arithmetic on these (gemm.nim:160-176 partitions by arithmetic too);
 # a divisor d travels as magic(d) = floor(2^32 / d) + 1 (0 for d == 1): x / d = mulhi(x, magic) while x * d < 2^32 (launcher)
@@ -166,6 +166,7 @@ class Gen:
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
+        self.s_csC4 = None if c.conv else S()      # column stride of C in bytes (KA_EPI + 12; 0 in the arguments = dense)
         self.alloc_sched()
         # accumulators
         self.acc = [p.aalloc(c.ACCR) for _ in range(c.NB)]
@@ -941,7 +942,17 @@ class Gen:
             e("s_and_b32", self.srdC[1], C_[1], 0xffff)
         e("s_sub_u32", st[0], self.s_M, 1)
         e("s_mul_i32", st[0], st[0], self.s_ldc4)
-        e("s_lshl_b32", st[2], self.s_N, 2)
+        if c.conv:
+            e("s_lshl_b32", st[2], self.s_N, 2)
+        else:
+            # C[i][j] at i * ldc + j * csC (MatrixView, gemm_utils.nim:36-60): bytes = (M - 1) * ldc * 4 + (N - 1) * csC * 4 + 4
+            e("s_load_dword", self.s_csC4, s(0, 2), KA_EPI + 12)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_max_u32", self.s_csC4, self.s_csC4, 1)
+            e("s_lshl_b32", self.s_csC4, self.s_csC4, 2)
+            e("s_sub_u32", st[2], self.s_N, 1)
+            e("s_mul_i32", st[2], st[2], self.s_csC4)
+            e("s_add_u32", st[2], st[2], 4)
         e("s_add_u32", self.srdC[2], st[0], st[2])
         e("s_mov_b32", self.srdC[3], 0x00020000)
         e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
@@ -1536,11 +1547,22 @@ class Gen:
         e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
         e("s_add_u32", st[1], self.s_n0, self.s_wn0)
         e("v_add_u32", t[4], st[1], lo)              # col of block n = 0
-        e("v_lshl_add_u32", t[3], t[4], 2, t[3])     # byte offset of (row, col)
+        dense = getattr(self, "s_csC4", None) is None      # (convolution / integer kernels: C's columns are adjacent)
+        if dense:
+            e("v_lshl_add_u32", t[3], t[4], 2, t[3])     # byte offset of (row, col)
+        else:
+            e("v_mul_lo_u32", t[6], t[4], self.s_csC4)
+            e("v_add_u32", t[3], t[3], t[6])             # byte offset of (row, col): row * ldc * 4 + col * csC * 4
+            e("s_lshl_b32", st[5], self.s_csC4, 5)       # 32 columns further
         for n in range(c.TN):
             e("v_add_u32", t[5], 32 * n, t[4])
             e("v_cmp_gt_u32", VCC, self.s_N, t[5])
-            e("v_add_u32", t[6], 128 * n, t[3])
+            if dense:
+                e("v_add_u32", t[6], 128 * n, t[3])
+            elif n == 0:
+                e("v_mov_b32", t[6], t[3])
+            else:
+                e("v_add_u32", t[6], st[5], t[6])
             e("v_mov_b32", t[7], 0x80000000)
             e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
             self.dump(f"vC[{n}]", self.vC[n])

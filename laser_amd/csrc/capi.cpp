@@ -511,7 +511,7 @@ int epi_check(const Epi<T> *e) {
   if (e->act < LASER_HIP_ACT_NONE || e->act > LASER_HIP_ACT_SIGMOID) return fail(LASER_HIP_E_INVALID, "unknown activation %d", e->act);
   if (!std::is_floating_point<T>::value) return fail(LASER_HIP_E_INVALID, "fused epilogue is float32/float64 only");
   if (std::is_same<T, double>::value && !g_ctx.f64_mfma && (e->bias || e->act))
-    return fail(LASER_HIP_E_INVALID, "fused epilogue needs the f64 MFMA kernel (laser_hip_set_f64_mfma(1))");
+    return fail(LASER_HIP_E_INVALID, "fused epilogue needs the f64 MFMA kernel (laser_hip_set_option(\"f64_mfma\", 1))");
   return LASER_HIP_OK;
 }
 template <typename T>
@@ -1277,7 +1277,8 @@ int laser_hip_finalize(void) {
 }
 
 const char *laser_hip_last_error(void) { return g_err.c_str(); }
-const char *laser_hip_version(void) { return "laser_hip 0.1.0 (gfx950)"; }
+const char *laser_hip_version(void) { return "laser_hip 0.2.0 (gfx950)"; }
+int laser_hip_abi_version(void) { return LASER_HIP_ABI_VERSION; }
 int laser_hip_device_count(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
@@ -1772,7 +1773,7 @@ template <typename T>
 int map_api(int op, bool binary, T *dst, const int64_t *ds, const T *a, const int64_t *as, const T *b, const int64_t *bs,
             const int64_t *shape, int rank, T alpha, T beta, void *stream) {
   if (rank < 0 || rank > kMaxRank) return fail(LASER_HIP_E_INVALID, "rank %d outside 0..%d (LASER_MAXRANK)", rank, kMaxRank);
-  const bool is_bin = op >= LASER_HIP_MAP_ADD && op <= LASER_HIP_MAP_AXPBY;
+  const bool is_bin = op >= LASER_HIP_MAP_ADD && op <= LASER_HIP_MAP_AXPBY && op != 35;   // (35: the removed DIV -- never a silent copy)
   const bool is_un = op >= LASER_HIP_MAP_COPY && op <= LASER_HIP_MAP_SQUARE;
   if (binary ? !is_bin : !is_un) return fail(LASER_HIP_E_INVALID, "map op %d is not a %s op", op, binary ? "binary" : "unary");
   const int nin = binary ? 2 : (op == LASER_HIP_MAP_FILL ? 0 : 1);

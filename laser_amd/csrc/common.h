@@ -170,6 +170,8 @@ extern std::atomic<int64_t> g_last_split;    // diagnostics: column cut of the l
 extern std::atomic<int> g_last_f32_cfg;       // diagnostics: the f32 tile configuration the last GEMM / conv launch used
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,
                                     int elem_size, hipStream_t s);
+hipError_t launch_transpose_pitched(void *dst, int64_t ld_dst, const void *src, int64_t ld_src, int64_t NR, int64_t NC, int elem_size,
+                                    hipStream_t s);
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,
                              int64_t C, int64_t H, int64_t W, int64_t kH, int64_t kW, int64_t pH,
                              int64_t pW, int64_t sH, int64_t sW, hipStream_t s);

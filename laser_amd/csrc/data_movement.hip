@@ -17,13 +17,13 @@ namespace laser_hip {
 template <typename T, bool VEC16, int TR = 64, int TC = 64, bool NT = false>
 __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                                                 int64_t NR, int64_t NC, int64_t tiles_c,
-                                                                int64_t tiles_r) {
+                                                                int64_t tiles_r, int64_t ld_src, int64_t ld_dst) {
   constexpr int V = 16 / sizeof(T);        // elements per 16-byte access: 4 (b32) or 2 (b64)
   __shared__ T tile[TR][TC + 1];           // TR source rows x TC source columns (+1: conflict-free column reads)
   const int64_t bid = blockIdx.x;
   const int64_t tc = bid % tiles_c, tr = (bid / tiles_c) % tiles_r, n = bid / (tiles_c * tiles_r);
-  const T *s = src + n * NR * NC;
-  T *d = dst + n * NR * NC;
+  const T *s = src + n * NR * ld_src;      // (row pitches: NC / NR for the dense batched form; the leading dimensions of a single
+  T *d = dst + n * NC * ld_dst;            // matrix when a strided operand is packed for the GEMM kernels)
   const int64_t r0 = tr * TR, c0 = tc * TC;
   const int t = threadIdx.x;
   if constexpr (VEC16) {
@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ 
         const int row = ty + RPI * i;
         const int64_t r = r0 + row, c = c0 + V * tx;
         if (r < NR && c < NC) {
-          const VT *p = reinterpret_cast<const VT *>(s + r * NC + c);
+          const VT *p = reinterpret_cast<const VT *>(s + r * ld_src + c);
           const VT q = NT ? __builtin_nontemporal_load(p) : *p;
 #pragma unroll
           for (int e = 0; e < V; e++) tile[row][V * tx + e] = q[e];
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ 
           VT q;
 #pragma unroll
           for (int e = 0; e < V; e++) q[e] = tile[V * tx + e][col];
-          VT *p = reinterpret_cast<VT *>(d + c * NR + r);
+          VT *p = reinterpret_cast<VT *>(d + c * ld_dst + r);
           if (NT)
             __builtin_nontemporal_store(q, p);
           else
@@ -71,47 +71,63 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
-      if (r < NR && c < NC) tile[ty + 4 * i][tx] = s[r * NC + c];
+      if (r < NR && c < NC) tile[ty + 4 * i][tx] = s[r * ld_src + c];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
-      if (r < NR && c < NC) d[c * NR + r] = tile[tx][ty + 4 * i];
+      if (r < NR && c < NC) d[c * ld_dst + r] = tile[tx][ty + 4 * i];
     }
   }
 }
 
 
 template <typename T, int TR, int TC, bool NT>
-static hipError_t launch_transpose_v(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s) {
+static hipError_t launch_transpose_v(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s, int64_t ld_src,
+                                     int64_t ld_dst) {
   const int64_t tiles_r = (NR + TR - 1) / TR, tiles_c = (NC + TC - 1) / TC;
   const int64_t blocks = N * tiles_r * tiles_c;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL((transpose_batched_kernel<T, true, TR, TC, NT>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst,
-                     (const T *)src, NR, NC, tiles_c, tiles_r);
+                     (const T *)src, NR, NC, tiles_c, tiles_r, ld_src, ld_dst);
   return hipGetLastError();
 }
 
+// ld_src / ld_dst: row pitches of the source / destination (0 = dense: NC / NR); N > 1 only with dense pitches
 template <typename T>
-static hipError_t launch_transpose_t(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s) {
+static hipError_t launch_transpose_t(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC, hipStream_t s, int64_t ld_src = 0,
+                                     int64_t ld_dst = 0) {
   constexpr int V = 16 / sizeof(T);
-  const bool vec = (NR % V == 0) && (NC % V == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  if (ld_src <= 0) ld_src = NC;
+  if (ld_dst <= 0) ld_dst = NR;
+  const bool vec = (NR % V == 0) && (NC % V == 0) && (ld_src % V == 0) && (ld_dst % V == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
   if (vec) {
     // Tile shape by problem size (scripts/probes/transpose_probe.hip, timed from C++ so that no interpreter sits between
     // launches; profiles/r03/transpose_probe_v1.jsonl): a problem of a few dozen microseconds wants MANY small workgroups
     // -- 16 source rows x 256 columns (1-KiB read segments, 64-B write segments): 4000 x 2000 f32 5.92 TB/s and 4096^2
     // 6.37 vs 5.57 / 5.67 with the 64 x 128 tile (a plain copy kernel of the same bytes: 6.3 / 6.7) -- while from ~100 us on
     // the write segments matter more: 32 x 256 (16384 x 8192: 5.27 vs 5.00; 8192^2: 5.01 vs 5.04; copy kernel 5.7).
-    if (N * NR * NC <= ((int64_t)1 << 24)) return launch_transpose_v<T, 16, 256, false>(dst, src, N, NR, NC, s);
-    return launch_transpose_v<T, 32, 256, false>(dst, src, N, NR, NC, s);
+    if (N * NR * NC <= ((int64_t)1 << 24)) return launch_transpose_v<T, 16, 256, false>(dst, src, N, NR, NC, s, ld_src, ld_dst);
+    return launch_transpose_v<T, 32, 256, false>(dst, src, N, NR, NC, s, ld_src, ld_dst);
   }
   const int64_t tiles_r = (NR + 63) / 64, tiles_c = (NC + 63) / 64;
   const int64_t blocks = N * tiles_r * tiles_c;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL((transpose_batched_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, (T *)dst, (const T *)src,
-                     NR, NC, tiles_c, tiles_r);
+                     NR, NC, tiles_c, tiles_r, ld_src, ld_dst);
   return hipGetLastError();
+}
+
+// dst[c * ld_dst + r] = src[r * ld_src + c]: one matrix with row pitches (a transposed GEMM operand packed row-major)
+hipError_t launch_transpose_pitched(void *dst, int64_t ld_dst, const void *src, int64_t ld_src, int64_t NR, int64_t NC, int elem_size,
+                                    hipStream_t s) {
+  if (NR <= 0 || NC <= 0) return hipSuccess;
+  if (ld_src < NC || ld_dst < NR) return hipErrorInvalidValue;
+  if (elem_size == 4) return launch_transpose_t<uint32_t>(dst, src, 1, NR, NC, s, ld_src, ld_dst);
+  if (elem_size == 8) return launch_transpose_t<uint64_t>(dst, src, 1, NR, NC, s, ld_src, ld_dst);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64_t NR, int64_t NC,

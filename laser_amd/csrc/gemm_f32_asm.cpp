@@ -122,7 +122,7 @@ struct KernArgs {
   uint64_t bsB_bytes, bsC_bytes;
   // fused epilogue of the f32 kernels (f32_kernel.py KA_BIAS / KA_EPI): bias view + activation; zero = plain epilogue
   const void *bias = nullptr;
-  uint32_t rsBias = 0, csBias = 0, act = 0, pad2_ = 0;
+  uint32_t rsBias = 0, csBias = 0, act = 0, csC = 0;   // csC: column stride of C in elements (f32 GEMM kernels; 0 = 1)
   SchedArgs sch;
 };
 static_assert(sizeof(KernArgs) == 232 && offsetof(KernArgs, sch) == 152, "kernel argument block layout (f32_kernel.py KA_*)");
@@ -362,8 +362,10 @@ void asm_kernels_release() {
   if (cur >= 0) (void)hipSetDevice(cur);
 }
 
-// hipErrorNotSupported: not this kernel's class of problem -- the caller takes the compiler-scheduled kernels
-hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
+namespace {
+// hipErrorNotSupported: not this kernel's class of problem.  A with unit column stride, B row-major-like or passed transposed, C with
+// any positive strides (the epilogue's address arithmetic takes the column stride; rows are the tile's fast direction).
+hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;
   if (a.batch < 1 || a.batch > 65535 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
   if (a.batch > 1 && (a.bsA < 0 || a.bsB < 0 || a.bsC < 0)) return hipErrorNotSupported;
@@ -374,7 +376,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (a.bias != nullptr && (a.rsBias < 0 || a.csBias < 0 || a.rsBias > 0x3fffffff || a.csBias > 0x3fffffff || (a.batch > 1 && a.bsBias != 0) ||
                             ((double)(a.M - 1) * a.rsBias + (double)(a.N - 1) * a.csBias + 1.0) * 4.0 >= 2147483648.0))
     return hipErrorNotSupported;
-  if (a.csA != 1 || a.csC != 1) return hipErrorNotSupported;
+  if (a.csA != 1 || a.csC < 1 || a.rsC < 1 || a.csC > 0x3fffffff) return hipErrorNotSupported;
   // (tile-padded pre-pack images -- Mext / Next / Kext beyond M / N / K, gemm_prepacked.nim:63-292 -- are plain padded row-major
   // copies: the kernels bound every access by M, N, K themselves and never need the padding)
   if (a.Mext < a.M || a.Next < a.N || a.Kext < a.K) return hipErrorNotSupported;
@@ -382,7 +384,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   const bool nt = a.csB != 1 && a.rsB == 1;
   if (!nt && a.csB != 1) return hipErrorNotSupported;
   const int64_t ldb = nt ? a.csB : a.rsB;
-  if (a.rsA < a.K || ldb < (nt ? a.K : a.N) || a.rsC < a.N) return hipErrorNotSupported;
+  if (a.rsA < a.K || ldb < (nt ? a.K : a.N)) return hipErrorNotSupported;
   // (a ragged last K-tile is zero-filled piece-wise -- 16 bytes = 4 k -- and, when K % 4 != 0, element-wise in the staging registers)
   if (a.K < 1 || a.M < 1 || a.N < 1) return hipErrorNotSupported;
   // laser-order results need the kc = 512 slices only when K > 512; one chain otherwise (the laser-order kernels are
@@ -392,7 +394,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   // 32-bit byte offsets inside the descriptors
   if ((double)a.rsA * 4.0 * 256 >= 4.0e9) return hipErrorNotSupported;
   if ((nt ? (double)ldb * 4.0 * 256 : (double)a.K * (double)ldb * 4.0) >= 4.0e9) return hipErrorNotSupported;
-  if (((double)(a.M - 1) * (double)a.rsC + (double)a.N) * 4.0 > 2147483648.0) return hipErrorNotSupported;
+  if (((double)(a.M - 1) * (double)a.rsC + (double)(a.N - 1) * (double)a.csC + 1.0) * 4.0 > 2147483648.0) return hipErrorNotSupported;
   // (batched problems -- gemm_strided_batched, the kc slices of the slice-parallel form -- are grid y: every tile count below is
   // per launch)
   // Which tile and which plan.  Workgroups that share a CU share its matrix pipes, so whatever the number of workgroup slots a
@@ -454,6 +456,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.rsBias = a.bias ? (uint32_t)a.rsBias : 0;
   ka.csBias = a.bias ? (uint32_t)a.csBias : 0;
   ka.act = (uint32_t)a.act;
+  ka.csC = a.csC == 1 ? 0u : (uint32_t)a.csC;
   e = launch_planned(m, pick, plan, ka, tiles_m, tiles_n, group_m, a.batch, (size_t)ki.bm * ki.bn * 4, s);
   if (e == hipErrorNotSupported && plan.persistent) {   // no workspace (a stream being captured, ...): one tile per workgroup
     Plan plain = plan_launch(ki, (int64_t)tiles_m * tiles_n, a.K, a.batch, exact, 512, cu_flops_per_us, false);
@@ -464,6 +467,59 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
     g_last_split = 0;  // one launch
   }
   return e;
+}
+}  // namespace
+
+// Any MatrixView (gemm_utils.nim:36-60: element strides on all three operands; README.md:211-213 advertises `myTensor[:, 0::2]`
+// and column-major operands) onto the kernels above:
+//   * C with unit ROW stride (column-major-like): C^T = B^T A^T -- every element is the same k-ascending chain, so the bits are the
+//     same -- which turns C into a row-major-like view;
+//   * A with a column stride / B with neither stride 1: the operand is packed once into a dense row-major scratch copy (a
+//     transposing pass for a unit-row-stride source: 16-byte accesses on both HBM sides; an element gather otherwise) -- Laser
+//     packs every panel it touches (gemm_packing.nim:24-94), here only operands the tile loaders cannot stream pay that pass
+//     (2 x 67 MB at 4096^2: ~3 % of the product's time);
+//   * C with a column stride: the kernels' own epilogue.
+// hipErrorNotSupported: not this kernel family's class of problem -- the caller takes the compiler-scheduled kernels.
+hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hipStream_t s) {
+  if (!g_f32_asm) return hipErrorNotSupported;
+  GemmArgs<float> a = a_in;
+  if (a.csC != 1 && a.rsC == 1 && a.batch == 1) {
+    std::swap(a.M, a.N);
+    std::swap(a.Mext, a.Next);
+    const float *pa = a.A;
+    const int64_t rsa = a.rsA, csa = a.csA;
+    a.A = a.B; a.rsA = a.csB; a.csA = a.rsB;
+    a.B = pa;  a.rsB = csa;   a.csB = rsa;
+    std::swap(a.rsC, a.csC);
+    std::swap(a.rsBias, a.csBias);
+  }
+  const bool packA = a.csA != 1, packB = a.csB != 1 && a.rsB != 1;
+  if (!packA && !packB) return launch_gemm_f32_asm_core(a, laser_order, s);
+  // packing pays for itself only on products that keep the chip busy for a while; plain / fused-epilogue single problems
+  if (a.batch != 1 || a.Mext != a.M || a.Next != a.N || a.Kext != a.K || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
+  if ((double)a.M * (double)a.N * (double)a.K < 1024.0 * 1024.0 * 1024.0 || a.K < 64) return hipErrorNotSupported;
+  if ((packA && (a.rsA < 0 || a.csA < 0)) || (packB && (a.rsB < 0 || a.csB < 0))) return hipErrorNotSupported;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return hipErrorNotSupported;
+  const size_t bytesA = packA ? (size_t)a.M * a.K * 4 : 0, bytesB = packB ? (size_t)a.K * a.N * 4 : 0;
+  if (bytesA + bytesB > ((size_t)4 << 30)) return hipErrorNotSupported;
+  float *scratch = nullptr;
+  hipError_t e = hipMallocAsync((void **)&scratch, bytesA + bytesB, s);
+  if (e != hipSuccess) return e;
+  if (packA) {      // A[m][k] at m * rsA + k * csA -> dense [M][K]
+    e = a.rsA == 1 ? launch_transpose_pitched(scratch, a.K, a.A, a.csA, a.K, a.M, 4, s)      // the source is a K x M row-major matrix (pitch csA)
+                   : launch_pack_pad<float>(scratch, a.M, a.K, a.A, a.M, a.K, a.rsA, a.csA, s);
+    a.A = scratch; a.rsA = a.K; a.csA = 1;
+  }
+  if (e == hipSuccess && packB) {      // neither stride of B is 1: dense [K][N]
+    float *sb = scratch + bytesA / 4;
+    e = launch_pack_pad<float>(sb, a.K, a.N, a.B, a.K, a.N, a.rsB, a.csB, s);
+    a.B = sb; a.rsB = a.N; a.csB = 1;
+  }
+  if (e == hipSuccess) e = launch_gemm_f32_asm_core(a, laser_order, s);
+  const hipError_t e2 = hipFreeAsync(scratch, s);
+  if (e == hipErrorNotSupported) return e;      // (nothing was launched but the packing passes, which touched only the scratch)
+  return e != hipSuccess ? e : e2;
 }
 
 

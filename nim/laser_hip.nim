@@ -22,6 +22,8 @@ const laserHip* = "liblaser_hip.so"
 
 # ---- C-ABI imports (Nim int == int64 on amd64, float32 == C float) ---------------------------
 proc laser_hip_last_error(): cstring {.lh, importc: "laser_hip_last_error".}
+proc laser_hip_abi_version*(): cint {.lh, importc: "laser_hip_abi_version".}
+const laserHipAbi* = 2                       # include/laser_hip.h LASER_HIP_ABI_VERSION this shim was written against
 proc laser_hip_init*(device: cint): cint {.lh, importc: "laser_hip_init".}
 proc laser_hip_finalize*(): cint {.lh, importc: "laser_hip_finalize".}
 proc laser_hip_device_count*(): cint {.lh, importc: "laser_hip_device_count".}
@@ -29,6 +31,10 @@ proc laser_hip_set_float_mode*(mode: cint): cint {.lh, importc: "laser_hip_set_f
 # every tuning / A-B switch by name (include/laser_hip.h lists them), and the read-only diagnostics of the last launch
 proc laser_hip_set_option(name: cstring, value: cint): cint {.lh, importc: "laser_hip_set_option".}
 proc laser_hip_get_option(name: cstring, value: ptr int): cint {.lh, importc: "laser_hip_get_option".}
+
+proc laserHipCheckAbi*() =
+  ## call once at start-up: a library with another ABI number takes other argument types for the same symbol names
+  doAssert laser_hip_abi_version() == laserHipAbi, "liblaser_hip.so has ABI " & $laser_hip_abi_version() & ", this shim expects " & $laserHipAbi
 
 template check(rc: cint) =
   # the reference procs return void and doAssert on precondition violations

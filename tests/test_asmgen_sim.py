@@ -52,6 +52,13 @@ GEMM_CASES += [
     ("exact_64x64x32", 70, 90, 100, dict(bias="full", act=0, alpha=0.5, beta=2.0)),
     ("fast_128x128x16_nt", 140, 150, 36, dict(act=1)),
 ]
+# C with a column stride (MatrixView, gemm_utils.nim:36-60): the epilogue's address arithmetic; nothing written between the columns
+GEMM_CASES += [
+    ("exact_64x64x32", 70, 90, 548, dict(csc=2, ldc=190)),
+    ("exact_256x128x32", 70, 140, 100, dict(csc=3, alpha=0.5, beta=-1.0)),
+    ("fast_256x256x16", 40, 300, 72, dict(csc=2, alpha=3.0, beta=0.5)),
+    ("exact_64x64x32", 70, 90, 100, dict(csc=2, bias="row", act=1)),
+]
 # C = beta * C0 + alpha * A B: the running sum starts as beta * C0, every slice is scaled before it is added
 GEMM_CASES += [
     ("exact_256x128x32", 70, 90, 1060, dict(alpha=0.75, beta=-1.5, ldc=100)),

@@ -635,9 +635,55 @@ def test_full_size_transposed_b_4096_every_element(la, oracle):
     Cbuf = torch.zeros((n, 2 * n), device="cuda")
     C = Cbuf[:, ::2]         # colStride 2
     la.matmul(A, B, 1, 0, C)
+    assert la.last_f32_asm() in (5, 7, 15, 33), la.last_f32_asm()      # the `_nt` assembly kernels: the strided C is their own epilogue
     want = oracle.matmul(np.ascontiguousarray(A.cpu().numpy()), np.ascontiguousarray(B.cpu().numpy()))
     assert np.array_equal(C.cpu().numpy(), want)
     assert (Cbuf[:, 1::2] == 0).all()
+
+
+def test_any_matrix_view_runs_on_the_assembly_kernels(la, oracle):
+    """MatrixView strides on all three operands (gemm_utils.nim:36-60; README.md:211-213: `myTensor[:, 0::2]`, column-major): A
+    column-major / every second column / both strides > 1, B with neither stride 1, C column-major / with a column stride -- all on
+    the hand-scheduled kernels (C^T = B^T A^T for a column-major C, a packing pass for an operand the tile loaders cannot stream,
+    the epilogue's own address arithmetic for a strided C), every element bit-exact, nothing written between C's elements."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(77)
+    M, N, K = 1100, 1300, 1500
+
+    def rnd(*shape):
+        return (torch.rand(shape, generator=g, device="cuda") - 0.5) * 0.2
+
+    def dense(t):
+        return np.ascontiguousarray(t.cpu().numpy())
+    cases = {
+        "A column-major": (rnd(K, M).t(), rnd(K, N), None),
+        "A[:, ::2]": (rnd(M, 2 * K)[:, ::2], rnd(K, N), None),
+        "A[::3, ::2], B transposed": (rnd(3 * M, 2 * K)[::3, ::2], rnd(N, K).t(), None),
+        "B[::2, ::3]": (rnd(M, K), rnd(2 * K, 3 * N)[::2, ::3], None),
+        "C column-major": (rnd(M, K), rnd(K, N), "colmajor"),
+        "C[:, ::3], A column-major, B transposed": (rnd(K, M).t(), rnd(N, K).t(), "stride3"),
+        "C column-major with a row stride, A[:, ::2]": (rnd(M, 2 * K)[:, ::2], rnd(K, N), "colmajor2"),
+    }
+    for name, (A, B, ckind) in cases.items():
+        for alpha, beta in ((1.0, 0.0), (0.5, -0.25)):
+            if ckind is None:
+                buf = rnd(M, N); C = buf
+            elif ckind == "colmajor":
+                buf = rnd(N, M); C = buf.t()
+            elif ckind == "stride3":
+                buf = rnd(M, 3 * N); C = buf[:, ::3]
+            else:
+                buf = rnd(N, 2 * M); C = buf.t()[::2]       # rows 2 apart, columns M*2 apart
+            before = buf.clone()
+            C0 = dense(C)
+            la.matmul(A, B, alpha, beta, C)
+            assert la.last_f32_asm() != 0, (name, alpha, beta)
+            want = oracle.matmul(dense(A), dense(B), alpha, beta, C0)
+            assert np.array_equal(dense(C), want), (name, alpha, beta)
+            if ckind == "stride3":
+                assert torch.equal(buf[:, 1::3], before[:, 1::3]) and torch.equal(buf[:, 2::3], before[:, 2::3]), name
+            if ckind == "colmajor2":
+                assert torch.equal(buf[:, 1::2], before[:, 1::2]), name
 
 
 def test_full_size_conv_c4_every_image(la, oracle):
