@@ -101,8 +101,9 @@ int laser_hip_f32_config_count(void);
  *                          2 = the persistent plan whenever legal: every workgroup slot of the chip gets an equal share of K-slice
  *                          units (laser-order: kc slices), a tile that straddles two workgroups is handed over in-kernel, in slice
  *                          order (gemm.nim:150-158) -- laser-order results are the same bits under every plan
- *   "asm_kernel" [-1] / "asm_wgs" [0] / "asm_slice" [0] / "asm_noseed" [0]  tuning / test overrides of that plan: force an assembly
- *                          kernel index, the number of workgroups, the K-tiles per slice of a one-chain cut, the two-run receive path
+ *   "asm_kernel" [-1] / "asm_wgs" [0] / "asm_slice" [0] / "asm_noseed" [0] / "asm_group_m" [0]  tuning / test overrides of that plan:
+ *                          force an assembly kernel index, the number of workgroups, the K-tiles per slice of a one-chain cut, the
+ *                          two-run receive path, the tile rows per raster group (which tiles share an XCD's L2)
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
  *   "last_f32_asm" / "last_f64_asm" / "last_i32_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
@@ -395,7 +396,9 @@ int laser_hip_get_shard_devices(void);
  *                                        copy stream per peer (all xGMI links at once, SDMA engines, no CUs);
  *                 LASER_HIP_GATHER_RCCL  ncclAllGather per slab (librccl.so loaded on first use; needs
  *                                        rowStrideC == N and dC[g] sized for padded_M rows).
- *   flags         LASER_HIP_SHARD_PIN_TILE: 128x128 tiles for the local products (RCCL's kernels hold CUs meanwhile). */
+ *   flags         LASER_HIP_SHARD_PIN_TILE: 128x128 tiles for the local products (RCCL's kernels hold CUs meanwhile).
+ * On an error return the operand buffers must stay alive until the devices are idle (work queued by the failed call may still
+ * name them); the library drops the streams it queued that work on and makes new ones for the next call. */
 #define LASER_HIP_GATHER_NONE 0
 #define LASER_HIP_GATHER_PEER 1
 #define LASER_HIP_GATHER_RCCL 2

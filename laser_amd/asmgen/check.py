@@ -88,7 +88,9 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         ldb = ldb if (ldb and ldb >= Kd) else Kd
     LA = (M - 1) * lda + Kd
     LB = (N - 1) * ldb + Kd if nt else (Kd - 1) * ldb + N
-    ldc = max(ldc, (N - 1) * csc + 1)
+    interleaved = csc > 1 and ldc < (N - 1) * csc + 1       # rows are the fast direction (a column-major-like view with a row stride)
+    if csc > 1 and not interleaved:
+        ldc = max(ldc, (N - 1) * csc + 1)
     LC = (M - 1) * ldc + (N - 1) * csc + 1                  # C[i][j] at i * ldc + j * csc (a strided view, gemm_utils.nim:36-60)
     Aall, Ball, Call = np.zeros(batch * LA, np.float32), np.zeros(batch * LB, np.float32), np.full(batch * LC, np.nan, dtype=np.float32)
     As, Bs, C0s = [], [], []
@@ -108,7 +110,10 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         Aall[b * LA:(b + 1) * LA] = Af.reshape(-1)[:LA]
         Ball[b * LB:(b + 1) * LB] = Bf.reshape(-1)[:LB]
         C0 = None
-        if beta != 0:           # C0 in the valid columns, NaN in the row padding
+        if beta != 0 and interleaved:
+            C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+            Call[b * LC + (np.arange(M)[:, None] * ldc + np.arange(N)[None, :] * csc)] = C0
+        elif beta != 0:           # C0 in the valid columns, NaN in the row padding
             C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
             full0 = np.full(M * ldc, np.nan, dtype=np.float32).reshape(M, ldc)
             full0[:, :(N - 1) * csc + 1:csc] = C0
@@ -143,9 +148,13 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     got = mem.get(c_, np.float32, (batch * LC,))
     ok = pad_ok = True
     for b in range(batch):
-        full = np.full(M * ldc, np.nan, dtype=np.float32)
+        full = np.full(max(M * ldc, LC), np.nan, dtype=np.float32)
         full[:LC] = got[b * LC:(b + 1) * LC]
-        Cout = full.reshape(M, ldc)[:, :(N - 1) * csc + 1:csc]
+        if interleaved:
+            idx = np.arange(M)[:, None] * ldc + np.arange(N)[None, :] * csc
+            Cout = full[idx]
+        else:
+            Cout = full.reshape(M, ldc)[:, :(N - 1) * csc + 1:csc]
         want = reference(As[b], Bs[b], 512 if c.exact else 0, alpha, beta, C0s[b])
         if Bias is not None:
             want = (want + np.broadcast_to(Bias, (M, N))).astype(np.float32)
@@ -156,9 +165,14 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         else:       # (a cut one-chain launch adds partial sums: another rounding order than the single chain, by design)
             err = float(np.max(np.abs(Cout.astype(np.float64) - want.astype(np.float64))))
             ok &= 0.0 < err <= tol
-        if ldc > N and csc == 1:
+        if interleaved:
+            mask = np.ones(LC, dtype=bool)
+            mask[idx.reshape(-1)] = False
+            if beta == 0:
+                pad_ok &= bool(np.all(np.isnan(full[:LC][mask])))
+        elif ldc > N and csc == 1:
             pad_ok &= bool(np.all(np.isnan(full.reshape(M, ldc)[:, N:][:-1])))
-        if csc > 1 and beta == 0:          # the elements between the columns of the view are never written
+        if csc > 1 and beta == 0 and not interleaved:          # the elements between the columns of the view are never written
             gaps = np.ones(ldc, dtype=bool)
             gaps[:(N - 1) * csc + 1:csc] = False
             pad_ok &= bool(np.all(np.isnan(full.reshape(M, ldc)[:-1][:, gaps])))

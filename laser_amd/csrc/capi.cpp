@@ -1326,6 +1326,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "asm_wgs") g_asm_wgs = value < 0 ? 0 : value;
   else if (n == "asm_slice") g_asm_slice = value < 0 ? 0 : value;
   else if (n == "asm_noseed") g_asm_noseed = on;
+  else if (n == "asm_group_m") g_asm_group_m = value < 0 ? 0 : value;
   else if (n == "slice_parallel") g_ctx.slice_parallel = on;
   else if (n == "slice_parallel_min") g_ctx.slice_parallel_min = value < 2 ? 2 : value;
   else if (n == "slice_parallel_tiles") g_ctx.slice_parallel_tiles = value < 0 ? 0 : value;
@@ -1357,6 +1358,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "asm_wgs") *value = g_asm_wgs;
   else if (n == "asm_slice") *value = g_asm_slice;
   else if (n == "asm_noseed") *value = g_asm_noseed;
+  else if (n == "asm_group_m") *value = g_asm_group_m;
   else if (n == "last_asm_wgs") *value = g_last_asm_wgs;
   else if (n == "last_asm_slices") *value = g_last_asm_slices;
   else if (n == "asm_fixup_timeouts") *value = asm_fixup_timeouts();

@@ -130,7 +130,7 @@ extern std::atomic<int> g_f64_asm, g_last_f64_asm;
 hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
 hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 extern std::atomic<int> g_i32_asm, g_last_i32_asm;
-extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
+extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed, g_asm_group_m;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
 extern std::atomic<int> g_last_asm_wgs, g_last_asm_slices;                  // diagnostics: workgroups / K slices per tile of the last assembly launch
 extern std::atomic<int> g_f32_asm;       // 1 default; 0 = never; 2 = whenever the kernel can (no tile-count rule: tests)
 extern std::atomic<int> g_last_f32_asm;  // 0 = the last f32 GEMM launch was a compiler-scheduled kernel, 1 / 2 = laser-order / fast assembly kernel

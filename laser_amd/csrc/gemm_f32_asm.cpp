@@ -32,6 +32,7 @@ std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model
 std::atomic<int> g_asm_kernel{-1};    // option "asm_kernel": force an index of kKernels (tuning sweeps); -1 = the model decides
 std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persistent launch (0 = every slot of the chip)
 std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
+std::atomic<int> g_asm_group_m{0};    // option "asm_group_m": tile rows per raster group of the f32 / f64 GEMM launches (0 = 4 for 256-row tiles, else 8)
 std::atomic<int> g_asm_noseed{0};     // option "asm_noseed": 1 = a piece never takes its received sum early (tests: forces the two-run receive path)
 std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
 
@@ -376,7 +377,9 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
   if (a.bias != nullptr && (a.rsBias < 0 || a.csBias < 0 || a.rsBias > 0x3fffffff || a.csBias > 0x3fffffff || (a.batch > 1 && a.bsBias != 0) ||
                             ((double)(a.M - 1) * a.rsBias + (double)(a.N - 1) * a.csBias + 1.0) * 4.0 >= 2147483648.0))
     return hipErrorNotSupported;
-  if (a.csA != 1 || a.csC < 1 || a.rsC < 1 || a.csC > 0x3fffffff) return hipErrorNotSupported;
+  // C: rows are the slow direction of the view -- a tile's rows beyond M are dropped by the descriptor's size alone (they lie past
+  // the last row), which needs every row to end before the next one starts
+  if (a.csA != 1 || a.csC < 1 || a.csC > 0x3fffffff || a.rsC < (a.N - 1) * a.csC + 1) return hipErrorNotSupported;
   // (tile-padded pre-pack images -- Mext / Next / Kext beyond M / N / K, gemm_prepacked.nim:63-292 -- are plain padded row-major
   // copies: the kernels bound every access by M, N, K themselves and never need the padding)
   if (a.Mext < a.M || a.Next < a.N || a.Kext < a.K) return hipErrorNotSupported;
@@ -432,7 +435,7 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
-  const int group_m = (ki.bm >= 2 * ki.bn) ? 4 : 8;
+  const int group_m = g_asm_group_m > 0 ? (int)g_asm_group_m : (ki.bm >= 2 * ki.bn) ? 4 : 8;
   KernArgs ka;
   zero_conv_fields(ka);
   ka.A = a.A;
@@ -472,8 +475,8 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
 
 // Any MatrixView (gemm_utils.nim:36-60: element strides on all three operands; README.md:211-213 advertises `myTensor[:, 0::2]`
 // and column-major operands) onto the kernels above:
-//   * C with unit ROW stride (column-major-like): C^T = B^T A^T -- every element is the same k-ascending chain, so the bits are the
-//     same -- which turns C into a row-major-like view;
+//   * C whose columns are its slow direction (column-major-like, colStride > rowStride): C^T = B^T A^T -- every element is the same
+//     k-ascending chain, so the bits are the same -- which turns C into a row-major-like view;
 //   * A with a column stride / B with neither stride 1: the operand is packed once into a dense row-major scratch copy (a
 //     transposing pass for a unit-row-stride source: 16-byte accesses on both HBM sides; an element gather otherwise) -- Laser
 //     packs every panel it touches (gemm_packing.nim:24-94), here only operands the tile loaders cannot stream pay that pass
@@ -483,7 +486,7 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;
   GemmArgs<float> a = a_in;
-  if (a.csC != 1 && a.rsC == 1 && a.batch == 1) {
+  if (a.csC > a.rsC && a.rsC >= 1 && a.batch == 1) {     // columns are the slow direction of C (column-major, with or without a row stride)
     std::swap(a.M, a.N);
     std::swap(a.Mext, a.Next);
     const float *pa = a.A;
@@ -602,9 +605,10 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t
   return e;
 }
 
-// float64 twin of launch_gemm_f32_asm (kernels of laser_amd/asmgen/f64_kernel.py): row-major A and C, B row-major or passed
+namespace {
+// float64 twin of launch_gemm_f32_asm_core (kernels of laser_amd/asmgen/f64_kernel.py): row-major A and C, B row-major or passed
 // transposed, any alpha / beta, K even, batches as grid y.
-hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipStream_t s) {
+hipError_t launch_gemm_f64_asm_core(const GemmArgs<double> &a, bool laser_order, hipStream_t s) {
   if (!g_f64_asm) return hipErrorNotSupported;
   if (a.batch < 1 || a.batch > 65535 || a.bias != nullptr || a.act != 0 || a.col0 != 0 || a.done_flags != nullptr) return hipErrorNotSupported;
   if (a.batch > 1 && (a.bsA < 0 || a.bsB < 0 || a.bsC < 0)) return hipErrorNotSupported;
@@ -668,6 +672,37 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a, bool laser_order, hipS
   }
   if (e == hipSuccess) g_last_f64_asm = 1 + pick;
   return e;
+}
+}  // namespace
+
+// float64: a column-major-like C as C^T = B^T A^T and a transposed A (unit row stride) through the packing pass, like
+// launch_gemm_f32_asm; other strides (a column stride on C, gathers) stay on the compiler-scheduled kernels.
+hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a_in, bool laser_order, hipStream_t s) {
+  if (!g_f64_asm) return hipErrorNotSupported;
+  GemmArgs<double> a = a_in;
+  if (a.csC != 1 && a.rsC == 1 && a.batch == 1 && a.bias == nullptr) {
+    std::swap(a.M, a.N);
+    std::swap(a.Mext, a.Next);
+    const double *pa = a.A;
+    const int64_t rsa = a.rsA, csa = a.csA;
+    a.A = a.B; a.rsA = a.csB; a.csA = a.rsB;
+    a.B = pa;  a.rsB = csa;   a.csB = rsa;
+    std::swap(a.rsC, a.csC);
+  }
+  if (a.csA == 1) return launch_gemm_f64_asm_core(a, laser_order, s);
+  if (a.rsA != 1 || a.batch != 1 || a.Mext != a.M || a.Next != a.N || a.Kext != a.K || a.col0 != 0 || a.done_flags != nullptr || a.csA < a.M) return hipErrorNotSupported;
+  if ((double)a.M * (double)a.N * (double)a.K < 1024.0 * 1024.0 * 1024.0 || a.K < 64 || a.K % 2 != 0) return hipErrorNotSupported;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return hipErrorNotSupported;
+  double *scratch = nullptr;
+  hipError_t e = hipMallocAsync((void **)&scratch, (size_t)a.M * a.K * 8, s);
+  if (e != hipSuccess) return e;
+  e = launch_transpose_pitched(scratch, a.K, a.A, a.csA, a.K, a.M, 8, s);
+  a.A = scratch; a.rsA = a.K; a.csA = 1;
+  if (e == hipSuccess) e = launch_gemm_f64_asm_core(a, laser_order, s);
+  const hipError_t e2 = hipFreeAsync(scratch, s);
+  if (e == hipErrorNotSupported) return e;
+  return e != hipSuccess ? e : e2;
 }
 
 // Implicit-GEMM convolution (conv2d_im2col.nim:102-166 minus the materialised im2col matrix): output pixels [0, a.N) of every

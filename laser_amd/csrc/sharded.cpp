@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,6 +92,85 @@ struct RankCtx {
 };
 RankCtx g_rank[kMaxRanks];
 std::mutex g_shard_mu;  // one sharded call at a time (they use every GPU anyway)
+
+// One persistent host thread per rank slot (created on first use, parked on a condition variable between calls): a sharded call
+// hands every slot its job and waits for all of them -- no thread is created or joined per call (that alone cost ~0.1 ms of an
+// 8192^3 step in round 3), and a slot's thread keeps its device context, its thread-local scratch and its tile pin warm.
+class WorkerPool {
+ public:
+  template <typename F>
+  void run(int n, F &&fn) {
+    if (n == 1) {
+      fn(0);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    while ((int)threads_.size() < n) {
+      const int slot = (int)threads_.size();
+      seen_.push_back(gen_);
+      threads_.emplace_back([this, slot] { loop(slot); });
+    }
+    job_ = [&fn](int g) { fn(g); };
+    njobs_ = n;
+    pending_ = n;
+    gen_++;
+    cv_.notify_all();
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      cv_.notify_all();
+    }
+    for (auto &t : threads_)
+      if (t.joinable()) t.join();
+  }
+
+ private:
+  void loop(int slot) {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || (gen_ != seen_[slot] && slot < njobs_); });
+      if (stop_) return;
+      seen_[slot] = gen_;
+      auto job = job_;
+      lk.unlock();
+      job(slot);
+      lk.lock();
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> threads_;
+  std::vector<uint64_t> seen_;
+  std::function<void(int)> job_;
+  uint64_t gen_ = 0;
+  int njobs_ = 0, pending_ = 0;
+  bool stop_ = false;
+};
+WorkerPool &pool() {
+  static WorkerPool *p = new WorkerPool();   // (never destroyed: worker threads must not be joined from a static destructor at exit)
+  return *p;
+}
+
+// a rank whose call failed may still have work queued that names the caller's buffers: its streams are dropped (the runtime
+// releases them when that work has drained) and recreated by the next call
+void rank_reset(int r) {
+  RankCtx &R = g_rank[r];
+  if (R.device < 0) return;
+  (void)hipSetDevice(R.device);
+  if (R.comp) (void)hipStreamDestroy(R.comp);
+  if (R.comm) (void)hipStreamDestroy(R.comm);
+  for (auto &p : R.peer)
+    if (p) (void)hipStreamDestroy(p), p = nullptr;
+  for (auto e : R.ev) (void)hipEventDestroy(e);
+  R.ev.clear();
+  R.comp = R.comm = nullptr;
+  R.device = -1;
+}
 
 int rank_setup(int r, int device, int ndev, int nev) {
   RankCtx &R = g_rank[r];
@@ -209,9 +290,12 @@ void rccl_abort_all() {
   g_rccl.devs.clear();
 }
 
-// Bounded wait for a stream: hipStreamSynchronize can block forever when a peer never enters a collective.
-// LASER_HIP_SHARD_TIMEOUT_S (default 120) seconds, then hipErrorTimeout.
-hipError_t sync_bounded(hipStream_t s) {
+// Bounded wait for a stream that may carry collectives: hipStreamSynchronize can block forever when a peer never enters one.
+// LASER_HIP_SHARD_TIMEOUT_S (default 120) seconds, then hipErrorTimeout.  Streams that carry only this rank's own kernels and
+// copies (no transport, peer pushes) cannot hang on a peer: those are waited for with hipStreamSynchronize, which returns the
+// moment the work is done (the 50-us poll below cost up to 0.7 % of an 8192^3 step).
+hipError_t sync_bounded(hipStream_t s, bool collectives = true) {
+  if (!collectives) return hipStreamSynchronize(s);
   static const double limit = [] {
     const char *e = getenv("LASER_HIP_SHARD_TIMEOUT_S");
     const double v = e ? atof(e) : 120.0;
@@ -307,11 +391,24 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
     };
     RankCtx &R = g_rank[g];
     hipError_t e = hipSetDevice(dev[g]);
-    if (e != hipSuccess) bail(api_fail(LASER_HIP_E_HIP, "hipSetDevice(%d): %s", dev[g], hipGetErrorString(e)));
+    const bool no_device = e != hipSuccess;      // then no stream / event call below may run (it would land on whatever device is current)
+    if (no_device) bail(api_fail(LASER_HIP_E_HIP, "hipSetDevice(%d): %s", dev[g], hipGetErrorString(e)));
     if (pin) api_set_thread_f32_config(pin_cfg);
-    for (int s = 0; s < plan.ppd; s++) {
+    // one device and nothing to exchange: the panels are one contiguous matrix -- one product, no per-panel launch boundary
+    const bool whole = ndev == 1 && gather != LASER_HIP_GATHER_RCCL && !no_device;
+    if (whole) {
+      const int r = Api<T>::dev(M, N, K, alpha, dA[0], rsA, csA, dB[0], rsB, csB, beta, dC[0], rsC, 1, R.comp);
+      if (r != LASER_HIP_OK) bail(r);
+    }
+    for (int s = 0; s < plan.ppd && !whole; s++) {
       int64_t start, valid;
       plan.panel(s, g, &start, &valid);
+      if (no_device) {      // keep the collective sequence alive for the peers (RCCL), touch nothing else
+        if (gather != LASER_HIP_GATHER_RCCL) break;
+        T *slab = dC[g] + (int64_t)s * ndev * plan.rows * N;
+        if (g_rccl.AllGather(slab + (int64_t)g * plan.rows * N, slab, (size_t)plan.rows * N, NcclType<T>::v, g_rccl.comms[g], R.comm) != 0) break;
+        continue;
+      }
       if (valid > 0 && rc[g] == LASER_HIP_OK) {
         const int r = Api<T>::dev(valid, N, K, alpha, dA[g] + (int64_t)s * plan.rows * rsA, rsA, csA, dB[g], rsB, csB, beta,
                                   dC[g] + start * rsC, rsC, 1, R.comp);
@@ -351,22 +448,23 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
       }
     }
     if (pin) api_set_thread_f32_config(-2);
-    // this rank's GEMMs and everything it sent -- bounded: a peer that never arrives must not hang the caller
-    e = sync_bounded(R.comp);
+    if (no_device) return;
+    // this rank's GEMMs and everything it sent; bounded where a peer that never arrives could hang the caller (RCCL)
+    const bool coll = gather == LASER_HIP_GATHER_RCCL && ndev > 1;
+    e = sync_bounded(R.comp, coll);
     if (e == hipSuccess && ndev > 1 && gather == LASER_HIP_GATHER_PEER)
       for (int p = 0; p < ndev && e == hipSuccess; p++)
-        if (p != g) e = sync_bounded(R.peer[p]);
-    if (e == hipSuccess && gather == LASER_HIP_GATHER_RCCL) e = sync_bounded(R.comm);
+        if (p != g) e = sync_bounded(R.peer[p], false);
+    if (e == hipSuccess && gather == LASER_HIP_GATHER_RCCL) e = sync_bounded(R.comm, coll);
     if (e != hipSuccess) bail(api_fail(LASER_HIP_E_HIP, "synchronising device %d: %s", dev[g], hipGetErrorString(e)));
   };
-  if (ndev == 1) {
-    worker(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int g = 0; g < ndev; g++) th.emplace_back(worker, g);
-    for (auto &t : th) t.join();
+  pool().run(ndev, worker);
+  if (failed) {
+    if (gather == LASER_HIP_GATHER_RCCL) rccl_abort_all();  // pending collectives of a failed call must not outlive it
+    // (queued work of a failed call may still name the caller's buffers: they must stay alive until the device is idle --
+    // include/laser_hip.h says so; the slots' streams are dropped here and recreated by the next call)
+    for (int g = 0; g < ndev; g++) rank_reset(g);
   }
-  if (failed && gather == LASER_HIP_GATHER_RCCL) rccl_abort_all();  // pending collectives of a failed call must not outlive it
   (void)hipSetDevice(prev_dev);
   for (int g = 0; g < ndev; g++)
     if (rc[g] != LASER_HIP_OK) return api_fail(rc[g], "device slot %d: %s", g, msg[g].c_str());
@@ -411,12 +509,9 @@ int sharded_host(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t 
     if (rc[g] != LASER_HIP_OK) msg[g] = laser_hip_last_error();
     api_set_thread_device(-1);
   };
-  if (ndev == 1) {
-    worker(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int g = 0; g < ndev; g++) th.emplace_back(worker, g);
-    for (auto &t : th) t.join();
+  {
+    std::lock_guard<std::mutex> lk(g_shard_mu);      // (the pool runs one call at a time)
+    pool().run(ndev, worker);
   }
   for (int g = 0; g < ndev; g++)
     if (rc[g] != LASER_HIP_OK) return api_fail(rc[g], "device %d: %s", dev[g], msg[g].c_str());

@@ -796,14 +796,15 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
     B = torch.from_numpy(rand(rng, (1024, 2048), np.float32)).cuda()
     la.matmul(A, B, 2.0, 0, cn)
     assert la.last_f32_asm() != 0 and not torch.isnan(cn).any()
-    # not this kernel's class: a strided C -> the compiler-scheduled kernels, same results as ever
+    # a strided C is the assembly kernels' own epilogue (round 3: the compiler-scheduled kernels): same results, gaps untouched
     M, N, K = 2048, 2048, 1024
     try:
         la.set_f32_asm(2)
         w = torch.full((M, 2 * N), 9.0, device="cuda"); la.matmul(A, B, 1, 0, w[:, ::2])
-        assert la.last_f32_asm() == 0
+        assert la.last_f32_asm() != 0
         ref = la.matmul(A, B)
-        assert la.last_f32_asm() in (1, 3, 13)
+        assert la.last_f32_asm() in (1, 3, 13, 31)
+        assert torch.equal(w[:, ::2], ref) and (w[:, 1::2] == 9.0).all()
         odd = la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous())      # K not a multiple of 4: element-wise tail mask
         assert la.last_f32_asm() != 0
         la.set_f32_asm(0)
