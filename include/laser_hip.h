@@ -256,6 +256,13 @@ int laser_hip_conv2d_im2col_f32_dev(float *d_output, const float *d_input, int64
  * M x N view whose strides may be 0: (1,0) = one value per row of C (a convolution's per-channel
  * bias), (0,1) = one per column (a dense layer's), (ldb,1) = a full residual matrix; NULL = none.
  * float32 / float64 only (the activations are floating-point functions). */
+/* Fused PROLOGUE (the other half of the reference's fusion roadmap, README.md:243-244: "fuse operations before the matrix
+ * multiplication kernel, during the prepacking ... for backward propagation"): OR these bits into `activation` and the product is
+ * taken of relu(A) and / or relu(B), elementwise x > 0 ? x : 0, applied as the operand tile travels from HBM into the LDS panel
+ * image (float32: the assembly kernels' `_pre` variants, in the staging registers; other paths: in the one packing pass the
+ * operand gets anyway, or one made for it).  C = act(alpha * pre(A) * pre(B) + beta * C + bias). */
+#define LASER_HIP_PRE_RELU_A 0x100
+#define LASER_HIP_PRE_RELU_B 0x200
 #define LASER_HIP_ACT_NONE 0
 #define LASER_HIP_ACT_RELU 1     /* x > 0 ? x : 0 */
 #define LASER_HIP_ACT_TANH 2

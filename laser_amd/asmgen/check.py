@@ -74,7 +74,7 @@ def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
 
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
-             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False, csc=1):
+             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False, csc=1, pre=0, interleaved=False):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart.
     G: workgroups of the (persistent) launch, default one per tile; split: cut tiles along K at slice boundaries (laser-order: kc;
     one chain: `split` K-tiles per slice) so that the G workgroups get equal numbers of units"""
@@ -88,7 +88,8 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         ldb = ldb if (ldb and ldb >= Kd) else Kd
     LA = (M - 1) * lda + Kd
     LB = (N - 1) * ldb + Kd if nt else (Kd - 1) * ldb + N
-    interleaved = csc > 1 and ldc < (N - 1) * csc + 1       # rows are the fast direction (a column-major-like view with a row stride)
+    # (interleaved: rows are the fast direction -- a column-major-like view with a row stride; the kernels do NOT take it, the
+    # launcher turns such a C into the transposed problem: kept here to show why, see the launcher's comment)
     if csc > 1 and not interleaved:
         ldc = max(ldc, (N - 1) * csc + 1)
     LC = (M - 1) * ldc + (N - 1) * csc + 1                  # C[i][j] at i * ldc + j * csc (a strided view, gemm_utils.nim:36-60)
@@ -137,7 +138,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
             Bias = rng.uniform(-1, 1, (M, N)).astype(np.float32); rsb, csb = N, 1
         bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
-    ka += struct.pack("<Q", LA * 4) + b"\0" * 32 + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, csc if csc != 1 else 0)
+    ka += struct.pack("<Q", LA * 4) + b"\0" * 28 + struct.pack("<I", pre) + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, csc if csc != 1 else 0)
     ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
@@ -155,7 +156,8 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
             Cout = full[idx]
         else:
             Cout = full.reshape(M, ldc)[:, :(N - 1) * csc + 1:csc]
-        want = reference(As[b], Bs[b], 512 if c.exact else 0, alpha, beta, C0s[b])
+        relu = lambda x: np.where(x > 0, x, np.float32(0)).astype(np.float32)
+        want = reference(relu(As[b]) if pre & 1 else As[b], relu(Bs[b]) if pre & 2 else Bs[b], 512 if c.exact else 0, alpha, beta, C0s[b])
         if Bias is not None:
             want = (want + np.broadcast_to(Bias, (M, N))).astype(np.float32)
         if act == 1:

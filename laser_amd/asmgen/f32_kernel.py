@@ -21,8 +21,14 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
                  b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32",
-                 persistent=None):
+                 persistent=None, pre=False):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
+        # pre: fused prologue (README.md:243-244: "fuse operations before the matrix multiplication kernel, during the prepacking"):
+        # relu applied to the elements of A and / or B in the staging registers, on their way into the LDS panel image; which operand
+        # is a run-time mask (KA_PRE).  Kernels of their own: the VALU work costs matrix-pipe time, the plain kernels carry none of it.
+        self.pre = pre
+        if pre and persistent is None:
+            persistent = False          # (the scheduler state and the masks do not both fit the SGPR file)
         self.dtype = dtype
         # persistent: the workgroup loops over unit runs handed out by the in-kernel scheduler (sched_next): whole tiles, and -- where
         # the launcher cuts tiles along K at slice boundaries -- head slices stored to a workspace / tail runs that fold them in
@@ -104,6 +110,12 @@ CONFIGS = {
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
     # one round of 128x128 tiles (129 .. 256 of them: 1920^3, 2048^3): a workgroup has its CU to itself, and the 16-deep K-tile of
     # the two-per-CU kernels (32 MFMAs between barriers) leaves its latencies uncovered; 32 deep = 64 MFMAs per barrier, 96 KiB of LDS
+    # fused prologue (relu on A and / or B elements on their way into LDS): variants of the main tiles
+    **{f"{base}_pre{nt}": dict(BM=bm, BN=bn, BK=bk, exact=ex, pre=True, **({"bar_gap": bg} if bg else {}), **({"b_kcontig": True} if nt else {}))
+       for base, bm, bn, bk, ex, bg in (("exact_256x128x32", 256, 128, 32, True, 95), ("fast_256x256x16", 256, 256, 16, False, 95),
+                                        ("exact_128x128x16", 128, 128, 16, True, None), ("fast_128x128x16", 128, 128, 16, False, None),
+                                        ("exact_64x64x32", 64, 64, 32, True, None), ("fast_64x64x32", 64, 64, 32, False, None))
+       for nt in ("", "_nt")},
     "exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True),
     "fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False),
     "exact_128x128x32_nt": dict(BM=128, BN=128, BK=32, exact=True, b_kcontig=True),
@@ -116,6 +128,7 @@ KA_A, KA_B, KA_C, KA_TAB, KA_LDA, KA_LDB, KA_LDC, KA_M, KA_N, KA_K, KA_DBG = 0, 
 KA_CONV0, KA_CONV1, KA_CONV2 = 72, 104, 120
 KA_BIAS, KA_EPI = 128, 136   # fused epilogue: bias pointer (u64; 0 = none); rowStrideBias, colStrideBias (elements), activation (0 none / 1 relu); GEMM kernels: column stride of C in elements (0 = 1)
 KA_BSA = 72      # GEMM kernels: batch stride of A in bytes (u64); B's and C's share the convolution kernels' slots at 112 / 120
+KA_PRE = 108     # GEMM kernels with a fused prologue: bit 0 = relu on A's elements, bit 1 = relu on B's (x > 0 ? x : 0)
 # scheduler block (every kernel): the workgroup -> tile map is arithmetic on these (gemm.nim:160-176 partitions by arithmetic too);
 # a divisor d travels as magic(d) = floor(2^32 / d) + 1 (0 for d == 1): x / d = mulhi(x, magic) while x * d < 2^32 (launcher)
 #   +0 tiles_m  +4 tiles_n  +8 group_m  +12 rows of the last group  +16 magic(group_m * tiles_n)  +20 magic(group_m)
@@ -167,6 +180,7 @@ class Gen:
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
         self.s_csC4 = None if c.conv else S()      # column stride of C in bytes (KA_EPI + 12; 0 in the arguments = dense)
+        self.s_preA, self.s_preB = (S(2, align=2), S(2, align=2)) if c.pre else (None, None)   # lane masks: all ones = apply relu
         self.alloc_sched()
         # accumulators
         self.acc = [p.aalloc(c.ACCR) for _ in range(c.NB)]
@@ -598,6 +612,13 @@ class Gen:
                 e("s_add_u32", ptr[0], ptr[0], st[2])
                 e("s_addc_u32", ptr[1], ptr[1], st[3])
         e("s_waitcnt", lgkmcnt=0)
+        if c.pre:
+            e("s_load_dword", st[2], s(0, 2), KA_PRE)
+            e("s_waitcnt", lgkmcnt=0)
+            for bit, m in ((0, self.s_preA), (1, self.s_preB)):
+                e("s_bitcmp1_b32", st[2], bit)
+                e("s_cselect_b32", m[0], -1, 0)
+                e("s_cselect_b32", m[1], -1, 0)
         if c.debug:
             e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
             e("s_waitcnt", lgkmcnt=0)
@@ -1147,11 +1168,28 @@ class Gen:
                 e(*o)
         return ops
 
+    def pre_op(self, regs, mask):
+        """fused prologue: the staged elements become (mask ? max(x, 0) : x) before they are stored -- all of a piece's VALU work in one
+        gap (the first VALU instruction of a gap costs ~11 cycles of matrix-pipe time, every further one ~4)"""
+        if not self.c.pre:
+            return []
+        tmp = [self.vt[4 + j] for j in range(4)]       # (free in the K loop: the fold uses vt[0..3] and vT)
+
+        def emit():
+            e = self.p.emit
+            for j, r in enumerate(regs):
+                e("v_max_f32", tmp[j % 4], 0, r)
+            for j, r in enumerate(regs):
+                e("v_cndmask_b32", r, r, tmp[j % 4], mask)
+        assert len(regs) <= 4
+        return [("call", emit)]
+
     def store_A_piece(self, pi, ops=None, k=0):
         """piece = 4 consecutive k (e0 e1 e2 e3) of one row: (e0, e2) -> chunk of MFMA half 0, (e1, e3) -> half 1"""
         out = []
         r = self.stA[pi]
         out.append(("vmwait", ("A", pi)))
+        out += self.pre_op([r[j] for j in range(4)], self.s_preA)
         # ds_write2_b32 takes its two dwords from two independent registers: no repacking VALU op (a v_swap on freshly
         # loaded registers cost 16 cycles of matrix-pipe time per piece, profiles/r03/asm_probe_v7.jsonl); the price is one
         # address register per (piece, half, stage)
@@ -1166,6 +1204,7 @@ class Gen:
         out = []
         r = self.stB[pj]
         out.append(("vmwait", ("B", pj)))
+        out += self.pre_op([r[j] for j in range(4)], self.s_preB)
         out.append(("ldsw", "ds_write2_b32", (self.WB[0][pj][k], r[0], r[2]), {"offset0": 0, "offset1": 1}))
         out.append(("ldsw", "ds_write2_b32", (self.WB[1][pj][k], r[1], r[3]), {"offset0": 0, "offset1": 1}))
         if ops is None:
@@ -1213,6 +1252,8 @@ class Gen:
         out = []
         P, Q = self.stB[2 * gi], self.stB[2 * gi + 1]
         out.append(("vmwait", ("B", 2 * gi + 1)))
+        out += self.pre_op([P[j] for j in range(4)], self.s_preB)
+        out += self.pre_op([Q[j] for j in range(4)], self.s_preB)
         if self.c.b_store == "write2":
             for ee in range(4):
                 out.append(("ldsw", "ds_write2_b32", (self.WB[gi][ee][k], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
@@ -1381,8 +1422,8 @@ class Gen:
         # waits ride with the op that follows them
         units = []
         for op in stg:
-            if units and units[-1][-1][0] in ("vmwait",):
-                units[-1].append(op)
+            if units and (units[-1][-1][0] in ("vmwait",) or (op[0] == "call" and units[-1][-1][0] == "call")):
+                units[-1].append(op)        # (a wait, and a fused prologue's VALU batch, ride with the op that follows / precedes them)
             else:
                 units.append([op])
         if c.conv:

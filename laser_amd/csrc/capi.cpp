@@ -327,8 +327,41 @@ hipError_t run_gemm_peeled(const GemmArgs<T> &a, int kc, bool laser, bool *taken
   return e == hipErrorNotSupported ? hipErrorInvalidValue : e;
 }
 
+// Fused prologue on a path that has no kernel for it: the operand is materialised once (relu applied while it is copied into a
+// dense row-major scratch matrix -- "during the prepacking", README.md:243-244) and the plain problem runs on it.
+template <typename T>
+hipError_t run_gemm_prologue_materialised(const GemmArgs<T> &a, hipStream_t s) {
+  if (a.batch != 1 || a.Mext != a.M || a.Next != a.N || a.Kext != a.K) return hipErrorInvalidValue;
+  const size_t nA = a.preA ? (size_t)a.M * a.K : 0, nB = a.preB ? (size_t)a.K * a.N : 0;
+  if (nA + nB == 0) return hipErrorInvalidValue;
+  T *scratch = nullptr;
+  hipError_t e = hipMallocAsync((void **)&scratch, (nA + nB) * sizeof(T), s);
+  if (e != hipSuccess) return e;
+  GemmArgs<T> b = a;
+  b.preA = b.preB = 0;
+  if (a.preA) {
+    e = launch_pack_pad<T>(scratch, a.M, a.K, a.A, a.M, a.K, a.rsA, a.csA, s, 1);
+    b.A = scratch; b.rsA = a.K; b.csA = 1;
+  }
+  if (e == hipSuccess && a.preB) {
+    e = launch_pack_pad<T>(scratch + nA, a.K, a.N, a.B, a.K, a.N, a.rsB, a.csB, s, 1);
+    b.B = scratch + nA; b.rsB = a.N; b.csB = 1;
+  }
+  if (e == hipSuccess) e = run_gemm<T>(b, s);
+  const hipError_t e2 = hipFreeAsync(scratch, s);
+  return e != hipSuccess ? e : e2;
+}
+
 template <>
 hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
+  if (a.preA || a.preB) {      // the `_pre` assembly kernels (relu in the staging registers), else one materialising pass
+    if (f32_cfg_now() < 0) {
+      const hipError_t e = launch_gemm_f32_asm(a, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, s);
+      if (e != hipErrorNotSupported) return e;
+    }
+    g_last_f32_asm = 0;
+    return run_gemm_prologue_materialised<float>(a, s);
+  }
   if (f32_cfg_now() < 0) {
     bool taken;
     const hipError_t e = run_gemm_peeled<float>(a, 512, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, &taken, s);
@@ -338,6 +371,7 @@ hipError_t run_gemm<float>(const GemmArgs<float> &a, hipStream_t s) {
 }
 template <>
 hipError_t run_gemm<double>(const GemmArgs<double> &a, hipStream_t s) {
+  if (a.preA || a.preB) return run_gemm_prologue_materialised<double>(a, s);
   if (g_ctx.f64_mfma) {
     bool taken;
     const hipError_t e = run_gemm_peeled<double>(a, 256, g_ctx.float_mode == LASER_HIP_F32_LASER_ORDER, &taken, s);
@@ -504,7 +538,19 @@ struct Epi {
   const T *bias = nullptr;
   int64_t rs = 0, cs = 0, bs = 0;
   int act = 0;
+  int pre = 0;     // fused prologue: bit 0 = relu on A's elements, bit 1 = relu on B's (LASER_HIP_PRE_RELU_A / _B >> 8)
+  bool on() const { return bias != nullptr || act != 0 || pre != 0; }
 };
+// the `activation` argument of the _ex_ entry points: low byte = activation, bits 8 / 9 = fused prologue
+template <typename T>
+Epi<T> make_epi(const T *bias, int64_t rs, int64_t cs, int act) {
+  Epi<T> e;
+  e.bias = bias; e.rs = rs; e.cs = cs;
+  e.act = act & 0xff;
+  e.pre = (act >> 8) & 3;
+  if (act & ~0x3ff) e.act = -1;      // unknown bits: rejected by epi_check
+  return e;
+}
 template <typename T>
 int epi_check(const Epi<T> *e) {
   if (!e) return LASER_HIP_OK;
@@ -518,6 +564,7 @@ template <typename T>
 void epi_apply(GemmArgs<T> &a, const Epi<T> *e) {
   if (!e) return;
   a.bias = e->bias; a.rsBias = e->rs; a.csBias = e->cs; a.bsBias = e->bs; a.act = e->act;
+  a.preA = e->pre & 1; a.preB = (e->pre >> 1) & 1;
 }
 
 template <typename T>
@@ -778,7 +825,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   // laser_hip_set_shard_devices(n != 1): a large plain gemm_strided call is cut into row ranges over n GPUs (rows of
   // C are independent, gemm.nim:160-176, so the arithmetic is unchanged).  Not for calls that already ARE a shard
   // (tl_device set by the sharded entry point's worker thread) and not worth it below ~4 tile rows per GPU.
-  if (g_ctx.shard_devices != 1 && tl_device < 0 && !(hepi && (hepi->bias || hepi->act))) {
+  if (g_ctx.shard_devices != 1 && tl_device < 0 && !(hepi && hepi->on())) {
     int ndev = g_ctx.shard_devices;
     if (ndev <= 0 && hipGetDeviceCount(&ndev) != hipSuccess) ndev = 1;
     if (ndev > 1 && M >= (int64_t)1024 * ndev && (double)M * (double)N * (double)K >= 64.0 * 1024 * 1024 * 1024)
@@ -795,7 +842,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t ab = up(an * sizeof(T)), bb = up(bn * sizeof(T)), cb = up(cn * sizeof(T));
-    const bool has_epi = hepi && (hepi->bias || hepi->act);
+    const bool has_epi = hepi && hepi->on();
     if (!has_epi && f32_cfg_now() < 0 && ab + bb + cb <= kZeroCopyMax && gemm_small_takes((int)sizeof(T), M, N, K, 1, true) &&
         std::is_floating_point<T>::value) {
       // completion flags, one per workgroup (= per 32x32 / 16x16 block of C; at most 256 by the dispatch rule), behind C
@@ -861,7 +908,7 @@ int gemm_host(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA,
   const bool panels_disjoint = rsA > 0 && rsC > 0 && rsA >= iabs(csA) * (K - 1) + 1 && rsC >= iabs(csC) * (N - 1) + 1;
   // fused epilogue: hepi->bias is a HOST view here; its span goes to the device next to the operands
   Epi<T> depi;
-  const bool fused = hepi && (hepi->bias || hepi->act);
+  const bool fused = hepi && hepi->on();
   if (fused) {
     depi = *hepi;
     if (hepi->bias) {
@@ -1646,16 +1693,14 @@ int laser_hip_conv2d_im2col_ex_f32(float *out, const float *in, int64_t iN, int6
                                       int64_t csA, const T *B, int64_t rsB, int64_t csB, T beta, T *C,        \
                                       int64_t rsC, int64_t csC, const T *bias, int64_t rsBias,                \
                                       int64_t csBias, int act) {                                              \
-    Epi<T> e;                                                                                                 \
-    e.bias = bias; e.rs = rsBias; e.cs = csBias; e.act = act;                                                 \
+    const Epi<T> e = make_epi<T>(bias, rsBias, csBias, act);                                                  \
     return gemm_host<T>(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, C, rsC, csC, &e);                     \
   }                                                                                                           \
   int laser_hip_gemm_strided_ex_##SFX##_dev(int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, \
                                             int64_t csA, const T *B, int64_t rsB, int64_t csB, T beta, T *C,  \
                                             int64_t rsC, int64_t csC, const T *bias, int64_t rsBias,          \
                                             int64_t csBias, int act, void *stream) {                          \
-    Epi<T> e;                                                                                                 \
-    e.bias = bias; e.rs = rsBias; e.cs = csBias; e.act = act;                                                 \
+    const Epi<T> e = make_epi<T>(bias, rsBias, csBias, act);                                                  \
     return gemm_dev<T>(1, M, N, K, alpha, A, rsA, csA, 0, B, rsB, csB, 0, beta, C, rsC, csC, 0, stream, &e);  \
   }
 LH_DEF_GEMM_EX(f32, float)

@@ -70,6 +70,11 @@ struct GemmArgs {
   // paying a stream synchronise.
   uint32_t *done_flags;
   uint32_t done_seq;
+  // Fused prologue (README.md:243-244: "fuse operations before the matrix multiplication kernel, during the prepacking"): relu
+  // (x > 0 ? x : 0) applied to the elements of A / of B as they are read.  Only run_gemm and the assembly launcher look at these:
+  // run_gemm either hands the problem to the `_pre` assembly kernels (the operation happens in the staging registers, on the way
+  // into the LDS panel image) or materialises the operand once and clears the flag.
+  int32_t preA, preB;
 };
 
 // How an operand tile is brought from HBM into its LDS panel image (the GPU analogue of
@@ -191,6 +196,6 @@ hipError_t launch_map_strided(int op, int nin, T *dst, const int64_t *dstrides, 
                               const int64_t *bstrides, const int64_t *shape, int rank, T alpha, T beta, hipStream_t s);
 template <typename T>
 hipError_t launch_pack_pad(T *dst, int64_t Rpad, int64_t Cpad, const T *src, int64_t R,
-                           int64_t Ccols, int64_t rs, int64_t cs, hipStream_t s);
+                           int64_t Ccols, int64_t rs, int64_t cs, hipStream_t s, int relu = 0);
 
 }  // namespace laser_hip

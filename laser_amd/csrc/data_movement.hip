@@ -189,30 +189,32 @@ hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in,
 template <typename T>
 __global__ void __launch_bounds__(256) pack_pad_kernel(T *__restrict__ dst, int64_t Rpad, int64_t Cpad,
                                                        const T *__restrict__ src, int64_t R, int64_t Cc,
-                                                       int64_t rs, int64_t cs) {
+                                                       int64_t rs, int64_t cs, int relu) {
   const int64_t total = Rpad * Cpad;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / Cpad, c = e % Cpad;
-    dst[e] = (r < R && c < Cc) ? src[r * rs + c * cs] : (T)0;
+    T x = (r < R && c < Cc) ? src[r * rs + c * cs] : (T)0;
+    if (relu) x = x > (T)0 ? x : (T)0;      // a fused prologue materialised (operands the `_pre` kernels do not take)
+    dst[e] = x;
   }
 }
 
 template <typename T>
 hipError_t launch_pack_pad(T *dst, int64_t Rpad, int64_t Cpad, const T *src, int64_t R, int64_t Cc,
-                           int64_t rs, int64_t cs, hipStream_t s) {
+                           int64_t rs, int64_t cs, hipStream_t s, int relu) {
   const int64_t total = Rpad * Cpad;
   if (total <= 0) return hipSuccess;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(pack_pad_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, dst, Rpad, Cpad, src, R,
-                     Cc, rs, cs);
+                     Cc, rs, cs, relu);
   return hipGetLastError();
 }
-template hipError_t launch_pack_pad<float>(float *, int64_t, int64_t, const float *, int64_t, int64_t, int64_t, int64_t, hipStream_t);
-template hipError_t launch_pack_pad<double>(double *, int64_t, int64_t, const double *, int64_t, int64_t, int64_t, int64_t, hipStream_t);
-template hipError_t launch_pack_pad<int32_t>(int32_t *, int64_t, int64_t, const int32_t *, int64_t, int64_t, int64_t, int64_t, hipStream_t);
-template hipError_t launch_pack_pad<int64_t>(int64_t *, int64_t, int64_t, const int64_t *, int64_t, int64_t, int64_t, int64_t, hipStream_t);
+template hipError_t launch_pack_pad<float>(float *, int64_t, int64_t, const float *, int64_t, int64_t, int64_t, int64_t, hipStream_t, int);
+template hipError_t launch_pack_pad<double>(double *, int64_t, int64_t, const double *, int64_t, int64_t, int64_t, int64_t, hipStream_t, int);
+template hipError_t launch_pack_pad<int32_t>(int32_t *, int64_t, int64_t, const int32_t *, int64_t, int64_t, int64_t, int64_t, hipStream_t, int);
+template hipError_t launch_pack_pad<int64_t>(int64_t *, int64_t, int64_t, const int64_t *, int64_t, int64_t, int64_t, int64_t, hipStream_t, int);
 
 // ---- rank-N strided copy: `forEachStrided d in dst, s in src: d = s` -----------------------------
 // (laser/tensor/initialization.nim:42-110: deepCopy / copyFrom of non-contiguous tensors.)  HBM-bound.

@@ -60,7 +60,9 @@ struct KernelInfo {
 // [29]: int64 via eight int8 limb planes (i8_kernel.py "i64_64x64x32")
 // [30..33]: 128x128 tiles with a 32-deep K-tile, one workgroup per CU (laser-order / one chain, plain / B transposed): one round of
 // 129 .. 256 tiles, where a workgroup has its CU to itself
-constexpr int kNumKernels = 34;
+// [34..45]: fused prologue (relu on A's and / or B's elements in the staging registers): `_pre` variants of [0] [4] [1] [5] [2] [6] [3]
+// [7] [12] [14] [13] [15], one tile per workgroup
+constexpr int kNumKernels = 46;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0, 1},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0, 1},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0, 2},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0, 2},
@@ -79,7 +81,21 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0, 2},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0, 2},
     {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0, 1},
     {"lh_f32_exact_128x128x32", 128, 128, 32, 0.92, 0.90, 7.0, 1},       {"lh_f32_fast_128x128x32", 128, 128, 32, 0.93, 0.91, 7.0, 1},
-    {"lh_f32_exact_128x128x32_nt", 128, 128, 32, 0.92, 0.90, 7.0, 1},    {"lh_f32_fast_128x128x32_nt", 128, 128, 32, 0.93, 0.91, 7.0, 1}};
+    {"lh_f32_exact_128x128x32_nt", 128, 128, 32, 0.92, 0.90, 7.0, 1},    {"lh_f32_fast_128x128x32_nt", 128, 128, 32, 0.93, 0.91, 7.0, 1},
+    {"lh_f32_exact_256x128x32_pre", 256, 128, 32, 0.92, 0.92, 10.0, 1},  {"lh_f32_exact_256x128x32_pre_nt", 256, 128, 32, 0.92, 0.92, 10.0, 1},
+    {"lh_f32_fast_256x256x16_pre", 256, 256, 16, 0.93, 0.93, 12.0, 1},   {"lh_f32_fast_256x256x16_pre_nt", 256, 256, 16, 0.93, 0.93, 12.0, 1},
+    {"lh_f32_exact_128x128x16_pre", 128, 128, 16, 0.90, 0.86, 6.0, 2},   {"lh_f32_exact_128x128x16_pre_nt", 128, 128, 16, 0.90, 0.86, 6.0, 2},
+    {"lh_f32_fast_128x128x16_pre", 128, 128, 16, 0.91, 0.87, 6.0, 2},    {"lh_f32_fast_128x128x16_pre_nt", 128, 128, 16, 0.91, 0.87, 6.0, 2},
+    {"lh_f32_exact_64x64x32_pre", 64, 64, 32, 0.84, 0.74, 3.0, 3},       {"lh_f32_exact_64x64x32_pre_nt", 64, 64, 32, 0.84, 0.74, 3.0, 3},
+    {"lh_f32_fast_64x64x32_pre", 64, 64, 32, 0.85, 0.76, 3.0, 3},        {"lh_f32_fast_64x64x32_pre_nt", 64, 64, 32, 0.85, 0.76, 3.0, 3}};
+// plain kernel -> its `_pre` variant (-1: none)
+int pre_variant(int k) {
+  switch (k) {
+    case 0: return 34; case 4: return 35; case 1: return 36; case 5: return 37; case 2: return 38; case 6: return 39;
+    case 3: return 40; case 7: return 41; case 12: return 42; case 14: return 43; case 13: return 44; case 15: return 45;
+    default: return -1;
+  }
+}
 constexpr int kCUs = 256;
 
 // Workspace of the cut launches of ONE stream on one device: partial tiles + their flags (all flags are zero between launches: the
@@ -412,17 +428,21 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
   const double cu_flops_per_us = 157.3e6 / 256.0;
   // the one-chain kernels' fused epilogue has no C read: beta != 0 with a bias / activation only on the laser-order kernels
   const auto lo_kernel = [](int k) { return k == 0 || k == 2 || k == 4 || k == 6 || k == 12 || k == 14 || k == 30 || k == 32; };
-  for (int k : {big, mid, small, deep, tiny}) {
-    if (k < 0 || (g_asm_kernel >= 0 && k != g_asm_kernel)) continue;
-    if (fused && !lo_kernel(k) && a.beta != 0.0f) continue;
+  const bool pre = a.preA != 0 || a.preB != 0;
+  for (int k0 : {big, mid, small, deep, tiny}) {
+    if (k0 < 0 || (g_asm_kernel >= 0 && k0 != g_asm_kernel)) continue;
+    if (fused && !lo_kernel(k0) && a.beta != 0.0f) continue;
+    const int k = pre ? pre_variant(k0) : k0;       // fused prologue: the variants that apply it in the staging registers
+    if (k < 0) continue;
     const KernelInfo &ki_ = kKernels[k];
     const int64_t tm = (a.M + ki_.bm - 1) / ki_.bm, tn = (a.N + ki_.bn - 1) / ki_.bn, t = tm * tn;
     if ((double)t * 8.0 * (double)tn >= 4.0e9) continue;    // the in-kernel tile arithmetic's range (fill_sched)
     // below ~5/8 of a round of the larger tiles (3/8 of the 64x64 ones) the compiler-scheduled kernels' slice-parallel and
     // small-problem forms do better
-    if (g_f32_asm < 2 && t * a.batch < (k == tiny ? 96 : 160)) continue;
-    // (laser-order with K <= kc is ONE chain that must stay one chain: cuts only at kc boundaries, or anywhere in one-chain mode)
-    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 512, cu_flops_per_us, exact || !laser_order);
+    if (g_f32_asm < 2 && t * a.batch < (k0 == tiny ? 96 : 160)) continue;
+    // (laser-order with K <= kc is ONE chain that must stay one chain: cuts only at kc boundaries, or anywhere in one-chain mode;
+    // the `_pre` variants run one tile per workgroup)
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 512, cu_flops_per_us, (exact || !laser_order) && !pre);
     if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;   // (near ties go to the larger tile: less L2 traffic)
   }
   if (pick < 0) return hipErrorNotSupported;
@@ -460,6 +480,7 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
   ka.csBias = a.bias ? (uint32_t)a.csBias : 0;
   ka.act = (uint32_t)a.act;
   ka.csC = a.csC == 1 ? 0u : (uint32_t)a.csC;
+  ka.pad_ = (a.preA ? 1u : 0u) | (a.preB ? 2u : 0u);      // f32_kernel.py KA_PRE (read by the `_pre` variants only)
   e = launch_planned(m, pick, plan, ka, tiles_m, tiles_n, group_m, a.batch, (size_t)ki.bm * ki.bn * 4, s);
   if (e == hipErrorNotSupported && plan.persistent) {   // no workspace (a stream being captured, ...): one tile per workgroup
     Plan plain = plan_launch(ki, (int64_t)tiles_m * tiles_n, a.K, a.batch, exact, 512, cu_flops_per_us, false);
@@ -495,6 +516,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hi
     a.B = pa;  a.rsB = csa;   a.csB = rsa;
     std::swap(a.rsC, a.csC);
     std::swap(a.rsBias, a.csBias);
+    std::swap(a.preA, a.preB);
   }
   const bool packA = a.csA != 1, packB = a.csB != 1 && a.rsB != 1;
   if (!packA && !packB) return launch_gemm_f32_asm_core(a, laser_order, s);
@@ -510,14 +532,15 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hi
   hipError_t e = hipMallocAsync((void **)&scratch, bytesA + bytesB, s);
   if (e != hipSuccess) return e;
   if (packA) {      // A[m][k] at m * rsA + k * csA -> dense [M][K]
-    e = a.rsA == 1 ? launch_transpose_pitched(scratch, a.K, a.A, a.csA, a.K, a.M, 4, s)      // the source is a K x M row-major matrix (pitch csA)
-                   : launch_pack_pad<float>(scratch, a.M, a.K, a.A, a.M, a.K, a.rsA, a.csA, s);
-    a.A = scratch; a.rsA = a.K; a.csA = 1;
+    // (a fused prologue on a packed operand happens in the packing pass -- "during the prepacking", README.md:243-244)
+    e = (a.rsA == 1 && !a.preA) ? launch_transpose_pitched(scratch, a.K, a.A, a.csA, a.K, a.M, 4, s)      // the source is a K x M row-major matrix (pitch csA)
+                                : launch_pack_pad<float>(scratch, a.M, a.K, a.A, a.M, a.K, a.rsA, a.csA, s, a.preA);
+    a.A = scratch; a.rsA = a.K; a.csA = 1; a.preA = 0;
   }
   if (e == hipSuccess && packB) {      // neither stride of B is 1: dense [K][N]
     float *sb = scratch + bytesA / 4;
-    e = launch_pack_pad<float>(sb, a.K, a.N, a.B, a.K, a.N, a.rsB, a.csB, s);
-    a.B = sb; a.rsB = a.N; a.csB = 1;
+    e = launch_pack_pad<float>(sb, a.K, a.N, a.B, a.K, a.N, a.rsB, a.csB, s, a.preB);
+    a.B = sb; a.rsB = a.N; a.csB = 1; a.preB = 0;
   }
   if (e == hipSuccess) e = launch_gemm_f32_asm_core(a, laser_order, s);
   const hipError_t e2 = hipFreeAsync(scratch, s);

@@ -213,13 +213,17 @@ def _activation_code(activation):
         raise ValueError(f"unknown activation {activation!r} (one of {sorted(k for k in ACTIVATIONS if k)})")
 
 
+PRE_RELU_A, PRE_RELU_B = 0x100, 0x200      # include/laser_hip.h LASER_HIP_PRE_RELU_A / _B: ORed into the activation code
+
+
 def gemm_strided(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta, C_,
-                 rowStrideC, colStrideC, bias=None, rowStrideBias=0, colStrideBias=0, activation=None):
+                 rowStrideC, colStrideC, bias=None, rowStrideBias=0, colStrideBias=0, activation=None, pre=0):
     """C <- alpha*A*B + beta*C, element X[r,c] at X_ptr[r*rowStride + c*colStride].
 
     Fused epilogue (what the reference plans, README.md:238-242): with `bias` (a strided M x N view whose
     strides may be 0) and/or `activation` ("relu" | "tanh" | "sigmoid"),
-    C <- act(alpha*A*B + beta*C + bias), applied once on the accumulator before the store; float32/float64."""
+    C <- act(alpha*A*B + beta*C + bias), applied once on the accumulator before the store; float32/float64.
+    Fused prologue (README.md:243-244): pre = PRE_RELU_A and / or PRE_RELU_B takes the product of relu(A) / relu(B)."""
     L = _lib.lib()
     s = _sfx(C_)
     if _sfx(A) != s or _sfx(B) != s:
@@ -227,7 +231,7 @@ def gemm_strided(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colSt
     ct = _lib.ctype_of(s)
     args = [M, N, K, ct(alpha), _ptr(A), rowStrideA, colStrideA, _ptr(B), rowStrideB, colStrideB,
             ct(beta), _ptr(C_), rowStrideC, colStrideC]
-    act = _activation_code(activation)
+    act = _activation_code(activation) | int(pre)
     if bias is not None or act:
         if s not in ("f32", "f64"):
             raise TypeError("the fused epilogue is float32/float64 only")
@@ -267,7 +271,7 @@ def _estrides(x):
     return tuple(st // x.dtype.itemsize for st in x.strides)
 
 
-def matmul(A, B, alpha=1, beta=0, out=None, bias=None, activation=None):
+def matmul(A, B, alpha=1, beta=0, out=None, bias=None, activation=None, pre=0):
     """Convenience over gemm_strided for 2-D views of any strides (numpy or torch.cuda).
     `bias`: a vector of N values (one per column, a dense layer's bias) or an (M, N) / broadcastable 2-D view."""
     M, K = A.shape
@@ -293,7 +297,7 @@ def matmul(A, B, alpha=1, beta=0, out=None, bias=None, activation=None):
                 raise ValueError("bias does not broadcast to (M, N)")
             rb, cb = _estrides(bias)
             rb, cb = (rb if r_ == M and M > 1 else 0), (cb if c_ == N and N > 1 else 0)
-    gemm_strided(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, out, rsC, csC, bias, rb, cb, activation)
+    gemm_strided(M, N, K, alpha, A, rsA, csA, B, rsB, csB, beta, out, rsC, csC, bias, rb, cb, activation, pre)
     return out
 
 
@@ -469,7 +473,7 @@ def conv2d_im2col(output, oshape, input_, ishape, kernel, kshape, padding, strid
     _f32_dense("pworkspace", pworkspace, im2col_workspace_size(ishape, kshape, padding, strides))   # ONE image's worth (the reference's contract)
     _f32_dense("bias", bias, kshape[0])
     args = [_ptr(output), _ptr(input_), *ishape, _ptr(kernel), *kshape, *padding, *strides, _ptr(pworkspace)]
-    act = _activation_code(activation)
+    act = _activation_code(activation) | int(pre)
     if bias is not None or act:
         if bias is not None and math.prod(bias.shape) != kshape[0]:
             raise ValueError("bias must hold c_out values")

@@ -136,6 +136,10 @@ proc gemm_strided*[T: SomeNumber](
 # C = act(alpha*A*B + beta*C + bias); bias is a strided M x N view whose strides may be 0.
 type Activation* = enum
   actNone = 0, actRelu = 1, actTanh = 2, actSigmoid = 3
+# fused PROLOGUE -- "fuse operations before the matrix multiplication kernel, during the prepacking" (README.md:243-244):
+# the product is taken of relu(A) and / or relu(B); the bits travel in the activation argument (LASER_HIP_PRE_RELU_A / _B)
+type Prologue* = enum
+  preNone = 0, preReluA = 0x100, preReluB = 0x200, preReluAB = 0x300
 
 proc gemm_strided_fused*[T: float32 or float64](
       M, N, K: int, alpha: T,
@@ -144,13 +148,14 @@ proc gemm_strided_fused*[T: float32 or float64](
       beta: T,
       C: ptr T, rowStrideC, colStrideC: int,
       bias: ptr T, rowStrideBias, colStrideBias: int,
-      activation = actNone) =
+      activation = actNone, prologue = preNone) =
+  let code = cint(ord(activation) or ord(prologue))
   when T is float32:
     check laser_hip_gemm_strided_ex_f32(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta,
-                                        C, rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, cint(activation))
+                                        C, rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, code)
   else:
     check laser_hip_gemm_strided_ex_f64(M, N, K, alpha, A, rowStrideA, colStrideA, B, rowStrideB, colStrideB, beta,
-                                        C, rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, cint(activation))
+                                        C, rowStrideC, colStrideC, bias, rowStrideBias, colStrideBias, code)
 
 # ---- pre-packed GEMM -- gemm_prepacked.nim:76-292 -----------------------------------------------
 proc gemm_prepackB_mem_required*(T: type, M, N, K: int): int =

@@ -59,6 +59,15 @@ GEMM_CASES += [
     ("fast_256x256x16", 40, 300, 72, dict(csc=2, alpha=3.0, beta=0.5)),
     ("exact_64x64x32", 70, 90, 100, dict(csc=2, bias="row", act=1)),
 ]
+# fused prologue (README.md:243-244): relu on A's / B's elements in the staging registers of the `_pre` variants (pre: bit 0 = A, 1 = B)
+GEMM_CASES += [
+    ("exact_64x64x32_pre", 70, 90, 548, dict(pre=1)),
+    ("exact_64x64x32_pre", 70, 90, 548, dict(pre=2, alpha=0.5, beta=2.0)),
+    ("exact_64x64x32_pre_nt", 70, 90, 550, dict(pre=3, lda=552, ldb=556)),
+    ("exact_64x64x32_pre", 70, 90, 100, dict(pre=0)),
+    ("fast_256x256x16_pre", 70, 300, 72, dict(pre=3)),
+    ("fast_128x128x16_pre", 140, 130, 50, dict(pre=2, bias="row", act=1)),
+]
 # C = beta * C0 + alpha * A B: the running sum starts as beta * C0, every slice is scaled before it is added
 GEMM_CASES += [
     ("exact_256x128x32", 70, 90, 1060, dict(alpha=0.75, beta=-1.5, ldc=100)),

@@ -241,6 +241,52 @@ def test_full_size_c3_transposed_b_dense_c_every_element(la, oracle):
     assert np.array_equal(C.cpu().numpy(), oracle.matmul(Ah, np.ascontiguousarray(Bt.T)))
 
 
+def test_fused_prologue_relu_on_a_and_b(la, oracle):
+    """README.md:243-244 (the reference's roadmap): an operation fused BEFORE the product -- relu(A) and / or relu(B), applied in the
+    staging registers of the `_pre` assembly kernels (kernel indices 35..46), in the packing pass of a strided operand, or
+    materialised for paths without a kernel (float64) -- C = act(alpha relu(A) relu(B) + beta C + bias), bit-exact against the
+    oracle run on operands with relu applied on the host, both accumulation orders' kernels, B plain and transposed."""
+    import torch
+    rng = np.random.default_rng(321)
+    relu = lambda x: np.where(x > 0, x, 0).astype(x.dtype)
+    for (M, N, K), nt in (((1100, 1300, 1500), False), ((2048, 2048, 1030), True), ((520, 700, 600), False)):
+        Ah, Bh = _rnd(rng, (M, K)), _rnd(rng, (K, N))
+        A = torch.from_numpy(Ah).cuda()
+        B = torch.from_numpy(np.ascontiguousarray(Bh.T)).cuda().t() if nt else torch.from_numpy(Bh).cuda()
+        C0 = _rnd(rng, (M, N))
+        bias = _rnd(rng, (N,))
+        for pre in (la.PRE_RELU_A, la.PRE_RELU_B, la.PRE_RELU_A | la.PRE_RELU_B):
+            for mode in (0, 1):
+                la.set_float_mode(mode)
+                try:
+                    C = torch.from_numpy(C0.copy()).cuda()
+                    la.matmul(A, B, 0.5, 0.25, C, bias=torch.from_numpy(bias).cuda(), activation="relu", pre=pre)
+                    used = la.last_f32_asm()
+                finally:
+                    la.set_float_mode(0)
+                assert 35 <= used <= 46, (M, N, K, pre, mode, used)
+                Ar, Br = (relu(Ah) if pre & la.PRE_RELU_A else Ah), (relu(Bh) if pre & la.PRE_RELU_B else Bh)
+                if mode == 0:
+                    want = relu((oracle.matmul(Ar, Br, 0.5, 0.25, C0.copy()) + bias[None, :]).astype(np.float32))
+                    assert np.array_equal(C.cpu().numpy(), want), (M, N, K, pre)
+                else:
+                    want = np.maximum(0.5 * (Ar.astype(np.float64) @ Br.astype(np.float64)) + 0.25 * C0 + bias[None, :], 0)
+                    assert np.allclose(C.cpu().numpy(), want, rtol=1e-4, atol=1e-5), (M, N, K, pre)
+    # a strided A (every second column): the prologue happens in the packing pass; float64: materialised
+    Ah2 = _rnd(rng, (1100, 3000))
+    A2 = torch.from_numpy(Ah2).cuda()[:, ::2]
+    Bh = _rnd(rng, (1500, 1300))
+    C = la.matmul(A2, torch.from_numpy(Bh).cuda(), pre=la.PRE_RELU_A)
+    assert la.last_f32_asm() != 0
+    assert np.array_equal(C.cpu().numpy(), oracle.matmul(relu(np.ascontiguousarray(Ah2[:, ::2])), Bh))
+    Ad, Bd = _rnd(rng, (300, 400), np.float64), _rnd(rng, (400, 500), np.float64)
+    Cd = la.matmul(torch.from_numpy(Ad).cuda(), torch.from_numpy(Bd).cuda(), pre=la.PRE_RELU_A | la.PRE_RELU_B)
+    assert np.array_equal(Cd.cpu().numpy(), oracle.matmul(relu(Ad), relu(Bd)))
+    # host-pointer entry point
+    Ch = la.matmul(Ah2[:, :1500].copy(), Bh, pre=la.PRE_RELU_B)
+    assert np.array_equal(Ch, oracle.matmul(Ah2[:, :1500].copy(), relu(Bh)))
+
+
 def test_no_fix_up_ever_gave_up_waiting(la):
     """(last in this file) the error word in front of every stream's flags: a fix-up that polled for ~2 s without seeing its partial
     would have counted itself here -- a lost release or a scheduling order the design does not allow"""
