@@ -473,7 +473,7 @@ def conv2d_im2col(output, oshape, input_, ishape, kernel, kshape, padding, strid
     _f32_dense("pworkspace", pworkspace, im2col_workspace_size(ishape, kshape, padding, strides))   # ONE image's worth (the reference's contract)
     _f32_dense("bias", bias, kshape[0])
     args = [_ptr(output), _ptr(input_), *ishape, _ptr(kernel), *kshape, *padding, *strides, _ptr(pworkspace)]
-    act = _activation_code(activation) | int(pre)
+    act = _activation_code(activation)
     if bias is not None or act:
         if bias is not None and math.prod(bias.shape) != kshape[0]:
             raise ValueError("bias must hold c_out values")
