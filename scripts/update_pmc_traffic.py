@@ -29,7 +29,7 @@ def main():
             per[kern]["_grid"] = int(g.group(1))
             per[kern]["_dispatches"] = int(g.group(2))
     import bench
-    out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 10 --warmup 3 "
+    out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 20 --warmup 10 "
                     "--no-cpu-baseline --no-single-process` (8192^3 sgemm, headline launches only), per launch. Both counters are "
                     "reported in KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B for wide coalesced loads, "
                     "MI355X_MICROARCH.md HBM section); it counts L2 fabric-side requests, Infinity-Cache hits included. "
