@@ -1417,7 +1417,7 @@ def test_asm_kernels_fuzz_strides_offsets(la, oracle):
 
 
 def test_finalize_unloads_and_the_library_comes_back(la, oracle):
-    """laser_hip_finalize releases the per-device state -- scratch, streams, the assembly kernels' code objects and tile tables --
+    """laser_hip_finalize releases the per-device state -- scratch, streams, the assembly kernels' code objects and workspaces --
     and the next call re-initialises lazily: same results before and after."""
     import torch
     rng = np.random.default_rng(5150)
