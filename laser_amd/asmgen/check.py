@@ -61,13 +61,16 @@ def virtual_id(g, G, xcd):
     return (g % 8) * (G // 8) + min(g % 8, G % 8) + g // 8 if xcd and G >= 8 else g
 
 
+BANK_MODEL = True      # LDS bank-conflict statistics (the CPU test suite switches them off: a quarter of the interpreter's time)
+
+
 def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
     """every workgroup of a launch, one after the other: ascending virtual id, so that the running sum a workgroup receives (from the
     workgroup before it in unit order) is already in the workspace; returns the last workgroup's wave-0 statistics"""
     stats = None
     for bi in range(batch):
         for g in sorted(range(G), key=lambda g_: virtual_id(g_, G, xcd)):
-            w = Workgroup(prog, mem, ka_, wg_id=(g, bi), lds_bytes=lds_bytes)
+            w = Workgroup(prog, mem, ka_, wg_id=(g, bi), lds_bytes=lds_bytes, bank_model=BANK_MODEL)
             w.run(order=order)
             stats = w.waves[0].stats
     return stats

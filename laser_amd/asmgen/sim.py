@@ -106,8 +106,9 @@ class Wave:
 
 
 class Workgroup:
-    def __init__(self, prog, mem, kernarg_addr, wg_id=(0, 0), nwaves=4, lds_bytes=160 * 1024, check=True):
+    def __init__(self, prog, mem, kernarg_addr, wg_id=(0, 0), nwaves=4, lds_bytes=160 * 1024, check=True, bank_model=True):
         self.prog, self.mem = prog, mem
+        self.bank_model = bank_model
         self.ins = [i for i in prog.ins]
         self.labels = {i.args[0]: n for n, i in enumerate(self.ins) if i.op == "label"}
         self.lds = np.zeros(lds_bytes // 4, dtype=U32)
@@ -253,8 +254,9 @@ class Workgroup:
                     self.lds_w_wave[idx] = w.wid
                 else:
                     self.lds_r_epoch[w.wid][idx] = w.epoch
-        per_lane = [[int(wd[l]) + d for d in range(ndw)] for l in range(LANES)]
-        w.stats["bank_conflict_cycles"] += self._bank_cycles(per_lane, groups, nbanks, act)
+        if self.bank_model:      # (statistics only -- a quarter of the interpreter's time: the test suite runs without it)
+            per_lane = [[int(wd[l]) + d for d in range(ndw)] for l in range(LANES)]
+            w.stats["bank_conflict_cycles"] += self._bank_cycles(per_lane, groups, nbanks, act)
         w.stats["lds_ops"] += 1
         return wd
 

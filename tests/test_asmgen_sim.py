@@ -10,6 +10,8 @@ import pytest
 from laser_amd.asmgen import check as C
 from laser_amd.asmgen import f32_kernel as K
 
+C.BANK_MODEL = False      # (bank-conflict statistics are printed by the command-line checker, nothing here asserts on them)
+
 
 @pytest.mark.parametrize("name", sorted(K.CONFIGS))
 def test_every_config_generates_and_carries_its_queue_state(name):
@@ -96,19 +98,19 @@ SPLIT_CASES = [
     ("exact_64x64x32", 70, 90, 1100, dict(G=2, split=True)),                       # whole tiles + one cut tile per workgroup
     ("exact_64x64x32", 70, 90, 1100, dict(G=3, split=False)),                      # persistent, whole tiles only
     ("exact_64x64x32_nt", 130, 70, 1030, dict(G=11, split=True, lda=1033, ldb=1036, ldc=75, alpha=0.75, beta=-1.5, group_m=2, xcd=True)),
-    ("exact_64x64x32", 130, 70, 1540, dict(G=16, split=True, bias="row", act=1, xcd=True, group_m=2)),   # fused epilogue after the fix-up
-    ("exact_128x128x16_nt", 140, 130, 1031, dict(G=9, split=True, lda=1034, ldb=1036)),
-    ("exact_256x128x32", 300, 140, 1060, dict(G=5, split=True, alpha=0.75, beta=-1.5, ldc=150, group_m=1)),
+    ("exact_64x64x32", 130, 70, 1030, dict(G=16, split=True, bias="row", act=1, xcd=True, group_m=2)),   # fused epilogue after the fix-up
+    ("exact_128x128x16_nt", 140, 130, 519, dict(G=5, split=True, lda=522, ldb=524)),
+    ("exact_256x128x32", 260, 130, 600, dict(G=3, split=True, alpha=0.75, beta=-1.5, ldc=150, group_m=1)),
     ("exact_64x64x32", 70, 40, 1100, dict(G=4, split=True, alpha=-2.0, beta=1.0, noseed=1)),
     ("exact_64x64x32", 70, 90, 1100, dict(G=2, split=True, noseed=1)),
     ("exact_64x64x32", 70, 40, 2100, dict(G=9, split=True, noseed=1, beta=0.5)),              # ranges inside one tile: receive, then send on
     ("exact_64x64x32", 70, 40, 2100, dict(G=9, split=True)),
     ("exact_64x64x32_nt", 130, 70, 1030, dict(G=11, split=True, lda=1033, ldb=1036, ldc=75, alpha=0.75, beta=-1.5, group_m=2, xcd=True, noseed=1)),
-    ("exact_128x128x16", 140, 130, 1100, dict(G=7, split=True, noseed=1, bias="col", act=1)),
+    ("exact_128x128x16", 140, 130, 600, dict(G=5, split=True, noseed=1, bias="col", act=1)),
     ("fast_64x64x32", 70, 40, 600, dict(G=9, split=2, integer=True, beta=2.0)),                # one chain, ranges inside one tile
     # two-level ranges (what the launcher uses for every cut launch): XCD x = id % 8 owns whole tiles, its G / 8 workgroups share them
-    ("exact_64x64x32", 130, 200, 1100, dict(G=16, split=True, two_level=True, group_m=2, beta=0.5)),
-    ("exact_64x64x32", 130, 200, 1100, dict(G=16, split=True, two_level=True, group_m=2, beta=0.5, noseed=1)),
+    ("exact_64x64x32", 130, 200, 600, dict(G=16, split=True, two_level=True, group_m=2, beta=0.5)),
+    ("exact_64x64x32", 130, 200, 600, dict(G=16, split=True, two_level=True, group_m=2, beta=0.5, noseed=1)),
     ("exact_64x64x32", 130, 70, 1100, dict(G=8, split=True, two_level=True, noseed=1)),
     ("fast_64x64x32", 130, 200, 300, dict(G=24, split=2, integer=True, two_level=True)),
     ("fast_64x64x32", 70, 90, 300, dict(G=5, split=2, alpha=0.5, beta=2.0, integer=True)),
@@ -147,7 +149,7 @@ F64_SPLIT_CASES = [
     ("exact_64x64x16", 70, 80, 530, dict(lda=532, G=7, split=True, alpha=2.0, beta=0.5, xcd=True, group_m=1)),
     ("fast_64x64x16_nt", 70, 80, 150, dict(G=6, split=2, alpha=2.0, beta=0.5)),
     ("fast_128x128x16", 130, 70, 86, dict(G=3, split=2)),
-    ("exact_128x128x16", 130, 140, 520, dict(G=5, split=True, alpha=-1.0, beta=2.0)),
+    ("exact_128x128x16", 130, 140, 300, dict(G=5, split=True, alpha=-1.0, beta=2.0)),
     ("exact_64x64x16", 70, 80, 530, dict(lda=532, G=7, split=True, alpha=2.0, beta=0.5, noseed=1)),
     ("exact_64x64x16_nt", 70, 40, 1040, dict(G=9, split=True, noseed=1, beta=-1.0)),
 ]
