@@ -869,6 +869,40 @@ class Gen:
             self.dump("WB00", self.WB[0][0][2])
             self.dump("RA0", self.RA[0][0])
             self.dump("RB0", self.RB[0][0])
+        L_slow, L_join = p.label("fewtiles"), p.label("tiles01")
+        fast = not c.conv and not c.debug
+        if fast:
+            # Three or more K-tiles (no tile of the first two is the ragged last one): tiles 0 AND 1 are requested back to back --
+            # tile 0 into the fragment registers (idle until the first fragment read), tile 1 into the staging registers where the loop
+            # expects it -- so a run starts after ONE memory latency instead of two (the request for tile 1 used to wait until
+            # tile 0 had arrived and been stored).  The counted waits below leave tile 1's loads in flight.
+            state = (list(self.vmq), list(self.lgq))
+            e("s_cmp_lt_u32", self.s_rem, 3)
+            e("s_cbranch_scc1", L_slow)
+            pool = [r for slot in range(2) for r in (self.fa[slot] + self.fb[slot])]
+            assert len(pool) >= c.NPA + c.NPB
+            real = (self.stA, self.stB)
+            tmp = (pool[:c.NPA], pool[c.NPA:c.NPA + c.NPB])
+            self.stA, self.stB = tmp
+            self.issue_loads_all()
+            self.advance_srds()
+            self.stA, self.stB = real
+            self.issue_loads_all()
+            self.advance_srds()
+            self.stA, self.stB = tmp
+            for pi in range(c.NPA):
+                self.store_A_piece(pi, k=2)
+            if c.b_kcontig:
+                for pj in range(c.NPB):
+                    self.store_B_kpiece(pj, k=2)
+            else:
+                for gi in range(c.NPB // 2):
+                    self.store_B_pair(gi, k=2)
+            self.stA, self.stB = real
+            e("s_branch", L_join)
+            fast_state = (list(self.vmq), list(self.lgq))
+            self.vmq, self.lgq = state
+            p.place(L_slow)
         self.tail_mask_if(self.s_rem, 1)        # a single K-tile: tile 0 is the last one
         self.issue_loads_all()
         self.mask_last_pieces_if(self.s_rem, 1)
@@ -909,6 +943,9 @@ class Gen:
         self.issue_loads_all()
         self.mask_last_pieces_if(self.s_rem, 2)
         self.advance_srds()
+        if fast:
+            assert (self.vmq, self.lgq) == fast_state, "the two prologue paths must leave the same loads and stores in flight"
+            p.place(L_join)
         self.tail_mask_if(self.s_rem, 3)        # the first loop body loads tile 2
         self.init_accumulators()
         self.lg_wait(None)

@@ -283,6 +283,34 @@ class Gen64(Gen):
         e("s_add_u32", self.s_rem, Keff, c.BK - 1)
         e("s_lshr_b32", self.s_rem, self.s_rem, (c.BK).bit_length() - 1)
         # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers ----
+        L_slow, L_join = p.label("fewtiles"), p.label("tiles01")
+        fast = not c.debug
+        if fast:
+            # three or more K-tiles: tiles 0 and 1 requested back to back (tile 0 through the idle fragment registers): a run starts
+            # after one memory latency instead of two (f32_kernel.py run_setup)
+            state = (list(self.vmq), list(self.lgq))
+            e("s_cmp_lt_u32", self.s_rem, 3)
+            e("s_cbranch_scc1", L_slow)
+            pool = [r for slot in range(2) for r in (self.fa[slot] + self.fb[slot])]
+            assert len(pool) >= c.NPA + c.NPB
+            real = (self.stA, self.stB)
+            tmp = (pool[:c.NPA], pool[c.NPA:c.NPA + c.NPB])
+            self.stA, self.stB = tmp
+            self.issue_loads_all()
+            self.advance_srds()
+            self.stA, self.stB = real
+            self.issue_loads_all()
+            self.advance_srds()
+            self.stA, self.stB = tmp
+            for pi in range(c.NPA):
+                self.store_A_piece(pi, k=2)
+            for pj in range(c.NPB):
+                self.store_B_piece(pj, k=2)
+            self.stA, self.stB = real
+            e("s_branch", L_join)
+            fast_state = (list(self.vmq), list(self.lgq))
+            self.vmq, self.lgq = state
+            p.place(L_slow)
         self.tail_mask_if(self.s_rem, 1)
         self.issue_loads_all()
         self.advance_srds()
@@ -307,6 +335,9 @@ class Gen64(Gen):
         self.tail_mask_if(self.s_rem, 2)
         self.issue_loads_all()
         self.advance_srds()
+        if fast:
+            assert (self.vmq, self.lgq) == fast_state, "the two prologue paths must leave the same loads and stores in flight"
+            p.place(L_join)
         self.tail_mask_if(self.s_rem, 3)
         self.init_accumulators()
         self.lg_wait(None)
