@@ -41,7 +41,7 @@ namespace {
 struct KernelInfo {
   const char *symbol;
   int bm, bn, bk;
-  // tile-choice model (fitted to profiles/r03/tile_probe_v1.txt, shape_sweep_v3.jsonl): fraction of the matrix peak a CU reaches on this tile when
+  // tile-choice model (round 4: refitted to profiles/r04/plan_sweep_f32_mid_v2.jsonl, every candidate x plan forced): fraction of the matrix peak a CU reaches on this tile when
   // its workgroup slots are full / when one workgroup has the CU to itself, and the launch's fixed cost (prologue, first
   // loads, epilogue of the last round) in microseconds
   double eff, eff_alone, fixed_us;
@@ -65,23 +65,23 @@ struct KernelInfo {
 constexpr int kNumKernels = 46;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0, 1},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0, 1},
-    {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.91, 6.0, 2},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.92, 6.0, 2},
+    {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.935, 6.0, 2},      {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.945, 6.0, 2},
     {"lh_f32_exact_256x128x32_nt", 256, 128, 32, 0.965, 0.965, 10.0, 1}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16, 0.98, 0.98, 12.0, 1},
-    {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.91, 6.0, 2},    {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.92, 6.0, 2},
+    {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.935, 6.0, 2},   {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.945, 6.0, 2},
     {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0, 1},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0, 1},
     {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1},
-    {"lh_f32_exact_64x64x32", 64, 64, 32, 0.88, 0.78, 3.0, 3},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.895, 0.80, 3.0, 3},
-    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.88, 0.78, 3.0, 3},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.895, 0.80, 3.0, 3},
-    {"lh_f64_exact_128x128x16", 128, 128, 16, 0.92, 0.92, 8.0, 1},       {"lh_f64_fast_128x128x16", 128, 128, 16, 0.93, 0.93, 8.0, 1},
-    {"lh_f64_exact_64x64x16", 64, 64, 16, 0.85, 0.75, 3.0, 2},           {"lh_f64_fast_64x64x16", 64, 64, 16, 0.86, 0.76, 3.0, 2},
+    {"lh_f32_exact_64x64x32", 64, 64, 32, 0.935, 0.865, 3.0, 3},         {"lh_f32_fast_64x64x32", 64, 64, 32, 0.945, 0.875, 3.0, 3},
+    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.935, 0.865, 3.0, 3},      {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.945, 0.875, 3.0, 3},
+    {"lh_f64_exact_128x128x16", 128, 128, 16, 0.937, 0.945, 8.0, 1},     {"lh_f64_fast_128x128x16", 128, 128, 16, 0.965, 0.97, 8.0, 1},
+    {"lh_f64_exact_64x64x16", 64, 64, 16, 0.915, 0.815, 3.0, 2},         {"lh_f64_fast_64x64x16", 64, 64, 16, 0.93, 0.83, 3.0, 2},
     {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0, 1},
     {"lh_f32_conv3x3_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1}, {"lh_f32_conv3x3_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1},
     {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},
-    {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.92, 0.92, 8.0, 1},     {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.93, 0.93, 8.0, 1},
-    {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.85, 0.75, 3.0, 2},         {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.86, 0.76, 3.0, 2},
+    {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.937, 0.945, 8.0, 1},   {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.965, 0.97, 8.0, 1},
+    {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.915, 0.815, 3.0, 2},       {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.93, 0.83, 3.0, 2},
     {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0, 1},
-    {"lh_f32_exact_128x128x32", 128, 128, 32, 0.92, 0.90, 7.0, 1},       {"lh_f32_fast_128x128x32", 128, 128, 32, 0.93, 0.91, 7.0, 1},
-    {"lh_f32_exact_128x128x32_nt", 128, 128, 32, 0.92, 0.90, 7.0, 1},    {"lh_f32_fast_128x128x32_nt", 128, 128, 32, 0.93, 0.91, 7.0, 1},
+    {"lh_f32_exact_128x128x32", 128, 128, 32, 0.95, 0.95, 7.0, 1},       {"lh_f32_fast_128x128x32", 128, 128, 32, 0.96, 0.96, 7.0, 1},
+    {"lh_f32_exact_128x128x32_nt", 128, 128, 32, 0.95, 0.95, 7.0, 1},    {"lh_f32_fast_128x128x32_nt", 128, 128, 32, 0.96, 0.96, 7.0, 1},
     {"lh_f32_exact_256x128x32_pre", 256, 128, 32, 0.92, 0.92, 10.0, 1},  {"lh_f32_exact_256x128x32_pre_nt", 256, 128, 32, 0.92, 0.92, 10.0, 1},
     {"lh_f32_fast_256x256x16_pre", 256, 256, 16, 0.93, 0.93, 12.0, 1},   {"lh_f32_fast_256x256x16_pre_nt", 256, 256, 16, 0.93, 0.93, 12.0, 1},
     {"lh_f32_exact_128x128x16_pre", 128, 128, 16, 0.90, 0.86, 6.0, 2},   {"lh_f32_exact_128x128x16_pre_nt", 128, 128, 16, 0.90, 0.86, 6.0, 2},
@@ -290,13 +290,16 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     const double extras = r ? std::min((double)wg_per_cu, std::ceil((double)r * (double)wg_per_cu / (double)G)) : 0.0;
     const double units_cu = (double)(q * wg_per_cu) + extras;
     const double unit_us = tile_us / (double)P;
-    double eff = G >= (int64_t)kCUs * ki.occ ? ki.eff - (ki.occ >= 3 ? 0.02 : 0.0)
+    // fitted to profiles/r04/plan_sweep_*_v2.jsonl.  Three-per-CU tiles: a workgroup that walks about one tile keeps its XCD's
+    // workgroups on neighbouring tiles and runs a little better than the plain launch's rounds (0.96); walking several tiles they
+    // drift apart in the tile order and lose shared panels (0.89 against 0.935 plain).  A launch that cuts tiles pays ~8 us (the
+    // two extra runs of a cut tile, its hand-over through the workspace) whatever its length -- all workgroups pay it at the same
+    // time, so the CU's other workgroups do not hide it -- and ranges up to 4/5 of a tile run into hand-over chains (+25 %)
+    const double tiles_per_wg = (double)U / (double)G / (double)P;
+    double eff = G >= (int64_t)kCUs * ki.occ ? (ki.occ >= 3 ? (tiles_per_wg <= 1.3 ? std::min(ki.eff + 0.025, 0.97) : ki.eff - 0.045) : ki.eff)
                                              : ki.eff_alone + (ki.eff - ki.eff_alone) * std::min(1.0, (double)(wg_per_cu - 1) / std::max(1, ki.occ - 1));
-    // fitted to profiles/r04/plan_sweep_*_f.jsonl: a launch that cuts tiles pays ~8 us (the two extra runs of a cut tile, its
-    // hand-over through the workspace) whatever its length -- all workgroups pay it at the same time, so the CU's other workgroups
-    // do not hide it -- and ranges under 3/4 of a tile run into hand-over chains (+25 %)
     double t_us = units_cu * unit_us / eff + ki.fixed_us + (cut ? 8.0 : 0.0);
-    if (cut && (double)U / (double)G / (double)P < 0.75) t_us *= 1.25;
+    if (cut && tiles_per_wg <= 0.8) t_us *= 1.25;
     if (t_us < pers.time_us) {       // the best cut; it replaces the plain launch only with a margin (below)
       pers.persistent = true;
       pers.G = G; pers.P = P; pers.slice_len = len;

@@ -88,9 +88,11 @@ for (M, N, K) in SHAPES:
                 if mode == 0:
                     ent["same_bits"] = bool(torch.equal(ref, C))
                 rec[f"{name}/{'plain' if plan == 1 else 'persistent'}"] = ent
-        best = max((v["tflops"], k) for k, v in rec.items() if isinstance(v, dict) and k != "auto")
-        rec["best"] = best[1]
-        rec["auto_vs_best"] = round(rec["auto"]["tflops"] / best[0], 3)
+        cands = [(v["tflops"], k) for k, v in rec.items() if isinstance(v, dict) and k != "auto"]
+        if cands:
+            best = max(cands)
+            rec["best"] = best[1]
+            rec["auto_vs_best"] = round(rec["auto"]["tflops"] / best[0], 3)
         print(json.dumps(rec), flush=True)
 laser_amd.set_option("asm_kernel", -1); laser_amd.set_option("asm_plan", 0); laser_amd.set_float_mode(0)
 laser_amd.set_option("f64_asm" if f64 else "f32_asm", 1)
