@@ -70,8 +70,8 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.935, 6.0, 2},   {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.945, 6.0, 2},
     {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0, 1},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0, 1},
     {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1},
-    {"lh_f32_exact_64x64x32", 64, 64, 32, 0.935, 0.865, 3.0, 3},         {"lh_f32_fast_64x64x32", 64, 64, 32, 0.945, 0.875, 3.0, 3},
-    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.935, 0.865, 3.0, 3},      {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.945, 0.875, 3.0, 3},
+    {"lh_f32_exact_64x64x32", 64, 64, 32, 0.90, 0.84, 3.0, 3},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.91, 0.85, 3.0, 3},
+    {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.90, 0.84, 3.0, 3},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.91, 0.85, 3.0, 3},
     {"lh_f64_exact_128x128x16", 128, 128, 16, 0.937, 0.945, 8.0, 1},     {"lh_f64_fast_128x128x16", 128, 128, 16, 0.965, 0.97, 8.0, 1},
     {"lh_f64_exact_64x64x16", 64, 64, 16, 0.915, 0.815, 3.0, 2},         {"lh_f64_fast_64x64x16", 64, 64, 16, 0.93, 0.83, 3.0, 2},
     {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0, 1},
@@ -290,16 +290,18 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     const double extras = r ? std::min((double)wg_per_cu, std::ceil((double)r * (double)wg_per_cu / (double)G)) : 0.0;
     const double units_cu = (double)(q * wg_per_cu) + extras;
     const double unit_us = tile_us / (double)P;
-    // fitted to profiles/r04/plan_sweep_*_v2.jsonl.  Three-per-CU tiles: a workgroup that walks about one tile keeps its XCD's
-    // workgroups on neighbouring tiles and runs a little better than the plain launch's rounds (0.96); walking several tiles they
-    // drift apart in the tile order and lose shared panels (0.89 against 0.935 plain).  A launch that cuts tiles pays ~8 us (the
-    // two extra runs of a cut tile, its hand-over through the workspace) whatever its length -- all workgroups pay it at the same
-    // time, so the CU's other workgroups do not hide it -- and ranges up to 4/5 of a tile run into hand-over chains (+25 %)
+    // fitted to the round-4 sweeps (profiles/r04/plan_sweep_*).  The 64x64 kernels' rate differs by up to 10 % between boxes
+    // (3072^3 plain: 130 TFLOP/s on one MI355X, 145.6 on another in the same hour; the large tiles repeat within 1 %), so their table
+    // entries sit at the low end and ties go to the larger tile.  Three-per-CU tiles: a workgroup that walks about one tile keeps
+    // its XCD's workgroups on neighbouring tiles and runs a little better than the plain launch's rounds; walking several tiles
+    // they drift apart in the tile order and lose shared panels.  A launch that cuts tiles pays ~8 us (the two extra runs of a cut
+    // tile, its hand-over through the workspace) whatever its length -- all workgroups pay it at the same time, so the CU's other
+    // workgroups do not hide it -- and ranges shorter than a tile minus one slice wait on their predecessors
     const double tiles_per_wg = (double)U / (double)G / (double)P;
     double eff = G >= (int64_t)kCUs * ki.occ ? (ki.occ >= 3 ? (tiles_per_wg <= 1.3 ? std::min(ki.eff + 0.025, 0.97) : ki.eff - 0.045) : ki.eff)
                                              : ki.eff_alone + (ki.eff - ki.eff_alone) * std::min(1.0, (double)(wg_per_cu - 1) / std::max(1, ki.occ - 1));
     double t_us = units_cu * unit_us / eff + ki.fixed_us + (cut ? 8.0 : 0.0);
-    if (cut && tiles_per_wg <= 0.8) t_us *= 1.25;
+    if (cut && q < P - 1) t_us *= 1.0 + 0.25 * (double)(P - 1 - q) / (double)P;
     if (t_us < pers.time_us) {       // the best cut; it replaces the plain launch only with a margin (below)
       pers.persistent = true;
       pers.G = G; pers.P = P; pers.slice_len = len;
