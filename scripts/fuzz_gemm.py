@@ -31,7 +31,9 @@ for it in range(cases):
         M = 64 * int(rng.integers(16, 28)) + (int(rng.integers(1, 9)) if rng.random() < 0.7 else 0)
         N = 64 * int(rng.integers(16, 28)) + (int(rng.integers(1, 9)) if rng.random() < 0.7 else 0)
         K = int(rng.integers(256, 1400))
-    elif shape_kind < 0.45 and is_int:   # integer K past the limb kernels' 8192-k launch chunk / fold interval
+    elif shape_kind < 0.60 and not is_int:   # many tiles x several kc slices: the assembly kernels' launch plans (below)
+        M, N, K = int(rng.integers(300, 1500)), int(rng.integers(300, 1500)), int(rng.integers(520, 3000))
+    elif shape_kind < 0.63 and is_int:   # integer K past the limb kernels' 8192-k launch chunk / fold interval
         M, N, K = int(rng.integers(64, 200)), int(rng.integers(64, 200)), int(rng.integers(8193, 17000))
     ta, tb = rng.random() < 0.4, rng.random() < 0.4
     offA, offB, offC = (int(rng.integers(0, 4)) for _ in range(3))
@@ -62,10 +64,30 @@ for it in range(cases):
     cfg = int(rng.integers(0, ncfg)) if (dtype == np.float32 and rng.random() < 0.5) else -1
     mode = int(rng.random() < 0.3)
     laser_amd.set_f32_config(cfg); laser_amd.set_float_mode(mode)
+    # launch plan of the assembly kernels (gemm_f32_asm.cpp): forced on, plain / persistent, random workgroup counts, both
+    # receive paths, every tile, raster group -- laser-order results must not move by a bit under any of them
+    plan = {}
+    if not is_int and 0.45 <= shape_kind < 0.60:
+        cfg = -1
+        laser_amd.set_f32_config(-1)
+        f64 = dtype == np.float64
+        kerns = ([16, 18] if mode == 0 else [17, 19]) if f64 else ([0, 2, 30, 12] if mode == 0 else [1, 8, 3, 31, 13])
+        plan = {"f64_asm" if f64 else "f32_asm": 2, "slice_parallel": 0, "asm_plan": int(rng.choice([0, 1, 2, 2])),
+                "asm_kernel": int(rng.choice(kerns + [-1])), "asm_wgs": int(rng.choice([0, 0, 8 * int(rng.integers(1, 97))])),
+                "asm_noseed": int(rng.random() < 0.4), "asm_group_m": int(rng.choice([0, 0, 1, 3, 8])),
+                "asm_slice": int(rng.choice([0, 0, 4, 9])) if mode == 1 else 0}
+        for k, v in plan.items():
+            laser_amd.set_option(k, v)
     want = oracle.matmul(np.ascontiguousarray(A), np.ascontiguousarray(B), alpha=alpha, beta=beta, C_=np.ascontiguousarray(C0).copy(),
                          isa=oracle.fused_isa(dtype))
     laser_amd.matmul(dA, dB, alpha, beta, dC)
     got = dC.cpu().numpy()
+    if plan:
+        plan["used"] = (laser_amd.get_option("last_f64_asm" if dtype == np.float64 else "last_f32_asm"), laser_amd.get_option("last_asm_wgs"),
+                        laser_amd.get_option("last_asm_slices"))
+        for k, v in (("f32_asm", 1), ("f64_asm", 1), ("slice_parallel", 1), ("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("asm_noseed", 0),
+                     ("asm_group_m", 0), ("asm_slice", 0)):
+            laser_amd.set_option(k, v)
     untouched = np.array_equal(dbufC.cpu().numpy()[:offC], bufC[:offC])
     if mode == 0 or is_int:
         ok = np.array_equal(got, want)
@@ -82,7 +104,7 @@ for it in range(cases):
     if not (ok and untouched):
         fails += 1
         print("FAIL", dict(it=it, dtype=dtype.__name__, M=M, N=N, K=K, ta=ta, tb=tb, offs=(offA, offB, offC), pads=(padA, padB, padC),
-                           alpha=float(alpha), beta=float(beta), cfg=cfg, mode=mode, nbad=int(np.sum(got != want))), flush=True)
+                           alpha=float(alpha), beta=float(beta), cfg=cfg, mode=mode, plan=plan, nbad=int(np.sum(got != want))), flush=True)
 laser_amd.set_f32_config(-1); laser_amd.set_float_mode(0)
-print(f"fuzz: {cases} cases, {fails} failures")
+print(f"fuzz: {cases} cases, {fails} failures, fix-up time-outs {laser_amd.get_option('asm_fixup_timeouts')}")
 sys.exit(1 if fails else 0)
