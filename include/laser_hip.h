@@ -88,7 +88,8 @@ int laser_hip_f32_config_count(void);
  *                          reference's literal structure (conv2d_im2col.nim:126-166)
  *   "conv_patch"       [1] implicit conv reads B from an LDS-resident input patch when it fits; 0 = per-element gather
  *   "conv_direct"      [1] convolutions with <= 32 output channels and C_in*kH*kW <= 256 (the reference's conv bench shape,
- *                          conv2d_bench.nim:130-170): the direct HBM-streaming kernel; 0 = the implicit-GEMM kernels
+ *                          conv2d_bench.nim:130-170): the direct HBM-streaming kernels; 0 = the implicit-GEMM kernels; 2 = without
+ *                          the scalar-filter forms of 3x3 filters (A/B switch: the matrix-core / LDS-filter forms everywhere)
  *   "conv_kslice"      [1] laser-order conv tail as parallel kc slices (gemm.nim:150-158) + ordered combine
  *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only
  *   "zero_copy_poll"   [1] small host-pointer calls poll completion flags in mapped memory; 0 = synchronise the stream

@@ -4,10 +4,16 @@
 //
 // As a GEMM the problem is M = 20 rows: a 64-row MFMA tile is 31 % full and the K loop is one tile long, so the tiled
 // kernels are launch- and latency-bound (124 us for 73 MB of traffic).  It is an HBM stream: 9.6 MB of input, 63 MB of
-// output, 851 MFLOP.  Here one lane owns PPT output pixels and all M channels of them: the filter bank (K x M floats) sits
-// in LDS and is read as broadcasts, the input is read with lanes along the output row (coalesced; the kH*kW-fold reuse
-// comes out of L1/L2), every output channel is stored as one coalesced row segment.  No im2col matrix, no LDS traffic for
-// the image.
+// output, 851 MFLOP.  Four forms, all with lanes along the output row (coalesced input reads whose kH*kW-fold reuse comes out
+// of L1 / L2, one coalesced row segment per output channel), no im2col matrix, no LDS traffic for the image:
+//   * 3x3 filters, M <= 24: the filter in SCALAR registers feeding packed FMAs (conv_direct_pairs_kernel when the output
+//     width is even, the column stride 1 and nothing is padded -- the reference's bench shape, 22.9 us = 3.2 TB/s; else
+//     conv_direct_scalar_kernel);
+//   * other filters with K <= 128: one 32-row MFMA block per 32 pixels (conv_direct_mfma_kernel, 26.6 us on that shape);
+//   * longer reductions: the filter as LDS broadcasts (conv_direct_small_kernel).
+// Where the time goes on the bench shape (profiles/r04/conv_direct_dbg_v2.jsonl, batch 64 = three rounds of the chip): the
+// kernel without its stores 41.9 us, its stores alone 33.6 us (= a fill of the output), both together 78.1 us -- the two
+// do not overlap, with four or with eight waves per SIMD, with or without a software pipeline inside the wave; VALU busy 38 %.
 //
 // Arithmetic: per output element the ascending-k fused multiply-add chain from +0, k = (c*kH + kh)*kW + kw
 // (conv2d_im2col.nim:62-87 order), zero-padding taps multiplied in as zeros -- exactly what the matrix cores compute on the
@@ -17,7 +23,7 @@
 
 namespace laser_hip {
 
-std::atomic<int> g_conv_direct{1};   // option "conv_direct": 0 = always the implicit-GEMM kernels
+std::atomic<int> g_conv_direct{1};   // option "conv_direct": 0 = always the implicit-GEMM kernels; 2 = without the scalar-filter forms
 
 namespace {
 
@@ -108,6 +114,188 @@ __global__ void __launch_bounds__(256) conv_direct_small_kernel(const ConvSmallA
 #pragma unroll
     for (int m = 0; m < MT; m++)
       if (m < g.M) out[(int64_t)m * g.rsC + p[j]] = acc[j][m];
+  }
+}
+
+// ---- 3x3 filters, at most 24 output channels: the VALU form with the filter in SCALAR registers -------------------------
+// The LDS-filter kernel above reads every filter value as an LDS broadcast: at 20-24 channels x 2 pixels per lane the
+// broadcasts, not the arithmetic, fill the LDS pipe; the matrix-core form below pays 32 rows for 20 channels and one VALU
+// address computation per MFMA.  Here a filter value is a wave-uniform scalar load (s_load from the [M][K] bank as the caller
+// holds it: no transposed copy, no LDS, no barrier) that feeds packed FMAs straight from its SGPR: a lane owns pairs of
+// pixels in 64-bit registers (v_pk_fma_f32: two chains per instruction, the matrix cores' f32 rate) and all MT channels of
+// them.  A row of the bank is addressed as min(m, M - 1): MT is M rounded up to a multiple of 4, the surplus chains are
+// computed and dropped.  Same arithmetic as above: per output the ascending-k fused chain from +0.
+// Measured on the reference's bench shape, (16,3,224,224) (*) (20,3,3,3): profiles/r04/conv_direct_probe_*.jsonl.
+typedef __attribute__((ext_vector_type(2))) float cs_f32x2;
+typedef __attribute__((address_space(4))) float cs_const_f32;
+
+template <int MT, int PPT, bool PAD>
+__global__ void __launch_bounds__(256, 4) conv_direct_scalar_kernel(const ConvSmallArgs g) {
+  static_assert(PPT % 2 == 0, "pixels are held in pairs");
+  const int t = threadIdx.x;
+  // (the constant address space: wave-uniform loads from it are scalar loads whatever else the kernel does to memory)
+  const cs_const_f32 *filt = (const cs_const_f32 *)g.filt;
+  const float *__restrict__ img = g.img + (int64_t)blockIdx.y * g.bsB;
+  int p[PPT], ih0[PPT], iw0[PPT], off[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; j++) {
+    p[j] = (int)blockIdx.x * (256 * PPT) + 256 * j + t;
+    const int q = p[j] < g.npix ? p[j] : 0;      // (lanes past the image compute pixel 0 again and store nothing)
+    const int oh = q / g.oW, ow = q - oh * g.oW;
+    ih0[j] = oh * g.sH - g.pH;
+    iw0[j] = ow * g.sW - g.pW;
+    off[j] = ih0[j] * g.W + iw0[j];
+  }
+  cs_f32x2 acc[PPT / 2][MT];
+#pragma unroll
+  for (int j = 0; j < PPT / 2; j++)
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[j][m] = (cs_f32x2){0.0f, 0.0f};
+  int wrow[MT];                                  // wave-uniform: element offset of channel m's filter row
+#pragma unroll
+  for (int m = 0; m < MT; m++) wrow[m] = (m < g.M ? m : g.M - 1) * g.K;
+  const int HW = g.H * g.W;
+  auto fetch = [&](const float *plane, int kh, int kw, float (&x)[PPT]) __attribute__((always_inline)) {
+    const int toff = kh * g.W + kw;
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+      if (PAD) {
+        const bool in = (unsigned)(ih0[j] + kh) < (unsigned)g.H && (unsigned)(iw0[j] + kw) < (unsigned)g.W;
+        x[j] = in ? plane[off[j] + toff] : 0.0f;
+      } else {
+        x[j] = plane[off[j] + toff];
+      }
+    }
+  };
+  int k = 0;
+  for (int c = 0; c < g.Cin; c++) {
+    const float *plane = img + (int64_t)c * HW;
+    {
+      // the nine taps of this channel in registers, then channel by channel: a filter row's nine values (one 8-dword and one
+      // 1-dword scalar load) are pinned just before use and the next channel's are issued behind them, so few scalars are live
+      // and a scalar load lands behind 9 * PPT / 2 packed FMAs (three taps at a time measured 25 % slower: the waits show).
+      // Left alone the compiler hoists every scalar load of the loop body to its top and spills the scalars through vector
+      // registers.
+      float x[9][PPT];
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) fetch(plane, kh, kw, x[3 * kh + kw]);
+      float wn[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) wn[q] = filt[wrow[0] + k + q];
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        float w[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) w[q] = wn[q];
+        asm volatile("" : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]), "+s"(w[4]), "+s"(w[5]), "+s"(w[6]), "+s"(w[7]), "+s"(w[8]));
+        if (m + 1 < MT) {
+#pragma unroll
+          for (int q = 0; q < 9; q++) wn[q] = filt[wrow[m + 1] + k + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+#pragma unroll
+          for (int j = 0; j < PPT / 2; j++)
+            acc[j][m] = __builtin_elementwise_fma((cs_f32x2){w[q], w[q]}, (cs_f32x2){x[q][2 * j], x[q][2 * j + 1]}, acc[j][m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      k += 9;
+    }
+  }
+  float *out = g.out + (int64_t)blockIdx.y * g.bsC;
+#pragma unroll
+  for (int j = 0; j < PPT; j++) {
+    if (p[j] >= g.npix) continue;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+      if (m < g.M) out[(int64_t)m * g.rsC + p[j]] = acc[j / 2][m][j & 1];
+  }
+}
+
+// ---- 3x3, unit column stride, no padding, an even output width (the reference's bench shape): pixel PAIRS --------------
+// A lane owns PPL pairs of horizontally adjacent output pixels.  The two pixels' inputs for the taps kw = 0 and 2 of a filter
+// row are one 16-byte load (elements o .. o+3: the pairs (0,1) and (2,3)), for kw = 1 one 8-byte load at o+1: two load
+// instructions per filter row and pair instead of six, and every pair arrives in an even-aligned register pair as
+// v_pk_fma_f32 wants it.  Addresses are a wave-uniform base (the channel plane + the filter row) plus one 32-bit byte offset
+// per pair.  An output pair is one 8-byte store; lanes along the output: 512 contiguous bytes per wave and channel.
+typedef __attribute__((ext_vector_type(4))) float cs_f32x4;
+typedef __attribute__((ext_vector_type(4), aligned(4))) float cs_f32x4u;
+typedef __attribute__((ext_vector_type(2), aligned(4))) float cs_f32x2u;
+
+template <int MT, int PPL, int WPS>
+__global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvSmallArgs g) {
+  const int t = threadIdx.x;
+  const cs_const_f32 *filt = (const cs_const_f32 *)g.filt;
+  const char *__restrict__ img = reinterpret_cast<const char *>(g.img + (int64_t)blockIdx.y * g.bsB);
+  const int PW = g.oW >> 1, npairs = g.npix >> 1;
+  int q[PPL];
+  unsigned boff[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; j++) {
+    q[j] = (int)blockIdx.x * (256 * PPL) + 256 * j + t;
+    const int qq = q[j] < npairs ? q[j] : 0;     // (lanes past the image compute pair 0 again and store nothing)
+    const int oh = qq / PW, pw = qq - oh * PW;
+    boff[j] = (unsigned)((oh * g.sH) * g.W + 2 * pw) * 4u;
+  }
+  cs_f32x2 acc[PPL][MT];
+#pragma unroll
+  for (int j = 0; j < PPL; j++)
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[j][m] = (cs_f32x2){0.0f, 0.0f};
+  int wrow[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++) wrow[m] = (m < g.M ? m : g.M - 1) * g.K;
+  const int64_t plane_bytes = (int64_t)g.H * g.W * 4, row_bytes = (int64_t)g.W * 4;
+  int k = 0;
+  for (int c = 0; c < g.Cin; c++, k += 9) {
+    const char *plane = img + c * plane_bytes;
+    cs_f32x2 x[9][PPL];
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++) {
+      const char *row = plane + kh * row_bytes;
+#pragma unroll
+      for (int j = 0; j < PPL; j++) {
+        const cs_f32x4u a = *reinterpret_cast<const cs_f32x4u *>(row + boff[j]);
+        const cs_f32x2u b = *reinterpret_cast<const cs_f32x2u *>(row + boff[j] + 4);
+        x[3 * kh + 0][j] = (cs_f32x2){a[0], a[1]};
+        x[3 * kh + 1][j] = (cs_f32x2){b[0], b[1]};
+        x[3 * kh + 2][j] = (cs_f32x2){a[2], a[3]};
+      }
+    }
+    // channel by channel: a filter row's nine values (one 8-dword and one 1-dword scalar load) are pinned just before use and
+    // the next channel's are issued behind them -- left alone the compiler hoists every scalar load of the body to its top
+    // and spills the scalars through vector registers
+    float wn[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) wn[r] = filt[wrow[0] + k + r];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      float w[9];
+#pragma unroll
+      for (int r = 0; r < 9; r++) w[r] = wn[r];
+      asm volatile("" : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]), "+s"(w[4]), "+s"(w[5]), "+s"(w[6]), "+s"(w[7]), "+s"(w[8]));
+      if (m + 1 < MT) {
+#pragma unroll
+        for (int r = 0; r < 9; r++) wn[r] = filt[wrow[m + 1] + k + r];
+      }
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+#pragma unroll
+        for (int j = 0; j < PPL; j++) acc[j][m] = __builtin_elementwise_fma((cs_f32x2){w[r], w[r]}, x[r][j], acc[j][m]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float *out = g.out + (int64_t)blockIdx.y * g.bsC;
+#pragma unroll
+  for (int j = 0; j < PPL; j++) {
+    if (q[j] >= npairs) continue;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+      if (m < g.M) *reinterpret_cast<cs_f32x2u *>(out + (int64_t)m * g.rsC + 2 * q[j]) = acc[j][m];
   }
 }
 
@@ -241,6 +429,46 @@ hipError_t launch_small(const ConvSmallArgs &g, int batch, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <int MT>
+hipError_t launch_scalar_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
+  const dim3 grid((unsigned)((g.npix + 511) / 512), (unsigned)batch);
+  if (g.pH == 0 && g.pW == 0) hipLaunchKernelGGL((conv_direct_scalar_kernel<MT, 2, false>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((conv_direct_scalar_kernel<MT, 2, true>), grid, dim3(256), 0, s, g);
+  return hipGetLastError();
+}
+
+template <int MT, int PPL, int WPS>
+hipError_t launch_pairs_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
+  const int npairs = g.npix / 2;
+  const dim3 grid((unsigned)((npairs + 256 * PPL - 1) / (256 * PPL)), (unsigned)batch);
+  hipLaunchKernelGGL((conv_direct_pairs_kernel<MT, PPL, WPS>), grid, dim3(256), 0, s, g);
+  return hipGetLastError();
+}
+
+// 3x3 filters, at most 24 output channels: the filter in scalar registers
+hipError_t launch_scalar(const ConvSmallArgs &g, int batch, hipStream_t s) {
+  // unit column stride, no padding, an even output width: pixel pairs (one pair per lane: 61 registers at 20 channels, eight
+  // waves per SIMD -- 22.7 us on the reference's bench shape against 24.3 with two pairs per lane at four waves)
+  if (g.pH == 0 && g.pW == 0 && g.sW == 1 && g.oW % 2 == 0 && (int64_t)g.H * g.W < ((int64_t)1 << 29)) {
+    switch ((g.M + 3) / 4) {
+      case 1: return launch_pairs_mt<4, 1, 8>(g, batch, s);
+      case 2: return launch_pairs_mt<8, 1, 8>(g, batch, s);
+      case 3: return launch_pairs_mt<12, 1, 8>(g, batch, s);
+      case 4: return launch_pairs_mt<16, 1, 8>(g, batch, s);
+      case 5: return launch_pairs_mt<20, 1, 8>(g, batch, s);
+      default: return launch_pairs_mt<24, 1, 6>(g, batch, s);
+    }
+  }
+  switch ((g.M + 3) / 4) {
+    case 1: return launch_scalar_mt<4>(g, batch, s);
+    case 2: return launch_scalar_mt<8>(g, batch, s);
+    case 3: return launch_scalar_mt<12>(g, batch, s);
+    case 4: return launch_scalar_mt<16>(g, batch, s);
+    case 5: return launch_scalar_mt<20>(g, batch, s);
+    default: return launch_scalar_mt<24>(g, batch, s);
+  }
+}
+
 }  // namespace
 
 // hipErrorNotSupported: not this kernel's class -- the caller takes the implicit-GEMM kernels
@@ -258,7 +486,9 @@ hipError_t launch_conv_direct_small_f32(const GemmArgs<float> &a, hipStream_t s)
   g.M = (int32_t)a.M; g.K = (int32_t)a.K; g.Cin = (int32_t)(a.K / khw);
   g.H = a.cH; g.W = a.cW; g.kH = a.ckH; g.kW = a.ckW; g.oW = a.coW; g.npix = (int32_t)a.N;
   g.pH = a.cpH; g.pW = a.cpW; g.sH = a.csH; g.sW = a.csW;
-  // K <= 128: the matrix-core form above; longer reductions: the VALU form
+  // 3x3 filters with at most 24 output channels: the filter in scalar registers (option conv_direct = 2: never);
+  // else K <= 128: the matrix-core form; longer reductions: the LDS-filter VALU form
+  if (g_conv_direct != 2 && g.kH == 3 && g.kW == 3 && g.M <= 24) return launch_scalar(g, a.batch, s);
   if (a.K <= 128) return launch_mfma(g, a.batch, s);
   if (a.M <= 8) return launch_small<8, 4>(g, a.batch, s);
   if (a.M <= 16) return launch_small<16, 4>(g, a.batch, s);

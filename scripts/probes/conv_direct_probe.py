@@ -1,7 +1,8 @@
 """Direct small-channel convolution (conv_small.hip): time per launch and effective HBM rate on the reference's conv bench
 geometry and neighbours, direct vs implicit GEMM.  Run on the GPU box: python scripts/probes/conv_direct_probe.py"""
 import torch, json, sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import laser_amd
 def t(fn, inner=8, reps=7):
     t0 = time.time()
@@ -22,10 +23,14 @@ for ishape, kshape, pad in (((16, 3, 224, 224), (20, 3, 3, 3), (0, 0)), ((16, 3,
     oshape = laser_amd.conv2d_out_shape(ishape, kshape, pad, st); o = torch.zeros(oshape, device="cuda")
     byts = 4.0 * (x.numel() + o.numel())
     row = {"conv": [ishape, kshape, pad]}
-    for direct in (1, 0):
+    ref = None
+    for direct in (1, 2, 0):    # 1 = shipped choice, 2 = without the scalar-filter forms (matrix cores / LDS filter everywhere), 0 = implicit GEMM
         laser_amd.set_option("conv_direct", direct)
         ms = t(lambda: laser_amd.conv2d_im2col(o, oshape, x, ishape, w, kshape, pad, st, None))
-        row["direct_us" if direct else "implicit_us"] = round(ms * 1e3, 1)
-        if direct: row["direct_TBps"] = round(byts / ms / 1e9, 2); row["cfg"] = laser_amd.get_option("last_f32_config")
+        name = {1: "direct", 2: "r03_forms", 0: "implicit"}[direct]
+        row[name + "_us"] = round(ms * 1e3, 1)
+        if direct: row[name + "_TBps"] = round(byts / ms / 1e9, 2)
+        if direct == 1: row["cfg"] = laser_amd.get_option("last_f32_config"); ref = o.clone()
+        else: row[name + "_same_bits"] = bool(torch.equal(ref, o))
     laser_amd.set_option("conv_direct", 1)
     print(json.dumps(row), flush=True)

@@ -1206,7 +1206,14 @@ def test_conv_direct_small_channels_bit_exact(la, oracle):
     cases = [((16, 3, 224, 224), (20, 3, 3, 3), (0, 0), (1, 1)), ((2, 4, 17, 19), (7, 4, 5, 3), (2, 1), (2, 1)),
              ((3, 8, 30, 30), (32, 8, 3, 3), (1, 1), (1, 1)), ((1, 1, 9, 300), (3, 1, 1, 7), (0, 3), (1, 2)),
              ((2, 28, 12, 12), (16, 28, 3, 3), (1, 1), (1, 1)), ((2, 12, 11, 13), (5, 12, 3, 3), (1, 1), (1, 1)),
-             ((1, 13, 40, 37), (31, 13, 3, 3), (0, 0), (1, 1)), ((1, 2, 70, 70), (9, 2, 4, 4), (3, 3), (3, 2))]
+             ((1, 13, 40, 37), (31, 13, 3, 3), (0, 0), (1, 1)), ((1, 2, 70, 70), (9, 2, 4, 4), (3, 3), (3, 2)),
+             # 3x3 filters, <= 24 channels: the scalar-filter forms -- pixel pairs (even output width, no padding, unit column
+             # stride) at every channel-count class, one ragged last workgroup; then odd width / strides / padding
+             ((2, 3, 20, 34), (3, 3, 3, 3), (0, 0), (1, 1)), ((1, 5, 11, 40), (8, 5, 3, 3), (0, 0), (2, 1)),
+             ((3, 2, 33, 66), (11, 2, 3, 3), (0, 0), (1, 1)), ((1, 4, 40, 130), (14, 4, 3, 3), (0, 0), (1, 1)),
+             ((2, 3, 37, 24), (24, 3, 3, 3), (0, 0), (1, 1)), ((2, 3, 37, 25), (20, 3, 3, 3), (0, 0), (1, 1)),
+             ((1, 6, 30, 31), (17, 6, 3, 3), (0, 0), (1, 2)), ((2, 3, 21, 23), (22, 3, 3, 3), (2, 2), (1, 1)),
+             ((1, 28, 12, 14), (6, 28, 3, 3), (1, 0), (1, 1))]
     for ishape, kshape, pad, st in cases:
         x = rng.uniform(-1, 1, ishape).astype(np.float32)
         w = rng.uniform(-1, 1, kshape).astype(np.float32)
@@ -1215,16 +1222,17 @@ def test_conv_direct_small_channels_bit_exact(la, oracle):
         outs = {}
         for mode in (0, 1):
             la.set_float_mode(mode)
-            for direct in (1, 0):
+            for direct in (1, 2, 0):      # 2: without the scalar-filter forms of 3x3 filters (the matrix-core / LDS-filter forms)
                 la.set_option("conv_direct", direct)
                 try:
                     o = torch.full(oshape, float("nan"), device="cuda")
                     la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, pad, st, None)
-                    assert (la.get_option("last_f32_config") == -3) == (direct == 1), (ishape, kshape, direct)
+                    assert (la.get_option("last_f32_config") == -3) == (direct != 0), (ishape, kshape, direct)
                     outs[(mode, direct)] = o
                 finally:
                     la.set_option("conv_direct", 1); la.set_float_mode(0)
         assert torch.equal(outs[(0, 1)], outs[(0, 0)]) and torch.equal(outs[(1, 1)], outs[(1, 0)]), (ishape, kshape)
+        assert torch.equal(outs[(0, 1)], outs[(0, 2)]) and torch.equal(outs[(1, 1)], outs[(1, 2)]), (ishape, kshape)
         assert np.array_equal(outs[(0, 1)].cpu().numpy(), oracle.conv2d_im2col(x, w, pad, st)), (ishape, kshape)
     for ishape, kshape in (((1, 8, 20, 20), (33, 8, 3, 3)), ((1, 32, 20, 20), (8, 32, 3, 3))):     # outside the class
         dx = torch.from_numpy(rng.uniform(-1, 1, ishape).astype(np.float32)).cuda()
