@@ -225,7 +225,10 @@ typedef __attribute__((ext_vector_type(4))) float cs_f32x4;
 typedef __attribute__((ext_vector_type(4), aligned(4))) float cs_f32x4u;
 typedef __attribute__((ext_vector_type(2), aligned(4))) float cs_f32x2u;
 
-template <int MT, int PPL, int WPS>
+// CB = input channels whose loads are issued together in front of their arithmetic.  Shipped: 1.  CB = 3 (all of the bench
+// shape's inputs requested at once, one exposed latency per wave instead of three; 86 registers) measured no faster: 25.1 vs
+// 23.7 us per call at 16 images, 71.8 vs 72.3 at 64 (profiles/r04/conv_direct_probe_v6.jsonl).
+template <int MT, int PPL, int CB, int WPS>
 __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvSmallArgs g) {
   const int t = threadIdx.x;
   const cs_const_f32 *filt = (const cs_const_f32 *)g.filt;
@@ -249,44 +252,56 @@ __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvS
 #pragma unroll
   for (int m = 0; m < MT; m++) wrow[m] = (m < g.M ? m : g.M - 1) * g.K;
   const int64_t plane_bytes = (int64_t)g.H * g.W * 4, row_bytes = (int64_t)g.W * 4;
-  int k = 0;
-  for (int c = 0; c < g.Cin; c++, k += 9) {
-    const char *plane = img + c * plane_bytes;
-    cs_f32x2 x[9][PPL];
+  for (int c0 = 0; c0 < g.Cin; c0 += CB) {
+    // the raw 16-byte rows: elements 0,1 / 2,3 are the kw = 0 / 2 pairs as they lie, (1,2) is put together at its use (built
+    // here it would be a wait for the load right behind its issue).  A channel past the last one re-reads the last (valid
+    // addresses, a known number of loads) and is not used.
+    cs_f32x4 raw[CB][3][PPL];
 #pragma unroll
-    for (int kh = 0; kh < 3; kh++) {
-      const char *row = plane + kh * row_bytes;
+    for (int i = 0; i < CB; i++) {
+      const int c = c0 + i < g.Cin ? c0 + i : g.Cin - 1;
+      const char *plane = img + c * plane_bytes;
 #pragma unroll
-      for (int j = 0; j < PPL; j++) {
-        const cs_f32x4u a = *reinterpret_cast<const cs_f32x4u *>(row + boff[j]);
-        const cs_f32x2u b = *reinterpret_cast<const cs_f32x2u *>(row + boff[j] + 4);
-        x[3 * kh + 0][j] = (cs_f32x2){a[0], a[1]};
-        x[3 * kh + 1][j] = (cs_f32x2){b[0], b[1]};
-        x[3 * kh + 2][j] = (cs_f32x2){a[2], a[3]};
-      }
+      for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int j = 0; j < PPL; j++) raw[i][kh][j] = *reinterpret_cast<const cs_f32x4u *>(plane + kh * row_bytes + boff[j]);
     }
-    // channel by channel: a filter row's nine values (one 8-dword and one 1-dword scalar load) are pinned just before use and
-    // the next channel's are issued behind them -- left alone the compiler hoists every scalar load of the body to its top
-    // and spills the scalars through vector registers
-    float wn[9];
 #pragma unroll
-    for (int r = 0; r < 9; r++) wn[r] = filt[wrow[0] + k + r];
+    for (int i = 0; i < CB; i++) {
+      if (c0 + i >= g.Cin) break;
+      const int k = 9 * (c0 + i);
+      cs_f32x2 x[9][PPL];
 #pragma unroll
-    for (int m = 0; m < MT; m++) {
-      float w[9];
+      for (int kh = 0; kh < 3; kh++)
 #pragma unroll
-      for (int r = 0; r < 9; r++) w[r] = wn[r];
-      asm volatile("" : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]), "+s"(w[4]), "+s"(w[5]), "+s"(w[6]), "+s"(w[7]), "+s"(w[8]));
-      if (m + 1 < MT) {
+        for (int j = 0; j < PPL; j++) {
+          x[3 * kh + 0][j] = (cs_f32x2){raw[i][kh][j][0], raw[i][kh][j][1]};
+          x[3 * kh + 1][j] = (cs_f32x2){raw[i][kh][j][1], raw[i][kh][j][2]};
+          x[3 * kh + 2][j] = (cs_f32x2){raw[i][kh][j][2], raw[i][kh][j][3]};
+        }
+      // channel by channel: a filter row's nine values (one 8-dword and one 1-dword scalar load) are pinned just before use and
+      // the next channel's are issued behind them -- left alone the compiler hoists every scalar load of the body to its top
+      // and spills the scalars through vector registers
+      float wn[9];
 #pragma unroll
-        for (int r = 0; r < 9; r++) wn[r] = filt[wrow[m + 1] + k + r];
+      for (int r = 0; r < 9; r++) wn[r] = filt[wrow[0] + k + r];
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        float w[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) w[r] = wn[r];
+        asm volatile("" : "+s"(w[0]), "+s"(w[1]), "+s"(w[2]), "+s"(w[3]), "+s"(w[4]), "+s"(w[5]), "+s"(w[6]), "+s"(w[7]), "+s"(w[8]));
+        if (m + 1 < MT) {
+#pragma unroll
+          for (int r = 0; r < 9; r++) wn[r] = filt[wrow[m + 1] + k + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+#pragma unroll
+          for (int j = 0; j < PPL; j++) acc[j][m] = __builtin_elementwise_fma((cs_f32x2){w[r], w[r]}, x[r][j], acc[j][m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-#pragma unroll
-        for (int j = 0; j < PPL; j++) acc[j][m] = __builtin_elementwise_fma((cs_f32x2){w[r], w[r]}, x[r][j], acc[j][m]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float *out = g.out + (int64_t)blockIdx.y * g.bsC;
@@ -437,11 +452,11 @@ hipError_t launch_scalar_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int MT, int PPL, int WPS>
+template <int MT, int WPS>
 hipError_t launch_pairs_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
   const int npairs = g.npix / 2;
-  const dim3 grid((unsigned)((npairs + 256 * PPL - 1) / (256 * PPL)), (unsigned)batch);
-  hipLaunchKernelGGL((conv_direct_pairs_kernel<MT, PPL, WPS>), grid, dim3(256), 0, s, g);
+  const dim3 grid((unsigned)((npairs + 255) / 256), (unsigned)batch);
+  hipLaunchKernelGGL((conv_direct_pairs_kernel<MT, 1, 1, WPS>), grid, dim3(256), 0, s, g);
   return hipGetLastError();
 }
 
@@ -451,12 +466,12 @@ hipError_t launch_scalar(const ConvSmallArgs &g, int batch, hipStream_t s) {
   // waves per SIMD -- 22.7 us on the reference's bench shape against 24.3 with two pairs per lane at four waves)
   if (g.pH == 0 && g.pW == 0 && g.sW == 1 && g.oW % 2 == 0 && (int64_t)g.H * g.W < ((int64_t)1 << 29)) {
     switch ((g.M + 3) / 4) {
-      case 1: return launch_pairs_mt<4, 1, 8>(g, batch, s);
-      case 2: return launch_pairs_mt<8, 1, 8>(g, batch, s);
-      case 3: return launch_pairs_mt<12, 1, 8>(g, batch, s);
-      case 4: return launch_pairs_mt<16, 1, 8>(g, batch, s);
-      case 5: return launch_pairs_mt<20, 1, 8>(g, batch, s);
-      default: return launch_pairs_mt<24, 1, 6>(g, batch, s);
+      case 1: return launch_pairs_mt<4, 8>(g, batch, s);
+      case 2: return launch_pairs_mt<8, 8>(g, batch, s);
+      case 3: return launch_pairs_mt<12, 8>(g, batch, s);
+      case 4: return launch_pairs_mt<16, 8>(g, batch, s);
+      case 5: return launch_pairs_mt<20, 8>(g, batch, s);
+      default: return launch_pairs_mt<24, 6>(g, batch, s);
     }
   }
   switch ((g.M + 3) / 4) {

@@ -15,7 +15,7 @@ def t(fn, inner=8, reps=7):
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / inner)
     return sorted(ts)[len(ts) // 2]
 g = torch.Generator(device="cuda").manual_seed(1)
-for ishape, kshape, pad in (((16, 3, 224, 224), (20, 3, 3, 3), (0, 0)), ((16, 3, 224, 224), (20, 3, 3, 3), (1, 1)),
+for ishape, kshape, pad in (((16, 3, 224, 224), (20, 3, 3, 3), (0, 0)), ((64, 3, 224, 224), (20, 3, 3, 3), (0, 0)), ((8, 8, 128, 128), (16, 8, 3, 3), (0, 0)), ((16, 3, 224, 224), (20, 3, 3, 3), (1, 1)),
                             ((16, 3, 224, 224), (32, 3, 3, 3), (1, 1)), ((8, 8, 128, 128), (16, 8, 3, 3), (1, 1)),
                             ((8, 14, 128, 128), (32, 14, 3, 3), (1, 1)), ((8, 3, 224, 224), (8, 3, 7, 7), (3, 3))):
     st = (1, 1)
