@@ -256,7 +256,7 @@ hipError_t gemm_slice_parallel(const GemmArgs<T> &a, int kc, hipStream_t s) {
   if (g_ctx.slice_parallel_tiles > 0) need = tiles64 <= g_ctx.slice_parallel_tiles.load() ? (int64_t)g_ctx.slice_parallel_min.load() : (int64_t)1 << 40;  // tuning override
   if (nsl < need || nsl > 65535 || ws_bytes > 1.5e9) return hipErrorNotSupported;
   T *W = nullptr;
-  hipError_t e = hipMallocAsync((void **)&W, (size_t)ws_bytes, s);
+  hipError_t e = scratch_alloc_async((void **)&W, (size_t)ws_bytes, s);
   if (e != hipSuccess) return e;
   const int64_t mn = a.M * a.N;
   GemmArgs<T> b = a;
@@ -335,7 +335,7 @@ hipError_t run_gemm_prologue_materialised(const GemmArgs<T> &a, hipStream_t s) {
   const size_t nA = a.preA ? (size_t)a.M * a.K : 0, nB = a.preB ? (size_t)a.K * a.N : 0;
   if (nA + nB == 0) return hipErrorInvalidValue;
   T *scratch = nullptr;
-  hipError_t e = hipMallocAsync((void **)&scratch, (nA + nB) * sizeof(T), s);
+  hipError_t e = scratch_alloc_async((void **)&scratch, (nA + nB) * sizeof(T), s);
   if (e != hipSuccess) return e;
   GemmArgs<T> b = a;
   b.preA = b.preB = 0;
@@ -472,7 +472,7 @@ hipError_t run_gemm<int32_t>(const GemmArgs<int32_t> &a, hipStream_t s) {
   const double work = (double)a.M * (double)a.N * (double)a.K;
   if (g_ctx.i32_mfma && a.batch == 1 && work >= 64.0 * 64.0 * 64.0 * 8.0) {
     void *ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, gemm_i32_mfma_workspace_bytes(a.M, a.N, a.K), s);
+    hipError_t e = scratch_alloc_async(&ws, gemm_i32_mfma_workspace_bytes(a.M, a.N, a.K), s);
     if (e != hipSuccess) return e;
     g_last_i32_asm = 0;
     // the hand-scheduled kernel (laser_amd/asmgen/i8_kernel.py) when eligible, K > 8192 in chunks
@@ -493,7 +493,7 @@ hipError_t run_gemm<int64_t>(const GemmArgs<int64_t> &a, hipStream_t s) {
   const double work = (double)a.M * (double)a.N * (double)a.K;
   if (g_ctx.i64_mfma && a.batch == 1 && work >= 64.0 * 64.0 * 64.0 * 8.0) {
     void *ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, gemm_i64_mfma_workspace_bytes(a.M, a.N, a.K), s);
+    hipError_t e = scratch_alloc_async(&ws, gemm_i64_mfma_workspace_bytes(a.M, a.N, a.K), s);
     if (e != hipSuccess) return e;
     g_last_i32_asm = 0;
     // the hand-scheduled kernel (i8_kernel.py "i64_64x64x32") when eligible, K > 8192 in chunks
@@ -1599,7 +1599,7 @@ static int conv2d_api_dev(float *dout, const float *din, int64_t iN, int64_t iC,
   int64_t imgs = iN;  // images expanded per pass
   if (!dws) {
     while (imgs > 1 && (double)imgs * (double)w1 * 4.0 > 2.0e9) imgs = (imgs + 1) / 2;  // bound the scratch
-    HIP_TRY(hipMallocAsync((void **)&own, (size_t)imgs * (size_t)w1 * 4, s));
+    HIP_TRY(scratch_alloc_async((void **)&own, (size_t)imgs * (size_t)w1 * 4, s));
     dws = own;
   } else {
     // capacity unknown (the plain entry points): the reference's contract is ONE image's worth -> image by image

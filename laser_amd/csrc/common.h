@@ -7,6 +7,24 @@
 
 namespace laser_hip {
 
+// Stream-ordered scratch (packing passes, limb planes, slice partials): hipMallocAsync from the device's default pool, whose
+// release threshold is raised once per device to 4 GiB -- at the default (0) every synchronisation hands the pool's free memory
+// back to the driver and the next call pays for mapping it again (a packed 4096^3 product timed 4 calls per synchronise lost
+// 60 us per call to that: profiles/r04/colmajor_a_probe_v1.jsonl against configs_v5.jsonl).
+inline hipError_t scratch_alloc_async(void **p, size_t bytes, hipStream_t s) {
+  static std::atomic<unsigned long long> done{0};      // one bit per device ordinal (< 64)
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(done.load(std::memory_order_relaxed) >> dev & 1ull)) {
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr) {
+      uint64_t keep = (uint64_t)4 << 30;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    done.fetch_or(1ull << dev, std::memory_order_relaxed);
+  }
+  return hipMallocAsync(p, bytes, s);
+}
+
 // One-time-per-DEVICE initialisation of a kernel (hipFuncSetAttribute acts on the current device's instance of the
 // function): a single process may drive all 8 GPUs of a node (the sharded entry points), so "done" is a bit per
 // device ordinal, not a per-process flag.

@@ -534,7 +534,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hi
   const size_t bytesA = packA ? (size_t)a.M * a.K * 4 : 0, bytesB = packB ? (size_t)a.K * a.N * 4 : 0;
   if (bytesA + bytesB > ((size_t)4 << 30)) return hipErrorNotSupported;
   float *scratch = nullptr;
-  hipError_t e = hipMallocAsync((void **)&scratch, bytesA + bytesB, s);
+  hipError_t e = scratch_alloc_async((void **)&scratch, bytesA + bytesB, s);
   if (e != hipSuccess) return e;
   if (packA) {      // A[m][k] at m * rsA + k * csA -> dense [M][K]
     // (a fused prologue on a packed operand happens in the packing pass -- "during the prepacking", README.md:243-244)
@@ -723,7 +723,7 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a_in, bool laser_order, h
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return hipErrorNotSupported;
   double *scratch = nullptr;
-  hipError_t e = hipMallocAsync((void **)&scratch, (size_t)a.M * a.K * 8, s);
+  hipError_t e = scratch_alloc_async((void **)&scratch, (size_t)a.M * a.K * 8, s);
   if (e != hipSuccess) return e;
   e = launch_transpose_pitched(scratch, a.K, a.A, a.csA, a.K, a.M, 8, s);
   a.A = scratch; a.rsA = a.K; a.csA = 1;

@@ -334,7 +334,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     if (hipError_t e = main_launch(m, s); e != hipSuccess) return e;
     const int64_t mn = a.M * ntail;
     float *W = nullptr;
-    if (hipError_t e = hipMallocAsync((void **)&W, (size_t)(nsl * a.batch * mn) * sizeof(float), s); e != hipSuccess) return e;
+    if (hipError_t e = scratch_alloc_async((void **)&W, (size_t)(nsl * a.batch * mn) * sizeof(float), s); e != hipSuccess) return e;
     t.alpha = 1.0f; t.beta = 0.0f;
     t.kc = 0;
     t.cs_imgs = a.batch; t.cs_len = 512;
