@@ -21,8 +21,15 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
                  b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32",
-                 persistent=None, pre=False):
+                 persistent=None, pre=False, deep=False):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
+        # deep (generator option, no shipped kernel uses it): TWO sets of staging registers -- a K-tile is requested two tile bodies before
+        # it is stored to LDS instead of one; six tile bodies instead of three (LDS stage x register set).  Built for the small tile,
+        # whose body is 16 MFMAs per wave and which runs 0.965 of peak with its global loads ablated against 0.83 - 0.87 with them:
+        # measured, it changes nothing (3072^3: 135.5 / 135.1 / 136.0 against 131.8 / 135.6 / 136.7 TFLOP/s, interleaved; 1024^3 110.3
+        # against 110.9: profiles/r04/asm_probe_64x64_deep_*.jsonl) -- the loads cost bandwidth there, not latency.
+        self.deep = deep
+        assert not (deep and (conv or pre or debug))
         # pre: fused prologue (README.md:243-244: "fuse operations before the matrix multiplication kernel, during the prepacking"):
         # relu applied to the elements of A and / or B in the staging registers, on their way into the LDS panel image; which operand
         # is a run-time mask (KA_PRE).  Kernels of their own: the VALU work costs matrix-pipe time, the plain kernels carry none of it.
@@ -191,6 +198,10 @@ class Gen:
         # staging pieces
         self.stA = [V(4) for _ in range(c.NPA)]
         self.stB = [V(2) for _ in range(c.NPB)] if c.conv else [V(4) for _ in range(c.NPB)]
+        # deep: tile t waits in set t & 1 (the loop body that multiplies tile t stores tile t + 1 from its set and requests tile t + 3 into it)
+        self.st_sets = [(self.stA, self.stB)]
+        if c.deep:
+            self.st_sets.append(([V(4) for _ in range(c.NPA)], [V(4) for _ in range(c.NPB)]))
         # per-lane LDS addresses, one register per LDS stage: [0] = the stage the tile being multiplied lives in (reads) /
         # the stage being filled (writes), [1] = the next one, [2] = the third; rotated with v_swap_b32 once per K-tile --
         # v_swap is free beside the MFMA stream while any other VALU op costs ~11 cycles of matrix-pipe time
@@ -869,6 +880,10 @@ class Gen:
             self.dump("WB00", self.WB[0][0][2])
             self.dump("RA0", self.RA[0][0])
             self.dump("RB0", self.RB[0][0])
+        if c.deep:
+            self.first_tiles_deep()
+            self.first_tiles_done()
+            return
         L_slow, L_join = p.label("fewtiles"), p.label("tiles01")
         fast = not c.conv and not c.debug
         if fast:
@@ -947,6 +962,61 @@ class Gen:
             assert (self.vmq, self.lgq) == fast_state, "the two prologue paths must leave the same loads and stores in flight"
             p.place(L_join)
         self.tail_mask_if(self.s_rem, 3)        # the first loop body loads tile 2
+        self.first_tiles_done()
+
+    def store_tile_to_lds(self, k):
+        """every piece of the tile in the current staging registers -> LDS (write-address triple index k)"""
+        c = self.c
+        for pi in range(c.NPA):
+            self.store_A_piece(pi, k=k)
+        if c.b_kcontig:
+            for pj in range(c.NPB):
+                self.store_B_kpiece(pj, k=k)
+        else:
+            for gi in range(c.NPB // 2):
+                self.store_B_pair(gi, k=k)
+
+    def first_tiles_deep(self):
+        """deep staging: tile 0 -> LDS stage 0, tile 1 -> register set 1, tile 2 -> register set 0, both still in flight at the loop's
+        entry.  Four or more K-tiles: all three requested back to back (tile 0 into the fragment registers), one memory latency
+        per run; fewer: one after the other, each with the masks of a ragged last tile."""
+        c, p = self.c, self.p
+        e = p.emit
+        set0, set1 = self.st_sets
+        L_slow, L_join = p.label("fewtiles"), p.label("tiles012")
+        state = (list(self.vmq), list(self.lgq))
+        e("s_cmp_lt_u32", self.s_rem, 4)
+        e("s_cbranch_scc1", L_slow)
+        pool = [r for slot in range(2) for r in (self.fa[slot] + self.fb[slot])]
+        assert len(pool) >= c.NPA + c.NPB
+        tmp = (pool[:c.NPA], pool[c.NPA:c.NPA + c.NPB])
+        for regs in (tmp, set1, set0):
+            self.stA, self.stB = regs
+            self.issue_loads_all()
+            self.advance_srds()
+        self.stA, self.stB = tmp
+        self.store_tile_to_lds(2)               # tile 0 goes to LDS stage 0 = the "third" stage of the write triples
+        self.stA, self.stB = set0
+        e("s_branch", L_join)
+        fast_state = (list(self.vmq), list(self.lgq))
+        self.vmq, self.lgq = state
+        p.place(L_slow)
+        for n, regs in ((1, set0), (2, set1), (3, set0)):
+            self.stA, self.stB = regs
+            self.tail_mask_if(self.s_rem, n)        # n K-tiles: tile n - 1 is the last one
+            self.issue_loads_all()
+            self.mask_last_pieces_if(self.s_rem, n)
+            self.advance_srds()
+            if n == 1:
+                self.store_tile_to_lds(2)
+        self.stA, self.stB = set0
+        assert (self.vmq, self.lgq) == fast_state, "the two prologue paths must leave the same loads and stores in flight"
+        p.place(L_join)
+        self.tail_mask_if(self.s_rem, 4)        # the first loop body loads tile 3
+
+    def first_tiles_done(self):
+        c, p = self.c, self.p
+        e = p.emit
         self.init_accumulators()
         self.lg_wait(None)
         e("s_barrier")
@@ -1415,9 +1485,10 @@ class Gen:
             e("v_accvgpr_write_b32", self.run[b][r], tt)
 
     # ------------------------------------------------------------------ one K-tile
-    def tile_body(self, fold, stage=None):
+    def tile_body(self, fold, stage=None, regset=0):
         c, p = self.c, self.p
         e = p.emit
+        self.stA, self.stB = self.st_sets[regset]      # the set this body drains into LDS and refills
         gaps = {m: [] for m in range(-1, c.NMF)}   # gap m: ops issued right after MFMA m (gap -1: before MFMA 0)
 
         def put(m, op):
@@ -1564,6 +1635,7 @@ class Gen:
             for op in gaps[m]:
                 self.run_op(op)
         assert len(order) == c.NMF
+        self.stA, self.stB = self.st_sets[0]
 
     # ------------------------------------------------------------------ main loop + epilogue
     def main_loop(self):
@@ -1577,17 +1649,25 @@ class Gen:
             # (profiles/r03/asm_probe_v6.jsonl).  Every body ends with the same dispatch: done? -> slice boundary? -> the
             # next stage's body.
             L_done = p.label("done")
-            N = [p.label(f"tile_s{k}") for k in range(3)]
-            F = [p.label(f"fold_s{k}") for k in range(3)] if c.exact else None
+            # deep: body j of six multiplies a tile in LDS stage j % 3 and stages with register set (j + 1) & 1
+            NBODY = 6 if c.deep else 3
+            ahead = 3 if c.deep else 2            # a body requests the tile `ahead` tiles past the one it multiplies
+            N = [p.label(f"tile_s{k}") for k in range(NBODY)]
+            F = [p.label(f"fold_s{k}") for k in range(NBODY)] if c.exact else None
             e("s_mov_b32", self.s_cnt, c.KC_TILES if c.exact else 0x7fffffff)
 
+            def rset(j):
+                return ((j + 1) & 1) if c.deep else 0
+
             def tail(k, fall_through):
-                nk = (k + 1) % 3
+                nk = (k + 1) % NBODY
                 e("s_sub_u32", self.s_rem, self.s_rem, 1)
                 e("s_cmp_eq_u32", self.s_rem, 0)
                 e("s_cbranch_scc1", L_done)
-                self.tail_mask_if(self.s_rem, 3)    # the next body loads the last K-tile
+                self.tail_mask_if(self.s_rem, ahead + 1)    # the next body loads the last K-tile
+                self.stA, self.stB = self.st_sets[rset(nk)]
                 self.mask_last_pieces_if(self.s_rem, 2)   # the next body stores it (K % 4 != 0: zero what lies beyond K)
+                self.stA, self.stB = self.st_sets[0]
                 if c.exact:
                     e("s_sub_u32", self.s_cnt, self.s_cnt, 1)
                     e("s_cmp_eq_u32", self.s_cnt, 0)
@@ -1595,17 +1675,17 @@ class Gen:
                 if not fall_through:
                     e("s_branch", N[nk])
             e("raw", ".p2align 6")
-            for k in range(3):
+            for k in range(NBODY):
                 p.place(N[k])
-                self.tile_body(False, stage=k)
+                self.tile_body(False, stage=k % 3, regset=rset(k))
                 assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs"
-                tail(k, fall_through=(k < 2))
+                tail(k, fall_through=(k < NBODY - 1))
             if c.exact:
                 assert c.KC_TILES > 1
-                for k in range(3):
+                for k in range(NBODY):
                     p.place(F[k])
                     e("s_mov_b32", self.s_cnt, c.KC_TILES)
-                    self.tile_body(True, stage=k)
+                    self.tile_body(True, stage=k % 3, regset=rset(k))
                     assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs (fold tile)"
                     tail(k, fall_through=False)
             p.place(L_done)

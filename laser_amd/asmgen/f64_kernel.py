@@ -60,6 +60,7 @@ class Gen64(Gen):
         self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
         self.stA = [V(4) for _ in range(c.NPA)]
         self.stB = [V(4) for _ in range(c.NPB)]
+        self.st_sets = [(self.stA, self.stB)]
         self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.WA = [[V() for _ in range(3)] for _ in range(c.NPA)]   # [piece][stage]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Schedule sweep of the hand-scheduled fp32 kernels (laser_amd/asmgen/f32_kernel.py): every variant is generated,
-assembled and loaded as its own code object, checked against torch.matmul (unless it is an ablation) and timed at
-8192^3 in interleaved rounds.  Writes one JSON line per variant (profiles/r03/asm_probe_*.jsonl are copies of that).
+assembled and loaded as its own code object, launched under the plain plan (one tile per workgroup, the kernel's own tile
+map), checked against torch.matmul (unless it is an ablation) and timed at 8192^3 (or --shape M N K) in interleaved rounds.  Writes one JSON line per variant (profiles/r03/asm_probe_*.jsonl are copies of that).
 
 usage: asm_probe.py [variants.json] [--n 8192] [--out file.jsonl]
 variants.json: [{"name": "...", "kernel": "exact_256x128x32", "over": {"bar_gap": 63}}, ...]"""
@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from laser_amd.asmgen import f32_kernel as K  # noqa: E402
+from laser_amd.asmgen import check as CHK  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
 LLD = "/opt/rocm/lib/llvm/bin/ld.lld"
@@ -25,20 +26,6 @@ hip = C.CDLL("libamdhip64.so")
 hip.hipModuleLoad.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
 hip.hipModuleGetFunction.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_char_p]
 hip.hipModuleLaunchKernel.argtypes = [C.c_void_p] + [C.c_uint] * 6 + [C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
-
-
-def make_table(tiles_m, tiles_n, group_m):
-    nwg = tiles_m * tiles_n
-    out = []
-    for bid in range(nwg):
-        xcd, loc, q, r = bid % 8, bid // 8, nwg // 8, nwg % 8
-        wgid = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + loc
-        width = group_m * tiles_n
-        group = wgid // width
-        first_m = group * group_m
-        gsz = min(tiles_m - first_m, group_m)
-        out.append((first_m + (wgid % width) % gsz) | (((wgid % width) // gsz) << 16))
-    return out
 
 
 def build(var, tmp):
@@ -81,15 +68,16 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     tmp = tempfile.mkdtemp()
     built = []
-    tables = {}
     for var in variants:
         cfg, fn = build(var, tmp)
         tm, tn = (M_ + cfg.BM - 1) // cfg.BM, (N_ + cfg.BN - 1) // cfg.BN
         gm = 4 if cfg.BM >= 2 * cfg.BN else 8
-        key = (tm, tn, gm)
-        if key not in tables:
-            tables[key] = torch.tensor(make_table(tm, tn, gm), dtype=torch.int32, device="cuda")
-        ka = struct.pack("<QQQQIIIIIIffQ", A.data_ptr(), B.data_ptr(), Cm.data_ptr(), tables[key].data_ptr(), K_, N_, N_, M_, N_, K_, 1.0, 0.0, 0) + b"\0" * 80
+        # the kernel arguments as gemm_f32_asm.cpp fills them for the plain plan: one tile per workgroup, XCD-aware remap, raster
+        # groups of gm tile rows, tiles never cut (f32_kernel.py: KA_SCHED .. KERNARG_SIZE)
+        ka = struct.pack("<QQQQIIIIIIffQ", A.data_ptr(), B.data_ptr(), Cm.data_ptr(), 0, K_, N_, N_, M_, N_, K_, 1.0, 0.0, 0) + b"\0" * 80
+        assert len(ka) == K.KA_SCHED
+        ka += CHK.sched_bytes(tm, tn, tm * tn, group_m=min(gm, tm), xcd=True)
+        assert len(ka) == K.KERNARG_SIZE, len(ka)
         buf = C.create_string_buffer(ka, len(ka))
         size = C.c_size_t(len(ka))
         extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)

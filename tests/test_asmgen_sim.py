@@ -125,6 +125,18 @@ def test_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, kw):
     assert C.run_case(name, M, N, Kd, verbose=False, **kw)
 
 
+DEEP_CASES = [("exact_64x64x32", 70, 50, 33, {}), ("exact_64x64x32", 64, 64, 96, {}), ("exact_64x64x32", 70, 50, 97, dict(alpha=0.5, beta=0.25)),
+              ("exact_64x64x32", 70, 50, 131, {}), ("exact_64x64x32", 64, 64, 1057, {}), ("fast_64x64x32_nt", 70, 90, 161, dict(alpha=0.5)),
+              ("exact_64x64x32_nt", 130, 70, 1100, dict(G=5, split=True)), ("fast_64x64x32", 100, 100, 545, dict(G=3, split=5, integer=True))]
+
+
+@pytest.mark.parametrize("name,M,N,Kd,kw", DEEP_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}" for c in DEEP_CASES])
+def test_two_tile_prefetch_option_in_the_interpreter(name, M, N, Kd, kw):
+    """Cfg.deep (two sets of staging registers, a K-tile requested two bodies ahead; no shipped kernel uses it -- it measured no
+    faster): one, two, three, four and many K-tiles, ragged K, K % 4 != 0, folds, a cut launch"""
+    assert C.run_case(name, M, N, Kd, verbose=False, over={"deep": True}, **kw)
+
+
 def test_one_chain_split_matches_within_rounding():
     """random data through a cut one-chain launch: not bit-equal to the single chain by design (the order did change), equal within
     float32 rounding (the sum did not)"""
