@@ -1308,6 +1308,7 @@ int laser_hip_finalize(void) {
     D.device = -1;
   }
   asm_kernels_release();
+  scratch_pools_trim();
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_ctx.device >= 0) (void)hipSetDevice(g_ctx.device);
   for (auto &kv : g_panels) (void)hipFree(kv.second.ptr);

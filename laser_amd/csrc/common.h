@@ -11,8 +11,9 @@ namespace laser_hip {
 // release threshold is raised once per device to 4 GiB -- at the default (0) every synchronisation hands the pool's free memory
 // back to the driver and the next call pays for mapping it again (a packed 4096^3 product timed 4 calls per synchronise lost
 // 60 us per call to that: profiles/r04/colmajor_a_probe_v1.jsonl against configs_v5.jsonl).
+inline std::atomic<unsigned long long> g_scratch_pool_devs{0};      // one bit per device ordinal (< 64) whose pool was raised
 inline hipError_t scratch_alloc_async(void **p, size_t bytes, hipStream_t s) {
-  static std::atomic<unsigned long long> done{0};      // one bit per device ordinal (< 64)
+  std::atomic<unsigned long long> &done = g_scratch_pool_devs;
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(done.load(std::memory_order_relaxed) >> dev & 1ull)) {
     hipMemPool_t pool = nullptr;
@@ -23,6 +24,15 @@ inline hipError_t scratch_alloc_async(void **p, size_t bytes, hipStream_t s) {
     done.fetch_or(1ull << dev, std::memory_order_relaxed);
   }
   return hipMallocAsync(p, bytes, s);
+}
+// laser_hip_finalize: the pools give back what they kept
+inline void scratch_pools_trim() {
+  const unsigned long long devs = g_scratch_pool_devs.load(std::memory_order_relaxed);
+  for (int dev = 0; dev < 64; dev++) {
+    if (!(devs >> dev & 1ull)) continue;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr) (void)hipMemPoolTrimTo(pool, 0);
+  }
 }
 
 // One-time-per-DEVICE initialisation of a kernel (hipFuncSetAttribute acts on the current device's instance of the
