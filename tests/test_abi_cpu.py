@@ -116,3 +116,25 @@ def test_no_kernel_in_the_library_spills():
     bad = [(n, k.get(".vgpr_spill_count"), k.get(".sgpr_spill_count"), k.get(".private_segment_fixed_size")) for n, k in ks
            if k.get(".vgpr_spill_count", 0) or k.get(".private_segment_fixed_size", 0)]
     assert not bad, bad[:5]
+
+
+def test_scalar_filter_conv_kernels_keep_their_scalars_and_their_occupancy():
+    """conv_small.hip's 3x3 kernels hold the filter in SGPRs (a channel's nine values pinned behind a scheduling barrier): left alone the
+    compiler hoists all scalar loads of the loop body and spills the scalars through v_writelane / v_readlane (827 lane reads against 360
+    packed FMAs in the first build) -- the metadata must show no SGPR spill (the padded forms: at most a dozen); and the pixel-pair form must fit eight waves per SIMD
+    (<= 64 VGPRs) up to 20 output channels, the general-stride form five (<= 96)."""
+    import laser_amd
+    ks = dict(_device_kernels(laser_amd.LIB_PATH))
+    pairs = {n: k for n, k in ks.items() if "conv_direct_pairs_kernel" in n}
+    scalar = {n: k for n, k in ks.items() if "conv_direct_scalar_kernel" in n}
+    assert len(pairs) == 6 and len(scalar) == 12, (sorted(pairs), sorted(scalar))
+    for n, k in list(pairs.items()) + list(scalar.items()):
+        # (the padded forms keep eighteen per-tap bounds masks beside the filter values: a handful of scalars may go through a lane of
+        # a vector register there -- a dozen, not the hundreds of the hoisted build)
+        padded = "Lb1E" in n
+        assert k.get(".sgpr_spill_count", 0) <= (16 if padded else 0) and k.get(".vgpr_spill_count", 0) == 0, (n, k.get(".sgpr_spill_count"))
+    for n, k in pairs.items():
+        mt = int(n.split("conv_direct_pairs_kernelILi")[1].split("E")[0])
+        assert k[".vgpr_count"] <= (64 if mt <= 20 else 80), (n, k[".vgpr_count"])
+    for n, k in scalar.items():
+        assert k[".vgpr_count"] <= 104, (n, k[".vgpr_count"])
