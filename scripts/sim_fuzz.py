@@ -2,17 +2,20 @@
 """Randomised cases through the interpreter (laser_amd/asmgen/sim.py) for every shipped assembly kernel -- f32 GEMM (all tiles, plain /
 transposed B, alpha / beta, batches, fused bias / relu), f64 (alpha / beta, batches), int32 / int64 (alpha / beta), 3x3 convolutions (any
 padding, bias / relu): addresses, layouts, counted waits and hazards of the generated programs, no GPU needed.
+Round 4: + persistent launches with K-slice cuts (one- and two-level ranges, both receive paths, XCD remap, raster groups; f32 and f64),
+strided C views, the fused-prologue kernels, the two-tile prefetch option.
 usage: sim_fuzz.py [seed] [seconds]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from laser_amd.asmgen import check as C, f32_kernel as K
+C.BANK_MODEL = False      # (bank-conflict statistics: a quarter of the interpreter's time, not a correctness check)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 T = float(sys.argv[2]) if len(sys.argv) > 2 else 600
 gemm = [n for n in K.CONFIGS if not n.startswith("conv")]
 t0 = time.time(); n = fails = 0
 while time.time() - t0 < T:
-    kind = rng.choice(["f32", "f32", "f64", "i32", "i64", "conv"])
+    kind = rng.choice(["f32", "f32", "f64", "i32", "i64", "conv", "sched", "sched", "sched64", "view"])
     try:
         if kind == "f32":
             name = str(rng.choice(gemm)); c = K.CONFIGS[name]
@@ -34,6 +37,52 @@ while time.time() - t0 < T:
                       batch=int(rng.choice([1, 2])), seed=int(rng.integers(1 << 30)))
             kw["ldb"] = (Kd if c.get("b_kcontig") else N) + int(rng.integers(0, 4))
             ok = C.run_case64(name, M, N, Kd, verbose=False, **kw); desc = (name, M, N, Kd, kw)
+        elif kind in ("sched", "sched64"):
+            # persistent launches: G workgroups share tiles x K-slice units; cut tiles handed over in-kernel (one-level and two-level
+            # ranges, either receive path, XCD remap, raster groups); one-chain kernels on integer-valued operands (their cut moves the
+            # rounding points, not the sum); a fifth of the f32 cases on the two-tile prefetch option
+            f64 = kind == "sched64"
+            if f64:
+                from laser_amd.asmgen import f64_kernel as K64
+                name = str(rng.choice([n_ for n_ in K64.CONFIGS])); c = K64.CONFIGS[name]; kc, bk = 256, c["BK"]
+            else:
+                name = str(rng.choice([n_ for n_ in gemm if "_pre" not in n_])); c = K.CONFIGS[name]; kc, bk = 512, c["BK"]
+            tm, tn = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            if rng.random() < 0.25: tm, tn = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+            M, N = (tm - 1) * c["BM"] + int(rng.integers(1, c["BM"] + 1)), (tn - 1) * c["BN"] + int(rng.integers(1, c["BN"] + 1))
+            Kd = int(rng.choice([rng.integers(kc + 1, 2 * kc + 40), rng.integers(2 * kc + 1, 4 * kc + 60), rng.integers(1, kc)]))
+            if f64: Kd += Kd & 1
+            exact = bool(c.get("exact", False))
+            P = -(-Kd // kc) if exact else max(1, -(-Kd // (bk * 5)))
+            units = tm * tn * P
+            G = int(rng.integers(1, units + 1))
+            kw = dict(G=G, split=(True if exact else 5), seed=int(rng.integers(1 << 30)), noseed=int(rng.random() < 0.4),
+                      alpha=float(rng.choice([1.0, 1.0, 0.5])), beta=float(rng.choice([0.0, 0.0, 0.25])))
+            if not exact: kw.update(integer=True, alpha=1.0, beta=float(rng.choice([0.0, 1.0])))
+            if rng.random() < 0.5: kw["group_m"] = int(rng.integers(1, tm + 1))
+            if tm * tn >= 8 and rng.random() < 0.5:
+                G = 8 * int(rng.integers(1, max(2, min(units, 4 * tm * tn) // 8 + 1)))
+                if (tm * tn // 8) * P >= G // 8: kw.update(G=G, two_level=True, xcd=True)
+            elif kw["G"] >= 8 and rng.random() < 0.5:
+                kw["xcd"] = True
+            if not f64 and rng.random() < 0.2 and c["BM"] == 64: kw["over"] = {"deep": True}
+            ok = (C.run_case64 if f64 else C.run_case)(name, M, N, Kd, verbose=False, **kw); desc = (name, M, N, Kd, kw)
+        elif kind == "view":
+            # C views (column stride, interleaved rows) and the fused prologue's kernel variants
+            if rng.random() < 0.5:
+                name = str(rng.choice([n_ for n_ in gemm if "_pre" not in n_])); c = K.CONFIGS[name]
+                M, N = int(rng.integers(1, 2 * c["BM"] + 20)), int(rng.integers(1, 2 * c["BN"] + 20))
+                Kd = int(rng.choice([rng.integers(1, 70), rng.integers(500, 1100)]))
+                csc = int(rng.integers(2, 4))
+                kw = dict(csc=csc, seed=int(rng.integers(1 << 30)), beta=float(rng.choice([0.0, 0.5])))
+                if rng.random() < 0.5: kw.update(ldc=(N - 1) * csc + 1 + int(rng.integers(0, 4)))
+                else: kw.update(interleaved=True, ldc=2) if csc >= M * 2 + 1 else kw.update(ldc=(N - 1) * csc + 1)
+            else:
+                name = str(rng.choice([n_ for n_ in gemm if "_pre" in n_])); c = K.CONFIGS[name]
+                M, N = int(rng.integers(1, 2 * c["BM"] + 20)), int(rng.integers(1, 2 * c["BN"] + 20))
+                Kd = int(rng.choice([rng.integers(1, 70), rng.integers(500, 1100)]))
+                kw = dict(pre=int(rng.integers(1, 4)), seed=int(rng.integers(1 << 30)), beta=float(rng.choice([0.0, 0.25])))
+            ok = C.run_case(name, M, N, Kd, verbose=False, **kw); desc = (name, M, N, Kd, kw)
         elif kind == "i32":
             M, N, Kd = int(rng.integers(1, 270)), int(rng.integers(1, 270)), int(rng.integers(1, 200))
             kw = dict(ldc=N + int(rng.integers(0, 4)), alpha=int(rng.choice([1, -3, 2**31 - 1])), beta=int(rng.choice([0, 1, 7])), seed=int(rng.integers(1 << 30)))
