@@ -44,7 +44,7 @@ while time.time() - t0 < T:
             f64 = kind == "sched64"
             if f64:
                 from laser_amd.asmgen import f64_kernel as K64
-                name = str(rng.choice([n_ for n_ in K64.CONFIGS])); c = K64.CONFIGS[name]; kc, bk = 256, c["BK"]
+                name = str(rng.choice([n_ for n_ in K64.CONFIGS])); c = K64.CONFIGS[name]; kc, bk = 256, c["BK"]      # (its operands are integer-valued: every cut is exact)
             else:
                 name = str(rng.choice([n_ for n_ in gemm if "_pre" not in n_])); c = K.CONFIGS[name]; kc, bk = 512, c["BK"]
             tm, tn = int(rng.integers(1, 4)), int(rng.integers(1, 4))
@@ -58,7 +58,8 @@ while time.time() - t0 < T:
             G = int(rng.integers(1, units + 1))
             kw = dict(G=G, split=(True if exact else 5), seed=int(rng.integers(1 << 30)), noseed=int(rng.random() < 0.4),
                       alpha=float(rng.choice([1.0, 1.0, 0.5])), beta=float(rng.choice([0.0, 0.0, 0.25])))
-            if not exact: kw.update(integer=True, alpha=1.0, beta=float(rng.choice([0.0, 1.0])))
+            if not exact: kw.update(alpha=1.0, beta=float(rng.choice([0.0, 1.0])))
+            if not exact and not f64: kw["integer"] = True
             if rng.random() < 0.5: kw["group_m"] = int(rng.integers(1, tm + 1))
             if tm * tn >= 8 and rng.random() < 0.5:
                 G = 8 * int(rng.integers(1, max(2, min(units, 4 * tm * tn) // 8 + 1)))
@@ -75,8 +76,9 @@ while time.time() - t0 < T:
                 Kd = int(rng.choice([rng.integers(1, 70), rng.integers(500, 1100)]))
                 csc = int(rng.integers(2, 4))
                 kw = dict(csc=csc, seed=int(rng.integers(1 << 30)), beta=float(rng.choice([0.0, 0.5])))
-                if rng.random() < 0.5: kw.update(ldc=(N - 1) * csc + 1 + int(rng.integers(0, 4)))
-                else: kw.update(interleaved=True, ldc=2) if csc >= M * 2 + 1 else kw.update(ldc=(N - 1) * csc + 1)
+                # (rows must be the slow direction of the view the kernel sees: rowStride >= (N - 1) * colStride + 1 -- the launcher
+                # runs the transposed product otherwise, gemm_f32_asm.cpp)
+                kw.update(ldc=(N - 1) * csc + 1 + int(rng.integers(0, 4)))
             else:
                 name = str(rng.choice([n_ for n_ in gemm if "_pre" in n_])); c = K.CONFIGS[name]
                 M, N = int(rng.integers(1, 2 * c["BM"] + 20)), int(rng.integers(1, 2 * c["BN"] + 20))
@@ -99,8 +101,8 @@ while time.time() - t0 < T:
             M = int(rng.integers(1, c["BM"] + 30))
             kw = dict(seed=int(rng.integers(1 << 30)), bias=bool(rng.random() < 0.3), act=int(rng.integers(0, 2)))
             ok = C.run_conv_case(name, int(rng.integers(1, 3)), Cin, H, W, M, pad, verbose=False, **kw); desc = (name, Cin, H, W, M, pad, kw)
-    except AssertionError as e:
-        ok = False; desc = ("ASSERT", kind, str(e)[:200])
+    except (AssertionError, TypeError, KeyError, ValueError) as e:
+        ok = False; desc = (type(e).__name__, kind, str(e)[:200])
     n += 1
     if not ok:
         fails += 1; print("FAIL", desc, flush=True)
