@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from laser_amd.asmgen import i8_kernel as KI, f32_kernel as K  # noqa: E402
-from scripts.asm_probe import make_table, CLANG, LLD, hip  # noqa: E402
+from laser_amd.asmgen import check as CHK  # noqa: E402
+from scripts.asm_probe import CLANG, LLD, hip  # noqa: E402
 
 args = sys.argv[1:]
 n = int(args[args.index("--n") + 1]) if "--n" in args else 8192
@@ -19,7 +20,6 @@ Ap = torch.randint(-128, 128, (4 * npad * kt * 32,), dtype=torch.int8, device="c
 Bp = torch.randint(-128, 128, (4 * npad * kt * 32,), dtype=torch.int8, device="cuda")
 Cm = torch.zeros((n, n), dtype=torch.int32, device="cuda")
 tm = npad // 128
-table = torch.tensor(make_table(tm, tm, 8), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 built = []
 for var in variants:
@@ -32,7 +32,11 @@ for var in variants:
     mod, fn = C.c_void_p(), C.c_void_p()
     assert hip.hipModuleLoad(C.byref(mod), (sp + ".hsaco").encode()) == 0
     assert hip.hipModuleGetFunction(C.byref(fn), mod, b"lh_probe") == 0
-    ka = struct.pack("<QQQQIIIIIIffQ", Ap.data_ptr(), Bp.data_ptr(), Cm.data_ptr(), table.data_ptr(), kt, 0, n, n, n, kt * 32, 1.0, 0.0, 0) + b"\0" * 80
+    # the kernel arguments as gemm_f32_asm.cpp: launch_gemm_i32_asm fills them (alpha = 1, beta = 0 as int32; the scheduler block of
+    # the plain plan: one tile per workgroup, XCD remap, raster groups of 8 tile rows)
+    ka = struct.pack("<QQQQIIIIIIiiQ", Ap.data_ptr(), Bp.data_ptr(), Cm.data_ptr(), 0, kt, 0, n, n, n, kt * 32, 1, 0, 0) + b"\0" * 80
+    ka += CHK.sched_bytes(tm, tm, tm * tm, group_m=min(8, tm), xcd=True)
+    assert len(ka) == K.KERNARG_SIZE
     buf = C.create_string_buffer(ka, len(ka)); size = C.c_size_t(len(ka))
     extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)
     built.append((var, fn, buf, size, extra))
