@@ -35,13 +35,28 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 # laser_hip_last_f32_asm() -> the hand-scheduled assembly kernel the last launch ran (laser_amd/csrc/gemm_f32_asm.cpp)
-ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerate(
-    ["lh_f32_exact_256x128x32", "lh_f32_fast_256x256x16", "lh_f32_exact_128x128x16", "lh_f32_fast_128x128x16",
-     "lh_f32_exact_256x128x32_nt", "lh_f32_fast_256x256x16_nt", "lh_f32_exact_128x128x16_nt", "lh_f32_fast_128x128x16_nt",
-     "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt", "lh_f32_conv3x3_exact_256x128x32", "lh_f32_conv3x3_fast_256x128x32",
-     "lh_f32_exact_64x64x32", "lh_f32_fast_64x64x32", "lh_f32_exact_64x64x32_nt", "lh_f32_fast_64x64x32_nt",
-     "lh_f64_exact_128x128x16", "lh_f64_fast_128x128x16", "lh_f64_exact_64x64x16", "lh_f64_fast_64x64x16", "lh_i32_128x128x32",
-     "lh_f32_conv3x3_exact_128x128x32", "lh_f32_conv3x3_fast_128x128x32", "lh_f32_conv3x3_exact_64x128x32", "lh_f32_conv3x3_fast_64x128x32"])}
+# (the symbol table of gemm_f32_asm.cpp: kKernels, in order; tests/test_host_logic_cpu.py checks the two lists agree)
+ASM_KERNEL_SYMBOLS = [
+    "lh_f32_exact_256x128x32", "lh_f32_fast_256x256x16", "lh_f32_exact_128x128x16", "lh_f32_fast_128x128x16",
+    "lh_f32_exact_256x128x32_nt", "lh_f32_fast_256x256x16_nt", "lh_f32_exact_128x128x16_nt", "lh_f32_fast_128x128x16_nt",
+    "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt", "lh_f32_conv3x3_exact_256x128x32", "lh_f32_conv3x3_fast_256x128x32",
+    "lh_f32_exact_64x64x32", "lh_f32_fast_64x64x32", "lh_f32_exact_64x64x32_nt", "lh_f32_fast_64x64x32_nt",
+    "lh_f64_exact_128x128x16", "lh_f64_fast_128x128x16", "lh_f64_exact_64x64x16", "lh_f64_fast_64x64x16", "lh_i32_128x128x32",
+    "lh_f32_conv3x3_exact_128x128x32", "lh_f32_conv3x3_fast_128x128x32", "lh_f32_conv3x3_exact_64x128x32", "lh_f32_conv3x3_fast_64x128x32",
+    "lh_f64_exact_128x128x16_nt", "lh_f64_fast_128x128x16_nt", "lh_f64_exact_64x64x16_nt", "lh_f64_fast_64x64x16_nt", "lh_i64_64x64x32",
+    "lh_f32_exact_128x128x32", "lh_f32_fast_128x128x32", "lh_f32_exact_128x128x32_nt", "lh_f32_fast_128x128x32_nt",
+    "lh_f32_exact_256x128x32_pre", "lh_f32_exact_256x128x32_pre_nt", "lh_f32_fast_256x256x16_pre", "lh_f32_fast_256x256x16_pre_nt",
+    "lh_f32_exact_128x128x16_pre", "lh_f32_exact_128x128x16_pre_nt", "lh_f32_fast_128x128x16_pre", "lh_f32_fast_128x128x16_pre_nt",
+    "lh_f32_exact_64x64x32_pre", "lh_f32_exact_64x64x32_pre_nt", "lh_f32_fast_64x64x32_pre", "lh_f32_fast_64x64x32_pre_nt"]
+ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerate(ASM_KERNEL_SYMBOLS)}
+COMPILER_KERNEL_NAME = "gemm_mfma_kernel<float,...> (compiler-scheduled)"
+
+
+def last_kernel_name(laser_amd):
+    """Name of the kernel the last f32 GEMM launch of this process ran (laser_hip_get_option "last_f32_asm")."""
+    return ASM_KERNEL_NAMES.get(laser_amd.last_f32_asm(), COMPILER_KERNEL_NAME)
+
+
 SIZE = 8192
 
 
@@ -182,6 +197,14 @@ def side_configs(budget_s=10.0):
         return {"launches": n, "min_ms": round(ts[0], 4), "median_ms": round(ts[n // 2], 4), "max_ms": round(ts[-1], 4),
                 "mean_ms": round(sum(ts) / n, 4)}
 
+    def side_roofline(flops, st_):
+        """`roofline` of a side line: algorithmic flops / the AVERAGE duration of one call (every launch timed on its own with HIP
+        events on the launch stream) against the fp32 MFMA peak; `kernel` = what the last launch ran."""
+        tf_ = flops / (st_["mean_ms"] * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(tf_, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf_ / FP32_MFMA_PEAK_TFLOPS, 4), "kernel": last_kernel_name(laser_amd), "kernel_ms": st_["mean_ms"],
+                "launches_timed": st_["launches"], "algorithmic_flops_per_launch": flops}
+
     def gpu_ms(fn, inner=4, reps=3):
         # steady state: the clocks ramp up over the first ~20 ms of work after an idle gap (the CPU oracle runs between the
         # lines); a C4 conv launch measured 470 us right after idle and 405 us fifty launches later
@@ -239,7 +262,7 @@ def side_configs(budget_s=10.0):
         elif stats:
             st_ = gpu_ms_stats(mirror)
             ms = st_["median_ms"]
-            extra = {"timing": st_, "kernel": laser_amd.last_f32_asm()}
+            extra = {"timing": st_, "kernel": laser_amd.last_f32_asm(), "roofline": side_roofline(2.0 * M * N * K, st_)}
         else:
             ms = gpu_ms(mirror)
             extra = {"kernel": laser_amd.last_f32_asm()}
@@ -275,9 +298,11 @@ def side_configs(budget_s=10.0):
                 ms = gpu_ms(lambda: fn(*cargs), inner=16)
                 extra = {"python_mirror_ms": round(gpu_ms(mirror, inner=16), 4), "timed": "C-ABI entry bound once via ctypes",
                          "hbm_frac": round(4.0 * (x.numel() + o.numel()) / (ms * 1e-3) / 8e12, 3)}
-            else:
-                ms = gpu_ms(mirror)
             fl = 2.0 * oshape[0] * oshape[1] * oshape[2] * oshape[3] * kshape[1] * kshape[2] * kshape[3]
+            if kshape[0] > 32:           # C4: every call timed on its own, like C3 (one call = the main launch + any tail launches)
+                st_ = gpu_ms_stats(mirror)
+                ms = st_["median_ms"]
+                extra = {"timing": st_, "roofline": side_roofline(fl, st_), "tail_cut_at_pixel": laser_amd.last_split()}
             tf = fl / (ms * 1e-3) / 1e12
             xh, wh = x.cpu().numpy(), w.cpu().numpy()
             cs = cpu_s(lambda: oracle.conv2d_im2col(xh, wh, pad, st))
@@ -425,8 +450,7 @@ def single_process_primary(args):
         },
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": ASM_KERNEL_NAMES.get(
-                         laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
+                     "kernel": last_kernel_name(laser_amd),
                      "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": fl,
                      "note": "per-GPU kernel alone (device slot 0's row share as one launch), timed after the sharded run"},
     }
@@ -603,7 +627,7 @@ def main():
 
     n = args.size
     M_total, N, K = n * world, n, n
-    from laser_amd.distributed import ShardedGemm, SHARDED_TILE_CONFIG
+    from laser_amd.distributed import ShardedGemm, SHARDED_ASM_TILE, SHARDED_TILE_NAME
 
     # Operands: hashed_rows (uniform [-0.1, 0.1), a pure function of the global index)
     def hashed(rows, cols, salt):
@@ -618,8 +642,8 @@ def main():
             torch.cuda.synchronize()
 
     def build(ppr, tile, gather="collective"):
-        """The sharded problem for `ppr` block-cyclic panels per rank; tile: None = the 128x128 pin of sharded runs,
-        -1 = the library heuristic, >= 0 = that configuration; gather: one all-gather collective per slab, or the same
+        """The sharded problem for `ppr` block-cyclic panels per rank; tile: None = the 128x128x16 ASSEMBLY tile pinned for sharded
+        runs (option asm_tile), -1 = the library heuristic (the 256x128 assembly tile at this size), >= 0 = that compiler configuration; gather: one all-gather collective per slab, or the same
         exchange as grouped point-to-point sends.  Returns (ShardedGemm, this rank's A panels, full C)."""
         g = ShardedGemm(M_total, N, K, torch.float32, dev, None, ppr if world > 1 else 1, tile_config=tile, gather=gather)
         pl = g.plan
@@ -644,7 +668,7 @@ def main():
         gathers = [args.gather] if args.gather != "auto" else ["collective", "p2p"]
         cands = [(ppr, tile, ga) for ga in gathers for tile in tiles for ppr in pprs]
         for ppr, tile, ga in cands:
-            rec = {"panels_per_rank": ppr, "tile": "128x128 pinned" if tile is None else
+            rec = {"panels_per_rank": ppr, "tile": "128x128x16 assembly tile pinned" if tile is None else
                    ("heuristic" if tile == -1 else laser_amd.f32_configs()[tile]), "gather": ga}
             ok = 1.0
             try:
@@ -709,26 +733,62 @@ def main():
     err = (C[check_rows].double() - ref).abs().max().item()
     assert err < 1e-4, f"bench self-check failed on rank {rank}: max abs err {err}"
 
-    # N > 1: the roofline object still prices the GEMM kernel alone -- this rank's 8192-row share, timed with
-    # HIP events on the launch stream after the timed region (no collective inside, every rank does the same)
-    k_ms_multi = None
+    # N > 1: (i) the same panels WITHOUT the exchange (compute-only: what the step would cost if the gather were free), max over
+    # ranks; (ii) the roofline object prices the GEMM kernel alone -- this rank's row share as ONE launch under the same tile pin
+    # the sharded run used, HIP events on the launch stream; (iii) who took part: every rank reports its device, so the line shows
+    # whether RCCL really spanned N GPUs
+    k_ms_multi = compute_only_ms = ranks_seen = None
     if world > 1:
+        def pinned(fn):
+            prev = laser_amd.get_option("asm_tile")
+            if tile_choice is None:
+                laser_amd.set_option("asm_tile", SHARDED_ASM_TILE)
+            elif tile_choice >= 0:
+                laser_amd.set_f32_config(tile_choice)
+            try:
+                return fn()
+            finally:
+                laser_amd.set_option("asm_tile", prev)
+                laser_amd.set_f32_config(args.cfg)
+
+        def panels_only():
+            for s_ in range(p.panels_per_rank):
+                start, valid = p.panel(s_, rank)
+                if valid > 0:
+                    laser_amd.matmul(A_local[s_ * p.rows: s_ * p.rows + valid], B, 1, 0, C[start:start + valid])
+
+        def timed_compute_only():
+            panels_only()
+            fence()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                panels_only()
+            fence()
+            return (time.perf_counter() - t0_) / args.steps * 1e3
+        tc = torch.tensor([pinned(timed_compute_only)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        compute_only_ms = float(tc.item())
+
         rows_local = min(n, A_local.shape[0])
-        names = laser_amd.f32_configs()   # same tile configuration as the sharded run used
-        laser_amd.set_f32_config(tile_choice if tile_choice is not None else names.index(SHARDED_TILE_CONFIG))
         Cs = torch.zeros((rows_local, N), dtype=torch.float32, device=dev)
-        for _ in range(2):
-            laser_amd.matmul(A_local[:rows_local], B, 1, 0, Cs)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
-            laser_amd.matmul(A_local[:rows_local], B, 1, 0, Cs)
-        e1.record()
-        torch.cuda.synchronize()
-        k_ms_multi = (e0.elapsed_time(e1) / args.steps, rows_local)
-        laser_amd.set_f32_config(args.cfg)
+
+        def timed_kernel():
+            for _ in range(2):
+                laser_amd.matmul(A_local[:rows_local], B, 1, 0, Cs)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                laser_amd.matmul(A_local[:rows_local], B, 1, 0, Cs)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / args.steps, rows_local, last_kernel_name(laser_amd)
+        k_ms_multi = pinned(timed_kernel)
         del Cs
+        me = {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
+              "kernel": k_ms_multi[2], "kernel_ms": round(k_ms_multi[0], 4)}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
 
     if rank == 0:
         flops_step = 2.0 * M_total * N * K
@@ -748,7 +808,7 @@ def main():
                 "M": M_total, "N": N, "K": K, "accumulation": mode,
                 "tile_config": (laser_amd.f32_configs()[args.cfg] if args.cfg >= 0 else
                                 "heuristic" if (world == 1 or tile_choice == -1) else
-                                SHARDED_TILE_CONFIG + " (pinned for sharded runs: shares the CUs with RCCL)"),
+                                SHARDED_TILE_NAME + " (pinned for sharded runs: shares the CUs with RCCL)"),
                 "parallelism": f"row-panels x{world}" + (f", {sg.plan.panels_per_rank} block-cyclic panels/rank" if world > 1 else ""),
                 "pct_of_fp32_mfma_peak": round(100.0 * value / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 2),
             },
@@ -767,8 +827,7 @@ def main():
                 "stddev": round((sum((x - mean) ** 2 for x in per) / max(1, len(per) - 1)) ** 0.5, 4)}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": ASM_KERNEL_NAMES.get(
-                                   laser_amd.last_f32_asm(), "gemm_mfma_kernel<float,...>"),
+                               "kernel": last_kernel_name(laser_amd),
                                "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": 2.0 * n * n * n}
             tr = pmc_traffic(mode) if (n == SIZE and args.cfg < 0) else None   # the profiled shape / configuration only
             if tr is not None:
@@ -797,12 +856,18 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         else:
-            k_ms, rows_local = k_ms_multi
+            k_ms, rows_local, k_name = k_ms_multi
             fl = 2.0 * rows_local * N * K
             ach = fl / (k_ms * 1e-3) / 1e12
+            # the step, taken apart: the same panels without the exchange, and what the exchange left exposed
+            out["config"]["compute_only_ms"] = round(compute_only_ms, 4)
+            out["config"]["exposed_gather_ms"] = round(ms_per_step - compute_only_ms, 4)
+            out["config"]["compute_only_gflops"] = round(flops_step / (compute_only_ms * 1e-3) / 1e9, 1)
+            out["config"]["backend"] = {"name": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks_seen,
+                                        "distinct_devices": len({r_["device"] for r_ in ranks_seen})}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "gemm_mfma_kernel<float,...>", "kernel_ms": round(k_ms, 4),
+                               "kernel": k_name, "kernel_ms": round(k_ms, 4),
                                "algorithmic_flops_per_launch": fl,
                                "note": "per-GPU kernel alone (rank 0's row share as one launch), timed after the sharded run"}
             # (traffic stays null: the committed PMC passes profiled the single-GPU run's tile configuration)

@@ -114,15 +114,19 @@ inline void gemm_prepack_release(void *packed) { check(laser_hip_gemm_prepack_re
 // swapaxes.nim:16-112
 template <typename T>
 void transpose2D_copy(T *dst, const T *src, int64_t NR, int64_t NC) {
-  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte elements");
+  static_assert(sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4 || sizeof(T) == 8, "1-, 2-, 4- or 8-byte elements");
   if constexpr (sizeof(T) == 4) check(laser_hip_transpose2d_copy_b32(dst, src, NR, NC));
-  else check(laser_hip_transpose2d_copy_b64(dst, src, NR, NC));
+  else if constexpr (sizeof(T) == 8) check(laser_hip_transpose2d_copy_b64(dst, src, NR, NC));
+  else if constexpr (sizeof(T) == 2) check(laser_hip_transpose2d_copy_b16(dst, src, NR, NC));
+  else check(laser_hip_transpose2d_copy_b8(dst, src, NR, NC));
 }
 template <typename T>
 void transpose2D_batched(T *dst, const T *src, int64_t N, int64_t NR, int64_t NC) {
-  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte elements");
+  static_assert(sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4 || sizeof(T) == 8, "1-, 2-, 4- or 8-byte elements");
   if constexpr (sizeof(T) == 4) check(laser_hip_transpose2d_batched_b32(dst, src, N, NR, NC));
-  else check(laser_hip_transpose2d_batched_b64(dst, src, N, NR, NC));
+  else if constexpr (sizeof(T) == 8) check(laser_hip_transpose2d_batched_b64(dst, src, N, NR, NC));
+  else if constexpr (sizeof(T) == 2) check(laser_hip_transpose2d_batched_b16(dst, src, N, NR, NC));
+  else check(laser_hip_transpose2d_batched_b8(dst, src, N, NR, NC));
 }
 template <typename T>
 void nchw2nhwc(T *dst_nhwc, const T *src_nchw, int64_t N, int64_t C, int64_t H, int64_t W) {
@@ -142,10 +146,17 @@ inline TensorShape conv2d_out_shape(TensorShape i, KernelShape k, Padding p, Str
 inline int64_t im2col_workspace_size(TensorShape i, KernelShape k, Padding p, Strides s) {
   return laser_hip_im2col_workspace_size(i.n, i.c, i.h, i.w, k.c_out, k.c_in, k.kH, k.kW, p.h, p.w, s.h, s.w);
 }
-inline void im2col(float *pworkspace, TensorShape oshape, const float *pinput, TensorShape ishape, KernelShape kshape,
-                   Padding padding, Strides strides) {
-  check(laser_hip_im2col_f32(pworkspace, oshape.h, oshape.w, pinput, ishape.c, ishape.h, ishape.w, kshape.kH, kshape.kW,
-                             padding.h, padding.w, strides.h, strides.w));
+// (conv2d_im2col.nim:42-50: generic in T; pure data movement, so dispatched on the element size)
+template <typename T>
+void im2col(T *pworkspace, TensorShape oshape, const T *pinput, TensorShape ishape, KernelShape kshape, Padding padding,
+            Strides strides) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte elements");
+  if constexpr (sizeof(T) == 4)
+    check(laser_hip_im2col_f32(reinterpret_cast<float *>(pworkspace), oshape.h, oshape.w, reinterpret_cast<const float *>(pinput),
+                               ishape.c, ishape.h, ishape.w, kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w));
+  else
+    check(laser_hip_im2col_f64(reinterpret_cast<double *>(pworkspace), oshape.h, oshape.w, reinterpret_cast<const double *>(pinput),
+                               ishape.c, ishape.h, ishape.w, kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w));
 }
 inline void conv2d_im2col(float *output, TensorShape oshape, const float *input, TensorShape ishape, const float *kernel,
                           KernelShape kshape, Padding padding, Strides strides, float *pworkspace) {

@@ -105,6 +105,12 @@ int laser_hip_f32_config_count(void);
  *   "asm_kernel" [-1] / "asm_wgs" [0] / "asm_slice" [0] / "asm_noseed" [0] / "asm_group_m" [0]  tuning / test overrides of that plan:
  *                          force an assembly kernel index, the number of workgroups, the K-tiles per slice of a one-chain cut, the
  *                          two-run receive path, the tile rows per raster group (which tiles share an XCD's L2)
+ *   "asm_tile"        [-1] pin a tile CLASS of the f32 assembly GEMM kernels (accumulation mode / transposed-B variant still follow the
+ *                          call): 0 = 256x128 (laser-order) / 256x256, 1 = 256x128 one chain, 2 = 128x128x16 (two workgroups per CU:
+ *                          degrades gracefully when another library's kernels -- RCCL's -- hold some CUs), 3 = 128x128x32, 4 = 64x64;
+ *                          one tile per workgroup, no minimum tile count; -1 = the launcher's model decides.  The per-GPU processes
+ *                          of laser_amd/distributed.py set 2 around their local products; LASER_HIP_SHARD_PIN_TILE is the same pin
+ *                          per call and per worker thread inside the single-process sharded entry points
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
  *   "last_f32_asm" / "last_f64_asm" / "last_i32_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
@@ -149,12 +155,16 @@ LASER_HIP_DECL_GEMM(i64, int64_t)
  *
  * As in the reference the packed buffers are opaque, machine dependent and "unsafe to store or
  * serialize" (:120-123).  Host variant: the caller allocates `mem_required` bytes, 64-B aligned
- * (same doAssert as :125/:208 -> LASER_HIP_E_INVALID); the library uploads the operand ONCE into
- * a tile-padded device-resident panel image and writes a handle into the first 64 bytes of dst.
- * Device memory is released by laser_hip_gemm_prepack_release(dst) or laser_hip_finalize().
+ * (same doAssert as :125/:208 -> LASER_HIP_E_INVALID), and the buffer is SELF-CONTAINED like the
+ * reference's (:111-135, Design.md:5-7): a 64-byte header followed by the tile-padded panel image.
+ * It may be copied with memcpy and freed at will.  gemm_packed multiplies from a device-resident
+ * copy of the image that the library caches (made by the prepack call; re-made from the caller's
+ * buffer when it is missing; bounded -- least recently used first -- so freeing buffers without
+ * telling the library cannot leak HBM).  laser_hip_gemm_prepack_release(dst) drops the cached copy
+ * early and invalidates the buffer (optional); laser_hip_finalize() drops them all.
  * `_dev` variant: dst is a DEVICE buffer of `mem_required` bytes that receives the padded panel
- * image itself (no handle, nothing to release).  Unlike the reference (whose prepackA indexing is
- * only right for K <= kc, :186/:265) these are valid for every K. */
+ * image itself at offset 0 (no header, nothing cached).  Unlike the reference (whose prepackA
+ * indexing is only right for K <= kc, :186/:265) these are valid for every K. */
 #define LASER_HIP_DECL_PACK(SFX, T)                                                               \
   int64_t laser_hip_gemm_prepackA_mem_required_##SFX(int64_t M, int64_t N, int64_t K);            \
   int64_t laser_hip_gemm_prepackB_mem_required_##SFX(int64_t M, int64_t N, int64_t K);            \
@@ -187,7 +197,8 @@ int laser_hip_gemm_prepack_release(void *packed);
  * transpose2D_batched*[T](dst, src, N, NR, NC)  :56-84
  * nchw2nhwc*[T](dst, src, N, C, H, W)           :86-98   = transpose2D_batched(N, C, H*W)
  * nhwc2nchw*[T](dst, src, N, C, H, W)           :100-112 = transpose2D_batched(N, H*W, C)
- * Pure data movement: one entry point per element size (b32: float32/int32, b64: float64/int64). */
+ * Pure data movement, generic in T like the reference: one entry point per element SIZE (b32: float32 / int32, b64: float64 /
+ * int64, b16: float16 / int16, b8: int8 / uint8). */
 #define LASER_HIP_DECL_TR(SFX)                                                                    \
   int laser_hip_transpose2d_copy_##SFX(void *dst, const void *src, int64_t NR, int64_t NC);       \
   int laser_hip_transpose2d_batched_##SFX(void *dst, const void *src, int64_t N, int64_t NR,      \
@@ -200,6 +211,8 @@ int laser_hip_gemm_prepack_release(void *packed);
                                                 int64_t NR, int64_t NC, void *stream);
 LASER_HIP_DECL_TR(b32)
 LASER_HIP_DECL_TR(b64)
+LASER_HIP_DECL_TR(b16)
+LASER_HIP_DECL_TR(b8)
 #undef LASER_HIP_DECL_TR
 
 /* ---- im2col + GEMM convolution -- benchmarks/convolution/conv2d_im2col.nim -----------------------
@@ -218,11 +231,19 @@ int64_t laser_hip_im2col_workspace_size(int64_t iN, int64_t iC, int64_t iH, int6
                                         int64_t c_out, int64_t c_in, int64_t kH, int64_t kW,
                                         int64_t padH, int64_t padW, int64_t strideH,
                                         int64_t strideW);
-/* One image [iC, iH, iW] -> workspace [iC*kH*kW, oH*oW]. */
+/* One image [iC, iH, iW] -> workspace [iC*kH*kW, oH*oW].  im2col*[T] is generic in the reference (conv2d_im2col.nim:42-50):
+ * _f32 and _f64 here (pure data movement; integer tensors of the same element size can be passed through a cast). */
 int laser_hip_im2col_f32(float *pworkspace, int64_t oH, int64_t oW, const float *pinput, int64_t iC,
                          int64_t iH, int64_t iW, int64_t kH, int64_t kW, int64_t padH, int64_t padW,
                          int64_t strideH, int64_t strideW);
 int laser_hip_im2col_f32_dev(float *d_workspace, int64_t oH, int64_t oW, const float *d_input,
+                             int64_t batch, int64_t iC, int64_t iH, int64_t iW, int64_t kH,
+                             int64_t kW, int64_t padH, int64_t padW, int64_t strideH,
+                             int64_t strideW, void *stream);
+int laser_hip_im2col_f64(double *pworkspace, int64_t oH, int64_t oW, const double *pinput, int64_t iC,
+                         int64_t iH, int64_t iW, int64_t kH, int64_t kW, int64_t padH, int64_t padW,
+                         int64_t strideH, int64_t strideW);
+int laser_hip_im2col_f64_dev(double *d_workspace, int64_t oH, int64_t oW, const double *d_input,
                              int64_t batch, int64_t iC, int64_t iH, int64_t iW, int64_t kH,
                              int64_t kW, int64_t padH, int64_t padW, int64_t strideH,
                              int64_t strideW, void *stream);
@@ -404,7 +425,8 @@ int laser_hip_get_shard_devices(void);
  *                                        copy stream per peer (all xGMI links at once, SDMA engines, no CUs);
  *                 LASER_HIP_GATHER_RCCL  ncclAllGather per slab (librccl.so loaded on first use; needs
  *                                        rowStrideC == N and dC[g] sized for padded_M rows).
- *   flags         LASER_HIP_SHARD_PIN_TILE: 128x128 tiles for the local products (RCCL's kernels hold CUs meanwhile).
+ *   flags         LASER_HIP_SHARD_PIN_TILE: the hand-scheduled 128x128x16 assembly tile (option "asm_tile" = 2) for the local f32
+ *                 products of this call (RCCL's kernels hold CUs meanwhile); other dtypes ignore it.
  * On an error return the operand buffers must stay alive until the devices are idle (work queued by the failed call may still
  * name them); the library drops the streams it queued that work on and makes new ones for the next call. */
 #define LASER_HIP_GATHER_NONE 0

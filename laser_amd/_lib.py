@@ -82,7 +82,7 @@ def lib():
         getattr(L, f"laser_hip_gemm_strided_ex_{sfx}").argtypes = g
         getattr(L, f"laser_hip_gemm_strided_ex_{sfx}_dev").argtypes = g + [vp]
     L.laser_hip_gemm_prepack_release.argtypes = [vp]
-    for b in ("b32", "b64"):
+    for b in ("b32", "b64", "b16", "b8"):
         getattr(L, f"laser_hip_transpose2d_copy_{b}").argtypes = [vp, vp, i64, i64]
         getattr(L, f"laser_hip_transpose2d_batched_{b}").argtypes = [vp, vp, i64, i64, i64]
         getattr(L, f"laser_hip_nchw2nhwc_{b}").argtypes = [vp, vp, i64, i64, i64, i64]
@@ -93,6 +93,8 @@ def lib():
     L.laser_hip_im2col_workspace_size.restype = i64
     L.laser_hip_im2col_f32.argtypes = [vp, i64, i64, vp] + [i64] * 9
     L.laser_hip_im2col_f32_dev.argtypes = [vp, i64, i64, vp] + [i64] * 10 + [vp]
+    L.laser_hip_im2col_f64.argtypes = [vp, i64, i64, vp] + [i64] * 9
+    L.laser_hip_im2col_f64_dev.argtypes = [vp, i64, i64, vp] + [i64] * 10 + [vp]
     L.laser_hip_conv2d_im2col_f32.argtypes = [vp, vp, i64, i64, i64, i64, vp] + [i64] * 8 + [vp]
     L.laser_hip_conv2d_im2col_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp] + [i64] * 8 + [vp, vp]
     L.laser_hip_conv2d_im2col_ex_f32.argtypes = [vp, vp, i64, i64, i64, i64, vp] + [i64] * 8 + [vp, vp, ci]
@@ -149,7 +151,8 @@ def declared_symbols():
         for ab in "AB":
             names += [f"laser_hip_gemm_prepack{ab}_mem_required_{s}", f"laser_hip_gemm_prepack{ab}_{s}",
                       f"laser_hip_gemm_prepack{ab}_{s}_dev"]
-    for b in ("b32", "b64"):
+    names += ["laser_hip_im2col_f64", "laser_hip_im2col_f64_dev"]
+    for b in ("b32", "b64", "b16", "b8"):
         names += [f"laser_hip_transpose2d_copy_{b}", f"laser_hip_transpose2d_batched_{b}",
                   f"laser_hip_nchw2nhwc_{b}", f"laser_hip_nhwc2nchw_{b}",
                   f"laser_hip_transpose2d_batched_{b}_dev"]

@@ -12,8 +12,10 @@ int api_ensure_init();
 void api_set_thread_device(int device);
 int api_thread_device();
 // Tile-configuration override for the f32 launches made BY THIS THREAD (-2 = none: the process-wide setting applies).
-// The sharded entry point's workers use it to pin the 128x128 tile for one call without touching global state.
+// (Forces the compiler-scheduled kernel of that configuration: tests and tuning sweeps.)
 void api_set_thread_f32_config(int cfg);
+// Tile-class pin of the hand-scheduled f32 kernels for the launches made BY THIS THREAD (option "asm_tile"'s values; -2 = none).
+void api_set_thread_asm_tile(int tile_class);
 // sharded.cpp: host-pointer gemm_strided cut into one row range per GPU (ndev <= 0: every visible GPU)
 template <typename T>
 int api_sharded_host(int ndev, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *B,

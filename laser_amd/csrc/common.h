@@ -7,32 +7,53 @@
 
 namespace laser_hip {
 
-// Stream-ordered scratch (packing passes, limb planes, slice partials): hipMallocAsync from the device's default pool, whose
-// release threshold is raised once per device to 4 GiB -- at the default (0) every synchronisation hands the pool's free memory
-// back to the driver and the next call pays for mapping it again (a packed 4096^3 product timed 4 calls per synchronise lost
-// 60 us per call to that: profiles/r04/colmajor_a_probe_v1.jsonl against configs_v5.jsonl).
-inline std::atomic<unsigned long long> g_scratch_pool_devs{0};      // one bit per device ordinal (< 64) whose pool was raised
+// Stream-ordered scratch (packing passes, limb planes, slice partials): hipMallocFromPoolAsync on a pool THIS LIBRARY owns (one per
+// device, made on first use, destroyed by laser_hip_finalize), with a release threshold of 4 GiB -- at the default (0) every
+// synchronisation hands a pool's free memory back to the driver and the next call pays for mapping it again (a packed 4096^3 product
+// timed 4 calls per synchronise lost 60 us per call to that: profiles/r04/colmajor_a_probe_v1.jsonl against configs_v5.jsonl).  The
+// device's DEFAULT pool belongs to the host application and its other libraries: its threshold is never touched.
+// Freed with hipFreeAsync like any stream-ordered allocation.  A runtime that cannot make a pool: plain hipMallocAsync.
+struct ScratchPools {
+  std::atomic<hipMemPool_t> pool[64] = {};
+  std::atomic<unsigned long long> failed{0};     // one bit per device ordinal whose pool could not be made
+};
+inline ScratchPools g_scratch_pools;
 inline hipError_t scratch_alloc_async(void **p, size_t bytes, hipStream_t s) {
-  std::atomic<unsigned long long> &done = g_scratch_pool_devs;
   int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(done.load(std::memory_order_relaxed) >> dev & 1ull)) {
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr) {
-      uint64_t keep = (uint64_t)4 << 30;
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || (g_scratch_pools.failed.load(std::memory_order_relaxed) >> dev & 1ull))
+    return hipMallocAsync(p, bytes, s);
+  hipMemPool_t pool = g_scratch_pools.pool[dev].load(std::memory_order_acquire);
+  if (pool == nullptr) {
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t made = nullptr;
+    if (hipMemPoolCreate(&made, &props) != hipSuccess || made == nullptr) {
+      (void)hipGetLastError();
+      g_scratch_pools.failed.fetch_or(1ull << dev, std::memory_order_relaxed);
+      return hipMallocAsync(p, bytes, s);
     }
-    done.fetch_or(1ull << dev, std::memory_order_relaxed);
+    uint64_t keep = (uint64_t)4 << 30;
+    (void)hipMemPoolSetAttribute(made, hipMemPoolAttrReleaseThreshold, &keep);
+    hipMemPool_t expect = nullptr;
+    if (g_scratch_pools.pool[dev].compare_exchange_strong(expect, made, std::memory_order_acq_rel)) {
+      pool = made;
+    } else {      // another host thread made this device's pool first
+      (void)hipMemPoolDestroy(made);
+      pool = expect;
+    }
   }
-  return hipMallocAsync(p, bytes, s);
+  return hipMallocFromPoolAsync(p, bytes, pool, s);
 }
-// laser_hip_finalize: the pools give back what they kept
+// laser_hip_finalize: the pools go (every device is idle by then; what they kept returns to the driver)
 inline void scratch_pools_trim() {
-  const unsigned long long devs = g_scratch_pool_devs.load(std::memory_order_relaxed);
   for (int dev = 0; dev < 64; dev++) {
-    if (!(devs >> dev & 1ull)) continue;
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr) (void)hipMemPoolTrimTo(pool, 0);
+    hipMemPool_t pool = g_scratch_pools.pool[dev].exchange(nullptr, std::memory_order_acq_rel);
+    if (pool != nullptr) (void)hipMemPoolDestroy(pool);
   }
+  g_scratch_pools.failed.store(0, std::memory_order_relaxed);
 }
 
 // One-time-per-DEVICE initialisation of a kernel (hipFuncSetAttribute acts on the current device's instance of the
@@ -163,6 +184,8 @@ extern std::atomic<int> g_f64_asm, g_last_f64_asm;
 hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
 hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
 extern std::atomic<int> g_i32_asm, g_last_i32_asm;
+extern std::atomic<int> g_asm_tile;   // option "asm_tile" (gemm_f32_asm.cpp)
+void asm_set_thread_tile(int tile_class);   // per-thread pin of the same (-2 = none)
 extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed, g_asm_group_m;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
 extern std::atomic<int> g_last_asm_wgs, g_last_asm_slices;                  // diagnostics: workgroups / K slices per tile of the last assembly launch
 extern std::atomic<int> g_f32_asm;       // 1 default; 0 = never; 2 = whenever the kernel can (no tile-count rule: tests)
@@ -205,6 +228,8 @@ hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64
                                     int elem_size, hipStream_t s);
 hipError_t launch_transpose_pitched(void *dst, int64_t ld_dst, const void *src, int64_t ld_src, int64_t NR, int64_t NC, int elem_size,
                                     hipStream_t s);
+hipError_t launch_im2col(void *ws, int64_t oH, int64_t oW, const void *in, int64_t batch, int64_t C, int64_t H, int64_t W, int64_t kH,
+                         int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, int elem_size, hipStream_t s);
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,
                              int64_t C, int64_t H, int64_t W, int64_t kH, int64_t kW, int64_t pH,
                              int64_t pW, int64_t sH, int64_t sW, hipStream_t s);

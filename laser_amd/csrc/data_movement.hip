@@ -18,7 +18,7 @@ template <typename T, bool VEC16, int TR = 64, int TC = 64, bool NT = false>
 __global__ void __launch_bounds__(256) transpose_batched_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                                                 int64_t NR, int64_t NC, int64_t tiles_c,
                                                                 int64_t tiles_r, int64_t ld_src, int64_t ld_dst) {
-  constexpr int V = 16 / sizeof(T);        // elements per 16-byte access: 4 (b32) or 2 (b64)
+  constexpr int V = 16 / sizeof(T);        // elements per 16-byte access: 4 (b32), 2 (b64), 8 (b16), 16 (b8)
   __shared__ T tile[TR][TC + 1];           // TR source rows x TC source columns (+1: conflict-free column reads)
   const int64_t bid = blockIdx.x;
   const int64_t tc = bid % tiles_c, tr = (bid / tiles_c) % tiles_r, n = bid / (tiles_c * tiles_r);
@@ -127,6 +127,8 @@ hipError_t launch_transpose_pitched(void *dst, int64_t ld_dst, const void *src, 
   if (ld_src < NC || ld_dst < NR) return hipErrorInvalidValue;
   if (elem_size == 4) return launch_transpose_t<uint32_t>(dst, src, 1, NR, NC, s, ld_src, ld_dst);
   if (elem_size == 8) return launch_transpose_t<uint64_t>(dst, src, 1, NR, NC, s, ld_src, ld_dst);
+  if (elem_size == 2) return launch_transpose_t<uint16_t>(dst, src, 1, NR, NC, s, ld_src, ld_dst);
+  if (elem_size == 1) return launch_transpose_t<uint8_t>(dst, src, 1, NR, NC, s, ld_src, ld_dst);
   return hipErrorInvalidValue;
 }
 
@@ -135,54 +137,156 @@ hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64
   if (N <= 0 || NR <= 0 || NC <= 0) return hipSuccess;
   if (elem_size == 4) return launch_transpose_t<uint32_t>(dst, src, N, NR, NC, s);
   if (elem_size == 8) return launch_transpose_t<uint64_t>(dst, src, N, NR, NC, s);
+  // (swapaxes.nim:16-19 is generic in T: 2- and 1-byte elements -- float16 / int16 / int8 tensors -- on the same tile kernel, 8 / 16
+  // elements per 16-byte access)
+  if (elem_size == 2) return launch_transpose_t<uint16_t>(dst, src, N, NR, NC, s);
+  if (elem_size == 1) return launch_transpose_t<uint8_t>(dst, src, N, NR, NC, s);
   return hipErrorInvalidValue;
 }
 
 // ---- im2col: [batch][C][H][W] -> [batch][C*kH*kW][oH*oW] -------------------------------------------
-// One workgroup = 1024 consecutive output pixels of ONE workspace row (image, channel, kernel row,
-// kernel col); 4 pixels per thread, one 16-byte store when oH*oW % 4 == 0.  Same index arithmetic as
-// conv2d_im2col.nim:62-87: row = -pH + krow + oh*sH, col = -pW + kcol + ow*sW, zero outside the image.
-__global__ void __launch_bounds__(256) im2col_f32_kernel(float *__restrict__ ws, const float *__restrict__ in,
-                                                         int chunks, int H, int W, int kH, int kW, int oH, int oW,
-                                                         int pH, int pW, int sH, int sW, int vec_ok) {
+// Same index arithmetic as conv2d_im2col.nim:62-87: row = -pH + krow + oh*sH, col = -pW + kcol + ow*sW, zero outside the image.
+// Generic in the element type like the reference's im2col*[T] (conv2d_im2col.nim:42-50); no arithmetic, so one instantiation per
+// element SIZE (b32: float32 / int32, b64: float64 / int64).
+//
+// Band kernel (round 5; the workspace is kH*kW times the input, so this is a WRITE stream): one workgroup = one (image, channel)
+// x one band of output pixels [P0, P1) -- P0 a multiple of the 16-byte vector, the bands a near-EQUAL split of oH*oW (the round-4
+// kernel cut 1024-pixel chunks: at 56x56 a quarter of its workgroups held 64 pixels) -- and ALL kH*kW workspace rows of that band.
+// The input rows the band touches are staged ONCE in LDS, zero rows above / below the image and pW zero columns either side
+// included, so the expansion has no bounds checks; every (krow, kcol) row of the workspace is then written from LDS with 16-byte
+// stores.  The input is read once from HBM (the old kernel gathered every element kH*kW times through L1 / L2).
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_band_kernel(T *__restrict__ ws, const T *__restrict__ in, int chunks, int chunk_pix,
+                                                          int H, int W, int kH, int kW, int oH, int oW, int pH, int pW, int sH,
+                                                          int sW, int Wp, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T *lds = reinterpret_cast<T *>(lds_raw);
+  constexpr int V = 16 / sizeof(T);
+  using VT = __attribute__((ext_vector_type(V))) T;
+  const int64_t nc = blockIdx.x / chunks;          // n*C + c
+  const int chunk = (int)(blockIdx.x - nc * chunks);
+  const int npix = oH * oW;
+  const int P0 = chunk * chunk_pix, P1 = min(npix, P0 + chunk_pix);
+  if (P0 >= P1) return;
+  const int oh_first = P0 / oW, oh_last = (P1 - 1) / oW;
+  const int row_lo = oh_first * sH - pH;           // input row held by LDS row 0
+  const int nrows = (oh_last - oh_first) * sH + kH;
+  const T *img = in + nc * (int64_t)H * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < nrows; r += 4) {
+    const int row = row_lo + r;
+    const bool row_ok = row >= 0 && row < H;
+    const T *src = img + (int64_t)row * W - pW;
+    for (int c = lane; c < Wp; c += 64) lds[r * Wp + c] = (row_ok && c >= pW && c < W + pW) ? src[c] : (T)0;
+  }
+  __syncthreads();
+  const int nquads = (P1 - P0 + V - 1) / V;
+  T *out0 = ws + nc * (int64_t)kH * kW * npix;
+  for (int q = threadIdx.x; q < nquads; q += 256) {
+    const int p = P0 + q * V;
+    int oh = p / oW, ow = p - oh * oW;
+    int base[V];
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      base[e] = (p + e < npix) ? (oh - oh_first) * sH * Wp + ow * sW : 0;
+      if (++ow == oW) { ow = 0; ++oh; }
+    }
+    const bool full = vec_ok && p + V <= P1;
+    for (int krow = 0; krow < kH; krow++)
+      for (int kcol = 0; kcol < kW; kcol++) {
+        const int off = krow * Wp + kcol;
+        T *o = out0 + (int64_t)(krow * kW + kcol) * npix + p;
+        VT v;
+#pragma unroll
+        for (int e = 0; e < V; e++) v[e] = lds[base[e] + off];
+        if (full) {
+          *reinterpret_cast<VT *>(o) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; e++)
+            if (p + e < P1) o[e] = v[e];
+        }
+      }
+  }
+}
+
+// Fallback (an image so wide that kH input rows do not fit in LDS): one workgroup = 1024 consecutive output pixels of ONE workspace
+// row (image, channel, kernel row, kernel col), V pixels per thread, gathered through the caches.
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_gather_kernel(T *__restrict__ ws, const T *__restrict__ in, int chunks, int H, int W,
+                                                            int kH, int kW, int oH, int oW, int pH, int pW, int sH, int sW,
+                                                            int vec_ok) {
+  constexpr int V = 16 / sizeof(T);
+  using VT = __attribute__((ext_vector_type(V))) T;
   const int64_t wrow = blockIdx.x / chunks;        // ((n*C + c)*kH + krow)*kW + kcol
   const int chunk = (int)(blockIdx.x % chunks);
   const int kcol = (int)(wrow % kW);
   const int krow = (int)((wrow / kW) % kH);
   const int64_t nc = wrow / ((int64_t)kW * kH);    // n*C + c
-  const float *img = in + nc * (int64_t)H * W;
-  float *out = ws + wrow * (int64_t)oH * oW;
+  const T *img = in + nc * (int64_t)H * W;
+  T *out = ws + wrow * (int64_t)oH * oW;
   const int npix = oH * oW;
-  const int p0 = (chunk * 256 + (int)threadIdx.x) * 4;
+  const int p0 = (chunk * 256 + (int)threadIdx.x) * V;
   if (p0 >= npix) return;
-  float v[4];
+  VT v;
   int oh = p0 / oW, ow = p0 - oh * oW;
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < V; e++) {
     const int row = -pH + krow + oh * sH, col = -pW + kcol + ow * sW;
-    v[e] = (p0 + e < npix && row >= 0 && row < H && col >= 0 && col < W) ? img[row * W + col] : 0.0f;
+    v[e] = (p0 + e < npix && row >= 0 && row < H && col >= 0 && col < W) ? img[(int64_t)row * W + col] : (T)0;
     if (++ow == oW) { ow = 0; ++oh; }
   }
-  if (vec_ok && p0 + 3 < npix) {
-    *reinterpret_cast<float4 *>(out + p0) = make_float4(v[0], v[1], v[2], v[3]);
+  if (vec_ok && p0 + V <= npix) {
+    *reinterpret_cast<VT *>(out + p0) = v;
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; e++)
+    for (int e = 0; e < V; e++)
       if (p0 + e < npix) out[p0 + e] = v[e];
   }
 }
 
+template <typename T>
+static hipError_t launch_im2col_t(T *ws, int64_t oH, int64_t oW, const T *in, int64_t batch, int64_t C, int64_t H, int64_t W,
+                                  int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, hipStream_t s) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t ncs = batch * C, npix = oH * oW;
+  if (ncs <= 0 || npix <= 0 || kH <= 0 || kW <= 0) return hipSuccess;
+  if (npix > 0x7fffffffLL / 8 || H * W > 0x7fffffffLL || pH < 0 || pW < 0 || pH > 0xffff || pW > 0xffff || sH > 0xffff || sW > 0xffff)
+    return hipErrorInvalidValue;
+  const int vec_ok = (npix % V == 0) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+  // bands: ~1024 b32 / 512 b64 pixels each, equal to within one vector; shrunk while the staged input rows exceed 64 KiB of LDS
+  const int64_t Wp = std::max<int64_t>(W + 2 * pW, (oW - 1) * sW + kW);
+  int64_t chunks = (npix + 256 * V - 1) / (256 * V), chunk_pix = 0;
+  size_t lds = 0;
+  for (;; chunks *= 2) {
+    chunk_pix = ((npix + chunks - 1) / chunks + V - 1) / V * V;
+    const int64_t nrows = ((chunk_pix + oW - 1) / oW + 1) * sH + kH;     // (an upper bound: a band may start mid-row)
+    lds = (size_t)nrows * Wp * sizeof(T);
+    if (lds <= (size_t)64 << 10 || chunk_pix <= V) break;
+  }
+  chunks = (npix + chunk_pix - 1) / chunk_pix;
+  if (lds <= ((size_t)64 << 10) && ncs * chunks <= 0x7fffffffLL && Wp <= 0x7fffffLL) {
+    hipLaunchKernelGGL(im2col_band_kernel<T>, dim3((unsigned)(ncs * chunks)), dim3(256), lds, s, ws, in, (int)chunks, (int)chunk_pix,
+                       (int)H, (int)W, (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW, (int)Wp, vec_ok);
+    return hipGetLastError();
+  }
+  const int64_t rows = ncs * kH * kW, gchunks = (npix + 256 * V - 1) / (256 * V);
+  if (rows * gchunks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(im2col_gather_kernel<T>, dim3((unsigned)(rows * gchunks)), dim3(256), 0, s, ws, in, (int)gchunks, (int)H, (int)W,
+                     (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW, vec_ok);
+  return hipGetLastError();
+}
+
+hipError_t launch_im2col(void *ws, int64_t oH, int64_t oW, const void *in, int64_t batch, int64_t C, int64_t H, int64_t W, int64_t kH,
+                         int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, int elem_size, hipStream_t s) {
+  if (elem_size == 4) return launch_im2col_t<uint32_t>((uint32_t *)ws, oH, oW, (const uint32_t *)in, batch, C, H, W, kH, kW, pH, pW, sH, sW, s);
+  if (elem_size == 8) return launch_im2col_t<uint64_t>((uint64_t *)ws, oH, oW, (const uint64_t *)in, batch, C, H, W, kH, kW, pH, pW, sH, sW, s);
+  return hipErrorInvalidValue;
+}
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch, int64_t C,
                              int64_t H, int64_t W, int64_t kH, int64_t kW, int64_t pH, int64_t pW,
                              int64_t sH, int64_t sW, hipStream_t s) {
-  const int64_t rows = batch * C * kH * kW, npix = oH * oW;
-  if (rows <= 0 || npix <= 0) return hipSuccess;
-  const int64_t chunks = (npix + 1023) / 1024;
-  if (npix > 0x7fffffffLL / 8 || H * W > 0x7fffffffLL || rows * chunks > 0x7fffffffLL) return hipErrorInvalidValue;
-  const int vec_ok = (npix % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
-  hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, s, ws, in, (int)chunks, (int)H,
-                     (int)W, (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW, vec_ok);
-  return hipGetLastError();
+  return launch_im2col(ws, oH, oW, in, batch, C, H, W, kH, kW, pH, pW, sH, sW, 4, s);
 }
 
 // ---- strided -> dense zero-padded panel image (pre-pack) -------------------------------------------

@@ -30,11 +30,15 @@ std::atomic<int> g_last_f32_asm{0};  // diagnostics: 0 = compiler-scheduled kern
 
 std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model decides; 1 = one tile per workgroup only; 2 = the persistent plan whenever legal
 std::atomic<int> g_asm_kernel{-1};    // option "asm_kernel": force an index of kKernels (tuning sweeps); -1 = the model decides
+std::atomic<int> g_asm_tile{-1};      // option "asm_tile": pin a tile class of the f32 GEMM kernels (0 = 256x128 / 256x256, 1 = 256x128 one chain, 2 = 128x128x16, 3 = 128x128x32, 4 = 64x64; -1 = the model decides)
+thread_local int tl_asm_tile = -2;    // the same pin for the launches made BY THIS THREAD (-2 = none: the option applies); asm_set_thread_tile
 std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persistent launch (0 = every slot of the chip)
 std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
 std::atomic<int> g_asm_group_m{0};    // option "asm_group_m": tile rows per raster group of the f32 / f64 GEMM launches (0 = 4 for 256-row tiles, else 8)
 std::atomic<int> g_asm_noseed{0};     // option "asm_noseed": 1 = a piece never takes its received sum early (tests: forces the two-run receive path)
 std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
+
+void asm_set_thread_tile(int tile_class) { tl_asm_tile = tile_class; }
 
 namespace {
 
@@ -111,6 +115,8 @@ struct DeviceModule {
   hipModule_t mod = nullptr;
   hipFunction_t fn[kNumKernels] = {};
   std::map<hipStream_t, StreamWs> ws;
+  std::vector<void *> retired;   // outgrown workspaces / flag arrays: freed by laser_hip_finalize only (get_ws)
+  int cus = 0;                   // compute units of the device (the launch plans are written for the full 256-CU, 8-XCD MI355X)
 };
 constexpr int kMaxDev = 16;
 DeviceModule g_mods[kMaxDev];
@@ -174,6 +180,15 @@ hipError_t get_module(int dev, DeviceModule **out) {
   if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
   DeviceModule &m = g_mods[dev];
   std::lock_guard<std::mutex> lk(m.mu);
+  if (m.cus == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+    m.cus = n;
+  }
+  // The tile maps, the XCD chunking and the hand-over order of the cut plans are written for the unpartitioned device (256 CUs in
+  // 8 XCDs, SPX mode).  A partitioned device (CPX / DPX ...) reports fewer: this kernel family steps aside (hipErrorNotSupported: the
+  // callers take the compiler-scheduled kernels, which make no such assumption).
+  if (m.cus != kCUs) return hipErrorNotSupported;
   if (!m.mod) {
     hipError_t e = hipModuleLoadData(&m.mod, lh_f32_asm_hsaco);
     if (e != hipSuccess) return e;
@@ -188,38 +203,48 @@ hipError_t get_module(int dev, DeviceModule **out) {
   return hipSuccess;
 }
 
-// The stream's workspace, grown when needed (rare: a blocking free + allocation + clear; never while the stream is being
-// captured -- hipErrorNotSupported then, and the caller takes the plan that needs no workspace).
+// The stream's workspace, grown when needed (rare: an allocation + a clear on the launch stream).  Addresses handed out stay valid
+// until laser_hip_finalize: a buffer that is outgrown is RETIRED, not freed -- a launch another host thread queued on the same stream
+// a moment ago, or one still running, keeps reading it; growth is geometric, so the retired buffers of a stream add up to
+// less than its current one.  Never while the stream is being captured (checked FIRST, also when a buffer is cached): a captured cut
+// launch would bake the workspace and its flags into a graph that may be replayed on another stream, or beside eager launches on this
+// one, sharing hand-over slots -- hipErrorNotSupported, and the caller takes the plan that needs no workspace.
 hipError_t get_ws(DeviceModule *m, hipStream_t s, size_t ws_bytes, size_t nflags, StreamWs *out) {
   if (ws_bytes > kWsMaxBytes) return hipErrorNotSupported;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return hipErrorNotSupported;
   std::lock_guard<std::mutex> lk(m->mu);
   auto it = m->ws.find(s);
   if (it != m->ws.end() && it->second.ws_bytes >= ws_bytes && it->second.nflags >= nflags) {
     *out = it->second;
     return hipSuccess;
   }
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return hipErrorNotSupported;
   if (it == m->ws.end() && m->ws.size() >= kWsMaxStreams) return hipErrorNotSupported;
   StreamWs w = it != m->ws.end() ? it->second : StreamWs();
   hipError_t e = hipSuccess;
   if (w.ws_bytes < ws_bytes) {
-    if (w.ws) (void)hipFree(w.ws);      // (hipFree waits for the device: no kernel still reads the old buffer)
-    w.ws = nullptr; w.ws_bytes = 0;
-    const size_t want = std::max(ws_bytes, (size_t)32 << 20);
-    e = hipMalloc(&w.ws, want);
-    if (e == hipSuccess) w.ws_bytes = want;
+    const size_t want = std::min(kWsMaxBytes, std::max({ws_bytes, 2 * w.ws_bytes, (size_t)32 << 20}));
+    void *nw = nullptr;
+    e = hipMalloc(&nw, want);
+    if (e == hipSuccess) {
+      if (w.ws) m->retired.push_back(w.ws);
+      w.ws = nw; w.ws_bytes = want;
+    }
   }
   if (e == hipSuccess && w.nflags < nflags) {
-    if (w.flags) (void)hipFree(w.flags);
-    w.flags = nullptr; w.nflags = 0;
-    const size_t want = std::max(nflags, (size_t)1 << 16);
-    e = hipMalloc((void **)&w.flags, want * sizeof(uint32_t));
+    const size_t want = std::max({nflags, 2 * w.nflags, (size_t)1 << 16});
+    uint32_t *nf = nullptr;
+    e = hipMalloc((void **)&nf, want * sizeof(uint32_t));
     // cleared ON THE LAUNCH STREAM: a null-stream hipMemset may still be pending when it returns, and a non-blocking stream's
     // kernel is not ordered behind it -- the clear would then wipe flags the running launch has set (seen: a receiver timing out
     // on the first cut launch of a fresh stream, profiles/r04/README.md)
-    if (e == hipSuccess) e = hipMemsetAsync(w.flags, 0, want * sizeof(uint32_t), s);
-    if (e == hipSuccess) w.nflags = want;
+    if (e == hipSuccess) e = hipMemsetAsync(nf, 0, want * sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+      if (w.flags) m->retired.push_back(w.flags);
+      w.flags = nf; w.nflags = want;
+    } else if (nf) {
+      (void)hipFree(nf);
+    }
   }
   m->ws[s] = w;
   if (e != hipSuccess) return e;
@@ -378,6 +403,8 @@ void asm_kernels_release() {
       if (kv.second.flags) (void)hipFree(kv.second.flags);
     }
     m.ws.clear();
+    for (void *p : m.retired) (void)hipFree(p);
+    m.retired.clear();
     (void)hipModuleUnload(m.mod);
     m.mod = nullptr;
   }
@@ -434,7 +461,14 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
   // the one-chain kernels' fused epilogue has no C read: beta != 0 with a bias / activation only on the laser-order kernels
   const auto lo_kernel = [](int k) { return k == 0 || k == 2 || k == 4 || k == 6 || k == 12 || k == 14 || k == 30 || k == 32; };
   const bool pre = a.preA != 0 || a.preB != 0;
-  for (int k0 : {big, mid, small, deep, tiny}) {
+  // A pinned tile class (option "asm_tile" / the sharded entry point's LASER_HIP_SHARD_PIN_TILE on its worker threads): the local
+  // products of a multi-GPU run that shares the CUs with RCCL's kernels.  One tile per workgroup then -- a persistent plan counts on
+  // every workgroup slot of the chip -- and no lower bound on the tile count (the caller asked for THIS kernel family).
+  const int tile_pin = tl_asm_tile >= -1 ? tl_asm_tile : (int)g_asm_tile;
+  const int classes[5] = {big, mid, small, deep, tiny};
+  for (int ci = 0; ci < 5; ci++) {
+    const int k0 = classes[ci];
+    if (tile_pin >= 0 && ci != (tile_pin == 1 && mid < 0 ? 0 : tile_pin)) continue;
     if (k0 < 0 || (g_asm_kernel >= 0 && k0 != g_asm_kernel)) continue;
     if (fused && !lo_kernel(k0) && a.beta != 0.0f) continue;
     const int k = pre ? pre_variant(k0) : k0;       // fused prologue: the variants that apply it in the staging registers
@@ -444,10 +478,10 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
     if ((double)t * 8.0 * (double)tn >= 4.0e9) continue;    // the in-kernel tile arithmetic's range (fill_sched)
     // below ~5/8 of a round of the larger tiles (3/8 of the 64x64 ones) the compiler-scheduled kernels' slice-parallel and
     // small-problem forms do better
-    if (g_f32_asm < 2 && t * a.batch < (k0 == tiny ? 96 : 160)) continue;
+    if (g_f32_asm < 2 && tile_pin < 0 && t * a.batch < (k0 == tiny ? 96 : 160)) continue;
     // (laser-order with K <= kc is ONE chain that must stay one chain: cuts only at kc boundaries, or anywhere in one-chain mode;
     // the `_pre` variants run one tile per workgroup)
-    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 512, cu_flops_per_us, (exact || !laser_order) && !pre);
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 512, cu_flops_per_us, (exact || !laser_order) && !pre && tile_pin < 0);
     if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;   // (near ties go to the larger tile: less L2 traffic)
   }
   if (pick < 0) return hipErrorNotSupported;
@@ -538,8 +572,10 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hi
   if (e != hipSuccess) return e;
   if (packA) {      // A[m][k] at m * rsA + k * csA -> dense [M][K]
     // (a fused prologue on a packed operand happens in the packing pass -- "during the prepacking", README.md:243-244)
-    e = (a.rsA == 1 && !a.preA) ? launch_transpose_pitched(scratch, a.K, a.A, a.csA, a.K, a.M, 4, s)      // the source is a K x M row-major matrix (pitch csA)
-                                : launch_pack_pad<float>(scratch, a.M, a.K, a.A, a.M, a.K, a.rsA, a.csA, s, a.preA);
+    // (the transposing pass reads a K x M row-major matrix of pitch csA: a broadcast or overlapping view -- csA < M -- is not one; the
+    // element gather takes any non-negative strides)
+    e = (a.rsA == 1 && !a.preA && a.csA >= a.M) ? launch_transpose_pitched(scratch, a.K, a.A, a.csA, a.K, a.M, 4, s)
+                                                : launch_pack_pad<float>(scratch, a.M, a.K, a.A, a.M, a.K, a.rsA, a.csA, s, a.preA);
     a.A = scratch; a.rsA = a.K; a.csA = 1; a.preA = 0;
   }
   if (e == hipSuccess && packB) {      // neither stride of B is 1: dense [K][N]
@@ -547,6 +583,8 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hi
     e = launch_pack_pad<float>(sb, a.K, a.N, a.B, a.K, a.N, a.rsB, a.csB, s, a.preB);
     a.B = sb; a.rsB = a.N; a.csB = 1; a.preB = 0;
   }
+  // (a packing pass that refuses its arguments has launched nothing: not this kernel family's problem, the compiler kernels take it)
+  if (e == hipErrorInvalidValue) e = hipErrorNotSupported;
   if (e == hipSuccess) e = launch_gemm_f32_asm_core(a, laser_order, s);
   const hipError_t e2 = hipFreeAsync(scratch, s);
   if (e == hipErrorNotSupported) return e;      // (nothing was launched but the packing passes, which touched only the scratch)

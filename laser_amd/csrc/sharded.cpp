@@ -22,7 +22,7 @@
 //                               compute units taken from the GEMM;
 //                         RCCL  ncclAllGather per slab on a communicator made by ncclCommInitAll (librccl.so is
 //                               dlopen'ed on first use, liblaser_hip.so does not link it); its kernels share the
-//                               CUs with the GEMM, so the 128x128 tile can be pinned for the local products.
+//                               CUs with the GEMM, so the 128x128 assembly tile can be pinned for the local products.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -372,8 +372,10 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
   // the local products may be pinned to the 128x128 tile (RCCL's kernels hold CUs while the next panel multiplies)
   // The pin is per CALL: every worker thread sets a thread-local override that only its own launches read -- the
   // process-wide configuration (and any concurrent caller's kernel choice) is never touched.
+  // (round 5: the pin selects the hand-scheduled `lh_f32_*_128x128x16` ASSEMBLY kernels -- tile class 2 of option "asm_tile" -- not
+  // the compiler-scheduled 128x128 configuration it used to force, which gave away 10-15 % per GPU before a byte crossed xGMI)
   const bool pin = (flags & LASER_HIP_SHARD_PIN_TILE) != 0 && std::is_same<T, float>::value;
-  const int pin_cfg = 2;  // 128x128x16_w2x2_s3 (gemm_mfma_cfgs.h)
+  const int pin_tile = 2;
   std::atomic<bool> failed{false};
 
   std::vector<int> rc(ndev, LASER_HIP_OK);
@@ -393,7 +395,7 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
     hipError_t e = hipSetDevice(dev[g]);
     const bool no_device = e != hipSuccess;      // then no stream / event call below may run (it would land on whatever device is current)
     if (no_device) bail(api_fail(LASER_HIP_E_HIP, "hipSetDevice(%d): %s", dev[g], hipGetErrorString(e)));
-    if (pin) api_set_thread_f32_config(pin_cfg);
+    if (pin) api_set_thread_asm_tile(pin_tile);
     // one device and nothing to exchange: the panels are one contiguous matrix -- one product, no per-panel launch boundary
     const bool whole = ndev == 1 && gather != LASER_HIP_GATHER_RCCL && !no_device;
     if (whole) {
@@ -447,7 +449,7 @@ int sharded_dev(int ndev_in, const int *devices, int64_t M, int64_t N, int64_t K
         }
       }
     }
-    if (pin) api_set_thread_f32_config(-2);
+    if (pin) api_set_thread_asm_tile(-2);
     if (no_device) return;
     // this rank's GEMMs and everything it sent; bounded where a peer that never arrives could hang the caller (RCCL)
     const bool coll = gather == LASER_HIP_GATHER_RCCL && ndev > 1;

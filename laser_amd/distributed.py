@@ -28,8 +28,11 @@ def _default_local_gemm(A, B, out):
 # workgroups (one per channel) hold some CUs for the whole transfer, and a 256x128-tile workgroup (144 KiB LDS,
 # 2 x 234 VGPRs per SIMD) cannot share a CU with them.  A panel of 512 such tiles is exactly two rounds on 256 CUs but
 # three on the ~224-240 left over; 128x128 tiles (2048 per panel, 2 per CU) degrade gracefully instead (about -3 % when
-# all CUs are free).  Multi-GPU runs therefore pin that configuration for the local products unless told otherwise.
-SHARDED_TILE_CONFIG = "128x128x16_w2x2_s3"
+# all CUs are free).  Multi-GPU runs therefore pin that tile CLASS of the hand-scheduled assembly kernels (option
+# "asm_tile" = 2: lh_f32_exact_128x128x16 / lh_f32_fast_128x128x16 by accumulation mode; round 5 -- the pin used to
+# force the compiler-scheduled 128x128 configuration, 10-15 % slower per GPU) for the local products unless told otherwise.
+SHARDED_ASM_TILE = 2
+SHARDED_TILE_NAME = "lh_f32_*_128x128x16 (hand-scheduled assembly, option asm_tile=2)"
 
 
 @dataclass
@@ -78,8 +81,9 @@ class ShardedGemm:
         self.dtype, self.device = dtype, device
         self.plan = make_plan(M, self.world, panels_per_rank)
         self.local_gemm = local_gemm or _default_local_gemm
-        # fp32 tile configuration for the local products: an index into laser_amd.f32_configs(), or None =
-        # SHARDED_TILE_CONFIG when more than one rank shares the work (single rank: the library heuristic)
+        # fp32 tile for the local products: None = the SHARDED_ASM_TILE class of the assembly kernels when more than one rank
+        # shares the work (single rank: the library heuristic); -1 = the library heuristic; >= 0 = that compiler-scheduled
+        # configuration of laser_amd.f32_configs() (tuning sweeps)
         self.tile_config = tile_config
         self._pin_tiles = local_gemm is None and dtype == torch.float32
         # how sub-panel s reaches the other ranks: "collective" = one in-place all_gather_into_tensor per slab;
@@ -117,24 +121,23 @@ class ShardedGemm:
     def run(self, A_local, B, C_full):
         """A_local: [panels_per_rank*rows, K] (from shard_A); B: [K,N] replicated; C_full: alloc_C().
         On return (after the stream/work sync at the end) every rank holds all of C."""
-        p = self.plan
-        works = []
         cfg = self.tile_config
+        prev_cfg = prev_tile = primitives = None
+        if self._pin_tiles:
+            from . import primitives
         if self._pin_tiles and cfg is None and self.world > 1:
-            from . import primitives
-            names = primitives.f32_configs()
-            cfg = names.index(SHARDED_TILE_CONFIG) if SHARDED_TILE_CONFIG in names else None
-        prev = None
-        if self._pin_tiles and cfg is not None:
-            from . import primitives
-            prev = primitives.get_f32_config()     # the caller's own setting is restored, not clobbered
+            prev_tile = primitives.get_option("asm_tile")     # the caller's own setting is restored, not clobbered
+            primitives.set_option("asm_tile", SHARDED_ASM_TILE)
+        elif self._pin_tiles and cfg is not None:
+            prev_cfg = primitives.get_f32_config()
             primitives.set_f32_config(cfg)
         try:
             works = self._run_panels(A_local, B, C_full)
         finally:
-            if prev is not None:
-                from . import primitives
-                primitives.set_f32_config(prev)
+            if prev_tile is not None:
+                primitives.set_option("asm_tile", prev_tile)
+            if prev_cfg is not None:
+                primitives.set_f32_config(prev_cfg)
         for w in works:
             w.wait()
         return C_full[: self.M]

@@ -380,9 +380,9 @@ def host_unregister(arr):
 # ---- transposes ------------------------------------------------------------------------------------
 def _bsfx(x):
     size = x.element_size() if (_is_dev(x) and not _is_lt(x)) else x.dtype.itemsize
-    if size not in (4, 8):
-        raise TypeError("transposes support 4- and 8-byte elements")
-    return "b32" if size == 4 else "b64"
+    if size not in (1, 2, 4, 8):
+        raise TypeError("transposes support 1-, 2-, 4- and 8-byte elements")
+    return {4: "b32", 8: "b64", 2: "b16", 1: "b8"}[size]
 
 
 def transpose2D_batched(dst, src, N, NR, NC):
@@ -428,14 +428,14 @@ def im2col_workspace_size(ishape, kshape, padding, strides):
     return _lib.lib().laser_hip_im2col_workspace_size(*ishape, *kshape, *padding, *strides)
 
 
-def _f32_dense(name, x, min_elems):
+def _f32_dense(name, x, min_elems, dtype="float32"):
     """The conv / im2col / cblas mirrors pass raw pointers of dense float32 buffers: refuse anything else instead of
     reinterpreting it (a float64 or non-contiguous array would silently be read as garbage, or out of bounds)."""
     if x is None:
         return
     dt = str(x.dtype).replace("torch.", "")
-    if dt != "float32":
-        raise TypeError(f"{name}: float32 expected, got {x.dtype}")
+    if dt != dtype:
+        raise TypeError(f"{name}: {dtype} expected, got {x.dtype}")
     contiguous = x.is_contiguous() if (_is_dev(x) and not _is_lt(x)) else (x.is_C_contiguous() if _is_lt(x) else x.flags["C_CONTIGUOUS"])
     if not contiguous:
         raise ValueError(f"{name}: a dense (C-contiguous) buffer is required")
@@ -445,16 +445,20 @@ def _f32_dense(name, x, min_elems):
 
 
 def im2col(pworkspace, oshape, pinput, ishape, kshape, padding, strides):
-    """One image [c,h,w] -> pworkspace [c*kH*kW, oH*oW]."""
+    """One image [c,h,w] -> pworkspace [c*kH*kW, oH*oW]; float32 or float64 (im2col*[T], conv2d_im2col.nim:42-50)."""
     L = _lib.lib()
-    _f32_dense("pworkspace", pworkspace, ishape[1] * kshape[2] * kshape[3] * oshape[2] * oshape[3])
-    _f32_dense("pinput", pinput, ishape[1] * ishape[2] * ishape[3])
+    dt = str(pinput.dtype).replace("torch.", "")
+    if dt not in ("float32", "float64"):
+        raise TypeError(f"pinput: float32 or float64 expected, got {pinput.dtype}")
+    sfx = "f32" if dt == "float32" else "f64"
+    _f32_dense("pworkspace", pworkspace, ishape[1] * kshape[2] * kshape[3] * oshape[2] * oshape[3], dt)
+    _f32_dense("pinput", pinput, ishape[1] * ishape[2] * ishape[3], dt)
     if _same_side(pworkspace, pinput):
-        _lib.check(L.laser_hip_im2col_f32_dev(_ptr(pworkspace), oshape[2], oshape[3], _ptr(pinput), 1, ishape[1],
-                                              ishape[2], ishape[3], kshape[2], kshape[3], *padding, *strides, _stream()))
+        _lib.check(getattr(L, f"laser_hip_im2col_{sfx}_dev")(_ptr(pworkspace), oshape[2], oshape[3], _ptr(pinput), 1, ishape[1],
+                                                             ishape[2], ishape[3], kshape[2], kshape[3], *padding, *strides, _stream()))
     else:
-        _lib.check(L.laser_hip_im2col_f32(_ptr(pworkspace), oshape[2], oshape[3], _ptr(pinput), ishape[1], ishape[2],
-                                          ishape[3], kshape[2], kshape[3], *padding, *strides))
+        _lib.check(getattr(L, f"laser_hip_im2col_{sfx}")(_ptr(pworkspace), oshape[2], oshape[3], _ptr(pinput), ishape[1], ishape[2],
+                                                         ishape[3], kshape[2], kshape[3], *padding, *strides))
     return pworkspace
 
 

@@ -81,10 +81,15 @@ proc laser_hip_transpose2d_copy_b32(dst, src: pointer, NR, NC: int): cint {.lh, 
 proc laser_hip_transpose2d_copy_b64(dst, src: pointer, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_copy_b64".}
 proc laser_hip_transpose2d_batched_b32(dst, src: pointer, N, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_batched_b32".}
 proc laser_hip_transpose2d_batched_b64(dst, src: pointer, N, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_batched_b64".}
+proc laser_hip_transpose2d_copy_b16(dst, src: pointer, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_copy_b16".}
+proc laser_hip_transpose2d_copy_b8(dst, src: pointer, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_copy_b8".}
+proc laser_hip_transpose2d_batched_b16(dst, src: pointer, N, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_batched_b16".}
+proc laser_hip_transpose2d_batched_b8(dst, src: pointer, N, NR, NC: int): cint {.lh, importc: "laser_hip_transpose2d_batched_b8".}
 
 # im2col + GEMM convolution, cblas-shaped gemm
 proc laser_hip_im2col_workspace_size(iN, iC, iH, iW, cOut, cIn, kH, kW, pH, pW, sH, sW: int): int {.lh, importc: "laser_hip_im2col_workspace_size".}
 proc laser_hip_im2col_f32(ws: ptr float32, oH, oW: int, input: ptr float32, iC, iH, iW, kH, kW, pH, pW, sH, sW: int): cint {.lh, importc: "laser_hip_im2col_f32".}
+proc laser_hip_im2col_f64(ws: ptr float64, oH, oW: int, input: ptr float64, iC, iH, iW, kH, kW, pH, pW, sH, sW: int): cint {.lh, importc: "laser_hip_im2col_f64".}
 proc laser_hip_conv2d_im2col_f32(output, input: ptr float32, iN, iC, iH, iW: int, kernel: ptr float32, cOut, cIn, kH, kW, pH, pW, sH, sW: int, ws: ptr float32): cint {.lh, importc: "laser_hip_conv2d_im2col_f32".}
 proc laser_hip_cblas_sgemm(order, tA, tB: cint, M, N, K: int, alpha: float32, A: ptr float32, lda: int, B: ptr float32, ldb: int, beta: float32, C: ptr float32, ldc: int): cint {.lh, importc: "laser_hip_cblas_sgemm".}
 proc laser_hip_cblas_dgemm(order, tA, tB: cint, M, N, K: int, alpha: float64, A: ptr float64, lda: int, B: ptr float64, ldb: int, beta: float64, C: ptr float64, ldc: int): cint {.lh, importc: "laser_hip_cblas_dgemm".}
@@ -196,12 +201,16 @@ proc gemm_packed*[T: SomeNumber](M, N, K: int, alpha: T,
 proc transpose2D_copy*[T](dst, src: ptr (T or UncheckedArray[T]), NR, NC: Natural) =
   when sizeof(T) == 4: check laser_hip_transpose2d_copy_b32(dst, src, NR, NC)
   elif sizeof(T) == 8: check laser_hip_transpose2d_copy_b64(dst, src, NR, NC)
-  else: {.error: "laser_hip transposes support 4- and 8-byte elements".}
+  elif sizeof(T) == 2: check laser_hip_transpose2d_copy_b16(dst, src, NR, NC)
+  elif sizeof(T) == 1: check laser_hip_transpose2d_copy_b8(dst, src, NR, NC)
+  else: {.error: "laser_hip transposes support 1-, 2-, 4- and 8-byte elements".}
 
 proc transpose2D_batched*[T](dst, src: ptr (T or UncheckedArray[T]), N, NR, NC: Natural) =
   when sizeof(T) == 4: check laser_hip_transpose2d_batched_b32(dst, src, N, NR, NC)
   elif sizeof(T) == 8: check laser_hip_transpose2d_batched_b64(dst, src, N, NR, NC)
-  else: {.error: "laser_hip transposes support 4- and 8-byte elements".}
+  elif sizeof(T) == 2: check laser_hip_transpose2d_batched_b16(dst, src, N, NR, NC)
+  elif sizeof(T) == 1: check laser_hip_transpose2d_batched_b8(dst, src, N, NR, NC)
+  else: {.error: "laser_hip transposes support 1-, 2-, 4- and 8-byte elements".}
 
 proc nchw2nhwc*[T](dst_nhwc, src_nchw: ptr (T or UncheckedArray[T]), N, C, H, W: Natural) {.inline.} =
   transpose2D_batched(dst_nhwc, src_nchw, N, C, H*W)       # swapaxes.nim:98
@@ -225,10 +234,16 @@ proc im2col_workspace_size*(ishape: TensorShape, kshape: KernelShape, padding: P
   laser_hip_im2col_workspace_size(ishape.n, ishape.c, ishape.h, ishape.w, kshape.c_out, kshape.c_in,
                                   kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w)
 
-proc im2col*(pworkspace: ptr float32, oshape: TensorShape, pinput: ptr UncheckedArray[float32],
-             ishape: TensorShape, kshape: KernelShape, padding: Padding, strides: Strides) =
-  check laser_hip_im2col_f32(pworkspace, oshape.h, oshape.w, cast[ptr float32](pinput), ishape.c, ishape.h,
-                             ishape.w, kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w)
+# conv2d_im2col.nim:42-50: generic in T (pure data movement: by element size -- int32 rides on the float32 entry point, int64 on the float64 one)
+proc im2col*[T](pworkspace: ptr T, oshape: TensorShape, pinput: ptr UncheckedArray[T],
+                ishape: TensorShape, kshape: KernelShape, padding: Padding, strides: Strides) =
+  when sizeof(T) == 4:
+    check laser_hip_im2col_f32(cast[ptr float32](pworkspace), oshape.h, oshape.w, cast[ptr float32](pinput), ishape.c, ishape.h,
+                               ishape.w, kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w)
+  elif sizeof(T) == 8:
+    check laser_hip_im2col_f64(cast[ptr float64](pworkspace), oshape.h, oshape.w, cast[ptr float64](pinput), ishape.c, ishape.h,
+                               ishape.w, kshape.kH, kshape.kW, padding.h, padding.w, strides.h, strides.w)
+  else: {.error: "laser_hip im2col supports 4- and 8-byte elements".}
 
 # conv2d_im2col.nim:90-100, parameter for parameter
 proc conv2d_im2col*(

@@ -31,7 +31,7 @@ hip.hipModuleLaunchKernel.argtypes = [C.c_void_p] + [C.c_uint] * 6 + [C.c_uint, 
 def build(var, tmp):
     g = K.make(var["kernel"], **var.get("over", {}))
     g.build()
-    sym = "lh_probe"
+    sym = "lh_probe_" + "".join(ch if ch.isalnum() else "_" for ch in var["name"])   # one symbol per variant: rocprofv3 rows stay apart
     spath = os.path.join(tmp, var["name"] + ".s")
     open(spath, "w").write(K.kernel_text(g, sym))
     subprocess.check_call([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", spath, "-o", spath + ".o"])

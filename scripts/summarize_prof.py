@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output (kernel stats + PMC counter collection) for the laser_hip kernels.
-usage: summarize_prof.py <dir> [kernel-substring]   -> markdown on stdout"""
+usage: summarize_prof.py <dir> [kernel-substring] [--skip K]   -> markdown on stdout
+
+Warm-only averages: when the per-dispatch kernel trace is present, every kernel also gets the average over its
+dispatches in time order with the first K dropped (K = --skip, default 10 = bench.py's warm-up launches; a kernel with fewer than
+3 K dispatches drops a third of them) -- the cold launches of a run (clock ramp, first-touch page mapping) are what made the
+all-dispatch average sit 1.5 % above bench.py's own HIP-event time in round 4.  `roofline.frac` is reproducible from THAT column."""
 import csv
 import glob
 import os
@@ -10,9 +15,41 @@ from collections import defaultdict
 csv.field_size_limit(1 << 30)
 
 
+def warm_table(root, pat, skip):
+    for f in sorted(glob.glob(os.path.join(root, "**", "*_kernel_trace.csv"), recursive=True)):
+        per = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            name = r.get("Kernel_Name", "")
+            if pat not in name and "lh_" not in name:
+                continue
+            try:
+                per[name.split("(")[0].replace("void ", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+            except (KeyError, ValueError):
+                continue
+        if not per:
+            continue
+        print(f"### warm-only kernel durations ({os.path.relpath(f, root)}; dispatches in time order, the first k dropped)\n")
+        print("| kernel | dispatches | k dropped | warm avg ms | warm min ms | warm median ms | warm max ms | all-dispatch avg ms |")
+        print("|---|---|---|---|---|---|---|---|")
+        for name, spans in sorted(per.items(), key=lambda kv: -sum(e - b for b, e in kv[1])):
+            spans.sort()
+            d = [(e - b) / 1e6 for b, e in spans]
+            k = skip if len(d) >= 3 * skip else len(d) // 3
+            w = sorted(d[k:])
+            print(f"| `{name}` | {len(d)} | {k} | {sum(w)/len(w):.4f} | {w[0]:.4f} | {w[len(w)//2]:.4f} | {w[-1]:.4f} | {sum(d)/len(d):.4f} |")
+        print()
+
+
 def main():
-    root = sys.argv[1]
-    pat = sys.argv[2] if len(sys.argv) > 2 else "laser_hip"
+    args = [a for a in sys.argv[1:]]
+    skip = 10
+    if "--skip" in args:
+        i = args.index("--skip")
+        skip = int(args[i + 1])
+        del args[i:i + 2]
+    root = args[0]
+    pat = args[1] if len(args) > 1 else "laser_hip"
+    warm_table(root, pat, skip)
     for f in sorted(glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=True)):
         print(f"### kernel stats ({os.path.relpath(f, root)})\n")
         print("| kernel | calls | avg ms | min ms | max ms | % |")

@@ -152,3 +152,23 @@ def test_dma_fed_lds_layouts_are_bank_conflict_free_in_the_model():
     for ks in range(2):
         swz = lambda l, ks=ks: (l % 32) * 64 + 16 * ((2 * ks + l // 32) ^ (((l % 32) >> 2) & 3))
         assert _b128_extra_cycles(swz) == 0, ks
+
+
+def test_bench_kernel_names_match_the_launcher_table():
+    """bench.py names the kernel of its `roofline` object from laser_hip_get_option("last_f32_asm") = 1 + index into kKernels
+    (gemm_f32_asm.cpp): the two tables must list the same symbols in the same order, and every symbol must be one the Makefile
+    assembles into the embedded code object."""
+    import re
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "laser_amd", "csrc", "gemm_f32_asm.cpp")).read()
+    table = src[src.index("const KernelInfo kKernels[kNumKernels] = {"):src.index("// plain kernel -> its `_pre` variant")]
+    symbols = re.findall(r'\{"(lh_[a-z0-9_x]+)"', table)
+    assert len(symbols) == int(re.search(r"constexpr int kNumKernels = (\d+);", src).group(1))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.ASM_KERNEL_SYMBOLS == symbols
+    mk = open(os.path.join(root, "laser_amd", "csrc", "Makefile")).read()
+    for sym in symbols:
+        assert re.search(r"\b" + sym + r"\b", mk), sym
