@@ -411,7 +411,9 @@ LASER_HIP_DECL_MAP(i64, int64_t)
  * unchanged Nim gemm_strided call uses the node. */
 int laser_hip_set_shard_devices(int ndev);
 int laser_hip_get_shard_devices(void);
-/* Device-resident form (operands already in HBM; what the roofline is measured on).  Rows are dealt block-cyclically:
+/* Device-resident form (operands already in HBM; what the roofline is measured on).  The call has no stream parameter: it works on
+ * the library's own streams (one set per device slot), so every operand must be COMPLETE in memory when it is made -- a caller that
+ * fills A / B / C asynchronously on its own stream synchronises that stream first (the Python mirror does).  Rows are dealt block-cyclically:
  * panel (s, g) -- sub-panel s of device slot g -- is rows [(s*ndev + g)*R, +R) of C, R = rows_per_panel from
  * laser_hip_shard_plan (a multiple of 256 when M allows; panels_per_dev is reduced if steps would be empty).
  *   dA_panels[g]  device slot g's panels of A stacked in local order: row s*R + i = global row (s*ndev + g)*R + i

@@ -155,7 +155,11 @@ hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64
 // The input rows the band touches are staged ONCE in LDS, zero rows above / below the image and pW zero columns either side
 // included, so the expansion has no bounds checks; every (krow, kcol) row of the workspace is then written from LDS with 16-byte
 // stores.  The input is read once from HBM (the old kernel gathered every element kH*kW times through L1 / L2).
-template <typename T>
+// ROWVEC (unit column stride, oW a multiple of the vector, kW <= V + 1: the 3x3 / 5x5 stride-1 cases): a thread's V pixels lie in ONE
+// output row and their taps of one kernel row are V + kW - 1 CONSECUTIVE elements of an LDS row whose pitch is a multiple of V, so two
+// 16-byte LDS reads serve all kW stores of that kernel row (lane-consecutive 16-byte reads: no bank conflicts); otherwise one 4-byte
+// (8-byte) LDS read per element -- measured round 5 on C4: 2.47 TB/s (round-4 kernel) -> 4.63 (element reads) -> see profiles/r05.
+template <typename T, bool ROWVEC>
 __global__ void __launch_bounds__(256) im2col_band_kernel(T *__restrict__ ws, const T *__restrict__ in, int chunks, int chunk_pix,
                                                           int H, int W, int kH, int kW, int oH, int oW, int pH, int pW, int sH,
                                                           int sW, int Wp, int vec_ok) {
@@ -185,28 +189,49 @@ __global__ void __launch_bounds__(256) im2col_band_kernel(T *__restrict__ ws, co
   for (int q = threadIdx.x; q < nquads; q += 256) {
     const int p = P0 + q * V;
     int oh = p / oW, ow = p - oh * oW;
-    int base[V];
+    if constexpr (ROWVEC) {
+      // (p + V <= npix and 16-byte stores are legal: oW % V == 0, checked by the launcher)
+      const T *row0 = lds + (oh - oh_first) * sH * Wp + ow;      // 16-byte aligned: Wp % V == 0, ow % V == 0
+      for (int krow = 0; krow < kH; krow++) {
+        const VT lo = *reinterpret_cast<const VT *>(row0 + krow * Wp), hi = *reinterpret_cast<const VT *>(row0 + krow * Wp + V);
+        T w[2 * V];
 #pragma unroll
-    for (int e = 0; e < V; e++) {
-      base[e] = (p + e < npix) ? (oh - oh_first) * sH * Wp + ow * sW : 0;
-      if (++ow == oW) { ow = 0; ++oh; }
-    }
-    const bool full = vec_ok && p + V <= P1;
-    for (int krow = 0; krow < kH; krow++)
-      for (int kcol = 0; kcol < kW; kcol++) {
-        const int off = krow * Wp + kcol;
-        T *o = out0 + (int64_t)(krow * kW + kcol) * npix + p;
-        VT v;
+        for (int e = 0; e < V; e++) { w[e] = lo[e]; w[V + e] = hi[e]; }
+        T *o = out0 + (int64_t)(krow * kW) * npix + p;
 #pragma unroll
-        for (int e = 0; e < V; e++) v[e] = lds[base[e] + off];
-        if (full) {
-          *reinterpret_cast<VT *>(o) = v;
-        } else {
+        for (int kcol = 0; kcol <= V; kcol++) {
+          if (kcol < kW) {
+            VT v;
 #pragma unroll
-          for (int e = 0; e < V; e++)
-            if (p + e < P1) o[e] = v[e];
+            for (int e = 0; e < V; e++) v[e] = w[e + kcol];
+            *reinterpret_cast<VT *>(o + (int64_t)kcol * npix) = v;
+          }
         }
       }
+    } else {
+      int base[V];
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        base[e] = (p + e < npix) ? (oh - oh_first) * sH * Wp + ow * sW : 0;
+        if (++ow == oW) { ow = 0; ++oh; }
+      }
+      const bool full = vec_ok && p + V <= P1;
+      for (int krow = 0; krow < kH; krow++)
+        for (int kcol = 0; kcol < kW; kcol++) {
+          const int off = krow * Wp + kcol;
+          T *o = out0 + (int64_t)(krow * kW + kcol) * npix + p;
+          VT v;
+#pragma unroll
+          for (int e = 0; e < V; e++) v[e] = lds[base[e] + off];
+          if (full) {
+            *reinterpret_cast<VT *>(o) = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < V; e++)
+              if (p + e < P1) o[e] = v[e];
+          }
+        }
+    }
   }
 }
 
@@ -255,7 +280,9 @@ static hipError_t launch_im2col_t(T *ws, int64_t oH, int64_t oW, const T *in, in
     return hipErrorInvalidValue;
   const int vec_ok = (npix % V == 0) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   // bands: ~1024 b32 / 512 b64 pixels each, equal to within one vector; shrunk while the staged input rows exceed 64 KiB of LDS
-  const int64_t Wp = std::max<int64_t>(W + 2 * pW, (oW - 1) * sW + kW);
+  const bool rowvec = vec_ok && sW == 1 && oW % V == 0 && kW <= V + 1;
+  int64_t Wp = std::max<int64_t>(W + 2 * pW, (oW - 1) * sW + kW);
+  if (rowvec) Wp = std::max<int64_t>((Wp + V - 1) / V * V, oW + V);      // 16-byte row pitch; a row's second vector read stays inside it
   int64_t chunks = (npix + 256 * V - 1) / (256 * V), chunk_pix = 0;
   size_t lds = 0;
   for (;; chunks *= 2) {
@@ -266,8 +293,12 @@ static hipError_t launch_im2col_t(T *ws, int64_t oH, int64_t oW, const T *in, in
   }
   chunks = (npix + chunk_pix - 1) / chunk_pix;
   if (lds <= ((size_t)64 << 10) && ncs * chunks <= 0x7fffffffLL && Wp <= 0x7fffffLL) {
-    hipLaunchKernelGGL(im2col_band_kernel<T>, dim3((unsigned)(ncs * chunks)), dim3(256), lds, s, ws, in, (int)chunks, (int)chunk_pix,
-                       (int)H, (int)W, (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW, (int)Wp, vec_ok);
+    if (rowvec)
+      hipLaunchKernelGGL((im2col_band_kernel<T, true>), dim3((unsigned)(ncs * chunks)), dim3(256), lds, s, ws, in, (int)chunks, (int)chunk_pix,
+                         (int)H, (int)W, (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW, (int)Wp, vec_ok);
+    else
+      hipLaunchKernelGGL((im2col_band_kernel<T, false>), dim3((unsigned)(ncs * chunks)), dim3(256), lds, s, ws, in, (int)chunks, (int)chunk_pix,
+                         (int)H, (int)W, (int)kH, (int)kW, (int)oH, (int)oW, (int)pH, (int)pW, (int)sH, (int)sW, (int)Wp, vec_ok);
     return hipGetLastError();
   }
   const int64_t rows = ncs * kH * kW, gchunks = (npix + 256 * V - 1) / (256 * V);

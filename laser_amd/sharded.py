@@ -71,6 +71,16 @@ def gemm_strided_sharded_dev(devices, M, N, K, alpha, A_panels, rowStrideA, colS
     if not (len(A_panels) == len(Bs) == len(Cs) == n):
         raise ValueError("one A panel stack, one B and one C per device slot")
     tab = lambda xs: (C.c_void_p * n)(*[C.c_void_p(x.data_ptr()) for x in xs])
+    # The C entry point has no stream parameter: it works on its own (non-blocking) streams, one set per device slot, and its
+    # contract is that the operands are READY when it is called.  torch fills tensors asynchronously on its current stream, so the
+    # producers of every operand are waited for here (round 5: a panel made by shard_rows a moment before the call was read
+    # half-written by the slot's first product -- tests/test_gpu_sharded.py caught it with the pinned one-chain kernel).
+    try:
+        import torch
+        for d in sorted({x.device.index for x in list(A_panels) + list(Bs) + list(Cs) if isinstance(x, torch.Tensor) and x.is_cuda}):
+            torch.cuda.current_stream(d).synchronize()
+    except ImportError:
+        pass
     fn = getattr(_lib.lib(), f"laser_hip_gemm_strided_{s}_sharded_dev")
     _lib.check(fn(n, _devs(devices), M, N, K, ct(alpha), tab(A_panels), rowStrideA, colStrideA, tab(Bs), rowStrideB, colStrideB,
                   ct(beta), tab(Cs), rowStrideC, int(panels_per_dev), int(gather), int(flags)))
