@@ -392,7 +392,9 @@ hipError_t run_gemm_core<float>(const GemmArgs<float> &a, hipStream_t s) {
   // Up to ~150 tiles of 64x64 the slice-parallel form (kc slices as one batched launch + ordered combine) fills the chip
   // better than any single launch; above that the hand-scheduled assembly kernels come first (their 64x64 tile covers the
   // few-tile x long-K problems the slice-parallel form was built for: 1024^2 x 8192 = 256 tiles).
-  const bool few_tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64) <= 150;
+  // (a pinned assembly tile class -- option "asm_tile", the sharded entry points' LASER_HIP_SHARD_PIN_TILE -- asks for THAT kernel
+  // family: the slice-parallel form does not come first then)
+  const bool few_tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64) <= 150 && asm_tile_pin_now() < 0;
   g_last_f32_asm = 0;
   if (f32_cfg_now() < 0 && few_tiles) {
     const hipError_t e = gemm_slice_parallel<float>(a, 512, s);

@@ -39,6 +39,7 @@ std::atomic<int> g_asm_noseed{0};     // option "asm_noseed": 1 = a piece never 
 std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
 
 void asm_set_thread_tile(int tile_class) { tl_asm_tile = tile_class; }
+int asm_tile_pin_now() { return tl_asm_tile >= -1 ? tl_asm_tile : (int)g_asm_tile; }
 
 namespace {
 
@@ -464,7 +465,7 @@ hipError_t launch_gemm_f32_asm_core(const GemmArgs<float> &a, bool laser_order, 
   // A pinned tile class (option "asm_tile" / the sharded entry point's LASER_HIP_SHARD_PIN_TILE on its worker threads): the local
   // products of a multi-GPU run that shares the CUs with RCCL's kernels.  One tile per workgroup then -- a persistent plan counts on
   // every workgroup slot of the chip -- and no lower bound on the tile count (the caller asked for THIS kernel family).
-  const int tile_pin = tl_asm_tile >= -1 ? tl_asm_tile : (int)g_asm_tile;
+  const int tile_pin = asm_tile_pin_now();
   const int classes[5] = {big, mid, small, deep, tiny};
   for (int ci = 0; ci < 5; ci++) {
     const int k0 = classes[ci];

@@ -35,9 +35,19 @@ def test_bench_two_rank_path_on_one_gpu():
     env = dict(os.environ, LASER_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--size", "1024"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--warmup", "1", "--size", "1024", "--panels-per-rank", "2", "--gather", "collective"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     out = _last_json(r.stdout)
     assert KEYS <= set(out) and out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["config"]["M"] == 2048 and "row-panels x2" in out["config"]["parallelism"]
     assert out["roofline"]["traffic"] is None
+    # the local products of the one-process-per-GPU form run the hand-scheduled 128x128x16 ASSEMBLY tile (the pin
+    # used to force the compiler-scheduled configuration), the line names the kernel that really ran, and it is taken apart:
+    # compute-only time, what the gather left exposed, and who took part
+    assert out["roofline"]["kernel"].startswith("lh_f32_exact_128x128x16"), out["roofline"]["kernel"]
+    cfg = out["config"]
+    assert "asm_tile=2" in cfg["tile_config"]
+    assert cfg["compute_only_ms"] > 0 and abs(cfg["exposed_gather_ms"] - (out["ms_per_step"] - cfg["compute_only_ms"])) < 1e-3
+    assert cfg["backend"]["world_size"] == 2 and len(cfg["backend"]["ranks"]) == 2
+    assert all(r_["kernel"].startswith("lh_f32_exact_128x128x16") for r_ in cfg["backend"]["ranks"])
