@@ -457,11 +457,19 @@ def single_process_primary(args):
     print(json.dumps(out), flush=True)
 
 
-def kernel_source_sha16():
-    """Identity of the two headline kernels' CODE: the sha-256 of their generated gfx950 assembly text (what the assembler turns into
-    the code object's .text; produced here by the same generator the build runs) plus the launch geometry constant that decides
-    which tiles share an L2.  The committed PMC traffic figure is quoted only while this matches the value recorded with the
-    measurement -- a change to the host launcher (or to any other kernel) no longer invalidates it, a change to these kernels does."""
+def headline_plan(laser_amd):
+    """The launch plan the LAST assembly GEMM launch of this process ran under (diagnostics of laser_hip_get_option): workgroups, K slices
+    per tile, raster group height / XCD chunking -- what decides which tiles share an XCD's L2, i.e. the HBM-side traffic."""
+    return {"wgs": laser_amd.get_option("last_asm_wgs"), "slices": laser_amd.get_option("last_asm_slices"),
+            "group_m": laser_amd.get_option("last_asm_group_m")}
+
+
+def kernel_source_sha16(plans):
+    """Identity of what the committed PMC traffic figure was measured on: the sha-256 of the two headline kernels' generated gfx950
+    assembly text (what the assembler turns into the code object's .text; produced here by the same generator the build runs) AND the
+    launch plan each ran under at the headline shape, as the launcher reports it after the launch (`plans` = {mode: headline_plan}).
+    A change to these kernels or to the launcher's plan for this shape (persistent vs plain, workgroup count, raster group, XCD
+    chunking -- ADVICE r4) invalidates the figure; a change to any other kernel or launcher path does not."""
     import hashlib
     from laser_amd.asmgen import f32_kernel as K
     h = hashlib.sha256()
@@ -469,20 +477,24 @@ def kernel_source_sha16():
         g = K.make(name)
         g.build()
         h.update(K.kernel_text(g, "lh_f32_" + name).encode())
-    h.update(b"group_m=4/8;xcd_chunks=8")      # (gemm_f32_asm.cpp: grouped raster of 4 (256x128) / 8 tile rows, 8 XCD chunks)
+    h.update(json.dumps(plans, sort_keys=True).encode())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(mode):
+def pmc_traffic(mode, plan):
     """HBM-side bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, in bytes).
-    Counters cannot be collected inside this process, so this is the latest committed measurement
-    of the same kernel on the same shape -- quoted ONLY while the kernel sources still hash to the value
-    recorded with the measurement (scripts/update_pmc_traffic.py) -- or None."""
+    Counters cannot be collected inside this process, so this is the latest COMMITTED MEASUREMENT
+    of the same kernel on the same shape under the same launch plan -- quoted ONLY while the kernel text and the plan this run
+    observed (`plan` = headline_plan after the timed launches) match what was recorded with the measurement
+    (scripts/update_pmc_traffic.py) -- or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             d = json.load(f)
-        if d.get("kernel_source_sha16") != kernel_source_sha16():
+        plans = dict(d.get("plans") or {})
+        if plans.get(mode) != plan:
+            return None      # another launch plan than the one the counters were collected under
+        if d.get("kernel_source_sha16") != kernel_source_sha16(plans):
             return None      # measured on other kernel sources: stale, do not quote it
         return d.get(mode)
     except (OSError, ValueError):
@@ -829,10 +841,12 @@ def main():
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                                "kernel": last_kernel_name(laser_amd),
                                "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": 2.0 * n * n * n}
-            tr = pmc_traffic(mode) if (n == SIZE and args.cfg < 0) else None   # the profiled shape / configuration only
+            plan_now = headline_plan(laser_amd)
+            out["roofline"]["launch_plan"] = plan_now
+            tr = pmc_traffic(mode, plan_now) if (n == SIZE and args.cfg < 0) else None   # the profiled shape / configuration only
             if tr is not None:
                 out["roofline"]["traffic"] = tr["bytes_per_launch"]
-                out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["traffic_source"] = "committed measurement (not collected in this run): " + tr["source"]
             # the other accumulation mode, same operands, same protocol (reported, not `value`)
             other = 1 if mode == "laser_order" else 0
             laser_amd.set_float_mode(other)

@@ -111,12 +111,15 @@ int laser_hip_f32_config_count(void);
  *                          one tile per workgroup, no minimum tile count; -1 = the launcher's model decides.  The per-GPU processes
  *                          of laser_amd/distributed.py set 2 around their local products; LASER_HIP_SHARD_PIN_TILE is the same pin
  *                          per call and per worker thread inside the single-process sharded entry points
+ *   "im2col_band"      [0] output pixels per workgroup band of the explicit im2col kernel (0 = 256 sixteen-byte vectors; tuning sweeps)
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
  *   "last_f32_asm" / "last_f64_asm" / "last_i32_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
  *   "last_asm_wgs" / "last_asm_slices"  workgroups and K slices per tile of the last assembly launch (slices 1 = tiles never cut)
- *   "asm_fixup_timeouts"  workgroups of cut launches on the current device that gave up waiting for a hand-over (0 in a correct
- *                      run; reading it synchronises the device)
+ *   "last_asm_group_m"  its raster group height in tile rows (which tiles share an XCD's L2), + 65536 when the workgroup ids were
+ *                      chunked per XCD
+ *   "asm_fixup_timeouts"  streams of the current device on which a workgroup of a cut launch gave up waiting for a hand-over (0 in a
+ *                      correct run; reading it synchronises the device, and a stream reported here has its hand-over flags reset)
  *   "last_split"       column where the last compiler-scheduled float GEMM / conv launch was cut into main + tail (0 = one launch) */
 int laser_hip_set_option(const char *name, int value);
 int laser_hip_get_option(const char *name, int64_t *value);

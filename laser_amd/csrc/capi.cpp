@@ -1458,7 +1458,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "i64_mfma") g_ctx.i64_mfma = on;
   else if (n == "conv_implicit") g_ctx.conv_implicit = on;
   else if (n == "conv_patch") g_conv_patch = on;
-  else if (n == "conv_direct") g_conv_direct = value < 0 ? 0 : value > 3 ? 3 : value;
+  else if (n == "conv_direct") g_conv_direct = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "conv_kslice") g_conv_kslice = on;
   else if (n == "host_pipeline_2d") g_ctx.host_pipeline_2d = on;
   else if (n == "zero_copy_poll") g_ctx.zc_poll = on;
@@ -1468,6 +1468,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "asm_kernel") g_asm_kernel = value < 0 ? -1 : value;
   else if (n == "asm_tile") g_asm_tile = value < 0 || value > 4 ? -1 : value;
+  else if (n == "im2col_band") g_im2col_band = value < 0 ? 0 : value;
   else if (n == "asm_wgs") g_asm_wgs = value < 0 ? 0 : value;
   else if (n == "asm_slice") g_asm_slice = value < 0 ? 0 : value;
   else if (n == "asm_noseed") g_asm_noseed = on;
@@ -1501,12 +1502,14 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "asm_plan") *value = g_asm_plan;
   else if (n == "asm_kernel") *value = g_asm_kernel;
   else if (n == "asm_tile") *value = g_asm_tile;
+  else if (n == "im2col_band") *value = g_im2col_band;
   else if (n == "asm_wgs") *value = g_asm_wgs;
   else if (n == "asm_slice") *value = g_asm_slice;
   else if (n == "asm_noseed") *value = g_asm_noseed;
   else if (n == "asm_group_m") *value = g_asm_group_m;
   else if (n == "last_asm_wgs") *value = g_last_asm_wgs;
   else if (n == "last_asm_slices") *value = g_last_asm_slices;
+  else if (n == "last_asm_group_m") *value = g_last_asm_group_m;
   else if (n == "asm_fixup_timeouts") *value = asm_fixup_timeouts();
   else if (n == "slice_parallel") *value = g_ctx.slice_parallel;
   else if (n == "slice_parallel_min") *value = g_ctx.slice_parallel_min;

@@ -187,6 +187,7 @@ extern std::atomic<int> g_i32_asm, g_last_i32_asm;
 extern std::atomic<int> g_asm_tile;   // option "asm_tile" (gemm_f32_asm.cpp)
 void asm_set_thread_tile(int tile_class);   // per-thread pin of the same (-2 = none)
 int asm_tile_pin_now();                     // the pin this thread's launches see (-1 = none)
+extern std::atomic<int> g_last_asm_group_m;
 extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed, g_asm_group_m;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
 extern std::atomic<int> g_last_asm_wgs, g_last_asm_slices;                  // diagnostics: workgroups / K slices per tile of the last assembly launch
 extern std::atomic<int> g_f32_asm;       // 1 default; 0 = never; 2 = whenever the kernel can (no tile-count rule: tests)
@@ -229,6 +230,7 @@ hipError_t launch_transpose_batched(void *dst, const void *src, int64_t N, int64
                                     int elem_size, hipStream_t s);
 hipError_t launch_transpose_pitched(void *dst, int64_t ld_dst, const void *src, int64_t ld_src, int64_t NR, int64_t NC, int elem_size,
                                     hipStream_t s);
+extern std::atomic<int> g_im2col_band;
 hipError_t launch_im2col(void *ws, int64_t oH, int64_t oW, const void *in, int64_t batch, int64_t C, int64_t H, int64_t W, int64_t kH,
                          int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, int elem_size, hipStream_t s);
 hipError_t launch_im2col_f32(float *ws, int64_t oH, int64_t oW, const float *in, int64_t batch,

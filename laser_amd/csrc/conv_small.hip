@@ -228,12 +228,12 @@ typedef __attribute__((ext_vector_type(2), aligned(4))) float cs_f32x2u;
 // CB = input channels whose loads are issued together in front of their arithmetic.  Shipped: 1.  CB = 3 (all of the bench
 // shape's inputs requested at once, one exposed latency per wave instead of three; 86 registers) measured no faster: 25.1 vs
 // 23.7 us per call at 16 images, 71.8 vs 72.3 at 64 (profiles/r04/conv_direct_probe_v6.jsonl).
-// QUAD (round 5; option "conv_direct" = 3 for the A/B): a lane's two pairs are ADJACENT (pairs 2i, 2i + 1: four consecutive output
-// pixels of the dense [M][npix] output, whichever rows they lie in) and leave as ONE 16-byte store per channel -- half the store
-// instructions, 1 KiB per wave and channel; needs npix % 4 == 0-aligned channel rows (rsC % 4 == 0, a 16-byte aligned base).
-template <int MT, int PPL, int CB, int WPS, bool QUAD = false>
+// (Round 5, measured and not kept: two ADJACENT pairs per lane leaving as ONE 16-byte store per channel -- half the store
+// instructions, 1 KiB per wave and channel, three / four waves per SIMD: 25.7 vs 22.2 us on the bench shape, 72.5 vs 66.5 at 64 images,
+// 18.8 vs 17.9 with 16 channels, bit-identical -- profiles/r05/conv_small_quad_store_ab_v1.jsonl.  Wider stores are not what the
+// kernel waits for; the eight-waves-per-SIMD form below stays.)
+template <int MT, int PPL, int CB, int WPS>
 __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvSmallArgs g) {
-  static_assert(!QUAD || PPL == 2, "a quad is two adjacent pairs");
   const int t = threadIdx.x;
   const cs_const_f32 *filt = (const cs_const_f32 *)g.filt;
   const char *__restrict__ img = reinterpret_cast<const char *>(g.img + (int64_t)blockIdx.y * g.bsB);
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvS
   unsigned boff[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; j++) {
-    q[j] = QUAD ? ((int)blockIdx.x * 256 + t) * PPL + j : (int)blockIdx.x * (256 * PPL) + 256 * j + t;
+    q[j] = (int)blockIdx.x * (256 * PPL) + 256 * j + t;
     const int qq = q[j] < npairs ? q[j] : 0;     // (lanes past the image compute pair 0 again and store nothing)
     const int oh = qq / PW, pw = qq - oh * PW;
     boff[j] = (unsigned)((oh * g.sH) * g.W + 2 * pw) * 4u;
@@ -309,15 +309,6 @@ __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvS
     }
   }
   float *out = g.out + (int64_t)blockIdx.y * g.bsC;
-  if constexpr (QUAD) {
-    if (q[1] < npairs) {
-#pragma unroll
-      for (int m = 0; m < MT; m++)
-        if (m < g.M)
-          *reinterpret_cast<cs_f32x4 *>(out + (int64_t)m * g.rsC + 2 * q[0]) = (cs_f32x4){acc[0][m][0], acc[0][m][1], acc[1][m][0], acc[1][m][1]};
-      return;
-    }
-  }
 #pragma unroll
   for (int j = 0; j < PPL; j++) {
     if (q[j] >= npairs) continue;
@@ -468,13 +459,6 @@ hipError_t launch_scalar_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
 template <int MT, int WPS>
 hipError_t launch_pairs_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
   const int npairs = g.npix / 2;
-  // adjacent pairs, one 16-byte store per lane and channel (A/B: option "conv_direct" = 3), where every channel row of every image
-  // starts 16-byte aligned
-  if (g_conv_direct == 3 && g.rsC % 4 == 0 && g.bsC % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0) {
-    const dim3 gridq((unsigned)((npairs + 511) / 512), (unsigned)batch);
-    hipLaunchKernelGGL((conv_direct_pairs_kernel<MT, 2, 1, (MT >= 20 ? 3 : 4), true>), gridq, dim3(256), 0, s, g);
-    return hipGetLastError();
-  }
   const dim3 grid((unsigned)((npairs + 255) / 256), (unsigned)batch);
   hipLaunchKernelGGL((conv_direct_pairs_kernel<MT, 1, 1, WPS>), grid, dim3(256), 0, s, g);
   return hipGetLastError();

@@ -7,6 +7,8 @@
 
 namespace laser_hip {
 
+std::atomic<int> g_im2col_band{0};   // option "im2col_band": output pixels per workgroup band of the im2col kernel (0 = 256 vectors)
+
 // ---- batched 2-D transpose: dst[n][j][i] = src[n][i][j] -------------------------------------------
 // 64x64 tile through LDS, 16-byte accesses on BOTH HBM sides (the reference writes contiguously and
 // reads strided, swapaxes.nim:34-39; with LDS in between both sides are contiguous here):
@@ -283,7 +285,8 @@ static hipError_t launch_im2col_t(T *ws, int64_t oH, int64_t oW, const T *in, in
   const bool rowvec = vec_ok && sW == 1 && oW % V == 0 && kW <= V + 1;
   int64_t Wp = std::max<int64_t>(W + 2 * pW, (oW - 1) * sW + kW);
   if (rowvec) Wp = std::max<int64_t>((Wp + V - 1) / V * V, oW + V);      // 16-byte row pitch; a row's second vector read stays inside it
-  int64_t chunks = (npix + 256 * V - 1) / (256 * V), chunk_pix = 0;
+  const int64_t band = g_im2col_band > 0 ? std::max<int64_t>(V, g_im2col_band) : 256 * V;      // option "im2col_band" (tuning sweeps)
+  int64_t chunks = (npix + band - 1) / band, chunk_pix = 0;
   size_t lds = 0;
   for (;; chunks *= 2) {
     chunk_pix = ((npix + chunks - 1) / chunks + V - 1) / V * V;

@@ -36,7 +36,7 @@ std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persi
 std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
 std::atomic<int> g_asm_group_m{0};    // option "asm_group_m": tile rows per raster group of the f32 / f64 GEMM launches (0 = 4 for 256-row tiles, else 8)
 std::atomic<int> g_asm_noseed{0};     // option "asm_noseed": 1 = a piece never takes its received sum early (tests: forces the two-run receive path)
-std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
+std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0}, g_last_asm_group_m{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
 
 void asm_set_thread_tile(int tile_class) { tl_asm_tile = tile_class; }
 int asm_tile_pin_now() { return tl_asm_tile >= -1 ? tl_asm_tile : (int)g_asm_tile; }
@@ -360,6 +360,7 @@ hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernAr
   if (e == hipSuccess) {
     g_last_asm_wgs = (int)plan.G;
     g_last_asm_slices = (int)plan.P;
+    g_last_asm_group_m = (int)ka.sch.group_m | (ka.sch.xcd_q ? 1 << 16 : 0);      // raster group height; bit 16: XCD-aware chunking of the ids
   }
   return e;
 }
@@ -373,8 +374,12 @@ void zero_conv_fields(KernArgs &ka) {
 
 }  // namespace
 
-// diagnostics (option "asm_fixup_timeouts", synchronises the device): workgroups on the current device that gave up waiting for a
-// running sum (asmgen/f32_kernel.py recv_block) -- never in a correct run
+// diagnostics (option "asm_fixup_timeouts", synchronises the device): streams of the current device on which some workgroup gave up
+// waiting for a running sum (asmgen/f32_kernel.py recv_block: after ~2 s of polling it stores 1 into the stream's error word and
+// goes on with what the slot holds -- a flagged wrong result instead of a hung GPU; never in a correct run).  A sender that was only
+// LATE sets its flag after its receiver has given up and cleared it: the flag would still be set when the next cut launch on that
+// stream starts and hand it a stale sum.  So a stream found with its error word set gets its whole flag array cleared here (the
+// device is idle at this point) -- the launches after the report are clean again.
 int64_t asm_fixup_timeouts() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -1;
@@ -384,8 +389,12 @@ int64_t asm_fixup_timeouts() {
   int64_t n = 0;
   for (auto &kv : m.ws) {
     uint32_t wv = 0;
-    if (kv.second.flags && hipMemcpy(&wv, kv.second.flags, 4, hipMemcpyDeviceToHost) == hipSuccess) n += wv;
+    if (kv.second.flags && hipMemcpy(&wv, kv.second.flags, 4, hipMemcpyDeviceToHost) == hipSuccess && wv != 0) {
+      n += wv;
+      (void)hipMemset(kv.second.flags, 0, kv.second.nflags * sizeof(uint32_t));
+    }
   }
+  if (n) (void)hipDeviceSynchronize();
   return n;
 }
 

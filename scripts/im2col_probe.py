@@ -23,5 +23,12 @@ for name, ishape, k, pad, stv, dt in (("C4 (32,128,56,56) 3x3 pad 1 f32", (32, 1
     assert fn(*args) == 0
     med, mn = ev_time(lambda: fn(*args), iters=9, inner=16)
     byts = (x.numel() + ws.numel()) * x.element_size()
-    print(json.dumps({"config": "im2col alone " + name, "ms_med": round(med, 4), "ms_min": round(mn, 4), "bytes": byts,
+    sweep = {}
+    if len(sys.argv) > 1 and sys.argv[1] == "bands":
+        for band in (256, 512, 784, 1568, 3136, 6272):
+            laser_amd.set_option("im2col_band", band)
+            m_, _ = ev_time(lambda: fn(*args), iters=7, inner=16)
+            sweep[str(band)] = round((x.numel() + ws.numel()) * x.element_size() / (m_ * 1e-3) / 1e9, 1)
+        laser_amd.set_option("im2col_band", 0)
+    print(json.dumps({"config": "im2col alone " + name, "gbps_by_band_pixels": sweep, "ms_med": round(med, 4), "ms_min": round(mn, 4), "bytes": byts,
                       "gbps": round(byts / (med * 1e-3) / 1e9, 1), "frac_hbm_peak": round(byts / (med * 1e-3) / 1e9 / 8000.0, 4)}), flush=True)

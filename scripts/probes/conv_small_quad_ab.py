@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The reference's own conv bench shape, (16,3,224,224) (*) (20,3,3,3) pad 0 (conv2d_bench.nim:130-170), on the direct small-channel
 kernels: option conv_direct = 1 (one pixel pair per lane, 8-byte stores) against 3 (two adjacent pairs per lane, 16-byte stores).
-C-ABI symbol bound once; results compared bit for bit."""
+C-ABI symbol bound once; results compared bit for bit.
+ONE-OFF: ran against commit 91f85e4, the only build that carried the 16-byte-store variant behind conv_direct = 3 (measured slower and
+removed: profiles/r05/conv_small_quad_store_ab_v1.jsonl); kept as the record of how the A/B was made."""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, laser_amd

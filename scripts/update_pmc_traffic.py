@@ -29,12 +29,30 @@ def main():
             per[kern]["_grid"] = int(g.group(1))
             per[kern]["_dispatches"] = int(g.group(2))
     import bench
+    # the launch plan of each headline kernel at the headline shape, read back from the library after one launch (this script runs on
+    # the GPU box, right after the counter passes)
+    plans = {}
+    try:
+        import torch
+        import laser_amd
+        n = bench.SIZE
+        A = torch.rand((n, n), device="cuda") * 0.2 - 0.1
+        B = torch.rand((n, n), device="cuda") * 0.2 - 0.1
+        C = torch.zeros((n, n), device="cuda")
+        for mode, name in ((0, "laser_order"), (1, "fast")):
+            laser_amd.set_float_mode(mode)
+            laser_amd.matmul(A, B, 1, 0, C)
+            torch.cuda.synchronize()
+            plans[name] = bench.headline_plan(laser_amd)
+        laser_amd.set_float_mode(0)
+    except Exception as e:      # no GPU here: the file is not rewritten
+        raise SystemExit(f"update_pmc_traffic.py needs the GPU the counters were collected on: {e}")
     out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 20 --warmup 10 "
                     "--no-cpu-baseline --no-single-process` (8192^3 sgemm, headline launches only), per launch. Both counters are "
                     "reported in KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B for wide coalesced loads, "
                     "MI355X_MICROARCH.md HBM section); it counts L2 fabric-side requests, Infinity-Cache hits included. "
                     "Algorithmic bytes are 0.805 GB: the rest is operand panels re-fetched by the 8 XCD-private L2s.",
-           "kernel_source_sha16": bench.kernel_source_sha16()}
+           "plans": plans, "kernel_source_sha16": bench.kernel_source_sha16(plans)}
     for mode, pat in (("laser_order", r"lh_f32_exact_256x128x32"), ("fast", r"lh_f32_fast_256x256x16")):
         ks = [k for k in per if re.search(pat, k) and "FETCH_SIZE" in per[k] and "WRITE_SIZE" in per[k]]
         if not ks:

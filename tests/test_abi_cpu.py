@@ -125,8 +125,7 @@ def test_scalar_filter_conv_kernels_keep_their_scalars_and_their_occupancy():
     (<= 64 VGPRs) up to 20 output channels, the general-stride form five (<= 96)."""
     import laser_amd
     ks = dict(_device_kernels(laser_amd.LIB_PATH))
-    quads = {n: k for n, k in ks.items() if "conv_direct_pairs_kernel" in n and n.endswith("Lb1EEEvNS0_13ConvSmallArgsE")}   # the QUAD A/B variants
-    pairs = {n: k for n, k in ks.items() if "conv_direct_pairs_kernel" in n and n not in quads}
+    pairs = {n: k for n, k in ks.items() if "conv_direct_pairs_kernel" in n}
     scalar = {n: k for n, k in ks.items() if "conv_direct_scalar_kernel" in n}
     assert len(pairs) == 6 and len(scalar) == 12, (sorted(pairs), sorted(scalar))
     for n, k in list(pairs.items()) + list(scalar.items()):
