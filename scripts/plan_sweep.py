@@ -23,6 +23,8 @@ SHAPES = {
             (1000, 3000, 2000), (1536, 1536, 4096), (4100,) * 3],
     "big": [(4096,) * 3, (6144,) * 3, (8192,) * 3],
     "f64": [(960,) * 3, (1024,) * 3, (1536,) * 3, (1792,) * 3, (2048,) * 3, (2304,) * 3, (4096,) * 3],
+    # short-K problems with exactly three rounds of 256x128 tiles: the GEMM twins of C4's main launch (K = C_in * 9 = 1152)
+    "shortk": [(8192, 3072, 1152), (8192, 3072, 576), (8192, 3072, 2304), (4096, 6144, 1152)],
     "small": [(512,) * 3, (640, 640, 4096), (768,) * 3, (896,) * 3, (1024, 1024, 8192), (512, 512, 8192)],
 }[which]
 PEAK = 78.6 if f64 else 157.3
