@@ -90,6 +90,9 @@ int laser_hip_f32_config_count(void);
  *   "conv_direct"      [1] convolutions with <= 32 output channels and C_in*kH*kW <= 256 (the reference's conv bench shape,
  *                          conv2d_bench.nim:130-170): the direct HBM-streaming kernels; 0 = the implicit-GEMM kernels; 2 = without
  *                          the scalar-filter forms of 3x3 filters (A/B switch: the matrix-core / LDS-filter forms everywhere)
+ *   "conv_tail"        [1] the pixel tail behind the hand-scheduled 3x3 conv main launch (npix % 128 pixels per image) as ONE launch
+ *                          of the latency-built direct kernel (a wave per 32x32 block and kc slice, ordered fold in LDS); 0 = the
+ *                          compiler-scheduled tail forms
  *   "conv_kslice"      [1] laser-order conv tail as parallel kc slices (gemm.nim:150-158) + ordered combine
  *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only
  *   "zero_copy_poll"   [1] small host-pointer calls poll completion flags in mapped memory; 0 = synchronise the stream
@@ -120,6 +123,8 @@ int laser_hip_f32_config_count(void);
  *                      chunked per XCD
  *   "asm_fixup_timeouts"  streams of the current device on which a workgroup of a cut launch gave up waiting for a hand-over (0 in a
  *                      correct run; reading it synchronises the device, and a stream reported here has its hand-over flags reset)
+ *   "last_conv_tail"   how the last convolution's pixel tail ran: 0 no tail, 1 the direct tail kernel, 2 kc slices + combine, 3 one
+ *                      compiler-kernel launch
  *   "last_split"       column where the last compiler-scheduled float GEMM / conv launch was cut into main + tail (0 = one launch) */
 int laser_hip_set_option(const char *name, int value);
 int laser_hip_get_option(const char *name, int64_t *value);

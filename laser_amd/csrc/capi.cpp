@@ -1460,6 +1460,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "conv_patch") g_conv_patch = on;
   else if (n == "conv_direct") g_conv_direct = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "conv_kslice") g_conv_kslice = on;
+  else if (n == "conv_tail") g_conv_tail = on;
   else if (n == "host_pipeline_2d") g_ctx.host_pipeline_2d = on;
   else if (n == "zero_copy_poll") g_ctx.zc_poll = on;
   else if (n == "skinny") g_ctx.skinny = on;
@@ -1494,6 +1495,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "conv_patch") *value = g_conv_patch;
   else if (n == "conv_direct") *value = g_conv_direct;
   else if (n == "conv_kslice") *value = g_conv_kslice;
+  else if (n == "conv_tail") *value = g_conv_tail;
   else if (n == "host_pipeline_2d") *value = g_ctx.host_pipeline_2d;
   else if (n == "zero_copy_poll") *value = g_ctx.zc_poll;
   else if (n == "skinny") *value = g_ctx.skinny;
@@ -1518,6 +1520,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "last_f32_config") *value = g_last_f32_cfg;
   else if (n == "last_f32_asm") *value = g_last_f32_asm;
   else if (n == "last_split") *value = g_last_split;
+  else if (n == "last_conv_tail") *value = g_last_conv_tail;
   else return fail(LASER_HIP_E_INVALID, "get_option: unknown option '%s'", name);
   return LASER_HIP_OK;
 }

@@ -222,6 +222,9 @@ hipError_t launch_gemm_i64_mfma(const GemmArgs<int64_t> &args, void *ws, hipStre
 extern std::atomic<int> g_conv_direct;        // few output channels x short K: the direct (HBM-streaming) kernel (1, default)
 hipError_t launch_conv_direct_small_f32(const GemmArgs<float> &a, hipStream_t s);
 extern std::atomic<int> g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
+extern std::atomic<int> g_last_conv_tail;
+extern std::atomic<int> g_conv_tail;          // the direct tail kernel behind the assembly conv main launch (1, default)
+hipError_t launch_conv_tail_f32(const GemmArgs<float> &a, int kc, hipStream_t s);
 extern std::atomic<int> g_conv_kslice;        // laser-order conv tail as parallel kc slices + ordered combine (1, default)
 extern std::atomic<int> g_split_tail;        // 1 (default): cut problems with a badly filled last round into main + tail launches
 extern std::atomic<int64_t> g_last_split;    // diagnostics: column cut of the last MFMA launch (0 = one launch)

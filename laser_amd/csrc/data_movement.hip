@@ -285,7 +285,10 @@ static hipError_t launch_im2col_t(T *ws, int64_t oH, int64_t oW, const T *in, in
   const bool rowvec = vec_ok && sW == 1 && oW % V == 0 && kW <= V + 1;
   int64_t Wp = std::max<int64_t>(W + 2 * pW, (oW - 1) * sW + kW);
   if (rowvec) Wp = std::max<int64_t>((Wp + V - 1) / V * V, oW + V);      // 16-byte row pitch; a row's second vector read stays inside it
-  const int64_t band = g_im2col_band > 0 ? std::max<int64_t>(V, g_im2col_band) : 256 * V;      // option "im2col_band" (tuning sweeps)
+  // band length (profiles/r05/im2col_bands_v1.jsonl): many (image, channel) planes -> longer bands (6 KiB of every workspace row per
+  // workgroup: C4 4.58 -> 5.16 TB/s); few planes -> 4 KiB bands so that the launch still has thousands of workgroups (the stride-2 case
+  // of that sweep loses 20 - 45 % on the long bands); option "im2col_band" overrides (tuning sweeps)
+  const int64_t band = g_im2col_band > 0 ? std::max<int64_t>(V, g_im2col_band) : (ncs >= 2048 ? 392 * V : 256 * V);
   int64_t chunks = (npix + band - 1) / band, chunk_pix = 0;
   size_t lds = 0;
   for (;; chunks *= 2) {

@@ -177,6 +177,8 @@ static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 
 std::atomic<int> g_conv_patch{1}; // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
 std::atomic<int> g_conv_kslice{1}; // laser-order conv: tail launch as parallel kc slices + ordered combine (0: one workgroup per tail tile)
+std::atomic<int> g_last_conv_tail{0};   // diagnostics: how the last convolution's pixel tail ran (0 none, 1 direct kernel, 2 kc slices + combine, 3 one compiler-kernel launch)
+std::atomic<int> g_conv_tail{1};   // option "conv_tail": the direct tail kernel behind the assembly main launch (conv_tail.hip); 0 = the round-3 forms
 std::atomic<int> g_last_f32_cfg{-1}; // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
 // Main launch, then the tail launch on the same stream.  (Running the tail BESIDE the main launch on a side stream was
@@ -317,6 +319,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     }
     return launch_conv_cfg(mm, plan.cfg_main, exact, q);
   };
+  g_last_conv_tail = 0;
   if (plan.n_cut <= 0) return main_launch(a, s);
   GemmArgs<float> m = a;  // output pixels [0, n_cut) of every image
   m.N = plan.n_cut; m.Next = plan.n_cut;
@@ -329,9 +332,26 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   // into a workspace, and the ordered combine pass folds them: same fused multiply-adds, same order => bit-identical.
   const int64_t nsl = (a.K + 511) / 512, ntail = a.N - plan.n_cut;
   // (the one-chain mode has no order to keep: it takes the same faster tail)
+  // (round 5) behind the hand-scheduled main launch the tail is one launch of the latency-built direct kernel (conv_tail.hip: one
+  // wave per 32x32 block and kc slice, operands straight into the MFMA lane layout, ordered fold in LDS -- no workspace, no combine
+  // pass); option "conv_tail" = 0: the round-3 forms below
+  bool main_done = false;
+  if (cfg < 0 && g_conv_tail && g_split_tail) {
+    if (hipError_t e = main_launch(m, s); e != hipSuccess) return e;
+    main_done = true;
+    if (g_last_f32_asm != 0) {
+      const hipError_t e = launch_conv_tail_f32(t, 512, s);
+      if (e != hipErrorNotSupported) {
+        g_last_conv_tail = 1;
+        return e;
+      }
+    }
+  }
   if ((exact || !laser_order) && g_conv_kslice && g_split_tail && nsl >= 2 && a.bias == nullptr && a.act == 0 && a.bsC == a.M * a.rsC &&
       (int64_t)a.batch * nsl <= 65535) {
-    if (hipError_t e = main_launch(m, s); e != hipSuccess) return e;
+    if (!main_done)
+      if (hipError_t e = main_launch(m, s); e != hipSuccess) return e;
+    g_last_conv_tail = 2;
     const int64_t mn = a.M * ntail;
     float *W = nullptr;
     if (hipError_t e = scratch_alloc_async((void **)&W, (size_t)(nsl * a.batch * mn) * sizeof(float), s); e != hipSuccess) return e;
@@ -348,6 +368,8 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     const hipError_t e2 = hipFreeAsync(W, s);
     return e != hipSuccess ? e : e2;
   }
+  g_last_conv_tail = 3;
+  if (main_done) return launch_conv_cfg(t, cfg_tail, exact, s);
   return launch_main_and_tail(
       s, [&](hipStream_t q) { return main_launch(m, q); },
       [&](hipStream_t q) { return launch_conv_cfg(t, cfg_tail, exact, q); });

@@ -608,6 +608,47 @@ def test_transposes_two_and_one_byte_elements(la, oracle):
         assert torch.equal(o, d.t())
 
 
+def test_conv_pixel_tail_direct_kernel_bit_exact(la, oracle):
+    """The pixel tail behind the hand-scheduled 3x3 conv main launch (npix % 128 pixels per image) on the direct tail kernel
+    (conv_tail.hip, round 5): tails of 1 .. 127 pixels, one to four kc slices (K = 36 .. 1332 + the K <= kc single-slice case), channel
+    counts that are not a multiple of the 32-row block, padding 0 / 1 / 2, both accumulation modes; bit-exact against the oracle in
+    laser-order mode (conv2d_im2col.nim:102-166 through Laser's GEMM), identical to the round-3 tail forms."""
+    import torch
+    rng = np.random.default_rng(515)
+    cases = [((6, 128, 56, 56), (256, 128, 3, 3), (1, 1)),      # C4's geometry: 64-pixel tail, 3 slices
+             ((3, 64, 30, 30), (100, 64, 3, 3), (1, 1)),        # 900 pixels: tail 4 (one block, 4 valid pixels), M = 100, 2 slices
+             ((2, 148, 24, 22), (70, 148, 3, 3), (0, 0)),       # 22 x 20 = 440: tail 56; K = 1332: 3 slices, the last 308 long
+             ((4, 8, 34, 34), (96, 8, 3, 3), (2, 2)),           # K = 72 <= kc: one slice; 36 x 36 = 1296: tail 16
+             ((2, 60, 28, 30), (130, 60, 3, 3), (1, 1))]        # 840: tail 72 (3 blocks); K = 540: slices 512 + 28
+    for ishape, kshape, pad in cases:
+        x = rng.uniform(0, 1, ishape).astype(np.float32)
+        w = rng.uniform(0, 1, kshape).astype(np.float32)
+        oshape = la.conv2d_out_shape(ishape, kshape, pad, (1, 1))
+        want = oracle.conv2d_im2col(x, w, pad, (1, 1))
+        dx, dw = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+        try:
+            la.set_f32_asm(2)                 # the assembly main launch whatever the tile count
+            outs = {}
+            for tail in (1, 0):
+                la.set_option("conv_tail", tail)
+                o = torch.full(oshape, float("nan"), device="cuda")
+                la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, pad, (1, 1), None)
+                assert la.last_f32_asm() != 0, (ishape, "the assembly main launch did not run")
+                assert la.get_option("last_conv_tail") == (1 if tail else 2 if kshape[1] * 9 > 512 else 3), (ishape, tail, la.get_option("last_conv_tail"))
+                outs[tail] = o.cpu().numpy()
+            assert np.array_equal(outs[1], want), (ishape, kshape, pad, "direct tail kernel differs from the oracle")
+            assert np.array_equal(outs[0], want), (ishape, kshape, pad)
+            la.set_option("conv_tail", 1)
+            la.set_float_mode(1)
+            o = torch.zeros(oshape, device="cuda")
+            la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, pad, (1, 1), None)
+            assert oracle.mean_relative_error(o.cpu().numpy(), want) <= 1e-5
+        finally:
+            la.set_float_mode(0)
+            la.set_f32_asm(1)
+            la.set_option("conv_tail", 1)
+
+
 def test_conv_device_workspace_contract(la, oracle):
     """on the explicit path a device workspace sized the REFERENCE way (one image, im2col_workspace_size
     elements) must be enough for any batch -- the images go through it one by one -- and NULL means stream-ordered
