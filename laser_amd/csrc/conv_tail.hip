@@ -34,6 +34,7 @@ struct ConvTailArgs {
 };
 
 constexpr int kCH = 16;          // MFMAs per step = 32 k
+constexpr int kDepth = 4;        // register sets of the load ring
 
 __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g) {
   extern __shared__ __attribute__((aligned(16))) float ct_lds[];      // [nsl][nblk][16][64]: slice sums of this workgroup's blocks
@@ -87,17 +88,23 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
       }
     };
     const int nsteps = (kend - k0 + 2 * kCH - 1) / (2 * kCH);
-    ct_f32x4 a0[8], a1[8];
-    float x0[kCH], x1[kCH];
-    issue(k0, a0, x0);
+    // A ring of kDepth register sets: the loads of steps s + 1 .. s + kDepth - 1 are in flight while step s multiplies.  With ONE
+    // wave per SIMD (the whole point of this launch) nothing else hides the ~2 us a gather takes: two sets left every step waiting
+    // (48 us for C4's tails, profiles/r05/conv_tail_ab_v1.jsonl); the wave has the SIMD's whole register file to itself.
+    // (unconditional issues: a step past the end loads nothing -- every piece / element is masked by kend -- and is never multiplied)
+    ct_f32x4 a[kDepth][8];
+    float x[kDepth][kCH];
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; d++) issue(k0 + d * 2 * kCH, a[d], x[d]);
 #pragma unroll 1
-    for (int s = 0; s < nsteps; s += 2) {
-      // (unconditional: a step past the end loads nothing -- every piece / element is masked by kend -- and is never multiplied)
-      issue(k0 + (s + 1) * 2 * kCH, a1, x1);
-      compute(a0, x0);
-      if (s + 1 >= nsteps) break;
-      issue(k0 + (s + 2) * 2 * kCH, a0, x0);
-      compute(a1, x1);
+    for (int s = 0; s < nsteps; s += kDepth) {
+#pragma unroll
+      for (int d = 0; d < kDepth; d++) {
+        if (s + d < nsteps) {
+          issue(k0 + (s + d + kDepth - 1) * 2 * kCH, a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth]);
+          compute(a[d], x[d]);
+        }
+      }
     }
     float *dst = ct_lds + ((size_t)(p * g.nblk + blk) * 16) * 64 + lane;
 #pragma unroll
