@@ -56,35 +56,44 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
     const bool p_ok = pix < g.npix;
     const int oh = p_ok ? pix / g.oW : 0, ow = p_ok ? pix - oh * g.oW : 0;
     const int ih0 = oh - g.pH, iw0 = ow - g.pW;
-    const float *src = img + ih0 * g.W + iw0;          // the window origin of this lane's pixel (may lie outside the image)
+    const int org = ih0 * g.W + iw0;                   // the window origin of this lane's pixel, as an element index (may be negative)
     // this lane's running tap: k = kl, c = kl / 9, r = kl % 9 (advances by 2 per MFMA)
     int kl = k0 + hi, c = kl / 9, r = kl - c * 9;
-    auto issue = [&](int ks, ct_f32x4 (&a)[8], float (&x)[kCH]) __attribute__((always_inline)) {
+    // Every load is UNCONDITIONAL (an invalid tap / piece reads element 0 of its operand instead and is replaced by zero where it is
+    // consumed): a load under a lane condition becomes a branch round the load, and the compiler then waits for all outstanding loads
+    // at every such branch -- the first build of this kernel ran one load at a time.  The validity bits travel with the ring.
+    auto issue = [&](int ks, ct_f32x4 (&a)[8], float (&x)[kCH], unsigned &vmask) __attribute__((always_inline)) {
+      unsigned vm = 0;
       // A: the 32 consecutive k of this step as eight 16-byte pieces (a piece beyond the slice's end is zero: kend % 4 == 0)
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int kq = ks + 4 * q;
-        a[q] = (m_ok && kq < kend) ? *reinterpret_cast<const ct_f32x4 *>(arow + kq) : (ct_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        const bool ok = m_ok && kq < kend;
+        a[q] = *reinterpret_cast<const ct_f32x4 *>(arow + (ok ? kq : 0));
+        vm |= ok ? (1u << (16 + q)) : 0u;
       }
 #pragma unroll
       for (int j = 0; j < kCH; j++) {
         const int kh = (r * 11) >> 5, kw = r - 3 * kh;
         const bool in = p_ok && kl < kend && (unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W;
-        x[j] = in ? src[c * HW + kh * g.W + kw] : 0.0f;
+        x[j] = img[in ? org + c * HW + kh * g.W + kw : 0];
+        vm |= in ? (1u << j) : 0u;
         kl += 2; r += 2;
         if (r >= 9) { r -= 9; c++; }
       }
+      vmask = vm;
     };
     ct_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    auto compute = [&](const ct_f32x4 (&a)[8], const float (&x)[kCH]) __attribute__((always_inline)) {
+    auto compute = [&](const ct_f32x4 (&a)[8], const float (&x)[kCH], unsigned vm) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < kCH; j++) {
-        const int e = 2 * j + hi;                      // element of the 32-k step this lane feeds MFMA j with (compile-time per half-wave)
-        const float av = hi ? a[(2 * j + 1) >> 2][(2 * j + 1) & 3] : a[(2 * j) >> 2][(2 * j) & 3];
-        (void)e;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[j], acc, 0, 0, 0);
+        // the element of the 32-k step this lane feeds MFMA j with: 2j + hi (piece (2j + hi) / 4; both halves' candidates are compile-time)
+        const float araw = hi ? a[(2 * j + 1) >> 2][(2 * j + 1) & 3] : a[(2 * j) >> 2][(2 * j) & 3];
+        const float av = (vm >> (16 + (j >> 1))) & 1u ? araw : 0.0f;
+        const float xv = (vm >> j) & 1u ? x[j] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xv, acc, 0, 0, 0);
       }
     };
     const int nsteps = (kend - k0 + 2 * kCH - 1) / (2 * kCH);
@@ -94,16 +103,17 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
     // (unconditional issues: a step past the end loads nothing -- every piece / element is masked by kend -- and is never multiplied)
     ct_f32x4 a[kDepth][8];
     float x[kDepth][kCH];
+    unsigned vm[kDepth];
 #pragma unroll
-    for (int d = 0; d < kDepth - 1; d++) issue(k0 + d * 2 * kCH, a[d], x[d]);
+    for (int d = 0; d < kDepth - 1; d++) issue(k0 + d * 2 * kCH, a[d], x[d], vm[d]);
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += kDepth) {
 #pragma unroll
       for (int d = 0; d < kDepth; d++) {
-        if (s + d < nsteps) {
-          issue(k0 + (s + d + kDepth - 1) * 2 * kCH, a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth]);
-          compute(a[d], x[d]);
-        }
+        // (no branch on s + d < nsteps: a step past the end is all-invalid -- it loads element 0 and multiplies zeros into the chain,
+        // which leaves every accumulator as it is: x + 0 * 0 = x for every x the chain can hold)
+        issue(k0 + (s + d + kDepth - 1) * 2 * kCH, a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth], vm[(d + kDepth - 1) % kDepth]);
+        compute(a[d], x[d], vm[d]);
       }
     }
     float *dst = ct_lds + ((size_t)(p * g.nblk + blk) * 16) * 64 + lane;
