@@ -30,22 +30,48 @@ struct ConvTailArgs {
   const float *img;    // [batch][Cin][H][W]
   float *out;          // [batch][M][npix]
   int64_t bsB, bsC;
-  int32_t M, K, H, W, oW, npix, pH, pW, n_cut, nblk, nsl, kc;
+  int32_t M, K, H, W, oW, npix, pH, pW, n_cut, nblk, nsl, kc, ktab;
 };
 
 constexpr int kCH = 16;          // MFMAs per step = 32 k
 constexpr int kDepth = 4;        // register sets of the load ring
 
+// a wave-uniform pointer as a bounds-checked raw buffer (what lies beyond `bytes` reads as 0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ct_rsrc(const void *p, int64_t bytes) {
+  const uint64_t b = reinterpret_cast<uint64_t>(p);
+  const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  const int nrec = __builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0x7fffffffll ? 0x7fffffffll : (bytes < 0 ? 0 : bytes)));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bu), 0, nrec, 0x00020000);
+}
+
+// The K loop runs with ONE wave per SIMD, so nothing hides what the wave itself does beside its MFMAs: a vector instruction beside
+// the MFMA stream costs matrix-pipe time.  Per MFMA this kernel spends four vector instructions and one LDS read:
+//   * the tap (c, kh, kw) of every k is a table in LDS, built once per workgroup: {element offset (c*H + kh)*W + kw, r = kh*3 + kw}
+//     (r = 9 beyond K); a lane reads the entry of ITS k (k + hi) with one ds_read_b64;
+//   * whether that tap exists for the lane's pixel is bit r of a per-lane mask (padding / beyond the image / no pixel): v_bfe_i32 gives
+//     0 or -1, OR-ed into the offset -- an offset of -4 is out of the buffer's range and reads as 0, no select, no branch;
+//   * the filter comes as the step's eight 16-byte pieces of the lane's row (rows beyond M start out of range and read as 0); lane
+//     (lo, hi) takes element 2j + hi for MFMA j.
+// Loads are never under a lane condition (a branch round a load makes the compiler drain every outstanding load there: the first
+// build of this kernel ran one load at a time) and kDepth - 1 steps are in flight while one multiplies.
 __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float ct_lds[];      // [nsl][nblk][16][64]: slice sums of this workgroup's blocks
+  extern __shared__ __attribute__((aligned(16))) float ct_lds[];      // [nsl][nblk][16][64] slice sums, then the tap table int2[ktab]
   const int t = threadIdx.x, lane = t & 63, lo = lane & 31, hi = lane >> 5, wave = t >> 6;
   const int mblks = (g.M + 31) / 32;
   const int b = (int)blockIdx.x / mblks, mb = (int)blockIdx.x - b * mblks;
-  const float *img = g.img + (int64_t)b * g.bsB;
-  const int m = mb * 32 + lo;
-  const bool m_ok = m < g.M;
-  const float *arow = g.filt + (int64_t)(m_ok ? m : g.M - 1) * g.K;
   const int HW = g.H * g.W;
+  int2 *tab = reinterpret_cast<int2 *>(ct_lds + (size_t)g.nsl * g.nblk * 16 * 64);
+  for (int k = t; k < g.ktab; k += 256) {
+    const int c = k / 9, r = k - c * 9, kh = (r * 11) >> 5, kw = r - 3 * kh;
+    tab[k] = k < g.K ? make_int2(c * HW + kh * g.W + kw, r) : make_int2(0, 9);
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rsA = ct_rsrc(g.filt, (int64_t)g.M * g.K * 4);
+  const __amdgpu_buffer_rsrc_t rsB = ct_rsrc(g.img + (int64_t)b * g.bsB, (int64_t)(g.K / 9) * HW * 4);
+  const int m = mb * 32 + lo;
+  // byte offset of this lane's filter row; rows beyond M: out of range (reads 0)
+  const int arow = m < g.M ? m * g.K * 4 : (int)0x80000000;
   const int ntask = g.nblk * g.nsl;
   // tasks in the order (slice, block): every slice but the last is kc long, so the four waves' first tasks are the long ones and
   // the short last slices fill up behind them
@@ -57,63 +83,59 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
     const int oh = p_ok ? pix / g.oW : 0, ow = p_ok ? pix - oh * g.oW : 0;
     const int ih0 = oh - g.pH, iw0 = ow - g.pW;
     const int org = ih0 * g.W + iw0;                   // the window origin of this lane's pixel, as an element index (may be negative)
-    // this lane's running tap: k = kl, c = kl / 9, r = kl % 9 (advances by 2 per MFMA)
-    int kl = k0 + hi, c = kl / 9, r = kl - c * 9;
-    // Every load is UNCONDITIONAL (an invalid tap / piece reads element 0 of its operand instead and is replaced by zero where it is
-    // consumed): a load under a lane condition becomes a branch round the load, and the compiler then waits for all outstanding loads
-    // at every such branch -- the first build of this kernel ran one load at a time.  The validity bits travel with the ring.
-    auto issue = [&](int ks, ct_f32x4 (&a)[8], float (&x)[kCH], unsigned &vmask) __attribute__((always_inline)) {
-      unsigned vm = 0;
-      // A: the 32 consecutive k of this step as eight 16-byte pieces (a piece beyond the slice's end is zero: kend % 4 == 0)
+    unsigned inv = 1u << 9;                            // bit r: tap r does not exist for this pixel (bit 9: k beyond K)
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int kq = ks + 4 * q;
-        const bool ok = m_ok && kq < kend;
-        a[q] = *reinterpret_cast<const ct_f32x4 *>(arow + (ok ? kq : 0));
-        vm |= ok ? (1u << (16 + q)) : 0u;
-      }
+    for (int r = 0; r < 9; r++) {
+      const int kh = r / 3, kw = r - 3 * kh;
+      const bool in = p_ok && (unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W;
+      inv |= in ? 0u : (1u << r);
+    }
+    auto issue = [&](int ks, ct_f32x4 (&a)[8], float (&x)[kCH]) __attribute__((always_inline)) {
+      const int av = arow + ks * 4;
+#pragma unroll
+      for (int q = 0; q < 8; q++) a[q] = __builtin_bit_cast(ct_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, av + 16 * q, 0, 0));
+      const int2 *tk = tab + ks + hi;
 #pragma unroll
       for (int j = 0; j < kCH; j++) {
-        const int kh = (r * 11) >> 5, kw = r - 3 * kh;
-        const bool in = p_ok && kl < kend && (unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W;
-        x[j] = img[in ? org + c * HW + kh * g.W + kw : 0];
-        vm |= in ? (1u << j) : 0u;
-        kl += 2; r += 2;
-        if (r >= 9) { r -= 9; c++; }
+        const int2 e = tk[2 * j];
+        const int bad = __builtin_amdgcn_sbfe(inv, e.y, 1);            // 0 (the tap exists) or -1
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, ((org + e.x) | bad) << 2, 0, 0));
       }
-      vmask = vm;
     };
     ct_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    auto compute = [&](const ct_f32x4 (&a)[8], const float (&x)[kCH], unsigned vm) __attribute__((always_inline)) {
+    auto compute = [&](const ct_f32x4 (&a)[8], const float (&x)[kCH]) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < kCH; j++) {
-        // the element of the 32-k step this lane feeds MFMA j with: 2j + hi (piece (2j + hi) / 4; both halves' candidates are compile-time)
-        const float araw = hi ? a[(2 * j + 1) >> 2][(2 * j + 1) & 3] : a[(2 * j) >> 2][(2 * j) & 3];
-        const float av = (vm >> (16 + (j >> 1))) & 1u ? araw : 0.0f;
-        const float xv = (vm >> j) & 1u ? x[j] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xv, acc, 0, 0, 0);
+        // element 2j + hi of the step's 32 k (both candidates are compile-time: one v_cndmask).  Both half-waves load the SAME pieces
+        // and every element of a piece is used by one of them: a piece with dead elements is narrowed by the compiler to a
+        // three-dword load whose dead middle register it then reuses at once -- and has to wait for the load (vmcnt(0) in the loop)
+        const float av = hi ? a[(2 * j + 1) >> 2][(2 * j + 1) & 3] : a[(2 * j) >> 2][(2 * j) & 3];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[j], acc, 0, 0, 0);
       }
     };
+    // steps of 32 k; a step that starts at or beyond kend is issued (the ring is unconditional; its loads hit valid table entries and
+    // in-range or zero-reading offsets) but never multiplied: the guard below is wave-uniform and wraps no load
     const int nsteps = (kend - k0 + 2 * kCH - 1) / (2 * kCH);
-    // A ring of kDepth register sets: the loads of steps s + 1 .. s + kDepth - 1 are in flight while step s multiplies.  With ONE
-    // wave per SIMD (the whole point of this launch) nothing else hides the ~2 us a gather takes: two sets left every step waiting
-    // (48 us for C4's tails, profiles/r05/conv_tail_ab_v1.jsonl); the wave has the SIMD's whole register file to itself.
-    // (unconditional issues: a step past the end loads nothing -- every piece / element is masked by kend -- and is never multiplied)
     ct_f32x4 a[kDepth][8];
     float x[kDepth][kCH];
-    unsigned vm[kDepth];
 #pragma unroll
-    for (int d = 0; d < kDepth - 1; d++) issue(k0 + d * 2 * kCH, a[d], x[d], vm[d]);
+    // (the scheduling barriers pin the ISSUE ORDER of the steps: the vector-memory counter retires in order, so a step can be waited
+    // for with the later ones still in flight only if its loads really were issued first -- left alone the compiler sorted the
+    // prologue's loads its own way and the loop waited for vmcnt(0))
+    for (int d = 0; d < kDepth - 1; d++) {
+      issue(k0 + d * 2 * kCH, a[d], x[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += kDepth) {
 #pragma unroll
       for (int d = 0; d < kDepth; d++) {
-        // (no branch on s + d < nsteps: a step past the end is all-invalid -- it loads element 0 and multiplies zeros into the chain,
-        // which leaves every accumulator as it is: x + 0 * 0 = x for every x the chain can hold)
-        issue(k0 + (s + d + kDepth - 1) * 2 * kCH, a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth], vm[(d + kDepth - 1) % kDepth]);
-        compute(a[d], x[d], vm[d]);
+        issue(k0 + (s + d + kDepth - 1) * 2 * kCH, a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + d < nsteps) compute(a[d], x[d]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     float *dst = ct_lds + ((size_t)(p * g.nblk + blk) * 16) * 64 + lane;
@@ -154,16 +176,18 @@ hipError_t launch_conv_tail_f32(const GemmArgs<float> &a, int kc, hipStream_t s)
   const int64_t npix = a.N, ntail = npix - a.col0;
   if (ntail <= 0 || ntail > 128 || a.col0 < 0) return hipErrorNotSupported;
   if (a.csA != 1 || a.rsA != a.K || a.csC != 1 || a.rsC != npix || a.K % 36 != 0 || kc % 32 != 0 || kc < 32) return hipErrorNotSupported;
-  if ((reinterpret_cast<uintptr_t>(a.A) & 15) != 0) return hipErrorNotSupported;      // (16-byte filter loads: K % 4 == 0 keeps every row aligned)
   const int64_t Cin = a.K / 9, nsl = (a.K + kc - 1) / kc, nblk = (ntail + 31) / 32, mblks = (a.M + 31) / 32;
   if ((double)Cin * a.cH * a.cW >= 2.0e9 || (double)a.M * npix >= 2.0e9 || npix >= ((int64_t)1 << 30)) return hipErrorNotSupported;
-  const size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float);
+  // the tap table covers every k a step of the ring can name: the slices + the steps issued past the last one
+  const int64_t ktab = nsl * kc + (int64_t)kDepth * 2 * kCH;
+  const size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float) + (size_t)ktab * sizeof(int2);
   if (lds > ((size_t)64 << 10) || (int64_t)a.batch * mblks > 0x7fffffffLL) return hipErrorNotSupported;
+  if ((double)a.M * a.K * 4.0 >= 2147483648.0 || (double)Cin * a.cH * a.cW * 4.0 >= 2147483648.0) return hipErrorNotSupported;   // 31-bit byte offsets
   ConvTailArgs g;
   g.filt = a.A; g.img = a.B; g.out = a.C;
   g.bsB = a.bsB; g.bsC = a.bsC;
   g.M = (int32_t)a.M; g.K = (int32_t)a.K; g.H = a.cH; g.W = a.cW; g.oW = a.coW; g.npix = (int32_t)npix;
-  g.pH = a.cpH; g.pW = a.cpW; g.n_cut = (int32_t)a.col0; g.nblk = (int32_t)nblk; g.nsl = (int32_t)nsl; g.kc = kc;
+  g.pH = a.cpH; g.pW = a.cpW; g.n_cut = (int32_t)a.col0; g.nblk = (int32_t)nblk; g.nsl = (int32_t)nsl; g.kc = kc; g.ktab = (int32_t)ktab;
   hipLaunchKernelGGL(conv3x3_tail_kernel, dim3((unsigned)(a.batch * mblks)), dim3(256), lds, s, g);
   return hipGetLastError();
 }
