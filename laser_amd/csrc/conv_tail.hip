@@ -90,16 +90,22 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
       const bool in = p_ok && (unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W;
       inv |= in ? 0u : (1u << r);
     }
-    auto issue = [&](int ks, ct_f32x4 (&a)[8], float (&x)[kCH]) __attribute__((always_inline)) {
+    // a step's loads are issued in two phases one step apart: its table entries are READ from LDS while the step before it multiplies
+    // (a wave alone on its SIMD has nothing else to cover an LDS read's ~100 cycles: sixteen reads each waited for where its
+    // address arithmetic starts were a third of the first build's time), the addresses and the loads follow from registers
+    auto tabread = [&](int ks, int2 (&e)[kCH]) __attribute__((always_inline)) {
+      const int2 *tk = tab + ks + hi;
+#pragma unroll
+      for (int j = 0; j < kCH; j++) e[j] = tk[2 * j];
+    };
+    auto issue = [&](int ks, const int2 (&e)[kCH], ct_f32x4 (&a)[8], float (&x)[kCH]) __attribute__((always_inline)) {
       const int av = arow + ks * 4;
 #pragma unroll
       for (int q = 0; q < 8; q++) a[q] = __builtin_bit_cast(ct_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, av + 16 * q, 0, 0));
-      const int2 *tk = tab + ks + hi;
 #pragma unroll
       for (int j = 0; j < kCH; j++) {
-        const int2 e = tk[2 * j];
-        const int bad = __builtin_amdgcn_sbfe(inv, e.y, 1);            // 0 (the tap exists) or -1
-        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, ((org + e.x) | bad) << 2, 0, 0));
+        const int bad = __builtin_amdgcn_sbfe(inv, e[j].y, 1);         // 0 (the tap exists) or -1
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, ((org + e[j].x) | bad) << 2, 0, 0));
       }
     };
     ct_f32x16 acc;
@@ -120,19 +126,26 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
     const int nsteps = (kend - k0 + 2 * kCH - 1) / (2 * kCH);
     ct_f32x4 a[kDepth][8];
     float x[kDepth][kCH];
-#pragma unroll
     // (the scheduling barriers pin the ISSUE ORDER of the steps: the vector-memory counter retires in order, so a step can be waited
     // for with the later ones still in flight only if its loads really were issued first -- left alone the compiler sorted the
     // prologue's loads its own way and the loop waited for vmcnt(0))
+    int2 e[2][kCH];
+    tabread(k0, e[0]);
+#pragma unroll
     for (int d = 0; d < kDepth - 1; d++) {
-      issue(k0 + d * 2 * kCH, a[d], x[d]);
+      tabread(k0 + (d + 1) * 2 * kCH, e[(d + 1) & 1]);
+      issue(k0 + d * 2 * kCH, e[d & 1], a[d], x[d]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    static_assert(kDepth % 2 == 0, "the table-entry sets alternate with the step's parity");
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += kDepth) {
 #pragma unroll
       for (int d = 0; d < kDepth; d++) {
-        issue(k0 + (s + d + kDepth - 1) * 2 * kCH, a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth]);
+        // step n = s + d + kDepth - 1 is issued from the entries read one step ago; the entries of step n + 1 are read now
+        issue(k0 + (s + d + kDepth - 1) * 2 * kCH, e[(d + kDepth - 1) & 1], a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth]);
+        __builtin_amdgcn_sched_barrier(0);
+        tabread(k0 + (s + d + kDepth) * 2 * kCH, e[(d + kDepth) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         if (s + d < nsteps) compute(a[d], x[d]);
         __builtin_amdgcn_sched_barrier(0);
@@ -179,7 +192,7 @@ hipError_t launch_conv_tail_f32(const GemmArgs<float> &a, int kc, hipStream_t s)
   const int64_t Cin = a.K / 9, nsl = (a.K + kc - 1) / kc, nblk = (ntail + 31) / 32, mblks = (a.M + 31) / 32;
   if ((double)Cin * a.cH * a.cW >= 2.0e9 || (double)a.M * npix >= 2.0e9 || npix >= ((int64_t)1 << 30)) return hipErrorNotSupported;
   // the tap table covers every k a step of the ring can name: the slices + the steps issued past the last one
-  const int64_t ktab = nsl * kc + (int64_t)kDepth * 2 * kCH;
+  const int64_t ktab = nsl * kc + (int64_t)(kDepth + 1) * 2 * kCH;
   size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float) + (size_t)ktab * sizeof(int2);
   if (lds > ((size_t)150 << 10) || (int64_t)a.batch * mblks > 0x7fffffffLL) return hipErrorNotSupported;
   // ONE workgroup per CU: the K loop is built for a wave that has its SIMD's matrix pipe to itself (two workgroups on a CU halve each
