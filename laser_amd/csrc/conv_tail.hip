@@ -193,18 +193,8 @@ hipError_t launch_conv_tail_f32(const GemmArgs<float> &a, int kc, hipStream_t s)
   if ((double)Cin * a.cH * a.cW >= 2.0e9 || (double)a.M * npix >= 2.0e9 || npix >= ((int64_t)1 << 30)) return hipErrorNotSupported;
   // the tap table covers every k a step of the ring can name: the slices + the steps issued past the last one
   const int64_t ktab = nsl * kc + (int64_t)(kDepth + 1) * 2 * kCH;
-  size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float) + (size_t)ktab * sizeof(int2);
-  if (lds > ((size_t)150 << 10) || (int64_t)a.batch * mblks > 0x7fffffffLL) return hipErrorNotSupported;
-  // ONE workgroup per CU: the K loop is built for a wave that has its SIMD's matrix pipe to itself (two workgroups on a CU halve each
-  // other's rate while other CUs idle -- the dispatcher does not spread 256 workgroups over 256 CUs by itself).  More than half of
-  // a CU's 160 KiB of LDS per workgroup makes the second one wait for another CU.
-  lds = std::max(lds, (size_t)84 << 10);
-  static PerDeviceOnce once;
-  if (hipError_t e = once.run([] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-      });
-      e != hipSuccess)
-    return e;
+  const size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float) + (size_t)ktab * sizeof(int2);
+  if (lds > ((size_t)64 << 10) || (int64_t)a.batch * mblks > 0x7fffffffLL) return hipErrorNotSupported;      // (longer reductions: the round-3 tail forms)
   if ((double)a.M * a.K * 4.0 >= 2147483648.0 || (double)Cin * a.cH * a.cW * 4.0 >= 2147483648.0) return hipErrorNotSupported;   // 31-bit byte offsets
   ConvTailArgs g;
   g.filt = a.A; g.img = a.B; g.out = a.C;
