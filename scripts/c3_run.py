@@ -15,7 +15,7 @@ Cbuf = torch.zeros((n, 2 * n), device="cuda")
 A, B, C = (Abig[::2], Bt.t(), Cbuf[:, ::2]) if full else (Abig[:n], Bt.t(), Cbuf[:, :n].contiguous())
 for mode in (0, 1):
     laser_amd.set_float_mode(mode)
-    for _ in range(10):
+    for _ in range(60):      # (the clocks ramp up over the first ~50 ms of work after idle: warm-only averages drop these)
         laser_amd.matmul(A, B, 1, 0, C)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for one command: kernel-trace stats, then PMC passes (each in its own run; never combined with
-# sys/hip/hsa tracing).  usage: gpu_profile_cmd.sh <outdir-tag> <command...>      -> gpurun_out/prof_<tag>/summary.md
+# sys/hip/hsa tracing).  usage: [SKIP=k] gpu_profile_cmd.sh <outdir-tag> <command...>      -> gpurun_out/prof_<tag>/summary.md
+# SKIP: dispatches per kernel dropped from the warm-only averages (default 10; the run scripts warm up for 60 launches: SKIP=60)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 TAG=$1; shift
@@ -12,7 +13,7 @@ timeout -k 5 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INS
 timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
 timeout -k 5 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- $CMD > $OUT/pmc_tcc.log 2>&1
-python scripts/summarize_prof.py $OUT > $OUT/summary.md 2>&1
+python scripts/summarize_prof.py $OUT --skip ${SKIP:-10} > $OUT/summary.md 2>&1
 for f in $(find $OUT/stats -name "*_kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
 grep -h '"metric"' $OUT/*.log | head -3 > $OUT/bench_lines_under_profiler.jsonl
 # keep the merged-back payload small: raw per-dispatch CSVs are large
