@@ -47,6 +47,7 @@ for it in range(cases):
     if use_epi: want = oracle.apply_epilogue(want, b.reshape(1, -1, 1, 1), "relu")
     dout = torch.full(oshape, float("nan"), device="cuda")
     laser_amd.set_conv_patch(bool(rng.random() < 0.8)); laser_amd.set_conv_kslice(bool(rng.random() < 0.8))
+    laser_amd.set_option("conv_tail", int(rng.random() < 0.7))      # the direct pixel-tail kernel / the round-3 tail forms
     laser_amd.conv2d_im2col(dout, oshape, torch.from_numpy(x).cuda(), ishape, torch.from_numpy(w).cuda(), kshape, pad, st, None,
                             bias=None if b is None else torch.from_numpy(b).cuda(), activation="relu" if use_epi else None)
     direct += laser_amd.get_option("last_f32_config") == -3
@@ -55,6 +56,24 @@ for it in range(cases):
     if not ok:
         fails += 1
         print("FAIL", dict(it=it, ishape=ishape, kshape=kshape, pad=pad, st=st, epi=use_epi, maxabs=float(np.nanmax(np.abs(got - want)))), flush=True)
-laser_amd.set_conv_patch(True); laser_amd.set_conv_kslice(True)
+    # the explicit im2col of the same geometry (the public im2col*[T] entry: band kernel, float32 / float64, device-resident, batched,
+    # a random band length now and then): pure data movement, bit-exact against the oracle's im2col of every image
+    if it % 3 == 0 and oshape[2] * oshape[3] * C * kH * kW * n < (1 << 24):
+        import ctypes
+        f64 = bool(rng.random() < 0.4)
+        dt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+        xi = np.rint(x * 100).astype(np.float32)          # integer-valued: the float32 oracle pins the float64 path too
+        wsw = np.stack([oracle.im2col(xi[i], kshape, pad, st) for i in range(n)]).astype(dt)
+        d_in = torch.from_numpy(xi.astype(dt)).cuda()
+        d_ws = torch.full(wsw.shape, -7, dtype=tdt, device="cuda")
+        laser_amd.set_option("im2col_band", int(rng.choice([0, 0, 4, 64, 300, 5000])))
+        fn = laser_amd.lib().laser_hip_im2col_f64_dev if f64 else laser_amd.lib().laser_hip_im2col_f32_dev
+        rc = fn(ctypes.c_void_p(d_ws.data_ptr()), oshape[2], oshape[3], ctypes.c_void_p(d_in.data_ptr()), n, C, H, W, kH, kW, pH, pW, sH, sW,
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        laser_amd.set_option("im2col_band", 0)
+        if rc != 0 or not np.array_equal(d_ws.cpu().numpy(), wsw):
+            fails += 1
+            print("FAIL im2col", dict(it=it, ishape=ishape, kshape=kshape, pad=pad, st=st, f64=f64, rc=rc), flush=True)
+laser_amd.set_conv_patch(True); laser_amd.set_conv_kslice(True); laser_amd.set_option("conv_tail", 1)
 print(f"fuzz_conv: {cases} cases, {fails} failures, {direct} on the direct small-channel kernels")
 sys.exit(1 if fails else 0)
