@@ -231,7 +231,11 @@ typedef __attribute__((ext_vector_type(2), aligned(4))) float cs_f32x2u;
 // (Round 5, measured and not kept: two ADJACENT pairs per lane leaving as ONE 16-byte store per channel -- half the store
 // instructions, 1 KiB per wave and channel, three / four waves per SIMD: 25.7 vs 22.2 us on the bench shape, 72.5 vs 66.5 at 64 images,
 // 18.8 vs 17.9 with 16 channels, bit-identical -- profiles/r05/conv_small_quad_store_ab_v1.jsonl.  Wider stores are not what the
-// kernel waits for; the eight-waves-per-SIMD form below stays.)
+// kernel waits for; the eight-waves-per-SIMD form below stays.  Also measured and not kept: every workgroup walking 2 / 4 / 8 chunks
+// (the stores of one chunk draining under the next chunk's arithmetic, the waves drifting out of their common compute-then-store
+// phase): 24.3 / 31.0 / 43.7 us against 21.3 -- the time grows with the chunks per wave: a wave's own dependent path (loads, 540
+// packed FMAs behind scalar filter loads, stores), not the chip's VALU or HBM rate, is what a launch of one round of waves takes;
+// profiles/r05/conv_small_chunk_loop_ab_v1.jsonl.)
 template <int MT, int PPL, int CB, int WPS>
 __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvSmallArgs g) {
   const int t = threadIdx.x;
