@@ -89,7 +89,8 @@ int laser_hip_f32_config_count(void);
  *   "conv_patch"       [1] implicit conv reads B from an LDS-resident input patch when it fits; 0 = per-element gather
  *   "conv_direct"      [1] convolutions with <= 32 output channels and C_in*kH*kW <= 256 (the reference's conv bench shape,
  *                          conv2d_bench.nim:130-170): the direct HBM-streaming kernels; 0 = the implicit-GEMM kernels; 2 = without
- *                          the scalar-filter forms of 3x3 filters (A/B switch: the matrix-core / LDS-filter forms everywhere)
+ *                          the scalar-filter forms of 3x3 filters (A/B switch: the matrix-core / LDS-filter forms everywhere); 3 = the scalar-filter forms
+ *                          without the two-channel-group split of small launches (A/B switch)
  *   "conv_tail"        [1] the pixel tail behind the hand-scheduled 3x3 conv main launch (npix % 128 pixels per image) as ONE launch
  *                          of the latency-built direct kernel (a wave per 32x32 block and kc slice, ordered fold in LDS); 0 = the
  *                          compiler-scheduled tail forms

@@ -1458,7 +1458,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "i64_mfma") g_ctx.i64_mfma = on;
   else if (n == "conv_implicit") g_ctx.conv_implicit = on;
   else if (n == "conv_patch") g_conv_patch = on;
-  else if (n == "conv_direct") g_conv_direct = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (n == "conv_direct") g_conv_direct = value < 0 ? 0 : value > 3 ? 3 : value;
   else if (n == "conv_kslice") g_conv_kslice = on;
   else if (n == "conv_tail") g_conv_tail = on;
   else if (n == "host_pipeline_2d") g_ctx.host_pipeline_2d = on;

@@ -134,7 +134,9 @@ __global__ void __launch_bounds__(256, 4) conv_direct_scalar_kernel(const ConvSm
   static_assert(PPT % 2 == 0, "pixels are held in pairs");
   const int t = threadIdx.x;
   // (the constant address space: wave-uniform loads from it are scalar loads whatever else the kernel does to memory)
-  const cs_const_f32 *filt = (const cs_const_f32 *)g.filt;
+  // grid z = groups of output channels, as in conv_direct_pairs_kernel
+  const int zM = (g.M + (int)gridDim.z - 1) / (int)gridDim.z, m0 = (int)blockIdx.z * zM, Mz = min(zM, g.M - m0);
+  const cs_const_f32 *filt = (const cs_const_f32 *)g.filt + (int64_t)m0 * g.K;
   const float *__restrict__ img = g.img + (int64_t)blockIdx.y * g.bsB;
   int p[PPT], ih0[PPT], iw0[PPT], off[PPT];
 #pragma unroll
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(256, 4) conv_direct_scalar_kernel(const ConvSm
     for (int m = 0; m < MT; m++) acc[j][m] = (cs_f32x2){0.0f, 0.0f};
   int wrow[MT];                                  // wave-uniform: element offset of channel m's filter row
 #pragma unroll
-  for (int m = 0; m < MT; m++) wrow[m] = (m < g.M ? m : g.M - 1) * g.K;
+  for (int m = 0; m < MT; m++) wrow[m] = (m < Mz ? m : Mz - 1) * g.K;
   const int HW = g.H * g.W;
   auto fetch = [&](const float *plane, int kh, int kw, float (&x)[PPT]) __attribute__((always_inline)) {
     const int toff = kh * g.W + kw;
@@ -205,13 +207,13 @@ __global__ void __launch_bounds__(256, 4) conv_direct_scalar_kernel(const ConvSm
       k += 9;
     }
   }
-  float *out = g.out + (int64_t)blockIdx.y * g.bsC;
+  float *out = g.out + (int64_t)blockIdx.y * g.bsC + (int64_t)m0 * g.rsC;
 #pragma unroll
   for (int j = 0; j < PPT; j++) {
     if (p[j] >= g.npix) continue;
 #pragma unroll
     for (int m = 0; m < MT; m++)
-      if (m < g.M) out[(int64_t)m * g.rsC + p[j]] = acc[j / 2][m][j & 1];
+      if (m < Mz) out[(int64_t)m * g.rsC + p[j]] = acc[j / 2][m][j & 1];
   }
 }
 
@@ -239,7 +241,9 @@ typedef __attribute__((ext_vector_type(2), aligned(4))) float cs_f32x2u;
 template <int MT, int PPL, int CB, int WPS>
 __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvSmallArgs g) {
   const int t = threadIdx.x;
-  const cs_const_f32 *filt = (const cs_const_f32 *)g.filt;
+  // grid z = groups of output channels (1 = all of them in one wave; 2 on launches of at most one round of waves: launch_scalar)
+  const int zM = (g.M + (int)gridDim.z - 1) / (int)gridDim.z, m0 = (int)blockIdx.z * zM, Mz = min(zM, g.M - m0);
+  const cs_const_f32 *filt = (const cs_const_f32 *)g.filt + (int64_t)m0 * g.K;
   const char *__restrict__ img = reinterpret_cast<const char *>(g.img + (int64_t)blockIdx.y * g.bsB);
   const int PW = g.oW >> 1, npairs = g.npix >> 1;
   int q[PPL];
@@ -258,7 +262,7 @@ __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvS
     for (int m = 0; m < MT; m++) acc[j][m] = (cs_f32x2){0.0f, 0.0f};
   int wrow[MT];
 #pragma unroll
-  for (int m = 0; m < MT; m++) wrow[m] = (m < g.M ? m : g.M - 1) * g.K;
+  for (int m = 0; m < MT; m++) wrow[m] = (m < Mz ? m : Mz - 1) * g.K;
   const int64_t plane_bytes = (int64_t)g.H * g.W * 4, row_bytes = (int64_t)g.W * 4;
   for (int c0 = 0; c0 < g.Cin; c0 += CB) {
     // the raw 16-byte rows: elements 0,1 / 2,3 are the kw = 0 / 2 pairs as they lie, (1,2) is put together at its use (built
@@ -312,13 +316,13 @@ __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvS
       }
     }
   }
-  float *out = g.out + (int64_t)blockIdx.y * g.bsC;
+  float *out = g.out + (int64_t)blockIdx.y * g.bsC + (int64_t)m0 * g.rsC;
 #pragma unroll
   for (int j = 0; j < PPL; j++) {
     if (q[j] >= npairs) continue;
 #pragma unroll
     for (int m = 0; m < MT; m++)
-      if (m < g.M) *reinterpret_cast<cs_f32x2u *>(out + (int64_t)m * g.rsC + 2 * q[j]) = acc[j][m];
+      if (m < Mz) *reinterpret_cast<cs_f32x2u *>(out + (int64_t)m * g.rsC + 2 * q[j]) = acc[j][m];
   }
 }
 
@@ -453,17 +457,17 @@ hipError_t launch_small(const ConvSmallArgs &g, int batch, hipStream_t s) {
 }
 
 template <int MT>
-hipError_t launch_scalar_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
-  const dim3 grid((unsigned)((g.npix + 511) / 512), (unsigned)batch);
+hipError_t launch_scalar_mt(const ConvSmallArgs &g, int batch, hipStream_t s, int zgroups = 1) {
+  const dim3 grid((unsigned)((g.npix + 511) / 512), (unsigned)batch, (unsigned)zgroups);
   if (g.pH == 0 && g.pW == 0) hipLaunchKernelGGL((conv_direct_scalar_kernel<MT, 2, false>), grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL((conv_direct_scalar_kernel<MT, 2, true>), grid, dim3(256), 0, s, g);
   return hipGetLastError();
 }
 
 template <int MT, int WPS>
-hipError_t launch_pairs_mt(const ConvSmallArgs &g, int batch, hipStream_t s) {
+hipError_t launch_pairs_mt(const ConvSmallArgs &g, int batch, hipStream_t s, int zgroups = 1) {
   const int npairs = g.npix / 2;
-  const dim3 grid((unsigned)((npairs + 255) / 256), (unsigned)batch);
+  const dim3 grid((unsigned)((npairs + 255) / 256), (unsigned)batch, (unsigned)zgroups);
   hipLaunchKernelGGL((conv_direct_pairs_kernel<MT, 1, 1, WPS>), grid, dim3(256), 0, s, g);
   return hipGetLastError();
 }
@@ -473,6 +477,20 @@ hipError_t launch_scalar(const ConvSmallArgs &g, int batch, hipStream_t s) {
   // unit column stride, no padding, an even output width: pixel pairs (one pair per lane: 61 registers at 20 channels, eight
   // waves per SIMD -- 22.7 us on the reference's bench shape against 24.3 with two pairs per lane at four waves)
   if (g.pH == 0 && g.pW == 0 && g.sW == 1 && g.oW % 2 == 0 && (int64_t)g.H * g.W < ((int64_t)1 << 29)) {
+    // Round 5: when the whole launch is at most ONE round of resident waves (8 per SIMD), the output channels go in two groups over
+    // grid z -- a wave's own dependent path (27 packed FMAs and a store per channel behind scalar filter loads) is what such a launch
+    // takes, so half the channels per wave and twice the waves: 22.1 -> 20.3 us on the reference's bench shape, 18.0 -> 16.6 with 16
+    // channels; three groups, or two groups on launches of several rounds (64 images: 65.4 vs 64.8 us), gain nothing
+    // (profiles/r05/conv_small_channel_groups_ab_v1.jsonl).  The input is read once more, from L2.
+    const int64_t waves = (int64_t)((g.npix / 2 + 255) / 256) * batch * 4;
+    if (g.M >= 12 && waves <= 256 * 4 * 8 && g_conv_direct != 3) {      // (option conv_direct = 3: never split -- the A/B switch)
+      const int zM = (g.M + 1) / 2;
+      switch ((zM + 3) / 4) {
+        case 1: return launch_pairs_mt<4, 8>(g, batch, s, 2);
+        case 2: return launch_pairs_mt<8, 8>(g, batch, s, 2);
+        default: return launch_pairs_mt<12, 8>(g, batch, s, 2);
+      }
+    }
     switch ((g.M + 3) / 4) {
       case 1: return launch_pairs_mt<4, 8>(g, batch, s);
       case 2: return launch_pairs_mt<8, 8>(g, batch, s);
@@ -480,6 +498,17 @@ hipError_t launch_scalar(const ConvSmallArgs &g, int batch, hipStream_t s) {
       case 4: return launch_pairs_mt<16, 8>(g, batch, s);
       case 5: return launch_pairs_mt<20, 8>(g, batch, s);
       default: return launch_pairs_mt<24, 6>(g, batch, s);
+    }
+  }
+  {      // the same two-group split for launches of at most one round of waves (four waves per SIMD here)
+    const int64_t waves = (int64_t)((g.npix + 511) / 512) * batch * 4;
+    if (g.M >= 12 && waves <= 256 * 4 * 4 && g_conv_direct != 3) {
+      const int zM = (g.M + 1) / 2;
+      switch ((zM + 3) / 4) {
+        case 1: return launch_scalar_mt<4>(g, batch, s, 2);
+        case 2: return launch_scalar_mt<8>(g, batch, s, 2);
+        default: return launch_scalar_mt<12>(g, batch, s, 2);
+      }
     }
   }
   switch ((g.M + 3) / 4) {

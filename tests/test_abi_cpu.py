@@ -130,9 +130,9 @@ def test_scalar_filter_conv_kernels_keep_their_scalars_and_their_occupancy():
     assert len(pairs) == 6 and len(scalar) == 12, (sorted(pairs), sorted(scalar))
     for n, k in list(pairs.items()) + list(scalar.items()):
         # (the padded forms keep eighteen per-tap bounds masks beside the filter values: a handful of scalars may go through a lane of
-        # a vector register there -- a dozen, not the hundreds of the hoisted build)
+        # a vector register there -- one or two dozen (round 5: the channel-group offsets are three more scalars), not the hundreds of the hoisted build)
         padded = "Lb1E" in n
-        assert k.get(".sgpr_spill_count", 0) <= (16 if padded else 0) and k.get(".vgpr_spill_count", 0) == 0, (n, k.get(".sgpr_spill_count"))
+        assert k.get(".sgpr_spill_count", 0) <= (24 if padded else 0) and k.get(".vgpr_spill_count", 0) == 0, (n, k.get(".sgpr_spill_count"))
     for n, k in pairs.items():
         mt = int(n.split("conv_direct_pairs_kernelILi")[1].split("E")[0])
         assert k[".vgpr_count"] <= (64 if mt <= 20 else 80), (n, k[".vgpr_count"])
