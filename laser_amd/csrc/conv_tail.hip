@@ -192,7 +192,8 @@ hipError_t launch_conv_tail_f32(const GemmArgs<float> &a, int kc, hipStream_t s)
   const int64_t Cin = a.K / 9, nsl = (a.K + kc - 1) / kc, nblk = (ntail + 31) / 32, mblks = (a.M + 31) / 32;
   if ((double)Cin * a.cH * a.cW >= 2.0e9 || (double)a.M * npix >= 2.0e9 || npix >= ((int64_t)1 << 30)) return hipErrorNotSupported;
   // the tap table covers every k a step of the ring can name: the slices + the steps issued past the last one
-  const int64_t ktab = nsl * kc + (int64_t)(kDepth + 1) * 2 * kCH;
+  // (the ring issues up to kDepth - 1 + kDepth steps beyond a slice's last one, each naming 2 * kCH entries: covered for every slice length)
+  const int64_t ktab = nsl * kc + (int64_t)(2 * kDepth + 1) * 2 * kCH;
   const size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float) + (size_t)ktab * sizeof(int2);
   if (lds > ((size_t)64 << 10) || (int64_t)a.batch * mblks > 0x7fffffffLL) return hipErrorNotSupported;      // (longer reductions: the round-3 tail forms)
   if ((double)a.M * a.K * 4.0 >= 2147483648.0 || (double)Cin * a.cH * a.cW * 4.0 >= 2147483648.0) return hipErrorNotSupported;   // 31-bit byte offsets
