@@ -1126,6 +1126,9 @@ int resolve_handle(const void *packed, bool want_a, int elem, int64_t M, int64_t
     return fail(LASER_HIP_E_HANDLE, "pre-packed buffer is for another operand / element type");
   if (want_a ? (h.M != M || h.K != K) : (h.N != N || h.K != K))
     return fail(LASER_HIP_E_HANDLE, "pre-packed buffer was made for a different shape");
+  // (the header is caller memory: the image size it states must be the one this shape has before it sizes an allocation and a copy)
+  const int64_t want_bytes = std::max<int64_t>((int64_t)elem * rup(want_a ? M : N, kPadMN) * rup(K, kPadK), 64);
+  if ((int64_t)h.image_bytes != want_bytes) return fail(LASER_HIP_E_HANDLE, "pre-packed buffer header is corrupt (image size)");
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t key = panel_key(h.id, dev);
