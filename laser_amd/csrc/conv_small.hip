@@ -237,7 +237,11 @@ typedef __attribute__((ext_vector_type(2), aligned(4))) float cs_f32x2u;
 // (the stores of one chunk draining under the next chunk's arithmetic, the waves drifting out of their common compute-then-store
 // phase): 24.3 / 31.0 / 43.7 us against 21.3 -- the time grows with the chunks per wave: a wave's own dependent path (loads, 540
 // packed FMAs behind scalar filter loads, stores), not the chip's VALU or HBM rate, is what a launch of one round of waves takes;
-// profiles/r05/conv_small_chunk_loop_ab_v1.jsonl.)
+// profiles/r05/conv_small_chunk_loop_ab_v1.jsonl.  And the same loop as a proper software pipeline -- loads(chunk i + 1) issued BEFORE
+// the FMAs and stores of chunk i, so that the in-order vector-memory counter lets the stores drain under the next chunk's arithmetic;
+// everything unconditional, stores through a bounds-checked buffer; ~110-135 registers, three waves per SIMD: 25.7 us (all channels
+// per wave) / 23.2 (two channel groups) against 20.9 -- eight small waves per SIMD hide more than a hand-made pipeline in three;
+// profiles/r05/conv_small_pipeline_ab_v1.jsonl.)
 template <int MT, int PPL, int CB, int WPS>
 __global__ void __launch_bounds__(256, WPS) conv_direct_pairs_kernel(const ConvSmallArgs g) {
   const int t = threadIdx.x;
