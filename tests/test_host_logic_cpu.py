@@ -172,3 +172,23 @@ def test_bench_kernel_names_match_the_launcher_table():
     mk = open(os.path.join(root, "laser_amd", "csrc", "Makefile")).read()
     for sym in symbols:
         assert re.search(r"\b" + sym + r"\b", mk), sym
+
+
+def test_committed_traffic_figure_matches_the_shipped_kernels():
+    """`roofline.traffic` of bench.py is a COMMITTED measurement (profiles/pmc_traffic.json), quoted only while the guard recorded with it
+    -- the sha of the two headline kernels' generated assembly text + the launch plans they were measured under -- matches the tree.
+    This test fails when the headline kernels changed without the counters being collected again (scripts/gpu_profile_bench.sh), which
+    is when the bench line would silently go back to `traffic: null`."""
+    import json
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert set(d["plans"]) == {"laser_order", "fast"}
+    assert d["kernel_source_sha16"] == bench.kernel_source_sha16(d["plans"])
+    for mode in ("laser_order", "fast"):
+        assert d[mode]["bytes_per_launch"] == int(round((2 * d[mode]["fetch_size_kib"] + d[mode]["write_size_kib"]) * 1024))
+        assert bench.pmc_traffic(mode, d["plans"][mode]) == d[mode]
+        assert bench.pmc_traffic(mode, dict(d["plans"][mode], wgs=1)) is None      # another launch plan: the figure is not quoted
