@@ -424,6 +424,9 @@ proc shardPlan*(M, ndev: int, panelsPerDev = 4): ShardPlan =
   check laser_hip_shard_plan(M, cint(ndev), cint(panelsPerDev), result.rowsPerPanel.addr, ppd.addr, result.paddedM.addr)
   result.panelsPerDev = int(ppd)
 
+# (The device-resident sharded call has no stream parameter: it works on the library's own streams, so every operand must be COMPLETE in
+# memory when it is made -- a caller that fills its device tensors asynchronously synchronises that stream first.  flags = 1
+# (LASER_HIP_SHARD_PIN_TILE): the hand-scheduled 128x128x16 assembly tile for the local float32 products, beside RCCL's kernels.)
 proc gemm_strided_sharded*[T: float32 or float64 or int32 or int64](
       devices: openarray[cint],                 ## HIP ordinals, one per device slot
       M, N, K: int, alpha: T,
