@@ -81,3 +81,68 @@ def test_panel_plan_covers_rows_once():
                 assert (seen[:M] == 1).all() and (seen[M:] == 0).all(), (M, world, ppr)
     p = make_plan(65536, 8, 4)
     assert p.rows == 2048 and p.padded_M == 65536
+
+
+def _pin_worker(rank, world, port, ret):
+    """ShardedGemm's default local product with the library mocked (no GPU here): the assembly tile pin (option "asm_tile" = 2) must be
+    in force around every local product of a multi-rank run, the caller's own value must come back afterwards -- also when a product
+    raises -- and a forced compiler configuration must be bracketed the same way."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import laser_amd.primitives as prim
+        from laser_amd import distributed as D
+        state = {"asm_tile": 7, "cfg": -1}        # 7: a value of the caller's own that must survive
+        seen = []
+        prim.get_option = lambda name: state[name]
+        prim.set_option = lambda name, v: state.__setitem__(name, int(v))
+        prim.get_f32_config = lambda: state["cfg"]
+        prim.set_f32_config = lambda v: state.__setitem__("cfg", int(v))
+        fail_after = {"n": None}
+
+        def fake_matmul(A, B, alpha, beta, out):
+            seen.append((state["asm_tile"], state["cfg"]))
+            if fail_after["n"] is not None and len(seen) > fail_after["n"]:
+                raise RuntimeError("injected")
+            out.copy_(A @ B)
+        prim.matmul = fake_matmul
+        M, N, K = 64, 16, 8
+        g = torch.Generator().manual_seed(5)
+        A, B = torch.rand((M, K), generator=g), torch.rand((K, N), generator=g)
+        sg = D.ShardedGemm(M, N, K, torch.float32, None, None, 2)
+        C = sg.alloc_C()
+        out = sg.run(sg.shard_A(A), B, C)
+        ok = torch.allclose(out, A @ B) and all(s_ == (D.SHARDED_ASM_TILE, -1) for s_ in seen) and len(seen) == 2
+        ok = ok and state == {"asm_tile": 7, "cfg": -1}
+        # a forced compiler configuration (tuning sweeps): bracketed, the tile option untouched
+        seen.clear()
+        sg2 = D.ShardedGemm(M, N, K, torch.float32, None, None, 2, tile_config=3)
+        sg2.run(sg2.shard_A(A), B, sg2.alloc_C())
+        ok = ok and all(s_ == (7, 3) for s_ in seen) and state == {"asm_tile": 7, "cfg": -1}
+        # the library heuristic asked for explicitly: nothing is set
+        seen.clear()
+        sg3 = D.ShardedGemm(M, N, K, torch.float32, None, None, 2, tile_config=-1)
+        sg3.run(sg3.shard_A(A), B, sg3.alloc_C())
+        ok = ok and all(s_ == (7, -1) for s_ in seen) and state == {"asm_tile": 7, "cfg": -1}
+        # a product that raises (on every rank, before any collective of that step): the pin is undone
+        seen.clear()
+        fail_after["n"] = 0
+        try:
+            sg.run(sg.shard_A(A), B, sg.alloc_C())
+            ok = False
+        except RuntimeError:
+            ok = ok and state == {"asm_tile": 7, "cfg": -1}
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gemm_tile_pin_is_bracketed_world2_gloo():
+    world = 2
+    port = 33500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pin_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
