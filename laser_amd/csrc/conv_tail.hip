@@ -35,6 +35,7 @@ struct ConvTailArgs {
 
 constexpr int kCH = 16;          // MFMAs per step = 32 k
 constexpr int kDepth = 4;        // register sets of the load ring
+constexpr int kAStep = 32 * 33;  // floats of one staged filter step in LDS
 
 // a wave-uniform pointer as a bounds-checked raw buffer (what lies beyond `bytes` reads as 0)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ct_rsrc(const void *p, int64_t bytes) {
@@ -51,8 +52,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ct_rsrc(const void *p, int64_t
 //     (r = 9 beyond K); a lane reads the entry of ITS k (k + hi) with one ds_read_b64;
 //   * whether that tap exists for the lane's pixel is bit r of a per-lane mask (padding / beyond the image / no pixel): v_bfe_i32 gives
 //     0 or -1, OR-ed into the offset -- an offset of -4 is out of the buffer's range and reads as 0, no select, no branch;
-//   * the filter comes as the step's eight 16-byte pieces of the lane's row (rows beyond M start out of range and read as 0); lane
-//     (lo, hi) takes element 2j + hi for MFMA j.
+//   * the filter block of a step is fetched coalesced and passes through a per-wave LDS buffer into the MFMA lane layout (below);
 // Loads are never under a lane condition (a branch round a load makes the compiler drain every outstanding load there: the first
 // build of this kernel ran one load at a time) and kDepth - 1 steps are in flight while one multiplies.
 __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g) {
@@ -62,6 +62,10 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
   const int b = (int)blockIdx.x / mblks, mb = (int)blockIdx.x - b * mblks;
   const int HW = g.H * g.W;
   int2 *tab = reinterpret_cast<int2 *>(ct_lds + (size_t)g.nsl * g.nblk * 16 * 64);
+  // this wave's filter-step buffer [32 k][33]: element (k, row) at k * 33 + row (the pitch puts the 32 rows of one k, and the k of
+  // one row, into different banks).  ONE buffer: a step's fragments are read back into registers right behind their stores, and a
+  // wave's LDS operations execute in order, so the next step's stores cannot overtake those reads
+  float *abuf = ct_lds + (size_t)g.nsl * g.nblk * 16 * 64 + (size_t)g.ktab * 2 + (size_t)wave * kAStep;
   for (int k = t; k < g.ktab; k += 256) {
     const int c = k / 9, r = k - c * 9, kh = (r * 11) >> 5, kw = r - 3 * kh;
     tab[k] = k < g.K ? make_int2(c * HW + kh * g.W + kw, r) : make_int2(0, 9);
@@ -69,9 +73,19 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
   __syncthreads();
   const __amdgpu_buffer_rsrc_t rsA = ct_rsrc(g.filt, (int64_t)g.M * g.K * 4);
   const __amdgpu_buffer_rsrc_t rsB = ct_rsrc(g.img + (int64_t)b * g.bsB, (int64_t)(g.K / 9) * HW * 4);
-  const int m = mb * 32 + lo;
-  // byte offset of this lane's filter row; rows beyond M: out of range (reads 0)
-  const int arow = m < g.M ? m * g.K * 4 : (int)0x80000000;
+  // The filter block of a step -- 32 rows x 32 k -- is fetched COALESCED (eight lanes per row: 128 contiguous bytes, 8 rows per
+  // instruction, four instructions) and passes through this wave's LDS buffer into the MFMA lane layout.  Loading the fragments
+  // straight from global memory (a lane per row: 32 cache lines per instruction, eight instructions a step) was what the first builds
+  // spent their time on: the kernel's time followed the cache-line look-ups per step, not the MFMAs or the VALU
+  // (profiles/r05/conv_tail_study_v1.md).  Rows beyond M and k beyond K start out of the buffer's range (read as 0).
+  int arow[4], awr[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (lane >> 3) + 8 * i, kq = (lane & 7) * 4, mrow = mb * 32 + row;
+    arow[i] = mrow < g.M ? (mrow * g.K + kq) * 4 : (int)0x80000000;
+    awr[i] = kq * 33 + row;                    // LDS float index of element (kq, row); (kq + e, row) is e * 33 further
+  }
+  const int ard = hi * 33 + lo;                // LDS float index of element (hi, lo); MFMA j reads (2j + hi, lo) = ard + 66 j
   const int ntask = g.nblk * g.nsl;
   // tasks in the order (slice, block): every slice but the last is kc long, so the four waves' first tasks are the long ones and
   // the short last slices fill up behind them
@@ -98,10 +112,11 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
 #pragma unroll
       for (int j = 0; j < kCH; j++) e[j] = tk[2 * j];
     };
-    auto issue = [&](int ks, const int2 (&e)[kCH], ct_f32x4 (&a)[8], float (&x)[kCH]) __attribute__((always_inline)) {
-      const int av = arow + ks * 4;
+    auto issue = [&](int ks, const int2 (&e)[kCH], ct_f32x4 (&a)[4], float (&x)[kCH]) __attribute__((always_inline)) {
+      const bool kin = ks + (lane & 7) * 4 < kend;                     // (kend % 4 == 0: a 16-byte piece is inside the slice or beyond it)
 #pragma unroll
-      for (int q = 0; q < 8; q++) a[q] = __builtin_bit_cast(ct_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, av + 16 * q, 0, 0));
+      for (int i = 0; i < 4; i++)
+        a[i] = __builtin_bit_cast(ct_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kin ? arow[i] + ks * 4 : (int)0x80000000, 0, 0));
 #pragma unroll
       for (int j = 0; j < kCH; j++) {
         const int bad = __builtin_amdgcn_sbfe(inv, e[j].y, 1);         // 0 (the tap exists) or -1
@@ -111,21 +126,27 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
     ct_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    auto compute = [&](const ct_f32x4 (&a)[8], const float (&x)[kCH]) __attribute__((always_inline)) {
+    // stage: the step's four pieces -> this wave's LDS buffer (k-major), then its sixteen fragment elements back into registers.
+    // Only this wave touches the buffer and a wave's LDS operations execute in order: no barrier.
+    auto stage = [&](const ct_f32x4 (&a)[4], float (&af)[kCH]) __attribute__((always_inline)) {
+      float *ab = abuf;
 #pragma unroll
-      for (int j = 0; j < kCH; j++) {
-        // element 2j + hi of the step's 32 k (both candidates are compile-time: one v_cndmask).  Both half-waves load the SAME pieces
-        // and every element of a piece is used by one of them: a piece with dead elements is narrowed by the compiler to a
-        // three-dword load whose dead middle register it then reuses at once -- and has to wait for the load (vmcnt(0) in the loop)
-        const float av = hi ? a[(2 * j + 1) >> 2][(2 * j + 1) & 3] : a[(2 * j) >> 2][(2 * j) & 3];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[j], acc, 0, 0, 0);
-      }
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int el = 0; el < 4; el++) ab[awr[i] + 33 * el] = a[i][el];
+#pragma unroll
+      for (int j = 0; j < kCH; j++) af[j] = ab[ard + 66 * j];
+    };
+    auto compute = [&](const float (&af)[kCH], const float (&x)[kCH]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < kCH; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], x[j], acc, 0, 0, 0);
     };
     // steps of 32 k; a step that starts at or beyond kend is issued (the ring is unconditional; its loads hit valid table entries and
     // in-range or zero-reading offsets) but never multiplied: the guard below is wave-uniform and wraps no load
     const int nsteps = (kend - k0 + 2 * kCH - 1) / (2 * kCH);
-    ct_f32x4 a[kDepth][8];
+    ct_f32x4 a[kDepth][4];
     float x[kDepth][kCH];
+    float af[2][kCH];
     // (the scheduling barriers pin the ISSUE ORDER of the steps: the vector-memory counter retires in order, so a step can be waited
     // for with the later ones still in flight only if its loads really were issued first -- left alone the compiler sorted the
     // prologue's loads its own way and the loop waited for vmcnt(0))
@@ -137,17 +158,23 @@ __global__ void __launch_bounds__(256) conv3x3_tail_kernel(const ConvTailArgs g)
       issue(k0 + d * 2 * kCH, e[d & 1], a[d], x[d]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(kDepth % 2 == 0, "the table-entry sets alternate with the step's parity");
+    stage(a[0], af[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    static_assert(kDepth % 2 == 0, "the table-entry sets and the fragment sets alternate with the step's parity");
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += kDepth) {
 #pragma unroll
       for (int d = 0; d < kDepth; d++) {
-        // step n = s + d + kDepth - 1 is issued from the entries read one step ago; the entries of step n + 1 are read now
+        // step n = s + d multiplies; step n + kDepth - 1 is issued from the table entries read one step ago, the entries of step
+        // n + kDepth are read, and the filter block of step n + 1 (loaded kDepth - 2 steps ago) passes through LDS into the fragment
+        // registers the next step multiplies from
         issue(k0 + (s + d + kDepth - 1) * 2 * kCH, e[(d + kDepth - 1) & 1], a[(d + kDepth - 1) % kDepth], x[(d + kDepth - 1) % kDepth]);
         __builtin_amdgcn_sched_barrier(0);
         tabread(k0 + (s + d + kDepth) * 2 * kCH, e[(d + kDepth) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + d < nsteps) compute(a[d], x[d]);
+        stage(a[(d + 1) % kDepth], af[(d + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + d < nsteps) compute(af[d & 1], x[d]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -194,7 +221,7 @@ hipError_t launch_conv_tail_f32(const GemmArgs<float> &a, int kc, hipStream_t s)
   // the tap table covers every k a step of the ring can name: the slices + the steps issued past the last one
   // (the ring issues up to kDepth - 1 + kDepth steps beyond a slice's last one, each naming 2 * kCH entries: covered for every slice length)
   const int64_t ktab = nsl * kc + (int64_t)(2 * kDepth + 1) * 2 * kCH;
-  const size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float) + (size_t)ktab * sizeof(int2);
+  const size_t lds = (size_t)nsl * nblk * 16 * 64 * sizeof(float) + (size_t)ktab * sizeof(int2) + (size_t)4 * kAStep * sizeof(float);
   if (lds > ((size_t)64 << 10) || (int64_t)a.batch * mblks > 0x7fffffffLL) return hipErrorNotSupported;      // (longer reductions: the round-3 tail forms)
   if ((double)a.M * a.K * 4.0 >= 2147483648.0 || (double)Cin * a.cH * a.cW * 4.0 >= 2147483648.0) return hipErrorNotSupported;   // 31-bit byte offsets
   ConvTailArgs g;
