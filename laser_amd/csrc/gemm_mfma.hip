@@ -178,6 +178,7 @@ static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 std::atomic<int> g_conv_patch{1}; // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
 std::atomic<int> g_conv_kslice{1}; // laser-order conv: tail launch as parallel kc slices + ordered combine (0: one workgroup per tail tile)
 std::atomic<int> g_last_conv_tail{0};   // diagnostics: how the last convolution's pixel tail ran (0 none, 1 direct kernel, 2 kc slices + combine, 3 one compiler-kernel launch)
+std::atomic<int> g_conv_cut_always{0};   // option "conv_cut_always" (tests, probes): cut a 3x3 convolution at its last whole 128-pixel tile whatever the model says
 std::atomic<int> g_conv_tail{1};   // option "conv_tail": the direct tail kernel behind the assembly main launch (conv_tail.hip); 0 = the round-3 forms
 std::atomic<int> g_last_f32_cfg{-1}; // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)
 
@@ -308,6 +309,11 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     plan = plan_split(a, exact, false, true, false);
   else
     plan.cfg_main = cfg;
+  if (g_conv_cut_always && cfg < 0 && plan.n_cut == 0 && a.N > 128 && a.N % 128 != 0 && a.ckH == 3 && a.ckW == 3) {
+    plan.n_cut = a.N / 128 * 128;           // (the tail forms on shapes the model would leave in one launch)
+    plan.cfg_main = kCfgWide;
+    plan.cfg_tail = kCfgSmall;
+  }
   plan.cfg_main = fix(plan.cfg_main);
   g_last_split = plan.n_cut;
   // the main part (whole 128-pixel tiles, or the whole image) on the hand-scheduled assembly kernel when it is a 3x3 /

@@ -620,7 +620,13 @@ def test_conv_pixel_tail_direct_kernel_bit_exact(la, oracle):
              ((3, 64, 30, 30), (100, 64, 3, 3), (1, 1)),        # 900 pixels: tail 4 (one block, 4 valid pixels), M = 100, 2 slices
              ((2, 148, 24, 22), (70, 148, 3, 3), (0, 0)),       # 22 x 20 = 440: tail 56; K = 1332: 3 slices, the last 308 long
              ((4, 8, 34, 34), (96, 8, 3, 3), (2, 2)),           # K = 72 <= kc: one slice; 36 x 36 = 1296: tail 16
-             ((2, 60, 28, 30), (130, 60, 3, 3), (1, 1))]        # 840: tail 72 (3 blocks); K = 540: slices 512 + 28
+             ((2, 60, 28, 30), (130, 60, 3, 3), (1, 1)),        # 840: tail 72 (3 blocks); K = 540: slices 512 + 28
+             # C_in a multiple of 32 (every slice whole 32-k steps): the loop without vector address arithmetic -- nine offset registers
+             # per lane, the channel pair in the scalar offset (C4 and the third case above are of this class too)
+             ((4, 32, 30, 30), (64, 32, 3, 3), (1, 1)),         # K = 288 <= kc: one slice of 9 steps (two rounds + 1); tail 4
+             ((3, 96, 26, 26), (50, 96, 3, 3), (0, 0)),         # 24 x 24 = 576: tail 64; K = 864: 512 + 352 (11 steps: two rounds + 3)
+             ((2, 160, 20, 22), (40, 160, 3, 3), (2, 2)),       # 22 x 24 = 528: tail 16; K = 1440: 512 + 512 + 416 (13 steps)
+             ((5, 64, 58, 58), (33, 64, 3, 3), (1, 1))]         # 3364 pixels: tail 36 (the pixel blocks break across image rows); M = 33
     forms = set()
     for ishape, kshape, pad in cases:
         x = rng.uniform(0, 1, ishape).astype(np.float32)
@@ -630,6 +636,7 @@ def test_conv_pixel_tail_direct_kernel_bit_exact(la, oracle):
         dx, dw = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
         try:
             la.set_f32_asm(2)                 # the assembly main launch whatever the tile count
+            la.set_option("conv_cut_always", 1)      # ... and the cut at the last whole 128-pixel tile whatever the launch model says
             outs = {}
             for tail in (1, 0):
                 la.set_option("conv_tail", tail)
@@ -651,6 +658,7 @@ def test_conv_pixel_tail_direct_kernel_bit_exact(la, oracle):
             la.set_float_mode(0)
             la.set_f32_asm(1)
             la.set_option("conv_tail", 1)
+            la.set_option("conv_cut_always", 0)
     assert 1 in forms, "no case exercised the direct tail kernel"
 
 
