@@ -72,7 +72,7 @@ class Cfg:
         self.trace = trace
         self.b_kcontig = b_kcontig
         self.b_store = b_store      # "write2": ds_write2_b32 straight from the two pieces; "swap64": 4 v_swap + 4 ds_write_b64
-        self.ablate = set(ablate)   # timing experiments only (results are wrong): "loads", "stores", "reads", "barrier"
+        self.ablate = set(ablate)   # timing experiments only (results are wrong): "loads", "stores", "reads", "barrier", "cstores" (the epilogue's stores of C)
         self.r_step = r_step
         self.filler, self.filler_every = filler, filler_every   # pricing experiments: one extra instruction of this kind per gap
         self.debug = debug          # dump intermediate state of workgroup 0 to the kernarg's debug buffer (asm_debug.py)
@@ -1895,7 +1895,8 @@ class Gen:
                         e("v_mul_f32", tt, self.s_alpha, tt)
                         e("v_accvgpr_read_b32", uu, self.run[b][r])
                         e("v_add_f32", tt, uu, tt)
-                        e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
+                        if "cstores" not in c.ablate:
+                            e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
                     self.c_step(i, q, rr)
             for i in range(c.TM):
                 for q in range(4):
@@ -1914,7 +1915,8 @@ class Gen:
                             tt = t[(2 * n) % 8]
                             e("v_accvgpr_read_b32", tt, self.acc[i * c.TN + n][r])
                             e("v_mul_f32", tt, self.s_alpha, tt)
-                            e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
+                            if "cstores" not in c.ablate:
+                                e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
                         self.c_step(i, q, rr)
             e("s_branch", done)
             p.place(withc)
