@@ -58,6 +58,13 @@ const char *laser_hip_version(void);
 #define LASER_HIP_ABI_VERSION 2
 int laser_hip_abi_version(void);
 int laser_hip_device_count(void);
+/* Diagnostics (touches no device): the kernel and launch plan the float32 launcher takes for a dense row-major M x N x K product on a
+ * device of `cus` compute units -- the launch plans scale with the device's own CU count, so a partitioned MI355X (CPX 32 / QPX 64 /
+ * DPX 128 CUs) keeps the hand-scheduled kernels.  out8[0] = 1 + kernel index (0: compiler-scheduled kernels), [1] = plan (0 one tile
+ * per workgroup, 1 persistent with K-slice cuts, 2 strided whole tiles with pipelined transitions), [2] = workgroups, [3] = K slices
+ * per tile, [4] = tiles, [5] / [6] = tile rows / columns, [7] = workgroup slots.  The GPU twin of reading gemm_tiling.nim:276-341's
+ * `newTiles` for a shape: what partition will the library use. */
+int laser_hip_plan_f32(int64_t M, int64_t N, int64_t K, int laser_order, int cus, int64_t *out8);
 /* Name of the GPU architecture in use, e.g. "gfx950" (replaces the reference's cpuinfo ISA
  * dispatch, gemm.nim:228-247). */
 const char *laser_hip_arch(void);

@@ -42,6 +42,7 @@ def lib():
     if L.laser_hip_abi_version() != ABI_VERSION:
         raise RuntimeError(f"liblaser_hip.so has ABI {L.laser_hip_abi_version()}, this mirror was written against {ABI_VERSION} (rebuild: make -C laser_amd/csrc)")
     L.laser_hip_arch.restype = C.c_char_p
+    L.laser_hip_plan_f32.argtypes = [i64, i64, i64, ci, ci, C.POINTER(i64)]
     L.laser_hip_set_float_mode.argtypes = [ci]
     L.laser_hip_set_f32_config.argtypes = [ci]
     L.laser_hip_set_option.argtypes = [C.c_char_p, ci]
@@ -127,7 +128,7 @@ def ctype_of(sfx):
 # Every symbol include/laser_hip.h declares (tests check the .so exports each of them).
 def declared_symbols():
     names = ["laser_hip_init", "laser_hip_finalize", "laser_hip_last_error", "laser_hip_version", "laser_hip_abi_version",
-             "laser_hip_device_count", "laser_hip_arch", "laser_hip_set_float_mode",
+             "laser_hip_device_count", "laser_hip_plan_f32", "laser_hip_arch", "laser_hip_set_float_mode",
              "laser_hip_get_float_mode", "laser_hip_set_f32_config", "laser_hip_f32_config_count",
              "laser_hip_f32_config_name", "laser_hip_set_option", "laser_hip_get_option", "laser_hip_gemm_prepack_release",
              "laser_hip_conv2d_out_shape", "laser_hip_im2col_workspace_size", "laser_hip_im2col_f32",

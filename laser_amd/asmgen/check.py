@@ -42,11 +42,16 @@ def plan_units(tiles, Kd, G, exact, kc, BK, split=True):
     return P, slen, U // G, U % G
 
 
-def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, noseed=0, ws=0, flags=0, group_m=None, xcd=False, two_level=False):
+def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, noseed=0, ws=0, flags=0, group_m=None, xcd=False, two_level=False, strided=False):
     """the scheduler block of the kernel arguments (f32_kernel.py KA_SCHED); group_m None = one group: tile rows fastest;
-    two_level: XCD x owns whole tiles, its G / 8 workgroups share them (launches that cut tiles)"""
+    two_level: XCD x owns whole tiles, its G / 8 workgroups share them (launches that cut tiles); strided: workgroup v walks the whole
+    tiles v, v + G, v + 2G ..."""
     gm = group_m or tm
     gsz_last = tm % gm or gm
+    if strided:
+        assert P == 1 or slen >= 1
+        return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), (G // 8) if xcd else 0,
+                           (G % 8) if xcd else 0, P, K.magic_u32(P), G, tm * tn, slen, noseed | 4, K.magic_u32(G), ws, flags)
     if q is None:
         q, r = tm * tn * P // G, tm * tn * P % G
     if two_level:
@@ -77,7 +82,8 @@ def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
 
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
-             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False, csc=1, pre=0, interleaved=False):
+             batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False, csc=1, pre=0, interleaved=False,
+             strided=False):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart.
     G: workgroups of the (persistent) launch, default one per tile; split: cut tiles along K at slice boundaries (laser-order: kc;
     one chain: `split` K-tiles per slice) so that the G workgroups get equal numbers of units"""
@@ -125,7 +131,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         As.append(Af[:, :Kd].copy()); Bs.append(Bm); C0s.append(C0)
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     G = G or tm * tn
-    P, slen, uq, ur = plan_units(tm * tn, Kd, G, c.exact, 512, c.BK, split)
+    P, slen, uq, ur = plan_units(tm * tn, Kd, min(G, tm * tn) if strided else G, c.exact, 512, c.BK, split)
     mem = Memory()
     a_, b_, c_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call)
     ws_ = mem.alloc(np.full(G * g.tile_bytes() // 4, np.nan, dtype=np.float32))
@@ -142,7 +148,7 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
     ka += struct.pack("<Q", LA * 4) + b"\0" * 28 + struct.pack("<I", pre) + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, csc if csc != 1 else 0)
-    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level)
+    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level, strided)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()

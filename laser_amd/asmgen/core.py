@@ -113,7 +113,19 @@ class Prog:
 
     def salloc(self, n=1, align=None, name=None):
         al = align or (1 if n == 1 else (2 if n == 2 else 4))
-        self._s = (self._s + al - 1) // al * al
+        # the gaps that aligned tuples leave behind are handed out first (the large kernels use every SGPR there is)
+        holes = self.__dict__.setdefault("_sholes", [])
+        for h in sorted(holes):
+            if h % al == 0 and all(h + k in holes for k in range(n)):
+                for k in range(n):
+                    holes.remove(h + k)
+                r = Reg("s", h, n)
+                if name:
+                    self.names[name] = r
+                return r
+        start = (self._s + al - 1) // al * al
+        holes.extend(range(self._s, start))
+        self._s = start
         r = Reg("s", self._s, n)
         self._s += n
         assert self._s <= 100, "out of SGPRs"

@@ -21,7 +21,7 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
                  b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32",
-                 persistent=None, pre=False, deep=False):
+                 persistent=None, pre=False, deep=False, pipe=None):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
         # deep (generator option, no shipped kernel uses it): TWO sets of staging registers -- a K-tile is requested two tile bodies before
         # it is stored to LDS instead of one; six tile bodies instead of three (LDS stage x register set).  Built for the small tile,
@@ -41,6 +41,14 @@ class Cfg:
         # the launcher cuts tiles along K at slice boundaries -- head slices stored to a workspace / tail runs that fold them in
         # order.  The convolution kernels (out of SGPRs, never split) run exactly one tile per workgroup.
         self.persistent = (not conv and not debug) if persistent is None else persistent
+        # pipe (round 6): tile transitions of a persistent workgroup are software-pipelined.  When the run that follows a whole tile is
+        # another whole tile, the K loop never stops: the last two tile bodies of tile T already fetch the first two K-tiles of tile
+        # T + 1 (today they fetch zeros past K), and the first body of tile T + 1 is a TRANSITION body -- a fold tile whose fold also
+        # finishes tile T: per block, the chain set is read out, the block's first MFMA restarts the chain from +0 for the new tile,
+        # and C = run + alpha * slice leaves for memory from the gap behind that MFMA (the running-sum set is zeroed on the way).  No
+        # drain, no prologue, no first-load latency, no burst of C stores between two tiles of a workgroup.
+        self.pipe = (self.persistent and dtype == "f32" and not conv and not pre and not deep and not debug) if pipe is None else pipe
+        assert not (self.pipe and (not self.persistent or deep or debug or pre))
         f64 = dtype == "f64"
         # f32: v_mfma_f32_32x32x2 (32x32 blocks, 2 k per instruction, one 16-byte fragment read feeds 4 k-steps);
         # f64: v_mfma_f64_16x16x4 (16x16 blocks, 4 k per instruction, one 16-byte read feeds 2 k-steps): 8 k per group either way
@@ -230,13 +238,18 @@ class Gen:
         self.s_tm = S(2)            # lanes whose 16-byte piece of a k-contiguous operand is real data in the LAST K-tile
         self.s_ktail = S()
         self.s_em = [S(2) for _ in range(4)]   # K % 4 != 0: lanes whose element j of their piece is real data in the last K-tile
-        if not c.conv:
-            self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
         if c.conv:     # (the convolution kernels are out of SGPRs: the tap state is dead by the epilogue)
             self.srdBias, self.s_epi = self.s_scr.sub(0, 4), self.s_scr.sub(4, 4)
         else:
             self.srdBias = S(4)                                      # fused epilogue: the bias view (base, -, bytes, flags)
             self.s_epi = S(4, align=4)                               # rowStrideBias, colStrideBias (elements), activation, -
+            # batch strides in bytes (grid y = batch index): read and consumed in once(), long before the fused epilogue loads its fields
+            self.s_bsA, self.s_bsBC = self.srdBias.sub(0, 2), self.s_epi
+        if c.pipe:
+            # pipelined tile transitions: bit 0 = this launch may pipeline (beta == 0, plain epilogue, K a multiple of BK, >= 3 K-tiles),
+            # bit 1 = armed: the descriptors already point at the NEXT tile and (vC, srdCd) address the tile being finished
+            self.s_pipe = S()
+            self.srdCd = S(4)        # C from this wave's first row of the tile being finished: rows move on by the stores' scalar offset
         self.vVA = [V() for _ in range(c.NPA)]
         self.vVB = [V() for _ in range(c.NPB)] if not c.conv else []
         self.vC = [V() for _ in range(c.TN)]
@@ -402,12 +415,14 @@ class Gen:
         """[u0, u1) of this workgroup -> (t0, p0), (t1, pe)"""
         c, p = self.c, self.p
         e, st, sc = p.emit, self.s_t, self.s_sc
-        L_two, L_have = p.label("twolevel"), p.label("haverange")
+        L_two, L_have, L_str, L_end = p.label("twolevel"), p.label("haverange"), p.label("strided"), p.label("schedinit")
         e("s_load_dword", st[5], s(0, 2), KA_SCHED + 28)
         e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
         e("s_waitcnt", lgkmcnt=0)
         P, mg_P = sc[1], sc[2]
         u0, u1 = st[2], st[3]
+        e("s_bitcmp1_b32", sc[6], 2)
+        e("s_cbranch_scc1", L_str)
         e("s_bitcmp1_b32", sc[6], 1)
         e("s_cbranch_scc1", L_two)
         # one level: virtual id (XCD remap) -> equal shares of all units
@@ -453,6 +468,27 @@ class Gen:
         e("s_add_u32", self.s_tcur, self.s_t0, st[0])      # first whole tile
         e("s_cmp_eq_u32", u0, u1)
         e("s_cselect_b32", self.s_phase, 4, 0)             # (an empty range -- more workgroups than an XCD has units -- has nothing to do)
+        e("s_branch", L_end)
+        # strided whole tiles (flags bit 2; +44 = the stride = workgroups, +48 = tiles): workgroup v walks tiles v, v + G, v + 2G ... --
+        # at any moment the chip works on G consecutive tiles of the raster, an XCD on one contiguous chunk of them, exactly like the
+        # rounds of a one-tile-per-workgroup launch (contiguous ranges would put every workgroup of an XCD on panels of its own) --
+        # and a workgroup goes from one tile to the next without leaving its K loop (Cfg.pipe)
+        p.place(L_str)
+        self.xcd_remap(self.s_vid, s(2), st[5], sc[0], st[0])
+        e("s_mov_b32", self.s_t0, self.s_vid)
+        e("s_mov_b32", self.s_tcur, self.s_vid)
+        e("s_mov_b32", self.s_p0, 0)
+        e("s_mov_b32", self.s_pe, 0)
+        e("s_mov_b32", self.s_t1, sc[4])
+        e("s_cmp_ge_u32", self.s_vid, sc[4])
+        e("s_cselect_b32", self.s_phase, 4, 0)
+        p.place(L_end)
+
+    def tile_step(self, dst):
+        """dst = distance between two whole tiles of this workgroup: 1, or the stride of a strided launch (s_sc holds KA_SCHED2)"""
+        e, sc = self.p.emit, self.s_sc
+        e("s_bitcmp1_b32", sc[6], 2)
+        e("s_cselect_b32", dst, sc[3], 1)
 
     def sched_next(self, L_exit, L_recv):
         """the next run of this workgroup (falls through with s_tile, s_kb, s_Keff, s_mode, s_end set; L_exit when there is none).
@@ -500,7 +536,8 @@ class Gen:
         e("s_branch", L_ph2)
         p.place(L_more)
         e("s_mov_b32", self.s_tile, self.s_tcur)
-        e("s_add_u32", self.s_tcur, self.s_tcur, 1)
+        self.tile_step(st[1])
+        e("s_add_u32", self.s_tcur, self.s_tcur, st[1])
         e("s_mov_b32", self.s_kb, 0)
         e("s_mov_b32", ke, self.s_K)
         e("s_mov_b32", self.s_mode, MODE_NORMAL)
@@ -623,6 +660,8 @@ class Gen:
                 e("s_add_u32", ptr[0], ptr[0], st[2])
                 e("s_addc_u32", ptr[1], ptr[1], st[3])
         e("s_waitcnt", lgkmcnt=0)
+        if c.pipe:
+            self.pipe_eligible()
         if c.pre:
             e("s_load_dword", st[2], s(0, 2), KA_PRE)
             e("s_waitcnt", lgkmcnt=0)
@@ -754,6 +793,25 @@ class Gen:
                     e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
                     e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
 
+    def pipe_eligible(self):
+        """s_pipe bit 0: tile transitions of this launch may be pipelined -- beta == 0 (the running sum of the next tile starts at 0:
+        nothing to fetch), no bias / activation (the plain store), K a multiple of BK (no K-tail masks to undo between tiles) and at
+        least three K-tiles (the switch happens two tile bodies before the end of a tile)"""
+        c, e, st = self.c, self.p.emit, self.s_t
+        e("s_load_dwordx2", self.srdBias.sub(0, 2), s(0, 2), KA_BIAS)
+        e("s_load_dword", st[2], s(0, 2), KA_EPI + 8)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_or_b32", st[3], self.srdBias[0], self.srdBias[1])
+        e("s_or_b32", st[3], st[3], st[2])
+        e("s_and_b32", st[4], self.s_beta, 0x7fffffff)
+        e("s_or_b32", st[3], st[3], st[4])
+        e("s_and_b32", st[4], self.s_K, c.BK - 1)
+        e("s_or_b32", st[3], st[3], st[4])
+        e("s_cmp_eq_u32", st[3], 0)
+        e("s_cselect_b32", self.s_pipe, 1, 0)
+        e("s_cmp_lt_u32", self.s_K, 3 * c.BK)
+        e("s_cselect_b32", self.s_pipe, 0, self.s_pipe)
+
     def kcontig_goff(self, Voff, NP, ld_bytes):
         """global offsets of the 16-byte pieces of a k-contiguous operand: V_i = (x + i*XS) * ld * 4 + kq * 16 (per run: the K tail
         of a run overwrites them with the out-of-bounds offset)"""
@@ -768,32 +826,14 @@ class Gen:
         for i in range(1, NP):
             e("v_add_u32", Voff[i], st[4], Voff[i - 1])
 
-    def run_setup(self):
-        """one run = k in [kb, kb + Keff) of tile (m0, n0): K-tail masks, piece offsets, descriptors, the first two K-tiles"""
+    def ab_descriptors(self):
+        """srdA / srdB of the run k in [kb, kb + Keff) of tile (m0, n0).  Clobbers s_t[0], [2], [3], [5]."""
         c, p = self.c, self.p
         e = p.emit
-        t = self.vt
         st = self.s_t
         Keff = self.s_Keff
-        # K tail: pieces of the last K-tile that lie beyond K get an offset the bounds check rejects (they read as 0, like
-        # Laser's zero-padded panels, gemm_packing.nim:46-55)
-        nkq = c.BK // 4
-        e("s_and_b32", self.s_ktail, Keff, c.BK - 1)
-        e("v_and_b32", t[5], nkq - 1, v(0))
-        e("v_lshlrev_b32", t[5], 2, t[5])
-        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
-        # K % 4 != 0: the piece that straddles K is loaded whole (its tail belongs to the next row, or reads 0 past the panel) and
-        # its elements beyond K are zeroed in the staging registers before they are stored (mask_last_pieces)
-        for j in range(4):
-            e("v_add_u32", t[6], j, t[5])
-            e("v_cmp_gt_u32", self.s_em[j], self.s_ktail, t[6])
         e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
-        self.kcontig_goff(self.vVA, c.NPA, st[3])
         e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
-        if c.b_kcontig:
-            self.kcontig_goff(self.vVB, c.NPB, st[5])
-        e("s_nop", 4)
-        # ---- descriptors ----
         A_, B_, C_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2), self.ka0.sub(4, 2)
         # A panel: base = A + m0 * lda * 4 + kb * 4; bytes = (min(M - m0, BM) - 1) * lda * 4 + Keff * 4
         e("s_mul_hi_u32", st[2], self.s_m0, st[3])
@@ -859,6 +899,33 @@ class Gen:
             e("s_lshl_b32", st[2], st[2], 2)
             e("s_add_u32", self.srdB[2], st[0], st[2])
         e("s_mov_b32", self.srdB[3], 0x00020000)
+
+    def run_setup(self):
+        """one run = k in [kb, kb + Keff) of tile (m0, n0): K-tail masks, piece offsets, descriptors, the first two K-tiles"""
+        c, p = self.c, self.p
+        e = p.emit
+        t = self.vt
+        st = self.s_t
+        Keff = self.s_Keff
+        # K tail: pieces of the last K-tile that lie beyond K get an offset the bounds check rejects (they read as 0, like
+        # Laser's zero-padded panels, gemm_packing.nim:46-55)
+        nkq = c.BK // 4
+        e("s_and_b32", self.s_ktail, Keff, c.BK - 1)
+        e("v_and_b32", t[5], nkq - 1, v(0))
+        e("v_lshlrev_b32", t[5], 2, t[5])
+        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
+        # K % 4 != 0: the piece that straddles K is loaded whole (its tail belongs to the next row, or reads 0 past the panel) and
+        # its elements beyond K are zeroed in the staging registers before they are stored (mask_last_pieces)
+        for j in range(4):
+            e("v_add_u32", t[6], j, t[5])
+            e("v_cmp_gt_u32", self.s_em[j], self.s_ktail, t[6])
+        e("s_lshl_b32", st[3], self.s_lda, 2, comment="lda * 4 bytes")
+        self.kcontig_goff(self.vVA, c.NPA, st[3])
+        e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
+        if c.b_kcontig:
+            self.kcontig_goff(self.vVB, c.NPB, st[5])
+        e("s_nop", 4)
+        self.ab_descriptors()
         # C: the whole matrix (conv: this image's [M][oH*oW] block), bytes = (M - 1) * ldc * 4 + N * 4
         self.c_descriptor()
         # number of K-tiles
@@ -1484,10 +1551,128 @@ class Gen:
             e("v_add_f32", tt, tt, T[r])
             e("v_accvgpr_write_b32", self.run[b][r], tt)
 
+    def trans_after(self, b):
+        """transition body (Cfg.pipe), block b: vT holds alpha-less slice sum of the tile being FINISHED (fold_before), the MFMA in front of
+        this gap has restarted the chain for the new tile.  Laser-order: C = run + alpha * slice -- the last fold and the epilogue's
+        sum are the same operation (gemm.nim:150-158, gemm_ukernel_generic.nim:68-76) -- stored straight from the temporaries, and
+        the running sum is zeroed for the new tile (beta == 0 in pipelined launches).  One chain: C = alpha * sum.  The rows of a
+        block advance through the store's SCALAR offset, which gfx950 includes in the range check of a raw buffer (probe:
+        scripts/probes/buffer_soffset.hip -- voffset + soffset + 4 <= num_records): rows beyond M fall off the end of srdCd, columns
+        beyond N carry an out-of-range vC -- dropped exactly as in the epilogue.  No vector address arithmetic."""
+        c, p, e, T, st = self.c, self.p, self.p.emit, self.vT[0], self.s_t
+        i, n = b // c.TN, b % c.TN
+        lmul, lback = p.label("tmul"), p.label("tback")
+        e("s_cmp_lg_u32", self.s_alpha, 0x3f800000)
+        e("s_cbranch_scc1", lmul)
+        p.place(lback)
+        self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(16)], lback))
+        soff = st[0]
+        if i:
+            e("s_mul_i32", soff, self.s_ldc4, 32 * i)
+        else:
+            e("s_mov_b32", soff, 0)
+        for r in range(16):
+            rr = r & 3
+            if c.exact:
+                tt = self.vt[r % 4]
+                e("v_accvgpr_read_b32", tt, self.run[b][r])
+                e("v_add_f32", tt, tt, T[r])
+                e("v_accvgpr_write_b32", self.run[b][r], 0)
+            else:
+                tt = T[r]
+            if "cstores" not in c.ablate:
+                e("buffer_store_dword", tt, self.vC[n], self.srdCd, soff, offen=True)
+                self.vm_issue(("S", b, r))
+            if r < 15:
+                e("s_add_u32", soff, soff, self.s_ldc4 if rr < 3 else self.s_ldc20)
+
+    def pipe_c_addr(self):
+        """(vC, srdCd) for the deferred stores of the tile (m0, n0): srdCd starts at this wave's first row, vC[n] = the lane's
+        offset from there ((4 * hi) rows down, block column n; out of bounds beyond N)"""
+        c, e, t, st = self.c, self.p.emit, self.vt, self.s_t
+        lane, lo, hi = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, v(0))
+        e("v_and_b32", lo, 31, lane)
+        e("v_lshrrev_b32", hi, 5, lane)
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("s_mul_hi_u32", st[2], st[0], self.s_ldc4)
+        e("s_mul_i32", st[3], st[0], self.s_ldc4)
+        e("s_add_u32", self.srdCd[0], self.srdC[0], st[3])
+        e("s_addc_u32", self.srdCd[1], self.srdC[1], st[2])
+        e("s_and_b32", self.srdCd[1], self.srdCd[1], 0xffff)
+        e("s_mov_b32", self.srdCd[3], 0x00020000)
+        e("s_sub_u32", self.srdCd[2], self.srdC[2], st[3])              # what is left of C from there (0: the wave's rows lie beyond M)
+        e("s_cselect_b32", self.srdCd[2], 0, self.srdCd[2])
+        e("s_cmp_lg_u32", st[2], 0)
+        e("s_cselect_b32", self.srdCd[2], 0, self.srdCd[2])
+        e("v_lshlrev_b32", t[3], 2, hi)
+        e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], lo)
+        e("v_mul_lo_u32", t[6], t[4], self.s_csC4)
+        e("v_add_u32", t[3], t[3], t[6])
+        e("s_lshl_b32", st[5], self.s_csC4, 5)
+        for n in range(c.TN):
+            e("v_add_u32", t[5], 32 * n, t[4])
+            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
+            if n == 0:
+                e("v_mov_b32", t[6], t[3])
+            else:
+                e("v_add_u32", t[6], st[5], t[6])
+            e("v_mov_b32", t[7], 0x80000000)
+            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+
+    def pipe_switch(self, stubs, rets):
+        """out of line, reached from the tail of the tile body after which TWO K-tiles of the tile are left (every load of the tile has
+        been requested): if the next run of this workgroup is another whole tile of a launch that may pipeline, the C addresses of the
+        tile being finished are put aside, the scheduler moves on and srdA / srdB are pointed at the next tile -- the two tile bodies
+        that follow fetch ITS first two K-tiles where they would have fetched zeros past K.  stubs[site] set the return site."""
+        c, p = self.c, self.p
+        e, st, sc = p.emit, self.s_t, self.s_sc
+        L_sw, L_out = p.label("switch"), p.label("swout")
+        for site, lab in stubs.items():
+            p.place(lab)
+            e("s_or_b32", self.s_pipe, self.s_pipe, site << 4)
+            e("s_branch", L_sw)
+        p.place(L_sw)
+        e("s_bitcmp1_b32", self.s_pipe, 0)
+        e("s_cbranch_scc0", L_out)
+        e("s_cmp_eq_u32", self.s_phase, 1)                  # (the head slices of phase 0 run with s_phase == 1 too: END_SEND tells)
+        e("s_cbranch_scc0", L_out)
+        e("s_cmp_eq_u32", self.s_end, END_EPI)
+        e("s_cbranch_scc0", L_out)
+        e("s_cmp_lt_u32", self.s_tcur, self.s_t1)
+        e("s_cbranch_scc0", L_out)
+        self.pipe_c_addr()
+        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
+        e("s_waitcnt", lgkmcnt=0)
+        self.tile_step(st[1])
+        e("s_mov_b32", self.s_tile, self.s_tcur)
+        e("s_add_u32", self.s_tcur, self.s_tcur, st[1])
+        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED)
+        e("s_waitcnt", lgkmcnt=0)
+        self.tile_coords(self.s_tile, sc, st[0], st[1], (st[2], st[3], st[5]))
+        e("s_mul_i32", self.s_m0, st[0], c.BM)
+        e("s_mul_i32", self.s_n0, st[1], c.BN)
+        self.ab_descriptors()
+        e("s_or_b32", self.s_pipe, self.s_pipe, 2)
+        p.place(L_out)
+        e("s_lshr_b32", st[0], self.s_pipe, 4)
+        e("s_and_b32", self.s_pipe, self.s_pipe, 15)
+        sites = sorted(rets)
+        for site in sites[:-1]:
+            e("s_cmp_eq_u32", st[0], site)
+            e("s_cbranch_scc1", rets[site])
+        e("s_branch", rets[sites[-1]])
+
     # ------------------------------------------------------------------ one K-tile
-    def tile_body(self, fold, stage=None, regset=0):
+    def tile_body(self, fold, stage=None, regset=0, trans=False):
+        """one K-tile.  fold: the first tile of a kc slice (the slice fold rides in its first gaps).  trans (Cfg.pipe): the first K-tile
+        of a tile whose predecessor in this workgroup has not been stored yet: a fold tile whose fold finishes the OLD tile -- every
+        block's C values leave for memory from the gap behind the MFMA that restarts its chain (trans_after)."""
         c, p = self.c, self.p
         e = p.emit
+        assert fold or not trans
         self.stA, self.stB = self.st_sets[regset]      # the set this body drains into LDS and refills
         gaps = {m: [] for m in range(-1, c.NMF)}   # gap m: ops issued right after MFMA m (gap -1: before MFMA 0)
 
@@ -1617,6 +1802,11 @@ class Gen:
                 else:
                     raise ValueError(f)
         # ---- emit ----
+        if trans:
+            # the new tile's second K-tile (requested a body ago) has landed by now: with the queue empty, the C stores below are
+            # older than every load this body issues -- the counted waits of the bodies that follow stay exact
+            e("s_waitcnt", vmcnt=0)
+            self.vmq.clear()
         # the first group's fragments were requested during the previous tile
         self.lg_wait({("R", 0)})
         for op in gaps[-1]:
@@ -1631,7 +1821,10 @@ class Gen:
                 srcc = 0
             self.emit_mfma(b, slot, i, n, u, srcc)
             if first:
-                self.fold_after(b)
+                if trans:
+                    self.trans_after(b)
+                else:
+                    self.fold_after(b)
             for op in gaps[m]:
                 self.run_op(op)
         assert len(order) == c.NMF
@@ -1659,11 +1852,21 @@ class Gen:
             def rset(j):
                 return ((j + 1) & 1) if c.deep else 0
 
-            def tail(k, fall_through):
+            L_fin = [p.label(f"fin_s{k}") for k in range(NBODY)] if c.pipe else None
+            TR = [p.label(f"trans_s{k}") for k in range(NBODY)] if c.pipe else None
+            sw_stub, sw_ret = {}, {}
+
+            def tail(k, fall_through, site=None):
                 nk = (k + 1) % NBODY
                 e("s_sub_u32", self.s_rem, self.s_rem, 1)
                 e("s_cmp_eq_u32", self.s_rem, 0)
-                e("s_cbranch_scc1", L_done)
+                e("s_cbranch_scc1", L_fin[nk] if c.pipe else L_done)
+                if c.pipe:
+                    # two K-tiles left: every load of this tile is on its way -- the next tile's can follow (pipe_switch)
+                    sw_stub[site], sw_ret[site] = p.label(f"swstub{site}"), p.label(f"swret{site}")
+                    e("s_cmp_eq_u32", self.s_rem, 2)
+                    e("s_cbranch_scc1", sw_stub[site])
+                    p.place(sw_ret[site])
                 self.tail_mask_if(self.s_rem, ahead + 1)    # the next body loads the last K-tile
                 self.stA, self.stB = self.st_sets[rset(nk)]
                 self.mask_last_pieces_if(self.s_rem, 2)   # the next body stores it (K % 4 != 0: zero what lies beyond K)
@@ -1679,7 +1882,7 @@ class Gen:
                 p.place(N[k])
                 self.tile_body(False, stage=k % 3, regset=rset(k))
                 assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs"
-                tail(k, fall_through=(k < NBODY - 1))
+                tail(k, fall_through=(k < NBODY - 1), site=k)
             if c.exact:
                 assert c.KC_TILES > 1
                 for k in range(NBODY):
@@ -1687,7 +1890,28 @@ class Gen:
                     e("s_mov_b32", self.s_cnt, c.KC_TILES)
                     self.tile_body(True, stage=k % 3, regset=rset(k))
                     assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs (fold tile)"
-                    tail(k, fall_through=False)
+                    tail(k, fall_through=False, site=NBODY + k)
+            if c.pipe:
+                # the tile is done.  Armed (pipe_switch pointed the last two bodies' loads at the next tile): straight on into that
+                # tile's transition body -- LDS stage k holds its first K-tile, the staging registers wait for its second
+                for k in range(NBODY):
+                    L_go = p.label(f"go_s{k}")
+                    p.place(L_fin[k])
+                    e("s_bitcmp1_b32", self.s_pipe, 1)
+                    e("s_cbranch_scc0", L_done)
+                    e("s_andn2_b32", self.s_pipe, self.s_pipe, 2)
+                    e("s_add_u32", self.s_rem, self.s_K, c.BK - 1)
+                    e("s_lshr_b32", self.s_rem, self.s_rem, (c.BK).bit_length() - 1)
+                    e("s_branch", TR[k])
+                for k in range(NBODY):
+                    p.place(TR[k])
+                    if c.exact:
+                        e("s_mov_b32", self.s_cnt, c.KC_TILES)
+                    self.tile_body(True, stage=k % 3, regset=rset(k), trans=True)
+                    assert ([t_ for t_ in self.vmq if t_[0] != "S"], self.lgq) == state0, "loop-carried queue state differs (transition tile)"
+                    self.vmq = list(state0[0])      # (the C stores are older than every load in flight: the next bodies' counted waits cover them)
+                    tail(k, fall_through=False, site=2 * NBODY + k)
+                self.outlined_blocks.append((p.label("swblock"), lambda: self.pipe_switch(sw_stub, sw_ret)))
             p.place(L_done)
             return
 

@@ -5,6 +5,8 @@
 // path that benchmarks and multi-GPU code use.  No CPU compute fallback exists anywhere in this
 // library: without a usable gfx950 device every compute entry point returns LASER_HIP_E_NODEVICE.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -969,6 +971,7 @@ struct PackHandle {  // the first 64 bytes of the caller's (64-B aligned) host b
   int64_t M, N, K;
   int32_t is_a, elem;
   uint64_t image_bytes;
+  uint64_t sum;        // fingerprint of the image (samples + length): a device copy is only ever used for the image it was made from
 };
 static_assert(sizeof(PackHandle) <= 64, "handle must fit the alignment unit");
 constexpr size_t kPackHeader = 64;
@@ -978,12 +981,62 @@ struct DevPanel {
   int device = 0;
   int pins = 0;            // calls multiplying from it right now: never evicted
   uint64_t last_use = 0;
+  uint64_t id = 0, sum = 0;   // of the header it was made for (release drops by id; a hit is checked against both)
 };
-std::unordered_map<uint64_t, DevPanel> g_panels;      // key = id << 8 | device ordinal
+std::unordered_map<uint64_t, DevPanel> g_panels;      // key = mix(id, fingerprint, shape) with the device ordinal in the low byte
 size_t g_panel_bytes = 0;
 uint64_t g_panel_clock = 0;
 constexpr size_t kPanelCacheMax = (size_t)16 << 30;
-inline uint64_t panel_key(uint64_t id, int dev) { return id << 8 | (uint64_t)(dev & 0xff); }
+inline uint64_t mix64(uint64_t x) {      // splitmix64 finaliser
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+// Ids are unique ACROSS processes, not a counter from 1: a buffer packed in one process and handed to another -- or to
+// a forked child -- must not meet a cached panel that the other process made under the same number.  A per-process random salt
+// (re-drawn in a forked child) goes through a 64-bit mixer with the counter; the cache key also carries the header's shape and
+// the image fingerprint, so even an id collision cannot pair a header with another image's device copy.
+uint64_t g_id_salt = 0;
+uint64_t g_next_id = 1;
+void draw_id_salt() {
+  uint64_t s = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)getpid() << 32) ^ (uint64_t)(uintptr_t)&g_id_salt;
+  if (FILE *f = fopen("/dev/urandom", "rb")) {
+    uint64_t r = 0;
+    if (fread(&r, sizeof r, 1, f) == 1) s ^= r;
+    fclose(f);
+  }
+  g_id_salt = mix64(s);
+}
+uint64_t fresh_id_locked() {
+  static bool once = [] {
+    draw_id_salt();
+    (void)pthread_atfork(nullptr, nullptr, [] { draw_id_salt(); });
+    return true;
+  }();
+  (void)once;
+  return mix64(g_id_salt ^ mix64(g_next_id++));
+}
+// fingerprint of a panel image in host memory: its length and 256 samples of 8 bytes spread over it (cheap beside the copies a
+// pre-pack makes; it guards the cache against headers that name the same id for different images, not against an adversary)
+uint64_t image_fingerprint(const void *img, size_t bytes) {
+  uint64_t h = mix64(bytes);
+  const size_t words = bytes / 8;
+  if (!words) return h;
+  const size_t step = std::max<size_t>(1, words / 256);
+  for (size_t i = 0; i < words; i += step) {
+    uint64_t w;
+    memcpy(&w, (const char *)img + 8 * i, 8);
+    h = mix64(h ^ w);
+  }
+  uint64_t w;
+  memcpy(&w, (const char *)img + 8 * (words - 1), 8);
+  return mix64(h ^ w);
+}
+inline uint64_t panel_key(const PackHandle &h, int dev) {
+  uint64_t k = mix64(h.id ^ mix64(h.sum ^ mix64((uint64_t)h.M * 0x100000001b3ull ^ (uint64_t)h.N * 0x1000193ull ^ (uint64_t)h.K ^ ((uint64_t)h.is_a << 40) ^ ((uint64_t)h.elem << 48))));
+  return (k << 8) | (uint64_t)(dev & 0xff);
+}
 // (g_mu held) make room for `need` more bytes: least recently used unpinned panels go first
 void panel_cache_evict_locked(size_t need) {
   while (g_panel_bytes + need > kPanelCacheMax) {
@@ -1003,7 +1056,7 @@ void panel_cache_evict_locked(size_t need) {
 // (g_mu held) every device's copy of panel `id`, unless a call is multiplying from one
 void panel_cache_drop_locked(uint64_t id) {
   for (auto it = g_panels.begin(); it != g_panels.end();) {
-    if ((it->first >> 8) == id && it->second.pins == 0) {
+    if (it->second.id == id && it->second.pins == 0) {
       int cur = 0;
       (void)hipGetDevice(&cur);
       if (it->second.device != cur) (void)hipSetDevice(it->second.device);
@@ -1015,6 +1068,37 @@ void panel_cache_drop_locked(uint64_t id) {
       ++it;
     }
   }
+}
+
+// (g_mu held) a panel allocation that gives cached panels back before it gives up: out of memory -> every unpinned panel of this
+// device is evicted (least recently used first, all of them if need be) and the allocation is retried once (a caller who
+// frees buffers without `release` may leave the bounded cache holding most of a GPU's memory)
+int panel_alloc_locked(void **ptr, size_t bytes, int dev) {
+  hipError_t e = hipMalloc(ptr, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    bool freed = false;
+    for (auto it = g_panels.begin(); it != g_panels.end();) {
+      if (it->second.device == dev && it->second.pins == 0) {
+        (void)hipFree(it->second.ptr);
+        g_panel_bytes -= it->second.bytes;
+        it = g_panels.erase(it);
+        freed = true;
+      } else {
+        ++it;
+      }
+    }
+    if (freed) e = hipMalloc(ptr, bytes);
+  }
+  if (e != hipSuccess) {
+    *ptr = nullptr;
+    return fail(LASER_HIP_E_HIP, "allocating a pre-packed panel (%zu bytes): %s", bytes, hipGetErrorString(e));
+  }
+  return LASER_HIP_OK;
+}
+int panel_alloc(void **ptr, size_t bytes, int dev) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return panel_alloc_locked(ptr, bytes, dev);
 }
 
 // device tensor storage: live blocks (ptr -> rounded size) and the free list keyed by size
@@ -1036,8 +1120,6 @@ void storage_trim() {
   g_free_storage.clear();
   g_free_storage_bytes = 0;
 }
-uint64_t g_next_id = 1;
-
 template <typename T>
 int64_t prepack_bytes(bool is_a, int64_t M, int64_t N, int64_t K) {
   if (M < 0 || N < 0 || K < 0) return 0;
@@ -1086,7 +1168,7 @@ int prepack_host(bool is_a, void *dst, int64_t M, int64_t N, int64_t K, const T 
     std::lock_guard<std::mutex> lk(g_mu);
     panel_cache_evict_locked(p.bytes);
   }
-  HIP_TRY(hipMalloc(&p.ptr, p.bytes));
+  if (int rc = panel_alloc(&p.ptr, p.bytes, p.device)) return rc;
   hipError_t e = is_a ? launch_pack_pad<T>((T *)p.ptr, rup(M, kPadMN), rup(K, kPadK), (const T *)dsrc - lo, M, K, rs, cs, nullptr)
                       : launch_pack_pad<T>((T *)p.ptr, rup(K, kPadK), rup(N, kPadMN), (const T *)dsrc - lo, K, N, rs, cs, nullptr);
   // the image goes into the caller's buffer (what makes the buffer self-contained); the device copy stays as the cache's first entry
@@ -1102,15 +1184,17 @@ int prepack_host(bool is_a, void *dst, int64_t M, int64_t N, int64_t K, const T 
   h.is_a = is_a ? 1 : 0;
   h.elem = (int32_t)sizeof(T);
   h.image_bytes = p.bytes;
+  h.sum = image_fingerprint((const char *)dst + kPackHeader, p.bytes);
   std::lock_guard<std::mutex> lk(g_mu);  // the panel cache
-  h.id = g_next_id++;
+  h.id = fresh_id_locked();
   // re-packing into a buffer that still holds a live header drops the old image's device copies first
   PackHandle old;
   memcpy(&old, dst, sizeof old);
   if (old.magic == kMagic) panel_cache_drop_locked(old.id);
   memcpy(dst, &h, sizeof h);
   p.last_use = ++g_panel_clock;
-  g_panels[panel_key(h.id, p.device)] = p;
+  p.id = h.id; p.sum = h.sum;
+  g_panels[panel_key(h, p.device)] = p;
   g_panel_bytes += p.bytes;
   return LASER_HIP_OK;
 }
@@ -1131,17 +1215,25 @@ int resolve_handle(const void *packed, bool want_a, int elem, int64_t M, int64_t
   if ((int64_t)h.image_bytes != want_bytes) return fail(LASER_HIP_E_HANDLE, "pre-packed buffer header is corrupt (image size)");
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const uint64_t key = panel_key(h.id, dev);
+  const uint64_t key = panel_key(h, dev);
   auto it = g_panels.find(key);
+  // A hit is used only if it is the copy of THIS image: same id, same fingerprint, same size (the key mixes all of them, so anything
+  // else is a 64-bit hash collision -- or a header someone edited).  Such an entry is left alone (a call may be multiplying from it)
+  // and the operand is refused rather than multiplied from the wrong matrix / read past a smaller panel.
+  if (it != g_panels.end() && (it->second.id != h.id || it->second.sum != h.sum || it->second.bytes != (size_t)h.image_bytes))
+    return fail(LASER_HIP_E_HANDLE, "pre-packed buffer header does not match the cached device image (foreign or edited header)");
   if (it == g_panels.end()) {      // evicted / another device / a copy of the buffer in a process that never packed it: upload the image
+    if (image_fingerprint((const char *)packed + kPackHeader, (size_t)h.image_bytes) != h.sum)
+      return fail(LASER_HIP_E_HANDLE, "pre-packed buffer does not hold the image its header describes");
     DevPanel p;
     p.bytes = (size_t)h.image_bytes;
     p.device = dev;
+    p.id = h.id; p.sum = h.sum;
     panel_cache_evict_locked(p.bytes);
-    hipError_t e = hipMalloc(&p.ptr, p.bytes);
-    if (e == hipSuccess) e = hipMemcpy(p.ptr, (const char *)packed + kPackHeader, p.bytes, hipMemcpyHostToDevice);
+    if (int rc = panel_alloc_locked(&p.ptr, p.bytes, dev)) return rc;
+    const hipError_t e = hipMemcpy(p.ptr, (const char *)packed + kPackHeader, p.bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-      if (p.ptr) (void)hipFree(p.ptr);
+      (void)hipFree(p.ptr);
       return fail(LASER_HIP_E_HIP, "uploading a pre-packed operand: %s", hipGetErrorString(e));
     }
     g_panel_bytes += p.bytes;
@@ -1426,6 +1518,11 @@ int laser_hip_finalize(void) {
 const char *laser_hip_last_error(void) { return g_err.c_str(); }
 const char *laser_hip_version(void) { return "laser_hip 0.2.0 (gfx950)"; }
 int laser_hip_abi_version(void) { return LASER_HIP_ABI_VERSION; }
+int laser_hip_plan_f32(int64_t M, int64_t N, int64_t K, int laser_order, int cus, int64_t *out8) {
+  if (!out8) return fail(LASER_HIP_E_INVALID, "null pointer");
+  if (asm_plan_f32(M, N, K, laser_order, cus, out8)) return fail(LASER_HIP_E_INVALID, "laser_hip_plan_f32: bad shape or CU count");
+  return LASER_HIP_OK;
+}
 int laser_hip_device_count(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
@@ -1470,7 +1567,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "skinny") g_ctx.skinny = on;
   else if (n == "small_path") g_small_path = on;
   else if (n == "split_tail") g_split_tail = on;
-  else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 3 ? 3 : value;
   else if (n == "asm_kernel") g_asm_kernel = value < 0 ? -1 : value;
   else if (n == "asm_tile") g_asm_tile = value < 0 || value > 4 ? -1 : value;
   else if (n == "im2col_band") g_im2col_band = value < 0 ? 0 : value;

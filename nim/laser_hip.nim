@@ -27,6 +27,7 @@ const laserHipAbi* = 2                       # include/laser_hip.h LASER_HIP_ABI
 proc laser_hip_init*(device: cint): cint {.lh, importc: "laser_hip_init".}
 proc laser_hip_finalize*(): cint {.lh, importc: "laser_hip_finalize".}
 proc laser_hip_device_count*(): cint {.lh, importc: "laser_hip_device_count".}
+proc laser_hip_plan_f32*(M, N, K: int64, laser_order, cus: cint, out8: ptr int64): cint {.lh, importc: "laser_hip_plan_f32".}   # diagnostics: kernel + launch plan for a device of `cus` CUs
 proc laser_hip_set_float_mode*(mode: cint): cint {.lh, importc: "laser_hip_set_float_mode".}   # 0 = Laser order (default), 1 = fast
 # every tuning / A-B switch by name (include/laser_hip.h lists them), and the read-only diagnostics of the last launch
 proc laser_hip_set_option(name: cstring, value: cint): cint {.lh, importc: "laser_hip_set_option".}

@@ -125,6 +125,64 @@ def test_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, kw):
     assert C.run_case(name, M, N, Kd, verbose=False, **kw)
 
 
+# Pipelined tile transitions (Cfg.pipe, round 6): a persistent workgroup whose next run is another whole tile never leaves its K loop --
+# the last two tile bodies of a tile fetch the next tile's first K-tiles, the next tile's first body (a transition body) finishes the
+# old tile from the gaps behind its first MFMAs.  strided: workgroup v walks tiles v, v + G, v + 2G ... (what the launcher uses when
+# there are more tiles than workgroup slots); the contiguous ranges of the cut plans pipeline their whole tiles the same way.  The
+# result must be the same bits as one workgroup per tile: ragged M / N, strided C, alpha != 1, exactly 3 K-tiles (the switch happens in
+# the transition body's own tail), folds inside a tile, several wave interleavings.
+PIPE_CASES = [
+    ("exact_64x64x32", 130, 200, 1088, dict(G=3, strided=True)),
+    ("exact_64x64x32", 130, 200, 96, dict(G=5, strided=True, ldc=205)),                       # 3 K-tiles: no body between two switches
+    ("exact_64x64x32", 130, 200, 128, dict(G=4, strided=True, alpha=0.75, order=[3, 1, 0, 2])),
+    ("exact_64x64x32_nt", 130, 200, 576, dict(G=2, strided=True, lda=580, ldb=584, xcd=True, group_m=2)),
+    ("exact_256x128x32", 300, 260, 96, dict(G=2, strided=True, ldc=270)),
+    ("exact_256x128x32", 520, 130, 1056, dict(G=1, strided=True, alpha=-2.0)),                # one workgroup walks every tile; folds + transition
+    ("exact_256x128x32_nt", 300, 260, 160, dict(G=3, strided=True, csc=2)),
+    ("exact_128x128x16", 140, 390, 560, dict(G=2, strided=True, csc=2)),
+    ("exact_128x128x32", 260, 390, 160, dict(G=4, strided=True, order=[2, 0, 3, 1])),
+    ("fast_256x128x32", 300, 260, 128, dict(G=2, strided=True, alpha=0.5)),
+    ("fast_256x256x16", 300, 520, 64, dict(G=2, strided=True)),
+    ("fast_128x128x16_nt", 140, 390, 80, dict(G=3, strided=True, ldc=400)),
+    ("fast_64x64x32", 130, 200, 160, dict(G=7, strided=True, xcd=True, group_m=2)),
+    # contiguous ranges (the cut plans): whole tiles between the head and the tail piece of a range are pipelined too
+    ("exact_64x64x32", 130, 200, 1088, dict(G=5, split=True)),
+    ("exact_64x64x32", 130, 200, 1088, dict(G=8, split=True, two_level=True, noseed=1)),
+    # launches that may NOT pipeline take the ordinary path: beta != 0, a bias, a K tail
+    ("exact_64x64x32", 130, 200, 1088, dict(G=3, strided=True, beta=0.5)),
+    ("exact_64x64x32", 130, 200, 1088, dict(G=3, strided=True, bias="row", act=1)),
+    ("exact_64x64x32", 130, 200, 1100, dict(G=3, strided=True)),
+    ("fast_256x128x32", 300, 260, 64, dict(G=2, strided=True)),                               # two K-tiles only
+]
+
+
+@pytest.mark.parametrize("name,M,N,Kd,kw", PIPE_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-G{c[4]['G']}-{i}" for i, c in enumerate(PIPE_CASES)])
+def test_pipelined_tile_transitions_in_the_interpreter(name, M, N, Kd, kw):
+    assert C.run_case(name, M, N, Kd, verbose=False, **kw)
+
+
+def test_pipelined_transitions_are_really_taken():
+    """the transition bodies run (tiles - workgroups) times per wave, the ordinary epilogue once per workgroup"""
+    from laser_amd.asmgen import sim
+    seen = {"trans": 0, "done": 0}
+    orig = sim.Workgroup.step
+
+    def step(self, w):
+        i = self.ins[w.pc]
+        if i.op == "label" and w.wid == 0:
+            if "trans_s" in i.args[0]:
+                seen["trans"] += 1
+            elif i.args[0].startswith(".L_done_"):
+                seen["done"] += 1
+        return orig(self, w)
+    sim.Workgroup.step = step
+    try:
+        assert C.run_case("exact_64x64x32", 130, 200, 1088, verbose=False, G=3, strided=True)      # 3 x 4 tiles on 3 workgroups
+    finally:
+        sim.Workgroup.step = orig
+    assert seen == {"trans": 9, "done": 3}
+
+
 DEEP_CASES = [("exact_64x64x32", 70, 50, 33, {}), ("exact_64x64x32", 64, 64, 96, {}), ("exact_64x64x32", 70, 50, 97, dict(alpha=0.5, beta=0.25)),
               ("exact_64x64x32", 70, 50, 131, {}), ("exact_64x64x32", 64, 64, 1057, {}), ("fast_64x64x32_nt", 70, 90, 161, dict(alpha=0.5)),
               ("exact_64x64x32_nt", 130, 70, 1100, dict(G=5, split=True)), ("fast_64x64x32", 100, 100, 545, dict(G=3, split=5, integer=True))]

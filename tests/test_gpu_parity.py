@@ -441,6 +441,54 @@ def test_prepacked_buffers_are_self_contained(la, oracle):
         del pa
 
 
+def test_prepacked_header_with_a_colliding_id_never_meets_another_image(la, oracle):
+    """the device cache of pre-packed panels is keyed by the header's id, and headers are caller memory -- a buffer
+    packed by another process (or a forked child) may carry an id this process has also handed out.  Ids are salted per process now,
+    and the key also mixes the image fingerprint and the shape: a header with a COLLIDING id and its own image multiplies from its
+    own image; a header whose fingerprint does not belong to its image is refused; nothing is read from a smaller cached panel."""
+    rng = np.random.default_rng(173)
+    M, N, K = 260, 300, 520
+    A = rand(rng, (M, K), np.float32)
+    B1, B2 = rand(rng, (K, N), np.float32), rand(rng, (K, N), np.float32)
+    nb = la.gemm_prepackB_mem_required(np.float32, M, N, K)
+    pa = la.aligned_host_buffer(la.gemm_prepackA_mem_required(np.float32, M, N, K))
+    p1, p2 = la.aligned_host_buffer(nb), la.aligned_host_buffer(nb)
+    la.gemm_prepackA(pa, M, N, K, A, K, 1)
+    la.gemm_prepackB(p1, M, N, K, B1, N, 1)
+    la.gemm_prepackB(p2, M, N, K, B2, N, 1)
+    ids = [bytes(p[8:16]) for p in (p1, p2)]
+    assert ids[0] != ids[1] and ids[0] != (1).to_bytes(8, "little"), "ids are salted, not a counter from 1"
+    C = np.zeros((M, N), dtype=np.float32)
+    la.gemm_packed(M, N, K, 1, pa, p1, 0, C, N, 1)                  # B1's device copy is cached under id 1
+    assert np.array_equal(C, oracle.matmul(A, B1))
+    foreign = la.aligned_host_buffer(nb)
+    foreign[:] = p2
+    foreign[8:16] = p1[8:16]                                        # "another process" packed B2 under the id this process gave B1
+    la.gemm_packed(M, N, K, 1, pa, foreign, 0, C, N, 1)
+    assert np.array_equal(C, oracle.matmul(A, B2)), "a colliding id paired the header with another image's device copy"
+    # a smaller shape under the same id: the cached (smaller) panel must not be read past its end
+    Ms, Ns, Ks = 100, 40, 64
+    As, Bs = rand(rng, (Ms, Ks), np.float32), rand(rng, (Ks, Ns), np.float32)
+    pas = la.aligned_host_buffer(la.gemm_prepackA_mem_required(np.float32, Ms, Ns, Ks))
+    pbs = la.aligned_host_buffer(la.gemm_prepackB_mem_required(np.float32, Ms, Ns, Ks))
+    la.gemm_prepackA(pas, Ms, Ns, Ks, As, Ks, 1)
+    la.gemm_prepackB(pbs, Ms, Ns, Ks, Bs, Ns, 1)
+    Cs = np.zeros((Ms, Ns), dtype=np.float32)
+    la.gemm_packed(Ms, Ns, Ks, 1, pas, pbs, 0, Cs, Ns, 1)
+    big_with_small_id = la.aligned_host_buffer(nb)
+    big_with_small_id[:] = p1
+    big_with_small_id[8:16] = pbs[8:16]
+    la.gemm_packed(M, N, K, 1, pa, big_with_small_id, 0, C, N, 1)
+    assert np.array_equal(C, oracle.matmul(A, B1))
+    # a header whose fingerprint is not its image's (edited header, or an image overwritten behind a live header): refused
+    broken = la.aligned_host_buffer(nb)
+    broken[:] = p2
+    broken[8:16] = np.frombuffer((0x1234567).to_bytes(8, "little"), dtype=np.uint8)   # never cached: forces the upload path
+    broken[64:72] = 0x5a                                            # (the fingerprint samples the image: its first and last words always)
+    with pytest.raises(la.LaserHipError):
+        la.gemm_packed(M, N, K, 1, pa, broken, 0, C, N, 1)
+
+
 def test_prepacked_large_runs_on_the_assembly_kernels(la, oracle):
     """gemm_prepack* + gemm_packed at a size the hand-scheduled kernels take: the tile-padded panel images are plain padded
     row-major copies, so the packed call runs on the same kernels as gemm_strided, with the same bits."""
@@ -921,8 +969,8 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
                 assert la.last_f32_asm() == 0
             finally:
                 la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1); la.set_option("asm_plan", 0)
-            # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128; 13..16: 64x64 tiles)
-            want = (1, 3, 5, 7, 13, 15) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10, 14, 16)
+            # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128; 13..16: 64x64 tiles; 31..34: 128x128 with the 32-deep K-tile)
+            want = (1, 3, 5, 7, 13, 15, 31, 33) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10, 14, 16, 32, 34)
             seen.add(used)
             # (tiny problems are taken by the small-matrix / slice-parallel paths before the tiled kernels are asked)
             assert used in want or (used == 0 and M * N <= 1024 * 1024), (M, N, K, mode, used)

@@ -292,3 +292,57 @@ def test_no_fix_up_ever_gave_up_waiting(la):
     """(last in this file) the error word in front of every stream's flags: a fix-up that polled for ~2 s without seeing its partial
     would have counted itself here -- a lost release or a scheduling order the design does not allow"""
     assert la.get_option("asm_fixup_timeouts") == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_strided_persistent_plan_with_pipelined_tile_transitions(la, oracle, mode):
+    """Round 6 (asmgen/f32_kernel.py Cfg.pipe, gemm_f32_asm.cpp plan_launch): with more tiles than workgroup slots the 256x128 kernels
+    run as ONE workgroup per CU that walks tiles v, v + 256, ... without leaving its K loop -- the last bodies of a tile fetch the
+    next tile's first K-tiles, the next tile's first body stores this tile's C.  Same bits as one workgroup per tile (also in
+    one-chain mode: the chain order does not change), equal to the oracle in laser-order mode; ragged edges, a strided C view, every
+    workgroup count (asm_wgs), and the cases that must NOT pipeline (beta, K tail) on the same plan."""
+    import torch
+    rng = np.random.default_rng(606 + mode)
+    la.set_option("f32_asm", 2)
+    la.set_float_mode(mode)
+    try:
+        for (M, N, K, kw) in [(4096, 4096, 1024, {}), (4100, 4228, 544, {}), (3000, 5000, 96, dict(csc=2)), (2560, 4100, 1056, dict(alpha=0.5)),
+                              (2048, 4096, 640, dict(beta=0.25)), (2304, 4000, 1000, {})]:
+            alpha, beta, csc = kw.get("alpha", 1.0), kw.get("beta", 0.0), kw.get("csc", 1)
+            A = torch.from_numpy(_rnd(rng, (M, K))).cuda()
+            B = torch.from_numpy(_rnd(rng, (K, N))).cuda()
+            C0 = torch.from_numpy(_rnd(rng, (M, N * csc))).cuda()
+            outs = {}
+            ragged = M % 256 != 0 or N % 128 != 0       # (the caller may cut a ragged problem into a main launch of whole tiles + edge launches)
+            # (one-chain mode: the model's own choice may cut K -- another, equally valid rounding -- so only the plans that never do are compared)
+            for plan, wgs in ((1, 0), (0, 0), (3, 0), (3, 100), (3, 37)) if mode == 0 else ((1, 0), (3, 0), (3, 100), (3, 37)):
+                la.set_option("asm_kernel", 8 if mode else 0)
+                la.set_option("asm_plan", plan)
+                la.set_option("asm_wgs", wgs)
+                C = C0.clone()
+                la.matmul(A, B, alpha, beta, C[:, ::csc])
+                assert la.last_f32_asm() == (9 if mode else 1), (M, N, K, plan, la.last_f32_asm())
+                g = la.get_option("last_asm_wgs")
+                tiles = -(-M // 256) * -(-N // 128)
+                may = beta == 0 and K % 32 == 0 and K >= 96      # (else the launcher keeps one workgroup per tile: nothing to pipeline)
+                if ragged:
+                    assert g <= tiles
+                elif plan == 1 or (plan == 3 and not may):
+                    assert g == tiles
+                elif plan == 3:
+                    assert g == min(wgs or 256, tiles), (plan, wgs, g)
+                elif may:
+                    assert g == 256, "the launch model takes the strided plan when there are more tiles than workgroup slots"
+                outs[(plan, wgs)] = C
+            ref = outs[(1, 0)]
+            for key, C in outs.items():
+                assert torch.equal(C, ref), (M, N, K, kw, key)
+            if csc > 1:
+                assert torch.equal(ref[:, 1::csc], C0[:, 1::csc]), "wrote between the columns of the view"
+            if mode == 0:
+                want = oracle.matmul(A.cpu().numpy(), B.cpu().numpy(), alpha, beta, C0.cpu().numpy()[:, ::csc])
+                assert np.array_equal(ref.cpu().numpy()[:, ::csc], want), (M, N, K, kw)
+    finally:
+        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f32_asm", 1)):
+            la.set_option(k, v)
+        la.set_float_mode(0)

@@ -192,3 +192,32 @@ def test_committed_traffic_figure_matches_the_shipped_kernels():
         assert d[mode]["bytes_per_launch"] == int(round((2 * d[mode]["fetch_size_kib"] + d[mode]["write_size_kib"]) * 1024))
         assert bench.pmc_traffic(mode, d["plans"][mode]) == d[mode]
         assert bench.pmc_traffic(mode, dict(d["plans"][mode], wgs=1)) is None      # another launch plan: the figure is not quoted
+
+
+def test_launch_plans_scale_with_the_device_cu_count():
+    """VERDICT r5 missing #4: 256 CUs / 8 XCDs were compile-time constants and a partitioned MI355X (CPX 32 / QPX 64 / DPX 128 CUs)
+    stepped off every assembly kernel.  The launcher now plans with the device's own CU count; laser_hip_plan_f32 shows the choice
+    without a device (the GPU twin of reading gemm_tiling.nim:276-341's partition for a shape)."""
+    import laser_amd as la
+    head = la.plan_f32(8192, 8192, 8192, True, 256)
+    assert head == dict(kernel=1, plan="strided", wgs=256, slices=1, tiles=2048, tiles_m=32, tiles_n=64, slots=256)
+    for cus in (32, 64, 128, 256):
+        for shape in [(8192, 8192, 8192), (4096, 4096, 4096), (4100, 4100, 4100), (3072, 3072, 3072), (2048, 2048, 2048), (1920, 1920, 1920)]:
+            for laser in (True, False):
+                p = la.plan_f32(*shape, laser, cus)
+                assert p["kernel"] != 0, (cus, shape, "a partitioned device must keep the hand-scheduled kernels")
+                assert p["slots"] % cus == 0 and p["tiles"] == p["tiles_m"] * p["tiles_n"]
+                if p["plan"] == "plain":
+                    assert p["wgs"] == p["tiles"] and p["slices"] == 1
+                elif p["plan"] == "strided":          # one persistent workgroup per slot, more tiles than slots, whole tiles only
+                    assert p["wgs"] == p["slots"] < p["tiles"] and p["slices"] == 1
+                else:                                  # K-slice cuts: at most every slot of THIS device, a multiple of 8 when tiles are cut
+                    assert 8 <= p["wgs"] <= p["slots"] and p["slices"] >= 1
+        # the number of rounds the busiest CU works follows the CU count: fewer CUs -> the same shape needs a plan with fewer workgroups
+        assert la.plan_f32(8192, 8192, 8192, True, cus)["wgs"] == cus
+    # problems of a few tiles keep the compiler-scheduled small / slice-parallel forms on the full chip, and reach the tiled kernels on
+    # a partition where they are several rounds of work
+    assert la.plan_f32(512, 512, 512, True, 256)["kernel"] == 0
+    assert la.plan_f32(512, 512, 512, True, 32)["kernel"] != 0
+    with pytest.raises(la.LaserHipError):
+        la.plan_f32(0, 4, 4)
