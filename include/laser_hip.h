@@ -113,7 +113,15 @@ int laser_hip_f32_config_count(void);
  *   "asm_plan"         [0] launch plan of the assembly GEMM kernels: 0 = the launcher's model decides; 1 = one tile per workgroup;
  *                          2 = the persistent plan whenever legal: every workgroup slot of the chip gets an equal share of K-slice
  *                          units (laser-order: kc slices), a tile that straddles two workgroups is handed over in-kernel, in slice
- *                          order (gemm.nim:150-158) -- laser-order results are the same bits under every plan
+ *                          order (gemm.nim:150-158) -- laser-order results are the same bits under every plan; 3 = the strided
+ *                          whole-tile plan whenever legal (round 6): one persistent workgroup per slot walks tiles v, v + G, ...
+ *                          WITHOUT leaving its K loop -- the last K-tile bodies of a tile fetch the next tile's first K-tiles, the next
+ *                          tile's first body stores this tile's C (beta == 0, plain epilogue, K a multiple of the K-tile); what the
+ *                          model takes by itself when there are more tiles than workgroup slots.  Same bits as plan 1, both modes.
+ *                          A K-cut launch whose hand-over times out (a receiver polls ~2 s for its predecessor's running sum; never in
+ *                          a correct run) is REPORTED: the error word travels back behind the launch and the next call on that stream
+ *                          fails with LASER_HIP_E_HIP, laser_hip_last_error() naming the stream -- never a silently wrong C
+ *                          ("asm_test_giveup" = 1 makes every receiver give up at once: tests of that report)
  *   "asm_kernel" [-1] / "asm_wgs" [0] / "asm_slice" [0] / "asm_noseed" [0] / "asm_group_m" [0]  tuning / test overrides of that plan:
  *                          force an assembly kernel index, the number of workgroups, the K-tiles per slice of a one-chain cut, the
  *                          two-run receive path, the tile rows per raster group (which tiles share an XCD's L2)

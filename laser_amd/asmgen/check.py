@@ -135,7 +135,8 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     mem = Memory()
     a_, b_, c_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call)
     ws_ = mem.alloc(np.full(G * g.tile_bytes() // 4, np.nan, dtype=np.float32))
-    fl_ = mem.alloc(np.zeros(G, dtype=np.uint32))
+    fl_base = mem.alloc(np.zeros(G + 1, dtype=np.uint32))      # [0] = the error word (receivers that gave up count themselves there)
+    fl_ = fl_base + 4
     # fused epilogue: bias = "row" (1 x N, row stride 0), "col" (M x 1, column stride 0) or "full" (M x N, padded rows); act 1 = relu
     bias_ptr, rsb, csb, Bias = 0, 0, 0, None
     if bias:
@@ -153,8 +154,12 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd or two_level)
-    if np.any(mem.get(fl_, np.uint32, (G,))):
+    flags_after = mem.get(fl_base, np.uint32, (G + 1,))
+    if np.any(flags_after[1:]):
         raise AssertionError("a workspace flag was left set: the next launch would take a stale sum")
+    run_case.last_error_word = int(flags_after[0])
+    if flags_after[0] and not (noseed & 8):
+        raise AssertionError("a receiver gave up waiting")
     got = mem.get(c_, np.float32, (batch * LC,))
     ok = pad_ok = True
     for b in range(batch):
@@ -299,7 +304,8 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     mem = Memory()
     a_, b_, c_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call)
     ws_ = mem.alloc(np.full(G * g.tile_bytes() // 8, np.nan))
-    fl_ = mem.alloc(np.zeros(G, dtype=np.uint32))
+    fl_base = mem.alloc(np.zeros(G + 1, dtype=np.uint32))      # [0] = the error word
+    fl_ = fl_base + 4
     bs = (LA * 8, LB * 8, LC * 8) if batch > 1 else (0, 0, 0)
     ka = (struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta)
           + struct.pack("<Q", bs[0]) + b"\0" * 16 + struct.pack("<QQ", bs[1], bs[2]) + b"\0" * 24)
@@ -308,8 +314,12 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
     stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd or two_level)
-    if np.any(mem.get(fl_, np.uint32, (G,))):
+    flags_after = mem.get(fl_base, np.uint32, (G + 1,))
+    if np.any(flags_after[1:]):
         raise AssertionError("a workspace flag was left set")
+    run_case64.last_error_word = int(flags_after[0])
+    if flags_after[0] and not (noseed & 8):
+        raise AssertionError("a receiver gave up waiting")
     got = mem.get(c_, np.float64, (batch * LC,))
     ok = True
     for b in range(batch):

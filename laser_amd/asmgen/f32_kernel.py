@@ -2293,6 +2293,12 @@ class Gen:
         e("s_sub_u32", slot, self.s_vid, 1)
         self.ws_descriptors(slot)
         e("v_lshlrev_b32", t[8], 2, v(0))
+        # flags bit 3 (tests only): the receiver gives up at once, as if its ~2 s of polling had run out -- the error report below and
+        # the launcher's handling of it are then exercised without a hung sender
+        e("s_load_dword", st[0], s(0, 2), KA_SCHED2 + 24)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_bitcmp1_b32", st[0], 3)
+        e("s_cbranch_scc1", lost)
         e("s_mov_b32", st[5], 0)
         p.place(spin)
         e("buffer_load_dword", t[9], OFF, self.srdA, 0, sc1=True)
@@ -2300,9 +2306,11 @@ class Gen:
         e("v_readfirstlane_b32", fv, t[9])
         e("s_cmp_lg_u32", fv, 0)
         e("s_cbranch_scc1", got)
-        # a legitimate wait is short (the sum is the first thing its sender computes); after ~2 s of polling the workgroup reports
-        # to the error word in front of the flags (launcher: option "asm_fixup_timeouts") and goes on -- a wrong result that is
-        # flagged, not a hung GPU
+        # a legitimate wait is short (the sum is the first thing its sender computes); after ~2 s of polling the workgroup COUNTS itself
+        # in the error word in front of the flags (an atomic add: every workgroup that gave up is in the sum) and goes on -- a wrong
+        # result that is flagged, not a hung GPU.  The launcher reads the word back behind every cut launch and fails the next call
+        # on the stream (gemm_f32_asm.cpp check_stream_poison): the reference aborts on a violated precondition
+        # (gemm_prepacked.nim:125); this library never returns a wrong C silently.
         e("s_add_u32", st[5], st[5], 1)
         e("s_cmp_lt_u32", st[5], 1 << 21)
         e("s_cbranch_scc0", lost)
@@ -2311,13 +2319,14 @@ class Gen:
         p.place(lost)
         e("s_load_dwordx2", self.s_sc.sub(0, 2), s(0, 2), KA_WS + 8)
         e("s_waitcnt", lgkmcnt=0)
-        e("s_sub_u32", self.srdC[0], sc[0], 4)
-        e("s_subb_u32", self.srdC[1], sc[1], 0)
-        e("s_and_b32", self.srdC[1], self.srdC[1], 0xffff)
-        e("s_mov_b32", self.srdC[2], 4)
-        e("s_mov_b32", self.srdC[3], 0x00020000)
+        srdE = self.s_sc.sub(0, 4)          # (the scheduler constants are reloaded where they are next used; srdC stays what the epilogue needs)
+        e("s_sub_u32", srdE[0], sc[0], 4)
+        e("s_subb_u32", srdE[1], sc[1], 0)
+        e("s_and_b32", srdE[1], srdE[1], 0xffff)
+        e("s_mov_b32", srdE[2], 4)
+        e("s_mov_b32", srdE[3], 0x00020000)
         e("v_mov_b32", t[9], 1)
-        e("buffer_store_dword", t[9], t[8], self.srdC, 0, offen=True, sc1=True)
+        e("buffer_atomic_add", t[9], t[8], srdE, 0, offen=True, sc1=True)     # (4 * tid: only thread 0 of the workgroup is in range)
         e("s_waitcnt", vmcnt=0)
         p.place(got)
         self.load_received(t[8])

@@ -695,6 +695,20 @@ class Workgroup:
             w.stats["lds_ops"] -= 1
             w.lgkm.append(("ldsw", []))
         # ------------------------------------------------------------ VMEM (raw buffers, offen)
+        elif op == "buffer_atomic_add":
+            # 32-bit integer add in memory, no return value (sc0 clear); raw buffer, offen: same range check as a dword store
+            data, voff, srd, soff = A
+            base, nrec = self._srd(w, srd)
+            so = rs(w, soff)
+            assert M.get("offen") and not M.get("sc0")
+            vo = rv(w, voff).astype(np.int64) + int(M.get("offset", 0))
+            vals = rv(w, data)
+            act = w.execmask()
+            for l in range(LANES):
+                if act[l] and vo[l] + so + 4 <= nrec and vo[l] >= 0:
+                    addr = base + so + int(vo[l])
+                    self.mem.write32(addr, (self.mem.read32(addr) + int(vals[l])) & 0xffffffff)
+            w.vm.append([])
         elif op in ("buffer_load_dword", "buffer_load_dwordx2", "buffer_load_dwordx4", "buffer_store_dword", "buffer_store_dwordx2",
                     "buffer_store_dwordx4"):
             ndw = {"dword": 1, "dwordx2": 2, "dwordx4": 4}[op.split("_")[2]]

@@ -47,9 +47,11 @@ int fail(int code, const char *fmt, ...) {
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess)                                                                     \
-      return fail(LASER_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
-                  __FILE__, __LINE__);                                                        \
+    if (e_ != hipSuccess) {                                                                   \
+      const char *why_ = asm_error_detail();                                                  \
+      return fail(LASER_HIP_E_HIP, "%s failed: %s%s%s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  why_[0] ? ": " : "", why_, __FILE__, __LINE__);                             \
+    }                                                                                         \
   } while (0)
 
 struct Context {
@@ -1574,6 +1576,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "asm_wgs") g_asm_wgs = value < 0 ? 0 : value;
   else if (n == "asm_slice") g_asm_slice = value < 0 ? 0 : value;
   else if (n == "asm_noseed") g_asm_noseed = on;
+  else if (n == "asm_test_giveup") g_asm_giveup = on;
   else if (n == "asm_group_m") g_asm_group_m = value < 0 ? 0 : value;
   else if (n == "slice_parallel") g_ctx.slice_parallel = on;
   else if (n == "slice_parallel_min") g_ctx.slice_parallel_min = value < 2 ? 2 : value;
@@ -1610,6 +1613,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "asm_wgs") *value = g_asm_wgs;
   else if (n == "asm_slice") *value = g_asm_slice;
   else if (n == "asm_noseed") *value = g_asm_noseed;
+  else if (n == "asm_test_giveup") *value = g_asm_giveup;
   else if (n == "asm_group_m") *value = g_asm_group_m;
   else if (n == "last_asm_wgs") *value = g_last_asm_wgs;
   else if (n == "last_asm_slices") *value = g_last_asm_slices;

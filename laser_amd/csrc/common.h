@@ -178,6 +178,7 @@ hipError_t launch_gemm_f32_asm(const GemmArgs<float> &args, bool laser_order, hi
 // implicit-GEMM convolution on the same framework (3x3 kernel, stride 1, padding 0 or 1): output pixels [0, args.N) of every image
 hipError_t launch_conv_f32_asm(const GemmArgs<float> &args, bool laser_order, hipStream_t s);
 int asm_plan_f32(int64_t M, int64_t N, int64_t K, int laser_order, int cus, int64_t out[8]);   // diagnostics: kernel + launch plan for a device of `cus` CUs (no device touched)
+const char *asm_error_detail();   // the assembly launcher's explanation of the error it just returned on this thread ("" = none)
 int64_t asm_fixup_timeouts();  // diagnostics: fix-ups of cut launches that gave up waiting (0 in a correct run; synchronises the device)
 void asm_kernels_release();   // unload the assembly kernels' code objects (laser_hip_finalize)
 hipError_t launch_gemm_f64_asm(const GemmArgs<double> &args, bool laser_order, hipStream_t s);
@@ -189,7 +190,7 @@ extern std::atomic<int> g_asm_tile;   // option "asm_tile" (gemm_f32_asm.cpp)
 void asm_set_thread_tile(int tile_class);   // per-thread pin of the same (-2 = none)
 int asm_tile_pin_now();                     // the pin this thread's launches see (-1 = none)
 extern std::atomic<int> g_last_asm_group_m;
-extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed, g_asm_group_m;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
+extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed, g_asm_group_m, g_asm_giveup;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
 extern std::atomic<int> g_last_asm_wgs, g_last_asm_slices;                  // diagnostics: workgroups / K slices per tile of the last assembly launch
 extern std::atomic<int> g_f32_asm;       // 1 default; 0 = never; 2 = whenever the kernel can (no tile-count rule: tests)
 extern std::atomic<int> g_last_f32_asm;  // 0 = the last f32 GEMM launch was a compiler-scheduled kernel, 1 / 2 = laser-order / fast assembly kernel

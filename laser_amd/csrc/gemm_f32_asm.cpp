@@ -36,6 +36,7 @@ std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persi
 std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
 std::atomic<int> g_asm_group_m{0};    // option "asm_group_m": tile rows per raster group of the f32 / f64 GEMM launches (0 = 4 for 256-row tiles, else 8)
 std::atomic<int> g_asm_noseed{0};     // option "asm_noseed": 1 = a piece never takes its received sum early (tests: forces the two-run receive path)
+std::atomic<int> g_asm_giveup{0};     // option "asm_test_giveup": 1 = every receiver of a cut launch gives up at once, as if its ~2 s of polling had run out (tests of the error report)
 std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0}, g_last_asm_group_m{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
 
 void asm_set_thread_tile(int tile_class) { tl_asm_tile = tile_class; }
@@ -123,6 +124,10 @@ struct StreamWs {
   size_t ws_bytes = 0;
   uint32_t *flags = nullptr;
   size_t nflags = 0;
+  // flags[0] is the stream's error word: a receiver that gave up waiting for its hand-over counts itself there (f32_kernel.py
+  // recv_block).  Behind every cut launch the word is read back -- an asynchronous 4-byte copy on the launch stream into this pinned
+  // host word, no synchronisation -- and the NEXT launch on the stream that finds it non-zero fails (check_stream_poison).
+  volatile uint32_t *host_err = nullptr;
 };
 struct DeviceModule {
   std::mutex mu;     // module load + this device's workspace map; never held across a launch
@@ -184,7 +189,7 @@ bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, in
   sc.mg_width = magic_u32((uint64_t)width); sc.mg_gm = magic_u32((uint64_t)group_m); sc.mg_last = magic_u32((uint64_t)gsz_last);
   sc.xcd_q = (xcd || two_level) && G >= 8 ? (uint32_t)(G / 8) : 0; sc.xcd_r = (xcd || two_level) && G >= 8 ? (uint32_t)(G % 8) : 0;
   sc.P = (uint32_t)P; sc.mg_P = magic_u32((uint64_t)P); sc.units_q = (uint32_t)(two_level ? T : q); sc.units_r = (uint32_t)(two_level ? 0 : r);
-  sc.slice_len = (uint32_t)slice_len; sc.flags_bits = (g_asm_noseed ? 1u : 0u) | (two_level ? 2u : 0u);
+  sc.slice_len = (uint32_t)slice_len; sc.flags_bits = (g_asm_noseed ? 1u : 0u) | (two_level ? 2u : 0u) | (g_asm_giveup ? 8u : 0u);
   sc.mg_G = magic_u32((uint64_t)(two_level ? G / 8 : G));
   sc.ws = w ? (uint64_t)(uintptr_t)w->ws : 0; sc.flags = w ? (uint64_t)(uintptr_t)(w->flags + 1) : 0;   // (flags[0] = the error word)
   return true;
@@ -262,6 +267,14 @@ hipError_t get_ws(DeviceModule *m, hipStream_t s, size_t ws_bytes, size_t nflags
     // kernel is not ordered behind it -- the clear would then wipe flags the running launch has set (seen: a receiver timing out
     // on the first cut launch of a fresh stream, profiles/r04/README.md)
     if (e == hipSuccess) e = hipMemsetAsync(nf, 0, want * sizeof(uint32_t), s);
+    if (e == hipSuccess && !w.host_err) {
+      void *he = nullptr;
+      e = hipHostMalloc(&he, 64, hipHostMallocDefault);
+      if (e == hipSuccess) {
+        w.host_err = (volatile uint32_t *)he;
+        *w.host_err = 0;
+      }
+    }
     if (e == hipSuccess) {
       if (w.flags) m->retired.push_back(w.flags);
       w.flags = nf; w.nflags = want;
@@ -273,6 +286,26 @@ hipError_t get_ws(DeviceModule *m, hipStream_t s, size_t ws_bytes, size_t nflags
   if (e != hipSuccess) return e;
   *out = w;
   return hipSuccess;
+}
+
+thread_local char tl_asm_err[256] = "";
+
+// A cut launch on stream `s` of this device reported receivers that gave up (their tiles hold wrong sums): fail THIS call -- the
+// reference aborts on a violated precondition (gemm_prepacked.nim:125), it never returns a wrong C -- say which stream, and make the
+// stream usable again: the error word and every hand-over flag are cleared on the stream (a sender that was only late sets its flag
+// after its receiver has gone; the next cut launch would take that stale sum), ordered before whatever is launched next.
+hipError_t check_stream_poison(DeviceModule *m, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(m->mu);
+  auto it = m->ws.find(s);
+  if (it == m->ws.end() || !it->second.host_err) return hipSuccess;
+  const uint32_t n = *it->second.host_err;
+  if (n == 0) return hipSuccess;
+  *it->second.host_err = 0;
+  (void)hipMemsetAsync(it->second.flags, 0, it->second.nflags * sizeof(uint32_t), s);
+  snprintf(tl_asm_err, sizeof tl_asm_err,
+           "an earlier K-cut launch on stream %p: %u workgroup(s) gave up waiting for a running sum -- the result of that launch is invalid "
+           "(the stream's hand-over flags have been reset; later calls are clean)", (void *)s, n);
+  return hipErrorLaunchFailure;
 }
 
 // One launch of the tiled problem described by (tiles, K): which plan.
@@ -385,6 +418,10 @@ hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernAr
                           size_t tile_bytes, hipStream_t s) {
   Plan plan = plan_in;
   StreamWs w;
+  {
+    const hipError_t pe = check_stream_poison(m, s);
+    if (pe != hipSuccess) return pe;
+  }
   const int64_t T = (int64_t)tiles_m * tiles_n, U = T * plan.P;
   const bool cuts = plan.persistent && !plan.strided && (U % plan.G != 0 || (U / plan.G) % plan.P != 0 || (plan.G >= 8 && T % 8 != 0));
   const bool two_level = cuts && plan.G >= 8 && plan.G % 8 == 0 && T >= 8;
@@ -405,6 +442,8 @@ hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernAr
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   const hipError_t e = hipModuleLaunchKernel(m->fn[kern], (unsigned)plan.G, (unsigned)batch, 1, 256, 1, 1, 0, s, nullptr, extra);
+  // (the error word travels back behind the launch; whoever launches next on this stream looks at it -- no wait here)
+  if (e == hipSuccess && cuts && w.host_err) (void)hipMemcpyAsync((void *)w.host_err, w.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) {
     g_last_asm_wgs = (int)plan.G;
     g_last_asm_slices = (int)plan.P;
@@ -421,6 +460,14 @@ void zero_conv_fields(KernArgs &ka) {
 }
 
 }  // namespace
+
+// what the assembly launcher has to say about the error it just returned on this thread ("" if nothing); cleared by the read
+const char *asm_error_detail() {
+  static thread_local char out[256];
+  snprintf(out, sizeof out, "%s", tl_asm_err);
+  tl_asm_err[0] = 0;
+  return out;
+}
 
 // diagnostics (option "asm_fixup_timeouts", synchronises the device): streams of the current device on which some workgroup gave up
 // waiting for a running sum (asmgen/f32_kernel.py recv_block: after ~2 s of polling it stores 1 into the stream's error word and
@@ -459,6 +506,7 @@ void asm_kernels_release() {
     for (auto &kv : m.ws) {
       if (kv.second.ws) (void)hipFree(kv.second.ws);
       if (kv.second.flags) (void)hipFree(kv.second.flags);
+      if (kv.second.host_err) (void)hipHostFree((void *)kv.second.host_err);
     }
     m.ws.clear();
     for (void *p : m.retired) (void)hipFree(p);

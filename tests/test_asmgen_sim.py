@@ -300,3 +300,15 @@ def test_interpreter_rejects_a_read_of_a_register_still_loading():
     from laser_amd.asmgen.sim import SimError
     with pytest.raises((SimError, AssertionError)):
         C.run_case("exact_256x128x32", 40, 40, 96, verbose=False, over=dict(ablate=("vmwaits",)))
+
+
+def test_receivers_that_give_up_count_themselves_in_the_error_word():
+    """flags bit 3 (tests): every receiver of a cut launch takes the path of a hand-over that timed out -- one atomic add per workgroup
+    to the error word in front of the flags -- and goes on; the launcher reads the word back behind the launch and fails the next
+    call on the stream (tests/test_gpu_scheduler.py).  In the interpreter the senders have run (workgroups execute in unit order),
+    so the results are still right: what is checked here is the count, the flags left clear, and that C is stored (srdC intact)."""
+    assert C.run_case("exact_64x64x32", 70, 90, 1100, G=5, split=True, noseed=8, verbose=False) and C.run_case.last_error_word == 3
+    assert C.run_case("exact_64x64x32", 70, 90, 1100, G=5, split=True, noseed=9, verbose=False) and C.run_case.last_error_word == 3
+    assert C.run_case("fast_64x64x32", 70, 40, 600, G=9, split=2, integer=True, beta=2.0, noseed=8, verbose=False) and C.run_case.last_error_word == 8
+    assert C.run_case64("exact_64x64x16", 70, 40, 600, G=5, split=True, noseed=8, verbose=False) and C.run_case64.last_error_word == 3
+    assert C.run_case("exact_64x64x32", 70, 90, 1100, G=5, split=True, verbose=False) and C.run_case.last_error_word == 0
