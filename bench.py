@@ -39,15 +39,17 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 ASM_KERNEL_SYMBOLS = [
     "lh_f32_exact_256x128x32", "lh_f32_fast_256x256x16", "lh_f32_exact_128x128x16", "lh_f32_fast_128x128x16",
     "lh_f32_exact_256x128x32_nt", "lh_f32_fast_256x256x16_nt", "lh_f32_exact_128x128x16_nt", "lh_f32_fast_128x128x16_nt",
-    "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt", "lh_f32_conv3x3_exact_256x128x32", "lh_f32_conv3x3_fast_256x128x32",
+    "lh_f32_fast_256x128x32", "lh_f32_fast_256x128x32_nt", "lh_f32_conv_exact_256x128x32", "lh_f32_conv_fast_256x128x32",
     "lh_f32_exact_64x64x32", "lh_f32_fast_64x64x32", "lh_f32_exact_64x64x32_nt", "lh_f32_fast_64x64x32_nt",
     "lh_f64_exact_128x128x16", "lh_f64_fast_128x128x16", "lh_f64_exact_64x64x16", "lh_f64_fast_64x64x16", "lh_i32_128x128x32",
-    "lh_f32_conv3x3_exact_128x128x32", "lh_f32_conv3x3_fast_128x128x32", "lh_f32_conv3x3_exact_64x128x32", "lh_f32_conv3x3_fast_64x128x32",
+    "lh_f32_conv_exact_128x128x32", "lh_f32_conv_fast_128x128x32", "lh_f32_conv_exact_64x128x32", "lh_f32_conv_fast_64x128x32",
     "lh_f64_exact_128x128x16_nt", "lh_f64_fast_128x128x16_nt", "lh_f64_exact_64x64x16_nt", "lh_f64_fast_64x64x16_nt", "lh_i64_64x64x32",
     "lh_f32_exact_128x128x32", "lh_f32_fast_128x128x32", "lh_f32_exact_128x128x32_nt", "lh_f32_fast_128x128x32_nt",
     "lh_f32_exact_256x128x32_pre", "lh_f32_exact_256x128x32_pre_nt", "lh_f32_fast_256x256x16_pre", "lh_f32_fast_256x256x16_pre_nt",
     "lh_f32_exact_128x128x16_pre", "lh_f32_exact_128x128x16_pre_nt", "lh_f32_fast_128x128x16_pre", "lh_f32_fast_128x128x16_pre_nt",
-    "lh_f32_exact_64x64x32_pre", "lh_f32_exact_64x64x32_pre_nt", "lh_f32_fast_64x64x32_pre", "lh_f32_fast_64x64x32_pre_nt"]
+    "lh_f32_exact_64x64x32_pre", "lh_f32_exact_64x64x32_pre_nt", "lh_f32_fast_64x64x32_pre", "lh_f32_fast_64x64x32_pre_nt",
+    "lh_f32x16_exact_96x96x32", "lh_f32x16_fast_96x96x32", "lh_f32x16_exact_96x96x32_nt", "lh_f32x16_fast_96x96x32_nt",
+    "lh_f32x16_exact_160x96x32", "lh_f32x16_fast_160x96x32", "lh_f32x16_exact_160x96x32_nt", "lh_f32x16_fast_160x96x32_nt"]
 ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerate(ASM_KERNEL_SYMBOLS)}
 COMPILER_KERNEL_NAME = "gemm_mfma_kernel<float,...> (compiler-scheduled)"
 
@@ -416,6 +418,43 @@ def single_process_primary(args):
         ref = hashed(tdev[g], chk, K, 1).double() @ Bs[g].double()
         err = max(err, (Cs[g][chk].double() - ref).abs().max().item())
     assert err < 1e-4, f"bench self-check failed: max abs err {err}"
+    # The step, taken apart: the SAME panels with every transport of the gather, each a labelled, timed figure --
+    # "none" (the local products only: what the step would cost if the gather were free), "peer" (each finished panel pushed to every
+    # other GPU over xGMI) and "rccl" (ncclAllGather per slab on a communicator over the N devices: the collective north_star names).
+    # exposed_gather_ms = that leg - the "none" leg.  Whatever the calibration picked as the headline transport, all three are in the line.
+    leg_steps = max(3, min(args.steps, 10))
+    transports = {}
+    for tname in ("none", "peer", "rccl"):
+        rec = {}
+        if tname == "rccl" and one_gpu and ndev > 1:
+            rec["skipped"] = "RCCL refuses two ranks on one device (LASER_BENCH_ONE_GPU test hook)"
+            transports[tname] = rec
+            continue
+        try:
+            call(Ap, Cs, ppd, tname)
+            for d in set(devices):
+                torch.cuda.synchronize(d)
+            t0_ = time.perf_counter()
+            for _ in range(leg_steps):
+                call(Ap, Cs, ppd, tname)
+            for d in set(devices):
+                torch.cuda.synchronize(d)
+            rec["ms_per_step"] = round((time.perf_counter() - t0_) / leg_steps * 1e3, 4)
+            rec["steps"] = leg_steps
+            if tname == "rccl":
+                rec["backend"] = {"name": "rccl (librccl.so loaded by liblaser_hip.so; ncclCommInitAll + ncclAllGather per slab)",
+                                  "communicator_ranks": laser_amd.get_option("shard_rccl_ranks"), "devices": devices}
+        except Exception as e:
+            rec["error"] = f"{type(e).__name__}: {e}"[:200]
+        transports[tname] = rec
+    none_ms = transports["none"].get("ms_per_step")
+    for tname in ("peer", "rccl"):
+        if none_ms is not None and "ms_per_step" in transports[tname]:
+            transports[tname]["exposed_gather_ms"] = round(transports[tname]["ms_per_step"] - none_ms, 4)
+    call(Ap, Cs, ppd, gather)       # (leave every GPU holding all of C again, as after the timed region)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    slot_kernel = last_kernel_name(laser_amd)      # every slot multiplies the same panel shape under the same pinned tile class
     # roofline: the GEMM kernel alone on device slot 0 (its n-row share as one launch), HIP events on the launch stream
     torch.cuda.set_device(devices[0])
     Cl = torch.zeros((n, N), dtype=torch.float32, device=tdev[0])
@@ -447,6 +486,12 @@ def single_process_primary(args):
             "pct_of_fp32_mfma_peak": round(100.0 * value / 1e3 / (FP32_MFMA_PEAK_TFLOPS * ndev), 2),
             "calibration_untimed": calibration, "max_abs_err_vs_fp64": err,
             "device_slots": "all on GPU 0 (LASER_BENCH_ONE_GPU test hook: timings meaningless)" if one_gpu else devices,
+            "slots": [{"slot": g, "device": devices[g], "device_name": torch.cuda.get_device_name(devices[g]), "kernel": slot_kernel,
+                       "rows": ppd_used * rows, "panels": ppd_used} for g in range(ndev)],
+            "transports": transports,
+            "compute_only_ms": none_ms,
+            "exposed_gather_ms": None if none_ms is None else round(wall / args.steps * 1e3 - none_ms, 4),
+            "compute_only_gflops": None if none_ms is None else round(2.0 * M * N * K / (none_ms * 1e-3) / 1e9, 1),
         },
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -454,6 +499,8 @@ def single_process_primary(args):
                      "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": fl,
                      "note": "per-GPU kernel alone (device slot 0's row share as one launch), timed after the sharded run"},
     }
+    if not args.no_cpu_baseline:      # the reference's OpenMP path restated, on this box's host cores: stated beside every line, N > 1 too
+        out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
 
 
@@ -885,6 +932,8 @@ def main():
                                "algorithmic_flops_per_launch": fl,
                                "note": "per-GPU kernel alone (rank 0's row share as one launch), timed after the sharded run"}
             # (traffic stays null: the committed PMC passes profiled the single-GPU run's tile configuration)
+            if not args.no_cpu_baseline:      # stated beside every line, N > 1 too (the other ranks wait at the barrier below)
+                out["cpu_baseline"] = cpu_baseline()
         side = None
         if not args.no_single_process:
             if world == 1:

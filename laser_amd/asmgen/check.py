@@ -83,11 +83,11 @@ def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
              batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False, csc=1, pre=0, interleaved=False,
-             strided=False):
+             strided=False, mod=None):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart.
     G: workgroups of the (persistent) launch, default one per tile; split: cut tiles along K at slice boundaries (laser-order: kc;
     one chain: `split` K-tiles per slice) so that the G workgroups get equal numbers of units"""
-    g = K.make(name, **(over or {}))
+    g = (mod or K).make(name, **(over or {}))      # mod: another generator module with the f32 kernels' argument block (f32x16_kernel)
     g.build()
     c = g.c
     rng = np.random.default_rng(seed)
@@ -209,29 +209,37 @@ if __name__ == "__main__":
     sys.exit(0 if ok else 1)
 
 
-def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=None, verbose=True, bias=False, act=0):
-    """3x3 / stride 1 convolution kernels: every image through the interpreter, against im2col + the slice-ordered model"""
+def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=None, verbose=True, bias=False, act=0, kernel=(3, 3), stride=(1, 1)):
+    """implicit-GEMM convolution kernels (any kH x kW of up to Cfg.ntmax taps, any strides / zero padding / output width): every image
+    through the interpreter, against im2col (conv2d_im2col.nim:62-87) + the slice-ordered model"""
     g = K.make(name)
     g.build()
     c = g.c
     rng = np.random.default_rng(seed)
     pH, pW = (pad, pad) if isinstance(pad, int) else pad
-    oH, oW = H + 2 * pH - 2, W + 2 * pW - 2
+    kH, kW = (kernel, kernel) if isinstance(kernel, int) else kernel
+    sH, sW = (stride, stride) if isinstance(stride, int) else stride
+    assert kH * kW <= c.ntmax
+    oH, oW = (H + 2 * pH - kH) // sH + 1, (W + 2 * pW - kW) // sW + 1
     npix = oH * oW
     N = n_cut or npix
-    Kd = Cin * 9
+    Kd = Cin * kH * kW
+    Kp = (Kd + 3) // 4 * 4          # (the launcher pads the filter rows to whole 16-byte pieces with zeros when Cin*kH*kW % 4 != 0)
     x = rng.uniform(-0.1, 0.1, (images, Cin, H, W)).astype(np.float32)
     w = rng.uniform(-0.1, 0.1, (M, Kd)).astype(np.float32)
+    wp = np.zeros((M, Kp), dtype=np.float32)
+    wp[:, :Kd] = w
     out = np.full((images, M, npix), np.nan, dtype=np.float32)
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     mem = Memory()
     # the input is placed with nothing mapped directly before / after it: any access outside the tensor is an error
-    a_, b_, c_ = mem.alloc(w), mem.alloc(x), mem.alloc(out)
+    a_, b_, c_ = mem.alloc(wp), mem.alloc(x), mem.alloc(out)
     Bias = rng.uniform(-1, 1, M).astype(np.float32) if bias else None
     bias_ptr = mem.alloc(Bias) if bias else 0
-    ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, Kd, 0, npix, M, N, Kd, 1.0, 0.0, 0)
-    ka += struct.pack("<IIIIIIII", H, W, oW, pH, pW, Cin, npix, (1 << 32) // oW + 1)
-    ka += struct.pack("<IIQ", 0, 0, Cin * H * W * 4)
+    NT = kH * kW
+    ka = struct.pack("<QQQIIIIIIIIffQ", a_, b_, c_, K.magic_u32(NT), 0, Kp, 0, npix, M, N, Kp, 1.0, 0.0, 0)
+    ka += struct.pack("<IIIIIIII", H, W, oW, pH, pW, Cin, npix, K.magic_u32(oW))
+    ka += struct.pack("<IIQ", kH | kW << 8 | sH << 16 | sW << 24, NT | ((1024 + kW - 1) // kW) << 16, Cin * H * W * 4)
     ka += struct.pack("<Q", M * npix * 4)
     ka += struct.pack("<QIIII", bias_ptr, 1, 0, act, 0)
     ka += sched_bytes(tm, tn, tm * tn)        # one tile per workgroup, tile rows fastest (an image's pixels stay together)
@@ -244,7 +252,7 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     for img in range(images):
         xp = np.zeros((Cin, H + 2 * pH, W + 2 * pW), dtype=np.float32)
         xp[:, pH:pH + H, pW:pW + W] = x[img]
-        Bm = np.stack([xp[ci, kh:kh + oH, kw:kw + oW].reshape(-1) for ci in range(Cin) for kh in range(3) for kw in range(3)])
+        Bm = np.stack([xp[ci, kh:kh + (oH - 1) * sH + 1:sH, kw:kw + (oW - 1) * sW + 1:sW].reshape(-1) for ci in range(Cin) for kh in range(kH) for kw in range(kW)])
         want = reference(w, Bm, 512 if c.exact else 0)
         if Bias is not None:
             want = (want + Bias[:, None]).astype(np.float32)
@@ -257,7 +265,7 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
             print("  image", img, "first mismatches", bad[:6].tolist(), "count", len(bad))
             break
     if verbose:
-        print(f"{name} images={images} Cin={Cin} {H}x{W} M={M} pad={pad} N={N}/{npix}: {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f} s)")
+        print(f"{name} images={images} Cin={Cin} {H}x{W} M={M} k={kH}x{kW} s={sH}x{sW} pad={pad} N={N}/{npix}: {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f} s)")
     return ok
 
 

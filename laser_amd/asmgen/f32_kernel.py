@@ -49,31 +49,36 @@ class Cfg:
         # drain, no prologue, no first-load latency, no burst of C stores between two tiles of a workgroup.
         self.pipe = (self.persistent and dtype == "f32" and not conv and not pre and not deep and not debug) if pipe is None else pipe
         assert not (self.pipe and (not self.persistent or deep or debug or pre))
-        f64 = dtype == "f64"
+        f64, x16 = dtype == "f64", dtype == "f32x16"
         # f32: v_mfma_f32_32x32x2 (32x32 blocks, 2 k per instruction, one 16-byte fragment read feeds 4 k-steps);
-        # f64: v_mfma_f64_16x16x4 (16x16 blocks, 4 k per instruction, one 16-byte read feeds 2 k-steps): 8 k per group either way
-        self.MB, self.KSTEP, self.KREAD, self.ACCR, self.ESZ = (16, 4, 2, 8, 8) if f64 else (32, 2, 4, 16, 4)
+        # f64: v_mfma_f64_16x16x4 (16x16 blocks, 4 k per instruction, one 16-byte read feeds 2 k-steps): 8 k per group either way;
+        # f32x16 (f32x16_kernel.py): v_mfma_f32_16x16x4 (16x16 blocks, 4 k per instruction, one 16-byte read feeds 4 k-steps: 16 k per group)
+        self.MB, self.KSTEP, self.KREAD, self.ACCR, self.ESZ = (16, 4, 2, 8, 8) if f64 else (16, 4, 4, 4, 4) if x16 else (32, 2, 4, 16, 4)
         self.KC = 256 if f64 else 512    # gemm_tiling.nim:310: kc = 2048 / sizeof(T)
-        self.RS = 144 if f64 else BK * 4  # bytes of one panel row in LDS (f64: 128 + 16 of padding: conflict-free b128 reads)
+        # bytes of one panel row in LDS (f64 / f32x16: 128 + 16 of padding: conflict-free b128 reads without a swizzle)
+        self.RS = 144 if f64 else (BK * 4 + 16) if x16 else BK * 4
         self.WTM, self.WTN = BM // 2, BN // 2
         self.TM, self.TN = self.WTM // self.MB, self.WTN // self.MB
         self.NB = self.TM * self.TN
-        self.NG = BK // 8            # fragment groups (8 k each) per K-tile
+        self.NG = BK // (16 if x16 else 8)            # fragment groups (8 k each; f32x16: 16 k) per K-tile
         self.NMF = self.NB * (BK // self.KSTEP)  # MFMAs per K-tile per wave
         self.GM = self.NMF // self.NG   # MFMAs per group
         self.STAGE = (BM + BN) * self.RS
         self.NPA = BM * BK * self.ESZ // 16 // 256   # 16-byte pieces of A per thread per tile
         self.NPB = BN * BK * self.ESZ // 16 // 256
-        # implicit-GEMM convolution (3x3, stride 1, any zero padding): B is the NCHW image; a piece = 2 output pixels per
-        # lane of one k = (channel, kernel row, kernel column), gathered by two dword loads whose per-lane offsets come
-        # from a 10-entry table in LDS (one entry per kernel tap + "nothing"), indexed by the wave-uniform tap
+        # implicit-GEMM convolution (round 6: any kH x kW of up to `ntmax` taps, strides 1 .. 255, any zero padding, any output
+        # width -- conv2d_im2col.nim:42-88 is generic in all of them): B is the NCHW image; a piece = 2 output pixels per lane of one
+        # k = (channel, kernel row, kernel column), gathered by two dword loads whose per-lane offsets come from a table in LDS (one
+        # entry per kernel tap + "nothing"), indexed by the wave-uniform tap.  The table is sized at generation time: 31 taps beside
+        # the 3 x 48 KiB stages of the 256-row tile (5 x 5, 3 x 7 ...), 49 (7 x 7) beside the smaller tiles
         self.conv = conv
-        self.TAB_ENTRY, self.TAB_E1 = 256, 2560          # bytes per table entry (64 lanes x 4), offset of the second pixel's table
+        self.ntmax = (31 if BM >= 256 else 49) if conv else 0
+        self.TAB_ENTRY, self.TAB_E1 = 256, 256 * (self.ntmax + 1)   # bytes per table entry (64 lanes x 4), offset of the second pixel's table
         self.LDS0 = 2 * self.TAB_E1 if conv else 0       # the table sits below the stage ring (ds_read_addtid reaches 64 KiB)
         if conv:
             assert (BN, BK) == (128, 32) and not b_kcontig
             self.NPB = 8
-        assert self.NPB % 2 == 0 or b_kcontig
+        assert self.NPB % 2 == 0 or b_kcontig or dtype != "f32"
         self.KC_TILES = self.KC // BK
         self.bar_gap = bar_gap if bar_gap is not None else (self.NMF - self.GM - 1)
         self.w_start, self.w_step = w_start, w_step
@@ -114,13 +119,13 @@ CONFIGS = {
     "exact_64x64x32_nt": dict(BM=64, BN=64, BK=32, exact=True, b_kcontig=True),
     "fast_64x64x32_nt": dict(BM=64, BN=64, BK=32, exact=False, b_kcontig=True),
     # implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (benchmarks/convolution/conv2d_im2col.nim)
-    "conv3x3_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True),
-    "conv3x3_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True),
+    "conv_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True),
+    "conv_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True),
     # fewer output channels: 128 / 64 rows of the same pixel tile (the B side -- the gather -- is unchanged)
-    "conv3x3_exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True, conv=True),
-    "conv3x3_fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False, conv=True),
-    "conv3x3_exact_64x128x32": dict(BM=64, BN=128, BK=32, exact=True, conv=True),
-    "conv3x3_fast_64x128x32": dict(BM=64, BN=128, BK=32, exact=False, conv=True),
+    "conv_exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True, conv=True),
+    "conv_fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False, conv=True),
+    "conv_exact_64x128x32": dict(BM=64, BN=128, BK=32, exact=True, conv=True),
+    "conv_fast_64x128x32": dict(BM=64, BN=128, BK=32, exact=False, conv=True),
     "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
     # one round of 128x128 tiles (129 .. 256 of them: 1920^3, 2048^3): a workgroup has its CU to itself, and the 16-deep K-tile of
@@ -224,10 +229,10 @@ class Gen:
             scr = S(16, align=4)
             self.s_scr = scr
             self.s_koff = [scr[i] for i in range(8)]       # per piece: (c*H*W + kh*W + kw) * 4 of the k it gathers
-            self.s_c0, self.s_r0 = S(), S()                # (channel, kh*3 + kw) of this wave's first k in the tile being loaded
-            self.s_rowm = [S(2) for _ in range(3)]         # prologue: lanes whose input row oh + kh - pH exists
-            self.s_c0m, self.s_c1m = S(2), S(2)            # prologue: lanes whose first / second pixel's column ow (+1) + kw - pW exists
-            self.s_m, self.s_m2 = S(2), S(2)
+            self.s_k0 = S()                                # this wave's first k (= c * taps + kh * kW + kw) in the tile being loaded
+            self.s_NT, self.s_kW, self.s_M10 = S(), S(), S()   # taps kH * kW; kW; ceil(1024 / kW): r / kW = (r * M10) >> 10 for r < 49
+            self.s_pok = [S(2), S(2)]                      # prologue: lanes whose first / second output pixel exists (ragged last tile)
+            self.s_m = S(2)
             self.s_HW4, self.s_W4, self.s_Cin = S(), S(), S()
             self.s_sc = scr.sub(0, 8)                      # (the scheduler constants are dead before conv_setup loads the geometry)
         elif c.b_kcontig:
@@ -855,12 +860,9 @@ class Gen:
         if c.conv:
             self.conv_setup()
             if c.debug:
-                for kh in range(3):
-                    self.dump(f"conv rowm[{kh}].lo", self.s_rowm[kh][0])
                 for r_ in range(0, 20, 4):
                     self.dump_lds(f"tab[{r_ * 256}+4tid]", r_ * 256)
-                self.dump("conv c0", self.s_c0)
-                self.dump("conv r0", self.s_r0)
+                self.dump("conv k0", self.s_k0)
                 self.dump("conv HW4", self.s_HW4)
                 self.dump("conv Cin", self.s_Cin)
                 self.dump("conv WB00", self.WB[0][0][2])
@@ -1163,68 +1165,96 @@ class Gen:
             self.load_B_piece(pj)
 
     # ------------------------------------------------------------------ implicit-GEMM convolution: the B operand
-    # B "matrix" [K = Cin*9][N = oH*oW] of image b is never materialised (conv2d_im2col.nim:62-87 builds it explicitly):
-    # element (k, pixel) = input[c][oh + kh - pH][ow + kw - pW], k = (c*3 + kh)*3 + kw.  One wave-instruction gathers one
-    # output pixel per lane of ONE k: lane l owns pixels n0 + 2l and n0 + 2l + 1 (two dword loads per piece).  The k part
-    # of the address is wave-uniform and rides in the load's SGPR offset; the pixel part is a per-lane constant
-    # (oh*W + ow)*4 -- or, where the tap falls into the zero padding (or beyond the image's pixels / K), the offset
-    # 0x80000000 that the bounds check rejects, so the load returns 0 without touching memory.  Which of the two depends
-    # on the tap (kh, kw), which is wave-uniform but changes every K-tile: the 9 (+1: "nothing") per-lane offset vectors
-    # live in LDS and ds_read_addtid_b32 (address = M0 + 4*lane, no VGPR, no VALU op) fetches the right one -- any VALU op
-    # in the loop costs ~11 cycles of matrix-pipe time (profiles/r03/asm_probe_v4_fillers.jsonl).  Wave w owns
+    # B "matrix" [K = Cin*kH*kW][N = oH*oW] of image b is never materialised (conv2d_im2col.nim:62-87 builds it explicitly):
+    # element (k, pixel) = input[c][oh*sH + kh - pH][ow*sW + kw - pW], k = (c*kH + kh)*kW + kw.  One wave-instruction gathers one
+    # output pixel per lane of ONE k: lane l owns pixels n0 + 2l and n0 + 2l + 1 (two dword loads per piece).  The k part of the
+    # address -- (c*H*W + kh*W + kw) * 4 -- is wave-uniform and rides in the load's SGPR offset; the pixel part is a per-lane
+    # constant (oh*sH*W + ow*sW) * 4 -- or, where the tap falls into the zero padding (or the pixel lies beyond the image, or k
+    # beyond K), the offset 0x80000000 that the bounds check rejects, so the load returns 0 without touching memory.  Which of
+    # the two depends on the tap (kh, kw), which is wave-uniform but changes every K-tile: the kH*kW (+1: "nothing") per-lane
+    # offset vectors live in LDS and ds_read_addtid_b32 (address = M0 + 4*lane, no VGPR, no VALU op) fetches the right one -- any
+    # VALU op in the loop costs ~11 cycles of matrix-pipe time (profiles/r03/asm_probe_v4_fillers.jsonl).  Kernel size, strides and
+    # padding are RUN-TIME values (round 6): they only shape the table (built once per tile by a scalar loop over the taps, the
+    # four waves taking every fourth tap) and the scalar tap arithmetic; the loop still has no vector instruction.  Wave w owns
     # k = 8w .. 8w+7 of every K-tile: pairs (k, k+2) per lane exactly like the GEMM's pair mode.
     CONV_DELTA = (0, 2, 1, 3, 4, 6, 5, 7)      # piece i = 2*pair + j gathers k = 8w + delta: pairs (0,2) (1,3) (4,6) (5,7)
 
     def conv_setup(self):
-        c, e, t, st, scr = self.c, self.p.emit, self.vt, self.s_t, self.s_scr
+        c, p, e, t, st, scr = self.c, self.p, self.p.emit, self.vt, self.s_t, self.s_scr
         B_ = self.ka0.sub(2, 2)
-        sH, sW, soW, spH, spW, sCin, sNpix, smagic, sshift = (scr[i] for i in range(9))
+        sH, sW, soW, spH, spW, sCin, sNpix, smagic, sgeo, snt = (scr[i] for i in range(10))
         e("s_load_dwordx8", scr.sub(0, 8), s(0, 2), KA_CONV0)
         e("s_load_dwordx4", scr.sub(8, 4), s(0, 2), KA_CONV1)
         e("s_load_dwordx2", scr.sub(12, 2), s(0, 2), KA_CONV2)
         e("s_waitcnt", lgkmcnt=0)
-        lane, pix, oh, ow, base, base4, tab = t[0], t[1], t[2], t[3], t[6], t[7], t[8]
+        # geometry word: kH | kW << 8 | strideH << 16 | strideW << 24; taps word: kH * kW | ceil(1024 / kW) << 16
+        e("s_bfe_u32", self.s_kW, sgeo, (8 << 16) | 8)
+        e("s_and_b32", self.s_NT, snt, 0xffff)
+        e("s_lshr_b32", self.s_M10, snt, 16)
+        e("s_bfe_u32", scr[14], sgeo, (8 << 16) | 16)         # strideH
+        e("s_lshr_b32", scr[15], sgeo, 24)                    # strideW
+        sSH, sSW = scr[14], scr[15]
+        lane, tab = t[0], t[1]
+        pix = [t[2], t[3]]
+        rowb, colb, base = [self.vT[0][0], self.vT[0][1]], [self.vT[0][2], self.vT[0][3]], [self.vT[0][4], self.vT[0][5]]
         e("v_and_b32", lane, 63, v(0))
-        e("v_lshl_add_u32", pix, lane, 1, self.s_n0)          # first of this lane's two output pixels
-        e("v_mul_hi_u32", oh, pix, smagic)
-        e("v_lshrrev_b32", oh, sshift, oh)                    # oh = pix / oW
-        e("v_mul_lo_u32", t[4], oh, soW)
-        e("v_sub_u32", ow, pix, t[4])                         # ow = pix % oW  (oW even: both pixels in one output row)
-        e("v_mul_lo_u32", t[4], oh, sW)
-        e("v_add_u32", t[4], t[4], ow)
-        e("v_lshlrev_b32", base, 2, t[4])                     # (oh*W + ow) * 4, relative to the window origin of pixel (0, 0)
-        e("v_add_u32", base4, 4, base)
         e("v_lshlrev_b32", tab, 2, lane)
-        e("v_cmp_gt_u32", self.s_m, sNpix, pix)               # pixels beyond the image (ragged last tile) gather nothing
-        for kh in range(3):
-            e("v_add_u32", t[5], kh, oh)
-            e("v_subrev_u32", t[5], spH, t[5])                # input row oh + kh - pH (as unsigned: negative = huge)
-            e("v_cmp_gt_u32", self.s_rowm[kh], sH, t[5])
+        e("s_cmp_eq_u32", smagic, 0)
+        e("s_cselect_b64", self.s_m, -1, 0)
+        for ee in range(2):
+            oh, ow = t[4], t[5]
+            e("v_lshl_add_u32", pix[ee], lane, 1, self.s_n0)      # this lane's output pixel ee: n0 + 2 * lane + ee
+            if ee:
+                e("v_add_u32", pix[ee], 1, pix[ee])
+            e("v_mul_hi_u32", oh, pix[ee], smagic)                # oh = pix / oW (the pair may straddle two output rows: odd widths)
+            e("v_cndmask_b32", oh, oh, pix[ee], self.s_m)         # (oW == 1 travels as magic 0: oh = pix)
+            e("v_mul_lo_u32", t[6], oh, soW)
+            e("v_sub_u32", ow, pix[ee], t[6])                     # ow = pix % oW
+            e("v_mul_lo_u32", t[6], oh, sSH)                      # oh * strideH
+            e("v_mul_lo_u32", t[7], ow, sSW)                      # ow * strideW
+            e("v_subrev_u32", rowb[ee], spH, t[6])                # input row of tap row 0 (as unsigned: negative = huge)
+            e("v_subrev_u32", colb[ee], spW, t[7])
+            e("v_mul_lo_u32", t[6], t[6], sW)
+            e("v_add_u32", t[6], t[6], t[7])
+            e("v_lshlrev_b32", base[ee], 2, t[6])                 # (oh*sH*W + ow*sW) * 4, relative to the window origin of pixel (0, 0)
+            e("v_cmp_gt_u32", self.s_pok[ee], sNpix, pix[ee])     # pixels beyond the image (ragged last tile) gather nothing
+        e("s_nop", 1)
+        # the table: entry r = kh * kW + kw holds, per lane and pixel, the base offset where the tap reads inside the image, the
+        # out-of-bounds offset elsewhere.  The same for the 4 waves (they own different k of the same 128 pixels): wave w writes the
+        # entries w, w + 4, ...; wave 0 also the "nothing" entry (index taps) that channels beyond Cin select
+        L_tap, L_tapd, L_non = p.label("tap"), p.label("tapsdone"), p.label("nonothing")
+        sr, skh, skw, soff = st[0], st[2], st[3], st[4]
+        e("s_mov_b32", sr, self.s_wave)
+        p.place(L_tap)
+        e("s_cmp_ge_u32", sr, self.s_NT)
+        e("s_cbranch_scc1", L_tapd)
+        e("s_mul_i32", skh, sr, self.s_M10)
+        e("s_lshr_b32", skh, skh, 10)                             # kh = r / kW
+        e("s_mul_i32", skw, skh, self.s_kW)
+        e("s_sub_u32", skw, sr, skw)                              # kw = r % kW
+        e("s_lshl_b32", soff, sr, 8)
+        e("v_add_u32", t[6], soff, tab)
+        for ee in range(2):
+            e("v_add_u32", t[4], skh, rowb[ee])
+            e("v_cmp_gt_u32", VCC, sH, t[4])                      # input row oh*sH + kh - pH exists
+            e("v_add_u32", t[5], skw, colb[ee])
+            e("v_cmp_gt_u32", self.s_m, sW, t[5])                 # input column exists
             e("s_nop", 1)
-            e("s_and_b64", self.s_rowm[kh], self.s_rowm[kh], self.s_m)
-        # the table is the same for the 4 waves (they own different k of the same 128 pixels): wave 0 writes it
-        skip = self.p.label("notab")
+            e("s_and_b64", self.s_m, self.s_m, VCC)
+            e("s_and_b64", self.s_m, self.s_m, self.s_pok[ee])
+            e("s_nop", 0)
+            e("v_cndmask_b32", t[7], self.v_oob, base[ee], self.s_m)
+            e("ds_write_b32", t[6], t[7], offset=ee * c.TAB_E1)
+        e("s_add_u32", sr, sr, 4)
+        e("s_branch", L_tap)
+        p.place(L_tapd)
         e("s_cmp_lg_u32", self.s_wave, 0)
-        e("s_cbranch_scc1", skip)
-        for kw in range(3):
-            e("v_add_u32", t[5], kw, ow)
-            e("v_subrev_u32", t[5], spW, t[5])                # input column of the first pixel, ow + kw - pW
-            e("v_cmp_gt_u32", self.s_c0m, sW, t[5])
-            e("v_add_u32", t[5], 1, t[5])                     # ... of the second pixel
-            e("v_cmp_gt_u32", self.s_c1m, sW, t[5])
-            e("s_nop", 1)
-            for kh in range(3):
-                r = 3 * kh + kw
-                e("s_and_b64", self.s_m, self.s_rowm[kh], self.s_c0m)
-                e("s_and_b64", self.s_m2, self.s_rowm[kh], self.s_c1m)
-                e("s_nop", 0)
-                e("v_cndmask_b32", t[4], self.v_oob, base, self.s_m)
-                e("v_cndmask_b32", t[9], self.v_oob, base4, self.s_m2)
-                e("ds_write_b32", tab, t[4], offset=r * c.TAB_ENTRY)
-                e("ds_write_b32", tab, t[9], offset=c.TAB_E1 + r * c.TAB_ENTRY)
-        e("ds_write_b32", tab, self.v_oob, offset=9 * c.TAB_ENTRY)
-        e("ds_write_b32", tab, self.v_oob, offset=c.TAB_E1 + 9 * c.TAB_ENTRY)
-        self.p.place(skip)
+        e("s_cbranch_scc1", L_non)
+        e("s_lshl_b32", soff, self.s_NT, 8)
+        e("v_add_u32", t[6], soff, tab)
+        e("ds_write_b32", t[6], self.v_oob)
+        e("ds_write_b32", t[6], self.v_oob, offset=c.TAB_E1)
+        p.place(L_non)
         e("s_waitcnt", lgkmcnt=0)
         e("s_barrier")
         # descriptor: base = B + b * bsB - (pH*W + pW) * 4 (the window origin of output pixel (0, 0), kernel tap (0, 0));
@@ -1260,37 +1290,36 @@ class Gen:
                 e("v_add_u32", self.WB[gi][ee][2], st[0], rr)
                 e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
                 e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
-        # running k state of this wave: k0 = 8w -> (c0, r0) = (k0 / 9, k0 % 9)
-        e("s_lshl_b32", st[0], self.s_wave, 3)
-        e("s_mul_i32", self.s_c0, st[0], 57)
-        e("s_lshr_b32", self.s_c0, self.s_c0, 9)
-        e("s_mul_i32", st[2], self.s_c0, 9)
-        e("s_sub_u32", self.s_r0, st[0], st[2])
+        # running k of this wave: 8w, + BK per K-tile
+        e("s_lshl_b32", self.s_k0, self.s_wave, 3)
 
     def conv_load_ops(self):
-        """per piece: [scalar tap state] [SGPR offset, table entry -> M0, the two offset vectors from LDS]; then, for every
-        piece, [the two gathers]; then the state moves on by BK.  Returns a list of op groups (one per MFMA gap)."""
+        """per piece: [scalar tap arithmetic] [SGPR offset, table entry -> M0, the two offset vectors from LDS]; then, for every
+        piece, [the two gathers]; then the state moves on by BK.  Returns a list of op groups (one per MFMA gap).
+        k -> channel c = k / taps (magic multiply: KA_TAB carries floor(2^32 / taps) + 1, 0 for one tap), r = k % taps,
+        kh = r / kW = (r * ceil(1024 / kW)) >> 10 (exact for r < 49), kw = r % kW."""
         c, st = self.c, self.s_t
+        mgNT = self.ka0[6]
         groups, loads = [], []
         for i in range(8):
             d = self.CONV_DELTA[i]
-            g1 = [("ins", "s_add_u32", (st[0], self.s_r0, d), {}),
-                  ("ins", "s_cmp_ge_u32", (st[0], 9), {}),
-                  ("ins", "s_cselect_b32", (st[2], 9, 0), {}),
-                  ("ins", "s_cselect_b32", (st[3], 1, 0), {}),
-                  ("ins", "s_sub_u32", (st[0], st[0], st[2]), {}),          # r = (r0 + delta) mod 9
-                  ("ins", "s_add_u32", (st[1], self.s_c0, st[3]), {}),      # c
-                  ("ins", "s_mul_i32", (st[2], st[0], 11), {}),
-                  ("ins", "s_lshr_b32", (st[2], st[2], 5), {}),             # kh = r / 3
-                  ("ins", "s_mul_i32", (st[3], st[2], 3), {}),
-                  ("ins", "s_sub_u32", (st[5], st[0], st[3]), {})]          # kw = r % 3
+            g1 = [("ins", "s_add_u32", (st[0], self.s_k0, d), {}),               # k
+                  ("ins", "s_mul_hi_u32", (st[1], st[0], mgNT), {}),
+                  ("ins", "s_cmp_eq_u32", (mgNT, 0), {}),
+                  ("ins", "s_cselect_b32", (st[1], st[0], st[1]), {}),           # c = k / taps
+                  ("ins", "s_mul_i32", (st[2], st[1], self.s_NT), {}),
+                  ("ins", "s_sub_u32", (st[0], st[0], st[2]), {}),               # r = k % taps
+                  ("ins", "s_mul_i32", (st[2], st[0], self.s_M10), {}),
+                  ("ins", "s_lshr_b32", (st[2], st[2], 10), {}),                 # kh = r / kW
+                  ("ins", "s_mul_i32", (st[3], st[2], self.s_kW), {}),
+                  ("ins", "s_sub_u32", (st[5], st[0], st[3]), {})]               # kw = r % kW
             g2 = [("ins", "s_mul_i32", (st[3], st[1], self.s_HW4), {}),
                   ("ins", "s_mul_i32", (st[4], st[2], self.s_W4), {}),
                   ("ins", "s_add_u32", (st[3], st[3], st[4]), {}),
                   ("ins", "s_lshl_b32", (st[4], st[5], 2), {}),
                   ("ins", "s_add_u32", (self.s_koff[i], st[3], st[4]), {}),  # (c*H*W + kh*W + kw) * 4
                   ("ins", "s_cmp_lt_u32", (st[1], self.s_Cin), {}),
-                  ("ins", "s_cselect_b32", (st[0], st[0], 9), {}),           # channels beyond Cin (k >= K): the "nothing" entry
+                  ("ins", "s_cselect_b32", (st[0], st[0], self.s_NT), {}),   # channels beyond Cin (k >= K): the "nothing" entry
                   ("ins", "s_lshl_b32", (M0, st[0], 8), {}),
                   ("ins", "s_nop", (0,), {}),                                # (S_MOV to M0 -> LDS add-TID instruction: 1 wait state)
                   ("ldsr", "ds_read_addtid_b32", (self.vB0[i],), {}, ("T", i)),
@@ -1298,13 +1327,7 @@ class Gen:
             groups += [g1, g2]
             loads.append([("lgwait", {("T", i)}), ("loadBc", i, 0), ("loadBc", i, 1)])
         groups += loads
-        groups.append([("ins", "s_add_u32", (self.s_r0, self.s_r0, c.BK % 9), {}),
-                       ("ins", "s_add_u32", (self.s_c0, self.s_c0, c.BK // 9), {}),
-                       ("ins", "s_cmp_ge_u32", (self.s_r0, 9), {}),
-                       ("ins", "s_cselect_b32", (st[2], 9, 0), {}),
-                       ("ins", "s_cselect_b32", (st[3], 1, 0), {}),
-                       ("ins", "s_sub_u32", (self.s_r0, self.s_r0, st[2]), {}),
-                       ("ins", "s_add_u32", (self.s_c0, self.s_c0, st[3]), {})])
+        groups.append([("ins", "s_add_u32", (self.s_k0, self.s_k0, c.BK), {})])
         return groups
 
     def conv_store_ops(self, k):

@@ -336,6 +336,12 @@ class Workgroup:
                  "s_xor_b32": x ^ y, "s_andn2_b32": x & ~y}[op] & 0xffffffff
             sw(A[0], r)
             w.scc = int(r != 0)
+        elif op == "s_bfe_u32":
+            x, y = rs(w, A[1]), rs(w, A[2])
+            off, width = y & 31, (y >> 16) & 0x7f
+            r = (x >> off) & ((1 << width) - 1) if width else 0
+            sw(A[0], r)
+            w.scc = int(r != 0)
         elif op == "s_subb_u32":
             x, y = rs(w, A[1]), rs(w, A[2])
             r = x - y - w.scc
@@ -532,6 +538,49 @@ class Workgroup:
             for r in range(16):
                 arr[D.idx + r] = u32(Ct[(r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5), lanes & 31])
                 w.mfma_wr[(D.kind, D.idx + r)] = w.state
+            w.n_mfma += 1
+            w.stats["mfma"] += 1
+        elif op == "v_mfma_f32_16x16x4_f32":
+            # D[i][j] += fmaf chain over k = 0..3 (ascending) of A[i][k] * B[k][j]; lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and
+            # D[4 * (l / 16) + d][l % 16] for d = 0..3 (one register each); 8 passes, 40 cycles until a dependent MFMA
+            cost = 8
+            D, SA, SB, SC = A
+            assert D.n == 4 and SA.n == 1 and SB.n == 1
+            if self.check:
+                for r_ in (SA, SB):
+                    k = (r_.kind, r_.idx)
+                    if k in w.valu_wr_state and w.state - w.valu_wr_state[k] < 2:
+                        raise SimError(f"wave {w.wid} pc {w.pc}: MFMA reads {r_} right after a VALU wrote it")
+            av = f32(rv(w, SA))
+            bv = f32(rv(w, SB))
+            lanes = np.arange(LANES)
+            Ct = np.zeros((16, 16), dtype=np.float32)
+            if isinstance(SC, Reg):
+                assert SC.n == 4
+                self._chk_pending(w, SC.regs())
+                arr = w.v if SC.kind == "v" else w.a
+                if self.check:
+                    for kk in SC.regs():
+                        if kk in w.mfma_wr and w.state - w.mfma_wr[kk] < 10 and not (SC.kind == D.kind and SC.idx == D.idx):
+                            raise SimError(f"wave {w.wid} pc {w.pc}: MFMA srcC overlaps a different in-flight MFMA result")
+                        if SC.kind == D.kind and SC.idx == D.idx and kk in w.mfma_wr and w.state - w.mfma_wr[kk] < 8:
+                            raise SimError(f"wave {w.wid} pc {w.pc}: back-to-back dependent 16x16x4 MFMAs on {D} (40-cycle dependent latency: the matrix pipe would idle)")
+                        if kk in w.valu_wr_state and w.state - w.valu_wr_state[kk] < 3:
+                            raise SimError(f"wave {w.wid} pc {w.pc}: MFMA srcC {SC} read {w.state - w.valu_wr_state[kk]} states after a VALU wrote it")
+                cm = f32(arr[SC.idx:SC.idx + 4].copy())  # [d][lane]
+                for d in range(4):
+                    Ct[4 * (lanes >> 4) + d, lanes & 15] = cm[d]
+            else:
+                assert int(SC) == 0
+            for kk in range(4):
+                arow = av[16 * kk:16 * kk + 16]  # A[i][k]: lane i + 16k
+                bcol = bv[16 * kk:16 * kk + 16]  # B[k][j]: lane j + 16k
+                Ct = fma32(arow[:, None] * np.ones((1, 16), np.float32), np.ones((16, 1), np.float32) * bcol[None, :], Ct)
+            arr = w.v if D.kind == "v" else w.a
+            self._chk_waw(w, D.regs())
+            for d in range(4):
+                arr[D.idx + d] = u32(Ct[4 * (lanes >> 4) + d, lanes & 15])
+                w.mfma_wr[(D.kind, D.idx + d)] = w.state
             w.n_mfma += 1
             w.stats["mfma"] += 1
         elif op == "v_mfma_i32_32x32x32_i8":

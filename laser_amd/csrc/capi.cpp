@@ -1571,7 +1571,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "split_tail") g_split_tail = on;
   else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 3 ? 3 : value;
   else if (n == "asm_kernel") g_asm_kernel = value < 0 ? -1 : value;
-  else if (n == "asm_tile") g_asm_tile = value < 0 || value > 4 ? -1 : value;
+  else if (n == "asm_tile") g_asm_tile = value < 0 || value > 6 ? -1 : value;
   else if (n == "im2col_band") g_im2col_band = value < 0 ? 0 : value;
   else if (n == "asm_wgs") g_asm_wgs = value < 0 ? 0 : value;
   else if (n == "asm_slice") g_asm_slice = value < 0 ? 0 : value;
@@ -1619,6 +1619,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "last_asm_slices") *value = g_last_asm_slices;
   else if (n == "last_asm_group_m") *value = g_last_asm_group_m;
   else if (n == "asm_fixup_timeouts") *value = asm_fixup_timeouts();
+  else if (n == "shard_rccl_ranks") *value = api_shard_rccl_ranks();
   else if (n == "slice_parallel") *value = g_ctx.slice_parallel;
   else if (n == "slice_parallel_min") *value = g_ctx.slice_parallel_min;
   else if (n == "slice_parallel_tiles") *value = g_ctx.slice_parallel_tiles;

@@ -16,6 +16,8 @@ int api_thread_device();
 void api_set_thread_f32_config(int cfg);
 // Tile-class pin of the hand-scheduled f32 kernels for the launches made BY THIS THREAD (option "asm_tile"'s values; -2 = none).
 void api_set_thread_asm_tile(int tile_class);
+// sharded.cpp: ranks of the RCCL communicator the last GATHER_RCCL call used (ncclCommCount); 0 = none yet
+int64_t api_shard_rccl_ranks();
 // sharded.cpp: host-pointer gemm_strided cut into one row range per GPU (ndev <= 0: every visible GPU)
 template <typename T>
 int api_sharded_host(int ndev, int64_t M, int64_t N, int64_t K, T alpha, const T *A, int64_t rsA, int64_t csA, const T *B,

@@ -30,7 +30,7 @@ std::atomic<int> g_last_f32_asm{0};  // diagnostics: 0 = compiler-scheduled kern
 
 std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model decides; 1 = one tile per workgroup only; 2 = the persistent plan with K-slice cuts whenever legal; 3 = the strided whole-tile plan whenever legal
 std::atomic<int> g_asm_kernel{-1};    // option "asm_kernel": force an index of kKernels (tuning sweeps); -1 = the model decides
-std::atomic<int> g_asm_tile{-1};      // option "asm_tile": pin a tile class of the f32 GEMM kernels (0 = 256x128 / 256x256, 1 = 256x128 one chain, 2 = 128x128x16, 3 = 128x128x32, 4 = 64x64; -1 = the model decides)
+std::atomic<int> g_asm_tile{-1};      // option "asm_tile": pin a tile class of the f32 GEMM kernels (0 = 256x128 / 256x256, 1 = 256x128 one chain, 2 = 128x128x16, 3 = 128x128x32, 4 = 64x64, 5 = 96x96 on 16x16 blocks, 6 = 160x96 on 16x16 blocks; -1 = the model decides)
 thread_local int tl_asm_tile = -2;    // the same pin for the launches made BY THIS THREAD (-2 = none: the option applies); asm_set_thread_tile
 std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persistent launch (0 = every slot of the chip)
 std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
@@ -68,21 +68,25 @@ struct KernelInfo {
 // 129 .. 256 tiles, where a workgroup has its CU to itself
 // [34..45]: fused prologue (relu on A's and / or B's elements in the staging registers): `_pre` variants of [0] [4] [1] [5] [2] [6] [3]
 // [7] [12] [14] [13] [15], one tile per workgroup
-constexpr int kNumKernels = 46;
+// [46..53]: float32 on 16x16 blocks (v_mfma_f32_16x16x4_f32; laser_amd/asmgen/f32x16_kernel.py): tiles whose sides are multiples of 32
+// -- 96x96 (laser-order / one chain, plain / B transposed) and 160x96 (same) -- for the problems the 32x32-block tiles quantise badly:
+// the reference's own benchmark shape 1920^3 (gemm_bench_float32.nim:383-410) is 240 tiles of 160x96 against 225 of 128x128 on 256
+// CUs; 1536^3 is 256 tiles of 96x96 against 144 of 128x128
+constexpr int kNumKernels = 54;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0, 1},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0, 1},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.935, 6.0, 2},      {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.945, 6.0, 2},
     {"lh_f32_exact_256x128x32_nt", 256, 128, 32, 0.965, 0.965, 10.0, 1}, {"lh_f32_fast_256x256x16_nt", 256, 256, 16, 0.98, 0.98, 12.0, 1},
     {"lh_f32_exact_128x128x16_nt", 128, 128, 16, 0.95, 0.935, 6.0, 2},   {"lh_f32_fast_128x128x16_nt", 128, 128, 16, 0.96, 0.945, 6.0, 2},
     {"lh_f32_fast_256x128x32", 256, 128, 32, 0.97, 0.97, 10.0, 1},       {"lh_f32_fast_256x128x32_nt", 256, 128, 32, 0.97, 0.97, 10.0, 1},
-    {"lh_f32_conv3x3_exact_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1}, {"lh_f32_conv3x3_fast_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1},
+    {"lh_f32_conv_exact_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1}, {"lh_f32_conv_fast_256x128x32", 256, 128, 32, 0.88, 0.88, 15.0, 1},
     {"lh_f32_exact_64x64x32", 64, 64, 32, 0.90, 0.84, 3.0, 3},           {"lh_f32_fast_64x64x32", 64, 64, 32, 0.91, 0.85, 3.0, 3},
     {"lh_f32_exact_64x64x32_nt", 64, 64, 32, 0.90, 0.84, 3.0, 3},        {"lh_f32_fast_64x64x32_nt", 64, 64, 32, 0.91, 0.85, 3.0, 3},
     {"lh_f64_exact_128x128x16", 128, 128, 16, 0.937, 0.945, 8.0, 1},     {"lh_f64_fast_128x128x16", 128, 128, 16, 0.965, 0.97, 8.0, 1},
     {"lh_f64_exact_64x64x16", 64, 64, 16, 0.915, 0.815, 3.0, 2},         {"lh_f64_fast_64x64x16", 64, 64, 16, 0.93, 0.83, 3.0, 2},
     {"lh_i32_128x128x32", 128, 128, 32, 0.8, 0.8, 10.0, 1},
-    {"lh_f32_conv3x3_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1}, {"lh_f32_conv3x3_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1},
-    {"lh_f32_conv3x3_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},  {"lh_f32_conv3x3_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},
+    {"lh_f32_conv_exact_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1}, {"lh_f32_conv_fast_128x128x32", 128, 128, 32, 0.8, 0.8, 12.0, 1},
+    {"lh_f32_conv_exact_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},  {"lh_f32_conv_fast_64x128x32", 64, 128, 32, 0.72, 0.72, 8.0, 2},
     {"lh_f64_exact_128x128x16_nt", 128, 128, 16, 0.937, 0.945, 8.0, 1},   {"lh_f64_fast_128x128x16_nt", 128, 128, 16, 0.965, 0.97, 8.0, 1},
     {"lh_f64_exact_64x64x16_nt", 64, 64, 16, 0.915, 0.815, 3.0, 2},       {"lh_f64_fast_64x64x16_nt", 64, 64, 16, 0.93, 0.83, 3.0, 2},
     {"lh_i64_64x64x32", 64, 64, 32, 0.7, 0.7, 10.0, 1},
@@ -93,7 +97,11 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_128x128x16_pre", 128, 128, 16, 0.90, 0.86, 6.0, 2},   {"lh_f32_exact_128x128x16_pre_nt", 128, 128, 16, 0.90, 0.86, 6.0, 2},
     {"lh_f32_fast_128x128x16_pre", 128, 128, 16, 0.91, 0.87, 6.0, 2},    {"lh_f32_fast_128x128x16_pre_nt", 128, 128, 16, 0.91, 0.87, 6.0, 2},
     {"lh_f32_exact_64x64x32_pre", 64, 64, 32, 0.84, 0.74, 3.0, 3},       {"lh_f32_exact_64x64x32_pre_nt", 64, 64, 32, 0.84, 0.74, 3.0, 3},
-    {"lh_f32_fast_64x64x32_pre", 64, 64, 32, 0.85, 0.76, 3.0, 3},        {"lh_f32_fast_64x64x32_pre_nt", 64, 64, 32, 0.85, 0.76, 3.0, 3}};
+    {"lh_f32_fast_64x64x32_pre", 64, 64, 32, 0.85, 0.76, 3.0, 3},        {"lh_f32_fast_64x64x32_pre_nt", 64, 64, 32, 0.85, 0.76, 3.0, 3},
+    {"lh_f32x16_exact_96x96x32", 96, 96, 32, 0.90, 0.90, 6.0, 1},        {"lh_f32x16_fast_96x96x32", 96, 96, 32, 0.91, 0.91, 6.0, 1},
+    {"lh_f32x16_exact_96x96x32_nt", 96, 96, 32, 0.90, 0.90, 6.0, 1},     {"lh_f32x16_fast_96x96x32_nt", 96, 96, 32, 0.91, 0.91, 6.0, 1},
+    {"lh_f32x16_exact_160x96x32", 160, 96, 32, 0.93, 0.93, 8.0, 1},      {"lh_f32x16_fast_160x96x32", 160, 96, 32, 0.94, 0.94, 8.0, 1},
+    {"lh_f32x16_exact_160x96x32_nt", 160, 96, 32, 0.93, 0.93, 8.0, 1},   {"lh_f32x16_fast_160x96x32_nt", 160, 96, 32, 0.94, 0.94, 8.0, 1}};
 // plain kernel -> its `_pre` variant (-1: none)
 int pre_variant(int k) {
   switch (k) {
@@ -573,8 +581,11 @@ hipError_t choose_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, int c
   // products of a multi-GPU run that shares the CUs with RCCL's kernels.  One tile per workgroup then -- a persistent plan counts on
   // every workgroup slot of the chip -- and no lower bound on the tile count (the caller asked for THIS kernel family).
   const int tile_pin = asm_tile_pin_now();
-  const int classes[5] = {big, mid, small, deep, tiny};
-  for (int ci = 0; ci < 5; ci++) {
+  // 16x16-block tiles (f32x16_kernel.py): 16-byte pieces are all-or-nothing (K % 4 == 0), dense columns of C, plain epilogue
+  const bool x16_ok = a.K % 4 == 0 && a.csC == 1 && !fused && !pre;
+  const int x96 = x16_ok ? 46 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0) : -1, x160 = x16_ok ? x96 + 4 : -1;
+  const int classes[7] = {big, mid, small, deep, tiny, x96, x160};
+  for (int ci = 0; ci < 7; ci++) {
     const int k0 = classes[ci];
     if (tile_pin >= 0 && ci != (tile_pin == 1 && mid < 0 ? 0 : tile_pin)) continue;
     if (k0 < 0 || (g_asm_kernel >= 0 && k0 != g_asm_kernel)) continue;
@@ -925,9 +936,14 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a_in, bool laser_order, h
 
 // Implicit-GEMM convolution (conv2d_im2col.nim:102-166 minus the materialised im2col matrix): output pixels [0, a.N) of every
 // image, a.N a multiple of the 128-pixel tile or the whole image.  GemmArgs as launch_conv_implicit_f32 builds them (A = the
-// filter [M][K], B = the NCHW input, batch = images).  hipErrorNotSupported: not this kernel's class.
-hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipStream_t s) {
+// filter [M][K], B = the NCHW input, batch = images).  Round 6: any kernel of up to 49 taps (31 on the 256-row tile, whose LDS
+// holds the smaller tap table), any strides, any zero padding, any output width -- the reference's im2col is generic in all of
+// them (conv2d_im2col.nim:42-88) -- and any Cin: a filter matrix whose rows are not whole 16-byte pieces (K % 4 != 0, or a strided
+// view) is packed once into a zero-padded dense copy, which changes no bit (0 * 0 added to a chain).  hipErrorNotSupported: not
+// this kernel's class.
+hipError_t launch_conv_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hipStream_t s) {
   if (!g_f32_asm) return hipErrorNotSupported;
+  GemmArgs<float> a = a_in;
   if (a.col0 != 0 || a.cs_imgs != 0) return hipErrorNotSupported;
   if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
   // fused epilogue (laser_hip_conv2d_im2col_ex_f32: per-channel bias, relu) as in the GEMM kernels; tanh / sigmoid: the compiler kernels
@@ -935,20 +951,27 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (a.bias != nullptr && (a.rsBias < 0 || a.csBias < 0 || a.bsBias != 0 || a.rsBias > 0x3fffffff || a.csBias > 0x3fffffff ||
                             ((double)(a.M - 1) * a.rsBias + (double)(a.N - 1) * a.csBias + 1.0) * 4.0 >= 2147483648.0))
     return hipErrorNotSupported;
-  if (a.ckH != 3 || a.ckW != 3 || a.csH != 1 || a.csW != 1) return hipErrorNotSupported;
-  if (a.cpH < 0 || a.cpW < 0 || a.cpH > 64 || a.cpW > 64) return hipErrorNotSupported;
-  const int64_t oW = a.coW, oH = a.cH + 2 * a.cpH - 2, npix = oH * oW;
-  if (oW != a.cW + 2 * a.cpW - 2 || oW <= 0 || oH <= 0 || (oW & 1)) return hipErrorNotSupported;  // a lane's pixel pair stays in one output row
-  if (a.csA != 1 || a.rsA != a.K || a.csC != 1 || a.rsC != npix || a.K % 36 != 0 || a.K < 36) return hipErrorNotSupported;  // K = Cin * 9, a multiple of 4
+  const int64_t kH = a.ckH, kW = a.ckW, sH = a.csH, sW = a.csW, taps = kH * kW;
+  if (kH < 1 || kW < 1 || kH > 255 || kW > 255 || taps > 49 || sH < 1 || sW < 1 || sH > 255 || sW > 255) return hipErrorNotSupported;
+  if (a.cpH < 0 || a.cpW < 0 || a.cpH > 255 || a.cpW > 255) return hipErrorNotSupported;
+  if (a.cH + 2 * a.cpH < kH || a.cW + 2 * a.cpW < kW) return hipErrorNotSupported;
+  const int64_t oW = (a.cW + 2 * a.cpW - kW) / sW + 1, oH = (a.cH + 2 * a.cpH - kH) / sH + 1, npix = oH * oW;
+  if (oW != a.coW || oW <= 0 || oH <= 0) return hipErrorNotSupported;
+  if (a.K % taps != 0 || a.K < taps || a.csC != 1 || a.rsC != npix) return hipErrorNotSupported;
   if (a.N > npix || (a.N != npix && a.N % 128 != 0)) return hipErrorNotSupported;
   if (a.batch < 1 || a.batch > 65535 || a.M > 0xffff * 64ll) return hipErrorNotSupported;
-  const int64_t Cin = a.K / 9;
-  if ((double)Cin * a.cH * a.cW * 4.0 >= 2.0e9 || (double)a.M * npix * 4.0 >= 2.0e9 || (double)a.rsA * 4.0 * 256 >= 4.0e9) return hipErrorNotSupported;
+  const int64_t Cin = a.K / taps;
+  const int64_t Kp = (a.K + 3) / 4 * 4;          // filter rows as whole 16-byte pieces
+  if ((double)Cin * a.cH * a.cW * 4.0 >= 2.0e9 || (double)a.M * npix * 4.0 >= 2.0e9 || (double)Kp * 4.0 * 256 >= 4.0e9 ||
+      (double)Kp * (double)taps >= 4.0e9)      // (the in-kernel k / taps: x * d < 2^32)
+    return hipErrorNotSupported;
   const bool exact = laser_order && a.K > 512;
-  // rows of the tile by the number of output channels: the smallest padded row count, weighted by what each tile reaches
+  // rows of the tile by the number of output channels: the smallest padded row count, weighted by what each tile reaches (the
+  // 256-row tile's tap table ends at 31 taps)
   int pick = -1;
   double best_cost = 1e300;
   for (int base : {10, 21, 23}) {
+    if (base == 10 && taps > 31) continue;
     const KernelInfo &kc = kKernels[base];
     const double cost = (double)((a.M + kc.bm - 1) / kc.bm * kc.bm) / kc.eff;
     if (cost < 0.99 * best_cost) best_cost = cost, pick = base;
@@ -961,26 +984,43 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   if (g_f32_asm < 2 && tiles * a.batch < 5 * (int64_t)current_cus() / 8) return hipErrorNotSupported;
   // a 256-row tile that is mostly padding (few output channels) loses to the compiler-scheduled 128 / 64-row tiles
   if (g_f32_asm < 2 && (double)a.M * (double)a.N < 0.75 * (double)tiles * ki.bm * ki.bn) return hipErrorNotSupported;
+  if ((double)npix * (double)oW >= 4.0e9) return hipErrorNotSupported;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
+  // the filter matrix as dense rows of Kp elements: as given when it already is (the usual case: K % 4 == 0, contiguous), else one
+  // small packing pass into stream-ordered scratch (C_out x K floats: the first layer of a network has C_in = 3)
+  float *packed = nullptr;
+  if (a.csA != 1 || a.rsA != a.K || Kp != a.K) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return hipErrorNotSupported;
+    if (a.rsA < 0 || a.csA < 0) return hipErrorNotSupported;
+    e = scratch_alloc_async((void **)&packed, (size_t)a.M * Kp * 4, s);
+    if (e != hipSuccess) return e;
+    e = launch_pack_pad<float>(packed, a.M, Kp, a.A, a.M, a.K, a.rsA, a.csA, s, 0);
+    if (e != hipSuccess) {
+      (void)hipFreeAsync(packed, s);
+      return e == hipErrorInvalidValue ? hipErrorNotSupported : e;
+    }
+  }
   // (one image's tiles are few: plain order of the tile ids -- tile rows fastest, no XCD remap -- keeps an image's pixels together
   // in an XCD's L2)
   const int group_m = 0;
   KernArgs ka;
   zero_conv_fields(ka);
-  ka.A = a.A;
+  ka.A = packed ? packed : a.A;
   ka.B = a.B;
   ka.C = a.C;
-  ka.lda = (uint32_t)a.rsA;
+  ka.unused_ = (const uint32_t *)(uintptr_t)magic_u32((uint64_t)taps);   // f32_kernel.py conv_load_ops: k / taps (KA_TAB's low word)
+  ka.lda = (uint32_t)Kp;
   ka.ldb = 0;
   ka.ldc = (uint32_t)npix;
   ka.M = (uint32_t)a.M;
   ka.N = (uint32_t)a.N;
-  ka.K = (uint32_t)a.K;
+  ka.K = (uint32_t)Kp;
   ka.alpha = 1.0f;
   ka.beta = 0.0f;
   ka.H = (uint32_t)a.cH;
@@ -990,19 +1030,22 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a, bool laser_order, hipSt
   ka.pW = (uint32_t)a.cpW;
   ka.Cin = (uint32_t)Cin;
   ka.Npix = (uint32_t)npix;
-  ka.magic_oW = (uint32_t)((1ull << 32) / (uint64_t)oW + 1);   // floor(p / oW) = mulhi(p, magic) for p * oW < 2^32
-  ka.shift_oW = 0;
-  ka.pad_ = 0;
+  ka.magic_oW = magic_u32((uint64_t)oW);   // floor(p / oW) = mulhi(p, magic) for p * oW < 2^32; 0 for oW == 1 (the kernel then takes p)
+  ka.shift_oW = (uint32_t)(kH | kW << 8 | sH << 16 | sW << 24);     // geometry word (f32_kernel.py conv_setup)
+  ka.pad_ = (uint32_t)(taps | ((1024 + kW - 1) / kW) << 16);         // taps | ceil(1024 / kW) << 16: kh = (r * that) >> 10
   ka.bsB_bytes = (uint64_t)a.bsB * 4;
   ka.bsC_bytes = (uint64_t)a.bsC * 4;
   ka.bias = a.bias;
   ka.rsBias = a.bias ? (uint32_t)a.rsBias : 0;
   ka.csBias = a.bias ? (uint32_t)a.csBias : 0;
   ka.act = (uint32_t)a.act;
-  if ((double)npix * (double)oW >= 4.0e9) return hipErrorNotSupported;
   Plan plain;
   plain.G = tiles;
   e = launch_planned(m, pick, plain, ka, tiles_m, tiles_n, group_m, a.batch, 0, s);
+  if (packed) {
+    const hipError_t e2 = hipFreeAsync(packed, s);
+    if (e == hipSuccess) e = e2;
+  }
   if (e == hipSuccess) g_last_f32_asm = 1 + pick;
   return e;
 }

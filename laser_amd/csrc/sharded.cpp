@@ -240,6 +240,7 @@ struct Rccl {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*CommCount)(ncclComm_t_, int *) = nullptr;      // optional: what the communicator itself says its size is
   std::vector<int> devs;  // the device list the cached communicators were made for
   std::vector<ncclComm_t_> comms;
 };
@@ -262,6 +263,7 @@ int rccl_load() {
   LD(GroupEnd, "ncclGroupEnd")
   LD(GetErrorString, "ncclGetErrorString")
 #undef LD
+  *(void **)(&g_rccl.CommCount) = dlsym(h, "ncclCommCount");
   g_rccl.h = h;
   return LASER_HIP_OK;
 }
@@ -280,6 +282,18 @@ int rccl_comms(const std::vector<int> &dev) {
   g_rccl.devs = dev;
   return LASER_HIP_OK;
 }
+
+}  // namespace
+// option "shard_rccl_ranks" (read-only diagnostics): the number of ranks of the RCCL communicator the last GATHER_RCCL call used, as
+// the communicator reports it (ncclCommCount; the number of communicators made when the library lacks that symbol); 0 = none yet.
+// bench.py's N > 1 lines quote it, so that the line itself says whether the all-gather north_star names really spanned N GPUs.
+int64_t laser_hip::api_shard_rccl_ranks() {
+  if (g_rccl.comms.empty() || !g_rccl.comms[0]) return 0;
+  int n = 0;
+  if (g_rccl.CommCount && g_rccl.CommCount(g_rccl.comms[0], &n) == 0) return n;
+  return (int64_t)g_rccl.comms.size();
+}
+namespace {
 
 // A rank failed (or the bounded wait expired) while collectives may still be pending: abort every communicator so no
 // peer stays blocked inside ncclAllGather, and drop the cache -- the next call builds fresh communicators.

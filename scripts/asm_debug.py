@@ -22,7 +22,7 @@ g.build()
 c = g.c
 rng = np.random.default_rng(0)
 NIMG = 1
-if c.conv:   # usage: asm_debug.py conv3x3_... images Cin H W M pad
+if c.conv:   # usage: asm_debug.py conv_... images Cin H W M pad
     NIMG, Cin, H, W, M, pad = (int(x) for x in sys.argv[2:8]) if len(sys.argv) > 7 else (2, 8, 12, 16, 40, 1)
     oH, oW = H + 2 * pad - 2, W + 2 * pad - 2
     N, Kd = oH * oW, Cin * 9

@@ -156,6 +156,31 @@ def main():
              tflops=round(flops0 / (med * 1e-3) / 1e12, 2), frac_mfma_peak=round(flops0 / (med * 1e-3) / 1e12 / PEAK_TF, 4))
     laser_amd.set_float_mode(0)
     del out0
+    # round 6: the assembly implicit-GEMM loader beyond 3x3 / stride 1 -- the geometries the reference's im2col is
+    # generic in (conv2d_im2col.nim:42-88).  FLOPs as conv2d_common.nim:76-79; the bounding roofline of each line is stated (a 7x7
+    # stride-2 first layer writes 4 bytes per 294 flops with a 5-K-tile reduction: its tiles live in their prologue and epilogue).
+    # (parity of exactly these geometries, every element against the oracle: tests/test_gpu_parity.py
+    # test_assembly_conv_loader_any_kernel_stride_width)
+    for tag, ish, ksh, pd, sd in [("7x7 s2 pad3 3->64 224^2 (K = 147)", (32, 3, 224, 224), (64, 3, 7, 7), (3, 3), (2, 2)),
+                                  ("3x3 s2 pad1 128->256 56^2->28^2", (32, 128, 56, 56), (256, 128, 3, 3), (1, 1), (2, 2)),
+                                  ("5x5 s1 pad2 64->128 56^2", (32, 64, 56, 56), (128, 64, 5, 5), (2, 2), (1, 1)),
+                                  ("1x1 s1 256->512 28^2", (32, 256, 28, 28), (512, 256, 1, 1), (0, 0), (1, 1))]:
+        xg, wg = rnd(ish, 21, 0, 1), rnd(ksh, 22, 0, 1)
+        osh = laser_amd.conv2d_out_shape(ish, ksh, pd, sd)
+        og = torch.zeros(osh, device="cuda")
+        fl = 2.0 * osh[0] * osh[1] * osh[2] * osh[3] * ksh[1] * ksh[2] * ksh[3]
+        byts = 4.0 * (xg.numel() + wg.numel() + og.numel())
+        for mode in (0, 1):
+            laser_amd.set_float_mode(mode)
+            med, mn = ev_time(lambda: laser_amd.conv2d_im2col(og, osh, xg, ish, wg, ksh, pd, sd, None))
+            used = laser_amd.last_f32_asm()
+            rec = dict(config=f"conv {tag}, 32 images (implicit GEMM, any-geometry assembly loader)", mode="laser_order" if mode == 0 else "fast",
+                       ms_med=round(med, 4), ms_min=round(mn, 4), tflops=round(fl / (med * 1e-3) / 1e12, 2),
+                       frac_mfma_peak=round(fl / (med * 1e-3) / 1e12 / PEAK_TF, 4), hbm_gbps_algorithmic=round(byts / (med * 1e-3) / 1e9, 1),
+                       assembly_kernel=used, direct_pixel_tail=laser_amd.get_option("last_conv_tail"))
+            emit(**rec)
+        laser_amd.set_float_mode(0)
+        del xg, wg, og
     L = laser_amd.lib()
     med, mn = ev_time(lambda: L.laser_hip_im2col_f32_dev(ws.data_ptr(), 56, 56, x.data_ptr(), 32, 128, 56, 56, 3, 3, 1, 1, 1, 1,
                                                          torch.cuda.current_stream().cuda_stream), iters=9, inner=8)

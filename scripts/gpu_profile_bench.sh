@@ -13,7 +13,7 @@ timeout -k 5 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetc
 timeout -k 5 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 timeout -k 5 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- $BENCH > $OUT/pmc_tcc.log 2>&1
 python scripts/summarize_prof.py $OUT --skip 10 > $OUT/summary.md 2>&1
-python scripts/update_pmc_traffic.py $OUT "profiles/r05/rocprof_bench_$TAG/summary.md" > /dev/null 2>&1
+python scripts/update_pmc_traffic.py $OUT "profiles/r06/rocprof_bench_$TAG/summary.md" > /dev/null 2>&1
 for f in $(find $OUT/stats -name "*_kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
 grep -h '"metric"' $OUT/*.log | head -3 > $OUT/bench_lines_under_profiler.jsonl
 # keep the merged-back payload small: raw per-dispatch CSVs are large

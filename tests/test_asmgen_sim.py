@@ -232,11 +232,11 @@ def test_f64_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, 
 
 # (name, images, Cin, H, W, M, pad, n_cut): padding 1 / 0 / asymmetric / 2, the kc fold, ragged last pixel tile, pixel cut
 CONV_CASES = [
-    ("conv3x3_exact_256x128x32", 2, 8, 12, 16, 40, 1, None),
-    ("conv3x3_fast_256x128x32", 1, 4, 10, 12, 24, 0, None),
-    ("conv3x3_exact_256x128x32", 1, 64, 6, 8, 20, 1, None),                     # K = 576: a fold and a K tail
-    ("conv3x3_fast_256x128x32", 1, 20, 14, 20, 16, (0, 1), 128),                # main launch of a main + tail split
-    ("conv3x3_exact_256x128x32", 1, 12, 9, 18, 260, (2, 2), None),              # two row tiles, two pixel tiles (ragged)
+    ("conv_exact_256x128x32", 2, 8, 12, 16, 40, 1, None),
+    ("conv_fast_256x128x32", 1, 4, 10, 12, 24, 0, None),
+    ("conv_exact_256x128x32", 1, 64, 6, 8, 20, 1, None),                     # K = 576: a fold and a K tail
+    ("conv_fast_256x128x32", 1, 20, 14, 20, 16, (0, 1), 128),                # main launch of a main + tail split
+    ("conv_exact_256x128x32", 1, 12, 9, 18, 260, (2, 2), None),              # two row tiles, two pixel tiles (ragged)
 ]
 
 
@@ -246,9 +246,35 @@ def test_conv_kernels_bit_exact_in_the_interpreter(name, images, Cin, H, W, M, p
     assert C.run_conv_case(name, images, Cin, H, W, M, pad, n_cut=n_cut, verbose=False)
 
 
+# Round 6: kernel size, strides, padding and output width are RUN-TIME values of the convolution kernels (conv2d_im2col.nim:42-88 is
+# generic in all of them): the tap table is built by a scalar loop, the tap arithmetic of the loop is scalar.  (name, images, Cin, H, W,
+# M, pad, n_cut, kernel, stride): 5x5; the 7x7 stride-2 first layer (C_in = 3: K = 147, filter rows zero-padded to whole 16-byte
+# pieces); 3x3 stride 2 with odd output widths (a lane's pixel pair straddles two output rows); 1x1; non-square and even kernels;
+# 42 and 49 taps (the smaller tiles' table); the reference's stride-2 KAT geometry (conv2d_common.nim:188-283).
+CONV_GEOMETRY_CASES = [
+    ("conv_exact_256x128x32", 1, 8, 11, 13, 40, 2, None, 5, 1),
+    ("conv_fast_64x128x32", 1, 3, 20, 22, 20, 3, None, 7, 2),
+    ("conv_exact_128x128x32", 2, 24, 9, 9, 70, 1, None, 3, 2),
+    ("conv_fast_128x128x32", 1, 40, 6, 7, 30, 0, None, 1, 1),
+    ("conv_exact_256x128x32", 1, 6, 9, 15, 30, (0, 3), None, (1, 7), 1),
+    ("conv_exact_64x128x32", 1, 6, 15, 9, 30, (3, 0), None, (7, 1), (2, 1)),
+    ("conv_exact_256x128x32", 1, 70, 8, 8, 20, 1, None, (2, 4), (1, 2)),        # K = 560: a fold
+    ("conv_fast_128x128x32", 1, 2, 30, 31, 12, 2, None, (6, 7), 3),
+    ("conv_fast_128x128x32", 1, 2, 40, 45, 12, 2, 128, 7, (2, 3)),              # 49 taps, the main part of a cut launch
+    ("conv_exact_256x128x32", 1, 3, 5, 5, 2, 1, None, 3, 2),
+    ("conv_exact_64x128x32", 1, 16, 43, 4, 40, (2, 0), None, (1, 3), (2, 3)),   # output width 1 (found by scripts/fuzz_conv.py: pix / oW with oW == 1)
+]
+
+
+@pytest.mark.parametrize("name,images,Cin,H,W,M,pad,n_cut,kernel,stride", CONV_GEOMETRY_CASES,
+                         ids=[f"{c[0]}-{c[2]}x{c[3]}x{c[4]}-k{c[8]}-s{c[9]}" for c in CONV_GEOMETRY_CASES])
+def test_conv_kernels_any_geometry_in_the_interpreter(name, images, Cin, H, W, M, pad, n_cut, kernel, stride):
+    assert C.run_conv_case(name, images, Cin, H, W, M, pad, n_cut=n_cut, kernel=kernel, stride=stride, verbose=False)
+
+
 def test_conv_kernels_fused_bias_relu_in_the_interpreter():
-    assert C.run_conv_case("conv3x3_exact_256x128x32", 2, 8, 12, 16, 40, 1, bias=True, act=1, verbose=False)
-    assert C.run_conv_case("conv3x3_fast_64x128x32", 1, 64, 6, 8, 70, (0, 1), bias=True, act=0, verbose=False)
+    assert C.run_conv_case("conv_exact_256x128x32", 2, 8, 12, 16, 40, 1, bias=True, act=1, verbose=False)
+    assert C.run_conv_case("conv_fast_64x128x32", 1, 64, 6, 8, 70, (0, 1), bias=True, act=0, verbose=False)
 
 
 # float64 kernels (f64_kernel.py): integer-valued operands (exact in f64: the interpreter's f64 MFMA is mul + add)
@@ -312,3 +338,44 @@ def test_receivers_that_give_up_count_themselves_in_the_error_word():
     assert C.run_case("fast_64x64x32", 70, 40, 600, G=9, split=2, integer=True, beta=2.0, noseed=8, verbose=False) and C.run_case.last_error_word == 8
     assert C.run_case64("exact_64x64x16", 70, 40, 600, G=5, split=True, noseed=8, verbose=False) and C.run_case64.last_error_word == 3
     assert C.run_case("exact_64x64x32", 70, 90, 1100, G=5, split=True, verbose=False) and C.run_case.last_error_word == 0
+
+
+# Round 6: the 16x16-block tile family (laser_amd/asmgen/f32x16_kernel.py: v_mfma_f32_16x16x4_f32, tiles 96x96 and 160x96 -- the
+# reference's bench shape 1920^3 is 240 tiles of 160x96 on 256 CUs, gemm_bench_float32.nim:383-410).  Same checks as the 32x32-block
+# kernels: bit-exact against the slice-ordered fmaf model, folds, K tails (K % 32 != 0), ragged M / N, padded rows (NaN between them),
+# alpha / beta, B transposed, batches, persistent launches with K-slice hand-overs.
+X16_CASES = [
+    ("fast_96x96x32", 100, 110, 64, {}),
+    ("exact_96x96x32", 100, 110, 548, dict(lda=552, ldb=116, ldc=120)),
+    ("exact_96x96x32", 70, 90, 1060, dict(alpha=0.75, beta=-1.5, ldc=100)),
+    ("fast_96x96x32", 33, 130, 100, dict(alpha=3.0, beta=0.5)),
+    ("exact_96x96x32_nt", 97, 100, 524, dict(lda=528, ldb=532)),
+    ("fast_96x96x32_nt", 140, 30, 12, {}),
+    ("exact_160x96x32", 170, 100, 548, dict(ldc=104)),
+    ("fast_160x96x32", 161, 97, 36, dict(beta=2.0)),
+    ("exact_160x96x32_nt", 330, 200, 580, dict(alpha=-2.0, beta=1.0)),
+    ("fast_160x96x32_nt", 40, 50, 96, {}),
+    ("exact_96x96x32", 4, 4, 4, {}),
+    ("exact_96x96x32", 100, 110, 64, dict(batch=2)),
+    ("exact_96x96x32", 100, 200, 1100, dict(G=3, split=True)),
+    ("exact_96x96x32", 200, 200, 1100, dict(G=5, split=True, alpha=0.75, beta=-1.5, noseed=1)),
+    ("exact_96x96x32_nt", 200, 300, 1028, dict(G=8, split=True, two_level=True, group_m=2)),
+    ("fast_96x96x32", 100, 200, 300, dict(G=5, split=2, integer=True, beta=2.0)),
+    ("exact_160x96x32", 330, 200, 600, dict(G=3, split=True, group_m=1)),
+    ("exact_96x96x32", 200, 200, 96, dict(G=2, strided=True)),
+]
+
+
+@pytest.mark.parametrize("name,M,N,Kd,kw", X16_CASES, ids=[f"x16-{c[0]}-{c[1]}x{c[2]}x{c[3]}-{i}" for i, c in enumerate(X16_CASES)])
+def test_16x16_block_kernels_bit_exact_in_the_interpreter(name, M, N, Kd, kw):
+    from laser_amd.asmgen import f32x16_kernel as K16
+    assert C.run_case(name, M, N, Kd, verbose=False, mod=K16, **kw)
+
+
+def test_16x16_block_kernels_generate_within_the_register_and_lds_budget():
+    from laser_amd.asmgen import f32x16_kernel as K16
+    for name in K16.CONFIGS:
+        g = K16.make(name)
+        g.build()
+        assert g.p._v <= 256 and g.p._a <= 256 and g.p._s <= 100 and g.c.lds_alloc <= 160 * 1024, name
+        assert "v_mfma_f32_16x16x4_f32" in K16.kernel_text(g, "lh_test")

@@ -51,3 +51,50 @@ def test_bench_two_rank_path_on_one_gpu():
     assert cfg["compute_only_ms"] > 0 and abs(cfg["exposed_gather_ms"] - (out["ms_per_step"] - cfg["compute_only_ms"])) < 1e-3
     assert cfg["backend"]["world_size"] == 2 and len(cfg["backend"]["ranks"]) == 2
     assert all(r_["kernel"].startswith("lh_f32_exact_128x128x16") for r_ in cfg["backend"]["ranks"])
+
+
+N_GT_1_SINGLE_PROCESS_KEYS = {"transports", "slots", "compute_only_ms", "exposed_gather_ms", "compute_only_gflops", "gather", "panels_per_dev"}
+
+
+def check_single_process_line(out, ndev):
+    """what VERDICT r5 next #3 asks of the single-process N > 1 line: none / peer / rccl as three labelled timed figures with the
+    exposed gather per transport, the kernel and device of every slot, the RCCL leg's communicator size, and a cpu_baseline"""
+    cfg = out["config"]
+    assert KEYS <= set(out) and out["n_gpus"] == ndev and out["scaling"] == "weak"
+    assert N_GT_1_SINGLE_PROCESS_KEYS <= set(cfg), sorted(N_GT_1_SINGLE_PROCESS_KEYS - set(cfg))
+    tr = cfg["transports"]
+    assert set(tr) == {"none", "peer", "rccl"}
+    assert tr["none"]["ms_per_step"] > 0 and tr["peer"]["ms_per_step"] > 0
+    assert abs(tr["peer"]["exposed_gather_ms"] - (tr["peer"]["ms_per_step"] - tr["none"]["ms_per_step"])) < 1e-3
+    assert cfg["compute_only_ms"] == tr["none"]["ms_per_step"]
+    assert abs(cfg["exposed_gather_ms"] - (out["ms_per_step"] - cfg["compute_only_ms"])) < 1e-3
+    if "ms_per_step" in tr["rccl"]:      # a real multi-GPU box (or one device): the collective north_star names, timed and labelled
+        assert tr["rccl"]["backend"]["communicator_ranks"] == ndev and len(tr["rccl"]["backend"]["devices"]) == ndev
+        assert "exposed_gather_ms" in tr["rccl"]
+    else:                                # the one-GPU test hook: RCCL refuses two ranks per device, and the line says so
+        assert "skipped" in tr["rccl"] or "error" in tr["rccl"]
+    assert len(cfg["slots"]) == ndev
+    for g, sl in enumerate(cfg["slots"]):
+        assert sl["slot"] == g and isinstance(sl["device"], int) and sl["kernel"].startswith("lh_f32_") and sl["rows"] > 0
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_bench_single_process_two_slots_on_one_gpu():
+    env = dict(os.environ, LASER_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "1024",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _last_json(r.stdout)
+    check_single_process_line(out, 2)
+
+
+def test_committed_n8_single_process_line_carries_every_field():
+    """CPU: the committed N = 8 line (all eight device slots on one GPU through the test hook, BASELINE configs[4]'s own shape --
+    profiles/r06/bench_gpus8_one_process_one_gpu_hook_v2.json) parses and carries what the first real 8-GPU lease will be judged on"""
+    path = os.path.join(ROOT, "profiles", "r06", "bench_gpus8_one_process_one_gpu_hook_v2.json")
+    out = json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+    check_single_process_line(out, 8)
+    assert out["config"]["M"] == 65536 and out["config"]["N"] == 8192 and out["config"]["K"] == 8192
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
