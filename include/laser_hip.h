@@ -127,10 +127,14 @@ int laser_hip_f32_config_count(void);
  *                          two-run receive path, the tile rows per raster group (which tiles share an XCD's L2)
  *   "asm_tile"        [-1] pin a tile CLASS of the f32 assembly GEMM kernels (accumulation mode / transposed-B variant still follow the
  *                          call): 0 = 256x128 (laser-order) / 256x256, 1 = 256x128 one chain, 2 = 128x128x16 (two workgroups per CU:
- *                          degrades gracefully when another library's kernels -- RCCL's -- hold some CUs), 3 = 128x128x32, 4 = 64x64;
- *                          one tile per workgroup, no minimum tile count; -1 = the launcher's model decides.  The per-GPU processes
- *                          of laser_amd/distributed.py set 2 around their local products; LASER_HIP_SHARD_PIN_TILE is the same pin
- *                          per call and per worker thread inside the single-process sharded entry points
+ *                          degrades gracefully when another library's kernels -- RCCL's -- hold some CUs), 3 = 128x128x32, 4 = 64x64,
+ *                          5 = 96x96 and 6 = 160x96 on 16x16 blocks (v_mfma_f32_16x16x4_f32: K % 4 == 0, dense C, plain epilogue);
+ *                          one tile per workgroup, no minimum tile count; -1 = the launcher's model decides.
+ *   "thread_asm_tile" [-2] the same pin for the launches made BY THE CALLING THREAD only (-2 = none: "asm_tile" applies; -1 = the
+ *                          model decides whatever "asm_tile" says).  The per-GPU processes of laser_amd/distributed.py set 2 around
+ *                          their local products on the thread that launches them -- other threads' GEMMs keep their own choice;
+ *                          LASER_HIP_SHARD_PIN_TILE is the same pin per call and per worker thread inside the single-process
+ *                          sharded entry points
  *   "im2col_band"      [0] output pixels per workgroup band of the explicit im2col kernel (0 = 256 sixteen-byte vectors; tuning sweeps)
  * laser_hip_get_option reads any of them back, plus the read-only diagnostics of the last launch:
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)

@@ -188,6 +188,7 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &args, void *ws, hipStrea
 extern std::atomic<int> g_i32_asm, g_last_i32_asm;
 extern std::atomic<int> g_asm_tile;   // option "asm_tile" (gemm_f32_asm.cpp)
 void asm_set_thread_tile(int tile_class);   // per-thread pin of the same (-2 = none)
+int asm_get_thread_tile();
 int asm_tile_pin_now();                     // the pin this thread's launches see (-1 = none)
 extern std::atomic<int> g_last_asm_group_m;
 extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed, g_asm_group_m, g_asm_giveup;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)

@@ -40,6 +40,7 @@ std::atomic<int> g_asm_giveup{0};     // option "asm_test_giveup": 1 = every rec
 std::atomic<int> g_last_asm_wgs{0}, g_last_asm_slices{0}, g_last_asm_group_m{0};   // diagnostics: workgroups / K slices per tile of the last assembly launch
 
 void asm_set_thread_tile(int tile_class) { tl_asm_tile = tile_class; }
+int asm_get_thread_tile() { return tl_asm_tile; }
 int asm_tile_pin_now() { return tl_asm_tile >= -1 ? tl_asm_tile : (int)g_asm_tile; }
 
 namespace {

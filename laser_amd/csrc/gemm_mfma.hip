@@ -318,10 +318,16 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   g_last_split = plan.n_cut;
   // the main part (whole 128-pixel tiles, or the whole image) on the hand-scheduled assembly kernel when it is a 3x3 /
   // stride-1 convolution; hipErrorNotSupported = not its class: the compiler-scheduled loaders below
+  // (whether the assembly kernel took THIS call's main part is reported through a local: the process-wide diagnostic
+  // g_last_f32_asm may be overwritten by another host thread's launch between the launch and a read -- ADVICE r5)
+  bool main_on_asm = false;
   const auto main_launch = [&](const GemmArgs<float> &mm, hipStream_t q) {
     if (cfg < 0) {
       const hipError_t e = launch_conv_f32_asm(mm, laser_order, q);
-      if (e != hipErrorNotSupported) return e;
+      if (e != hipErrorNotSupported) {
+        main_on_asm = e == hipSuccess;
+        return e;
+      }
     }
     return launch_conv_cfg(mm, plan.cfg_main, exact, q);
   };
@@ -345,7 +351,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   if (cfg < 0 && g_conv_tail && g_split_tail) {
     if (hipError_t e = main_launch(m, s); e != hipSuccess) return e;
     main_done = true;
-    if (g_last_f32_asm != 0) {
+    if (main_on_asm) {
       const hipError_t e = launch_conv_tail_f32(t, 512, s);
       if (e != hipErrorNotSupported) {
         g_last_conv_tail = 1;

@@ -126,8 +126,10 @@ class ShardedGemm:
         if self._pin_tiles:
             from . import primitives
         if self._pin_tiles and cfg is None and self.world > 1:
-            prev_tile = primitives.get_option("asm_tile")     # the caller's own setting is restored, not clobbered
-            primitives.set_option("asm_tile", SHARDED_ASM_TILE)
+            # per THREAD (the process-wide option forced every other thread's f32 GEMMs onto this tile class for the
+            # duration of the run, and stayed set if the process died inside it); the caller's own setting is restored
+            prev_tile = primitives.get_option("thread_asm_tile")
+            primitives.set_option("thread_asm_tile", SHARDED_ASM_TILE)
         elif self._pin_tiles and cfg is not None:
             prev_cfg = primitives.get_f32_config()
             primitives.set_f32_config(cfg)
@@ -135,7 +137,7 @@ class ShardedGemm:
             works = self._run_panels(A_local, B, C_full)
         finally:
             if prev_tile is not None:
-                primitives.set_option("asm_tile", prev_tile)
+                primitives.set_option("thread_asm_tile", prev_tile)
             if prev_cfg is not None:
                 primitives.set_f32_config(prev_cfg)
         for w in works:

@@ -84,7 +84,7 @@ def test_panel_plan_covers_rows_once():
 
 
 def _pin_worker(rank, world, port, ret):
-    """ShardedGemm's default local product with the library mocked (no GPU here): the assembly tile pin (option "asm_tile" = 2) must be
+    """ShardedGemm's default local product with the library mocked (no GPU here): the assembly tile pin (option "thread_asm_tile" = 2: per thread) must be
     in force around every local product of a multi-rank run, the caller's own value must come back afterwards -- also when a product
     raises -- and a forced compiler configuration must be bracketed the same way."""
     sys.path.insert(0, ROOT)
@@ -94,7 +94,7 @@ def _pin_worker(rank, world, port, ret):
     try:
         import laser_amd.primitives as prim
         from laser_amd import distributed as D
-        state = {"asm_tile": 7, "cfg": -1}        # 7: a value of the caller's own that must survive
+        state = {"thread_asm_tile": 7, "cfg": -1}        # 7: a value of the caller's own that must survive
         seen = []
         prim.get_option = lambda name: state[name]
         prim.set_option = lambda name, v: state.__setitem__(name, int(v))
@@ -103,7 +103,7 @@ def _pin_worker(rank, world, port, ret):
         fail_after = {"n": None}
 
         def fake_matmul(A, B, alpha, beta, out):
-            seen.append((state["asm_tile"], state["cfg"]))
+            seen.append((state["thread_asm_tile"], state["cfg"]))
             if fail_after["n"] is not None and len(seen) > fail_after["n"]:
                 raise RuntimeError("injected")
             out.copy_(A @ B)
@@ -115,17 +115,17 @@ def _pin_worker(rank, world, port, ret):
         C = sg.alloc_C()
         out = sg.run(sg.shard_A(A), B, C)
         ok = torch.allclose(out, A @ B) and all(s_ == (D.SHARDED_ASM_TILE, -1) for s_ in seen) and len(seen) == 2
-        ok = ok and state == {"asm_tile": 7, "cfg": -1}
+        ok = ok and state == {"thread_asm_tile": 7, "cfg": -1}
         # a forced compiler configuration (tuning sweeps): bracketed, the tile option untouched
         seen.clear()
         sg2 = D.ShardedGemm(M, N, K, torch.float32, None, None, 2, tile_config=3)
         sg2.run(sg2.shard_A(A), B, sg2.alloc_C())
-        ok = ok and all(s_ == (7, 3) for s_ in seen) and state == {"asm_tile": 7, "cfg": -1}
+        ok = ok and all(s_ == (7, 3) for s_ in seen) and state == {"thread_asm_tile": 7, "cfg": -1}
         # the library heuristic asked for explicitly: nothing is set
         seen.clear()
         sg3 = D.ShardedGemm(M, N, K, torch.float32, None, None, 2, tile_config=-1)
         sg3.run(sg3.shard_A(A), B, sg3.alloc_C())
-        ok = ok and all(s_ == (7, -1) for s_ in seen) and state == {"asm_tile": 7, "cfg": -1}
+        ok = ok and all(s_ == (7, -1) for s_ in seen) and state == {"thread_asm_tile": 7, "cfg": -1}
         # a product that raises (on every rank, before any collective of that step): the pin is undone
         seen.clear()
         fail_after["n"] = 0
@@ -133,7 +133,7 @@ def _pin_worker(rank, world, port, ret):
             sg.run(sg.shard_A(A), B, sg.alloc_C())
             ok = False
         except RuntimeError:
-            ok = ok and state == {"asm_tile": 7, "cfg": -1}
+            ok = ok and state == {"thread_asm_tile": 7, "cfg": -1}
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

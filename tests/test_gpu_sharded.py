@@ -278,13 +278,34 @@ def test_asm_tile_option_selects_the_tile_class(la):
     A, B = _operands(2048, 2048, 1100, np.float32, seed=21)
     want = la.matmul(A, B)
     try:
-        for cls, asm_id in ((0, 1), (2, 3), (3, 31), (4, 13)):
+        for cls, asm_id in ((0, 1), (2, 3), (3, 31), (4, 13), (5, 47), (6, 51)):
             la.set_option("asm_tile", cls)
             got = la.matmul(A, B)
             assert la.last_f32_asm() == asm_id, (cls, la.last_f32_asm())
             assert torch.equal(got, want), cls
+        la.set_option("asm_tile", -1)
+        # "thread_asm_tile": the same pin for the calling thread only (what laser_amd/distributed.py sets around its local products,
+        # ADVICE r5): this thread's launches take the class, another thread's keep the model's choice
+        import threading
+        la.matmul(A, B)
+        free_choice = la.last_f32_asm()
+        la.set_option("thread_asm_tile", 4)
+        assert la.get_option("thread_asm_tile") == 4 and la.get_option("asm_tile") == -1
+        got = la.matmul(A, B)
+        assert la.last_f32_asm() == 13 and torch.equal(got, want)
+        seen = {}
+
+        def other():
+            torch.cuda.set_device(0)
+            seen["pin"] = la.get_option("thread_asm_tile")
+            seen["equal"] = bool(torch.equal(la.matmul(A, B), want))
+            seen["kernel"] = la.last_f32_asm()
+        th = threading.Thread(target=other)
+        th.start(); th.join()
+        assert seen == {"pin": -2, "equal": True, "kernel": free_choice}, (seen, free_choice)
     finally:
         la.set_option("asm_tile", -1)
+        la.set_option("thread_asm_tile", -2)
 
 
 def test_c5_shape_eight_slots_every_panel_sampled_vs_oracle(la):
