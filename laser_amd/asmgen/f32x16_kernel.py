@@ -405,7 +405,8 @@ class Gen16(Gen64):
                     e("v_mul_f32", tt, self.s_alpha, tt)
                     e("v_accvgpr_read_b32", uu, self.run[b][d])
                     e("v_add_f32", tt, uu, tt)
-                    e("buffer_store_dword", tt, self.vC[n], self.srdC, soff, offen=True)
+                    if "cstores" not in c.ablate:
+                        e("buffer_store_dword", tt, self.vC[n], self.srdC, soff, offen=True)
             self.c_rows(row)
         else:
             # one chain: C = beta * C0 + alpha * sum (beta == 0: C0 is never read, gemm_ukernel_generic.nim:59-66)

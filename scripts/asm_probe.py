@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from laser_amd.asmgen import f32_kernel as K  # noqa: E402
+from laser_amd.asmgen import f32x16_kernel as K16  # noqa: E402
 from laser_amd.asmgen import check as CHK  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
@@ -29,7 +30,7 @@ hip.hipModuleLaunchKernel.argtypes = [C.c_void_p] + [C.c_uint] * 6 + [C.c_uint, 
 
 
 def build(var, tmp):
-    g = K.make(var["kernel"], **var.get("over", {}))
+    g = (K16 if var.get("module") == "x16" else K).make(var["kernel"], **var.get("over", {}))      # "module": "x16" = the 16x16-block family
     g.build()
     sym = "lh_probe_" + "".join(ch if ch.isalnum() else "_" for ch in var["name"])   # one symbol per variant: rocprofv3 rows stay apart
     spath = os.path.join(tmp, var["name"] + ".s")
