@@ -49,7 +49,10 @@ ASM_KERNEL_SYMBOLS = [
     "lh_f32_exact_128x128x16_pre", "lh_f32_exact_128x128x16_pre_nt", "lh_f32_fast_128x128x16_pre", "lh_f32_fast_128x128x16_pre_nt",
     "lh_f32_exact_64x64x32_pre", "lh_f32_exact_64x64x32_pre_nt", "lh_f32_fast_64x64x32_pre", "lh_f32_fast_64x64x32_pre_nt",
     "lh_f32x16_exact_96x96x32", "lh_f32x16_fast_96x96x32", "lh_f32x16_exact_96x96x32_nt", "lh_f32x16_fast_96x96x32_nt",
-    "lh_f32x16_exact_160x96x32", "lh_f32x16_fast_160x96x32", "lh_f32x16_exact_160x96x32_nt", "lh_f32x16_fast_160x96x32_nt"]
+    "lh_f32x16_exact_160x96x32", "lh_f32x16_fast_160x96x32", "lh_f32x16_exact_160x96x32_nt", "lh_f32x16_fast_160x96x32_nt",
+    "lh_f32x16_exact_128x96x32", "lh_f32x16_fast_128x96x32", "lh_f32x16_exact_128x96x32_nt", "lh_f32x16_fast_128x96x32_nt",
+    "lh_f32x16_exact_192x96x32", "lh_f32x16_fast_192x96x32", "lh_f32x16_exact_192x96x32_nt", "lh_f32x16_fast_192x96x32_nt",
+    "lh_f32x16_exact_160x160x32", "lh_f32x16_fast_160x160x32", "lh_f32x16_exact_160x160x32_nt", "lh_f32x16_fast_160x160x32_nt"]
 ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerate(ASM_KERNEL_SYMBOLS)}
 COMPILER_KERNEL_NAME = "gemm_mfma_kernel<float,...> (compiler-scheduled)"
 

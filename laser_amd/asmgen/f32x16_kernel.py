@@ -35,6 +35,11 @@ CONFIGS = {
     "fast_160x96x32": dict(BM=160, BN=96, BK=32, exact=False),
     "exact_160x96x32_nt": dict(BM=160, BN=96, BK=32, exact=True, b_kcontig=True),
     "fast_160x96x32_nt": dict(BM=160, BN=96, BK=32, exact=False, b_kcontig=True),
+    # more sides for more problems (a tile is picked per problem, gemm_f32_asm.cpp): 128x96 (2 x 2 waves of 64x48 = 12 blocks:
+    # 1000x3000x2000 is 256 tiles of it), 192x96 (96x48 = 18 blocks: 3072^3 is 512 tiles = two exact rounds), 160x160 (80x80 = 25
+    # blocks, 100 + 100 accumulator registers, 135 KiB of LDS: 2560^3 is 256 tiles, 5120^3 four exact rounds)
+    **{f"{ex}_{bm}x{bn}x32{nt}": dict(BM=bm, BN=bn, BK=32, exact=(ex == "exact"), **({"b_kcontig": True} if nt else {}))
+       for bm, bn in ((128, 96), (192, 96), (160, 160)) for nt in ("", "_nt") for ex in ("exact", "fast")},
 }
 
 

@@ -1571,8 +1571,8 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "split_tail") g_split_tail = on;
   else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 3 ? 3 : value;
   else if (n == "asm_kernel") g_asm_kernel = value < 0 ? -1 : value;
-  else if (n == "asm_tile") g_asm_tile = value < 0 || value > 6 ? -1 : value;
-  else if (n == "thread_asm_tile") asm_set_thread_tile(value < -1 || value > 6 ? -2 : value);
+  else if (n == "asm_tile") g_asm_tile = value < 0 || value > 9 ? -1 : value;
+  else if (n == "thread_asm_tile") asm_set_thread_tile(value < -1 || value > 9 ? -2 : value);
   else if (n == "im2col_band") g_im2col_band = value < 0 ? 0 : value;
   else if (n == "asm_wgs") g_asm_wgs = value < 0 ? 0 : value;
   else if (n == "asm_slice") g_asm_slice = value < 0 ? 0 : value;

@@ -30,7 +30,7 @@ std::atomic<int> g_last_f32_asm{0};  // diagnostics: 0 = compiler-scheduled kern
 
 std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model decides; 1 = one tile per workgroup only; 2 = the persistent plan with K-slice cuts whenever legal; 3 = the strided whole-tile plan whenever legal
 std::atomic<int> g_asm_kernel{-1};    // option "asm_kernel": force an index of kKernels (tuning sweeps); -1 = the model decides
-std::atomic<int> g_asm_tile{-1};      // option "asm_tile": pin a tile class of the f32 GEMM kernels (0 = 256x128 / 256x256, 1 = 256x128 one chain, 2 = 128x128x16, 3 = 128x128x32, 4 = 64x64, 5 = 96x96 on 16x16 blocks, 6 = 160x96 on 16x16 blocks; -1 = the model decides)
+std::atomic<int> g_asm_tile{-1};      // option "asm_tile": pin a tile class of the f32 GEMM kernels (0 = 256x128 / 256x256, 1 = 256x128 one chain, 2 = 128x128x16, 3 = 128x128x32, 4 = 64x64; on 16x16 blocks: 5 = 96x96, 6 = 160x96, 7 = 128x96, 8 = 192x96, 9 = 160x160; -1 = the model decides)
 thread_local int tl_asm_tile = -2;    // the same pin for the launches made BY THIS THREAD (-2 = none: the option applies); asm_set_thread_tile
 std::atomic<int> g_asm_wgs{0};        // option "asm_wgs": workgroups of a persistent launch (0 = every slot of the chip)
 std::atomic<int> g_asm_slice{0};      // option "asm_slice": K-tiles per slice of a cut one-chain launch (0 = the model decides)
@@ -73,7 +73,8 @@ struct KernelInfo {
 // -- 96x96 (laser-order / one chain, plain / B transposed) and 160x96 (same) -- for the problems the 32x32-block tiles quantise badly:
 // the reference's own benchmark shape 1920^3 (gemm_bench_float32.nim:383-410) is 240 tiles of 160x96 against 225 of 128x128 on 256
 // CUs; 1536^3 is 256 tiles of 96x96 against 144 of 128x128
-constexpr int kNumKernels = 54;
+// [54..65]: the same family's 128x96, 192x96 and 160x160 tiles (four variants each, in that order)
+constexpr int kNumKernels = 66;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0, 1},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0, 1},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.935, 6.0, 2},      {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.945, 6.0, 2},
@@ -103,7 +104,13 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32x16_exact_96x96x32", 96, 96, 32, 0.91, 0.92, 5.0, 1},        {"lh_f32x16_fast_96x96x32", 96, 96, 32, 0.935, 0.92, 5.0, 1},
     {"lh_f32x16_exact_96x96x32_nt", 96, 96, 32, 0.91, 0.92, 5.0, 1},     {"lh_f32x16_fast_96x96x32_nt", 96, 96, 32, 0.935, 0.92, 5.0, 1},
     {"lh_f32x16_exact_160x96x32", 160, 96, 32, 0.945, 0.953, 6.0, 1},    {"lh_f32x16_fast_160x96x32", 160, 96, 32, 0.96, 0.963, 6.0, 1},
-    {"lh_f32x16_exact_160x96x32_nt", 160, 96, 32, 0.945, 0.953, 6.0, 1}, {"lh_f32x16_fast_160x96x32_nt", 160, 96, 32, 0.96, 0.963, 6.0, 1}};
+    {"lh_f32x16_exact_160x96x32_nt", 160, 96, 32, 0.945, 0.953, 6.0, 1}, {"lh_f32x16_fast_160x96x32_nt", 160, 96, 32, 0.96, 0.963, 6.0, 1},
+    {"lh_f32x16_exact_128x96x32", 128, 96, 32, 0.925, 0.93, 5.5, 1},     {"lh_f32x16_fast_128x96x32", 128, 96, 32, 0.945, 0.94, 5.5, 1},
+    {"lh_f32x16_exact_128x96x32_nt", 128, 96, 32, 0.925, 0.93, 5.5, 1},  {"lh_f32x16_fast_128x96x32_nt", 128, 96, 32, 0.945, 0.94, 5.5, 1},
+    {"lh_f32x16_exact_192x96x32", 192, 96, 32, 0.95, 0.955, 6.5, 1},     {"lh_f32x16_fast_192x96x32", 192, 96, 32, 0.962, 0.965, 6.5, 1},
+    {"lh_f32x16_exact_192x96x32_nt", 192, 96, 32, 0.95, 0.955, 6.5, 1},  {"lh_f32x16_fast_192x96x32_nt", 192, 96, 32, 0.962, 0.965, 6.5, 1},
+    {"lh_f32x16_exact_160x160x32", 160, 160, 32, 0.955, 0.96, 8.0, 1},   {"lh_f32x16_fast_160x160x32", 160, 160, 32, 0.965, 0.97, 8.0, 1},
+    {"lh_f32x16_exact_160x160x32_nt", 160, 160, 32, 0.955, 0.96, 8.0, 1}, {"lh_f32x16_fast_160x160x32_nt", 160, 160, 32, 0.965, 0.97, 8.0, 1}};
 // plain kernel -> its `_pre` variant (-1: none)
 int pre_variant(int k) {
   switch (k) {
@@ -586,8 +593,9 @@ hipError_t choose_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, int c
   // 16x16-block tiles (f32x16_kernel.py): 16-byte pieces are all-or-nothing (K % 4 == 0), dense columns of C, plain epilogue
   const bool x16_ok = a.K % 4 == 0 && a.csC == 1 && !fused && !pre;
   const int x96 = x16_ok ? 46 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0) : -1, x160 = x16_ok ? x96 + 4 : -1;
-  const int classes[7] = {big, mid, small, deep, tiny, x96, x160};
-  for (int ci = 0; ci < 7; ci++) {
+  const int x128 = x16_ok ? x96 + 8 : -1, x192 = x16_ok ? x96 + 12 : -1, x160s = x16_ok ? x96 + 16 : -1;
+  const int classes[10] = {big, mid, small, deep, tiny, x96, x160, x128, x192, x160s};
+  for (int ci = 0; ci < 10; ci++) {
     const int k0 = classes[ci];
     if (tile_pin >= 0 && ci != (tile_pin == 1 && mid < 0 ? 0 : tile_pin)) continue;
     if (k0 < 0 || (g_asm_kernel >= 0 && k0 != g_asm_kernel)) continue;

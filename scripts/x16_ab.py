@@ -22,15 +22,17 @@ nt = len(sys.argv) > 3 and sys.argv[3] == "nt"
 SHAPES = {
     "mid": [(1536,) * 3, (1920,) * 3, (2048,) * 3, (2560,) * 3, (3072,) * 3, (1000, 3000, 2000), (4100, 4100, 4100), (5120,) * 3],
     "ref": [(1920,) * 3, (1536,) * 3],
+    "more": [(1664,) * 3, (2304,) * 3, (2560,) * 3, (2944,) * 3, (3072,) * 3, (3584,) * 3, (5120,) * 3, (1000, 3000, 2000), (4100, 4100, 4100)],
     "small": [(768,) * 3, (960,) * 3, (1152,) * 3, (1344,) * 3],
     "big": [(4096,) * 3, (6144,) * 3, (8192,) * 3],
 }[which]
 # mode -> kernel index -> name (gemm_f32_asm.cpp kKernels)
 o = 4 if nt else 0
 o2 = 2 if nt else 0
-CANDS = {0: {0 + o: "256x128x32", 2 + o: "128x128x16", 30 + o2: "128x128x32", 12 + o2: "64x64x32", 46 + o2: "96x96x32 (16x16 blocks)", 50 + o2: "160x96x32 (16x16 blocks)"},
+CANDS = {0: {0 + o: "256x128x32", 2 + o: "128x128x16", 30 + o2: "128x128x32", 12 + o2: "64x64x32", 46 + o2: "96x96x32 (16x16 blocks)", 50 + o2: "160x96x32 (16x16 blocks)",
+             54 + o2: "128x96x32 (16x16 blocks)", 58 + o2: "192x96x32 (16x16 blocks)", 62 + o2: "160x160x32 (16x16 blocks)"},
          1: {1 + o: "256x256x16", (9 if nt else 8): "256x128x32", 3 + o: "128x128x16", 31 + o2: "128x128x32", 13 + o2: "64x64x32", 47 + o2: "96x96x32 (16x16 blocks)",
-             51 + o2: "160x96x32 (16x16 blocks)"}}
+             51 + o2: "160x96x32 (16x16 blocks)", 55 + o2: "128x96x32 (16x16 blocks)", 59 + o2: "192x96x32 (16x16 blocks)", 63 + o2: "160x160x32 (16x16 blocks)"}}
 fn = L.laser_hip_gemm_strided_f32_dev
 ct = ctypes.c_float
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

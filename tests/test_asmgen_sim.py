@@ -363,6 +363,12 @@ X16_CASES = [
     ("fast_96x96x32", 100, 200, 300, dict(G=5, split=2, integer=True, beta=2.0)),
     ("exact_160x96x32", 330, 200, 600, dict(G=3, split=True, group_m=1)),
     ("exact_96x96x32", 200, 200, 96, dict(G=2, strided=True)),
+    ("exact_128x96x32", 130, 100, 548, dict(lda=552, ldb=104, ldc=108)),
+    ("fast_128x96x32_nt", 129, 97, 100, dict(alpha=3.0, beta=0.5)),
+    ("exact_192x96x32_nt", 390, 100, 548, dict(G=2, split=True)),
+    ("fast_192x96x32", 193, 97, 36, {}),
+    ("exact_160x160x32", 170, 170, 548, dict(ldc=172)),
+    ("exact_160x160x32_nt", 330, 170, 1060, dict(G=3, split=True, alpha=0.75, beta=-1.5)),
 ]
 
 

@@ -970,8 +970,8 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
             finally:
                 la.set_f32_asm(1); la.set_float_mode(0); la.set_option("slice_parallel", 1); la.set_option("asm_plan", 0)
             # (large / 128x128 tile; + 4: B transposed; 9 / 10: one chain on 256x128; 13..16: 64x64 tiles; 31..34: 128x128 with the 32-deep K-tile;
-            # 47..54: the 16x16-block tiles 96x96 / 160x96)
-            want = (1, 3, 5, 7, 13, 15, 31, 33, 47, 49, 51, 53) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10, 14, 16, 32, 34, 48, 50, 52, 54)
+            # 47..66: the 16x16-block tiles 96x96 / 160x96 / 128x96 / 192x96 / 160x160)
+            want = (1, 3, 5, 7, 13, 15, 31, 33) + tuple(range(47, 67, 2)) if (mode == 0 or K <= 512) else (2, 4, 6, 8, 9, 10, 14, 16, 32, 34) + tuple(range(48, 67, 2))
             seen.add(used)
             # (tiny problems are taken by the small-matrix / slice-parallel paths before the tiled kernels are asked)
             assert used in want or (used == 0 and M * N <= 1024 * 1024), (M, N, K, mode, used)
@@ -1017,7 +1017,7 @@ def test_f32_asm_kernels_bit_exact(la, oracle):
         w = torch.full((M, 2 * N), 9.0, device="cuda"); la.matmul(A, B, 1, 0, w[:, ::2])
         assert la.last_f32_asm() != 0
         ref = la.matmul(A, B)
-        assert la.last_f32_asm() in (1, 3, 13, 31, 47, 51)
+        assert la.last_f32_asm() in (1, 3, 13, 31, 47, 51, 55, 59, 63)
         assert torch.equal(w[:, ::2], ref) and (w[:, 1::2] == 9.0).all()
         odd = la.matmul(A[:, :1022].contiguous(), B[:1022].contiguous())      # K not a multiple of 4: element-wise tail mask
         assert la.last_f32_asm() != 0
@@ -2000,7 +2000,7 @@ def test_assembly_conv_loader_any_kernel_stride_width(la, oracle, kats):
 
 @pytest.mark.gpu
 def test_f32_16x16_block_tiles_bit_exact(la, oracle):
-    """The 16x16-block tile family (laser_amd/asmgen/f32x16_kernel.py: v_mfma_f32_16x16x4_f32, tiles 96x96 and 160x96 -- the tiles
+    """The 16x16-block tile family (laser_amd/asmgen/f32x16_kernel.py: v_mfma_f32_16x16x4_f32, tiles 96x96, 160x96, 128x96, 192x96, 160x160 -- the tiles
     that fill 256 CUs at the reference's own benchmark shape 1920^3, gemm_bench_float32.nim:383-410, and at 1536^3), each kernel
     forced (option asm_kernel) under the plain and the persistent K-cut plans: laser-order results are the oracle's bits (the
     instruction is an ascending fmaf chain over its 4 k like the 32x32x2 form over its 2: gemm_ukernel_generic.nim:56-66), one-chain
@@ -2030,7 +2030,7 @@ def test_f32_16x16_block_tiles_bit_exact(la, oracle):
                 la.set_f32_asm(2)
                 la.set_option("slice_parallel", 0)
                 exact = mode == 0 or K <= 512
-                for base in (46, 50):
+                for base in (46, 50, 54, 58, 62):
                     kern = base + (0 if exact else 1) + (2 if nt else 0)
                     la.set_option("asm_kernel", kern)
                     for plan in ((1, 0, 2) if mode == 0 else (1,)):       # (one chain: a K cut is another rounding order)
@@ -2052,7 +2052,7 @@ def test_f32_16x16_block_tiles_bit_exact(la, oracle):
                 for mode in (0, 1):
                     la.set_float_mode(mode)
                     exact = mode == 0 or K <= 512
-                    for base in (46, 50):
+                    for base in (46, 50, 54, 58, 62):
                         kern = base + (0 if exact else 1) + (2 if nt else 0)
                         la.set_f32_asm(2); la.set_option("asm_kernel", kern); la.set_option("asm_plan", 1)
                         c1 = C0.clone(); la.matmul(A, B, al, be, c1)
@@ -2065,7 +2065,7 @@ def test_f32_16x16_block_tiles_bit_exact(la, oracle):
                             assert np.array_equal(c1.cpu().numpy(), w), (M, N, K, al, be, kern)
         # the launch model takes them where they fill the chip better: the reference's bench shape and 1536^3
         la.set_f32_asm(1); la.set_float_mode(0); la.set_option("asm_kernel", -1); la.set_option("asm_plan", 0)
-        for n, fam in ((1920, (51, 47)), (1536, (47,))):
+        for n, fam in ((1920, (51, 47)), (1536, (47,)), (2560, (63,))):
             A = torch.from_numpy(rand(rng, (n, n), np.float32)).cuda()
             B = torch.from_numpy(rand(rng, (n, n), np.float32)).cuda()
             C = la.matmul(A, B)

@@ -364,8 +364,9 @@ def test_a_hand_over_that_gives_up_is_reported_on_the_next_call(la):
     la.set_option("f32_asm", 2)
     try:
         la.set_option("asm_plan", 2)
-        la.matmul(A, B, 1, 0, C)
-        assert la.get_option("last_asm_slices") > 1, "this shape must run as a K-cut launch"
+        la.set_option("asm_kernel", 30)               # 144 tiles of 128x128 x 8 slices over 256 workgroups = 4.5 units each: tiles ARE handed over
+        la.matmul(A, B, 1, 0, C)                      # (the model's own pick here -- 256 tiles of 96x96, one per workgroup -- cuts nothing)
+        assert la.get_option("last_asm_slices") > 1 and la.last_f32_asm() == 31, "this shape must run as a K-cut launch"
         torch.cuda.synchronize()
         ref = C.clone()
         la.set_option("asm_test_giveup", 1)
@@ -380,5 +381,5 @@ def test_a_hand_over_that_gives_up_is_reported_on_the_next_call(la):
         assert torch.equal(C, ref)
         assert la.get_option("asm_fixup_timeouts") == 0
     finally:
-        for k, v in (("asm_plan", 0), ("asm_test_giveup", 0), ("f32_asm", 1)):
+        for k, v in (("asm_plan", 0), ("asm_test_giveup", 0), ("f32_asm", 1), ("asm_kernel", -1)):
             la.set_option(k, v)
