@@ -15,9 +15,32 @@ T = float(sys.argv[2]) if len(sys.argv) > 2 else 600
 gemm = [n for n in K.CONFIGS if not n.startswith("conv")]
 t0 = time.time(); n = fails = 0
 while time.time() - t0 < T:
-    kind = rng.choice(["f32", "f32", "f64", "i32", "i64", "conv", "sched", "sched", "sched64", "view"])
+    kind = rng.choice(["f32", "f32", "f64", "i32", "i64", "conv", "sched", "sched", "sched64", "view", "x16", "x16"])
     try:
-        if kind == "f32":
+        if kind == "x16":
+            # round 6: the 16x16-block tile family (f32x16_kernel.py): plain and persistent K-cut launches, K a multiple of 4
+            from laser_amd.asmgen import f32x16_kernel as K16
+            name = str(rng.choice(list(K16.CONFIGS))); c = K16.CONFIGS[name]
+            exact = bool(c.get("exact", False))
+            if rng.random() < 0.5:
+                M, N = int(rng.integers(1, 2 * c["BM"] + 20)), int(rng.integers(1, 2 * c["BN"] + 20))
+                Kd = 4 * int(rng.choice([rng.integers(1, 18), rng.integers(125, 275)]))
+                kw = dict(lda=Kd + int(rng.integers(0, 5)), ldc=N + int(rng.integers(0, 5)), alpha=float(rng.choice([1.0, 0.5, -2.0])), beta=float(rng.choice([0.0, 0.0, 1.0, 0.25])),
+                          batch=int(rng.choice([1, 1, 2])), seed=int(rng.integers(1 << 30)))
+                kw["ldb"] = (Kd if c.get("b_kcontig") else N) + int(rng.integers(0, 5))
+            else:
+                tm, tn = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+                M, N = (tm - 1) * c["BM"] + int(rng.integers(1, c["BM"] + 1)), (tn - 1) * c["BN"] + int(rng.integers(1, c["BN"] + 1))
+                Kd = 4 * int(rng.choice([rng.integers(129, 270), rng.integers(257, 530), rng.integers(1, 128)]))
+                P = -(-Kd // 512) if exact else max(1, -(-Kd // (32 * 5)))
+                units = tm * tn * P
+                kw = dict(G=int(rng.integers(1, units + 1)), split=(True if exact else 5), seed=int(rng.integers(1 << 30)), noseed=int(rng.random() < 0.4),
+                          alpha=float(rng.choice([1.0, 1.0, 0.5])), beta=float(rng.choice([0.0, 0.0, 0.25])))
+                if not exact: kw.update(alpha=1.0, beta=float(rng.choice([0.0, 1.0])), integer=True)
+                if rng.random() < 0.5: kw["group_m"] = int(rng.integers(1, tm + 1))
+                if kw["G"] >= 8 and rng.random() < 0.5: kw["xcd"] = True
+            ok = C.run_case(name, M, N, Kd, verbose=False, mod=K16, **kw); desc = (name, M, N, Kd, kw)
+        elif kind == "f32":
             name = str(rng.choice(gemm)); c = K.CONFIGS[name]
             M, N = int(rng.integers(1, 2 * c["BM"] + 20)), int(rng.integers(1, 2 * c["BN"] + 20))
             Kd = int(rng.choice([rng.integers(1, 70), rng.integers(500, 1100)]))
