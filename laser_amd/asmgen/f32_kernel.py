@@ -21,8 +21,20 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
                  b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32",
-                 persistent=None, pre=False, deep=False, pipe=None):
+                 persistent=None, pre=False, deep=False, pipe=None, il=False, runv=False, dataa=None):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
+        # il (round 6): the three LDS stages are INTERLEAVED by row -- row r of stage s at r * 3 * RS + s * RS -- instead of three
+        # consecutive panel images.  A stage is then an immediate offset of the LDS instructions (s * 128 bytes: inside the 16-bit offset
+        # of ds_read_b128 next to the block offset, and inside ds_write2_b32's 8-bit dword offsets), so ONE address register per
+        # (group / piece) serves all three stages where the consecutive layout needs three: 96 address registers become 32.  The bank
+        # of every access is unchanged (the row pitch 96 dwords = 32 mod 64, the pitch of the consecutive layout).
+        # runv (needs il): the laser-order running sum lives in arch VGPRs (the registers il frees), the fragment and staging registers
+        # move to AGPRs (LDS and buffer instructions take either file, and so do the MFMA's A / B operands): the slice fold is then
+        # v_accvgpr_read + v_pk_add_f32 -- 1.5 VALU operations per element where the all-AGPR plan needs 4.
+        self.il, self.runv = il, runv
+        self.dataa = (runv and il) if dataa is None else dataa        # fragments + staging in AGPRs (where the running sum would not fit beside them)
+        assert not (runv and not exact) and not (il and (deep or dtype != "f32" or b_store != "write2"))
+        assert not (self.dataa and pre), "the fused prologue works on the staging registers with VALU instructions"
         # deep (generator option, no shipped kernel uses it): TWO sets of staging registers -- a K-tile is requested two tile bodies before
         # it is stored to LDS instead of one; six tile bodies instead of three (LDS stage x register set).  Built for the small tile,
         # whose body is 16 MFMAs per wave and which runs 0.965 of peak with its global loads ablated against 0.83 - 0.87 with them:
@@ -64,6 +76,7 @@ class Cfg:
         self.NMF = self.NB * (BK // self.KSTEP)  # MFMAs per K-tile per wave
         self.GM = self.NMF // self.NG   # MFMAs per group
         self.STAGE = (BM + BN) * self.RS
+        self.ROWP = 3 * self.RS if il else self.RS      # bytes between two rows of a panel in LDS
         self.NPA = BM * BK * self.ESZ // 16 // 256   # 16-byte pieces of A per thread per tile
         self.NPB = BN * BK * self.ESZ // 16 // 256
         # implicit-GEMM convolution (round 6: any kH x kW of up to `ntmax` taps, strides 1 .. 255, any zero padding, any output
@@ -99,32 +112,32 @@ class Cfg:
 
 CONFIGS = {
     # barrier positions from the schedule sweeps (profiles/r03/asm_probe_v1.jsonl, asm_probe_v2.jsonl)
-    "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95),
+    "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, il=True, runv=True),
     "fast_256x256x16": dict(BM=256, BN=256, BK=16, exact=False, bar_gap=95),
     # mid-size problems (fewer than one round of the large tiles): 128 VGPRs + 128 AGPRs and 48 KiB of LDS per workgroup, so
     # two workgroups share a CU -- two waves per SIMD that cover each other's barrier and waits
-    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True),
+    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True, runv=True),
     "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False),
     # B passed transposed (rowStrideB == 1: k-contiguous like A) -- BASELINE configs[2]
-    "exact_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, b_kcontig=True),
+    "exact_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, b_kcontig=True, il=True, runv=True),
     "fast_256x256x16_nt": dict(BM=256, BN=256, BK=16, exact=False, bar_gap=95, b_kcontig=True),
-    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True),
+    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True, runv=True),
     "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
     # one chain on the laser-order kernels' tile: halves the tile quantisation of the 256x256 tile (4100^3: 289 tiles of
     # 256x256 are 1.13 rounds of the chip, 561 tiles of 256x128 are 2.19)
     # small tiles for problems with few large tiles (1024^3 = 32 tiles of 256x128 on 256 CUs) and for the tile quantisation of
     # mid-size ones: 2 - 3 workgroups share a CU
-    "exact_64x64x32": dict(BM=64, BN=64, BK=32, exact=True),
+    "exact_64x64x32": dict(BM=64, BN=64, BK=32, exact=True, runv=True),
     "fast_64x64x32": dict(BM=64, BN=64, BK=32, exact=False),
-    "exact_64x64x32_nt": dict(BM=64, BN=64, BK=32, exact=True, b_kcontig=True),
+    "exact_64x64x32_nt": dict(BM=64, BN=64, BK=32, exact=True, b_kcontig=True, runv=True),
     "fast_64x64x32_nt": dict(BM=64, BN=64, BK=32, exact=False, b_kcontig=True),
     # implicit-GEMM convolution, 3x3 kernel, stride 1, any zero padding (benchmarks/convolution/conv2d_im2col.nim)
-    "conv_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, conv=True),
+    "conv_exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, il=True, runv=True, bar_gap=95, conv=True),
     "conv_fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True),
     # fewer output channels: 128 / 64 rows of the same pixel tile (the B side -- the gather -- is unchanged)
-    "conv_exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True, conv=True),
+    "conv_exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True, il=True, runv=True, conv=True),
     "conv_fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False, conv=True),
-    "conv_exact_64x128x32": dict(BM=64, BN=128, BK=32, exact=True, conv=True),
+    "conv_exact_64x128x32": dict(BM=64, BN=128, BK=32, exact=True, il=True, runv=True, conv=True),
     "conv_fast_64x128x32": dict(BM=64, BN=128, BK=32, exact=False, conv=True),
     "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
@@ -136,9 +149,9 @@ CONFIGS = {
                                         ("exact_128x128x16", 128, 128, 16, True, None), ("fast_128x128x16", 128, 128, 16, False, None),
                                         ("exact_64x64x32", 64, 64, 32, True, None), ("fast_64x64x32", 64, 64, 32, False, None))
        for nt in ("", "_nt")},
-    "exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True),
+    "exact_128x128x32": dict(BM=128, BN=128, BK=32, exact=True, runv=True),
     "fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False),
-    "exact_128x128x32_nt": dict(BM=128, BN=128, BK=32, exact=True, b_kcontig=True),
+    "exact_128x128x32_nt": dict(BM=128, BN=128, BK=32, exact=True, b_kcontig=True, runv=True),
     "fast_128x128x32_nt": dict(BM=128, BN=128, BK=32, exact=False, b_kcontig=True),
 }
 
@@ -176,6 +189,10 @@ def magic_u32(d):
     return 0 if d == 1 else ((1 << 32) // d + 1) & 0xffffffff
 
 
+def c_runv(gen):
+    return getattr(gen.c, "runv", False)
+
+
 class Gen:
     def __init__(self, cfg):
         self.c = cfg
@@ -204,13 +221,15 @@ class Gen:
         self.alloc_sched()
         # accumulators
         self.acc = [p.aalloc(c.ACCR) for _ in range(c.NB)]
-        self.run = [p.aalloc(c.ACCR) for _ in range(c.NB)] if c.exact else None
+        # (runv: the running sum in arch VGPRs -- VALU instructions cannot address AGPRs -- and the data-only registers in AGPRs)
+        self.run = ([V(c.ACCR) if c.runv else p.aalloc(c.ACCR) for _ in range(c.NB)]) if c.exact else None
+        D4 = (lambda n: p.aalloc(n)) if c.dataa else V
         # fragments: 2 slots
-        self.fa = [[V(4) for _ in range(c.TM)] for _ in range(2)]
-        self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
+        self.fa = [[D4(4) for _ in range(c.TM)] for _ in range(2)]
+        self.fb = [[D4(4) for _ in range(c.TN)] for _ in range(2)]
         # staging pieces
-        self.stA = [V(4) for _ in range(c.NPA)]
-        self.stB = [V(2) for _ in range(c.NPB)] if c.conv else [V(4) for _ in range(c.NPB)]
+        self.stA = [D4(4) for _ in range(c.NPA)]
+        self.stB = [D4(2) for _ in range(c.NPB)] if c.conv else [D4(4) for _ in range(c.NPB)]
         # deep: tile t waits in set t & 1 (the loop body that multiplies tile t stores tile t + 1 from its set and requests tile t + 3 into it)
         self.st_sets = [(self.stA, self.stB)]
         if c.deep:
@@ -219,11 +238,17 @@ class Gen:
         # the stage being filled (writes), [1] = the next one, [2] = the third; rotated with v_swap_b32 once per K-tile --
         # v_swap is free beside the MFMA stream while any other VALU op costs ~11 cycles of matrix-pipe time
         # (profiles/r03/asm_probe_v3_fillers.jsonl, asm_probe_v4_fillers.jsonl), so the loop computes no address at all
-        self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
-        self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
-        self.WA = [[[V() for _ in range(3)] for _ in range(c.NPA)] for _ in range(2)]   # [MFMA half][piece][stage]
+        # (il: one register + the stage as an immediate offset: an entry is (register, bytes); see lds_at)
+        def triple(read):
+            if not c.il:
+                return [V() for _ in range(3)]
+            r = V()
+            return [(r, 0), (r, c.RS), (r, 2 * c.RS)] if read else [(r, c.RS), (r, 2 * c.RS), (r, 0)]
+        self.RA = [triple(True) for _ in range(c.NG)]
+        self.RB = [triple(True) for _ in range(c.NG)]
+        self.WA = [[triple(False) for _ in range(c.NPA)] for _ in range(2)]   # [MFMA half][piece][stage]
         if c.conv:
-            self.WB = [[[V() for _ in range(3)] for _ in range(2)] for _ in range(4)]       # [pair][pixel of the piece][stage]
+            self.WB = [[triple(False) for _ in range(2)] for _ in range(4)]       # [pair][pixel of the piece][stage]
             self.vB0 = [V() for _ in range(8)]             # per piece: buffer offset of the lane's first / second pixel for the
             self.vB1 = [V() for _ in range(8)]             # piece's tap (read from the LDS table; 0x80000000 = padding)
             scr = S(16, align=4)
@@ -236,9 +261,9 @@ class Gen:
             self.s_HW4, self.s_W4, self.s_Cin = S(), S(), S()
             self.s_sc = scr.sub(0, 8)                      # (the scheduler constants are dead before conv_setup loads the geometry)
         elif c.b_kcontig:
-            self.WB = [[[V() for _ in range(3)] for _ in range(c.NPB)] for _ in range(2)]   # like A: [MFMA half][piece][stage]
+            self.WB = [[triple(False) for _ in range(c.NPB)] for _ in range(2)]   # like A: [MFMA half][piece][stage]
         else:
-            self.WB = [[[V() for _ in range(3)] for _ in range(4)] for _ in range(c.NPB // 2)]   # [pair][element][stage]
+            self.WB = [[triple(False) for _ in range(4)] for _ in range(c.NPB // 2)]   # [pair][element][stage]
         self.v_oob = V()            # 0x80000000: a buffer offset the bounds check always rejects (reads as 0)
         self.s_tm = S(2)            # lanes whose 16-byte piece of a k-contiguous operand is real data in the LAST K-tile
         self.s_ktail = S()
@@ -316,6 +341,11 @@ class Gen:
         del self.lgq[:len(self.lgq) - n]
 
     # ------------------------------------------------------------------ small helpers
+    @staticmethod
+    def lds_at(entry):
+        """(address register, extra byte offset) of one stage's entry of an address triple (Cfg.il: the stage is an immediate offset)"""
+        return entry if isinstance(entry, tuple) else (entry, 0)
+
     def kq_swz(self, dst, x, tmp):
         """dst = kq_swz<BK>(x): BK 32: ((x>>1) ^ (x&1)) & 7; BK 16: ((x>>2) ^ ((x>>1)&1)) & 3"""
         e = self.p.emit
@@ -703,17 +733,20 @@ class Gen:
         e("s_mul_i32", self.s_wn0, st[2], c.WTN)
         # fragment reads of group g: (wm0 + lor) * BK * 4 [+ BK*BM*4 + (wn0 + lor) * BK * 4 for B] + 16 * ((2g + hi) ^ kqs)
         e("v_add_u32", t[5], self.s_wm0, lor)
-        e("v_mul_u32_u24", t[6], c.BK * 4, t[5])
+        e("v_mul_u32_u24", t[6], c.ROWP, t[5])
         if c.LDS0:
             e("v_add_u32", t[6], c.LDS0, t[6])
         e("v_add_u32", t[5], self.s_wn0, lor)
-        e("v_mul_u32_u24", t[7], c.BK * 4, t[5])
-        e("v_add_u32", t[7], c.LDS0 + c.BK * c.BM * 4, t[7])
+        e("v_mul_u32_u24", t[7], c.ROWP, t[5])
+        e("v_add_u32", t[7], c.LDS0 + c.ROWP * c.BM, t[7])
         for g in range(c.NG):
             e("v_or_b32", t[5], 2 * g, hi)
             e("v_xor_b32", t[5], t[5], kqs)
             e("v_lshlrev_b32", t[5], 4, t[5])
             for R, row in ((self.RA, t[6]), (self.RB, t[7])):
+                if c.il:
+                    e("v_add_u32", R[g][0][0], t[5], row)
+                    continue
                 e("v_add_u32", R[g][0], t[5], row)
                 e("v_add_u32", R[g][1], c.STAGE, R[g][0])
                 e("v_add_u32", R[g][2], 2 * c.STAGE, R[g][0])
@@ -731,24 +764,28 @@ class Gen:
             e("v_lshrrev_b32", t[5], 1, kq)          # kq / 2
             e("v_lshlrev_b32", t[5], 1, t[5])        # 2 * (kq / 2)
             e("v_and_b32", t[6], 1, kq)              # kq % 2
-            e("v_mul_u32_u24", t[7], c.BK * 4, row)  # row * BK * 4
+            e("v_mul_u32_u24", t[7], c.ROWP, row)    # row * (bytes between rows)
             e("v_lshl_add_u32", t[7], t[6], 3, t[7])  # + 8 * (kq % 2)
             if lds_off:
                 e("v_add_u32", t[7], lds_off, t[7])
+            XSB = (256 // nkq) * c.ROWP              # bytes between two pieces of a thread: XS rows
             for cc in range(2):
                 e("v_or_b32", t[8], cc, t[5])
                 e("v_xor_b32", t[8], t[8], sw)
-                e("v_lshl_add_u32", W[cc][0][2], t[8], 4, t[7])
+                w0 = self.lds_at(W[cc][0][2])[0]
+                e("v_lshl_add_u32", w0, t[8], 4, t[7])
                 for pi in range(NP):
                     if pi:
-                        e("v_add_u32", W[cc][pi][2], 4096 * pi, W[cc][0][2])
+                        e("v_add_u32", self.lds_at(W[cc][pi][2])[0], XSB * pi, w0)
+                    if c.il:
+                        continue
                     e("v_add_u32", W[cc][pi][0], c.STAGE, W[cc][pi][2])
                     e("v_add_u32", W[cc][pi][1], 2 * c.STAGE, W[cc][pi][2])
 
         kcontig_lds(self.WA, c.NPA, c.LDS0)
         e("s_lshl_b32", st[5], self.s_ldb, 2, comment="ldb * 4 bytes")
         if c.b_kcontig:
-            kcontig_lds(self.WB, c.NPB, c.BK * c.BM * 4)
+            kcontig_lds(self.WB, c.NPB, c.ROWP * c.BM)
             e("s_mov_b32", self.s_bstep, c.BK * 4, comment="B (stored transposed) advances BK elements along its rows per K-tile")
         if not c.b_kcontig and not c.conv:
             # B pieces (x-contiguous, 16 B = 4 consecutive x of row k), handled in pairs (k, k+2) -- DESIGN.md 3.2 pair mode
@@ -776,7 +813,7 @@ class Gen:
             e("s_mul_i32", self.s_bstep, st[5], c.BK, comment="B advances BK rows per K-tile")
             # LDS write addresses of the B pairs: for element e of the pieces: x = 4xq + e, row = 4xq + (e ^ (xq & 1)),
             #   L = 2 * (k / 8) + (k & 1), word = (k % 8) >> 1;  WB = BK*BM*4 + row*BK*4 + 16 * (L ^ kq_swz(x)) + 4 * word
-            e("s_mov_b32", st[0], c.BK * c.BM * 4, comment="the B panel follows the A panel in a stage")
+            e("s_mov_b32", st[0], c.ROWP * c.BM, comment="the B panel follows the A panel in a stage")
             for gi in range(c.NPB // 2):
                 kk = t[7]
                 e("v_add_u32", kk, gi * KG, kb0)
@@ -792,9 +829,11 @@ class Gen:
                     self.kq_row(rr, xx, t[5])
                     self.kq_swz(ss, xx, t[5])
                     e("v_xor_b32", ss, ss, t[8])                 # L ^ swz
-                    e("v_mul_u32_u24", rr, c.BK * 4, rr)
+                    e("v_mul_u32_u24", rr, c.ROWP, rr)
                     e("v_lshl_add_u32", rr, ss, 4, rr)
-                    e("v_add3_u32", self.WB[gi][ee][2], rr, t[9], st[0])
+                    e("v_add3_u32", self.lds_at(self.WB[gi][ee][2])[0], rr, t[9], st[0])
+                    if c.il:
+                        continue
                     e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
                     e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
 
@@ -865,8 +904,8 @@ class Gen:
                 self.dump("conv k0", self.s_k0)
                 self.dump("conv HW4", self.s_HW4)
                 self.dump("conv Cin", self.s_Cin)
-                self.dump("conv WB00", self.WB[0][0][2])
-                self.dump("conv WB31", self.WB[3][1][2])
+                self.dump("conv WB00", self.lds_at(self.WB[0][0][2])[0])
+                self.dump("conv WB31", self.lds_at(self.WB[3][1][2])[0])
         elif c.b_kcontig:
             # B^T panel: base = B + n0 * ldb * 4 + kb * 4; bytes = (min(N - n0, BN) - 1) * ldb * 4 + Keff * 4
             e("s_mul_hi_u32", st[2], self.s_n0, st[5])
@@ -944,11 +983,11 @@ class Gen:
             if not c.conv:
                 self.dump("vVB0", self.vVB[0])
                 self.dump("vVB1", self.vVB[1])
-            self.dump("WA0", self.WA[0][0][2])
-            self.dump("WA1", self.WA[1][0][2])
-            self.dump("WB00", self.WB[0][0][2])
-            self.dump("RA0", self.RA[0][0])
-            self.dump("RB0", self.RB[0][0])
+            self.dump("WA0", self.lds_at(self.WA[0][0][2])[0])
+            self.dump("WA1", self.lds_at(self.WA[1][0][2])[0])
+            self.dump("WB00", self.lds_at(self.WB[0][0][2])[0])
+            self.dump("RA0", self.lds_at(self.RA[0][0])[0])
+            self.dump("RB0", self.lds_at(self.RB[0][0])[0])
         if c.deep:
             self.first_tiles_deep()
             self.first_tiles_done()
@@ -1119,7 +1158,7 @@ class Gen:
             e("s_cbranch_scc1", keep)
         for b in range(c.NB):
             for r in range(c.ACCR):
-                e("v_accvgpr_write_b32", self.run[b][r], 0)
+                e("v_mov_b32" if c.runv else "v_accvgpr_write_b32", self.run[b][r], 0)
         self.load_beta_c()
         p.place(keep)
 
@@ -1274,7 +1313,7 @@ class Gen:
         e("s_mul_i32", self.s_HW4, self.s_W4, sH)
         e("s_mov_b32", self.s_Cin, sCin)
         # LDS write addresses of pair gi, pixel e: x = 2*lane + e, k = 8w + (0, 1, 4, 5)[gi]: L = 2w + (gi & 1), word = (0,0,2,2)[gi]
-        e("s_mov_b32", st[0], c.LDS0 + c.BK * c.BM * 4)
+        e("s_mov_b32", st[0], c.LDS0 + c.ROWP * c.BM)
         for gi in range(4):
             e("s_lshl_b32", st[3], self.s_wave, 1)
             e("s_add_u32", st[3], st[3], gi & 1)
@@ -1284,10 +1323,12 @@ class Gen:
                 self.kq_row(rr, xx, t[7])
                 self.kq_swz(ss, xx, t[7])
                 e("v_xor_b32", ss, st[3], ss)
-                e("v_mul_u32_u24", rr, c.BK * 4, rr)
+                e("v_mul_u32_u24", rr, c.ROWP, rr)
                 e("v_lshl_add_u32", rr, ss, 4, rr)
                 e("v_add_u32", rr, 4 * (0, 0, 2, 2)[gi], rr)
-                e("v_add_u32", self.WB[gi][ee][2], st[0], rr)
+                e("v_add_u32", self.lds_at(self.WB[gi][ee][2])[0], st[0], rr)
+                if c.il:
+                    continue
                 e("v_add_u32", self.WB[gi][ee][0], c.STAGE, self.WB[gi][ee][2])
                 e("v_add_u32", self.WB[gi][ee][1], 2 * c.STAGE, self.WB[gi][ee][2])
         # running k of this wave: 8w, + BK per K-tile
@@ -1337,7 +1378,7 @@ class Gen:
             P, Q = self.stB[2 * gi], self.stB[2 * gi + 1]
             for ee in range(2):
                 g = [("vmwait", ("B", 2 * gi + 1, 1))] if ee == 0 else []
-                g.append(("ldsw", "ds_write2_b32", (self.WB[gi][ee][k], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
+                g.append(self.w2(self.WB[gi][ee][k], P[ee], Q[ee]))
                 out.append(g)
         return out
 
@@ -1381,6 +1422,11 @@ class Gen:
         assert len(regs) <= 4
         return [("call", emit)]
 
+    def w2(self, entry, d0, d1):
+        """two adjacent words of one stage's panel image from two registers (entry = that stage's slot of a write-address triple)"""
+        reg, off = self.lds_at(entry)
+        return ("ldsw", "ds_write2_b32", (reg, d0, d1), {"offset0": off // 4, "offset1": off // 4 + 1})
+
     def store_A_piece(self, pi, ops=None, k=0):
         """piece = 4 consecutive k (e0 e1 e2 e3) of one row: (e0, e2) -> chunk of MFMA half 0, (e1, e3) -> half 1"""
         out = []
@@ -1390,8 +1436,8 @@ class Gen:
         # ds_write2_b32 takes its two dwords from two independent registers: no repacking VALU op (a v_swap on freshly
         # loaded registers cost 16 cycles of matrix-pipe time per piece, profiles/r03/asm_probe_v7.jsonl); the price is one
         # address register per (piece, half, stage)
-        out.append(("ldsw", "ds_write2_b32", (self.WA[0][pi][k], r[0], r[2]), {"offset0": 0, "offset1": 1}))
-        out.append(("ldsw", "ds_write2_b32", (self.WA[1][pi][k], r[1], r[3]), {"offset0": 0, "offset1": 1}))
+        out.append(self.w2(self.WA[0][pi][k], r[0], r[2]))
+        out.append(self.w2(self.WA[1][pi][k], r[1], r[3]))
         if ops is None:
             self.run_ops(out)
         return out
@@ -1402,8 +1448,8 @@ class Gen:
         r = self.stB[pj]
         out.append(("vmwait", ("B", pj)))
         out += self.pre_op([r[j] for j in range(4)], self.s_preB)
-        out.append(("ldsw", "ds_write2_b32", (self.WB[0][pj][k], r[0], r[2]), {"offset0": 0, "offset1": 1}))
-        out.append(("ldsw", "ds_write2_b32", (self.WB[1][pj][k], r[1], r[3]), {"offset0": 0, "offset1": 1}))
+        out.append(self.w2(self.WB[0][pj][k], r[0], r[2]))
+        out.append(self.w2(self.WB[1][pj][k], r[1], r[3]))
         if ops is None:
             self.run_ops(out)
         return out
@@ -1430,6 +1476,12 @@ class Gen:
         e("s_waitcnt", vmcnt=0)
         for r in list(self.stA) + (list(self.stB) if c.b_kcontig else []):
             for j in range(4):
+                if r.kind == "a":      # (runv: the staging registers are AGPRs -- through a temporary; once per run, K % 4 != 0 only)
+                    tmp = self.vt[4 + j]
+                    e("v_accvgpr_read_b32", tmp, r[j])
+                    e("v_cndmask_b32", tmp, 0, tmp, self.s_em[j])
+                    e("v_accvgpr_write_b32", r[j], tmp)
+                    continue
                 e("v_cndmask_b32", r[j], 0, r[j], self.s_em[j])
         self.p.place(skip)
 
@@ -1453,7 +1505,7 @@ class Gen:
         out += self.pre_op([Q[j] for j in range(4)], self.s_preB)
         if self.c.b_store == "write2":
             for ee in range(4):
-                out.append(("ldsw", "ds_write2_b32", (self.WB[gi][ee][k], P[ee], Q[ee]), {"offset0": 0, "offset1": 1}))
+                out.append(self.w2(self.WB[gi][ee][k], P[ee], Q[ee]))
         else:
             # (P0 P1 P2 P3 Q0 Q1 Q2 Q3) -> (P0 Q0 P1 Q1 P2 Q2 P3 Q3): two 3-cycles = 4 swaps; P, Q are adjacent registers
             assert Q.idx == P.idx + 4
@@ -1514,11 +1566,13 @@ class Gen:
         """fragment reads of group g (4 k-steps) into register slot `slot`; stage 0: the tile being multiplied, 1: the next tile"""
         c = self.c
         ops = []
-        blk = c.MB * c.RS
+        blk = c.MB * c.ROWP
+        ra, oa = self.lds_at(self.RA[g][stage])
+        rb, ob = self.lds_at(self.RB[g][stage])
         for i in range(c.TM):
-            ops.append(("ldsr", "ds_read_b128", (self.fa[slot][i], self.RA[g][stage]), {"offset": i * blk}, ("R", slot)))
+            ops.append(("ldsr", "ds_read_b128", (self.fa[slot][i], ra), {"offset": i * blk + oa}, ("R", slot)))
         for n in range(c.TN):
-            ops.append(("ldsr", "ds_read_b128", (self.fb[slot][n], self.RB[g][stage]), {"offset": n * blk}, ("R", slot)))
+            ops.append(("ldsr", "ds_read_b128", (self.fb[slot][n], rb), {"offset": n * blk + ob}, ("R", slot)))
         return ops
 
     def read_group(self, g, stage, slot):
@@ -1568,6 +1622,11 @@ class Gen:
         e("s_cbranch_scc1", lmul)
         p.place(lback)
         self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(16)], lback))
+        if c_runv(self):
+            # the running sum is in arch VGPRs: two adds per instruction, nothing to move (8 VALU operations where the AGPR plan has 48)
+            for j in range(8):
+                e("v_pk_add_f32", self.run[b].sub(2 * j, 2), self.run[b].sub(2 * j, 2), T.sub(2 * j, 2))
+            return
         for r in range(16):
             tt = self.vt[r % 4]
             e("v_accvgpr_read_b32", tt, self.run[b][r])
@@ -1594,9 +1653,17 @@ class Gen:
             e("s_mul_i32", soff, self.s_ldc4, 32 * i)
         else:
             e("s_mov_b32", soff, 0)
+        blk4 = v(self.vt[0].idx, 4)      # vt[0..3]: two register pairs
         for r in range(16):
             rr = r & 3
-            if c.exact:
+            if c.runv:
+                # run in arch VGPRs: C = run + alpha * slice two elements at a time into a temporary pair, the pair of the running sum zeroed
+                pair = blk4.sub(2 * ((r >> 1) & 1), 2)
+                if r % 2 == 0:
+                    e("v_pk_add_f32", pair, self.run[b].sub(r, 2), T.sub(r, 2))
+                    e("v_mov_b64", self.run[b].sub(r, 2), 0)
+                tt = pair[r & 1]
+            elif c.exact:
                 tt = self.vt[r % 4]
                 e("v_accvgpr_read_b32", tt, self.run[b][r])
                 e("v_add_f32", tt, tt, T[r])
@@ -2000,11 +2067,17 @@ class Gen:
             for q in range(4):
                 for rr in range(4):
                     for n in range(c.TN):
-                        e("buffer_load_dword", pool[rr * c.TN + n], self.vC[n], self.srdC, 0, offen=True)
+                        # (runv: straight into the running sum's own registers -- the fragment registers are AGPRs there)
+                        dst = self.run[i * c.TN + n][4 * q + rr] if c.runv else pool[rr * c.TN + n]
+                        e("buffer_load_dword", dst, self.vC[n], self.srdC, 0, offen=True)
                     self.c_step(i, q, rr)
                 e("s_waitcnt", vmcnt=0)
                 for rr in range(4):
                     for n in range(c.TN):
+                        if c.runv:
+                            x = self.run[i * c.TN + n][4 * q + rr]
+                            e("v_mul_f32", x, self.s_beta, x)
+                            continue
                         x = pool[rr * c.TN + n]
                         e("v_mul_f32", x, self.s_beta, x)
                         e("v_accvgpr_write_b32", self.run[i * c.TN + n][4 * q + rr], x)
@@ -2086,7 +2159,9 @@ class Gen:
                         bias = P[n] if (c.TN == 4 and rr == 3) else P[rr * per + n]
                         e("v_accvgpr_read_b32", tt, self.acc[b][r])
                         e("v_mul_f32", tt, self.s_alpha, tt)
-                        if c.exact:
+                        if c.runv:
+                            e("v_add_f32", tt, self.run[b][r], tt)
+                        elif c.exact:
                             e("v_accvgpr_read_b32", uu, self.run[b][r])
                             e("v_add_f32", tt, uu, tt)
                         e("v_add_f32", tt, bias, tt)
@@ -2140,8 +2215,11 @@ class Gen:
                         tt, uu = t[(2 * n) % 8], t[(2 * n + 1) % 8]
                         e("v_accvgpr_read_b32", tt, self.acc[b][r])
                         e("v_mul_f32", tt, self.s_alpha, tt)
-                        e("v_accvgpr_read_b32", uu, self.run[b][r])
-                        e("v_add_f32", tt, uu, tt)
+                        if c.runv:
+                            e("v_add_f32", tt, self.run[b][r], tt)
+                        else:
+                            e("v_accvgpr_read_b32", uu, self.run[b][r])
+                            e("v_add_f32", tt, uu, tt)
                         if "cstores" not in c.ablate:
                             e("buffer_store_dword", tt, self.vC[n], self.srdC, 0, offen=True)
                     self.c_step(i, q, rr)
@@ -2272,6 +2350,10 @@ class Gen:
             e("v_accvgpr_read_b32", T[r], self.acc[b][r])
         for r in range(16):
             e("v_mul_f32", T[r], self.s_alpha, T[r])      # (1.0 * x is x: no branch here, the hand-over is not the hot loop)
+        if self.c.runv:
+            for j in range(8):
+                e("v_pk_add_f32", self.run[b].sub(2 * j, 2), self.run[b].sub(2 * j, 2), T.sub(2 * j, 2))
+            return
         for r in range(16):
             tt = self.vt[r % 4]
             e("v_accvgpr_read_b32", tt, self.run[b][r])

@@ -26,19 +26,21 @@ from .f64_kernel import Gen64
 
 CONFIGS = {
     # 2 x 2 waves of 48x48 = 9 blocks: 36 accumulator registers (+ 36 for the running sum); 81 KiB of LDS
-    "exact_96x96x32": dict(BM=96, BN=96, BK=32, exact=True),
+    "exact_96x96x32": dict(BM=96, BN=96, BK=32, exact=True, runv=True),
     "fast_96x96x32": dict(BM=96, BN=96, BK=32, exact=False),
-    "exact_96x96x32_nt": dict(BM=96, BN=96, BK=32, exact=True, b_kcontig=True),
+    "exact_96x96x32_nt": dict(BM=96, BN=96, BK=32, exact=True, b_kcontig=True, runv=True),
     "fast_96x96x32_nt": dict(BM=96, BN=96, BK=32, exact=False, b_kcontig=True),
     # 2 x 2 waves of 80x48 = 15 blocks: 60 + 60 registers; 108 KiB of LDS
-    "exact_160x96x32": dict(BM=160, BN=96, BK=32, exact=True),
+    "exact_160x96x32": dict(BM=160, BN=96, BK=32, exact=True, runv=True),
     "fast_160x96x32": dict(BM=160, BN=96, BK=32, exact=False),
-    "exact_160x96x32_nt": dict(BM=160, BN=96, BK=32, exact=True, b_kcontig=True),
+    "exact_160x96x32_nt": dict(BM=160, BN=96, BK=32, exact=True, b_kcontig=True, runv=True),
     "fast_160x96x32_nt": dict(BM=160, BN=96, BK=32, exact=False, b_kcontig=True),
     # more sides for more problems (a tile is picked per problem, gemm_f32_asm.cpp): 128x96 (2 x 2 waves of 64x48 = 12 blocks:
     # 1000x3000x2000 is 256 tiles of it), 192x96 (96x48 = 18 blocks: 3072^3 is 512 tiles = two exact rounds), 160x160 (80x80 = 25
     # blocks, 100 + 100 accumulator registers, 135 KiB of LDS: 2560^3 is 256 tiles, 5120^3 four exact rounds)
-    **{f"{ex}_{bm}x{bn}x32{nt}": dict(BM=bm, BN=bn, BK=32, exact=(ex == "exact"), **({"b_kcontig": True} if nt else {}))
+    # (laser-order: the running sum in arch VGPRs; the two largest tiles move fragments + staging to AGPRs to make room)
+    **{f"{ex}_{bm}x{bn}x32{nt}": dict(BM=bm, BN=bn, BK=32, exact=(ex == "exact"), **({"b_kcontig": True} if nt else {}),
+                                      **({"runv": True, "dataa": bm >= 160} if ex == "exact" else {}))
        for bm, bn in ((128, 96), (192, 96), (160, 160)) for nt in ("", "_nt") for ex in ("exact", "fast")},
 }
 
@@ -62,11 +64,14 @@ class Gen16(Gen64):
         self.s_ldc4 = S()
         self.alloc_sched()
         self.acc = [p.aalloc(4) for _ in range(c.NB)]
-        self.run = [p.aalloc(4) for _ in range(c.NB)] if c.exact else None
-        self.fa = [[V(4) for _ in range(c.TM)] for _ in range(2)]
-        self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
-        self.stA = [V(4) for _ in range(c.NPA)]
-        self.stB = [V(4) for _ in range(c.NPB)]
+        # runv (f32_kernel.py Cfg): the running sum in arch VGPRs -- the slice fold is 4 v_accvgpr_read + 2 v_pk_add_f32 per block where
+        # the all-AGPR plan has 16 VALU operations; dataa: fragments + staging in AGPRs (the tiles whose VGPR file would overflow)
+        self.run = [V(4) if c.runv else p.aalloc(4) for _ in range(c.NB)] if c.exact else None
+        D4 = (lambda n: p.aalloc(n)) if c.dataa else V
+        self.fa = [[D4(4) for _ in range(c.TM)] for _ in range(2)]
+        self.fb = [[D4(4) for _ in range(c.TN)] for _ in range(2)]
+        self.stA = [D4(4) for _ in range(c.NPA)]
+        self.stB = [D4(4) for _ in range(c.NPB)]
         self.st_sets = [(self.stA, self.stB)]
         self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
@@ -300,11 +305,35 @@ class Gen16(Gen64):
         e("s_cbranch_scc1", lmul)
         p.place(lback)
         self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(4)], lback))
+        if self.c.runv:
+            for j in range(2):
+                e("v_pk_add_f32", self.run[b].sub(2 * j, 2), self.run[b].sub(2 * j, 2), T.sub(2 * j, 2))
+            return
         for r in range(4):
             tt = self.vt[r]
             e("v_accvgpr_read_b32", tt, self.run[b][r])
             e("v_add_f32", tt, tt, T[r])
             e("v_accvgpr_write_b32", self.run[b][r], tt)
+
+    def init_accumulators(self):
+        if not self.c.runv:
+            return Gen.init_accumulators(self)
+        # (f32_kernel.Gen.init_accumulators with the running sum in arch VGPRs)
+        from .f32_kernel import MODE_NORMAL
+        c, p = self.c, self.p
+        e = p.emit
+        for b in range(c.NB):
+            for r in range(c.ACCR):
+                e("v_accvgpr_write_b32", self.acc[b][r], 0)
+        keep = p.label("keeprun")
+        if c.persistent:
+            e("s_cmp_lg_u32", self.s_mode, MODE_NORMAL)
+            e("s_cbranch_scc1", keep)
+        for b in range(c.NB):
+            for j in range(2):
+                e("v_mov_b64", self.run[b].sub(2 * j, 2), 0)
+        self.load_beta_c()
+        p.place(keep)
 
     def fold_block(self, b):
         e, T = self.p.emit, self.vT[0]
@@ -312,6 +341,10 @@ class Gen16(Gen64):
             e("v_accvgpr_read_b32", T[r], self.acc[b][r])
         for r in range(4):
             e("v_mul_f32", T[r], self.s_alpha, T[r])      # (1.0 * x is x)
+        if self.c.runv:
+            for j in range(2):
+                e("v_pk_add_f32", self.run[b].sub(2 * j, 2), self.run[b].sub(2 * j, 2), T.sub(2 * j, 2))
+            return
         for r in range(4):
             tt = self.vt[r]
             e("v_accvgpr_read_b32", tt, self.run[b][r])
@@ -380,10 +413,16 @@ class Gen16(Gen64):
                 else:
                     e("s_mul_i32", self.s_t[0], self.s_ldc4, 16 * i + d)
                 for n in range(c.TN):
-                    e("buffer_load_dword", pool[d * c.TN + n], self.vC[n], self.srdC, self.s_t[0], offen=True)
+                    # (runv: straight into the running sum's own registers)
+                    dst = self.run[i * c.TN + n][d] if c.runv else pool[d * c.TN + n]
+                    e("buffer_load_dword", dst, self.vC[n], self.srdC, self.s_t[0], offen=True)
             e("s_waitcnt", vmcnt=0)
             for d in range(4):
                 for n in range(c.TN):
+                    if c.runv:
+                        x = self.run[i * c.TN + n][d]
+                        e("v_mul_f32", x, self.s_beta, x)
+                        continue
                     x = pool[d * c.TN + n]
                     e("v_mul_f32", x, self.s_beta, x)
                     e("v_accvgpr_write_b32", self.run[i * c.TN + n][d], x)
@@ -408,8 +447,11 @@ class Gen16(Gen64):
                     tt, uu = t[(2 * n) % 8], t[(2 * n + 1) % 8]
                     e("v_accvgpr_read_b32", tt, self.acc[b][d])
                     e("v_mul_f32", tt, self.s_alpha, tt)
-                    e("v_accvgpr_read_b32", uu, self.run[b][d])
-                    e("v_add_f32", tt, uu, tt)
+                    if c.runv:
+                        e("v_add_f32", tt, self.run[b][d], tt)
+                    else:
+                        e("v_accvgpr_read_b32", uu, self.run[b][d])
+                        e("v_add_f32", tt, uu, tt)
                     if "cstores" not in c.ablate:
                         e("buffer_store_dword", tt, self.vC[n], self.srdC, soff, offen=True)
             self.c_rows(row)

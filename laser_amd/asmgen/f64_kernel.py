@@ -19,15 +19,15 @@ from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_CONV1  #
 
 CONFIGS = {
     # one wave per SIMD: 2 x 2 waves of 64x64 = 16 blocks = 128 accumulator registers (+ 128 for the running sum)
-    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True),
+    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True, runv=True, dataa=True),
     "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False),
     # problems of few tiles (the reference's f64 bench shape, 960^3 = 225 tiles): 2 x 2 waves of 32x32, several workgroups per CU
-    "exact_64x64x16": dict(BM=64, BN=64, BK=16, exact=True),
+    "exact_64x64x16": dict(BM=64, BN=64, BK=16, exact=True, runv=True),
     "fast_64x64x16": dict(BM=64, BN=64, BK=16, exact=False),
     # B passed transposed (rowStrideB == 1: k-contiguous like A)
-    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True),
+    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True, runv=True, dataa=True),
     "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
-    "exact_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=True, b_kcontig=True),
+    "exact_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=True, b_kcontig=True, runv=True),
     "fast_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=False, b_kcontig=True),
 }
 KA_ALPHA64 = 72      # alpha, beta as float64 (the f32 kernels' float fields at 56 / 60 are unused here)
@@ -55,11 +55,14 @@ class Gen64(Gen):
         self.s_ldc4, self.s_ldc20 = S(), S()      # here: ldc * 8 bytes, 4 * ldc * 8 (the next accumulator row of a lane)
         self.alloc_sched()
         self.acc = [p.aalloc(8) for _ in range(c.NB)]
-        self.run = [p.aalloc(8) for _ in range(c.NB)] if c.exact else None
-        self.fa = [[V(4) for _ in range(c.TM)] for _ in range(2)]
-        self.fb = [[V(4) for _ in range(c.TN)] for _ in range(2)]
-        self.stA = [V(4) for _ in range(c.NPA)]
-        self.stB = [V(4) for _ in range(c.NPB)]
+        # runv / dataa (f32_kernel.py Cfg, round 6): the running sum in arch VGPRs (the slice fold of a block is 8 v_accvgpr_read + 4
+        # v_add_f64 where the all-AGPR plan has 28 VALU operations), fragments + staging in AGPRs where the VGPR file would overflow
+        self.run = [V(8) if c.runv else p.aalloc(8) for _ in range(c.NB)] if c.exact else None
+        D4 = (lambda n: p.aalloc(n)) if c.dataa else V
+        self.fa = [[D4(4) for _ in range(c.TM)] for _ in range(2)]
+        self.fb = [[D4(4) for _ in range(c.TN)] for _ in range(2)]
+        self.stA = [D4(4) for _ in range(c.NPA)]
+        self.stB = [D4(4) for _ in range(c.NPB)]
         self.st_sets = [(self.stA, self.stB)]
         self.RA = [[V() for _ in range(3)] for _ in range(c.NG)]
         self.RB = [[V() for _ in range(3)] for _ in range(c.NG)]
@@ -436,6 +439,10 @@ class Gen64(Gen):
         e("s_cbranch_scc1", lmul)
         p.place(lback)
         self.outlined.append((lmul, [("v_mul_f64", T.sub(2 * d, 2), self.s_al, T.sub(2 * d, 2)) for d in range(4)], lback))
+        if self.c.runv:
+            for d in range(4):
+                e("v_add_f64", self.run[b].sub(2 * d, 2), self.run[b].sub(2 * d, 2), T.sub(2 * d, 2))
+            return
         for d in range(4):
             tt = T.sub(8 + 2 * (d % 2), 2)
             e("v_accvgpr_read_b32", tt[0], self.run[b][2 * d])
@@ -444,12 +451,35 @@ class Gen64(Gen):
             e("v_accvgpr_write_b32", self.run[b][2 * d], tt[0])
             e("v_accvgpr_write_b32", self.run[b][2 * d + 1], tt[1])
 
+    def init_accumulators(self):
+        if not self.c.runv:
+            return Gen.init_accumulators(self)
+        from .f32_kernel import MODE_NORMAL
+        c, p = self.c, self.p
+        e = p.emit
+        for b in range(c.NB):
+            for r in range(c.ACCR):
+                e("v_accvgpr_write_b32", self.acc[b][r], 0)
+        keep = p.label("keeprun")
+        if c.persistent:
+            e("s_cmp_lg_u32", self.s_mode, MODE_NORMAL)
+            e("s_cbranch_scc1", keep)
+        for b in range(c.NB):
+            for d in range(4):
+                e("v_mov_b64", self.run[b].sub(2 * d, 2), 0)
+        self.load_beta_c()
+        p.place(keep)
+
     def fold_block(self, b):
         e, T = self.p.emit, self.vT[0]
         for r in range(8):
             e("v_accvgpr_read_b32", T[r], self.acc[b][r])
         for d in range(4):
             e("v_mul_f64", T.sub(2 * d, 2), self.s_al, T.sub(2 * d, 2))      # (1.0 * x is x)
+        if self.c.runv:
+            for d in range(4):
+                e("v_add_f64", self.run[b].sub(2 * d, 2), self.run[b].sub(2 * d, 2), T.sub(2 * d, 2))
+            return
         for d in range(4):
             tt = T.sub(8 + 2 * (d % 2), 2)
             e("v_accvgpr_read_b32", tt[0], self.run[b][2 * d])
@@ -514,9 +544,15 @@ class Gen64(Gen):
 
         def row(i, d):
             for n in range(c.TN):
-                e("buffer_load_dwordx2", pool[n], self.vC[n], self.srdC, 0, offen=True)
+                # (runv: straight into the running sum's own registers)
+                dst = self.run[i * c.TN + n].sub(2 * d, 2) if c.runv else pool[n]
+                e("buffer_load_dwordx2", dst, self.vC[n], self.srdC, 0, offen=True)
             e("s_waitcnt", vmcnt=0)
             for n in range(c.TN):
+                if c.runv:
+                    x = self.run[i * c.TN + n].sub(2 * d, 2)
+                    e("v_mul_f64", x, self.s_be, x)
+                    continue
                 e("v_mul_f64", pool[n], self.s_be, pool[n])
                 e("v_accvgpr_write_b32", self.run[i * c.TN + n][2 * d], pool[n][0])
                 e("v_accvgpr_write_b32", self.run[i * c.TN + n][2 * d + 1], pool[n][1])
@@ -550,9 +586,12 @@ class Gen64(Gen):
                     b = i * c.TN + n
                     tt, uu = T.sub(4 * (n % 2), 2), T.sub(4 * (n % 2) + 2, 2)
                     read_acc(tt, b, d)
-                    e("v_accvgpr_read_b32", uu[0], self.run[b][2 * d])
-                    e("v_accvgpr_read_b32", uu[1], self.run[b][2 * d + 1])
-                    e("v_add_f64", tt, uu, tt)
+                    if c.runv:
+                        e("v_add_f64", tt, self.run[b].sub(2 * d, 2), tt)
+                    else:
+                        e("v_accvgpr_read_b32", uu[0], self.run[b][2 * d])
+                        e("v_accvgpr_read_b32", uu[1], self.run[b][2 * d + 1])
+                        e("v_add_f64", tt, uu, tt)
                     e("buffer_store_dwordx2", tt, self.vC[n], self.srdC, 0, offen=True)
             self.c_walk(row)
         else:

@@ -473,6 +473,17 @@ class Workgroup:
             with np.errstate(all="ignore"):
                 r = {"v_add_f32": x + y, "v_mul_f32": x * y, "v_sub_f32": x - y, "v_max_f32": np.fmax(x, y)}[op]
             self.wr_v(w, A[0], u32(r.astype(np.float32)))
+        elif op == "v_mov_b64":
+            assert A[0].n == 2 and A[0].kind == "v"
+            if isinstance(A[1], Reg):
+                assert A[1].n == 2
+                for h in range(2):
+                    self.wr_v(w, A[0][h], rv(w, A[1][h]))
+            else:
+                val = int(A[1])
+                assert 0 <= val <= 64, "inline constant"
+                self.wr_v(w, A[0][0], np.full(LANES, val, dtype=U32))
+                self.wr_v(w, A[0][1], np.zeros(LANES, dtype=U32))
         elif op == "v_pk_add_f32":
             assert A[0].n == 2 and A[1].n == 2 and A[2].n == 2
             for h in range(2):
