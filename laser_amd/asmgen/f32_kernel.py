@@ -1610,6 +1610,8 @@ class Gen:
         # VALU work is batched, never spread.  (Moving the sums AGPR -> LDS -> VGPR instead, which needs no VALU
         # moves, measured slower: profiles/r03/asm_probe_v8.jsonl "exact_lds".)
         T = self.vT[0]
+        if "foldreads" in self.c.ablate:      # (pricing experiments: results are wrong)
+            return
         for r in range(16):
             self.p.emit("v_accvgpr_read_b32", T[r], self.acc[b][r])
 
@@ -1624,6 +1626,12 @@ class Gen:
         self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(16)], lback))
         if c_runv(self):
             # the running sum is in arch VGPRs: two adds per instruction, nothing to move (8 VALU operations where the AGPR plan has 48)
+            if "foldadds" in self.c.ablate:
+                return
+            if "foldscalar" in self.c.ablate:     # (pricing: 16 single adds instead of 8 packed ones -- same result)
+                for r in range(16):
+                    e("v_add_f32", self.run[b][r], self.run[b][r], T[r])
+                return
             for j in range(8):
                 e("v_pk_add_f32", self.run[b].sub(2 * j, 2), self.run[b].sub(2 * j, 2), T.sub(2 * j, 2))
             return

@@ -132,12 +132,12 @@ def test_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, kw):
 # result must be the same bits as one workgroup per tile: ragged M / N, strided C, alpha != 1, exactly 3 K-tiles (the switch happens in
 # the transition body's own tail), folds inside a tile, several wave interleavings.
 PIPE_CASES = [
-    ("exact_64x64x32", 130, 200, 1088, dict(G=3, strided=True)),
+    ("exact_64x64x32", 130, 200, 576, dict(G=3, strided=True)),
     ("exact_64x64x32", 130, 200, 96, dict(G=5, strided=True, ldc=205)),                       # 3 K-tiles: no body between two switches
     ("exact_64x64x32", 130, 200, 128, dict(G=4, strided=True, alpha=0.75, order=[3, 1, 0, 2])),
     ("exact_64x64x32_nt", 130, 200, 576, dict(G=2, strided=True, lda=580, ldb=584, xcd=True, group_m=2)),
     ("exact_256x128x32", 300, 260, 96, dict(G=2, strided=True, ldc=270)),
-    ("exact_256x128x32", 520, 130, 1056, dict(G=1, strided=True, alpha=-2.0)),                # one workgroup walks every tile; folds + transition
+    ("exact_256x128x32", 520, 130, 544, dict(G=1, strided=True, alpha=-2.0)),                # one workgroup walks every tile; folds + transition
     ("exact_256x128x32_nt", 300, 260, 160, dict(G=3, strided=True, csc=2)),
     ("exact_128x128x16", 140, 390, 560, dict(G=2, strided=True, csc=2)),
     ("exact_128x128x32", 260, 390, 160, dict(G=4, strided=True, order=[2, 0, 3, 1])),
@@ -146,12 +146,12 @@ PIPE_CASES = [
     ("fast_128x128x16_nt", 140, 390, 80, dict(G=3, strided=True, ldc=400)),
     ("fast_64x64x32", 130, 200, 160, dict(G=7, strided=True, xcd=True, group_m=2)),
     # contiguous ranges (the cut plans): whole tiles between the head and the tail piece of a range are pipelined too
-    ("exact_64x64x32", 130, 200, 1088, dict(G=5, split=True)),
-    ("exact_64x64x32", 130, 200, 1088, dict(G=8, split=True, two_level=True, noseed=1)),
+    ("exact_64x64x32", 130, 200, 576, dict(G=5, split=True)),
+    ("exact_64x64x32", 130, 200, 576, dict(G=8, split=True, two_level=True, noseed=1)),
     # launches that may NOT pipeline take the ordinary path: beta != 0, a bias, a K tail
-    ("exact_64x64x32", 130, 200, 1088, dict(G=3, strided=True, beta=0.5)),
-    ("exact_64x64x32", 130, 200, 1088, dict(G=3, strided=True, bias="row", act=1)),
-    ("exact_64x64x32", 130, 200, 1100, dict(G=3, strided=True)),
+    ("exact_64x64x32", 130, 200, 576, dict(G=3, strided=True, beta=0.5)),
+    ("exact_64x64x32", 130, 200, 576, dict(G=3, strided=True, bias="row", act=1)),
+    ("exact_64x64x32", 130, 200, 588, dict(G=3, strided=True)),
     ("fast_256x128x32", 300, 260, 64, dict(G=2, strided=True)),                               # two K-tiles only
 ]
 
@@ -177,7 +177,7 @@ def test_pipelined_transitions_are_really_taken():
         return orig(self, w)
     sim.Workgroup.step = step
     try:
-        assert C.run_case("exact_64x64x32", 130, 200, 1088, verbose=False, G=3, strided=True)      # 3 x 4 tiles on 3 workgroups
+        assert C.run_case("exact_64x64x32", 130, 200, 576, verbose=False, G=3, strided=True)      # 3 x 4 tiles on 3 workgroups
     finally:
         sim.Workgroup.step = orig
     assert seen == {"trans": 9, "done": 3}
@@ -353,22 +353,22 @@ X16_CASES = [
     ("fast_96x96x32_nt", 140, 30, 12, {}),
     ("exact_160x96x32", 170, 100, 548, dict(ldc=104)),
     ("fast_160x96x32", 161, 97, 36, dict(beta=2.0)),
-    ("exact_160x96x32_nt", 330, 200, 580, dict(alpha=-2.0, beta=1.0)),
+    ("exact_160x96x32_nt", 170, 100, 580, dict(alpha=-2.0, beta=1.0)),
     ("fast_160x96x32_nt", 40, 50, 96, {}),
     ("exact_96x96x32", 4, 4, 4, {}),
     ("exact_96x96x32", 100, 110, 64, dict(batch=2)),
-    ("exact_96x96x32", 100, 200, 1100, dict(G=3, split=True)),
-    ("exact_96x96x32", 200, 200, 1100, dict(G=5, split=True, alpha=0.75, beta=-1.5, noseed=1)),
-    ("exact_96x96x32_nt", 200, 300, 1028, dict(G=8, split=True, two_level=True, group_m=2)),
+    ("exact_96x96x32", 100, 100, 1100, dict(G=2, split=True)),
+    ("exact_96x96x32", 100, 200, 548, dict(G=3, split=True, alpha=0.75, beta=-1.5, noseed=1)),
+    ("exact_96x96x32_nt", 200, 300, 548, dict(G=8, split=True, two_level=True, group_m=2)),
     ("fast_96x96x32", 100, 200, 300, dict(G=5, split=2, integer=True, beta=2.0)),
-    ("exact_160x96x32", 330, 200, 600, dict(G=3, split=True, group_m=1)),
+    ("exact_160x96x32", 170, 200, 600, dict(G=3, split=True, group_m=1)),
     ("exact_96x96x32", 200, 200, 96, dict(G=2, strided=True)),
     ("exact_128x96x32", 130, 100, 548, dict(lda=552, ldb=104, ldc=108)),
     ("fast_128x96x32_nt", 129, 97, 100, dict(alpha=3.0, beta=0.5)),
-    ("exact_192x96x32_nt", 390, 100, 548, dict(G=2, split=True)),
+    ("exact_192x96x32_nt", 200, 100, 548, dict(G=2, split=True)),
     ("fast_192x96x32", 193, 97, 36, {}),
     ("exact_160x160x32", 170, 170, 548, dict(ldc=172)),
-    ("exact_160x160x32_nt", 330, 170, 1060, dict(G=3, split=True, alpha=0.75, beta=-1.5)),
+    ("exact_160x160x32_nt", 170, 170, 548, dict(G=2, split=True, alpha=0.75, beta=-1.5)),
 ]
 
 
