@@ -2073,3 +2073,33 @@ def test_f32_16x16_block_tiles_bit_exact(la, oracle):
             assert np.array_equal(C.cpu().numpy(), oracle.matmul(A.cpu().numpy(), B.cpu().numpy())), n
     finally:
         la.set_f32_asm(1); la.set_float_mode(0); la.set_option("asm_kernel", -1); la.set_option("asm_plan", 0); la.set_option("slice_parallel", 1)
+
+
+@pytest.mark.gpu
+def test_subnormal_products_sums_and_folds_bit_exact(la, oracle):
+    """Operands scaled so that products, chain sums, slice folds and results fall into the subnormal range (the oracle's fmaf chain on
+    the host keeps subnormals; the kernels run with denormals preserved: .amdhsa_float_denorm_mode_32 / _16_64 = 3): the matrix
+    instructions, the packed adds of the slice fold (v_pk_add_f32, round 6) and the epilogues must keep every bit -- every f32 tile
+    family forced, and float64 at ~1e-310 (scripts/denormal_probe.py is the same walk with counts)."""
+    import torch
+    rng = np.random.default_rng(5)
+    M, N, K = 640, 768, 1100
+    try:
+        for dt, scales in ((np.float32, (3e-20, 1e-20)), (np.float64, (3e-155,))):
+            for sc in scales:
+                A = (rng.uniform(-1, 1, (M, K)) * sc).astype(dt)
+                B = (rng.uniform(-1, 1, (K, N)) * sc).astype(dt)
+                want = oracle.matmul(A, B)
+                tiny = np.finfo(dt).tiny
+                assert np.mean((np.abs(want) < tiny) & (want != 0)) > 0.5, "the case must live in the subnormal range"
+                dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+                for kern in ((-1, 0, 2, 12, 30, 46, 50, 54, 58, 62) if dt == np.float32 else (-1,)):
+                    la.set_option("f32_asm", 2 if kern >= 0 else 1)
+                    la.set_option("asm_kernel", kern)
+                    la.set_option("asm_plan", 1 if kern >= 0 else 0)
+                    C = la.matmul(dA, dB).cpu().numpy()
+                    if dt == np.float32 and kern >= 0:
+                        assert la.last_f32_asm() == kern + 1
+                    assert np.array_equal(C, want), (np.dtype(dt).name, sc, kern, int(np.sum(C != want)))
+    finally:
+        la.set_option("asm_kernel", -1); la.set_option("asm_plan", 0); la.set_option("f32_asm", 1)
