@@ -59,7 +59,7 @@ class Cfg:
         # finishes tile T: per block, the chain set is read out, the block's first MFMA restarts the chain from +0 for the new tile,
         # and C = run + alpha * slice leaves for memory from the gap behind that MFMA (the running-sum set is zeroed on the way).  No
         # drain, no prologue, no first-load latency, no burst of C stores between two tiles of a workgroup.
-        self.pipe = (self.persistent and dtype == "f32" and not conv and not pre and not deep and not debug) if pipe is None else pipe
+        self.pipe = (self.persistent and dtype == "f32" and not conv and not pre and not deep and not debug) if pipe is None else pipe      # (f32x16: per configuration, f32x16_kernel.py)
         assert not (self.pipe and (not self.persistent or deep or debug or pre))
         f64, x16 = dtype == "f64", dtype == "f32x16"
         # f32: v_mfma_f32_32x32x2 (32x32 blocks, 2 k per instruction, one 16-byte fragment read feeds 4 k-steps);

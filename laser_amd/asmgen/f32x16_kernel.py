@@ -63,6 +63,10 @@ class Gen16(Gen64):
         self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
         self.s_ldc4 = S()
         self.alloc_sched()
+        if c.pipe:
+            # pipelined tile transitions (f32_kernel.py Cfg.pipe): bit 0 = this launch may pipeline, bit 1 = armed
+            self.s_pipe = S()
+            self.srdCd = S(4)        # C from this wave's first row of the tile being finished
         self.acc = [p.aalloc(4) for _ in range(c.NB)]
         # runv (f32_kernel.py Cfg): the running sum in arch VGPRs -- the slice fold is 4 v_accvgpr_read + 2 v_pk_add_f32 per block where
         # the all-AGPR plan has 16 VALU operations; dataa: fragments + staging in AGPRs (the tiles whose VGPR file would overflow)
@@ -112,6 +116,16 @@ class Gen16(Gen64):
             e("s_add_u32", st[3], st[3], st[4])
             e("s_add_u32", ptr[0], ptr[0], st[2])
             e("s_addc_u32", ptr[1], ptr[1], st[3])
+        if c.pipe:
+            # tile transitions of this launch may be pipelined: beta == 0 (the next tile's running sum starts at 0), K a multiple of BK
+            # (no K-tail masks to undo between tiles), at least three K-tiles (the switch happens two tile bodies before a tile's end)
+            e("s_and_b32", st[3], self.s_beta, 0x7fffffff)
+            e("s_and_b32", st[4], self.s_K, c.BK - 1)
+            e("s_or_b32", st[3], st[3], st[4])
+            e("s_cmp_eq_u32", st[3], 0)
+            e("s_cselect_b32", self.s_pipe, 1, 0)
+            e("s_cmp_lt_u32", self.s_K, 3 * c.BK)
+            e("s_cselect_b32", self.s_pipe, 0, self.s_pipe)
         tid = v(0)
         lane, r16, q = t[0], t[1], t[2]
         e("v_and_b32", lane, 63, tid)
@@ -315,6 +329,72 @@ class Gen16(Gen64):
             e("v_add_f32", tt, tt, T[r])
             e("v_accvgpr_write_b32", self.run[b][r], tt)
 
+    def trans_after(self, b):
+        """transition body (Cfg.pipe), block b = (i, n): vT[0..3] hold the slice sum of the tile being FINISHED, the MFMA in front of this
+        gap has restarted the chain for the new tile: C = run + alpha * slice (one chain: alpha * sum) leaves for memory from here, the
+        running sum is zeroed for the new tile (beta == 0 in pipelined launches).  Rows (+ d, + 16 i) through the stores' scalar offset
+        from srdCd = this wave's first row of the old tile."""
+        c, p, e, T, st = self.c, self.p, self.p.emit, self.vT[0], self.s_t
+        i, n = b // c.TN, b % c.TN
+        lmul, lback = p.label("tmul"), p.label("tback")
+        e("s_cmp_lg_u32", self.s_alpha, 0x3f800000)
+        e("s_cbranch_scc1", lmul)
+        p.place(lback)
+        self.outlined.append((lmul, [("v_mul_f32", T[r], self.s_alpha, T[r]) for r in range(4)], lback))
+        soff = st[0]
+        pair = v(self.vt[0].idx, 4)
+        for d in range(4):
+            if c.exact:
+                if c.runv:
+                    if d % 2 == 0:
+                        e("v_pk_add_f32", pair.sub(d, 2), self.run[b].sub(d, 2), T.sub(d, 2))
+                        e("v_mov_b64", self.run[b].sub(d, 2), 0)
+                    tt = pair[d]
+                else:
+                    tt = self.vt[d]
+                    e("v_accvgpr_read_b32", tt, self.run[b][d])
+                    e("v_add_f32", tt, tt, T[d])
+                    e("v_accvgpr_write_b32", self.run[b][d], 0)
+            else:
+                tt = T[d]
+            if 16 * i + d:
+                e("s_mul_i32", soff, self.s_ldc4, 16 * i + d)
+            else:
+                e("s_mov_b32", soff, 0)
+            e("buffer_store_dword", tt, self.vC[n], self.srdCd, soff, offen=True)
+            self.vm_issue(("S", b, d))
+
+    def pipe_c_addr(self):
+        """(vC, srdCd) for the deferred stores of the tile (m0, n0): srdCd starts at this wave's first row, vC[n] = the lane's offset
+        from there (4 q rows down, block column n; out of bounds beyond N)"""
+        c, e, t, st = self.c, self.p.emit, self.vt, self.s_t
+        lane, r16, q = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, v(0))
+        e("v_and_b32", r16, 15, lane)
+        e("v_lshrrev_b32", q, 4, lane)
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("s_mul_hi_u32", st[2], st[0], self.s_ldc4)
+        e("s_mul_i32", st[3], st[0], self.s_ldc4)
+        e("s_add_u32", self.srdCd[0], self.srdC[0], st[3])
+        e("s_addc_u32", self.srdCd[1], self.srdC[1], st[2])
+        e("s_and_b32", self.srdCd[1], self.srdCd[1], 0xffff)
+        e("s_mov_b32", self.srdCd[3], 0x00020000)
+        e("s_sub_u32", self.srdCd[2], self.srdC[2], st[3])              # what is left of C from there (0: the wave's rows lie beyond M)
+        e("s_cselect_b32", self.srdCd[2], 0, self.srdCd[2])
+        e("s_cmp_lg_u32", st[2], 0)
+        e("s_cselect_b32", self.srdCd[2], 0, self.srdCd[2])
+        e("v_lshlrev_b32", t[3], 2, q)
+        e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], r16)
+        e("v_lshl_add_u32", t[3], t[4], 2, t[3])
+        for n in range(c.TN):
+            e("v_add_u32", t[5], 16 * n, t[4])
+            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
+            e("v_add_u32", t[6], 64 * n, t[3])
+            e("v_mov_b32", t[7], 0x80000000)
+            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+
     def init_accumulators(self):
         if not self.c.runv:
             return Gen.init_accumulators(self)
@@ -491,6 +571,7 @@ class Gen16(Gen64):
 
 def make(name, **over):
     kw = dict(CONFIGS[name])
+    kw.setdefault("pipe", True)       # pipelined tile transitions (the strided plan of the launcher): every tile of the family
     kw.update(over)
     return Gen16(Cfg(name, dtype="f32x16", **kw))
 

@@ -22,8 +22,12 @@ SHAPES = {
     "head": [(8192,) * 3],
     "shortk": [(8192, 3072, 1152), (8192, 3072, 576), (8192, 3072, 2304), (4096, 6144, 1152)],
     "mid": [(2560,) * 3, (3072,) * 3, (4096,) * 3, (4100, 4100, 4096), (5120,) * 3],
+    "x16": [(3072,) * 3, (4608,) * 3, (5120,) * 3, (7680,) * 3, (8192, 3072, 1152)],
 }[which]
 CANDS = {0: {0: "256x128", 30: "128x128x32", 2: "128x128", 12: "64x64"}, 1: {1: "256x256", 8: "256x128", 31: "128x128x32", 3: "128x128"}}
+if which == "x16":      # the 16x16-block tiles (f32x16_kernel.py), pipelined since round 6
+    CANDS = {0: {46: "96x96 (x16)", 50: "160x96 (x16)", 54: "128x96 (x16)", 58: "192x96 (x16)", 62: "160x160 (x16)"},
+             1: {47: "96x96 (x16)", 51: "160x96 (x16)", 55: "128x96 (x16)", 59: "192x96 (x16)", 63: "160x160 (x16)"}}
 if len(sys.argv) > 3:      # only these kernel indices
     keep = {int(x) for x in sys.argv[3].split(",")}
     CANDS = {m: {k: v for k, v in d.items() if k in keep} for m, d in CANDS.items()}

@@ -24,6 +24,7 @@ SHAPES = {
     "ref": [(1920,) * 3, (1536,) * 3],
     "more": [(1664,) * 3, (2304,) * 3, (2560,) * 3, (2944,) * 3, (3072,) * 3, (3584,) * 3, (5120,) * 3, (1000, 3000, 2000), (4100, 4100, 4100)],
     "small": [(768,) * 3, (960,) * 3, (1152,) * 3, (1344,) * 3],
+    "big2": [(5632,) * 3, (6912,) * 3, (7936,) * 3, (3328,) * 3],
     "big": [(4096,) * 3, (6144,) * 3, (8192,) * 3],
 }[which]
 # mode -> kernel index -> name (gemm_f32_asm.cpp kKernels)

@@ -369,6 +369,15 @@ X16_CASES = [
     ("fast_192x96x32", 193, 97, 36, {}),
     ("exact_160x160x32", 170, 170, 548, dict(ldc=172)),
     ("exact_160x160x32_nt", 170, 170, 548, dict(G=2, split=True, alpha=0.75, beta=-1.5)),
+    # pipelined tile transitions on this family: strided whole-tile plans, folds inside a tile, one chain, exactly three
+    # K-tiles, launches that may not pipeline (beta != 0, a K tail)
+    ("exact_96x96x32", 200, 300, 96, dict(G=2, strided=True, ldc=304)),
+    ("exact_96x96x32", 200, 300, 576, dict(G=3, strided=True, alpha=0.75)),
+    ("fast_96x96x32_nt", 200, 300, 128, dict(G=4, strided=True)),
+    ("exact_160x160x32_nt", 330, 170, 544, dict(G=1, strided=True)),
+    ("exact_192x96x32", 390, 200, 96, dict(G=3, strided=True, xcd=True, group_m=2)),
+    ("exact_96x96x32", 200, 300, 576, dict(G=3, strided=True, beta=0.5)),
+    ("exact_96x96x32", 200, 300, 580, dict(G=3, strided=True)),
 ]
 
 

@@ -2033,7 +2033,7 @@ def test_f32_16x16_block_tiles_bit_exact(la, oracle):
                 for base in (46, 50, 54, 58, 62):
                     kern = base + (0 if exact else 1) + (2 if nt else 0)
                     la.set_option("asm_kernel", kern)
-                    for plan in ((1, 0, 2) if mode == 0 else (1,)):       # (one chain: a K cut is another rounding order)
+                    for plan in ((1, 0, 2, 3) if mode == 0 else (1, 3)):       # (one chain: a K cut is another rounding order; 3 = strided whole tiles, pipelined transitions)
                         la.set_option("asm_plan", plan)
                         dC = wide.clone(); la.matmul(dA, dB, 1, 0, dC[:, :N])
                         assert la.last_f32_asm() == kern + 1, (M, N, K, mode, kern, plan, la.last_f32_asm())
