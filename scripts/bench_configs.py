@@ -219,8 +219,11 @@ def main():
             laser_amd.set_i32_mfma(on)
             med, mn = ev_time(lambda: laser_amd.matmul(Af, Bf, 1, 0, C))
             medq, _ = ev_time(lambda: laser_amd.matmul(Aq, Bq, 1, 0, C))
+            # roofline of the limb form: the int8 matrix-core ceiling (MI355X_MICROARCH.md: >= 3944 TOPS measured, dense) / 10 limb products
+            # per int32 multiply-add (README.md:214 of the reference: "int32 ... via the 8-bit path") = 394.4 Tint-op/s
             emit(config=f"gemm int32 {n}^3 " + ("(int8-limb MFMA)" if on else "(VALU kernel)"), operands="full range [-2^31, 2^31)",
                  ms_med=round(med, 4), tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3),
+                 **({"frac_i8_mfma_ceiling_over_10": round(2.0 * n ** 3 / (med * 1e-3) / 1e12 / 394.4, 4)} if on else {}),
                  quiet_operands_0_100={"ms_med": round(medq, 4), "tops": round(2.0 * n ** 3 / (medq * 1e-3) / 1e12, 3),
                                        "note": "the reference bench's inputs: three of four digit planes are zero, the chip clocks up"})
         laser_amd.set_i32_mfma(True)
@@ -251,7 +254,8 @@ def main():
             laser_amd.set_i64_mfma(on)
             med, mn = ev_time(lambda: laser_amd.matmul(A, B, 1, 0, C), iters=5 if n > 4096 else 9)
             emit(config=f"gemm int64 {n}^3 " + ("(int8-limb MFMA, 36 limb products)" if on else "(VALU kernel)"), operands="full range [-2^62, 2^62)", ms_med=round(med, 4),
-                 tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3))
+                 tops=round(2.0 * n ** 3 / (med * 1e-3) / 1e12, 3),
+                 **({"frac_i8_mfma_ceiling_over_36": round(2.0 * n ** 3 / (med * 1e-3) / 1e12 / (3944.0 / 36.0), 4)} if on else {}))
         laser_amd.set_i64_mfma(True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/configs.jsonl", "w") as f:
