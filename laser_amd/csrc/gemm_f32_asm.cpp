@@ -101,18 +101,18 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_fast_128x128x16_pre", 128, 128, 16, 0.91, 0.87, 6.0, 2},    {"lh_f32_fast_128x128x16_pre_nt", 128, 128, 16, 0.91, 0.87, 6.0, 2},
     {"lh_f32_exact_64x64x32_pre", 64, 64, 32, 0.84, 0.74, 3.0, 3},       {"lh_f32_exact_64x64x32_pre_nt", 64, 64, 32, 0.84, 0.74, 3.0, 3},
     {"lh_f32_fast_64x64x32_pre", 64, 64, 32, 0.85, 0.76, 3.0, 3},        {"lh_f32_fast_64x64x32_pre_nt", 64, 64, 32, 0.85, 0.76, 3.0, 3},
-    // (fitted to profiles/r06/x16_ab_{ref,mid}_g.jsonl, x16_ab_more_i.jsonl; the laser-order entries + 0.007 with the running sum in VGPRs, x16_ab_big2_n.jsonl: plain launches at 1536^3 .. 5120^3, 1000x3000x2000; the 64x64 tiles'
+    // (fitted to profiles/r06/x16_ab_{ref,mid}_g.jsonl, x16_ab_more_i.jsonl; the laser-order entries + 0.007 with the running sum in VGPRs, x16_ab_big2_n.jsonl; the many-round figures of pipe_ab_x16_p.jsonl at 7680^3 -- 0.963 / 0.972 on 160x160, 0.934 / 0.952 on 96x96 --: plain launches at 1536^3 .. 5120^3, 1000x3000x2000; the 64x64 tiles'
     // fixed cost 3 -> 6 us from the same runs: 1664^3 and 1000x3000x2000 took 84 / 98 us where the table said 80 / 92)
-    {"lh_f32x16_exact_96x96x32", 96, 96, 32, 0.917, 0.925, 5.0, 1},        {"lh_f32x16_fast_96x96x32", 96, 96, 32, 0.935, 0.92, 5.0, 1},
-    {"lh_f32x16_exact_96x96x32_nt", 96, 96, 32, 0.917, 0.925, 5.0, 1},     {"lh_f32x16_fast_96x96x32_nt", 96, 96, 32, 0.935, 0.92, 5.0, 1},
+    {"lh_f32x16_exact_96x96x32", 96, 96, 32, 0.925, 0.925, 5.0, 1},        {"lh_f32x16_fast_96x96x32", 96, 96, 32, 0.943, 0.93, 5.0, 1},
+    {"lh_f32x16_exact_96x96x32_nt", 96, 96, 32, 0.925, 0.925, 5.0, 1},     {"lh_f32x16_fast_96x96x32_nt", 96, 96, 32, 0.943, 0.93, 5.0, 1},
     {"lh_f32x16_exact_160x96x32", 160, 96, 32, 0.952, 0.958, 6.0, 1},    {"lh_f32x16_fast_160x96x32", 160, 96, 32, 0.96, 0.963, 6.0, 1},
     {"lh_f32x16_exact_160x96x32_nt", 160, 96, 32, 0.952, 0.958, 6.0, 1}, {"lh_f32x16_fast_160x96x32_nt", 160, 96, 32, 0.96, 0.963, 6.0, 1},
-    {"lh_f32x16_exact_128x96x32", 128, 96, 32, 0.932, 0.922, 5.5, 1},    {"lh_f32x16_fast_128x96x32", 128, 96, 32, 0.935, 0.94, 5.5, 1},
-    {"lh_f32x16_exact_128x96x32_nt", 128, 96, 32, 0.932, 0.922, 5.5, 1}, {"lh_f32x16_fast_128x96x32_nt", 128, 96, 32, 0.935, 0.94, 5.5, 1},
+    {"lh_f32x16_exact_128x96x32", 128, 96, 32, 0.938, 0.922, 5.5, 1},    {"lh_f32x16_fast_128x96x32", 128, 96, 32, 0.935, 0.94, 5.5, 1},
+    {"lh_f32x16_exact_128x96x32_nt", 128, 96, 32, 0.938, 0.922, 5.5, 1}, {"lh_f32x16_fast_128x96x32_nt", 128, 96, 32, 0.935, 0.94, 5.5, 1},
     {"lh_f32x16_exact_192x96x32", 192, 96, 32, 0.95, 0.952, 6.5, 1},    {"lh_f32x16_fast_192x96x32", 192, 96, 32, 0.962, 0.965, 6.5, 1},
     {"lh_f32x16_exact_192x96x32_nt", 192, 96, 32, 0.95, 0.952, 6.5, 1}, {"lh_f32x16_fast_192x96x32_nt", 192, 96, 32, 0.962, 0.965, 6.5, 1},
-    {"lh_f32x16_exact_160x160x32", 160, 160, 32, 0.952, 0.945, 8.0, 1},  {"lh_f32x16_fast_160x160x32", 160, 160, 32, 0.96, 0.956, 8.0, 1},
-    {"lh_f32x16_exact_160x160x32_nt", 160, 160, 32, 0.952, 0.945, 8.0, 1}, {"lh_f32x16_fast_160x160x32_nt", 160, 160, 32, 0.96, 0.956, 8.0, 1}};
+    {"lh_f32x16_exact_160x160x32", 160, 160, 32, 0.959, 0.945, 8.0, 1},  {"lh_f32x16_fast_160x160x32", 160, 160, 32, 0.968, 0.956, 8.0, 1},
+    {"lh_f32x16_exact_160x160x32_nt", 160, 160, 32, 0.959, 0.945, 8.0, 1}, {"lh_f32x16_fast_160x160x32_nt", 160, 160, 32, 0.968, 0.956, 8.0, 1}};
 // plain kernel -> its `_pre` variant (-1: none)
 int pre_variant(int k) {
   switch (k) {
@@ -606,8 +606,11 @@ hipError_t choose_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, int c
   const bool x16_ok = a.K % 4 == 0 && a.csC == 1 && !fused && !pre;
   const int x96 = x16_ok ? 46 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0) : -1, x160 = x16_ok ? x96 + 4 : -1;
   const int x128 = x16_ok ? x96 + 8 : -1, x192 = x16_ok ? x96 + 12 : -1, x160s = x16_ok ? x96 + 16 : -1;
-  const int classes[10] = {big, mid, small, deep, tiny, x96, x160, x128, x192, x160s};
-  for (int ci = 0; ci < 10; ci++) {
+  const int classes[10] = {big, mid, small, deep, tiny, x96, x160, x128, x192, x160s};      // (index = the tile class of option "asm_tile")
+  // near ties go to the class asked first: within a block family, the larger tile (less L2 traffic, fewer workgroups)
+  const int order[10] = {0, 1, 2, 3, 4, 9, 8, 6, 7, 5};
+  for (int oi = 0; oi < 10; oi++) {
+    const int ci = order[oi];
     const int k0 = classes[ci];
     if (tile_pin >= 0 && ci != (tile_pin == 1 && mid < 0 ? 0 : tile_pin)) continue;
     if (k0 < 0 || (g_asm_kernel >= 0 && k0 != g_asm_kernel)) continue;
