@@ -129,7 +129,7 @@ int laser_hip_f32_config_count(void);
  *                          call): 0 = 256x128 (laser-order) / 256x256, 1 = 256x128 one chain, 2 = 128x128x16 (two workgroups per CU:
  *                          degrades gracefully when another library's kernels -- RCCL's -- hold some CUs), 3 = 128x128x32, 4 = 64x64,
  *                          5 = 96x96, 6 = 160x96, 7 = 128x96, 8 = 192x96, 9 = 160x160 on 16x16 blocks (v_mfma_f32_16x16x4_f32: K % 4 == 0,
- *                          dense C, plain epilogue);
+ *                          no fused prologue);
  *                          one tile per workgroup, no minimum tile count; -1 = the launcher's model decides.
  *   "thread_asm_tile" [-2] the same pin for the launches made BY THE CALLING THREAD only (-2 = none: "asm_tile" applies; -1 = the
  *                          model decides whatever "asm_tile" says).  The per-GPU processes of laser_amd/distributed.py set 2 around

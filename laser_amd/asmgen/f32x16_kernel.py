@@ -17,11 +17,11 @@ K-slice hand-overs), with the f64 kernels' padded-row LDS image (f64_kernel.py) 
   16 different 4-bank groups, no swizzle).  Stores are two ds_write2_b32 per 16-byte piece:
   A piece (k0 .. k0 + 3 of one row, k0 = 4 pc)   -> the same word of chunks 4g .. 4g + 3:   +0, +16, +32, +48 bytes
   B piece (columns x0 .. x0 + 3 of one k)        -> the same word of rows x0 .. x0 + 3:      +0, +144, +288, +432 bytes
-Operands: A row-major (k-contiguous), B row-major or passed transposed (`_nt`), C row-major with unit column stride; K a multiple
-of 4 (16-byte pieces are all-or-nothing); any alpha / beta; no fused bias / activation (the launcher keeps those on the 32x32-block
-kernels)."""
+Operands: A row-major (k-contiguous), B row-major or passed transposed (`_nt`), C with any positive column stride (rows slow); K a multiple
+of 4 (16-byte pieces are all-or-nothing); any alpha / beta; fused epilogue C = act(.. + bias) with a strided bias view and relu like the
+32x32-block kernels (README.md:238-242 of the reference plans this fusion); no fused prologue."""
 from .core import v, s, VCC
-from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_CONV1, KA_BSA  # noqa: F401
+from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_CONV1, KA_BSA, KA_BIAS, KA_EPI  # noqa: F401
 from .f64_kernel import Gen64
 
 CONFIGS = {
@@ -62,7 +62,10 @@ class Gen16(Gen64):
         self.s_t = [S() for _ in range(6)]
         self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
         self.s_ldc4 = S()
+        self.s_csC4 = S()                      # column stride of C in bytes (KA_EPI + 12; 0 in the arguments = dense)
         self.alloc_sched()
+        self.srdBias = S(4)                    # fused epilogue: the bias view (base, -, bytes, flags)
+        self.s_epi = S(4, align=4)             # rowStrideBias, colStrideBias (elements), activation, -
         if c.pipe:
             # pipelined tile transitions (f32_kernel.py Cfg.pipe): bit 0 = this launch may pipeline, bit 1 = armed
             self.s_pipe = S()
@@ -119,7 +122,13 @@ class Gen16(Gen64):
         if c.pipe:
             # tile transitions of this launch may be pipelined: beta == 0 (the next tile's running sum starts at 0), K a multiple of BK
             # (no K-tail masks to undo between tiles), at least three K-tiles (the switch happens two tile bodies before a tile's end)
-            e("s_and_b32", st[3], self.s_beta, 0x7fffffff)
+            e("s_load_dwordx2", self.srdBias.sub(0, 2), s(0, 2), KA_BIAS)
+            e("s_load_dword", st[2], s(0, 2), KA_EPI + 8)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_or_b32", st[3], self.srdBias[0], self.srdBias[1])
+            e("s_or_b32", st[3], st[3], st[2])             # (a bias pointer or an activation: the fused epilogue, not a transition body)
+            e("s_and_b32", st[4], self.s_beta, 0x7fffffff)
+            e("s_or_b32", st[3], st[3], st[4])
             e("s_and_b32", st[4], self.s_K, c.BK - 1)
             e("s_or_b32", st[3], st[3], st[4])
             e("s_cmp_eq_u32", st[3], 0)
@@ -275,7 +284,14 @@ class Gen16(Gen64):
         e("s_and_b32", self.srdC[1], C_[1], 0xffff)
         e("s_sub_u32", st[0], self.s_M, 1)
         e("s_mul_i32", st[0], st[0], self.s_ldc4)
-        e("s_lshl_b32", st[2], self.s_N, 2)
+        # C[i][j] at i * ldc + j * csC (MatrixView, gemm_utils.nim:36-60): bytes = (M - 1) * ldc * 4 + (N - 1) * csC * 4 + 4
+        e("s_load_dword", self.s_csC4, s(0, 2), KA_EPI + 12)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_max_u32", self.s_csC4, self.s_csC4, 1)
+        e("s_lshl_b32", self.s_csC4, self.s_csC4, 2)
+        e("s_sub_u32", st[2], self.s_N, 1)
+        e("s_mul_i32", st[2], st[2], self.s_csC4)
+        e("s_add_u32", st[2], st[2], 4)
         e("s_add_u32", self.srdC[2], st[0], st[2])
         e("s_mov_b32", self.srdC[3], 0x00020000)
 
@@ -387,13 +403,16 @@ class Gen16(Gen64):
         e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
         e("s_add_u32", st[1], self.s_n0, self.s_wn0)
         e("v_add_u32", t[4], st[1], r16)
-        e("v_lshl_add_u32", t[3], t[4], 2, t[3])
+        e("v_mul_lo_u32", t[6], t[4], self.s_csC4)
+        e("v_add_u32", t[3], t[3], t[6])
+        e("s_lshl_b32", st[1], self.s_csC4, 4)
         for n in range(c.TN):
             e("v_add_u32", t[5], 16 * n, t[4])
             e("v_cmp_gt_u32", VCC, self.s_N, t[5])
-            e("v_add_u32", t[6], 64 * n, t[3])
+            if n:
+                e("v_add_u32", t[3], st[1], t[3])
             e("v_mov_b32", t[7], 0x80000000)
-            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+            e("v_cndmask_b32", self.vC[n], t[7], t[3], VCC)
 
     def init_accumulators(self):
         if not self.c.runv:
@@ -455,13 +474,16 @@ class Gen16(Gen64):
         e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
         e("s_add_u32", st[1], self.s_n0, self.s_wn0)
         e("v_add_u32", t[4], st[1], r16)
-        e("v_lshl_add_u32", t[3], t[4], 2, t[3])
+        e("v_mul_lo_u32", t[6], t[4], self.s_csC4)
+        e("v_add_u32", t[3], t[3], t[6])                 # row * ldc * 4 + col * csC * 4
+        e("s_lshl_b32", st[1], self.s_csC4, 4)           # 16 columns further
         for n in range(c.TN):
             e("v_add_u32", t[5], 16 * n, t[4])
             e("v_cmp_gt_u32", VCC, self.s_N, t[5])
-            e("v_add_u32", t[6], 64 * n, t[3])
+            if n:
+                e("v_add_u32", t[3], st[1], t[3])
             e("v_mov_b32", t[7], 0x80000000)
-            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
+            e("v_cndmask_b32", self.vC[n], t[7], t[3], VCC)
 
     def c_rows(self, fn):
         """fn(i, d, soff): this lane's accumulator rows in C order; soff = the SGPR holding (16 i + d) * ldc * 4"""
@@ -508,6 +530,90 @@ class Gen16(Gen64):
                     e("v_accvgpr_write_b32", self.run[i * c.TN + n][d], x)
         p.place(skip)
 
+    def fused_epilogue(self):
+        """bias pointer != 0 or activation != 0: C = act((run | 0) + alpha * sum + bias), the bias added with one more rounding after the
+        last slice, relu = max(x, 0) -- f32_kernel.Gen.fused_epilogue on the 16x16 lane map; a path of its own so that the plain epilogue
+        carries none of it.  One-chain kernels: beta == 0 only (the launcher guarantees it).  Ends the program."""
+        c, p = self.c, self.p
+        e, t, st = p.emit, self.vt, self.s_t
+        plain = p.label("plain")
+        e("s_load_dwordx2", self.srdBias.sub(0, 2), s(0, 2), KA_BIAS)
+        e("s_load_dwordx4", self.s_epi, s(0, 2), KA_EPI)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_or_b32", st[0], self.srdBias[0], self.srdBias[1])
+        e("s_or_b32", st[1], st[0], self.s_epi[2])
+        e("s_cmp_eq_u32", st[1], 0)
+        e("s_cbranch_scc1", plain)
+        # bias descriptor: a null pointer gets a zero-size buffer (every load returns 0: x + 0 is x); bytes of the view =
+        # ((M - 1) * rowStride + (N - 1) * colStride + 1) * 4 -- rows / columns of a ragged tile beyond it read 0
+        e("s_and_b32", self.srdBias[1], self.srdBias[1], 0xffff)
+        e("s_sub_u32", st[2], self.s_M, 1)
+        e("s_mul_i32", st[2], st[2], self.s_epi[0])
+        e("s_sub_u32", st[3], self.s_N, 1)
+        e("s_mul_i32", st[3], st[3], self.s_epi[1])
+        e("s_add_u32", st[2], st[2], st[3])
+        e("s_add_u32", st[2], st[2], 1)
+        e("s_lshl_b32", st[2], st[2], 2)
+        e("s_cmp_eq_u32", st[0], 0)
+        e("s_cselect_b32", self.srdBias[2], 0, st[2])
+        e("s_mov_b32", self.srdBias[3], 0x00020000)
+        self.c_addr_setup()
+        # bias offsets of D[4 q][r16] of block column n: (row * rsBias + col * csBias) * 4; the rows of a lane travel in the loads'
+        # scalar offset like C's ((16 i + d) * rsBias * 4)
+        lane, r16, q = t[0], t[1], t[2]
+        vB = [self.vT[0][8 + n] for n in range(c.TN)]
+        assert c.TN <= 8
+        e("s_lshl_b32", st[2], self.s_epi[0], 2)          # rowStrideBias * 4
+        e("s_add_u32", st[3], self.s_m0, self.s_wm0)
+        e("v_lshl_add_u32", t[3], q, 2, st[3])
+        e("v_mul_lo_u32", t[3], t[3], st[2])
+        e("s_add_u32", st[3], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[3], r16)
+        e("s_lshl_b32", st[4], self.s_epi[1], 2)          # colStrideBias * 4
+        e("v_mul_lo_u32", t[4], t[4], st[4])
+        e("v_add_u32", t[3], t[3], t[4])
+        e("s_lshl_b32", st[4], st[4], 4)                  # 16 columns further
+        for n in range(c.TN):
+            if n == 0:
+                e("v_mov_b32", vB[0], t[3])
+            else:
+                e("v_add_u32", vB[n], st[4], vB[n - 1])
+        P = self.vT[0]
+        soff, boff = st[0], st[1]
+        for i in range(c.TM):
+            for d in range(4):
+                if i == 0 and d == 0:
+                    e("s_mov_b32", soff, 0)
+                    e("s_mov_b32", boff, 0)
+                else:
+                    e("s_mul_i32", soff, self.s_ldc4, 16 * i + d)
+                    e("s_mul_i32", boff, st[2], 16 * i + d)
+                for n in range(c.TN):
+                    e("buffer_load_dword", P[n], vB[n], self.srdBias, boff, offen=True)
+                e("s_waitcnt", vmcnt=0)
+                assert c.TN <= 5      # (one temporary per block column: the whole row is computed, then the activation, then the stores)
+                for n in range(c.TN):
+                    b = i * c.TN + n
+                    tt, uu = t[n], t[5 + n]
+                    e("v_accvgpr_read_b32", tt, self.acc[b][d])
+                    e("v_mul_f32", tt, self.s_alpha, tt)
+                    if c.exact and c.runv:
+                        e("v_add_f32", tt, self.run[b][d], tt)
+                    elif c.exact:
+                        e("v_accvgpr_read_b32", uu, self.run[b][d])
+                        e("v_add_f32", tt, uu, tt)
+                    e("v_add_f32", tt, P[n], tt)
+                skip = p.label("norelu")
+                e("s_cmp_lg_u32", self.s_epi[2], 1)
+                e("s_cbranch_scc1", skip)
+                for n in range(c.TN):
+                    e("v_max_f32", t[n], 0, t[n])
+                p.place(skip)
+                for n in range(c.TN):
+                    e("buffer_store_dword", t[n], self.vC[n], self.srdC, soff, offen=True)
+        self.end_run()
+        p.place(plain)
+
     def epilogue(self):
         """C = beta * C0 + alpha * (slice sums in order) -- gemm_ukernel_generic.nim:53-76 -- predicated by the descriptor's bounds check"""
         c, p = self.c, self.p
@@ -518,6 +624,7 @@ class Gen16(Gen64):
         self.vmq.clear()
         self.lgq.clear()
         self.mode_dispatch()
+        self.fused_epilogue()
         self.c_addr_setup()
         if c.exact:
             # C = run + alpha * (the last slice's sum); run already carries beta * C0 and the earlier slices

@@ -596,14 +596,15 @@ hipError_t choose_gemm_f32_asm(const GemmArgs<float> &a, bool laser_order, int c
   const int deep = 30 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0);    // 128x128 with the 32-deep K-tile: one workgroup per CU
   const double cu_flops_per_us = 157.3e6 / 256.0;
   // the one-chain kernels' fused epilogue has no C read: beta != 0 with a bias / activation only on the laser-order kernels
-  const auto lo_kernel = [](int k) { return k == 0 || k == 2 || k == 4 || k == 6 || k == 12 || k == 14 || k == 30 || k == 32; };
+  const auto lo_kernel = [](int k) { return k == 0 || k == 2 || k == 4 || k == 6 || k == 12 || k == 14 || k == 30 || k == 32 || (k >= 46 && k <= 65 && (k - 46) % 2 == 0); };
   const bool pre = a.preA != 0 || a.preB != 0;
   // A pinned tile class (option "asm_tile" / the sharded entry point's LASER_HIP_SHARD_PIN_TILE on its worker threads): the local
   // products of a multi-GPU run that shares the CUs with RCCL's kernels.  One tile per workgroup then -- a persistent plan counts on
   // every workgroup slot of the chip -- and no lower bound on the tile count (the caller asked for THIS kernel family).
   const int tile_pin = asm_tile_pin_now();
-  // 16x16-block tiles (f32x16_kernel.py): 16-byte pieces are all-or-nothing (K % 4 == 0), dense columns of C, plain epilogue
-  const bool x16_ok = a.K % 4 == 0 && a.csC == 1 && !fused && !pre;
+  // 16x16-block tiles (f32x16_kernel.py): 16-byte pieces are all-or-nothing (K % 4 == 0), no fused prologue (the fused epilogue --
+  // bias view + relu -- and a column stride on C are theirs too)
+  const bool x16_ok = a.K % 4 == 0 && !pre;
   const int x96 = x16_ok ? 46 + ((exact || a.K <= 512) ? 0 : 1) + (nt ? 2 : 0) : -1, x160 = x16_ok ? x96 + 4 : -1;
   const int x128 = x16_ok ? x96 + 8 : -1, x192 = x16_ok ? x96 + 12 : -1, x160s = x16_ok ? x96 + 16 : -1;
   const int classes[10] = {big, mid, small, deep, tiny, x96, x160, x128, x192, x160s};      // (index = the tile class of option "asm_tile")

@@ -378,6 +378,16 @@ X16_CASES = [
     ("exact_192x96x32", 390, 200, 96, dict(G=3, strided=True, xcd=True, group_m=2)),
     ("exact_96x96x32", 200, 300, 576, dict(G=3, strided=True, beta=0.5)),
     ("exact_96x96x32", 200, 300, 580, dict(G=3, strided=True)),
+    # fused epilogue C = act(beta * C0 + alpha * A B + bias): bias as a row / a column / a full view, relu; five block columns (160x160)
+    ("exact_96x96x32", 100, 110, 548, dict(bias="row", act=1, ldc=114)),
+    ("fast_96x96x32", 100, 210, 40, dict(bias="col", act=1)),
+    ("exact_160x96x32", 170, 100, 100, dict(bias="full", act=0, alpha=0.5, beta=2.0)),
+    ("fast_160x160x32_nt", 170, 165, 36, dict(act=1)),
+    ("exact_96x96x32", 200, 300, 96, dict(G=3, strided=True, bias="row", act=1)),
+    # C with a column stride (MatrixView, gemm_utils.nim:36-60): nothing written between the columns
+    ("exact_96x96x32", 70, 90, 548, dict(csc=2, ldc=190)),
+    ("fast_160x160x32", 40, 300, 72, dict(csc=2, alpha=3.0, beta=0.5)),
+    ("exact_192x96x32_nt", 300, 260, 160, dict(G=3, strided=True, csc=2)),
 ]
 
 

@@ -848,7 +848,7 @@ def test_full_size_transposed_b_4096_every_element(la, oracle):
     Cbuf = torch.zeros((n, 2 * n), device="cuda")
     C = Cbuf[:, ::2]         # colStride 2
     la.matmul(A, B, 1, 0, C)
-    assert la.last_f32_asm() in (5, 7, 15, 33), la.last_f32_asm()      # the `_nt` assembly kernels: the strided C is their own epilogue (the 16x16-block tiles take dense columns only)
+    assert la.last_f32_asm() in (5, 7, 15, 33, 49, 53, 57, 61, 65), la.last_f32_asm()      # the `_nt` assembly kernels: the strided C is their own epilogue
     want = oracle.matmul(np.ascontiguousarray(A.cpu().numpy()), np.ascontiguousarray(B.cpu().numpy()))
     assert np.array_equal(C.cpu().numpy(), want)
     assert (Cbuf[:, 1::2] == 0).all()
@@ -2063,6 +2063,20 @@ def test_f32_16x16_block_tiles_bit_exact(la, oracle):
                         if mode == 0:
                             w = oracle.matmul(A.cpu().numpy(), np.ascontiguousarray(B.cpu().numpy()), al, be, C0.cpu().numpy().copy())
                             assert np.array_equal(c1.cpu().numpy(), w), (M, N, K, al, be, kern)
+        # a column stride on C (MatrixView, gemm_utils.nim:36-60): the tiles' own epilogue, plain and pipelined; the gaps stay untouched
+        M, N, K = 1000, 1056, 1028
+        A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
+        B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
+        la.set_float_mode(0); la.set_f32_asm(0)
+        ref = la.matmul(A, B)
+        la.set_f32_asm(2)
+        for base in (46, 50, 54, 58, 62):
+            for plan in (1, 3):
+                la.set_option("asm_kernel", base); la.set_option("asm_plan", plan)
+                w = torch.full((M, 3 * N), 9.0, device="cuda")
+                la.matmul(A, B, 1, 0, w[:, ::3])
+                assert la.last_f32_asm() == base + 1, (base, la.last_f32_asm())
+                assert torch.equal(w[:, ::3], ref) and (w[:, 1::3] == 9.0).all() and (w[:, 2::3] == 9.0).all(), (base, plan)
         # the launch model takes them where they fill the chip better: the reference's bench shape and 1536^3
         la.set_f32_asm(1); la.set_float_mode(0); la.set_option("asm_kernel", -1); la.set_option("asm_plan", 0)
         for n, fam in ((1920, (51, 47)), (1536, (47,)), (2560, (63,))):
@@ -2103,3 +2117,45 @@ def test_subnormal_products_sums_and_folds_bit_exact(la, oracle):
                     assert np.array_equal(C, want), (np.dtype(dt).name, sc, kern, int(np.sum(C != want)))
     finally:
         la.set_option("asm_kernel", -1); la.set_option("asm_plan", 0); la.set_option("f32_asm", 1)
+
+
+@pytest.mark.gpu
+def test_fused_epilogue_on_the_16x16_block_tiles(la, oracle):
+    """The fused epilogue act(alpha*A*B + beta*C + bias) of the 16x16-block tile family (f32x16_kernel.py fused_epilogue: bias row / column /
+    full views through the loads' scalar offset, relu): every tile forced, same bits as the compiler-scheduled EPI kernels and, in
+    laser-order mode, as the oracle; a fused launch never takes the pipelined transitions."""
+    import torch
+    rng = np.random.default_rng(405)
+    try:
+        for (M, N, K) in [(1056, 1100, 1028), (800, 1000, 260)]:
+            A = torch.from_numpy(rand(rng, (M, K), np.float32)).cuda()
+            B = torch.from_numpy(rand(rng, (K, N), np.float32)).cuda()
+            C0 = torch.from_numpy(rand(rng, (M, N), np.float32)).cuda()
+            biases = {"col": torch.from_numpy(rand(rng, (1, N), np.float32)).cuda(), "row": torch.from_numpy(rand(rng, (M, 1), np.float32)).cuda(),
+                      "full": torch.from_numpy(rand(rng, (M, N), np.float32)).cuda(), "none": None}
+            for mode in (0, 1):
+                al, be = (0.75, -0.5) if mode == 0 else (0.75, 0.0)
+                exact = mode == 0 or K <= 512
+                for bname, bias in biases.items():
+                    act = "relu" if bname in ("col", "none") else None
+                    la.set_float_mode(mode); la.set_f32_asm(0); la.set_option("slice_parallel", 0)
+                    ref = la.matmul(A, B, alpha=al, beta=be, out=C0.clone(), bias=bias, activation=act)
+                    assert la.last_f32_asm() == 0
+                    want = None
+                    if mode == 0:
+                        base = oracle.matmul(A.cpu().numpy(), B.cpu().numpy(), alpha=np.float32(al), beta=np.float32(be), C_=C0.cpu().numpy().copy(),
+                                             isa=oracle.fused_isa(np.float32))
+                        want = oracle.apply_epilogue(base, None if bias is None else bias.cpu().numpy(), act)
+                    la.set_f32_asm(2)
+                    for base_k in (46, 50, 54, 58, 62):
+                        kern = base_k + (0 if exact else 1)
+                        for plan in (1, 3):
+                            la.set_option("asm_kernel", kern); la.set_option("asm_plan", plan)
+                            got = la.matmul(A, B, alpha=al, beta=be, out=C0.clone(), bias=bias, activation=act)
+                            assert la.last_f32_asm() == kern + 1, (M, N, K, mode, bname, kern, la.last_f32_asm())
+                            assert torch.equal(got, ref), (M, N, K, mode, bname, kern, plan)
+                            if want is not None:
+                                assert np.array_equal(got.cpu().numpy(), want), (M, N, K, bname, kern, plan)
+                    la.set_option("asm_kernel", -1); la.set_option("asm_plan", 0)
+    finally:
+        la.set_f32_asm(1); la.set_float_mode(0); la.set_option("asm_kernel", -1); la.set_option("asm_plan", 0); la.set_option("slice_parallel", 1)

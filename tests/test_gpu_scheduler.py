@@ -237,7 +237,7 @@ def test_full_size_c3_transposed_b_dense_c_every_element(la, oracle):
     A, B = torch.from_numpy(Ah).cuda(), torch.from_numpy(Bt).cuda().t()
     C = torch.zeros((n, n), device="cuda")
     la.matmul(A, B, 1, 0, C)
-    assert la.last_f32_asm() in (5, 7, 15), la.last_f32_asm()
+    assert la.last_f32_asm() in (5, 7, 15, 33, 49, 53, 57, 61, 65), la.last_f32_asm()
     assert np.array_equal(C.cpu().numpy(), oracle.matmul(Ah, np.ascontiguousarray(Bt.T)))
 
 
