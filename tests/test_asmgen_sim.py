@@ -359,7 +359,7 @@ X16_CASES = [
     ("exact_96x96x32", 100, 110, 64, dict(batch=2)),
     ("exact_96x96x32", 100, 100, 1100, dict(G=2, split=True)),
     ("exact_96x96x32", 100, 200, 548, dict(G=3, split=True, alpha=0.75, beta=-1.5, noseed=1)),
-    ("exact_96x96x32_nt", 200, 300, 548, dict(G=8, split=True, two_level=True, group_m=2)),
+    ("exact_96x96x32_nt", 200, 200, 548, dict(G=8, split=True, two_level=True, group_m=2)),
     ("fast_96x96x32", 100, 200, 300, dict(G=5, split=2, integer=True, beta=2.0)),
     ("exact_160x96x32", 170, 200, 600, dict(G=3, split=True, group_m=1)),
     ("exact_96x96x32", 200, 200, 96, dict(G=2, strided=True)),
@@ -367,17 +367,17 @@ X16_CASES = [
     ("fast_128x96x32_nt", 129, 97, 100, dict(alpha=3.0, beta=0.5)),
     ("exact_192x96x32_nt", 200, 100, 548, dict(G=2, split=True)),
     ("fast_192x96x32", 193, 97, 36, {}),
-    ("exact_160x160x32", 170, 170, 548, dict(ldc=172)),
+    ("exact_160x160x32", 170, 100, 548, dict(ldc=104)),
     ("exact_160x160x32_nt", 170, 170, 548, dict(G=2, split=True, alpha=0.75, beta=-1.5)),
     # pipelined tile transitions on this family: strided whole-tile plans, folds inside a tile, one chain, exactly three
     # K-tiles, launches that may not pipeline (beta != 0, a K tail)
     ("exact_96x96x32", 200, 300, 96, dict(G=2, strided=True, ldc=304)),
-    ("exact_96x96x32", 200, 300, 576, dict(G=3, strided=True, alpha=0.75)),
+    ("exact_96x96x32", 200, 200, 576, dict(G=2, strided=True, alpha=0.75)),
     ("fast_96x96x32_nt", 200, 300, 128, dict(G=4, strided=True)),
-    ("exact_160x160x32_nt", 330, 170, 544, dict(G=1, strided=True)),
+    ("exact_160x160x32_nt", 330, 170, 96, dict(G=1, strided=True)),
     ("exact_192x96x32", 390, 200, 96, dict(G=3, strided=True, xcd=True, group_m=2)),
-    ("exact_96x96x32", 200, 300, 576, dict(G=3, strided=True, beta=0.5)),
-    ("exact_96x96x32", 200, 300, 580, dict(G=3, strided=True)),
+    ("exact_96x96x32", 100, 200, 576, dict(G=1, strided=True, beta=0.5)),
+    ("exact_96x96x32", 100, 200, 580, dict(G=1, strided=True)),
     # fused epilogue C = act(beta * C0 + alpha * A B + bias): bias as a row / a column / a full view, relu; five block columns (160x160)
     ("exact_96x96x32", 100, 110, 548, dict(bias="row", act=1, ldc=114)),
     ("fast_96x96x32", 100, 210, 40, dict(bias="col", act=1)),
