@@ -993,7 +993,7 @@ class Gen:
             self.first_tiles_done()
             return
         L_slow, L_join = p.label("fewtiles"), p.label("tiles01")
-        fast = not c.conv and not c.debug
+        fast = not c.debug      # (round 6: the convolution kernels too -- their prologue used to pay two memory latencies per tile)
         if fast:
             # Three or more K-tiles (no tile of the first two is the ragged last one): tiles 0 AND 1 are requested back to back --
             # tile 0 into the fragment registers (idle until the first fragment read), tile 1 into the staging registers where the loop
@@ -1003,9 +1003,13 @@ class Gen:
             e("s_cmp_lt_u32", self.s_rem, 3)
             e("s_cbranch_scc1", L_slow)
             pool = [r for slot in range(2) for r in (self.fa[slot] + self.fb[slot])]
-            assert len(pool) >= c.NPA + c.NPB
             real = (self.stA, self.stB)
-            tmp = (pool[:c.NPA], pool[c.NPA:c.NPA + c.NPB])
+            if c.conv:      # (B's pieces are register PAIRS there: two to a fragment register quad)
+                assert 4 * len(pool) >= 4 * c.NPA + 2 * c.NPB
+                tmp = (pool[:c.NPA], [pool[c.NPA + i // 2].sub(2 * (i % 2), 2) for i in range(c.NPB)])
+            else:
+                assert len(pool) >= c.NPA + c.NPB
+                tmp = (pool[:c.NPA], pool[c.NPA:c.NPA + c.NPB])
             self.stA, self.stB = tmp
             self.issue_loads_all()
             self.advance_srds()
@@ -1013,9 +1017,16 @@ class Gen:
             self.issue_loads_all()
             self.advance_srds()
             self.stA, self.stB = tmp
+            if c.conv:
+                # (the gathers of a tile are requested before its filter pieces: stored in that order, so that every counted wait names
+                # tile 0's loads; the table reads of tile 1's gathers were waited for before these stores were issued, in the other path
+                # after them: all LDS operations drained here keeps the two paths' queues alike)
+                self.run_ops([o for grp in self.conv_store_ops(2) for o in grp])
             for pi in range(c.NPA):
                 self.store_A_piece(pi, k=2)
-            if c.b_kcontig:
+            if c.conv:
+                self.lg_wait(None)
+            elif c.b_kcontig:
                 for pj in range(c.NPB):
                     self.store_B_kpiece(pj, k=2)
             else:
