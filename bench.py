@@ -52,7 +52,9 @@ ASM_KERNEL_SYMBOLS = [
     "lh_f32x16_exact_160x96x32", "lh_f32x16_fast_160x96x32", "lh_f32x16_exact_160x96x32_nt", "lh_f32x16_fast_160x96x32_nt",
     "lh_f32x16_exact_128x96x32", "lh_f32x16_fast_128x96x32", "lh_f32x16_exact_128x96x32_nt", "lh_f32x16_fast_128x96x32_nt",
     "lh_f32x16_exact_192x96x32", "lh_f32x16_fast_192x96x32", "lh_f32x16_exact_192x96x32_nt", "lh_f32x16_fast_192x96x32_nt",
-    "lh_f32x16_exact_160x160x32", "lh_f32x16_fast_160x160x32", "lh_f32x16_exact_160x160x32_nt", "lh_f32x16_fast_160x160x32_nt"]
+    "lh_f32x16_exact_160x160x32", "lh_f32x16_fast_160x160x32", "lh_f32x16_exact_160x160x32_nt", "lh_f32x16_fast_160x160x32_nt",
+    "lh_f32_conv_exact_256x128x32_p", "lh_f32_conv_fast_256x128x32_p", "lh_f32_conv_exact_128x128x32_p", "lh_f32_conv_fast_128x128x32_p",
+    "lh_f32_conv_exact_64x128x32_p", "lh_f32_conv_fast_64x128x32_p"]
 ASM_KERNEL_NAMES = {1 + i: n + " (hand-scheduled assembly)" for i, n in enumerate(ASM_KERNEL_SYMBOLS)}
 COMPILER_KERNEL_NAME = "gemm_mfma_kernel<float,...> (compiler-scheduled)"
 

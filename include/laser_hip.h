@@ -101,6 +101,9 @@ int laser_hip_f32_config_count(void);
  *   "conv_tail"        [1] the pixel tail behind the hand-scheduled 3x3 conv main launch (npix % 128 pixels per image) as ONE launch
  *                          of the latency-built direct kernel (a wave per 32x32 block and kc slice, ordered fold in LDS); 0 = the
  *                          compiler-scheduled tail forms
+ *   "conv_walk"        [1] assembly convolution main launch as unit walkers (a workgroup runs units (image, tile) g, g + G, ... with
+ *                          pipelined transitions) where there are more units than workgroup slots; 0 never, 2 whenever there are two units,
+ *                          >= 3: that many workgroups (tests).  Same bits either way.
  *   "conv_cut_always"  [0] tests / probes: cut every 3x3 convolution at its last whole 128-pixel tile, whatever the launch model says
  *   "conv_kslice"      [1] laser-order conv tail as parallel kc slices (gemm.nim:150-158) + ordered combine
  *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only

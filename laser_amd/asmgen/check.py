@@ -209,10 +209,11 @@ if __name__ == "__main__":
     sys.exit(0 if ok else 1)
 
 
-def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=None, verbose=True, bias=False, act=0, kernel=(3, 3), stride=(1, 1)):
+def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=None, verbose=True, bias=False, act=0, kernel=(3, 3), stride=(1, 1), G=None):
     """implicit-GEMM convolution kernels (any kH x kW of up to Cfg.ntmax taps, any strides / zero padding / output width): every image
-    through the interpreter, against im2col (conv2d_im2col.nim:62-87) + the slice-ordered model"""
-    g = K.make(name)
+    through the interpreter, against im2col (conv2d_im2col.nim:62-87) + the slice-ordered model.  G: the unit-walking form of the
+    kernel (Cfg.cpers), G workgroups over images x tiles units with pipelined transitions"""
+    g = K.make(name, cpers=True) if G else K.make(name)
     g.build()
     c = g.c
     rng = np.random.default_rng(seed)
@@ -242,11 +243,21 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
     ka += struct.pack("<IIQ", kH | kW << 8 | sH << 16 | sW << 24, NT | ((1024 + kW - 1) // kW) << 16, Cin * H * W * 4)
     ka += struct.pack("<Q", M * npix * 4)
     ka += struct.pack("<QIIII", bias_ptr, 1, 0, act, 0)
-    ka += sched_bytes(tm, tn, tm * tn)        # one tile per workgroup, tile rows fastest (an image's pixels stay together)
+    if G:
+        # units = images x tiles (an image's tiles stay together), workgroup g walks units g, g + G, ...
+        T = tm * tn
+        sb = bytearray(sched_bytes(tm, tn, T))
+        sb[32:64] = struct.pack("<8I", 0, T, K.magic_u32(T), G, T * images, 0, 0, 0)
+        ka += bytes(sb)
+    else:
+        ka += sched_bytes(tm, tn, tm * tn)        # one tile per workgroup, tile rows fastest (an image's pixels stay together)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
-    run_grid(g.p, mem, ka_, tm * tn, images, c.lds_alloc, order)
+    if G:
+        run_grid(g.p, mem, ka_, G, 1, c.lds_alloc, order)
+    else:
+        run_grid(g.p, mem, ka_, tm * tn, images, c.lds_alloc, order)
     got = mem.get(c_, np.float32, (images, M, npix))
     ok = True
     for img in range(images):

@@ -21,8 +21,15 @@ from .core import Prog, Reg, Sym, v, a, s, VCC, EXEC, OFF, M0
 class Cfg:
     def __init__(self, name, BM, BN, BK, exact, bar_gap=None, w_start=2, w_step=None, trace=False, b_kcontig=False,
                  b_store="write2", ablate=(), r_step=1, debug=False, filler=None, filler_every=1, conv=False, dtype="f32",
-                 persistent=None, pre=False, deep=False, pipe=None, il=False, runv=False, dataa=None):
+                 persistent=None, pre=False, deep=False, pipe=None, il=False, runv=False, dataa=None, cpers=False):
         self.name, self.BM, self.BN, self.BK, self.exact = name, BM, BN, BK, exact
+        # cpers (round 6): a convolution kernel whose workgroups walk units (image, tile) g, g + G, g + 2G ... of the launch with
+        # PIPELINED transitions (pipe, below) -- a scheduler of three SGPRs (next unit, image, armed bit): the K-slice hand-overs of the
+        # GEMM scheduler do not exist here (the convolution is never cut along K), and its state would not fit beside the tap arithmetic
+        self.cpers = cpers
+        assert not cpers or (conv and not debug and not persistent)
+        if cpers:
+            persistent, pipe = False, True
         # il (round 6): the three LDS stages are INTERLEAVED by row -- row r of stage s at r * 3 * RS + s * RS -- instead of three
         # consecutive panel images.  A stage is then an immediate offset of the LDS instructions (s * 128 bytes: inside the 16-bit offset
         # of ds_read_b128 next to the block offset, and inside ds_write2_b32's 8-bit dword offsets), so ONE address register per
@@ -60,7 +67,7 @@ class Cfg:
         # and C = run + alpha * slice leaves for memory from the gap behind that MFMA (the running-sum set is zeroed on the way).  No
         # drain, no prologue, no first-load latency, no burst of C stores between two tiles of a workgroup.
         self.pipe = (self.persistent and dtype == "f32" and not conv and not pre and not deep and not debug) if pipe is None else pipe      # (f32x16: per configuration, f32x16_kernel.py)
-        assert not (self.pipe and (not self.persistent or deep or debug or pre))
+        assert not (self.pipe and ((not self.persistent and not cpers) or deep or debug or pre))
         f64, x16 = dtype == "f64", dtype == "f32x16"
         # f32: v_mfma_f32_32x32x2 (32x32 blocks, 2 k per instruction, one 16-byte fragment read feeds 4 k-steps);
         # f64: v_mfma_f64_16x16x4 (16x16 blocks, 4 k per instruction, one 16-byte read feeds 2 k-steps): 8 k per group either way;
@@ -139,6 +146,13 @@ CONFIGS = {
     "conv_fast_128x128x32": dict(BM=128, BN=128, BK=32, exact=False, conv=True),
     "conv_exact_64x128x32": dict(BM=64, BN=128, BK=32, exact=True, il=True, runv=True, conv=True),
     "conv_fast_64x128x32": dict(BM=64, BN=128, BK=32, exact=False, conv=True),
+    # the convolution kernels as unit walkers (Cfg.cpers): workgroup g runs units (image, tile) g, g + G, ... with pipelined transitions
+    "conv_exact_256x128x32_p": dict(BM=256, BN=128, BK=32, exact=True, il=True, runv=True, bar_gap=95, conv=True, cpers=True),
+    "conv_fast_256x128x32_p": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, conv=True, cpers=True),
+    "conv_exact_128x128x32_p": dict(BM=128, BN=128, BK=32, exact=True, il=True, runv=True, conv=True, cpers=True),
+    "conv_fast_128x128x32_p": dict(BM=128, BN=128, BK=32, exact=False, conv=True, cpers=True),
+    "conv_exact_64x128x32_p": dict(BM=64, BN=128, BK=32, exact=True, il=True, runv=True, conv=True, cpers=True),
+    "conv_fast_64x128x32_p": dict(BM=64, BN=128, BK=32, exact=False, conv=True, cpers=True),
     "fast_256x128x32": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95),
     "fast_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=False, bar_gap=95, b_kcontig=True),
     # one round of 128x128 tiles (129 .. 256 of them: 1920^3, 2048^3): a workgroup has its CU to itself, and the 16-deep K-tile of
@@ -312,6 +326,8 @@ class Gen:
             self.s_tile = None
             if not c.conv:
                 self.s_sc = S(8, align=4)
+            if c.cpers:
+                self.s_tcur, self.s_img = S(), S()         # the next unit of this workgroup; the image of the tile being loaded
 
     # ------------------------------------------------------------------ queue models -> counted waits
     def vm_issue(self, tag):
@@ -659,6 +675,13 @@ class Gen:
             tile = self.s_tile
             e("s_load_dwordx8", self.s_sc, s(0, 2), KA_SCHED)
             e("s_waitcnt", lgkmcnt=0)
+        elif c.cpers:
+            e("s_mov_b32", self.s_tcur, s(2))
+            p.place(self.L_run)
+            e("s_barrier", comment="every wave is done with the previous unit's LDS tiles and tap table")
+            self.next_unit(self.L_exit)
+            self.run_setup()
+            return
         else:
             e("s_load_dwordx8", self.s_sc, s(0, 2), KA_SCHED)
             e("s_load_dword", st[5], s(0, 2), KA_SCHED2)
@@ -870,7 +893,7 @@ class Gen:
         for i in range(1, NP):
             e("v_add_u32", Voff[i], st[4], Voff[i - 1])
 
-    def ab_descriptors(self):
+    def ab_descriptors(self, again=False):
         """srdA / srdB of the run k in [kb, kb + Keff) of tile (m0, n0).  Clobbers s_t[0], [2], [3], [5]."""
         c, p = self.c, self.p
         e = p.emit
@@ -897,7 +920,7 @@ class Gen:
         e("s_add_u32", self.srdA[2], st[0], st[2])
         e("s_mov_b32", self.srdA[3], 0x00020000)
         if c.conv:
-            self.conv_setup()
+            self.conv_setup(again)
             if c.debug:
                 for r_ in range(0, 20, 4):
                     self.dump_lds(f"tab[{r_ * 256}+4tid]", r_ * 256)
@@ -1179,8 +1202,9 @@ class Gen:
         C_ = self.ka0.sub(4, 2)
         e("s_lshl_b32", self.s_ldc4, self.s_ldc, 2)
         if c.conv:
-            e("s_mul_hi_u32", st[2], s(3), self.s_scr[12])
-            e("s_mul_i32", st[0], s(3), self.s_scr[12])
+            img = self.s_img if c.cpers else s(3)
+            e("s_mul_hi_u32", st[2], img, self.s_scr[12])
+            e("s_mul_i32", st[0], img, self.s_scr[12])
             e("s_add_u32", self.srdC[0], C_[0], st[0])
             e("s_addc_u32", self.srdC[1], C_[1], st[2])
             e("s_and_b32", self.srdC[1], self.srdC[1], 0xffff)
@@ -1229,7 +1253,9 @@ class Gen:
     # k = 8w .. 8w+7 of every K-tile: pairs (k, k+2) per lane exactly like the GEMM's pair mode.
     CONV_DELTA = (0, 2, 1, 3, 4, 6, 5, 7)      # piece i = 2*pair + j gathers k = 8w + delta: pairs (0,2) (1,3) (4,6) (5,7)
 
-    def conv_setup(self):
+    def conv_setup(self, again=False):
+        """per tile: the geometry, the lanes' pixels, the tap table, srdB, the tap state; again (Cfg.cpers, the switch to the next unit
+        inside the K loop): the per-lane LDS write addresses -- the same for every tile -- are left alone"""
         c, p, e, t, st, scr = self.c, self.p, self.p.emit, self.vt, self.s_t, self.s_scr
         B_ = self.ka0.sub(2, 2)
         sH, sW, soW, spH, spW, sCin, sNpix, smagic, sgeo, snt = (scr[i] for i in range(10))
@@ -1309,8 +1335,9 @@ class Gen:
         e("s_barrier")
         # descriptor: base = B + b * bsB - (pH*W + pW) * 4 (the window origin of output pixel (0, 0), kernel tap (0, 0));
         # every address a valid lane forms lies inside the image -- the bounds field only has to reject v_oob
-        e("s_mul_hi_u32", st[2], s(3), scr[10])
-        e("s_mul_i32", st[0], s(3), scr[10])
+        img = self.s_img if c.cpers else s(3)
+        e("s_mul_hi_u32", st[2], img, scr[10])
+        e("s_mul_i32", st[0], img, scr[10])
         e("s_add_u32", st[0], B_[0], st[0])
         e("s_addc_u32", st[2], B_[1], st[2])
         e("s_mul_i32", st[3], spH, sW)
@@ -1325,7 +1352,7 @@ class Gen:
         e("s_mov_b32", self.s_Cin, sCin)
         # LDS write addresses of pair gi, pixel e: x = 2*lane + e, k = 8w + (0, 1, 4, 5)[gi]: L = 2w + (gi & 1), word = (0,0,2,2)[gi]
         e("s_mov_b32", st[0], c.LDS0 + c.ROWP * c.BM)
-        for gi in range(4):
+        for gi in range(0 if again else 4):
             e("s_lshl_b32", st[3], self.s_wave, 1)
             e("s_add_u32", st[3], st[3], gi & 1)
             for ee in range(2):
@@ -1718,9 +1745,13 @@ class Gen:
         e("v_mul_lo_u32", t[3], t[3], self.s_ldc4)
         e("s_add_u32", st[1], self.s_n0, self.s_wn0)
         e("v_add_u32", t[4], st[1], lo)
-        e("v_mul_lo_u32", t[6], t[4], self.s_csC4)
-        e("v_add_u32", t[3], t[3], t[6])
-        e("s_lshl_b32", st[5], self.s_csC4, 5)
+        if self.s_csC4 is None:           # (convolution kernels: C's columns are adjacent)
+            e("v_lshl_add_u32", t[3], t[4], 2, t[3])
+            e("s_mov_b32", st[5], 128)
+        else:
+            e("v_mul_lo_u32", t[6], t[4], self.s_csC4)
+            e("v_add_u32", t[3], t[3], t[6])
+            e("s_lshl_b32", st[5], self.s_csC4, 5)
         for n in range(c.TN):
             e("v_add_u32", t[5], 32 * n, t[4])
             e("v_cmp_gt_u32", VCC, self.s_N, t[5])
@@ -1731,7 +1762,62 @@ class Gen:
             e("v_mov_b32", t[7], 0x80000000)
             e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
 
+    def next_unit(self, L_none):
+        """Cfg.cpers: the workgroup's next unit -> s_img, s_m0, s_n0 (L_none when there is none).  KA_SCHED2 carries, for these kernels,
+        +4 the tiles of one image, +8 their magic number, +12 the stride (= workgroups), +16 the units of the launch (images x tiles).
+        Clobbers s_scr[0..7] (dead outside a tile body's load section) and s_t[0..5]."""
+        c, e, st, sc = self.c, self.p.emit, self.s_t, self.s_sc
+        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED2)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_cmp_ge_u32", self.s_tcur, sc[4])
+        e("s_cbranch_scc1", L_none)
+        self.udiv(self.s_img, self.s_tcur, sc[2])
+        e("s_mul_i32", st[4], self.s_img, sc[1])
+        e("s_sub_u32", st[4], self.s_tcur, st[4])                     # the tile inside the image
+        e("s_add_u32", self.s_tcur, self.s_tcur, sc[3])
+        e("s_load_dwordx8", sc, s(0, 2), KA_SCHED)
+        e("s_waitcnt", lgkmcnt=0)
+        self.tile_coords(st[4], sc, st[0], st[1], (st[2], st[3], st[5]))
+        e("s_mul_i32", self.s_m0, st[0], c.BM)
+        e("s_mul_i32", self.s_n0, st[1], c.BN)
+
+    def pipe_switch_conv(self, stubs, rets):
+        """pipe_switch of the convolution kernels (Cfg.cpers).  Every wave that gets here has passed the barrier of the tile body it
+        comes from, and a wave only reaches that barrier after its last look at the tap table (the table reads of a body precede its
+        gathers, the gathers the barrier): the table of the tile being finished can be overwritten at once; conv_setup's own barrier
+        stands between the new table's writes and its first reads.  Scalar tap state, srdB and srdC move to the next unit; the C
+        addresses of the tile being finished were put aside first."""
+        c, p = self.c, self.p
+        e, st = p.emit, self.s_t
+        L_sw, L_out = p.label("switch"), p.label("swout")
+        for site, lab in stubs.items():
+            p.place(lab)
+            e("s_or_b32", self.s_pipe, self.s_pipe, site << 4)
+            e("s_branch", L_sw)
+        p.place(L_sw)
+        e("s_bitcmp1_b32", self.s_pipe, 0)
+        e("s_cbranch_scc0", L_out)
+        e("s_load_dword", st[0], s(0, 2), KA_SCHED2 + 16)
+        e("s_waitcnt", lgkmcnt=0)
+        e("s_cmp_lt_u32", self.s_tcur, st[0])
+        e("s_cbranch_scc0", L_out)
+        self.pipe_c_addr()
+        self.next_unit(L_out)
+        self.ab_descriptors(again=True)
+        self.c_descriptor()
+        e("s_or_b32", self.s_pipe, self.s_pipe, 2)
+        p.place(L_out)
+        e("s_lshr_b32", st[0], self.s_pipe, 4)
+        e("s_and_b32", self.s_pipe, self.s_pipe, 15)
+        sites = sorted(rets)
+        for site in sites[:-1]:
+            e("s_cmp_eq_u32", st[0], site)
+            e("s_cbranch_scc1", rets[site])
+        e("s_branch", rets[sites[-1]])
+
     def pipe_switch(self, stubs, rets):
+        if self.c.cpers:
+            return self.pipe_switch_conv(stubs, rets)
         """out of line, reached from the tail of the tile body after which TWO K-tiles of the tile are left (every load of the tile has
         been requested): if the next run of this workgroup is another whole tile of a launch that may pipeline, the C addresses of the
         tile being finished are put aside, the scheduler moves on and srdA / srdB are pointed at the next tile -- the two tile bodies
@@ -2294,7 +2380,7 @@ class Gen:
 
     # ------------------------------------------------------------------ runs that share a tile: workspace, flags, ordered fix-up
     def end_run(self):
-        if self.c.persistent:
+        if self.c.persistent or self.c.cpers:
             self.p.emit("s_branch", self.L_run)
         else:
             self.p.emit("s_endpgm")
@@ -2514,7 +2600,7 @@ class Gen:
         for label, fn in self.outlined_blocks:
             self.p.place(label)
             fn()
-        if self.c.persistent:
+        if self.c.persistent or self.c.cpers:
             self.p.place(self.L_exit)
             self.p.emit("s_endpgm")
         return self.p

@@ -1564,6 +1564,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "conv_kslice") g_conv_kslice = on;
   else if (n == "conv_tail") g_conv_tail = on;
   else if (n == "conv_cut_always") g_conv_cut_always = on;
+  else if (n == "conv_walk") g_conv_walk = value < 0 ? 0 : value > 65535 ? 65535 : value;
   else if (n == "host_pipeline_2d") g_ctx.host_pipeline_2d = on;
   else if (n == "zero_copy_poll") g_ctx.zc_poll = on;
   else if (n == "skinny") g_ctx.skinny = on;
@@ -1602,6 +1603,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "conv_kslice") *value = g_conv_kslice;
   else if (n == "conv_tail") *value = g_conv_tail;
   else if (n == "conv_cut_always") *value = g_conv_cut_always;
+  else if (n == "conv_walk") *value = g_conv_walk;
   else if (n == "host_pipeline_2d") *value = g_ctx.host_pipeline_2d;
   else if (n == "zero_copy_poll") *value = g_ctx.zc_poll;
   else if (n == "skinny") *value = g_ctx.skinny;

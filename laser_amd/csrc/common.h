@@ -226,6 +226,7 @@ extern std::atomic<int> g_conv_direct;        // few output channels x short K: 
 hipError_t launch_conv_direct_small_f32(const GemmArgs<float> &a, hipStream_t s);
 extern std::atomic<int> g_conv_patch;         // implicit conv: LDS input patch where it fits (1, default) or always the gather (0)
 extern std::atomic<int> g_last_conv_tail;
+extern std::atomic<int> g_conv_walk;          // assembly conv main launch as unit walkers with pipelined transitions: 1 where units > slots (default), 0 never, 2 always, >= 3 that many workgroups (tests)
 extern std::atomic<int> g_conv_cut_always;    // tests / probes: cut every 3x3 convolution at its last whole 128-pixel tile (0, default)
 extern std::atomic<int> g_conv_tail;          // the direct tail kernel behind the assembly conv main launch (1, default)
 hipError_t launch_conv_tail_f32(const GemmArgs<float> &a, int kc, hipStream_t s);

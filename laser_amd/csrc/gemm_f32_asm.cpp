@@ -75,7 +75,10 @@ struct KernelInfo {
 // the reference's own benchmark shape 1920^3 (gemm_bench_float32.nim:383-410) is 240 tiles of 160x96 against 225 of 128x128 on 256
 // CUs; 1536^3 is 256 tiles of 96x96 against 144 of 128x128
 // [54..65]: the same family's 128x96, 192x96 and 160x160 tiles (four variants each, in that order)
-constexpr int kNumKernels = 66;
+// [66..71]: the convolution kernels [10] [11] [21..24] as unit walkers (f32_kernel.py Cfg.cpers): a workgroup runs units (image, tile)
+// g, g + G, g + 2G ... and goes from one to the next inside its K loop (the next unit's first gathers before the old tile's last
+// K-tiles are multiplied, the old tile's C stores from the gaps of the new tile's first K-tile body)
+constexpr int kNumKernels = 72;
 const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32_exact_256x128x32", 256, 128, 32, 0.965, 0.965, 10.0, 1},    {"lh_f32_fast_256x256x16", 256, 256, 16, 0.98, 0.98, 12.0, 1},
     {"lh_f32_exact_128x128x16", 128, 128, 16, 0.95, 0.92, 6.0, 2},       {"lh_f32_fast_128x128x16", 128, 128, 16, 0.96, 0.93, 6.0, 2},
@@ -112,7 +115,10 @@ const KernelInfo kKernels[kNumKernels] = {
     {"lh_f32x16_exact_192x96x32", 192, 96, 32, 0.95, 0.952, 6.5, 1},    {"lh_f32x16_fast_192x96x32", 192, 96, 32, 0.962, 0.965, 6.5, 1},
     {"lh_f32x16_exact_192x96x32_nt", 192, 96, 32, 0.95, 0.952, 6.5, 1}, {"lh_f32x16_fast_192x96x32_nt", 192, 96, 32, 0.962, 0.965, 6.5, 1},
     {"lh_f32x16_exact_160x160x32", 160, 160, 32, 0.959, 0.945, 8.0, 1},  {"lh_f32x16_fast_160x160x32", 160, 160, 32, 0.968, 0.956, 8.0, 1},
-    {"lh_f32x16_exact_160x160x32_nt", 160, 160, 32, 0.959, 0.945, 8.0, 1}, {"lh_f32x16_fast_160x160x32_nt", 160, 160, 32, 0.968, 0.956, 8.0, 1}};
+    {"lh_f32x16_exact_160x160x32_nt", 160, 160, 32, 0.959, 0.945, 8.0, 1}, {"lh_f32x16_fast_160x160x32_nt", 160, 160, 32, 0.968, 0.956, 8.0, 1},
+    {"lh_f32_conv_exact_256x128x32_p", 256, 128, 32, 0.90, 0.90, 15.0, 1}, {"lh_f32_conv_fast_256x128x32_p", 256, 128, 32, 0.90, 0.90, 15.0, 1},
+    {"lh_f32_conv_exact_128x128x32_p", 128, 128, 32, 0.82, 0.82, 12.0, 1}, {"lh_f32_conv_fast_128x128x32_p", 128, 128, 32, 0.82, 0.82, 12.0, 1},
+    {"lh_f32_conv_exact_64x128x32_p", 64, 128, 32, 0.74, 0.74, 8.0, 2},    {"lh_f32_conv_fast_64x128x32_p", 64, 128, 32, 0.74, 0.74, 8.0, 2}};
 // plain kernel -> its `_pre` variant (-1: none)
 int pre_variant(int k) {
   switch (k) {
@@ -444,7 +450,7 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
 
 // Fill the scheduler block for `plan` and launch.  The workspace is taken only by launches that cut tiles.
 hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernArgs &ka, int tiles_m, int tiles_n, int group_m, int64_t batch,
-                          size_t tile_bytes, hipStream_t s) {
+                          size_t tile_bytes, hipStream_t s, int64_t walk_G = 0) {
   Plan plan = plan_in;
   StreamWs w;
   {
@@ -468,13 +474,26 @@ hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernAr
     ka.sch.units_r = (uint32_t)T;
     ka.sch.flags_bits |= 4u;
   }
+  unsigned gx = (unsigned)plan.G, gy = (unsigned)batch;
+  if (walk_G > 0) {
+    // unit walkers (convolution, f32_kernel.py next_unit): units = images x tiles of one image, workgroup g runs g, g + walk_G, ...;
+    // +4 the tiles of an image, +8 their magic number (unit / tiles: exact while units * tiles < 2^32), +12 the stride, +16 the units
+    const int64_t units = T * batch;
+    if (plan.persistent || plan.P != 1 || walk_G > units || (double)units * (double)T >= 4.0e9) return hipErrorNotSupported;
+    ka.sch.P = (uint32_t)T;
+    ka.sch.mg_P = magic_u32((uint64_t)T);
+    ka.sch.units_q = (uint32_t)walk_G;
+    ka.sch.units_r = (uint32_t)units;
+    gx = (unsigned)walk_G;
+    gy = 1;
+  }
   size_t sz = sizeof(ka);
   void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  const hipError_t e = hipModuleLaunchKernel(m->fn[kern], (unsigned)plan.G, (unsigned)batch, 1, 256, 1, 1, 0, s, nullptr, extra);
+  const hipError_t e = hipModuleLaunchKernel(m->fn[kern], gx, gy, 1, 256, 1, 1, 0, s, nullptr, extra);
   // (the error word travels back behind the launch; whoever launches next on this stream looks at it -- no wait here)
   if (e == hipSuccess && cuts && w.host_err) (void)hipMemcpyAsync((void *)w.host_err, w.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) {
-    g_last_asm_wgs = (int)plan.G;
+    g_last_asm_wgs = walk_G > 0 ? (int)walk_G : (int)plan.G;
     g_last_asm_slices = (int)plan.P;
     g_last_asm_group_m = (int)ka.sch.group_m | (ka.sch.xcd_q ? 1 << 16 : 0);      // raster group height; bit 16: XCD-aware chunking of the ids
   }
@@ -1067,7 +1086,17 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hi
   ka.act = (uint32_t)a.act;
   Plan plain;
   plain.G = tiles;
-  e = launch_planned(m, pick, plain, ka, tiles_m, tiles_n, group_m, a.batch, 0, s);
+  // more units (images x tiles) than workgroup slots: the unit-walking form of the kernel -- every slot's workgroup goes through its
+  // share of the units with pipelined transitions (option conv_walk: 1 = where it applies, 0 = never, 2 = whenever there are two units)
+  const int64_t units = tiles * a.batch, slots = (int64_t)m->cus * ki.occ;
+  const bool can_walk = a.bias == nullptr && a.act == 0 && Kp % 32 == 0 && Kp >= 96 && (double)units * (double)tiles < 4.0e9;
+  int64_t walk_G = 0;
+  if (can_walk && ((g_conv_walk == 1 && units > slots) || (g_conv_walk >= 2 && units >= 2))) {
+    walk_G = std::min(slots, units);
+    if (g_conv_walk >= 3) walk_G = std::min<int64_t>(g_conv_walk, units - 1);       // (tests: a forced workgroup count)
+    pick = (pick == 10 || pick == 11 ? 66 + (pick - 10) : 68 + (pick - 21));
+  }
+  e = launch_planned(m, pick, plain, ka, tiles_m, tiles_n, group_m, a.batch, 0, s, walk_G);
   if (packed) {
     const hipError_t e2 = hipFreeAsync(packed, s);
     if (e == hipSuccess) e = e2;

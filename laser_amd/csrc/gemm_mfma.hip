@@ -178,6 +178,7 @@ static int gen_cfg(const GemmArgs<double> &, bool) { return 1; }
 std::atomic<int> g_conv_patch{1}; // implicit conv: B from an LDS input patch where it fits (0: always the per-element gather)
 std::atomic<int> g_conv_kslice{1}; // laser-order conv: tail launch as parallel kc slices + ordered combine (0: one workgroup per tail tile)
 std::atomic<int> g_last_conv_tail{0};   // diagnostics: how the last convolution's pixel tail ran (0 none, 1 direct kernel, 2 kc slices + combine, 3 one compiler-kernel launch)
+std::atomic<int> g_conv_walk{1};         // option "conv_walk": gemm_f32_asm.cpp launch_conv_f32_asm
 std::atomic<int> g_conv_cut_always{0};   // option "conv_cut_always" (tests, probes): cut a 3x3 convolution at its last whole 128-pixel tile whatever the model says
 std::atomic<int> g_conv_tail{1};   // option "conv_tail": the direct tail kernel behind the assembly main launch (conv_tail.hip); 0 = the round-3 forms
 std::atomic<int> g_last_f32_cfg{-1}; // last configuration launch_mfma<float> / the conv launcher ran (diagnostics, tests)

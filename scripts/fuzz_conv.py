@@ -14,7 +14,7 @@ fails = 0
 small = len(sys.argv) > 3 and sys.argv[3] == "small"
 direct = 0
 tailk = 0
-asmk = asm_want = 0
+asmk = asm_want = walked = 0
 isa = oracle.fused_isa(np.float32)
 for it in range(cases):
     kH, kW = int(rng.integers(1, 8)), int(rng.integers(1, 8))
@@ -38,7 +38,7 @@ for it in range(cases):
         H, W = int(rng.integers(12, 40)), int(rng.choice([12, 14, 16, 20, 22, 24, 26, 28, 30, 34, 36, 38]))
         n, C, Co = int(rng.integers(1, 6)), int(rng.choice([4, 8, 20, 32, 60, 64, 96, 100, 128, 160])), int(rng.integers(1, 200))
         cut_always = 1
-    asm_any = 0
+    asm_any, walk = 0, 1
     if not small and not cut_always and rng.random() < 0.3:
         # round 6: the assembly loader on ANY geometry (kernel of up to 49 taps, strides, odd widths, any C_in): forced onto the
         # hand-scheduled kernels whatever the tile count, enough output channels to stay out of the direct kernels' class
@@ -46,6 +46,10 @@ for it in range(cases):
         Co = int(rng.choice([33, 40, 64, 100, 128, 200, 256, 300]))
         C = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 23, 32, 40, 64]))
         if rng.random() < 0.3: H, W = int(rng.integers(max(kH, 30), 90)), int(rng.integers(max(kW, 30), 90))
+        if rng.random() < 0.5:
+            # the unit-walking form of the kernels (pipelined transitions need K a multiple of 32, three K-tiles or more, the plain
+            # epilogue): forced onto few workgroups, so that every one walks several units (2 = one per slot)
+            C = int(rng.choice([32, 64, 96])); n = int(rng.integers(2, 5)); walk = int(rng.choice([2, 3, 4, 5, 7]))
     if small:
         Co = int(rng.integers(1, 33))
         C = int(rng.integers(1, max(2, min(70, 256 // (kH * kW) + 1))))
@@ -66,6 +70,7 @@ for it in range(cases):
     dout = torch.full(oshape, float("nan"), device="cuda")
     laser_amd.set_conv_patch(bool(rng.random() < 0.8)); laser_amd.set_conv_kslice(bool(rng.random() < 0.8))
     laser_amd.set_option("conv_tail", int(rng.random() < 0.7))      # the direct pixel-tail kernel / the round-3 tail forms
+    laser_amd.set_option("conv_walk", walk)
     laser_amd.set_option("conv_cut_always", cut_always); laser_amd.set_f32_asm(2 if (cut_always or asm_any) else 1)
     laser_amd.conv2d_im2col(dout, oshape, torch.from_numpy(x).cuda(), ishape, torch.from_numpy(w).cuda(), kshape, pad, st, None,
                             bias=None if b is None else torch.from_numpy(b).cuda(), activation="relu" if use_epi else None)
@@ -73,6 +78,7 @@ for it in range(cases):
     tailk += laser_amd.get_option("last_conv_tail") == 1
     asmk += laser_amd.last_f32_asm() != 0
     asm_want += asm_any
+    walked += laser_amd.last_f32_asm() >= 67
     if asm_any and kH * kW <= 49 and laser_amd.last_f32_asm() == 0 and laser_amd.get_option("last_f32_config") != -3:
         fails += 1
         print("FAIL (not on the assembly loader)", dict(it=it, ishape=ishape, kshape=kshape, pad=pad, st=st), flush=True)
@@ -100,7 +106,7 @@ for it in range(cases):
             fails += 1
             print("FAIL im2col", dict(it=it, ishape=ishape, kshape=kshape, pad=pad, st=st, f64=f64, rc=rc), flush=True)
 laser_amd.set_conv_patch(True); laser_amd.set_conv_kslice(True); laser_amd.set_option("conv_tail", 1)
-laser_amd.set_option("conv_cut_always", 0); laser_amd.set_f32_asm(1)
+laser_amd.set_option("conv_cut_always", 0); laser_amd.set_option("conv_walk", 1); laser_amd.set_f32_asm(1)
 print(f"fuzz_conv: {cases} cases, {fails} failures, {direct} on the direct small-channel kernels, {tailk} with the direct pixel-tail kernel, "
-      f"{asmk} on the assembly implicit-GEMM loader ({asm_want} forced there with a random kernel / stride / width)")
+      f"{asmk} on the assembly implicit-GEMM loader ({asm_want} forced there with a random kernel / stride / width; {walked} as unit walkers with pipelined transitions)")
 sys.exit(1 if fails else 0)
