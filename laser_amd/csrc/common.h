@@ -177,6 +177,7 @@ hipError_t launch_gemm_f64(const GemmArgs<double> &args, bool laser_order, hipSt
 hipError_t launch_gemm_f32_asm(const GemmArgs<float> &args, bool laser_order, hipStream_t s);
 // implicit-GEMM convolution on the same framework (3x3 kernel, stride 1, padding 0 or 1): output pixels [0, args.N) of every image
 hipError_t launch_conv_f32_asm(const GemmArgs<float> &args, bool laser_order, hipStream_t s);
+int64_t conv_asm_plan_cut(const GemmArgs<float> &args, bool laser_order);   // pixel cut for an assembly main launch (-1: not its class, 0: none)
 int asm_plan_f32(int64_t M, int64_t N, int64_t K, int laser_order, int cus, int64_t out[8]);   // diagnostics: kernel + launch plan for a device of `cus` CUs (no device touched)
 const char *asm_error_detail();   // the assembly launcher's explanation of the error it just returned on this thread ("" = none)
 int64_t asm_fixup_timeouts();  // diagnostics: fix-ups of cut launches that gave up waiting (0 in a correct run; synchronises the device)

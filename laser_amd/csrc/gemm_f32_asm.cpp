@@ -979,16 +979,16 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &a_in, bool laser_order, h
   return e != hipSuccess ? e : e2;
 }
 
-// Implicit-GEMM convolution (conv2d_im2col.nim:102-166 minus the materialised im2col matrix): output pixels [0, a.N) of every
-// image, a.N a multiple of the 128-pixel tile or the whole image.  GemmArgs as launch_conv_implicit_f32 builds them (A = the
-// filter [M][K], B = the NCHW input, batch = images).  Round 6: any kernel of up to 49 taps (31 on the 256-row tile, whose LDS
-// holds the smaller tap table), any strides, any zero padding, any output width -- the reference's im2col is generic in all of
-// them (conv2d_im2col.nim:42-88) -- and any Cin: a filter matrix whose rows are not whole 16-byte pieces (K % 4 != 0, or a strided
-// view) is packed once into a zero-padded dense copy, which changes no bit (0 * 0 added to a chain).  hipErrorNotSupported: not
-// this kernel's class.
-hipError_t launch_conv_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hipStream_t s) {
+namespace {
+// what the assembly convolution launcher makes of a call: the kernel (kKernels index), the padded K, the geometry and the tile grid
+struct ConvClass {
+  int pick = -1, tiles_m = 0, tiles_n = 0;
+  int64_t kH = 0, kW = 0, sH = 0, sW = 0, taps = 0, oW = 0, oH = 0, npix = 0, Cin = 0, Kp = 0, tiles = 0;
+  bool exact = false;
+};
+// hipErrorNotSupported: not this launcher's class (launch_conv_f32_asm's comment); no device work
+hipError_t conv_asm_classify(const GemmArgs<float> &a, bool laser_order, ConvClass &cc) {
   if (!g_f32_asm) return hipErrorNotSupported;
-  GemmArgs<float> a = a_in;
   if (a.col0 != 0 || a.cs_imgs != 0) return hipErrorNotSupported;
   if (a.alpha != 1.0f || a.beta != 0.0f) return hipErrorNotSupported;
   // fused epilogue (laser_hip_conv2d_im2col_ex_f32: per-channel bias, relu) as in the GEMM kernels; tanh / sigmoid: the compiler kernels
@@ -1030,6 +1030,72 @@ hipError_t launch_conv_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hi
   // a 256-row tile that is mostly padding (few output channels) loses to the compiler-scheduled 128 / 64-row tiles
   if (g_f32_asm < 2 && (double)a.M * (double)a.N < 0.75 * (double)tiles * ki.bm * ki.bn) return hipErrorNotSupported;
   if ((double)npix * (double)oW >= 4.0e9) return hipErrorNotSupported;
+  // the 64-row tile (two workgroups per CU, each at half the CU's rate): a CU works through ceil(units / CUs) units' worth of time
+  // whatever the count; where that leaves a fifth of the chip idle the compiler-scheduled kernels' smaller tiles are ahead by 6 - 10 %
+  // (profiles/r06/conv_m64_ab_w.jsonl: 800 units = 3.125 per CU, 320 units = 1.25 per CU), elsewhere behind by 4 - 25 %
+  if (g_f32_asm < 2 && ki.bm == 64) {
+    const int64_t cus = current_cus(), units_ = tiles * a.batch, per_cu = (units_ + cus - 1) / cus;
+    if ((double)units_ < 0.8 * (double)(per_cu * cus)) return hipErrorNotSupported;
+  }
+  cc.pick = pick; cc.tiles_m = tiles_m; cc.tiles_n = tiles_n; cc.tiles = tiles;
+  cc.kH = kH; cc.kW = kW; cc.sH = sH; cc.sW = sW; cc.taps = taps; cc.oW = oW; cc.oH = oH; cc.npix = npix; cc.Cin = Cin; cc.Kp = Kp;
+  cc.exact = exact;
+  return hipSuccess;
+}
+}  // namespace
+
+// Where to cut the pixel axis of a convolution whose main part the assembly kernels would take (round 6: the launch plan of
+// gemm_mfma.hip plan_split is written for the compiler-scheduled configurations' tiles; in laser-order mode it cut 3136 pixels at
+// 2048 where the 128-pixel assembly tile wants 3072: 109 against 127 TFLOP/s on 5x5 64 -> 128 channels, conv_geometry_ab_w.jsonl).
+// Candidates: the whole image, or the first k whole 128-pixel tiles of every image with the rest as a tail launch.  A CU works
+// through ceil(units / CUs) units one after the other (two workgroups of the 64-row tile share a CU at half its rate each: the same
+// time); the tail is priced as a launch of its own at a fraction of the chip's rate (C4's 64-pixel tail: 14.4 us).
+// Returns -1: not the assembly launcher's class (the caller keeps its own plan), 0: one launch, > 0: the cut.
+int64_t conv_asm_plan_cut(const GemmArgs<float> &a_in, bool laser_order) {
+  GemmArgs<float> a = a_in;
+  const int cus = current_cus();
+  if (cus < 8) return -1;
+  const double cu_rate = 157.3e12 / 256.0;
+  const auto main_us = [&](const ConvClass &cc) {
+    const KernelInfo &ki = kKernels[cc.pick];
+    const int64_t units = cc.tiles * a.batch;
+    const double unit_us = 2.0 * ki.bm * ki.bn * (double)cc.Kp / (cu_rate * (ki.eff + 0.02)) * 1e6;
+    return 8.0 + (double)((units + cus - 1) / cus) * unit_us;
+  };
+  double best = 1e300;
+  int64_t best_cut = -1;
+  ConvClass cc;
+  if (conv_asm_classify(a, laser_order, cc) == hipSuccess) best = main_us(cc), best_cut = 0;
+  const int64_t npix = a.N, kfull = npix / 128;
+  for (int64_t k = kfull; k >= 1 && k >= kfull - 12; k--) {
+    if (k * 128 == npix) continue;
+    a.N = k * 128;
+    if (conv_asm_classify(a, laser_order, cc) != hipSuccess) continue;
+    // (the 64-row tile with a short reduction: a cut launch loses 5 - 10 % to one launch of the compiler-scheduled kernels, K = 288 / 864;
+    // from K = 1152 on it is 5 - 9 % ahead: profiles/r06/conv_m64_ab_x.jsonl)
+    if (kKernels[cc.pick].bm == 64 && cc.Kp < 1024) continue;
+    const double tail_flops = 2.0 * (double)a.M * (double)(npix - k * 128) * (double)a.K * (double)a.batch;
+    const double t = main_us(cc) + 12.0 + tail_flops / 50.0e6;       // (us: 12 + flops / 50 TFLOP/s)
+    if (t < 0.98 * best) best = t, best_cut = k * 128;
+  }
+  return best_cut;
+}
+
+// Implicit-GEMM convolution (conv2d_im2col.nim:102-166 minus the materialised im2col matrix): output pixels [0, a.N) of every
+// image, a.N a multiple of the 128-pixel tile or the whole image.  GemmArgs as launch_conv_implicit_f32 builds them (A = the
+// filter [M][K], B = the NCHW input, batch = images).  Round 6: any kernel of up to 49 taps (31 on the 256-row tile, whose LDS
+// holds the smaller tap table), any strides, any zero padding, any output width -- the reference's im2col is generic in all of
+// them (conv2d_im2col.nim:42-88) -- and any Cin: a filter matrix whose rows are not whole 16-byte pieces (K % 4 != 0, or a strided
+// view) is packed once into a zero-padded dense copy, which changes no bit (0 * 0 added to a chain).  hipErrorNotSupported: not
+// this kernel's class.
+hipError_t launch_conv_f32_asm(const GemmArgs<float> &a_in, bool laser_order, hipStream_t s) {
+  GemmArgs<float> a = a_in;
+  ConvClass cc;
+  if (const hipError_t ce = conv_asm_classify(a, laser_order, cc); ce != hipSuccess) return ce;
+  int pick = cc.pick;
+  const KernelInfo &ki = kKernels[pick];
+  const int tiles_m = cc.tiles_m, tiles_n = cc.tiles_n;
+  const int64_t kH = cc.kH, kW = cc.kW, sH = cc.sH, sW = cc.sW, taps = cc.taps, oW = cc.oW, npix = cc.npix, Cin = cc.Cin, Kp = cc.Kp, tiles = cc.tiles;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;

@@ -310,6 +310,17 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
     plan = plan_split(a, exact, false, true, false);
   else
     plan.cfg_main = cfg;
+  // the main part on the hand-scheduled kernels: the cut their 128-pixel tiles want (gemm_f32_asm.cpp conv_asm_plan_cut)
+  if (cfg < 0 && g_f32_asm && g_split_tail && a.bias == nullptr && a.act == 0) {
+    const int64_t cut = conv_asm_plan_cut(a, laser_order);
+    if (cut >= 0 && cut != plan.n_cut) {
+      plan.n_cut = cut;
+      if (cut > 0) {
+        if (plan.cfg_main < 0 || kCfgsF32[plan.cfg_main].bn > 128) plan.cfg_main = kCfgWide;
+        if (plan.cfg_tail < 0) plan.cfg_tail = kCfgSmall;
+      }
+    }
+  }
   if (g_conv_cut_always && cfg < 0 && plan.n_cut == 0 && a.N > 128 && a.N % 128 != 0 && a.ckH == 3 && a.ckW == 3) {
     plan.n_cut = a.N / 128 * 128;           // (the tail forms on shapes the model would leave in one launch)
     plan.cfg_main = kCfgWide;

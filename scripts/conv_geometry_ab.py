@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 6: the any-geometry assembly implicit-GEMM loader against the compiler-scheduled loaders of the same library, per shape and
 accumulation mode (f32_asm 1 vs 0; interleaved), same bits required in laser-order mode.  One JSON line per (shape, mode).
-usage: conv_geometry_ab.py [batch]"""
+usage: conv_geometry_ab.py [batch] [m64]"""
 import json
 import os
 import sys
@@ -34,6 +34,11 @@ SHAPES = [((3, 224, 224), (64, 3, 7, 7), (3, 3), (2, 2)), ((128, 56, 56), (256, 
           ((256, 28, 28), (512, 256, 1, 1), (0, 0), (1, 1)), ((64, 56, 56), (256, 64, 1, 1), (0, 0), (1, 1)), ((256, 56, 56), (64, 256, 1, 1), (0, 0), (1, 1)),
           ((256, 14, 14), (256, 256, 3, 3), (1, 1), (1, 1)), ((512, 7, 7), (512, 512, 3, 3), (1, 1), (1, 1)), ((128, 28, 28), (128, 128, 3, 3), (1, 1), (1, 1)),
           ((64, 57, 57), (128, 64, 3, 3), (1, 1), (1, 1)), ((32, 112, 112), (64, 32, 3, 3), (1, 1), (2, 2)), ((16, 64, 64), (96, 16, 7, 7), (3, 3), (1, 1))]
+if len(sys.argv) > 2 and sys.argv[2] == "m64":      # few output channels: the 64-row assembly tile against the compiler-scheduled kernels
+    SHAPES = [((64, 56, 56), (64, 64, 3, 3), (1, 1), (1, 1)), ((128, 56, 56), (64, 128, 3, 3), (1, 1), (1, 1)), ((32, 56, 56), (64, 32, 3, 3), (1, 1), (1, 1)),
+              ((64, 28, 28), (64, 64, 3, 3), (1, 1), (1, 1)), ((256, 28, 28), (64, 256, 3, 3), (1, 1), (1, 1)), ((64, 56, 56), (48, 64, 3, 3), (1, 1), (1, 1)),
+              ((64, 56, 56), (33, 64, 3, 3), (1, 1), (1, 1)), ((64, 112, 112), (64, 64, 3, 3), (1, 1), (1, 1)), ((128, 56, 56), (64, 128, 1, 1), (0, 0), (1, 1)),
+              ((64, 56, 56), (64, 64, 5, 5), (2, 2), (1, 1)), ((96, 35, 35), (64, 96, 3, 3), (1, 1), (1, 1)), ((64, 56, 56), (96, 64, 3, 3), (1, 1), (1, 1))]
 for (chw, kshape, pad, st) in SHAPES:
     ishape = (batch,) + chw
     x = torch.rand(ishape, generator=g, device="cuda")
@@ -53,7 +58,7 @@ for (chw, kshape, pad, st) in SHAPES:
                 rec[key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / 157.3, 3), "kernel": laser_amd.last_f32_asm(),
                             "cut": laser_amd.last_split(), "tail": laser_amd.get_option("last_conv_tail"), "cfg": laser_amd.get_option("last_f32_config")}
             outs[asm] = o.clone()
-        rec["bit_identical"] = bool(torch.equal(outs[0], outs[1]))
+        rec["bit_identical"] = bool(torch.equal(outs[0], outs[1]))       # (required in laser-order mode; one-chain mode has no order to keep: a different cut's tail may sum its kc slices separately)
         rec["asm_gain_pct"] = round(100.0 * (rec["compiler"]["ms"] / rec["asm"]["ms"] - 1.0), 1)
         print(json.dumps(rec), flush=True)
 laser_amd.set_float_mode(0)

@@ -272,6 +272,37 @@ def test_conv_kernels_any_geometry_in_the_interpreter(name, images, Cin, H, W, M
     assert C.run_conv_case(name, images, Cin, H, W, M, pad, n_cut=n_cut, kernel=kernel, stride=stride, verbose=False)
 
 
+# Round 6: the convolution kernels as unit walkers (Cfg.cpers; `_p` kernels): G workgroups over images x tiles units, the transition
+# from one unit to the next inside the K loop when K is a multiple of 32 with three K-tiles or more and the epilogue is the plain store
+# (the next unit's tap table, gathers and filter pieces requested before the old tile's last two K-tiles are multiplied; its C stores from
+# the gaps of the new tile's first K-tile body), through the ordinary epilogue otherwise.
+CONV_WALK_CASES = [
+    # (name, images, Cin, H, W, M, pad, kernel, stride, G, bias)
+    ("conv_fast_64x128x32_p", 2, 32, 17, 18, 40, 1, 3, 1, 2, False),              # 6 units (ragged last tile of each image) on 2 workgroups
+    ("conv_exact_64x128x32_p", 2, 64, 17, 18, 70, 1, 3, 1, 3, False),             # K = 576: a fold inside every tile + transitions, two row tiles
+    ("conv_exact_256x128x32_p", 2, 32, 12, 12, 260, 1, 3, 1, 3, False),           # 8 units on 3 workgroups (3 + 3 + 2)
+    ("conv_fast_256x128x32_p", 3, 32, 12, 12, 260, 0, (1, 3), (2, 1), 2, False),
+    ("conv_exact_128x128x32_p", 2, 96, 20, 13, 130, 0, 1, 1, 3, False),           # 1x1: K = 96, exactly the three K-tiles the switch needs
+    ("conv_fast_128x128x32_p", 3, 12, 17, 18, 40, 1, 3, 1, 4, False),             # K = 108: not a multiple of 32 -> every unit through the epilogue
+    ("conv_exact_64x128x32_p", 2, 32, 17, 18, 40, 1, 3, 1, 2, True),              # bias + relu: not pipelined either
+    ("conv_exact_128x128x32_p", 1, 64, 9, 9, 130, 1, 3, 1, 1, False),             # one workgroup, both units of the image
+]
+
+
+@pytest.mark.parametrize("name,images,Cin,H,W,M,pad,kernel,stride,G,bias", CONV_WALK_CASES)
+def test_conv_unit_walkers_bit_exact_in_the_interpreter(name, images, Cin, H, W, M, pad, kernel, stride, G, bias):
+    assert C.run_conv_case(name, images, Cin, H, W, M, pad, kernel=kernel, stride=stride, G=G, bias=bias, act=1 if bias else 0, verbose=False)
+
+
+def test_conv_unit_walkers_take_the_pipelined_transition(monkeypatch):
+    """the transition body is really what stores a walked tile: without its stores the result is wrong (and with K not a multiple
+    of the K-tile the same kernel never gets there)"""
+    from laser_amd.asmgen import f32_kernel as K
+    monkeypatch.setattr(K.Gen, "trans_after", lambda self, b: None)
+    assert not C.run_conv_case("conv_fast_64x128x32_p", 2, 32, 17, 18, 40, 1, G=2, verbose=False)
+    assert C.run_conv_case("conv_fast_64x128x32_p", 2, 12, 17, 18, 40, 1, G=2, verbose=False)
+
+
 def test_conv_kernels_fused_bias_relu_in_the_interpreter():
     assert C.run_conv_case("conv_exact_256x128x32", 2, 8, 12, 16, 40, 1, bias=True, act=1, verbose=False)
     assert C.run_conv_case("conv_fast_64x128x32", 1, 64, 6, 8, 70, (0, 1), bias=True, act=0, verbose=False)

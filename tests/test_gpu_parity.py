@@ -1924,6 +1924,61 @@ def test_fused_conv_epilogue_on_the_assembly_kernels(la, oracle):
             assert np.array_equal(outs[2].cpu().numpy(), want), (ishape, kshape, act)
 
 
+def test_conv_unit_walkers_bit_exact(la, oracle):
+    """Round 6: the convolution kernels as unit walkers -- a workgroup runs units (image, tile) g, g + G, ... and
+    goes from one to the next inside its K loop (f32_kernel.py Cfg.cpers, option conv_walk).  Against oracle.conv2d_im2col bit for bit
+    in laser-order mode, whatever the number of workgroups (every one a different split of the units, down to two workgroups walking
+    them all), and the same bits as the one-tile-per-workgroup launch in both modes."""
+    import torch
+    rng = np.random.default_rng(616)
+    isa = oracle.fused_isa(np.float32)
+    la.set_f32_asm(2)
+    cases = [
+        # (ishape, kshape, pad, stride, walker kernel ids (laser-order, one chain))
+        ((5, 64, 30, 30), (256, 64, 3, 3), (1, 1), (1, 1), (67, 68)),        # K = 576: 8 tiles an image (ragged), 256-row tile
+        ((6, 32, 27, 29), (130, 32, 3, 3), (1, 1), (1, 1), (69, 70)),        # two row tiles of the 128-row kernel (the second ragged), K = 288
+        ((7, 48, 20, 24), (50, 48, 1, 2), (0, 0), (1, 1), (71, 72)),         # 1x2 kernel, K = 96: exactly the three K-tiles the switch needs; 64-row tile
+        ((4, 64, 40, 37), (200, 64, 5, 3), (2, 1), (2, 1), (67, 68)),        # 15 taps, strides, K = 960
+    ]
+    try:
+        for ishape, kshape, pad, st, kern in cases:
+            x = rng.uniform(-1, 1, ishape).astype(np.float32)
+            w = rng.uniform(-1, 1, kshape).astype(np.float32)
+            oshape = la.conv2d_out_shape(ishape, kshape, pad, st)
+            want = oracle.conv2d_im2col(x, w, pad, st, isa=isa)
+            dx, dw = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+            for mode in (0, 1):
+                la.set_float_mode(mode)
+                la.set_option("conv_walk", 0)
+                o = torch.full(oshape, float("nan"), device="cuda")
+                la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, pad, st, None)
+                assert 0 < la.last_f32_asm() < 67
+                plain = o.cpu().numpy()
+                if mode == 0:
+                    assert np.array_equal(plain, want), (ishape, kshape)
+                for walk in (2, 3, 5, 11, 64):
+                    la.set_option("conv_walk", walk)
+                    o = torch.full(oshape, float("nan"), device="cuda")
+                    la.conv2d_im2col(o, oshape, dx, ishape, dw, kshape, pad, st, None)
+                    assert la.last_f32_asm() >= 67, (ishape, kshape, walk, la.last_f32_asm())     # (one of the six walker kernels)
+                    assert np.array_equal(o.cpu().numpy(), plain), (ishape, kshape, mode, walk)
+        # a K that is not whole K-tiles stays on the one-tile-per-workgroup kernels
+        la.set_float_mode(0)
+        la.set_option("conv_walk", 2)
+        ishape, kshape = (3, 12, 30, 30), (64, 12, 3, 3)
+        x = rng.uniform(-1, 1, ishape).astype(np.float32)
+        w = rng.uniform(-1, 1, kshape).astype(np.float32)
+        oshape = la.conv2d_out_shape(ishape, kshape, (1, 1), (1, 1))
+        o = torch.full(oshape, float("nan"), device="cuda")
+        la.conv2d_im2col(o, oshape, torch.from_numpy(x).cuda(), ishape, torch.from_numpy(w).cuda(), kshape, (1, 1), (1, 1), None)
+        assert 0 < la.last_f32_asm() < 67
+        assert np.array_equal(o.cpu().numpy(), oracle.conv2d_im2col(x, w, (1, 1), (1, 1), isa=isa))
+    finally:
+        la.set_option("conv_walk", 1)
+        la.set_float_mode(0)
+        la.set_f32_asm(1)
+
+
 def test_assembly_conv_loader_any_kernel_stride_width(la, oracle, kats):
     """Round 6 (VERDICT r5 missing #2): the hand-scheduled implicit-GEMM loader took 3x3 / stride 1 / even output widths / C_in % 4 == 0
     only; the reference's im2col is generic in kH, kW, stride and padding (conv2d_im2col.nim:42-88).  Kernel size, strides and padding
