@@ -22,6 +22,7 @@ SHAPES = {
     "head": [(8192,) * 3],
     "shortk": [(8192, 3072, 1152), (8192, 3072, 576), (8192, 3072, 2304), (4096, 6144, 1152)],
     "mid": [(2560,) * 3, (3072,) * 3, (4096,) * 3, (4100, 4100, 4096), (5120,) * 3],
+    "frac": [(6912,) * 3, (6656,) * 3, (5888,) * 3, (2816,) * 3, (4608,) * 3, (7424,) * 3],      # tile counts a fraction of a round above whole rounds
     "x16": [(3072,) * 3, (4608,) * 3, (5120,) * 3, (7680,) * 3, (8192, 3072, 1152)],
 }[which]
 CANDS = {0: {0: "256x128", 30: "128x128x32", 2: "128x128", 12: "64x64"}, 1: {1: "256x256", 8: "256x128", 31: "128x128x32", 3: "128x128"}}
@@ -71,9 +72,10 @@ for (M, N, K) in SHAPES:
         for kern, kname in CANDS[mode].items():
             laser_amd.set_option("asm_kernel", kern)
             rec = {"M": M, "N": N, "K": K, "mode": "laser_order" if mode == 0 else "fast", "kernel": kname}
-            outs, times, meta = {}, {1: [], 3: []}, {}
+            PLANS = (1, 3, 2) if "cut" in sys.argv[4:] else (1, 3)      # 2 = the persistent plan with K-slice cuts and hand-overs
+            outs, times, meta = {}, {p_: [] for p_ in PLANS}, {}
             ok = True
-            for plan in (1, 3):
+            for plan in PLANS:
                 laser_amd.set_option("asm_plan", plan)
                 C.fill_(float("nan"))
                 rc = call()
@@ -87,16 +89,16 @@ for (M, N, K) in SHAPES:
                 rec["skipped"] = "kernel not eligible"
                 print(json.dumps(rec), flush=True)
                 continue
-            rec["bit_identical"] = bool(torch.equal(outs[1], outs[3]))
+            rec["bit_identical"] = bool(torch.equal(outs[1], outs[3])) and (2 not in outs or mode == 1 or bool(torch.equal(outs[1], outs[2])))
             rec["finite"] = bool(torch.isfinite(outs[3]).all())
             laser_amd.set_option("asm_plan", 1)
             warm(call)
             for _ in range(reps):
-                for plan in (1, 3):
+                for plan in PLANS:
                     laser_amd.set_option("asm_plan", plan)
                     call()
                     times[plan].append(timed(call, fl))
-            for plan, nm in ((1, "plain"), (3, "pipe")):
+            for plan, nm in ((1, "plain"), (3, "pipe"), (2, "cut"))[:len(PLANS)]:
                 ts = sorted(times[plan])
                 ms = ts[len(ts) // 2]
                 rec[nm] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / 157.3, 4), "min_ms": round(ts[0], 4), **meta[plan]}

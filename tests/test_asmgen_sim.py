@@ -279,8 +279,8 @@ def test_conv_kernels_any_geometry_in_the_interpreter(name, images, Cin, H, W, M
 CONV_WALK_CASES = [
     # (name, images, Cin, H, W, M, pad, kernel, stride, G, bias)
     ("conv_fast_64x128x32_p", 2, 32, 17, 18, 40, 1, 3, 1, 2, False),              # 6 units (ragged last tile of each image) on 2 workgroups
-    ("conv_exact_64x128x32_p", 2, 64, 17, 18, 70, 1, 3, 1, 3, False),             # K = 576: a fold inside every tile + transitions, two row tiles
-    ("conv_exact_256x128x32_p", 2, 32, 12, 12, 260, 1, 3, 1, 3, False),           # 8 units on 3 workgroups (3 + 3 + 2)
+    ("conv_exact_64x128x32_p", 1, 64, 17, 18, 70, 1, 3, 1, 2, False),             # K = 576: a fold inside every tile + transitions, two row tiles
+    ("conv_exact_256x128x32_p", 3, 32, 12, 12, 200, 1, 3, 1, 4, False),           # 6 units on 4 workgroups (2 + 2 + 1 + 1)
     ("conv_fast_256x128x32_p", 3, 32, 12, 12, 260, 0, (1, 3), (2, 1), 2, False),
     ("conv_exact_128x128x32_p", 2, 96, 20, 13, 130, 0, 1, 1, 3, False),           # 1x1: K = 96, exactly the three K-tiles the switch needs
     ("conv_fast_128x128x32_p", 3, 12, 17, 18, 40, 1, 3, 1, 4, False),             # K = 108: not a multiple of 32 -> every unit through the epilogue
