@@ -311,7 +311,7 @@ hipError_t launch_conv_implicit_f32(const GemmArgs<float> &args, int cfg, bool l
   else
     plan.cfg_main = cfg;
   // the main part on the hand-scheduled kernels: the cut their 128-pixel tiles want (gemm_f32_asm.cpp conv_asm_plan_cut)
-  if (cfg < 0 && g_f32_asm && g_split_tail && a.bias == nullptr && a.act == 0) {
+  if (cfg < 0 && g_f32_asm && g_split_tail) {
     const int64_t cut = conv_asm_plan_cut(a, laser_order);
     if (cut >= 0 && cut != plan.n_cut) {
       plan.n_cut = cut;
