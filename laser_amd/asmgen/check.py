@@ -281,7 +281,7 @@ def run_conv_case(name, images, Cin, H, W, M, pad, n_cut=None, seed=0, order=Non
 
 
 def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None, over=None, verbose=True, alpha=1.0, beta=0.0, batch=1,
-               G=None, split=False, group_m=None, xcd=False, noseed=0, two_level=False):
+               G=None, split=False, group_m=None, xcd=False, noseed=0, two_level=False, strided=False):
     """float64 kernels (f64_kernel.py) through the interpreter.  Operands are small integers (alpha, beta dyadic), for which every
     product and partial sum is exact in float64 (the interpreter's f64 MFMA is mul + add, not an exact fma): this checks every
     address, layout, wait and hazard of the program; the accumulation ORDER with rounding is checked on hardware against the
@@ -319,6 +319,8 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
         Call[b * LC:b * LC + LC - 5] = full0.reshape(-1)[:(M - 1) * ldc + N]
     tm, tn = (M + c.BM - 1) // c.BM, (N + c.BN - 1) // c.BN
     G = G or tm * tn
+    if strided:
+        G = min(G, tm * tn)         # workgroup v walks the whole tiles v, v + G, ... (pipelined transitions: f32_kernel.py Cfg.pipe)
     P, slen, uq, ur = plan_units(tm * tn, Kd, G, c.exact, 256, c.BK, split)
     mem = Memory()
     a_, b_, c_ = mem.alloc(Aall), mem.alloc(Ball), mem.alloc(Call)
@@ -328,7 +330,7 @@ def run_case64(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, order=None,
     bs = (LA * 8, LB * 8, LC * 8) if batch > 1 else (0, 0, 0)
     ka = (struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, 1.0, 0.0, 0) + struct.pack("<dd", alpha, beta)
           + struct.pack("<Q", bs[0]) + b"\0" * 16 + struct.pack("<QQ", bs[1], bs[2]) + b"\0" * 24)
-    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level)
+    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level, strided)
     assert len(ka) == K.KERNARG_SIZE
     ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()

@@ -46,6 +46,8 @@ CONFIGS = {
 
 
 class Gen16(Gen64):
+    ab_descriptors = Gen.ab_descriptors      # 4-byte elements: the f32 kernels' descriptors (run_setup and the pipelined switch)
+
     # ------------------------------------------------------------------ registers
     def alloc(self):
         c, p = self.c, self.p

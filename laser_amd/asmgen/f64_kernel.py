@@ -19,16 +19,16 @@ from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_CONV1  #
 
 CONFIGS = {
     # one wave per SIMD: 2 x 2 waves of 64x64 = 16 blocks = 128 accumulator registers (+ 128 for the running sum)
-    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True, runv=True, dataa=True),
-    "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False),
+    "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True, runv=True, dataa=True, pipe=True),
+    "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False, pipe=True),
     # problems of few tiles (the reference's f64 bench shape, 960^3 = 225 tiles): 2 x 2 waves of 32x32, several workgroups per CU
-    "exact_64x64x16": dict(BM=64, BN=64, BK=16, exact=True, runv=True),
-    "fast_64x64x16": dict(BM=64, BN=64, BK=16, exact=False),
+    "exact_64x64x16": dict(BM=64, BN=64, BK=16, exact=True, runv=True, pipe=True),
+    "fast_64x64x16": dict(BM=64, BN=64, BK=16, exact=False, pipe=True),
     # B passed transposed (rowStrideB == 1: k-contiguous like A)
-    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True, runv=True, dataa=True),
-    "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),
-    "exact_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=True, b_kcontig=True, runv=True),
-    "fast_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=False, b_kcontig=True),
+    "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True, runv=True, dataa=True, pipe=True),
+    "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True, pipe=True),
+    "exact_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=True, b_kcontig=True, runv=True, pipe=True),
+    "fast_64x64x16_nt": dict(BM=64, BN=64, BK=16, exact=False, b_kcontig=True, pipe=True),
 }
 KA_ALPHA64 = 72      # alpha, beta as float64 (the f32 kernels' float fields at 56 / 60 are unused here)
 KA_BSA64 = 88        # batch stride of A in bytes (u64); B's and C's at 112 / 120 as in the f32 kernels
@@ -53,6 +53,11 @@ class Gen64(Gen):
         self.s_a1, self.s_b0 = S(), S()           # 0 when alpha == 1.0 / when beta == +-0.0
         self.s_bsA, self.s_bsBC = S(2, align=2), S(4, align=4)   # batch strides in bytes (grid y = batch index)
         self.s_ldc4, self.s_ldc20 = S(), S()      # here: ldc * 8 bytes, 4 * ldc * 8 (the next accumulator row of a lane)
+        self.s_csC4 = None
+        if c.pipe:
+            # pipelined tile transitions (f32_kernel.py Cfg.pipe): bit 0 = this launch may pipeline, bit 1 = armed
+            self.s_pipe = S()
+            self.srdCd = S(4)        # C from this wave's first row of the tile being finished (rows through the stores' scalar offset)
         self.alloc_sched()
         self.acc = [p.aalloc(8) for _ in range(c.NB)]
         # runv / dataa (f32_kernel.py Cfg, round 6): the running sum in arch VGPRs (the slice fold of a block is 8 v_accvgpr_read + 4
@@ -112,6 +117,15 @@ class Gen64(Gen):
         e("s_or_b32", self.s_a1, st[2], self.s_al[0])
         e("s_and_b32", st[2], self.s_be[1], 0x7fffffff)
         e("s_or_b32", self.s_b0, st[2], self.s_be[0])
+        if c.pipe:
+            # tile transitions of this launch may be pipelined: beta == 0 (the next tile's running sum starts at 0), K a multiple of BK
+            # (no K-tail masks to undo between tiles), at least three K-tiles (the switch happens two tile bodies before a tile ends)
+            e("s_and_b32", st[2], self.s_K, c.BK - 1)
+            e("s_or_b32", st[2], st[2], self.s_b0)
+            e("s_cmp_eq_u32", st[2], 0)
+            e("s_cselect_b32", self.s_pipe, 1, 0)
+            e("s_cmp_lt_u32", self.s_K, 3 * c.BK)
+            e("s_cselect_b32", self.s_pipe, 0, self.s_pipe)
         if c.debug:
             e("s_load_dwordx2", self.srdD.sub(0, 2), s(0, 2), KA_DBG)
             e("s_waitcnt", lgkmcnt=0)
@@ -213,24 +227,14 @@ class Gen64(Gen):
         for i in range(1, NP):
             e("v_add_u32", Voff[i], st[4], Voff[i - 1])
 
-    def run_setup(self):
-        """one run = k in [kb, kb + Keff) of tile (m0, n0)"""
+    def ab_descriptors(self, again=False):
+        """srdA / srdB of the run k in [kb, kb + Keff) of tile (m0, n0).  Clobbers s_t[0], [2], [3], [5]."""
         c, p = self.c, self.p
         e = p.emit
-        t, st = self.vt, self.s_t
-        RS = c.RS
+        st = self.s_t
         Keff = self.s_Keff
-        # K tail (Keff a multiple of 2): A pieces of the last K-tile beyond K read as 0
-        e("s_and_b32", self.s_ktail, Keff, c.BK - 1)
-        e("v_and_b32", t[5], 7, v(0))
-        e("v_lshlrev_b32", t[5], 1, t[5])
-        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
         e("s_lshl_b32", st[3], self.s_lda, 3, comment="lda * 8 bytes")
-        self.kcontig_goff64(self.vVA, c.NPA, st[3])
         e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
-        if c.b_kcontig:
-            self.kcontig_goff64(self.vVB, c.NPB, st[5])
-        e("s_nop", 4)
         A_, B_ = self.ka0.sub(0, 2), self.ka0.sub(2, 2)
         # A panel: base = A + m0 * lda * 8 + kb * 8; bytes = (min(M - m0, BM) - 1) * lda * 8 + Keff * 8
         e("s_mul_hi_u32", st[2], self.s_m0, st[3])
@@ -283,6 +287,26 @@ class Gen64(Gen):
             e("s_lshl_b32", st[2], st[2], 3)
             e("s_add_u32", self.srdB[2], st[0], st[2])
         e("s_mov_b32", self.srdB[3], 0x00020000)
+
+    def run_setup(self):
+        """one run = k in [kb, kb + Keff) of tile (m0, n0)"""
+        c, p = self.c, self.p
+        e = p.emit
+        t, st = self.vt, self.s_t
+        RS = c.RS
+        Keff = self.s_Keff
+        # K tail (Keff a multiple of 2): A pieces of the last K-tile beyond K read as 0
+        e("s_and_b32", self.s_ktail, Keff, c.BK - 1)
+        e("v_and_b32", t[5], 7, v(0))
+        e("v_lshlrev_b32", t[5], 1, t[5])
+        e("v_cmp_gt_u32", self.s_tm, self.s_ktail, t[5])
+        e("s_lshl_b32", st[3], self.s_lda, 3, comment="lda * 8 bytes")
+        self.kcontig_goff64(self.vVA, c.NPA, st[3])
+        e("s_lshl_b32", st[5], self.s_ldb, 3, comment="ldb * 8 bytes")
+        if c.b_kcontig:
+            self.kcontig_goff64(self.vVB, c.NPB, st[5])
+        e("s_nop", 4)
+        self.ab_descriptors()
         self.c_descriptor()
         e("s_add_u32", self.s_rem, Keff, c.BK - 1)
         e("s_lshr_b32", self.s_rem, self.s_rem, (c.BK).bit_length() - 1)
@@ -497,6 +521,65 @@ class Gen64(Gen):
             e("v_add_f64", tt, tt, T.sub(2 * d, 2))
             e("v_accvgpr_write_b32", self.acc[b][2 * d], tt[0])
             e("v_accvgpr_write_b32", self.acc[b][2 * d + 1], tt[1])
+
+    # ------------------------------------------------------------------ pipelined tile transitions (f32_kernel.py Cfg.pipe)
+    def trans_after(self, b):
+        """transition body, block b = (i, n): vT[0..7] hold the slice sum (4 doubles: rows q + 4 d of the block) of the tile being
+        FINISHED, the MFMA in front of this gap has restarted the chain for the new tile: C = run + alpha * slice (one chain: alpha *
+        sum) leaves for memory from here, the running sum is zeroed for the new tile (beta == 0 in pipelined launches).  Rows (+ 4 d,
+        + 16 i) through the stores' scalar offset from srdCd = this wave's first row of the old tile."""
+        c, p, e, T, st = self.c, self.p, self.p.emit, self.vT[0], self.s_t
+        i, n = b // c.TN, b % c.TN
+        assert c.runv or not c.exact
+        lmul, lback = p.label("tmul"), p.label("tback")
+        e("s_cmp_lg_u32", self.s_a1, 0)
+        e("s_cbranch_scc1", lmul)
+        p.place(lback)
+        self.outlined.append((lmul, [("v_mul_f64", T.sub(2 * d, 2), self.s_al, T.sub(2 * d, 2)) for d in range(4)], lback))
+        soff = st[0]
+        for d in range(4):
+            if c.exact:
+                tt = T.sub(8 + 2 * (d % 2), 2)
+                e("v_add_f64", tt, self.run[b].sub(2 * d, 2), T.sub(2 * d, 2))
+                e("v_mov_b64", self.run[b].sub(2 * d, 2), 0)
+            else:
+                tt = T.sub(2 * d, 2)
+            if 16 * i + 4 * d:
+                e("s_mul_i32", soff, self.s_ldc4, 16 * i + 4 * d)
+            else:
+                e("s_mov_b32", soff, 0)
+            e("buffer_store_dwordx2", tt, self.vC[n], self.srdCd, soff, offen=True)
+            self.vm_issue(("S", b, d))
+
+    def pipe_c_addr(self):
+        """(vC, srdCd) for the deferred stores of the tile (m0, n0): srdCd starts at this wave's first row, vC[n] = the lane's offset
+        from there (q rows down, block column n; out of bounds beyond N)"""
+        c, e, t, st = self.c, self.p.emit, self.vt, self.s_t
+        lane, r16, q = t[0], t[1], t[2]
+        e("v_and_b32", lane, 63, v(0))
+        e("v_and_b32", r16, 15, lane)
+        e("v_lshrrev_b32", q, 4, lane)
+        e("s_add_u32", st[0], self.s_m0, self.s_wm0)
+        e("s_mul_hi_u32", st[2], st[0], self.s_ldc4)
+        e("s_mul_i32", st[3], st[0], self.s_ldc4)
+        e("s_add_u32", self.srdCd[0], self.srdC[0], st[3])
+        e("s_addc_u32", self.srdCd[1], self.srdC[1], st[2])
+        e("s_and_b32", self.srdCd[1], self.srdCd[1], 0xffff)
+        e("s_mov_b32", self.srdCd[3], 0x00020000)
+        e("s_sub_u32", self.srdCd[2], self.srdC[2], st[3])              # what is left of C from there (0: the wave's rows lie beyond M)
+        e("s_cselect_b32", self.srdCd[2], 0, self.srdCd[2])
+        e("s_cmp_lg_u32", st[2], 0)
+        e("s_cselect_b32", self.srdCd[2], 0, self.srdCd[2])
+        e("v_mul_lo_u32", t[3], q, self.s_ldc4)
+        e("s_add_u32", st[1], self.s_n0, self.s_wn0)
+        e("v_add_u32", t[4], st[1], r16)
+        e("v_lshl_add_u32", t[3], t[4], 3, t[3])
+        for n in range(c.TN):
+            e("v_add_u32", t[5], 16 * n, t[4])
+            e("v_cmp_gt_u32", VCC, self.s_N, t[5])
+            e("v_add_u32", t[6], 128 * n, t[3])
+            e("v_mov_b32", t[7], 0x80000000)
+            e("v_cndmask_b32", self.vC[n], t[7], t[6], VCC)
 
     # ------------------------------------------------------------------ epilogue
     def c_addr_setup(self):

@@ -138,6 +138,7 @@ double pipe_gain_us(int k) {
   if (k == 0 || k == 4 || k == 8 || k == 9) return 2.5;       // 256x128x32 (laser-order / one chain, B plain / transposed): one workgroup per CU
   if (k >= 30 && k <= 33) return 1.0;                         // 128x128x32 (one workgroup per CU): +0.3 ... +3 %, a tile the model rarely picks
   if (k >= 46 && k <= 65) return 1.5;                         // the 16x16-block tiles (one workgroup per CU; f32x16_kernel.py trans_after)
+  if (k == 16 || k == 17 || k == 25 || k == 26) return 3.0;   // float64 128x128x16 (one workgroup per CU; f64_kernel.py trans_after)
   // 256x256x16: -1.8 ... +1.1 % (sixteen blocks' stores in the first sixteen gaps of a 16-deep body): left alone.  Two or three
   // workgroups per CU (128x128x16, 64x64) cover each other's transitions already, and a static share of the tiles quantises in
   // workgroup slots where the plain launch quantises in CUs: -0.3 ... -14 %
@@ -907,7 +908,9 @@ hipError_t launch_gemm_f64_asm_core(const GemmArgs<double> &a, bool laser_order,
     const int64_t tm = (a.M + ki_.bm - 1) / ki_.bm, tn = (a.N + ki_.bn - 1) / ki_.bn, t = tm * tn;   // (batches are grid y)
     if ((double)t * 8.0 * (double)tn >= 4.0e9) continue;
     if (g_f64_asm < 2 && t * a.batch < (k == tiny ? 3 : 5) * (int64_t)cus / 8) continue;
-    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 256, cu_flops_per_us, exact || !laser_order, -1.0, cus);
+    // (pipelined tile transitions, round 6: beta == 0, whole K-tiles, three or more of them -- f64_kernel.py once())
+    const bool may_pipe = a.beta == 0.0 && a.K % ki_.bk == 0 && a.K >= 3 * ki_.bk && a.batch == 1;
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 256, cu_flops_per_us, exact || !laser_order, may_pipe ? pipe_gain_us(k) : -1.0, cus);
     if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;
   }
   if (pick < 0) return hipErrorNotSupported;

@@ -324,6 +324,32 @@ def test_f64_kernels_exact_in_the_interpreter(name, M, N, Kd, kw):
     assert C.run_case64(name, M, N, Kd, verbose=False, **kw)
 
 
+# Round 6: pipelined tile transitions in the float64 kernels (f64_kernel.py trans_after / pipe_c_addr; the strided plan): workgroup v
+# walks the whole tiles v, v + G, ...; K a multiple of 16 with three K-tiles or more and beta == 0 go from tile to tile inside the K
+# loop, anything else through the ordinary epilogue of the same kernel
+F64_PIPE_CASES = [
+    ("fast_64x64x16", 130, 130, 64, dict(G=3)),
+    ("exact_64x64x16", 130, 130, 288, dict(G=3)),                       # a kc fold inside every tile + transitions
+    ("exact_64x64x16_nt", 130, 130, 288, dict(G=5, xcd=True)),
+    ("exact_128x128x16", 260, 130, 272, dict(G=1)),                     # one workgroup walks all three tiles (the last one ragged)
+    ("fast_128x128x16_nt", 140, 390, 48, dict(G=2)),                    # exactly three K-tiles
+    ("exact_64x64x16", 130, 130, 290, dict(G=3)),                       # K not a multiple of 16: not pipelined
+    ("exact_64x64x16", 130, 130, 288, dict(G=3, alpha=0.5)),
+    ("exact_64x64x16", 130, 130, 288, dict(G=3, beta=2.0)),             # beta != 0: not pipelined
+]
+
+
+@pytest.mark.parametrize("name,M,N,Kd,kw", F64_PIPE_CASES, ids=[f"f64-pipe-{c[0]}-{c[1]}x{c[2]}x{c[3]}-{i}" for i, c in enumerate(F64_PIPE_CASES)])
+def test_f64_pipelined_tile_transitions_in_the_interpreter(name, M, N, Kd, kw):
+    assert C.run_case64(name, M, N, Kd, verbose=False, strided=True, **kw)
+
+
+def test_f64_pipelined_transitions_are_really_taken(monkeypatch):
+    from laser_amd.asmgen import f64_kernel as K64
+    monkeypatch.setattr(K64.Gen64, "trans_after", lambda self, b: None)
+    assert not C.run_case64("fast_64x64x16", 130, 130, 64, G=3, strided=True, verbose=False)
+
+
 def test_f64_configs_generate():
     from laser_amd.asmgen import f64_kernel as K64
     for name in K64.CONFIGS:

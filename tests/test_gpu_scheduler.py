@@ -133,6 +133,21 @@ def test_f64_plans_bit_identical(la, oracle):
                 la.matmul(A, B, -1.5, 0.5, C)
                 assert la.get_option("last_f64_asm") == kern + 1, (kern, plan, wgs, la.get_option("last_f64_asm"))
                 assert np.array_equal(C.cpu().numpy(), want), (kern, plan, wgs)
+            # round 6: the strided plan with pipelined transitions (beta == 0, K a multiple of 16): workgroup counts that give every
+            # workgroup several tiles, against the plain launch's bits and the oracle
+            K2 = 1024 + 128
+            A2, B2 = A[:, :K2].contiguous(), (B[:K2, :] if not nt else torch.from_numpy(np.ascontiguousarray(Bh[:K2].T)).cuda().t())
+            want2 = oracle.matmul(Ah[:, :K2], Bh[:K2], 1.0, 0.0, None)
+            la.set_option("asm_noseed", 0)
+            for plan, wgs in ((1, 0), (3, 0), (3, 2), (3, 5), (3, 11)):
+                la.set_option("asm_plan", plan)
+                la.set_option("asm_wgs", wgs)
+                C = torch.full((M, N), float("nan"), dtype=torch.float64, device="cuda")
+                la.matmul(A2, B2, 1.0, 0.0, C)
+                assert la.get_option("last_f64_asm") == kern + 1, (kern, plan, wgs, la.get_option("last_f64_asm"))
+                if plan == 3 and wgs:
+                    assert la.get_option("last_asm_wgs") == wgs, (kern, wgs, la.get_option("last_asm_wgs"))
+                assert np.array_equal(C.cpu().numpy(), want2), (kern, plan, wgs)
     finally:
         for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f64_asm", 1), ("asm_noseed", 0)):
             la.set_option(k, v)
