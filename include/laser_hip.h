@@ -61,8 +61,8 @@ int laser_hip_device_count(void);
 /* Diagnostics (touches no device): the kernel and launch plan the float32 launcher takes for a dense row-major M x N x K product on a
  * device of `cus` compute units -- the launch plans scale with the device's own CU count, so a partitioned MI355X (CPX 32 / QPX 64 /
  * DPX 128 CUs) keeps the hand-scheduled kernels.  out8[0] = 1 + kernel index (0: compiler-scheduled kernels), [1] = plan (0 one tile
- * per workgroup, 1 persistent with K-slice cuts, 2 strided whole tiles with pipelined transitions), [2] = workgroups, [3] = K slices
- * per tile, [4] = tiles, [5] / [6] = tile rows / columns, [7] = workgroup slots.  The GPU twin of reading gemm_tiling.nim:276-341's
+ * per workgroup, 1 persistent with K-slice cuts, 2 strided whole tiles with pipelined transitions, 3 hybrid: 2 for the whole rounds + 1 for the remaining tiles), [2] = workgroups,
+ * [3] = K slices per tile (hybrid: of the second launch), [4] = tiles, [5] / [6] = tile rows / columns, [7] = workgroup slots.  The GPU twin of reading gemm_tiling.nim:276-341's
  * `newTiles` for a shape: what partition will the library use. */
 int laser_hip_plan_f32(int64_t M, int64_t N, int64_t K, int laser_order, int cus, int64_t *out8);
 /* Name of the GPU architecture in use, e.g. "gfx950" (replaces the reference's cpuinfo ISA
@@ -121,6 +121,9 @@ int laser_hip_f32_config_count(void);
  *                          WITHOUT leaving its K loop -- the last K-tile bodies of a tile fetch the next tile's first K-tiles, the next
  *                          tile's first body stores this tile's C (beta == 0, plain epilogue, K a multiple of the K-tile); what the
  *                          model takes by itself when there are more tiles than workgroup slots.  Same bits as plan 1, both modes.
+ *                          4 = the hybrid plan whenever legal (round 6): two launches of one kernel -- the whole rounds of the tile
+ *                          raster under plan 3, the remaining tiles (a fraction of a round, >= 8) under plan 2 -- what the model takes
+ *                          in one-chain mode when the fraction is small; laser-order results are the same bits as under every plan.
  *                          A K-cut launch whose hand-over times out (a receiver polls ~2 s for its predecessor's running sum; never in
  *                          a correct run) is REPORTED: the error word travels back behind the launch and the next call on that stream
  *                          fails with LASER_HIP_E_HIP, laser_hip_last_error() naming the stream -- never a silently wrong C
@@ -144,6 +147,7 @@ int laser_hip_f32_config_count(void);
  *   "last_f32_config"  tile configuration index (-1 none yet, -2 small-matrix kernel, -3 direct small-channel conv kernel)
  *   "last_f32_asm" / "last_f64_asm" / "last_i32_asm"  0 = compiler-scheduled kernel, else 1 + index of the assembly kernel (gemm_f32_asm.cpp)
  *   "last_asm_wgs" / "last_asm_slices"  workgroups and K slices per tile of the last assembly launch (slices 1 = tiles never cut)
+ *   "last_asm_rem"     tiles the last assembly launch left to the K-cut launch of a hybrid plan (0: one launch)
  *   "last_asm_group_m"  its raster group height in tile rows (which tiles share an XCD's L2), + 65536 when the workgroup ids were
  *                      chunked per XCD
  *   "asm_fixup_timeouts"  streams of the current device on which a workgroup of a cut launch gave up waiting for a hand-over (0 in a

@@ -42,22 +42,23 @@ def plan_units(tiles, Kd, G, exact, kc, BK, split=True):
     return P, slen, U // G, U % G
 
 
-def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, noseed=0, ws=0, flags=0, group_m=None, xcd=False, two_level=False, strided=False):
+def sched_bytes(tm, tn, G, P=1, slen=1 << 30, q=None, r=0, noseed=0, ws=0, flags=0, group_m=None, xcd=False, two_level=False, strided=False, T=None):
     """the scheduler block of the kernel arguments (f32_kernel.py KA_SCHED); group_m None = one group: tile rows fastest;
     two_level: XCD x owns whole tiles, its G / 8 workgroups share them (launches that cut tiles); strided: workgroup v walks the whole
     tiles v, v + G, v + 2G ..."""
     gm = group_m or tm
     gsz_last = tm % gm or gm
+    T = tm * tn if T is None else T       # (T: the tiles this launch covers -- the raster constants stay those of the whole grid)
     if strided:
         assert P == 1 or slen >= 1
         return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), (G // 8) if xcd else 0,
-                           (G % 8) if xcd else 0, P, K.magic_u32(P), G, tm * tn, slen, noseed | 4, K.magic_u32(G), ws, flags)
+                           (G % 8) if xcd else 0, P, K.magic_u32(P), G, T, slen, noseed | 4, K.magic_u32(G), ws, flags)
     if q is None:
-        q, r = tm * tn * P // G, tm * tn * P % G
+        q, r = T * P // G, T * P % G
     if two_level:
         assert G % 8 == 0
         return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), G // 8,
-                           0, P, K.magic_u32(P), tm * tn, 0, slen, noseed | 2, K.magic_u32(G // 8), ws, flags)
+                           0, P, K.magic_u32(P), T, 0, slen, noseed | 2, K.magic_u32(G // 8), ws, flags)
     return struct.pack("<16IQQ", tm, tn, gm, gsz_last, K.magic_u32(gm * tn), K.magic_u32(gm), K.magic_u32(gsz_last), (G // 8) if xcd else 0,
                        (G % 8) if xcd else 0, P, K.magic_u32(P), q, r, slen, noseed, K.magic_u32(G), ws, flags)
 
@@ -83,8 +84,10 @@ def run_grid(prog, mem, ka_, G, batch, lds_bytes, order=None, xcd=False):
 
 def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False, order=None, over=None, verbose=True, alpha=1.0, beta=0.0,
              batch=1, bias=None, act=0, G=None, split=False, group_m=None, xcd=False, tol=None, noseed=0, two_level=False, csc=1, pre=0, interleaved=False,
-             strided=False, mod=None):
+             strided=False, mod=None, hybrid=False):
     """one f32 GEMM kernel through the interpreter; batch > 1: workgroup id y = batch index, operands `batch` spans apart.
+    hybrid: the launcher's two-launch plan -- the whole rounds of the raster (tiles [0, T1), T1 = (T // G) * G) as a strided launch, the
+    remaining tiles [T1, T) as a second launch of G2 = `hybrid` workgroups that cuts them along K (the kernels' tile base, KA_TAB).
     G: workgroups of the (persistent) launch, default one per tile; split: cut tiles along K at slice boundaries (laser-order: kc;
     one chain: `split` K-tiles per slice) so that the G workgroups get equal numbers of units"""
     g = (mod or K).make(name, **(over or {}))      # mod: another generator module with the f32 kernels' argument block (f32x16_kernel)
@@ -149,10 +152,27 @@ def run_case(name, M, N, Kd, lda=None, ldb=None, ldc=None, seed=0, integer=False
         bias_ptr = mem.alloc(Bias.reshape(-1).copy())
     ka = struct.pack("<QQQQIIIIIIffQ", a_, b_, c_, 0, lda, ldb, ldc, M, N, Kd, alpha, beta, 0)
     ka += struct.pack("<Q", LA * 4) + b"\0" * 28 + struct.pack("<I", pre) + struct.pack("<QQ", LB * 4, LC * 4) + struct.pack("<QIIII", bias_ptr, rsb, csb, act, csc if csc != 1 else 0)
-    ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level, strided)
-    assert len(ka) == K.KERNARG_SIZE
-    ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     t0 = time.time()
+    if hybrid:
+        T, G2 = tm * tn, int(hybrid)
+        T1 = T // G * G
+        assert batch == 1 and 0 < T1 < T and G2 >= 1
+        ka1 = ka + sched_bytes(tm, tn, G, 1, (Kd + c.BK - 1) // c.BK * c.BK, None, 0, noseed, 0, 0, group_m, xcd, False, True, T=T1)
+        ka1_ = mem.alloc(np.frombuffer(ka1, dtype=np.uint8))
+        run_grid(g.p, mem, ka1_, G, 1, c.lds_alloc, order, xcd)
+        R = T - T1
+        P, slen, uq, ur = plan_units(R, Kd, G2, c.exact, 512, c.BK, split or True)
+        ws2 = mem.alloc(np.full(G2 * g.tile_bytes() // 4, np.nan, dtype=np.float32))
+        fl2 = mem.alloc(np.zeros(G2 + 1, dtype=np.uint32))
+        kb = bytearray(ka)
+        kb[24:28] = struct.pack("<I", T1)                      # KA_TAB's low word: the launch's first tile
+        ka2 = bytes(kb) + sched_bytes(tm, tn, G2, P, slen, uq, ur, noseed, ws2, fl2 + 4, group_m, xcd or two_level, two_level, False, T=R)
+        ka_ = mem.alloc(np.frombuffer(ka2, dtype=np.uint8))
+        G, fl_base = G2, fl2
+    else:
+        ka += sched_bytes(tm, tn, G, P, slen, uq, ur, noseed, ws_, fl_, group_m, xcd or two_level, two_level, strided)
+        assert len(ka) == K.KERNARG_SIZE
+        ka_ = mem.alloc(np.frombuffer(ka, dtype=np.uint8))
     stats = run_grid(g.p, mem, ka_, G, batch, c.lds_alloc, order, xcd or two_level)
     flags_after = mem.get(fl_base, np.uint32, (G + 1,))
     if np.any(flags_after[1:]):

@@ -672,7 +672,10 @@ class Gen:
             self.sched_next(self.L_exit, self.L_recv)
             p.place(self.L_setup)
             e("s_barrier", comment="every wave is done with the previous run's LDS tiles")
-            tile = self.s_tile
+            # (KA_TAB's low word, GEMM kernels: the first tile of this launch -- a launch may cover the tiles [base, base + T') of the
+            # raster only, the two launches of the launcher's hybrid plan; 0 otherwise.  The scheduler's tile numbers stay relative.)
+            e("s_add_u32", st[4], self.s_tile, self.ka0[6])
+            tile = st[4]
             e("s_load_dwordx8", self.s_sc, s(0, 2), KA_SCHED)
             e("s_waitcnt", lgkmcnt=0)
         elif c.cpers:
@@ -687,6 +690,8 @@ class Gen:
             e("s_load_dword", st[5], s(0, 2), KA_SCHED2)
             e("s_waitcnt", lgkmcnt=0)
             self.xcd_remap(st[4], s(2), self.s_sc[7], st[5], st[0])
+            if not c.conv:
+                e("s_add_u32", st[4], st[4], self.ka0[6])       # (the launch's first tile, see above)
             tile = st[4]
         self.tile_coords(tile, self.s_sc, st[0], st[1], (st[2], st[3], st[5]))
         self.dump("pid_m", st[0])
@@ -1846,7 +1851,8 @@ class Gen:
         e("s_add_u32", self.s_tcur, self.s_tcur, st[1])
         e("s_load_dwordx8", sc, s(0, 2), KA_SCHED)
         e("s_waitcnt", lgkmcnt=0)
-        self.tile_coords(self.s_tile, sc, st[0], st[1], (st[2], st[3], st[5]))
+        e("s_add_u32", st[4], self.s_tile, self.ka0[6])           # (the launch's first tile: prologue)
+        self.tile_coords(st[4], sc, st[0], st[1], (st[2], st[3], st[5]))
         e("s_mul_i32", self.s_m0, st[0], c.BM)
         e("s_mul_i32", self.s_n0, st[1], c.BN)
         self.ab_descriptors()

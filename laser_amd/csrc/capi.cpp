@@ -1570,7 +1570,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "skinny") g_ctx.skinny = on;
   else if (n == "small_path") g_small_path = on;
   else if (n == "split_tail") g_split_tail = on;
-  else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 3 ? 3 : value;
+  else if (n == "asm_plan") g_asm_plan = value < 0 ? 0 : value > 4 ? 4 : value;
   else if (n == "asm_kernel") g_asm_kernel = value < 0 ? -1 : value;
   else if (n == "asm_tile") g_asm_tile = value < 0 || value > 9 ? -1 : value;
   else if (n == "thread_asm_tile") asm_set_thread_tile(value < -1 || value > 9 ? -2 : value);
@@ -1620,6 +1620,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "asm_test_giveup") *value = g_asm_giveup;
   else if (n == "asm_group_m") *value = g_asm_group_m;
   else if (n == "last_asm_wgs") *value = g_last_asm_wgs;
+  else if (n == "last_asm_rem") *value = g_last_asm_rem;
   else if (n == "last_asm_slices") *value = g_last_asm_slices;
   else if (n == "last_asm_group_m") *value = g_last_asm_group_m;
   else if (n == "asm_fixup_timeouts") *value = asm_fixup_timeouts();

@@ -192,6 +192,7 @@ void asm_set_thread_tile(int tile_class);   // per-thread pin of the same (-2 = 
 int asm_get_thread_tile();
 int asm_tile_pin_now();                     // the pin this thread's launches see (-1 = none)
 extern std::atomic<int> g_last_asm_group_m;
+extern std::atomic<int> g_last_asm_rem;       // tiles the last assembly launch left to the K-cut launch of a hybrid plan (0: one launch)
 extern std::atomic<int> g_asm_plan, g_asm_kernel, g_asm_wgs, g_asm_slice, g_asm_noseed, g_asm_group_m, g_asm_giveup;   // launch-plan overrides of the assembly kernels (tuning sweeps, tests)
 extern std::atomic<int> g_last_asm_wgs, g_last_asm_slices;                  // diagnostics: workgroups / K slices per tile of the last assembly launch
 extern std::atomic<int> g_f32_asm;       // 1 default; 0 = never; 2 = whenever the kernel can (no tile-count rule: tests)

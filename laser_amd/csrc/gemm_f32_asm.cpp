@@ -28,7 +28,8 @@ std::atomic<int> g_last_f64_asm{0};  // diagnostics: 0 = compiler-scheduled kern
 std::atomic<int> g_f32_asm{1};       // 1 (default): eligible problems run on the hand-scheduled kernels
 std::atomic<int> g_last_f32_asm{0};  // diagnostics: 0 = compiler-scheduled kernel; 1 + index into kKernels otherwise
 
-std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model decides; 1 = one tile per workgroup only; 2 = the persistent plan with K-slice cuts whenever legal; 3 = the strided whole-tile plan whenever legal
+std::atomic<int> g_last_asm_rem{0};    // diagnostics: tiles the last launch left to the second launch of a hybrid plan (0: one launch)
+std::atomic<int> g_asm_plan{0};       // option "asm_plan": 0 = the launch model decides; 1 = one tile per workgroup only; 2 = the persistent plan with K-slice cuts whenever legal; 3 = the strided whole-tile plan whenever legal; 4 = strided whole rounds + a K-cut launch over the remaining tiles (hybrid) whenever legal
 std::atomic<int> g_asm_kernel{-1};    // option "asm_kernel": force an index of kKernels (tuning sweeps); -1 = the model decides
 std::atomic<int> g_asm_tile{-1};      // option "asm_tile": pin a tile class of the f32 GEMM kernels (0 = 256x128 / 256x256, 1 = 256x128 one chain, 2 = 128x128x16, 3 = 128x128x32, 4 = 64x64; on 16x16 blocks: 5 = 96x96, 6 = 160x96, 7 = 128x96, 8 = 192x96, 9 = 160x160; -1 = the model decides)
 thread_local int tl_asm_tile = -2;    // the same pin for the launches made BY THIS THREAD (-2 = none: the option applies); asm_set_thread_tile
@@ -204,13 +205,15 @@ inline uint32_t magic_u32(uint64_t d) { return d <= 1 ? 0u : (uint32_t)(((uint64
 // tiles [T x / 8, T (x + 1) / 8) and its G / 8 workgroups share them -- a cut tile's sender is always started before its receiver
 // (asmgen/f32_kernel.py KA_SCHED).  false: a quotient of the in-kernel arithmetic would leave the range of its magic number.
 bool fill_sched(SchedArgs &sc, int64_t tiles_m, int64_t tiles_n, int group_m, int64_t G, int64_t P, int64_t slice_len,
-                const StreamWs *w, bool xcd, bool two_level) {
-  const int64_t T = tiles_m * tiles_n, U = T * P;
+                const StreamWs *w, bool xcd, bool two_level, int64_t T_cover = 0) {
+  // (T_cover: the launch covers that many tiles of the raster only -- the unit arithmetic runs over them, the raster constants stay
+  // those of the whole grid; the kernel adds the launch's first tile, KA_TAB)
+  const int64_t Tgrid = tiles_m * tiles_n, T = T_cover > 0 ? T_cover : Tgrid, U = T * P;
   if (group_m <= 0 || group_m > tiles_m) group_m = (int)tiles_m;   // one group: tile rows fastest (the convolution's order)
   const int64_t width = (int64_t)group_m * tiles_n, gsz_last = tiles_m % group_m ? tiles_m % group_m : group_m;
-  if ((double)T * (double)width >= 4.0e9 || (double)U * (double)P >= 4.0e9 || G < 1 || G > U) return false;
+  if ((double)Tgrid * (double)width >= 4.0e9 || (double)U * (double)P >= 4.0e9 || G < 1 || G > U) return false;
   const int64_t q = U / G, r = U % G;
-  if ((double)G * (double)r * (double)G >= 4.0e9 || tiles_m > 0x7fffffff || tiles_n > 0x7fffffff || U > 0x7fffffff || T >= ((int64_t)1 << 28)) return false;
+  if ((double)G * (double)r * (double)G >= 4.0e9 || tiles_m > 0x7fffffff || tiles_n > 0x7fffffff || U > 0x7fffffff || Tgrid >= ((int64_t)1 << 28)) return false;
   if (two_level && (G % 8 != 0 || T < 8 || (T / 8) * P < G / 8 || (double)(U / 8 + P) * (double)(G / 8) >= 4.0e9)) return false;
   sc.tiles_m = (uint32_t)tiles_m; sc.tiles_n = (uint32_t)tiles_n; sc.group_m = (uint32_t)group_m; sc.gsz_last = (uint32_t)gsz_last;
   sc.mg_width = magic_u32((uint64_t)width); sc.mg_gm = magic_u32((uint64_t)group_m); sc.mg_last = magic_u32((uint64_t)gsz_last);
@@ -347,6 +350,10 @@ struct Plan {
   bool strided = false;      // persistent, whole tiles only: workgroup v takes tiles v, v + G, v + 2G ... (pipelined transitions)
   int64_t G = 0, P = 1, slice_len = 0;
   double time_us = 1e300;
+  // hybrid (round 6; strided only): the strided launch covers the whole rounds of the raster, tiles [0, T - rem_tiles); the remaining
+  // rem_tiles tiles -- a fraction of a round that would cost every workgroup's wait for the few that got one more tile -- follow as a
+  // second launch of rem_G workgroups that cuts them along K into rem_P slices (the kernels' tile base, KA_TAB; f32_kernel.py prologue)
+  int64_t rem_tiles = 0, rem_G = 0, rem_P = 1, rem_slice_len = 0;
 };
 
 Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, bool exact, int kc, double cu_flops_per_us, bool may_cut,
@@ -365,7 +372,7 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     // contiguous chunk of the raster), minus what a fresh workgroup per tile costs -- drain, C store burst, prologue, first loads.
     const int64_t slots = g_asm_wgs > 0 ? std::min<int64_t>(g_asm_wgs, 4096) : (int64_t)kCUs * ki.occ;
     // (pipe_us < 0: this problem may not pipeline; asm_plan = 3 forces the plan wherever it is legal -- sweeps, tests)
-    if (pipe_us >= 0.0 && batch == 1 && g_asm_plan != 1 && g_asm_plan != 2 && ((pipe_us > 0.0 && tiles > slots) || (g_asm_plan == 3 && tiles >= 2))) {
+    if (pipe_us >= 0.0 && batch == 1 && g_asm_plan != 1 && g_asm_plan != 2 && ((pipe_us > 0.0 && tiles > slots) || (g_asm_plan >= 3 && tiles >= 2))) {
       const int64_t G = std::min(slots, tiles), per_wg = (tiles + G - 1) / G;
       if (per_wg >= 2) {
         best.persistent = true;
@@ -379,9 +386,12 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     if (g_asm_plan == 3) return best;
   }
   if (g_asm_plan == 1 || !may_cut || batch != 1 || !g_split_tail) return best;
-  Plan pers;
   const int64_t slots = g_asm_wgs > 0 ? std::min<int64_t>(g_asm_wgs, 4096) : (int64_t)kCUs * ki.occ;
   const int64_t kt = (K + ki.bk - 1) / ki.bk;
+  // the best plan that cuts `tiles` tiles along K (remainder: the tiles are what a strided launch leaves over -- ranges shorter than a
+  // tile are what it is for)
+  const auto best_cut = [&](int64_t tiles, bool remainder) {
+  Plan pers;
   // candidate cuts: laser-order: the kc slices; one chain: 1..16 slices of equal numbers of K-tiles (or the forced length)
   int64_t cuts[18];
   int ncuts = 0;
@@ -394,7 +404,7 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
       // (two or three long slices per tile: every workgroup's range is a send piece + a receive piece and the launch runs about one
       // slice longer than the model says -- 3328^3 one chain on 256x128 in 3 slices: 117.9 TFLOP/s where the plain 160x96 launch runs
       // 137.7; 2048^3 / 1920^3 in 2: 0.77 / 0.69 of peak, profiles/r06/size_sweep_vendor_j.jsonl, x16_ab_mid_g.jsonl)
-      if ((p == 2 || p == 3) && g_asm_plan != 2) continue;
+      if ((p == 2 || p == 3) && g_asm_plan != 2 && !remainder) continue;
       const int64_t len = (kt + p - 1) / p * ki.bk;
       if (len >= 4 * ki.bk || p == 1) cuts[ncuts++] = len;
     }
@@ -409,14 +419,14 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
     // some tile straddles two workgroups (an XCD's share of the tiles may be one more or less than T / 8: then its units do not
     // divide evenly even where U / G does)
     const bool cut = U % G != 0 || (U / G) % P != 0 || (G >= 8 && tiles % 8 != 0);
-    if (!cut && G >= tiles && g_asm_plan != 2) continue;  // one whole tile per workgroup: that is the plain launch
+    if (!cut && G >= tiles && g_asm_plan != 2 && !remainder) continue;  // one whole tile per workgroup: that is the plain launch
     // many tiles per workgroup: the workgroups of an XCD drift apart in the tile order and lose their shared panels -- the plain
     // launch keeps them on neighbouring tiles
     if ((double)U / (double)G / (double)P > 4.0 && g_asm_plan != 2) continue;
     const int64_t q = U / G, r = U % G;
     // ranges much shorter than a tile: a workgroup waits for the sum of a predecessor that is still computing it (hand-over
     // chains); such problems are few-tile x long-K: the slice-parallel form / the plain launch serve them
-    if (q < P - 2 && g_asm_plan != 2) continue;
+    if (q < P - 2 && g_asm_plan != 2 && !remainder) continue;
     // the busiest CU: its workgroups' units back to back (the r longer ranges are spread evenly over the workgroup ids), at the
     // average unit length (the last slice of a tile is shorter)
     const int64_t wg_per_cu = (G + kCUs - 1) / kCUs;
@@ -445,6 +455,29 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
       pers.time_us = t_us;
     }
   }
+  return pers;
+  };
+  // hybrid: the whole rounds strided, the rest of the raster cut along K over every slot (a strided launch of 5.3 rounds takes 6).
+  // Measured (profiles/r06/plan_ab_frac_hybrid_ab.jsonl, 256x128 and 256x256 tiles at 4608^3 .. 7424^3): the second launch takes
+  // 0.35 + 0.95 x its share of a round, in tile times -- its workgroups sit on K ranges of their own, so nothing of an operand panel is
+  // shared through L2 the way a round of whole tiles shares it -- in ONE-CHAIN mode: 0.46 / 0.62 / 0.71 tile times for 0.13 / 0.28 /
+  // 0.53 of a round (6656^3 131 -> 143 TFLOP/s, 5888^3 135 -> 141, 4608^3 137 -> 142).  Laser-order: a workgroup folds its slices onto
+  // the received sum IN ORDER, so all but the first slice of its piece wait for the predecessor's whole piece (f32_kernel.py
+  // sched_next): with ranges much shorter than a tile the pieces of a tile run one after the other -- 0.76 .. 1.08 tile times whatever
+  // the share -- and the extra strided round is no worse: not offered (asm_plan = 4 forces it: same bits).
+  if (best.strided && g_asm_plan != 3 && tiles % best.G >= 8 && tiles / best.G >= 1 && (!exact || g_asm_plan == 4)) {
+    const int64_t R = tiles % best.G, full = tiles / best.G;
+    const Plan rem = best_cut(R, true);
+    if (rem.persistent) {
+      const double t = ((double)full + 0.35 + 0.95 * (double)R / (double)best.G) * tile_us / ki.eff + ki.fixed_us + 8.0 - (double)(full - 1) * std::max(0.0, pipe_us);
+      if (t < 0.985 * best.time_us || g_asm_plan == 4) {
+        best.rem_tiles = R; best.rem_G = rem.G; best.rem_P = rem.P; best.rem_slice_len = rem.slice_len;
+        best.time_us = t;
+      }
+    }
+  }
+  if (g_asm_plan == 4) return best;
+  const Plan pers = best_cut(tiles, false);
   if (pers.persistent && (pers.time_us < 1.0 * best.time_us || g_asm_plan == 2)) return pers;      // (0.96 before the 1.045 above: the same margin)
   return best;
 }
@@ -459,6 +492,43 @@ hipError_t launch_planned(DeviceModule *m, int kern, const Plan &plan_in, KernAr
     if (pe != hipSuccess) return pe;
   }
   const int64_t T = (int64_t)tiles_m * tiles_n, U = T * plan.P;
+  if (plan.strided && plan.rem_tiles > 0) {
+    // hybrid: whole rounds strided, then the rest of the raster cut along K (Plan::rem_*).  Everything the second launch needs is
+    // prepared BEFORE the first is issued (its workspace is refused while the stream is being captured): if anything is missing the
+    // strided launch simply covers all tiles.
+    const int64_t R = plan.rem_tiles, T1 = T - R, G2 = plan.rem_G, P2 = plan.rem_P, U2 = R * P2;
+    bool ok = walk_G == 0 && batch == 1 && T1 > 0 && T1 % plan.G == 0 && G2 >= 1 && G2 <= U2 && ka.unused_ == nullptr;
+    const bool cuts2 = ok && (U2 % G2 != 0 || (U2 / G2) % P2 != 0 || (G2 >= 8 && R % 8 != 0));
+    const bool two2 = cuts2 && G2 >= 8 && G2 % 8 == 0 && R >= 8;
+    if (cuts2 && G2 >= 8 && !two2) ok = false;
+    StreamWs w2;
+    if (ok && cuts2) ok = get_ws(m, s, (size_t)G2 * tile_bytes, (size_t)G2 + 1, &w2) == hipSuccess;
+    KernArgs ka2 = ka;
+    if (ok) ok = fill_sched(ka2.sch, tiles_m, tiles_n, group_m, G2, P2, plan.rem_slice_len, cuts2 ? &w2 : nullptr, group_m > 0 && (!cuts2 || two2), two2, R);
+    if (ok) ok = fill_sched(ka.sch, tiles_m, tiles_n, group_m, plan.G, 1, plan.slice_len, nullptr, group_m > 0, false, T1);
+    if (ok) {
+      ka.sch.units_q = (uint32_t)plan.G;
+      ka.sch.units_r = (uint32_t)T1;
+      ka.sch.flags_bits |= 4u;
+      ka2.unused_ = (const uint32_t *)(uintptr_t)T1;       // KA_TAB's low word: the second launch's first tile
+      size_t sz = sizeof(ka);
+      void *extra1[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      hipError_t e = hipModuleLaunchKernel(m->fn[kern], (unsigned)plan.G, 1, 1, 256, 1, 1, 0, s, nullptr, extra1);
+      if (e != hipSuccess) return e;
+      void *extra2[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka2, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      e = hipModuleLaunchKernel(m->fn[kern], (unsigned)G2, 1, 1, 256, 1, 1, 0, s, nullptr, extra2);
+      if (e == hipSuccess && cuts2 && w2.host_err) (void)hipMemcpyAsync((void *)w2.host_err, w2.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) {
+        g_last_asm_wgs = (int)plan.G;
+        g_last_asm_slices = (int)P2;
+        g_last_asm_rem = (int)R;
+        g_last_asm_group_m = (int)ka.sch.group_m | (ka.sch.xcd_q ? 1 << 16 : 0);
+      }
+      return e;
+    }
+    plan.rem_tiles = 0;
+  }
+  g_last_asm_rem = 0;
   const bool cuts = plan.persistent && !plan.strided && (U % plan.G != 0 || (U / plan.G) % plan.P != 0 || (plan.G >= 8 && T % 8 != 0));
   const bool two_level = cuts && plan.G >= 8 && plan.G % 8 == 0 && T >= 8;
   if (cuts && plan.G >= 8 && !two_level) return hipErrorNotSupported;
@@ -731,7 +801,8 @@ int asm_plan_f32(int64_t M, int64_t N, int64_t K, int laser_order, int cus, int6
   if (choose_gemm_f32_asm(a, laser_order != 0, cus, &pick, &plan) != hipSuccess) return 0;
   const KernelInfo &ki = kKernels[pick];
   out[0] = 1 + pick;
-  out[1] = plan.strided ? 2 : plan.persistent ? 1 : 0;
+  out[1] = plan.strided ? (plan.rem_tiles > 0 ? 3 : 2) : plan.persistent ? 1 : 0;     // (3: hybrid -- [3] then holds the K slices of the second launch)
+  if (plan.rem_tiles > 0) plan.P = plan.rem_P;
   out[2] = plan.G;
   out[3] = plan.P;
   out[5] = (M + ki.bm - 1) / ki.bm;

@@ -130,10 +130,11 @@ def last_f32_asm():
 def plan_f32(M, N, K, laser_order=True, cus=256):
     """Diagnostics (no device needed): the kernel and launch plan the float32 launcher takes for a dense M x N x K product on a device
     of `cus` compute units (laser_hip_plan_f32): dict(kernel, plan, wgs, slices, tiles, tiles_m, tiles_n, slots); kernel 0 = the
-    compiler-scheduled kernels take the problem; plan: "plain" / "cut" / "strided"."""
+    compiler-scheduled kernels take the problem; plan: "plain" / "cut" / "strided" / "hybrid" (strided whole rounds + a K-cut launch over
+    the remaining tiles: `slices` are the second launch's)."""
     out = (C.c_int64 * 8)()
     _lib.check(_lib.lib().laser_hip_plan_f32(M, N, K, 1 if laser_order else 0, cus, out))
-    return dict(kernel=int(out[0]), plan=("plain", "cut", "strided")[int(out[1])], wgs=int(out[2]), slices=int(out[3]), tiles=int(out[4]),
+    return dict(kernel=int(out[0]), plan=("plain", "cut", "strided", "hybrid")[int(out[1])], wgs=int(out[2]), slices=int(out[3]), tiles=int(out[4]),
                 tiles_m=int(out[5]), tiles_n=int(out[6]), slots=int(out[7]))
 
 

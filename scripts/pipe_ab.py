@@ -73,6 +73,8 @@ for (M, N, K) in SHAPES:
             laser_amd.set_option("asm_kernel", kern)
             rec = {"M": M, "N": N, "K": K, "mode": "laser_order" if mode == 0 else "fast", "kernel": kname}
             PLANS = (1, 3, 2) if "cut" in sys.argv[4:] else (1, 3)      # 2 = the persistent plan with K-slice cuts and hand-overs
+            if "hyb" in sys.argv[4:]:
+                PLANS = PLANS + (4,)                                      # 4 = strided whole rounds + a K-cut launch over the remaining tiles
             outs, times, meta = {}, {p_: [] for p_ in PLANS}, {}
             ok = True
             for plan in PLANS:
@@ -85,11 +87,13 @@ for (M, N, K) in SHAPES:
                     break
                 outs[plan] = C.clone()
                 meta[plan] = {"wgs": laser_amd.get_option("last_asm_wgs"), "slices": laser_amd.get_option("last_asm_slices")}
+                if plan == 4:
+                    meta[plan]["rem_tiles"] = laser_amd.get_option("last_asm_rem")
             if not ok:
                 rec["skipped"] = "kernel not eligible"
                 print(json.dumps(rec), flush=True)
                 continue
-            rec["bit_identical"] = bool(torch.equal(outs[1], outs[3])) and (2 not in outs or mode == 1 or bool(torch.equal(outs[1], outs[2])))
+            rec["bit_identical"] = bool(torch.equal(outs[1], outs[3])) and all(q_ not in outs or mode == 1 or bool(torch.equal(outs[1], outs[q_])) for q_ in (2, 4))
             rec["finite"] = bool(torch.isfinite(outs[3]).all())
             laser_amd.set_option("asm_plan", 1)
             warm(call)
@@ -98,7 +102,7 @@ for (M, N, K) in SHAPES:
                     laser_amd.set_option("asm_plan", plan)
                     call()
                     times[plan].append(timed(call, fl))
-            for plan, nm in ((1, "plain"), (3, "pipe"), (2, "cut"))[:len(PLANS)]:
+            for plan, nm in [(p_, {1: "plain", 3: "pipe", 2: "cut", 4: "hybrid"}[p_]) for p_ in PLANS]:
                 ts = sorted(times[plan])
                 ms = ts[len(ts) // 2]
                 rec[nm] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / 157.3, 4), "min_ms": round(ts[0], 4), **meta[plan]}

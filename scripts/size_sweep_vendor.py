@@ -40,7 +40,7 @@ for n in range(a0, a1 + 1, st):
         if name != "vendor":
             k = laser_amd.last_f32_asm()
             rec[name + "_kernel"] = bench.ASM_KERNEL_SYMBOLS[k - 1] if k else "compiler-scheduled"
-            rec[name + "_plan"] = [laser_amd.get_option("last_asm_wgs"), laser_amd.get_option("last_asm_slices")]
+            rec[name + "_plan"] = [laser_amd.get_option("last_asm_wgs"), laser_amd.get_option("last_asm_slices"), laser_amd.get_option("last_asm_rem")]      # (workgroups, K slices, tiles left to the K-cut launch of a hybrid plan)
     ts = {k: [] for k in calls}
     for _ in range(5):
         for name, f in calls.items():

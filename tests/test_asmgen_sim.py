@@ -132,26 +132,26 @@ def test_persistent_and_k_split_launches_in_the_interpreter(name, M, N, Kd, kw):
 # result must be the same bits as one workgroup per tile: ragged M / N, strided C, alpha != 1, exactly 3 K-tiles (the switch happens in
 # the transition body's own tail), folds inside a tile, several wave interleavings.
 PIPE_CASES = [
-    ("exact_64x64x32", 130, 200, 576, dict(G=3, strided=True)),
+    ("exact_64x64x32", 130, 130, 544, dict(G=3, strided=True)),
     ("exact_64x64x32", 130, 200, 96, dict(G=5, strided=True, ldc=205)),                       # 3 K-tiles: no body between two switches
     ("exact_64x64x32", 130, 200, 128, dict(G=4, strided=True, alpha=0.75, order=[3, 1, 0, 2])),
-    ("exact_64x64x32_nt", 130, 200, 576, dict(G=2, strided=True, lda=580, ldb=584, xcd=True, group_m=2)),
+    ("exact_64x64x32_nt", 130, 130, 544, dict(G=2, strided=True, lda=548, ldb=552, xcd=True, group_m=2)),
     ("exact_256x128x32", 300, 260, 96, dict(G=2, strided=True, ldc=270)),
-    ("exact_256x128x32", 520, 130, 544, dict(G=1, strided=True, alpha=-2.0)),                # one workgroup walks every tile; folds + transition
+    ("exact_256x128x32", 300, 130, 544, dict(G=1, strided=True, alpha=-2.0)),                # one workgroup walks every tile; folds + transition
     ("exact_256x128x32_nt", 300, 260, 160, dict(G=3, strided=True, csc=2)),
-    ("exact_128x128x16", 140, 390, 560, dict(G=2, strided=True, csc=2)),
+    ("exact_128x128x16", 140, 260, 560, dict(G=2, strided=True, csc=2)),
     ("exact_128x128x32", 260, 390, 160, dict(G=4, strided=True, order=[2, 0, 3, 1])),
     ("fast_256x128x32", 300, 260, 128, dict(G=2, strided=True, alpha=0.5)),
     ("fast_256x256x16", 300, 520, 64, dict(G=2, strided=True)),
     ("fast_128x128x16_nt", 140, 390, 80, dict(G=3, strided=True, ldc=400)),
     ("fast_64x64x32", 130, 200, 160, dict(G=7, strided=True, xcd=True, group_m=2)),
     # contiguous ranges (the cut plans): whole tiles between the head and the tail piece of a range are pipelined too
-    ("exact_64x64x32", 130, 200, 576, dict(G=5, split=True)),
-    ("exact_64x64x32", 130, 200, 576, dict(G=8, split=True, two_level=True, noseed=1)),
+    ("exact_64x64x32", 130, 130, 544, dict(G=5, split=True)),
+    ("exact_64x64x32", 130, 130, 544, dict(G=8, split=True, two_level=True, noseed=1)),
     # launches that may NOT pipeline take the ordinary path: beta != 0, a bias, a K tail
-    ("exact_64x64x32", 130, 200, 576, dict(G=3, strided=True, beta=0.5)),
-    ("exact_64x64x32", 130, 200, 576, dict(G=3, strided=True, bias="row", act=1)),
-    ("exact_64x64x32", 130, 200, 588, dict(G=3, strided=True)),
+    ("exact_64x64x32", 130, 130, 544, dict(G=3, strided=True, beta=0.5)),
+    ("exact_64x64x32", 130, 130, 544, dict(G=3, strided=True, bias="row", act=1)),
+    ("exact_64x64x32", 130, 130, 556, dict(G=3, strided=True)),
     ("fast_256x128x32", 300, 260, 64, dict(G=2, strided=True)),                               # two K-tiles only
 ]
 
@@ -308,6 +308,27 @@ def test_conv_kernels_fused_bias_relu_in_the_interpreter():
     assert C.run_conv_case("conv_fast_64x128x32", 1, 64, 6, 8, 70, (0, 1), bias=True, act=0, verbose=False)
 
 
+# Round 6: the launcher's hybrid plan -- whole rounds of the raster as a strided launch, the remaining tiles as a second launch that cuts
+# them along K; the kernels add the launch's first tile (KA_TAB's low word) to the scheduler's relative tile numbers
+HYBRID_CASES = [
+    ("exact_64x64x32", 130, 200, 600, dict(G=5, hybrid=3)),                                        # 12 tiles: 10 strided + 2 tiles x 2 slices on 3 workgroups
+    ("fast_64x64x32", 130, 200, 160, dict(G=5, hybrid=4, tol=1e-3)),
+    ("exact_128x128x16", 260, 260, 560, dict(G=4, hybrid=2)),                                      # 9 tiles: 8 + 1 tile whose two slices go to two workgroups
+    ("exact_64x64x32", 130, 380, 600, dict(G=10, hybrid=8, two_level=True, group_m=2)),            # 18 tiles: 10 + 8 tiles on 8 workgroups, one per XCD
+    ("exact_64x64x32_nt", 130, 264, 600, dict(G=7, hybrid=2, group_m=2, noseed=1)),                # 15 tiles: 14 + 1; the late receive path
+]
+
+
+@pytest.mark.parametrize("name,M,N,Kd,kw", HYBRID_CASES, ids=[f"hybrid-{c[0]}-{c[1]}x{c[2]}x{c[3]}" for c in HYBRID_CASES])
+def test_hybrid_two_launch_plan_in_the_interpreter(name, M, N, Kd, kw):
+    assert C.run_case(name, M, N, Kd, verbose=False, **kw)
+
+
+def test_hybrid_plan_16x16_block_tile_in_the_interpreter():
+    from laser_amd.asmgen import f32x16_kernel as K16
+    assert C.run_case("exact_96x96x32", 200, 300, 544, G=5, hybrid=3, mod=K16, verbose=False)      # 12 tiles: 10 + 2
+
+
 # float64 kernels (f64_kernel.py): integer-valued operands (exact in f64: the interpreter's f64 MFMA is mul + add)
 F64_CASES = [
     ("fast_64x64x16", 70, 90, 48, {}),
@@ -414,11 +435,11 @@ X16_CASES = [
     ("fast_160x96x32_nt", 40, 50, 96, {}),
     ("exact_96x96x32", 4, 4, 4, {}),
     ("exact_96x96x32", 100, 110, 64, dict(batch=2)),
-    ("exact_96x96x32", 100, 100, 1100, dict(G=2, split=True)),
+    ("exact_96x96x32", 100, 100, 620, dict(G=2, split=True)),
     ("exact_96x96x32", 100, 200, 548, dict(G=3, split=True, alpha=0.75, beta=-1.5, noseed=1)),
     ("exact_96x96x32_nt", 200, 200, 548, dict(G=8, split=True, two_level=True, group_m=2)),
     ("fast_96x96x32", 100, 200, 300, dict(G=5, split=2, integer=True, beta=2.0)),
-    ("exact_160x96x32", 170, 200, 600, dict(G=3, split=True, group_m=1)),
+    ("exact_160x96x32", 170, 100, 600, dict(G=3, split=True, group_m=1)),
     ("exact_96x96x32", 200, 200, 96, dict(G=2, strided=True)),
     ("exact_128x96x32", 130, 100, 548, dict(lda=552, ldb=104, ldc=108)),
     ("fast_128x96x32_nt", 129, 97, 100, dict(alpha=3.0, beta=0.5)),
@@ -429,7 +450,7 @@ X16_CASES = [
     # pipelined tile transitions on this family: strided whole-tile plans, folds inside a tile, one chain, exactly three
     # K-tiles, launches that may not pipeline (beta != 0, a K tail)
     ("exact_96x96x32", 200, 300, 96, dict(G=2, strided=True, ldc=304)),
-    ("exact_96x96x32", 200, 200, 576, dict(G=2, strided=True, alpha=0.75)),
+    ("exact_96x96x32", 200, 100, 576, dict(G=2, strided=True, alpha=0.75)),
     ("fast_96x96x32_nt", 200, 300, 128, dict(G=4, strided=True)),
     ("exact_160x160x32_nt", 330, 170, 96, dict(G=1, strided=True)),
     ("exact_192x96x32", 390, 200, 96, dict(G=3, strided=True, xcd=True, group_m=2)),

@@ -79,6 +79,44 @@ def test_laser_order_bit_identical_for_every_plan_and_workgroup_count(la, oracle
             la.set_option(k, v)
 
 
+def test_hybrid_plan_bit_identical(la, oracle):
+    """Round 6: the two-launch plan (asm_plan = 4) -- the whole rounds of the raster as a strided launch with pipelined transitions, the
+    remaining tiles as a second launch of the same kernel that cuts them along K (the kernels' tile base) -- against the oracle bit for
+    bit in laser-order mode (the hand-over folds the kc slices in order: same bits under every plan), within the one-chain tolerance
+    in fast mode; workgroup counts that leave 8 .. 30 tiles to the second launch, the early and the late receive path."""
+    import torch
+    rng = np.random.default_rng(414)
+    la.set_option("f32_asm", 2)
+    try:
+        for mode in (0, 1):
+            la.set_float_mode(mode)
+            for kern, (bm, bn), nt in (((0, 8)[mode], (256, 128), False), ((12, 13)[mode], (64, 64), False), ((30, 31)[mode], (128, 128), False),
+                                       ((46, 47)[mode], (96, 96), False), ((6, 7)[mode], (128, 128), True), ((62, 63)[mode], (160, 160), False)):
+                M, N, K = 10 * bm - 17, 13 * bn - 5, 1600               # 130 tiles, 3.1 kc slices
+                Ah, Bh = _rnd(rng, (M, K)), _rnd(rng, (K, N))
+                A = torch.from_numpy(Ah).cuda()
+                B = torch.from_numpy(np.ascontiguousarray(Bh.T)).cuda().t() if nt else torch.from_numpy(Bh).cuda()
+                want = oracle.matmul(Ah, Bh) if mode == 0 else Ah.astype(np.float64) @ Bh.astype(np.float64)
+                la.set_option("asm_kernel", kern)
+                for wgs, late in ((24, 0), (24, 1), (40, 0), (61, 1), (100, 0)):
+                    la.set_option("asm_plan", 4)
+                    la.set_option("asm_wgs", wgs)
+                    la.set_option("asm_noseed", late)
+                    C = torch.full((M, N), float("nan"), device="cuda")
+                    la.matmul(A, B, 1, 0, C)
+                    assert la.last_f32_asm() == kern + 1, (kern, wgs, la.last_f32_asm())
+                    assert la.get_option("last_asm_wgs") == wgs and la.get_option("last_asm_rem") == 130 % wgs, (kern, wgs, la.get_option("last_asm_rem"))
+                    got = C.cpu().numpy()
+                    if mode == 0:
+                        assert np.array_equal(got, want), (kern, wgs, late)
+                    else:
+                        assert _mre(got, want) <= 1e-5, (kern, wgs, _mre(got, want))
+    finally:
+        la.set_float_mode(0)
+        for k, v in (("asm_plan", 0), ("asm_kernel", -1), ("asm_wgs", 0), ("f32_asm", 1), ("asm_noseed", 0)):
+            la.set_option(k, v)
+
+
 def test_one_chain_cut_launches_within_tolerance_and_deterministic(la, oracle):
     """FAST mode: a cut launch adds partial sums (another rounding order than the single chain, by design): <= 1e-5 mean relative
     error against the float64 product, and the same bits on every repetition (the fix-up order is fixed, not first-come)"""

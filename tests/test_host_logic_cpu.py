@@ -211,6 +211,8 @@ def test_launch_plans_scale_with_the_device_cu_count():
                     assert p["wgs"] == p["tiles"] and p["slices"] == 1
                 elif p["plan"] == "strided":          # one persistent workgroup per slot, more tiles than slots, whole tiles only
                     assert p["wgs"] == p["slots"] < p["tiles"] and p["slices"] == 1
+                elif p["plan"] == "hybrid":           # (one-chain mode only) whole rounds strided, >= 8 remaining tiles cut along K
+                    assert not laser and p["wgs"] == p["slots"] < p["tiles"] and p["tiles"] % p["wgs"] >= 8 and p["slices"] >= 1
                 else:                                  # K-slice cuts: at most every slot of THIS device, a multiple of 8 when tiles are cut
                     assert 8 <= p["wgs"] <= p["slots"] and p["slices"] >= 1
         # the number of rounds the busiest CU works follows the CU count: fewer CUs -> the same shape needs a plan with fewer workgroups
