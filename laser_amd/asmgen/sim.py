@@ -43,6 +43,19 @@ def fma32(a, b, c):
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
 
 
+# accumulator layouts as index maps [register][lane] -> (row, column) of the block (one fancy-indexed copy instead of a loop per register)
+_L64 = np.arange(64)
+_R32 = np.stack([(r & 3) + 8 * (r >> 2) + 4 * (_L64 >> 5) for r in range(16)])      # v_mfma_f32_32x32x2: element r of lane l
+_C32 = np.broadcast_to(_L64 & 31, (16, 64)).copy()
+_R16 = np.stack([4 * (_L64 >> 4) + d for d in range(4)])                            # v_mfma_f32_16x16x4: register d of lane l
+_C16 = np.broadcast_to(_L64 & 15, (4, 64)).copy()
+
+
+def fma32_outer(acol, brow, c):
+    """c[i][j] = fmaf(a[i], b[j], c[i][j]) (fma32's arithmetic on the outer product, broadcast instead of materialised operands)"""
+    return (acol.astype(np.float64)[:, None] * brow.astype(np.float64)[None, :] + c.astype(np.float64)).astype(np.float32)
+
+
 class Memory:
     """Flat global memory: named numpy byte buffers at fake 64-bit addresses."""
 
@@ -66,6 +79,20 @@ class Memory:
     def read32(self, addr):
         raw, o = self._find(addr, 4)
         return int(raw[o:o + 4].view(np.uint32)[0])
+
+    def read32_vec(self, addrs):
+        """read32 of every address of an int64 array: one gather when they lie in ONE allocation (the usual case), else lane by lane
+        (which also raises for an access outside every allocation)"""
+        if len(addrs) == 0:
+            return np.zeros(0, dtype=np.uint32)
+        lo, hi = int(addrs.min()), int(addrs.max())
+        for base, raw in self.bufs:
+            if base <= lo and hi + 4 <= base + len(raw):
+                off = addrs - base
+                if len(raw) % 4 == 0 and not np.any(off & 3):
+                    return raw.view(np.uint32)[off >> 2]
+                break
+        return np.array([self.read32(int(a_)) for a_ in addrs], dtype=np.uint32)
 
     def write32(self, addr, val):
         raw, o = self._find(addr, 4)
@@ -102,7 +129,9 @@ class Wave:
         self.stats = {"bank_conflict_cycles": 0, "lds_ops": 0, "mfma": 0, "waits_vm": [], "ins": 0}
 
     def execmask(self):
-        return np.array([(self.exec >> l) & 1 for l in range(LANES)], dtype=bool)
+        if getattr(self, "_em_exec", None) != self.exec:
+            self._em_exec, self._em = self.exec, np.array([(self.exec >> l) & 1 for l in range(LANES)], dtype=bool)
+        return self._em
 
 
 class Workgroup:
@@ -537,17 +566,14 @@ class Workgroup:
                 cm = np.full((16, LANES), f32(np.array([self.rd_s(w, SC)], dtype=U32))[0], dtype=np.float32)
             # C tile [32][32]: element r of lane l -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l & 31
             Ct = np.zeros((32, 32), dtype=np.float32)
-            lanes = np.arange(LANES)
-            for r in range(16):
-                Ct[(r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5), lanes & 31] = cm[r]
+            Ct[_R32, _C32] = cm
             for kk in range(2):
-                arow = av[32 * kk:32 * kk + 32]  # A[i][k]: lane i + 32k
-                bcol = bv[32 * kk:32 * kk + 32]  # B[k][j]: lane j + 32k
-                Ct = fma32(arow[:, None] * np.ones((1, 32), np.float32), np.ones((32, 1), np.float32) * bcol[None, :], Ct)
+                # A[i][k]: lane i + 32k; B[k][j]: lane j + 32k
+                Ct = fma32_outer(av[32 * kk:32 * kk + 32], bv[32 * kk:32 * kk + 32], Ct)
             arr = w.v if D.kind == "v" else w.a
             self._chk_waw(w, D.regs())
+            arr[D.idx:D.idx + 16] = u32(Ct[_R32, _C32])
             for r in range(16):
-                arr[D.idx + r] = u32(Ct[(r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5), lanes & 31])
                 w.mfma_wr[(D.kind, D.idx + r)] = w.state
             w.n_mfma += 1
             w.stats["mfma"] += 1
@@ -579,18 +605,16 @@ class Workgroup:
                         if kk in w.valu_wr_state and w.state - w.valu_wr_state[kk] < 3:
                             raise SimError(f"wave {w.wid} pc {w.pc}: MFMA srcC {SC} read {w.state - w.valu_wr_state[kk]} states after a VALU wrote it")
                 cm = f32(arr[SC.idx:SC.idx + 4].copy())  # [d][lane]
-                for d in range(4):
-                    Ct[4 * (lanes >> 4) + d, lanes & 15] = cm[d]
+                Ct[_R16, _C16] = cm
             else:
                 assert int(SC) == 0
             for kk in range(4):
-                arow = av[16 * kk:16 * kk + 16]  # A[i][k]: lane i + 16k
-                bcol = bv[16 * kk:16 * kk + 16]  # B[k][j]: lane j + 16k
-                Ct = fma32(arow[:, None] * np.ones((1, 16), np.float32), np.ones((16, 1), np.float32) * bcol[None, :], Ct)
+                # A[i][k]: lane i + 16k; B[k][j]: lane j + 16k
+                Ct = fma32_outer(av[16 * kk:16 * kk + 16], bv[16 * kk:16 * kk + 16], Ct)
             arr = w.v if D.kind == "v" else w.a
             self._chk_waw(w, D.regs())
+            arr[D.idx:D.idx + 4] = u32(Ct[_R16, _C16])
             for d in range(4):
-                arr[D.idx + d] = u32(Ct[4 * (lanes >> 4) + d, lanes & 15])
                 w.mfma_wr[(D.kind, D.idx + d)] = w.state
             w.n_mfma += 1
             w.stats["mfma"] += 1
@@ -791,11 +815,11 @@ class Workgroup:
                 dst = w.v if data.kind == "v" else w.a
                 for d in range(ndw):
                     vals = np.zeros(LANES, dtype=U32)
-                    for l in range(LANES):
-                        # gfx950 (scripts/probes/buffer_soffset.hip, profiles/r06/buffer_soffset_a.txt): the SCALAR offset is part of the
-                        # range check of a raw buffer -- voffset + inst_offset + soffset + 4 <= num_records
-                        if act[l] and vo[l] + so + 4 * d + 4 <= nrec and vo[l] + 4 * d >= 0:
-                            vals[l] = self.mem.read32(base + so + int(vo[l]) + 4 * d)
+                    # gfx950 (scripts/probes/buffer_soffset.hip, profiles/r06/buffer_soffset_a.txt): the SCALAR offset is part of the
+                    # range check of a raw buffer -- voffset + inst_offset + soffset + 4 <= num_records
+                    ok_ = act & (vo + so + 4 * d + 4 <= nrec) & (vo + 4 * d >= 0)
+                    if np.any(ok_):
+                        vals[ok_] = self.mem.read32_vec(base + so + vo[ok_] + 4 * d)
                     dst[data.idx + d][act] = vals[act]
                     w.pending[(data.kind, data.idx + d)] = op
                 w.vm.append(data.regs())
