@@ -357,7 +357,7 @@ struct Plan {
 };
 
 Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, bool exact, int kc, double cu_flops_per_us, bool may_cut,
-                 double pipe_us = -1.0, int cus = kFullCUs) {
+                 double pipe_us = -1.0, int cus = kFullCUs, bool allow_hybrid = true) {
   const int64_t kCUs = cus;
   Plan best;
   const double tile_us = 2.0 * ki.bm * ki.bn * (double)K / cu_flops_per_us;
@@ -465,7 +465,7 @@ Plan plan_launch(const KernelInfo &ki, int64_t tiles, int64_t K, int64_t batch, 
   // the received sum IN ORDER, so all but the first slice of its piece wait for the predecessor's whole piece (f32_kernel.py
   // sched_next): with ranges much shorter than a tile the pieces of a tile run one after the other -- 0.76 .. 1.08 tile times whatever
   // the share -- and the extra strided round is no worse: not offered (asm_plan = 4 forces it: same bits).
-  if (best.strided && g_asm_plan != 3 && tiles % best.G >= 8 && tiles / best.G >= 1 && (!exact || g_asm_plan == 4)) {
+  if (allow_hybrid && best.strided && g_asm_plan != 3 && tiles % best.G >= 8 && tiles / best.G >= 1 && (!exact || g_asm_plan == 4)) {
     const int64_t R = tiles % best.G, full = tiles / best.G;
     const Plan rem = best_cut(R, true);
     if (rem.persistent) {
@@ -981,7 +981,8 @@ hipError_t launch_gemm_f64_asm_core(const GemmArgs<double> &a, bool laser_order,
     if (g_f64_asm < 2 && t * a.batch < (k == tiny ? 3 : 5) * (int64_t)cus / 8) continue;
     // (pipelined tile transitions, round 6: beta == 0, whole K-tiles, three or more of them -- f64_kernel.py once())
     const bool may_pipe = a.beta == 0.0 && a.K % ki_.bk == 0 && a.K >= 3 * ki_.bk && a.batch == 1;
-    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 256, cu_flops_per_us, exact || !laser_order, may_pipe ? pipe_gain_us(k) : -1.0, cus);
+    // (the hybrid plan is fitted and tested on the f32 kernels only: not offered here)
+    const Plan p = plan_launch(ki_, t, a.K, a.batch, exact, 256, cu_flops_per_us, exact || !laser_order, may_pipe ? pipe_gain_us(k) : -1.0, cus, false);
     if (p.time_us < 0.99 * plan.time_us) plan = p, pick = k;
   }
   if (pick < 0) return hipErrorNotSupported;

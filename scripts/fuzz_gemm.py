@@ -72,7 +72,7 @@ for it in range(cases):
         laser_amd.set_f32_config(-1)
         f64 = dtype == np.float64
         kerns = ([16, 18] if mode == 0 else [17, 19]) if f64 else ([0, 2, 30, 12, 46, 50, 54, 58, 62] if mode == 0 else [1, 8, 3, 31, 13, 47, 51, 55, 59, 63])      # (46..: the 16x16-block tiles; ineligible picks -- K % 4 != 0, transposed B -- fall to the model's own)
-        plan = {"f64_asm" if f64 else "f32_asm": 2, "slice_parallel": 0, "asm_plan": int(rng.choice([0, 1, 2, 2, 4])),
+        plan = {"f64_asm" if f64 else "f32_asm": 2, "slice_parallel": 0, "asm_plan": int(rng.choice([0, 1, 2, 2, 3, 4])),
                 "asm_kernel": int(rng.choice(kerns + [-1])), "asm_wgs": int(rng.choice([0, 0, 8 * int(rng.integers(1, 97))])),
                 "asm_noseed": int(rng.random() < 0.4), "asm_group_m": int(rng.choice([0, 0, 1, 3, 8])),
                 "asm_slice": int(rng.choice([0, 0, 4, 9])) if mode == 1 else 0}

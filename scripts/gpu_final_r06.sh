@@ -5,8 +5,8 @@ export TMPDIR=/tmp
 T=${1:-v3}
 bash scripts/gpu_full_validation_r06.sh $T
 O=gpurun_out/r06
-timeout 1500 python scripts/fuzz_gemm.py 1200 71 > $O/fuzz_gemm_$T.log 2>&1; echo "fuzz gemm rc=$?"; tail -2 $O/fuzz_gemm_$T.log | cut -c1-300
-timeout 1200 python scripts/fuzz_conv.py 500 72 > $O/fuzz_conv_$T.log 2>&1; echo "fuzz conv rc=$?"; tail -2 $O/fuzz_conv_$T.log | cut -c1-300
+timeout 2400 python scripts/fuzz_gemm.py 2000 71 > $O/fuzz_gemm_$T.log 2>&1; echo "fuzz gemm rc=$?"; tail -2 $O/fuzz_gemm_$T.log | cut -c1-300
+timeout 1800 python scripts/fuzz_conv.py 800 72 > $O/fuzz_conv_$T.log 2>&1; echo "fuzz conv rc=$?"; tail -2 $O/fuzz_conv_$T.log | cut -c1-300
 timeout 900 python scripts/size_sweep_vendor.py 1024 8192 256 > $O/size_sweep_vendor_$T.jsonl 2> /dev/null; python - <<PY
 import json
 for l in open("$O/size_sweep_vendor_$T.jsonl"):

@@ -258,8 +258,9 @@ def test_dev_entry_point_captured_into_a_graph_and_replayed(la, oracle):
     C = torch.zeros((M, N), device="cuda")
     la.set_option("f32_asm", 2)
     try:
-        for plan in (1, 2):
+        for plan in (1, 2, 3, 4):             # (3, 4: the strided plan and the two-launch hybrid; 40 workgroups so that both have something to do)
             la.set_option("asm_plan", plan)
+            la.set_option("asm_wgs", 40 if plan >= 3 else 0)
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 la.matmul(A, B, 1, 0, C)          # warm: module load, (plan 2) this stream's workspace
@@ -275,8 +276,34 @@ def test_dev_entry_point_captured_into_a_graph_and_replayed(la, oracle):
                 g.replay()
                 torch.cuda.synchronize()
                 assert np.array_equal(C.cpu().numpy(), oracle.matmul(Ah, B.cpu().numpy())), (plan, rep)
+        # a convolution whose main launch walks units (no workspace, nothing allocated): captured and replayed the same way
+        la.set_option("asm_plan", 0)
+        la.set_option("asm_wgs", 0)
+        la.set_option("conv_walk", 5)
+        ishape, kshape = (4, 64, 30, 30), (256, 64, 3, 3)
+        x = torch.from_numpy(_rnd(rng, ishape)).cuda()
+        w = torch.from_numpy(_rnd(rng, kshape)).cuda()
+        oshape = la.conv2d_out_shape(ishape, kshape, (1, 1), (1, 1))
+        o = torch.zeros(oshape, device="cuda")
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            la.conv2d_im2col(o, oshape, x, ishape, w, kshape, (1, 1), (1, 1), None)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            la.conv2d_im2col(o, oshape, x, ishape, w, kshape, (1, 1), (1, 1), None)
+        assert la.last_f32_asm() >= 67
+        for rep in range(2):
+            xh = _rnd(rng, ishape)
+            x.copy_(torch.from_numpy(xh))
+            o.fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(o.cpu().numpy(), oracle.conv2d_im2col(xh, w.cpu().numpy(), (1, 1), (1, 1), isa=oracle.fused_isa(np.float32))), rep
     finally:
         la.set_option("asm_plan", 0)
+        la.set_option("asm_wgs", 0)
+        la.set_option("conv_walk", 1)
         la.set_option("f32_asm", 1)
 
 
