@@ -104,6 +104,8 @@ int laser_hip_f32_config_count(void);
  *   "conv_walk"        [1] assembly convolution main launch as unit walkers (a workgroup runs units (image, tile) g, g + G, ... with
  *                          pipelined transitions) where there are more units than workgroup slots; 0 never, 2 whenever there are two units,
  *                          >= 3: that many workgroups (tests).  Same bits either way.
+ *   "conv_1x1_implicit" [0] probes: 1x1 / stride 1 / no padding convolutions through the implicit-GEMM kernels instead of the reference's
+ *                          GEMM shortcut (conv2d_im2col.nim:121-153; measured 0.6 % ahead to 40 % behind it: profiles/r06/conv_1x1_probe_ae.jsonl)
  *   "conv_cut_always"  [0] tests / probes: cut every 3x3 convolution at its last whole 128-pixel tile, whatever the launch model says
  *   "conv_kslice"      [1] laser-order conv tail as parallel kc slices (gemm.nim:150-158) + ordered combine
  *   "host_pipeline_2d" [1] large host-pointer calls with pinned B and C: row panels x column panels; 0 = row panels only

@@ -1356,6 +1356,8 @@ bool conv_takes_implicit(int64_t iC, int64_t iH, int64_t iW, int64_t kH, int64_t
   return g_ctx.conv_implicit && kH <= 8 && kW <= 8 && iC * iH * iW + reach < (1ll << 30) && iC * kH * kW < (1ll << 30);
 }
 
+std::atomic<int> g_conv_1x1_implicit{0};   // option "conv_1x1_implicit" (probes): no GEMM shortcut for 1x1 / stride 1 / pad 0
+
 int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, int64_t iW, const float *dker,
              int64_t c_out, int64_t kH, int64_t kW, int64_t pH, int64_t pW, int64_t sH, int64_t sW, float *dws,
              hipStream_t s, const float *dbias = nullptr, int act = 0) {
@@ -1368,7 +1370,8 @@ int conv_dev(float *dout, const float *din, int64_t iN, int64_t iC, int64_t iH, 
   const int64_t M = c_out, K = iC * kH * kW, N = oH * oW;
   // 1x1 shortcut (conv2d_im2col.nim:121,128,151-153): the input already is the [K, N] matrix --
   // taken only for stride 1 / no padding, where that is actually true.
-  const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1;
+  // (option conv_1x1_implicit = 1, probes: the 1x1 / stride 1 / no padding case through the implicit-GEMM kernels as well)
+  const bool direct = (kH * kW == 1) && pH == 0 && pW == 0 && sH == 1 && sW == 1 && !g_conv_1x1_implicit;
   if (!direct && conv_takes_implicit(iC, iH, iW, kH, kW, pH, pW, sH, sW)) {
     // implicit GEMM: im2col's index arithmetic runs inside the B-tile loader, nothing is materialised
     GemmArgs<float> a = make_args<float>(iN, M, N, K, 1.0f, dker, K, 1, 0, din, 0, 1, iC * iH * iW, 0.0f, dout, N, 1, M * N);
@@ -1564,6 +1567,7 @@ int laser_hip_set_option(const char *name, int value) {
   else if (n == "conv_kslice") g_conv_kslice = on;
   else if (n == "conv_tail") g_conv_tail = on;
   else if (n == "conv_cut_always") g_conv_cut_always = on;
+  else if (n == "conv_1x1_implicit") g_conv_1x1_implicit = on;
   else if (n == "conv_walk") g_conv_walk = value < 0 ? 0 : value > 65535 ? 65535 : value;
   else if (n == "host_pipeline_2d") g_ctx.host_pipeline_2d = on;
   else if (n == "zero_copy_poll") g_ctx.zc_poll = on;
@@ -1603,6 +1607,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "conv_kslice") *value = g_conv_kslice;
   else if (n == "conv_tail") *value = g_conv_tail;
   else if (n == "conv_cut_always") *value = g_conv_cut_always;
+  else if (n == "conv_1x1_implicit") *value = g_conv_1x1_implicit;
   else if (n == "conv_walk") *value = g_conv_walk;
   else if (n == "host_pipeline_2d") *value = g_ctx.host_pipeline_2d;
   else if (n == "zero_copy_poll") *value = g_ctx.zc_poll;
