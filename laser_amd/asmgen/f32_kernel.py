@@ -119,14 +119,14 @@ class Cfg:
 
 CONFIGS = {
     # barrier positions from the schedule sweeps (profiles/r03/asm_probe_v1.jsonl, asm_probe_v2.jsonl)
-    "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, il=True, runv=True),
+    "exact_256x128x32": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, w_step=1, il=True, runv=True),
     "fast_256x256x16": dict(BM=256, BN=256, BK=16, exact=False, bar_gap=95),
     # mid-size problems (fewer than one round of the large tiles): 128 VGPRs + 128 AGPRs and 48 KiB of LDS per workgroup, so
     # two workgroups share a CU -- two waves per SIMD that cover each other's barrier and waits
     "exact_128x128x16": dict(BM=128, BN=128, BK=16, exact=True, runv=True),
     "fast_128x128x16": dict(BM=128, BN=128, BK=16, exact=False),
     # B passed transposed (rowStrideB == 1: k-contiguous like A) -- BASELINE configs[2]
-    "exact_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, b_kcontig=True, il=True, runv=True),
+    "exact_256x128x32_nt": dict(BM=256, BN=128, BK=32, exact=True, bar_gap=95, w_step=1, b_kcontig=True, il=True, runv=True),
     "fast_256x256x16_nt": dict(BM=256, BN=256, BK=16, exact=False, bar_gap=95, b_kcontig=True),
     "exact_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=True, b_kcontig=True, runv=True),
     "fast_128x128x16_nt": dict(BM=128, BN=128, BK=16, exact=False, b_kcontig=True),

@@ -175,6 +175,8 @@ class GenI8(Gen):
         for srd in (self.srdA, self.srdB):
             ops += [("s_add_u32", srd[0], srd[0], BLOCK), ("s_addc_u32", srd[1], srd[1], 0),
                     ("s_sub_u32", srd[2], srd[2], BLOCK), ("s_cselect_b32", srd[2], 0, srd[2])]
+        if "advance" in self.c.ablate:     # (timing experiment: every K-tile re-reads the first blocks -- cache-hot loads of real data)
+            ops = []
         if which is None:
             for o in ops:
                 self.p.emit(*o)
@@ -213,7 +215,10 @@ class GenI8(Gen):
         units = []
         for i in range(8):
             units.append([st[2 * i], st[2 * i + 1]])
-            units.append([("loadA", i) if i < 4 else ("loadB", i - 4)])
+            if "looploads" not in c.ablate:       # (timing experiments: the loop keeps storing / multiplying the prologue's real data)
+                units.append([("loadA", i) if i < 4 else ("loadB", i - 4)])
+        if "loopreads" in c.ablate:
+            fs = 0
         bar = c.bar_gap
         for k, u in enumerate(units):
             gaps[1 + k * (bar - 2) // len(units)] += u
@@ -222,7 +227,7 @@ class GenI8(Gen):
             gaps[min(bar + 1 + k, NMF - 1)].append(("ins", o[0], o[1:], {}))
         # the 16 fragment reads of tile t+1 follow the barrier one per gap: all issued >= 8 gaps before the tile ends, so the
         # wait at the top of the next body finds them done
-        rd = self.read_ops(nstage, 1 - fs)
+        rd = [] if "loopreads" in c.ablate else self.read_ops(nstage, 1 - fs)
         for k, o in enumerate(rd):
             gaps[min(bar + 1 + k * c.r_step, NMF - 2)].append(o)
         self.lg_wait({("R", 0)})
@@ -247,7 +252,7 @@ class GenI8(Gen):
         for k in range(6):
             p.place(B[k])
             self.tile_body(k % 3, k % 2)
-            assert (self.vmq, self.lgq) == state0, "loop-carried queue state differs"
+            assert (self.vmq, self.lgq) == state0 or c.ablate, "loop-carried queue state differs"
             e("s_sub_u32", self.s_rem, self.s_rem, 1)
             e("s_cmp_eq_u32", self.s_rem, 0)
             e("s_cbranch_scc1", L_done)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Schedule sweep of the hand-scheduled int32 limb kernel (laser_amd/asmgen/i8_kernel.py): every variant is generated, assembled,
 loaded as its own code object and timed on random digit planes (the packing pass is not part of the timing; results are not
-checked here -- tests/test_gpu_parity.py does).   usage: i8_probe.py variants.json [--n 8192]"""
+checked here -- tests/test_gpu_parity.py does).   usage: i8_probe.py variants.json [--n 8192] [--data random|zeros|low]
+--data: the digit planes' content -- random bytes (default; what full-range operands give), zeros, or only the lowest plane random (operands in
+[-128, 127]): the int8 matrix instructions' clock depends on the operand bits they toggle"""
 import ctypes as C
 import json, os, struct, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +18,13 @@ n = int(args[args.index("--n") + 1]) if "--n" in args else 8192
 variants = json.load(open([a for a in args if a.endswith(".json")][0]))
 tmp = tempfile.mkdtemp()
 npad, kt = (n + 127) // 128 * 128, (n + 31) // 32
+data = args[args.index("--data") + 1] if "--data" in args else "random"
 Ap = torch.randint(-128, 128, (4 * npad * kt * 32,), dtype=torch.int8, device="cuda")
 Bp = torch.randint(-128, 128, (4 * npad * kt * 32,), dtype=torch.int8, device="cuda")
+if data == "zeros":
+    Ap.zero_(); Bp.zero_()
+elif data == "low":      # blocks are [plane p][k half][row][16 bytes] of 16 KiB: planes 1 .. 3 of every block cleared
+    Ap.view(-1, 4, 4096)[:, 1:].zero_(); Bp.view(-1, 4, 4096)[:, 1:].zero_()
 Cm = torch.zeros((n, n), dtype=torch.int32, device="cuda")
 tm = npad // 128
 st = torch.cuda.current_stream().cuda_stream
@@ -60,5 +67,5 @@ for r in range(6):
             res[b[0]["name"]].append(e0.elapsed_time(e1) / 4)
 for b in built:
     v_ = sorted(res[b[0]["name"]]); med = v_[len(v_) // 2]
-    print(json.dumps({"variant": b[0]["name"], "over": b[0].get("over", {}), "n": n, "ms_median": round(med, 4), "tintops": round(2.0 * n ** 3 / med / 1e9, 1),
+    print(json.dumps({"variant": b[0]["name"], "over": b[0].get("over", {}), "n": n, "data": data, "ms_median": round(med, 4), "tintops": round(2.0 * n ** 3 / med / 1e9, 1),
                       "i8_tops": round(20.0 * n ** 3 / med / 1e9, 0)}), flush=True)
