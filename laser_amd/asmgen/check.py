@@ -398,10 +398,10 @@ def pack_limb_tiles(X, np_=4):
     return out.reshape(-1), xp, kp
 
 
-def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, alpha=1, beta=0):
+def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, alpha=1, beta=0, over=None):
     """int64 GEMM kernel (i8_kernel.py, "i64_64x64x32") through the interpreter: C = A B mod 2^64 with full-range int64 operands"""
     from . import i8_kernel as KI
-    g = KI.make("i64_64x64x32")
+    g = KI.make("i64_64x64x32", **(over or {}))
     g.build()
     c = g.c
     rng = np.random.default_rng(seed)
@@ -446,10 +446,10 @@ def run_case_i64(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, alpha=1, 
     return ok
 
 
-def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_range=True, alpha=1, beta=0):
+def run_case_i32(M, N, Kd, ldc=None, seed=0, order=None, verbose=True, full_range=True, alpha=1, beta=0, over=None):
     """int32 GEMM kernel (i8_kernel.py) through the interpreter: C = A B mod 2^32 with full-range int32 operands"""
     from . import i8_kernel as KI
-    g = KI.make()
+    g = KI.make(**(over or {}))
     g.build()
     c = g.c
     rng = np.random.default_rng(seed)

@@ -8,8 +8,12 @@ LDS ring with one barrier per K-tile, counted waits.
 
 Operands are the digit planes written by the packing pass (limb_planes.h, tile-major form): for every 128-row tile and 32-k
 tile one contiguous 16-KiB block [plane p][k half h][row r][16 bytes] -- so the global->LDS stage is a lane-linear copy (thread t
-moves bytes 16 t + 4096 i, fully coalesced, one ds_write_b128 each, no address arithmetic) and a fragment read is 32 consecutive
-16-byte chunks per half wave (conflict-free).  Workgroup tile 128x128, 2 x 2 waves of 64x64 (2 x 2 blocks); a K-tile is one
+moves bytes 16 t + 4096 i, fully coalesced, no address arithmetic) and a fragment read is 32 consecutive 16-byte chunks per half wave
+(conflict-free).  Because the LDS image IS the memory image, the copy is an LDS-DMA: `buffer_load_dwordx4 voffset, srsrc, 0 offen lds`
+writes lane l's 16 bytes at M0 + 16 l, M0 = stage + 4096 i + 1024 wave (one s_add_u32 + s_nop 0 per piece); tile t+2 is requested
+during tile t into the stage tile t-1 was read from, and a counted vmcnt wait in front of tile t+1's barrier proves this wave's pieces
+of tile t+1 have landed (the barrier covers the other waves').  No staging registers, no ds_write pass: +2 % on the kernel against the
+register-staged loop (`dma=False`; profiles/r06/i8_dma_an.jsonl), same bits.  Workgroup tile 128x128, 2 x 2 waves of 64x64 (2 x 2 blocks); a K-tile is one
 k-step: 40 MFMAs.  The fragments of tile t+1 (16 ds_read_b128) are read after the barrier of tile t into the other of two
 register sets, so the loop is unrolled x6 (3 LDS stages x 2 fragment sets).  Any int32 alpha / beta (wrapping), K <= 8192 (no
 fold of the accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything else stays on the compiler-scheduled kernel.
@@ -17,7 +21,7 @@ fold of the accumulator groups: |G_s| <= 4 * 8192 * 2^14 = 2^29); everything els
 int64 (`make("i64_64x64x32")`): eight planes, 36 products, eight accumulator groups = 128 AGPRs per 32x32 block, so a wave owns ONE
 block and the workgroup tile is 64x64 (blocks of [8 planes][2 halves][64 rows][16 bytes] = the same 16 KiB); the epilogue sums
 sext(G_s) << 8s in 64-bit (add-with-carry for s <= 3, shifted adds into the high word above), then alpha * (...) + beta * C0 wrapping."""
-from .core import v, a, s, VCC
+from .core import v, a, s, VCC, M0
 from .f32_kernel import Gen, Cfg, kernel_text, KA_A, KA_LDA, KA_DBG, KA_SCHED, KA_SCHED2  # noqa: F401
 
 KA_ALPHA64 = 72   # int64 alpha, beta (16 bytes): the slot of the f64 kernels' doubles
@@ -51,16 +55,17 @@ class GenI8(Gen):
         self.s_m0, self.s_n0, self.s_wave, self.s_wm0, self.s_wn0 = S(), S(), S(), S(), S()
         self.s_t = [S() for _ in range(6)]
         self.s_ldc4, self.s_ldc20 = S(), S()
+        self.s_dma = S() if c.dma else None                      # LDS byte offset of this wave's 1-KiB share of a 4-KiB piece
         self.s_sc = S(8, align=4)                                # tile map constants (f32_kernel.py KA_SCHED)
         self.s_ab64 = S(4, align=4) if c.NP == 8 else None      # int64 alpha (lo, hi), beta (lo, hi): loaded by the epilogue
         self.acc = [[p.aalloc(16) for _ in range(c.WB * c.WB)] for _ in range(c.NP)]        # [power of 256][block = WB * i + n]
         self.fa = [[[V(4) for _ in range(c.NP)] for _ in range(c.WB)] for _ in range(2)]   # [set][i][plane]
         self.fb = [[[V(4) for _ in range(c.NP)] for _ in range(c.WB)] for _ in range(2)]   # [set][n][plane]
-        self.stA = [V(4) for _ in range(4)]
-        self.stB = [V(4) for _ in range(4)]
-        self.vW = [V() for _ in range(3)]
-        self.RA = [V() for _ in range(3)]
-        self.RB = [V() for _ in range(3)]
+        self.stA = [V(4) for _ in range(4)] if not c.dma else None
+        self.stB = [V(4) for _ in range(4)] if not c.dma else None
+        self.vW = [V() for _ in range(c.NS)]
+        self.RA = [V() for _ in range(c.NS)]
+        self.RB = [V() for _ in range(c.NS)]
         self.vV = [V() for _ in range(4)]
         self.vC = [V() for _ in range(c.WB)]
         if c.debug:
@@ -108,11 +113,11 @@ class GenI8(Gen):
         e("v_add_u32", t[7], self.s_wn0, lo)
         e("v_lshl_add_u32", t[7], t[7], 4, t[5])
         e("v_add_u32", t[7], BLOCK, t[7])
-        for k in range(3):
+        for k in range(c.NS):
             e("v_add_u32", self.RA[k], k * c.STAGE, t[6])
             e("v_add_u32", self.RB[k], k * c.STAGE, t[7])
         e("v_lshlrev_b32", t[5], 4, tid)
-        for k in range(3):
+        for k in range(c.NS):
             e("v_add_u32", self.vW[k], k * c.STAGE, t[5])
         for i in range(4):
             e("v_add_u32", self.vV[i], 4096 * i, t[5])
@@ -143,15 +148,23 @@ class GenI8(Gen):
         e("s_mul_i32", self.s_ldc20, self.s_ldc4, 5)
         e("s_mov_b32", self.s_rem, self.s_lda)
         # ---- tile 0 -> LDS stage 0, tile 1 -> staging registers, fragments of tile 0 -> set 0 ----
-        self.issue_loads_all()
-        self.advance_srds()
-        self.run_ops(self.store_ops(0))
-        self.issue_loads_all()
-        self.advance_srds()
+        if c.dma:
+            e("s_lshl_b32", self.s_dma, self.s_wave, 10)
+            for k in range(c.NS - 1):
+                self.run_ops(self.dma_ops(k))
+                self.advance_srds()
+        else:
+            self.issue_loads_all()
+            self.advance_srds()
+            self.run_ops(self.store_ops(0))
+            self.issue_loads_all()
+            self.advance_srds()
         for sgrp in range(c.NP):
             for b in range(c.WB * c.WB):
                 for r in range(16):
                     e("v_accvgpr_write_b32", self.acc[sgrp][b][r], 0)
+        if c.dma:
+            self.vm_wait(("D", 0, 7))
         self.lg_wait(None)
         e("s_barrier")
         self.run_ops(self.read_ops(0, 0))
@@ -182,6 +195,19 @@ class GenI8(Gen):
                 self.p.emit(*o)
         return ops
 
+    def dma_ops(self, k):
+        """the 8 pieces of one K-tile's two blocks -> LDS stage k, no registers in between: piece i of a block lands at stage + 4096 i
+        + 16 * thread = M0 + 16 * lane with M0 = stage + 4096 i + 1024 * wave (the lane-linear image the staged path writes)"""
+        out = []
+        for i in range(8):
+            out.append([("ins", "s_add_u32", (M0, self.s_dma, k * self.c.STAGE + (BLOCK if i >= 4 else 0) + 4096 * (i % 4)), {}),
+                        ("ins", "s_nop", (0,), {}), ("call", (lambda i=i, k=k: self.dma_piece(i, k)))])
+        return [op for u in out for op in u]
+
+    def dma_piece(self, i, k):
+        self.p.emit("buffer_load_dwordx4", self.vV[i % 4], self.srdA if i < 4 else self.srdB, 0, offen=True, lds=True)
+        self.vm_issue(("D", k, i))
+
     def store_ops(self, k):
         """staging registers -> LDS stage k: a lane-linear copy"""
         out = []
@@ -209,11 +235,15 @@ class GenI8(Gen):
         c, e = self.c, self.p.emit
         NMF = c.NMF
         gaps = {m: [] for m in range(-1, NMF)}
-        nstage = (stage + 1) % 3
+        nstage = (stage + 1) % c.NS
         # LDS stores of tile t+1 (staging registers -> stage t+1), each followed by the load of tile t+2 into the drained registers
-        st = self.store_ops(nstage)
         units = []
-        for i in range(8):
+        if c.dma:
+            d = self.dma_ops((stage + c.NS - 1) % c.NS)      # tile t+2 (t+3 with a four-stage ring) -> the stage tile t-1 was read from (every wave is past barrier t-1)
+            units = [d[3 * i: 3 * i + 3] for i in range(8)]
+        else:
+            st = self.store_ops(nstage)
+        for i in range(0 if c.dma else 8):
             units.append([st[2 * i], st[2 * i + 1]])
             if "looploads" not in c.ablate:       # (timing experiments: the loop keeps storing / multiplying the prologue's real data)
                 units.append([("loadA", i) if i < 4 else ("loadB", i - 4)])
@@ -221,7 +251,18 @@ class GenI8(Gen):
             fs = 0
         bar = c.bar_gap
         for k, u in enumerate(units):
-            gaps[1 + k * (bar - 2) // len(units)] += u
+            at = 1 + k * (bar - 2) // len(units)
+            if c.dma and c.dma_sched == "early":        # (schedule probes, scripts/i8_probe.py: the spread placement is the shipped one)
+                at = 1 + k
+            elif c.dma and c.dma_sched == "late":
+                at = bar - len(units) + k
+            if c.dma and c.dma_sched == "split":        # M0 one gap ahead of its load: no wait state needed
+                gaps[at - 1] += u[:1]
+                gaps[at] += u[2:]
+            else:
+                gaps[at] += u
+        if c.dma:
+            gaps[bar].append(("vmwait", ("D", nstage, 7)))      # tile t+1 has landed (this wave's pieces; the barrier covers the others')
         gaps[bar].append(("barrier",))
         for k, o in enumerate(self.advance_srds(which="ops")):
             gaps[min(bar + 1 + k, NMF - 1)].append(("ins", o[0], o[1:], {}))
@@ -247,16 +288,17 @@ class GenI8(Gen):
         e = p.emit
         state0 = (list(self.vmq), list(self.lgq))
         L_done = p.label("done")
-        B = [p.label(f"tile_{k}") for k in range(6)]
+        nb = 6 if c.NS == 3 else 4             # bodies = lcm(LDS stages, fragment register sets)
+        B = [p.label(f"tile_{k}") for k in range(nb)]
         e("raw", ".p2align 6")
-        for k in range(6):
+        for k in range(nb):
             p.place(B[k])
-            self.tile_body(k % 3, k % 2)
-            assert (self.vmq, self.lgq) == state0 or c.ablate, "loop-carried queue state differs"
+            self.tile_body(k % c.NS, k % 2)
+            assert (self.vmq, self.lgq) == state0 or c.ablate or (c.dma and len(self.vmq) == len(state0[0])), "loop-carried queue state differs"
             e("s_sub_u32", self.s_rem, self.s_rem, 1)
             e("s_cmp_eq_u32", self.s_rem, 0)
             e("s_cbranch_scc1", L_done)
-            if k == 5:
+            if k == nb - 1:
                 e("s_branch", B[0])
         p.place(L_done)
 
@@ -411,7 +453,14 @@ def make(name="i32_128x128x32", **over):
     i64 = name.startswith("i64")
     kw = dict(BM=64 if i64 else 128, BN=64 if i64 else 128, BK=32, exact=False, bar_gap=18 if i64 else 20)   # (scripts/i8_probe.py: barrier 9 / 12 / 16 / 20 -> 275 / 279 / 283 / 286 Tint-op/s, int32)
     kw.update(over)
+    dma = kw.pop("dma", True)                  # operand blocks straight into LDS (`buffer_load_dwordx4 ... lds`), no staging registers; False: the register-staged loop of rounds 4-5 (A/B, ablations)
+    dma_sched = kw.pop("dma_sched", "spread")
+    ns = kw.pop("stages", 3)                   # LDS ring: 3 stages (tile t+2 requested during tile t) or, LDS-DMA only, 4 (tile t+3)
+    assert ns == 3 or (ns == 4 and dma)
     c = Cfg(name, persistent=False, **kw)       # one tile per workgroup (the limb kernels are never cut along K)
+    c.dma = dma
+    c.dma_sched = dma_sched
+    c.NS = ns
     c.dtype = "i8"
     c.NP = 8 if i64 else 4                     # digit planes = bytes of the element
     c.WB = 1 if i64 else 2                     # 32x32 blocks per wave in each direction
@@ -420,7 +469,7 @@ def make(name="i32_128x128x32", **over):
     c.ESH = 3 if i64 else 2                    # log2(bytes of an element of C)
     c.TM = c.TN = c.WB
     c.NB, c.NMF, c.STAGE, c.NPA, c.NPB = c.WB * c.WB, c.WB * c.WB * len(c.PRODUCTS), 2 * BLOCK, 4, 4
-    c.lds_bytes = c.lds_alloc = 3 * c.STAGE
+    c.lds_bytes = c.lds_alloc = c.NS * c.STAGE
     return GenI8(c)
 
 

@@ -54,6 +54,15 @@ def launch(b):
 for _ in range(8):
     launch(built[0])
 torch.cuda.synchronize()
+# every variant's C against the first variant's (the shipped kernel, which tests/test_gpu_parity.py holds to the oracle) on the same planes
+same = {}
+ref = None
+for b in built:
+    Cm.fill_(-7)
+    launch(b); torch.cuda.synchronize()
+    if ref is None:
+        ref = Cm.clone()
+    same[b[0]["name"]] = bool(torch.equal(Cm, ref))
 res = {b[0]["name"]: [] for b in built}
 for r in range(6):
     for b in built:
@@ -67,5 +76,5 @@ for r in range(6):
             res[b[0]["name"]].append(e0.elapsed_time(e1) / 4)
 for b in built:
     v_ = sorted(res[b[0]["name"]]); med = v_[len(v_) // 2]
-    print(json.dumps({"variant": b[0]["name"], "over": b[0].get("over", {}), "n": n, "data": data, "ms_median": round(med, 4), "tintops": round(2.0 * n ** 3 / med / 1e9, 1),
+    print(json.dumps({"variant": b[0]["name"], "over": b[0].get("over", {}), "n": n, "data": data, "same_c_as_first": same[b[0]["name"]], "ms_median": round(med, 4), "tintops": round(2.0 * n ** 3 / med / 1e9, 1),
                       "i8_tops": round(20.0 * n ** 3 / med / 1e9, 0)}), flush=True)

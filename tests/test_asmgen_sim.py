@@ -393,6 +393,20 @@ def test_i64_limb_kernel_exact_in_the_interpreter(M, N, Kd, ldc):
     assert C.run_case_i64(M, N, Kd, ldc=ldc, verbose=False)
 
 
+@pytest.mark.parametrize("which,M,N,Kd,ldc", [("i32", 130, 129, 100, 133), ("i64", 70, 90, 100, 93)])
+def test_integer_limb_kernels_register_staged_loop_still_exact(which, M, N, Kd, ldc):
+    """the shipped integer kernels bring their operand blocks into LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, what the cases above
+    run); the register-staged loop of rounds 4-5 stays as a generator option (A/B timing, ablations) and must keep the same bits"""
+    run = C.run_case_i32 if which == "i32" else C.run_case_i64
+    assert run(M, N, Kd, ldc=ldc, verbose=False, over=dict(dma=False))
+
+
+def test_interpreter_holds_lds_dma_bytes_back_until_the_counted_wait():
+    """an LDS-DMA piece is in LDS only once a vmcnt wait has retired it (a ds_read issued earlier sees the OLD bytes, no stall): with the
+    counted waits dropped the fragments are read from stages that have not landed -- the result must be wrong, not silently right"""
+    assert not C.run_case_i32(128, 128, 224, verbose=False, over=dict(ablate=("vmwaits",)))
+
+
 @pytest.mark.parametrize("alpha,beta", [(-3, 0), (0x123456789abcdef, -0x7654321fedcba987), (1, 5)])
 def test_i64_limb_kernel_alpha_beta_in_the_interpreter(alpha, beta):
     """C = alpha * A B + beta * C0 mod 2^64 in the int64 kernel's epilogue (three bodies: plain, alpha only, alpha and beta)"""
