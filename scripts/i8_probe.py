@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Schedule sweep of the hand-scheduled int32 limb kernel (laser_amd/asmgen/i8_kernel.py): every variant is generated, assembled,
 loaded as its own code object and timed on random digit planes (the packing pass is not part of the timing; results are not
-checked here -- tests/test_gpu_parity.py does).   usage: i8_probe.py variants.json [--n 8192] [--data random|zeros|low]
+checked here -- tests/test_gpu_parity.py does).   usage: i8_probe.py variants.json [--n 8192] [--data random|zeros|low]   (a variant may carry "group_m": the raster's tile rows per group, default 8)
 --data: the digit planes' content -- random bytes (default; what full-range operands give), zeros, or only the lowest plane random (operands in
 [-128, 127]): the int8 matrix instructions' clock depends on the operand bits they toggle"""
 import ctypes as C
@@ -42,7 +42,7 @@ for var in variants:
     # the kernel arguments as gemm_f32_asm.cpp: launch_gemm_i32_asm fills them (alpha = 1, beta = 0 as int32; the scheduler block of
     # the plain plan: one tile per workgroup, XCD remap, raster groups of 8 tile rows)
     ka = struct.pack("<QQQQIIIIIIiiQ", Ap.data_ptr(), Bp.data_ptr(), Cm.data_ptr(), 0, kt, 0, n, n, n, kt * 32, 1, 0, 0) + b"\0" * 80
-    ka += CHK.sched_bytes(tm, tm, tm * tm, group_m=min(8, tm), xcd=True)
+    ka += CHK.sched_bytes(tm, tm, tm * tm, group_m=min(var.get("group_m", 8), tm), xcd=bool(var.get("xcd", True)))
     assert len(ka) == K.KERNARG_SIZE
     buf = C.create_string_buffer(ka, len(ka)); size = C.c_size_t(len(ka))
     extra = (C.c_void_p * 5)(1, C.cast(buf, C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)
