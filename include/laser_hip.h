@@ -89,6 +89,7 @@ int laser_hip_f32_config_count(void);
  *                          alpha / beta, K even; laser_amd/asmgen/f64_kernel.py)
  *   "i32_asm"          [1] int32 / int64 limb GEMMs, any alpha / beta: the hand-scheduled kernels (laser_amd/asmgen/i8_kernel.py;
  *                          K > 8192 in chunks)
+ *   "int_group_m"      [4] tile rows per raster group of those kernels' workgroup -> tile map (1 .. 64; a scheduling knob: same results)
  *   "f64_mfma" "i32_mfma" "i64_mfma"  [1] matrix-core kernels (f64 MFMA; int8-limb decomposition for the integers, the
  *                          reference's integer micro-kernels: gemm_ukernel_avx512.nim:40-74); 0 = the VALU kernels
  *   "conv_implicit"    [1] im2col fused into the GEMM's B loader; 0 = explicit im2col workspace + batched GEMM, the

@@ -1558,6 +1558,7 @@ int laser_hip_set_option(const char *name, int value) {
   if (n == "f32_asm") g_f32_asm = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "f64_asm") g_f64_asm = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (n == "i32_asm") g_i32_asm = value < 0 ? 0 : value > 2 ? 2 : value;
+  else if (n == "int_group_m") g_int_group_m = value < 1 ? 1 : value > 64 ? 64 : value;
   else if (n == "f64_mfma") g_ctx.f64_mfma = on;
   else if (n == "i32_mfma") g_ctx.i32_mfma = on;
   else if (n == "i64_mfma") g_ctx.i64_mfma = on;
@@ -1597,6 +1598,7 @@ int laser_hip_get_option(const char *name, int64_t *value) {
   else if (n == "f64_asm") *value = g_f64_asm;
   else if (n == "last_f64_asm") *value = g_last_f64_asm;
   else if (n == "i32_asm") *value = g_i32_asm;
+  else if (n == "int_group_m") *value = g_int_group_m;
   else if (n == "last_i32_asm") *value = g_last_i32_asm;
   else if (n == "f64_mfma") *value = g_ctx.f64_mfma;
   else if (n == "i32_mfma") *value = g_ctx.i32_mfma;

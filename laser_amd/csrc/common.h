@@ -186,7 +186,7 @@ hipError_t launch_gemm_f64_asm(const GemmArgs<double> &args, bool laser_order, h
 extern std::atomic<int> g_f64_asm, g_last_f64_asm;
 hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &args, void *ws, hipStream_t s);
 hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &args, void *ws, hipStream_t s);
-extern std::atomic<int> g_i32_asm, g_last_i32_asm;
+extern std::atomic<int> g_i32_asm, g_last_i32_asm, g_int_group_m;
 extern std::atomic<int> g_asm_tile;   // option "asm_tile" (gemm_f32_asm.cpp)
 void asm_set_thread_tile(int tile_class);   // per-thread pin of the same (-2 = none)
 int asm_get_thread_tile();

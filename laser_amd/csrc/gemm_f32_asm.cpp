@@ -21,6 +21,7 @@
 
 namespace laser_hip {
 
+std::atomic<int> g_int_group_m{4};   // tile rows per raster group of the integer limb kernels (option int_group_m; 8192^3 int32: 4 is 2-3 % ahead of 8, profiles/r06/i8_raster*_a{r,s}.jsonl)
 std::atomic<int> g_i32_asm{1};       // int32 / int64 limb GEMMs: the hand-scheduled kernels when eligible (0 = the compiler-scheduled ones)
 std::atomic<int> g_last_i32_asm{0};
 std::atomic<int> g_f64_asm{1};       // float64: same meaning as g_f32_asm
@@ -894,7 +895,7 @@ hipError_t launch_gemm_i32_asm(const GemmArgs<int32_t> &a, void *ws, hipStream_t
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
-  const int tiles_m = (int)(Mpad / 128), tiles_n = (int)(Npad / 128), group_m = 8;
+  const int tiles_m = (int)(Mpad / 128), tiles_n = (int)(Npad / 128), group_m = g_int_group_m;
   KernArgs ka;
   zero_conv_fields(ka);
   ka.A = Ap; ka.B = Bp; ka.C = a.C;
@@ -932,7 +933,7 @@ hipError_t launch_gemm_i64_asm(const GemmArgs<int64_t> &a, void *ws, hipStream_t
   DeviceModule *m = nullptr;
   e = get_module(dev, &m);
   if (e != hipSuccess) return e;
-  const int tiles_m = (int)(Mpad / 64), tiles_n = (int)(Npad / 64), group_m = 8;
+  const int tiles_m = (int)(Mpad / 64), tiles_n = (int)(Npad / 64), group_m = g_int_group_m;
   KernArgs ka;
   zero_conv_fields(ka);
   ka.A = Ap; ka.B = Bp; ka.C = a.C;
