@@ -1508,6 +1508,40 @@ def test_f64_asm_kernels_bit_exact(la, oracle):
         la.set_option("f64_asm", 1)
 
 
+@pytest.mark.parametrize("dtype", ["int32", "int64"])
+def test_integer_packing_pass_vector_and_scalar_loads_agree_with_the_oracle(la, oracle, dtype):
+    """The packing pass of the integer limb GEMMs (limb_planes.h) reads 16 bytes per lane when the operand's contiguous axis has unit
+    stride and the other stride and the base are 16-byte aligned, elements otherwise; a vector that crosses the operand's edge falls
+    back to predicated elements.  Views that take every path -- padded rows (stride a multiple of 16 bytes, width not), a base moved
+    by one element, an odd row stride -- on the hand-scheduled kernels (tile-major planes: the 128 x 32 x-contiguous kernel for a
+    row-major B) and on the compiler-scheduled ones (plane-major), against the oracle, full-range operands."""
+    import torch
+    tdt = getattr(torch, dtype)
+    info = np.iinfo(dtype)
+    rng = np.random.default_rng(123)
+    M, N, K = 257, 262, 203            # none a multiple of a vector; ragged tiles in every direction
+    for pad_a, off_a, pad_b, off_b in [(205, 0, 264, 0), (208, 0, 264, 0), (208, 1, 264, 1), (208, 0, 263, 0), (208, 4, 272, 4)]:
+        bufA = torch.from_numpy(rng.integers(info.min, info.max, (M * pad_a + 8,), dtype=dtype)).cuda()
+        bufB = torch.from_numpy(rng.integers(info.min, info.max, (K * pad_b + 8,), dtype=dtype)).cuda()
+        A = bufA[off_a:off_a + M * pad_a].view(M, pad_a)[:, :K]
+        B = bufB[off_b:off_b + K * pad_b].view(K, pad_b)[:, :N]
+        want = oracle.matmul(A.cpu().numpy(), B.cpu().numpy())
+        for asm in (2, 0):
+            la.set_option("i32_asm", asm)
+            try:
+                got = torch.zeros((M, N), dtype=tdt, device="cuda")
+                la.matmul(A, B, 1, 0, got)
+                assert (la.get_option("last_i32_asm") != 0) == (asm == 2)
+                assert np.array_equal(got.cpu().numpy(), want), (dtype, pad_a, off_a, pad_b, off_b, asm)
+                # B passed transposed (k-contiguous like A) and A column-major (x-contiguous): the other kernel for each operand
+                Bt = B.t().contiguous().t()
+                Af = A.t().contiguous().t()
+                la.matmul(Af, Bt, 1, 0, got)
+                assert np.array_equal(got.cpu().numpy(), want), (dtype, "swapped layouts", asm)
+            finally:
+                la.set_option("i32_asm", 1)
+
+
 def test_i32_asm_kernel_bit_exact(la, oracle):
     """The hand-scheduled int32 limb kernel (laser_amd/asmgen/i8_kernel.py; option i32_asm): == the compiler-scheduled limb kernel
     (i32_asm = 0) == the oracle, full-range operands (wrap-around mod 2^32), ragged M / N / K, strided and transposed operand views,
