@@ -138,14 +138,15 @@ __global__ void __launch_bounds__(LP_THREADS) limb_planes_tiled_kernel(int8_t *_
 constexpr int LPX_TX = 128, LPX_TK = 32;
 template <typename T>
 __global__ void __launch_bounds__(LP_THREADS) limb_planes_xfast_kernel(int8_t *__restrict__ planes, const T *__restrict__ src, int64_t X, int64_t K,
-                                                                      int64_t sk, int64_t Xpad, int64_t Kpad, int tiles_k, int TR) {
+                                                                      int64_t sk, int64_t Xpad, int64_t Kpad, int tiles_x, int TR) {
   constexpr int NW = (int)sizeof(T) / 4;
   constexpr int EV = 16 / (int)sizeof(T);
   typedef __attribute__((ext_vector_type(4))) int lp_vec16;
   union VecT { lp_vec16 q; T e[EV]; };
   __shared__ __attribute__((aligned(16))) T tile[LPX_TX][LPX_TK + 4];      // row stride 36 elements: phase 2's 8-lane groups are conflict-free
   const int t = threadIdx.x;
-  const int64_t x0 = (int64_t)(blockIdx.x / tiles_k) * LPX_TX, k0 = (int64_t)(blockIdx.x % tiles_k) * LPX_TK;
+  // consecutive workgroups walk along x: neighbours read neighbouring 512-byte segments of the same 32 source rows
+  const int64_t x0 = (int64_t)(blockIdx.x % tiles_x) * LPX_TX, k0 = (int64_t)(blockIdx.x / tiles_x) * LPX_TK;
   constexpr int XV = LPX_TX / EV, KB = LPX_TK / EV;      // blocks of EV x EV elements: XV along x (lanes), KB along k
 #pragma unroll
   for (int i = 0; i < XV * KB / LP_THREADS; i++) {
@@ -208,7 +209,7 @@ inline hipError_t launch_limb_planes(int8_t *dst, const T *src, int64_t X, int64
   if (vec && x_fast && tile_major > 0 && Kpad % 32 == 0) {
     const int64_t tx = (Xpad + LPX_TX - 1) / LPX_TX, tk = Kpad / LPX_TK;
     if (tx * tk > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(limb_planes_xfast_kernel<T>, dim3((unsigned)(tx * tk)), dim3(LP_THREADS), 0, s, dst, src, X, K, sk, Xpad, Kpad, (int)tk, tile_major);
+    hipLaunchKernelGGL(limb_planes_xfast_kernel<T>, dim3((unsigned)(tx * tk)), dim3(LP_THREADS), 0, s, dst, src, X, K, sk, Xpad, Kpad, (int)tx, tile_major);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(limb_planes_tiled_kernel<T>, dim3((unsigned)(tiles_x * tiles_k)), dim3(LP_THREADS), 0, s, dst, src, X, K, sx, sk, Xpad,
