@@ -45,6 +45,23 @@ def test_metadata_calls_work_without_gpu(built):
     assert built.im2col_workspace_size((32, 128, 56, 56), (256, 128, 3, 3), (1, 1), (1, 1)) == 128 * 9 * 56 * 56
 
 
+def test_scheduling_options_round_trip_without_gpu(built):
+    """options that only steer a launch (same results) are plain process state: readable and writable with no device, clamped to their
+    documented ranges (include/laser_hip.h): the integer limb kernels' raster group defaults to 4 tile rows"""
+    assert built.get_option("int_group_m") == 4
+    try:
+        built.set_option("int_group_m", 8)
+        assert built.get_option("int_group_m") == 8
+        built.set_option("int_group_m", 0)
+        assert built.get_option("int_group_m") == 1
+        built.set_option("int_group_m", 1000)
+        assert built.get_option("int_group_m") == 64
+    finally:
+        built.set_option("int_group_m", 4)
+    with pytest.raises(built.LaserHipError):
+        built.set_option("no_such_option", 1)
+
+
 def test_no_cpu_fallback(built):
     import torch
     if torch.cuda.is_available():
